@@ -1,0 +1,331 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/*.npz by running the REFERENCE
+(Cornell-RelaxML/QuIP, mounted read-only at /root/reference) on CPU.
+
+Run only in the authoring container (the GPU box has no /root/reference):
+
+    python tests/golden/make_golden.py
+
+Nothing in tests/, bench.py or __graft_entry__.py imports the reference at run
+time; they read the .npz files this script writes.  Every fixture records the
+reference symbol (file:line) it came from in its `__doc__` entry.
+
+The reference needs one shim: `primefac` (method.py:8) is not installed here, so
+tests/golden/_shims/primefac.py supplies ascending trial division.
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(HERE, "_shims"))
+sys.path.insert(0, REF)
+
+import quant as ref_quant            # noqa: E402
+import method as ref_method          # noqa: E402
+import vector_balance as ref_vb      # noqa: E402
+import bal as ref_bal                # noqa: E402
+import near as ref_near              # noqa: E402
+import optq_counter as ref_counter   # noqa: E402
+
+_spec = importlib.util.spec_from_file_location(
+    "ref_zs_quant", os.path.join(REF, "zeroShot/models/quant.py"))
+ref_zs_quant = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(ref_zs_quant)
+
+torch.set_num_threads(1)   # deterministic summation order for the fp32 fixtures
+
+
+def save(name, doc, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    out["__doc__"] = np.asarray(doc)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def correlated_H(d, seed):
+    """SURVEY.md section 4 / 8(d) parity fixture: strongly correlated Hessian."""
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(d, d, generator=g) / d ** 0.5
+    sv = torch.arange(1, d + 1, dtype=torch.float32) ** -0.75
+    X = (torch.randn(2 * d, d, generator=g) * sv) @ A
+    H = X.T @ X / (2 * d)
+    H = H + 0.01 * torch.diag(H).mean() * torch.eye(d)
+    return H.float().contiguous()
+
+
+# ---------------------------------------------------------------- A. grid functions
+def gen_grids():
+    g = torch.Generator().manual_seed(1)
+    W32 = (0.02 * torch.randn(24, 64, generator=g)).float()
+    W32[3, :] = 0.0                       # all-zero row: xmin=xmax=0 branch (quant.py:87-89)
+    W32[5, :] = W32[5, :].abs()           # strictly non-negative row (xmin clamps to 0)
+    W16 = W32.half()
+    arrs = {"W32": W32, "W16": W16.view(torch.int16)}
+    for bits in (2, 3, 4):
+        for tag, W in (("f32", W32), ("f16", W16)):
+            # qfn a: quant.py:57-136 (find_params_qfna), quant.py:6-8
+            q = ref_quant.Quantizer()
+            q.configure(bits, perchannel=True, sym=False, qfn='a', mse=False)
+            q.find_params(W, weight=True)
+            out = q.quantize(W)
+            arrs[f"a{bits}_{tag}_scale"] = q.scale.float()
+            arrs[f"a{bits}_{tag}_zero"] = q.zero.float()
+            arrs[f"a{bits}_{tag}_out"] = out.float()
+            arrs[f"a{bits}_{tag}_outdtype"] = str(out.dtype)
+            # qfn c: quant.py:17-21
+            q = ref_quant.Quantizer()
+            q.configure(bits, perchannel=True, sym=False, qfn='c', mse=False)
+            q.find_params(W, weight=True)
+            arrs[f"c{bits}_{tag}_out"] = q.quantize(W).float()
+            # qfn b: quant.py:10-15, 148-151
+            q = ref_quant.Quantizer()
+            q.configure(bits, perchannel=True, sym=False, qfn='b', mse=False)
+            q.find_params(W, weight=True)
+            out = q.quantize(W)
+            arrs[f"b{bits}_{tag}_scale"] = q.scale.float().reshape(1)
+            arrs[f"b{bits}_{tag}_out"] = out.float()
+            arrs[f"b{bits}_{tag}_outdtype"] = str(out.dtype)
+    # sym=True / perchannel=False variants of find_params_qfna (quant.py:82-86,121-126)
+    q = ref_quant.Quantizer()
+    q.configure(4, perchannel=False, sym=True, qfn='a', mse=False)
+    q.find_params(W32, weight=True)
+    arrs["a4_sym_tensor_scale"] = q.scale.float()
+    arrs["a4_sym_tensor_zero"] = q.zero.float()
+    arrs["a4_sym_tensor_out"] = q.quantize(W32)
+    save("grids", "quant.py:6-21 quantize_qfn{a,b,c}; quant.py:23-163 Quantizer "
+         "(configure/find_params/quantize), bits 2/3/4, fp32 and fp16 inputs", **arrs)
+
+
+# ---------------------------------------------------------------- B. packers
+def gen_pack():
+    g = torch.Generator().manual_seed(2)
+    arrs = {}
+    # 4-bit: zeroShot/models/quant.py:183-199
+    m, d = 24, 64
+    lin = torch.nn.Linear(d, m)
+    lin.weight.data = 0.05 * torch.randn(m, d, generator=g)
+    lin.bias.data = torch.randn(m, generator=g)
+    q = ref_quant.Quantizer()
+    q.configure(4, perchannel=True, sym=False, qfn='a', mse=False)
+    q.find_params(lin.weight.data, weight=True)
+    lin.weight.data = q.quantize(lin.weight.data)       # on-grid weights
+    ql = ref_zs_quant.Quant4Linear(lin, q.scale, q.zero)
+    codes = torch.round((lin.weight.data + ql.zeros) / ql.scales).to(torch.int)
+    arrs.update(p4_W=lin.weight.data, p4_scale=q.scale, p4_zero=q.zero, p4_bias=lin.bias.data,
+                p4_codes=codes.to(torch.uint8), p4_qweight=ql.qweight, p4_zeros=ql.zeros,
+                p4_scales=ql.scales)
+    # 3-bit: quant.py:173-220
+    m, d = 8, 1024
+    lin = torch.nn.Linear(d, m)
+    lin.weight.data = 0.05 * torch.randn(m, d, generator=g)
+    q = ref_quant.Quantizer()
+    q.configure(3, perchannel=True, sym=False, qfn='a', mse=False)
+    q.find_params(lin.weight.data, weight=True)
+    lin.weight.data = q.quantize(lin.weight.data)
+    ql = ref_quant.Quant3Linear(d, m)
+    ql.pack(lin, q.scale, q.zero)
+    codes = torch.round((lin.weight.data + ql.zeros) / ql.scales).to(torch.int)
+    arrs.update(p3_codes=codes.to(torch.uint8), p3_qweight=ql.qweight)
+    save("pack", "zeroShot/models/quant.py:183-199 Quant4Linear.__init__ (int4 rule); "
+         "quant.py:185-220 Quant3Linear.pack (3-bit rule)", **arrs)
+
+
+# ---------------------------------------------------------------- C. butterfly
+def gen_butterfly():
+    arrs = {}
+    gens = {"blocked": ref_method.gen_rand_ortho_butterfly,
+            "noblock": ref_method.gen_rand_ortho_butterfly_noblock,
+            "nopermute": ref_method.gen_rand_ortho_butterfly_nopermute}
+    for n in (6, 40, 64, 192, 768):
+        arrs[f"n{n}_factors"] = np.asarray(ref_method.butterfly_factors(n))
+        for gname, gen in gens.items():
+            if n == 768 and gname != "blocked":
+                continue
+            np.random.seed(100 + n)
+            torch.manual_seed(100 + n)
+            (B, p_in, p_out) = gen(n)
+            X = torch.randn(n, 5)
+            Y = ref_method.mul_ortho_butterfly((B, p_in, p_out), X)
+            y1 = ref_method.mul_ortho_butterfly((B, p_in, p_out), X[:, 0].clone())
+            key = f"n{n}_{gname}"
+            arrs[key + "_B0"] = B[0]
+            arrs[key + "_B1"] = B[1]
+            arrs[key + "_pin"] = p_in
+            arrs[key + "_pout"] = p_out
+            arrs[key + "_X"] = X
+            arrs[key + "_Y"] = Y
+            arrs[key + "_y1"] = y1
+            if n <= 64:
+                arrs[key + "_dense"] = ref_method.mul_ortho_butterfly((B, p_in, p_out), torch.eye(n))
+    for n in (2, 6, 40, 64, 192, 768, 2048, 3072, 4096, 7168, 8192, 11008, 28672):
+        arrs[f"factors_{n}"] = np.asarray(ref_method.butterfly_factors(n))
+    save("butterfly", "method.py:16-78 butterfly_factors / gen_rand_orthos / "
+         "gen_rand_ortho_butterfly{,_noblock,_nopermute} / mul_ortho_butterfly; seeds "
+         "np.random.seed(100+n); torch.manual_seed(100+n) before each generator call", **arrs)
+
+
+# ---------------------------------------------------------------- D/E. LDLQ
+def gen_ldlq():
+    arrs = {}
+    d, m = 192, 40
+    H = correlated_H(d, 3)
+    arrs["H"] = H
+    for bits in (2, 4):
+        g = torch.Generator().manual_seed(10 + bits)
+        maxq = 2 ** bits - 1
+        W = (torch.rand(m, d, generator=g) * (maxq + 0.6) - 0.3).clamp(0, maxq).float()
+        arrs[f"W{bits}"] = W
+        # vector_balance.py:155-199
+        arrs[f"ldl{bits}"] = ref_vb.round_ldl(W, H, bits, n_greedy_passes=0)
+        # vector_balance.py:218-291
+        arrs[f"ldlblock{bits}"] = ref_vb.round_ldl_block(W, H, bits, n_greedy_passes=0)
+        # vector_balance.py:381-422
+        arrs[f"gptqequiv{bits}"] = ref_vb.round_ldl_gptqequiv(W, H, bits)
+        # unbiased: eta = torch.rand(w.shape) drawn inside (vector_balance.py:174-175)
+        torch.manual_seed(77 + bits)
+        eta = torch.rand(W.shape)
+        torch.manual_seed(77 + bits)
+        arrs[f"ldl{bits}_unbiased"] = ref_vb.round_ldl(W, H, bits, n_greedy_passes=0, unbiased=True)
+        arrs[f"eta{bits}"] = eta
+        near = torch.clamp(torch.floor(W + 0.5), 0, maxq)
+        arrs[f"proxy_ldl{bits}"] = ref_vb.hessian_loss(arrs[f"ldl{bits}"] - W, H).item()
+        arrs[f"proxy_near{bits}"] = ref_vb.hessian_loss(near - W, H).item()
+    # E. quantize_weight_vecbal (vector_balance.py:500-532), fp16 and fp32 inputs
+    g = torch.Generator().manual_seed(5)
+    Wf = (0.02 * torch.randn(m, d, generator=g)).float()
+    arrs["Wf32"] = Wf
+    arrs["Wf16"] = Wf.half().view(torch.int16)
+    for bits in (2, 4):
+        for tag, W in (("f32", Wf), ("f16", Wf.half())):
+            q = ref_quant.Quantizer()
+            q.configure(bits, perchannel=True, sym=False, qfn='a', mse=False)
+            q.find_params(W, weight=True)
+            for lazy in (False, True):
+                out = ref_vb.quantize_weight_vecbal(
+                    w=W, H=H, nbits=bits, npasses=0, scale=q.scale, zero=q.zero, maxq=q.maxq,
+                    unbiased=False, qfn='a', qmethod='ldlq', lazy_batch=lazy)
+                arrs[f"vecbal_a{bits}_{tag}_lazy{int(lazy)}"] = out.float()
+                out = ref_vb.quantize_weight_vecbal(
+                    w=W, H=H, nbits=bits, npasses=0, scale=None, zero=None, maxq=q.maxq,
+                    unbiased=False, qfn='b', qmethod='ldlq', lazy_batch=lazy)
+                arrs[f"vecbal_b{bits}_{tag}_lazy{int(lazy)}"] = out.float()
+    save("ldlq", "vector_balance.py:155-199 round_ldl; :218-291 round_ldl_block; :381-422 "
+         "round_ldl_gptqequiv; :500-532 quantize_weight_vecbal.  H = correlated fixture "
+         "(SURVEY.md 8(d)), d=192 (one full + one ragged 128-block), m=40", **arrs)
+
+
+# ---------------------------------------------------------------- F/G. QuantMethod end to end
+def gen_method():
+    arrs = {}
+    m, d = 24, 96
+
+    def fresh_layer():
+        torch.manual_seed(1234)
+        np.random.seed(1234)
+        lin = torch.nn.Linear(d, m).half()
+        lin.weight.data = (0.02 * torch.randn(m, d)).half()
+        A = torch.randn(d, d) / d ** 0.5
+        sv = torch.arange(1, d + 1, dtype=torch.float32) ** -0.5
+        X = ((torch.randn(6, 64, d) * sv) @ A).half()          # 6 "samples" x 64 tokens
+        return lin, X
+
+    for case, (extra, lazy, bits, qfn) in {
+            "incoh_w2": (0, False, 2, 'b'),
+            "incoh_w4_noblock_lazy": (1, True, 4, 'b'),
+            "plain_w4_qfna": (None, False, 4, 'a')}.items():
+        lin, X = fresh_layer()
+        W0 = lin.weight.data.clone()
+        meth = ref_bal.Balance(lin)
+        meth.configure('ldlq', bits, 0, unbiased=False)
+        meth.quantizer = ref_quant.Quantizer()
+        meth.quantizer.configure(bits, perchannel=True, sym=False, qfn=qfn, mse=False)
+        for j in range(X.shape[0]):
+            meth.add_batch(X[j].unsqueeze(0), None)             # method.py:98-120
+        H64 = meth.H.clone()
+        meth.post_batch()                                       # method.py:122-123
+        Hraw = meth.H.clone()
+        arrs.update(X=X.view(torch.int16), W0=W0.view(torch.int16), H64=H64, Hraw=Hraw)
+        log = []
+        names = ("gen_rand_ortho_butterfly", "gen_rand_ortho_butterfly_noblock")
+        origs = {g: getattr(ref_method, g) for g in names}
+        for gname in names:
+            def rec(n, _orig=origs[gname]):
+                r = _orig(n)
+                log.append(r)
+                return r
+            setattr(ref_method, gname, rec)
+        np.random.seed(4321)
+        torch.manual_seed(4321)
+        if extra is None:
+            meth.preproc(preproc_gptqH=True, percdamp=.01)
+        else:
+            meth.preproc(preproc_gptqH=True, percdamp=.01, preproc_rescale=True,
+                         preproc_proj=True, preproc_proj_extra=extra)      # method.py:125-193
+        for gname in names:
+            setattr(ref_method, gname, origs[gname])
+        arrs[case + "_Wpre"] = lin.weight.data.clone().view(torch.int16)
+        arrs[case + "_Hpre"] = meth.H.clone()
+        if extra is not None:
+            arrs[case + "_scaleWH"] = meth.scaleWH
+            arrs[case + "_projU"] = meth.projU
+            for side, (B, p_in, p_out) in zip("UV", log):
+                arrs[f"{case}_{side}_B0"] = B[0]
+                arrs[f"{case}_{side}_B1"] = B[1]
+                arrs[f"{case}_{side}_pin"] = p_in
+                arrs[f"{case}_{side}_pout"] = p_out
+        meth.fasterquant(lazy_batch=lazy)                        # bal.py:21-48
+        arrs[case + "_Wq"] = lin.weight.data.clone().view(torch.int16)
+        if case == "incoh_w2":
+            arrs[case + "_Hpost"] = meth.H.clone()
+        arrs[case + "_error"] = meth.error
+        arrs[case + "_Hmag"] = meth.Hmag
+    # Nearest (near.py:7-20) on the same layer, qfn a w4 with gptqH only
+    lin, X = fresh_layer()
+    meth = ref_near.Nearest(lin)
+    meth.quantizer = ref_quant.Quantizer()
+    meth.quantizer.configure(4, perchannel=True, sym=False, qfn='a', mse=False)
+    meth.H = arrs["Hraw"].clone()
+    meth.preproc(preproc_gptqH=True, percdamp=.01)
+    meth.fasterquant()
+    arrs["nearest_w4_Wq"] = lin.weight.data.clone().view(torch.int16)
+    arrs["nearest_w4_error"] = meth.error
+    save("method", "method.py:80-233 QuantMethod (add_batch/post_batch/preproc/postproc/"
+         "error_compute) driven through bal.py:13-48 Balance and near.py:5-20 Nearest on an "
+         "fp16 nn.Linear(96->24). Seeds: manual_seed(1234) for data, np/torch seed 4321 "
+         "immediately before preproc (U drawn first, then V: method.py:162-163)", **arrs)
+
+
+# ---------------------------------------------------------------- H. optq_counter
+def gen_counter():
+    import io
+    import contextlib
+    arrs = {}
+    for n in (64, 256):
+        torch.manual_seed(0)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            ref_counter.counter(n, n, 0.01)                     # optq_counter.py:7-31
+        vals = {ln.split(":")[0]: float(ln.split(":")[1]) for ln in buf.getvalue().strip().splitlines()}
+        arrs[f"n{n}_ldl_loss"] = vals["ldl_loss"]
+        arrs[f"n{n}_near_loss"] = vals["near_loss"]
+    save("counter", "optq_counter.py:7-31 counter(n, n, 0.01): deterministic ldl_loss / near_loss "
+         "(round_ldl_gptqequiv vs nearest on the constructed (W,H))", **arrs)
+
+
+if __name__ == "__main__":
+    gen_grids()
+    gen_pack()
+    gen_butterfly()
+    gen_ldlq()
+    gen_method()
+    gen_counter()
