@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on configs[1]: fused 2-bit dequant-GEMM, single 4096x4096 Linear,
+w2 qfn-b, bs=16, synthetic data, on N MI355X GPUs of one node (one rank per GPU, independent replicas:
+the path is data-parallel, there is no collective on it -> "scaling": "weak").
+
+A step = ONE launch of quipamd_dequant_gemm (C ABI) on one batch x[16,4096] (bf16) already resident in HBM.
+Two residency regimes are timed, each as K back-to-back launches captured in a hipGraph (the loop is
+launch-bound: a launch is ~2 us of GPU work):
+  cold : every launch streams a DIFFERENT packed weight copy out of a 96-copy ring (384 MiB > 256 MiB
+         Infinity Cache), i.e. the weights really come from HBM as in a decode step of a large model.
+         This is `value` and the `roofline` (bound "hbm").
+  warm : the same 4 MiB weight every launch (L2 / Infinity-Cache resident) -> `warm` / `roofline_warm`
+         (bound "mfma"), never presented as an HBM fraction.
+`cpu_baseline` = what the reference actually runs at inference (dense fake-quant nn.Linear: torch CPU
+F.linear, fp32) on the host cores, a bounded sample, rank 0 / N=1 only ("port": same library call, not
+the reference's files).
+"""
+import argparse
+import ctypes
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+M = D = 4096
+BS = 16
+BITS = 2
+MAXQ = 3
+FLOPS = 2.0 * BS * M * D                                   # 536 870 912
+BYTES = M * D * BITS // 8 + 2 * BS * D + 2 * BS * M        # 4 456 448 (bf16 in, bf16 out)
+HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_PEAK_TF = 2500.0                                      # dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--ring", type=int, default=96, help="number of distinct weight copies for the cold regime")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="time eager launches instead of a hipGraph")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from quip_amd import ops, _lib
+
+    # ---- synthetic layer: SURVEY.md 8(d) config A --------------------------------------------------------
+    torch.manual_seed(0)
+    W = (0.02 * torch.randn(M, D)).to(dev)
+    scale = ops.qfnb_scale(W)                                               # K5
+    _, codes = ops.quantize(W, "b", scale, None, MAXQ, want_codes=True)     # qfn-b grid, quant.py:10-15
+    qs = ops.pack(codes, BITS, ops.LAYOUT_STREAM)                           # K1
+    x = torch.randn(BS, D).to(torch.bfloat16).to(dev)
+    y = torch.empty(BS, M, dtype=torch.bfloat16, device=dev)
+
+    # parity of the thing being timed (not timed): fp32 dense matmul of the dequantised weights
+    What = ops.codes_to_weight(codes, "b", scale, None, MAXQ, out_dtype=torch.float32)
+    y32 = ops.dequant_gemm(x, qs, BITS, "b", scale, None, None, out_dtype=torch.float32)
+    ref = x.float().double() @ What.double().T
+    rel = float((y32.double() - ref).norm() / ref.norm())
+    assert rel < 1e-3, f"parity check failed: rel err {rel}"
+    del W, What, y32, ref
+
+    ring = [qs] + [qs.clone() for _ in range(max(args.ring, 1) - 1)]
+    lib = _lib.load()
+    fn = lib.quipamd_dequant_gemm
+    vp = ctypes.c_void_p
+
+    def launch(qw, stream):
+        rc = fn(vp(x.data_ptr()), 2, vp(qw.data_ptr()), BITS, 1, 1, vp(scale.data_ptr()), vp(0), vp(0),
+                vp(y.data_ptr()), 2, 0, BS, M, D, stream)
+        if rc:
+            raise RuntimeError(lib.quipamd_last_error())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(weights, steps, warmup):
+        """returns seconds for exactly `steps` launches (max over ranks)."""
+        side = torch.cuda.Stream()
+        nw = len(weights)
+        if args.eager:
+            with torch.cuda.stream(side):
+                st = vp(side.cuda_stream)
+                for i in range(warmup):
+                    launch(weights[i % nw], st)
+                barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+                for i in range(steps):
+                    launch(weights[i % nw], st)
+                e1.record(side)
+                barrier()
+            t = e0.elapsed_time(e1) * 1e-3
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                st = vp(side.cuda_stream)
+                for i in range(min(warmup, 32)):
+                    launch(weights[i % nw], st)
+                side.synchronize()
+                with torch.cuda.graph(graph, stream=side):
+                    cst = vp(torch.cuda.current_stream().cuda_stream)
+                    for i in range(steps):
+                        launch(weights[i % nw], cst)
+            wgraph = None
+            if warmup > 0:                                   # W untimed warm-up steps through the same path
+                wgraph = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(wgraph, stream=side):
+                        cst = vp(torch.cuda.current_stream().cuda_stream)
+                        for i in range(warmup):
+                            launch(weights[i % nw], cst)
+                wgraph.replay()
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            graph.replay()
+            e1.record()
+            barrier()
+            t = e0.elapsed_time(e1) * 1e-3
+        if dist is not None:
+            tt = torch.tensor([t], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        return t
+
+    t_cold = timed(ring, args.steps, args.warmup)
+    t_warm = timed([qs], args.steps, args.warmup)
+
+    us_cold = t_cold / args.steps * 1e6
+    us_warm = t_warm / args.steps * 1e6
+    tf_cold = FLOPS * world / (t_cold / args.steps) / 1e12
+    tf_warm = FLOPS * world / (t_warm / args.steps) / 1e12
+    gbs_cold = BYTES / (t_cold / args.steps) / 1e9         # per GPU
+    out = {
+        "metric": "2-bit dequant-GEMM TFLOP/s (4096x4096, bs=16)",
+        "value": round(tf_cold, 3),
+        "unit": "TFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": us_cold * 1e-3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: single 4096x4096 Linear, w2 qfn-b, fused dequant-GEMM, bs=16, "
+                               "cold weights (96-copy ring, 384 MiB)", "m": M, "d": D, "bs": BS, "bits": BITS,
+                   "launch": "eager" if args.eager else "hipGraph", "parallelism": f"dp{world} (replicas)"},
+        "parity_rel_err": rel,
+        "roofline": {"bound": "hbm", "achieved": round(gbs_cold, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(gbs_cold / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": BYTES, "us_per_launch": round(us_cold, 3),
+                     "pct_mfma_peak": round(100 * tf_cold / world / MFMA_PEAK_TF, 2)},
+        "warm": {"value": round(tf_warm, 3), "unit": "TFLOP/s", "us_per_launch": round(us_warm, 3)},
+        "roofline_warm": {"bound": "mfma", "achieved": round(tf_warm / world, 2), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
+                          "frac": round(tf_warm / world / MFMA_PEAK_TF, 4)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        Wd = ops.codes_to_weight(codes, "b", scale, None, MAXQ, out_dtype=torch.float32).cpu()
+        xc = x.float().cpu()
+        cores = torch.get_num_threads()
+        for _ in range(5):
+            torch.nn.functional.linear(xc, Wd)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0:
+            for _ in range(20):
+                torch.nn.functional.linear(xc, Wd)
+            n += 20
+        dt = (time.perf_counter() - t0) / n
+        out["cpu_baseline"] = {"value": round(FLOPS / dt / 1e12, 4), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+                               "sample": f"{n} calls of torch CPU F.linear fp32 x[16,4096] @ What[4096,4096]^T "
+                                         f"(dense fake-quant weights, what the reference runs at inference), "
+                                         f"{dt * 1e3:.3f} ms/call"}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+/*
+ * quip_amd.h -- C ABI of libquip_amd.so, the MI355X (gfx950) native replacement for the
+ * low-bit linear hot path of Cornell-RelaxML/QuIP.
+ *
+ * The reference has exactly one native boundary: the (absent) `quant_cuda` extension,
+ * called at quant.py:229 (`vecquant3matmul`) and zeroShot/models/quant.py:207
+ * (`vecquant4matmul`).  Everything else on the hot path is torch tensor code in
+ * quant.py / method.py / vector_balance.py; each entry point below names the reference
+ * lines whose arithmetic it takes over.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch tensor data_ptr) unless it
+ *     says "host"; the library never allocates, the caller owns every buffer;
+ *   - matrices are row-major; W is [m, d] = [out_features, in_features] as nn.Linear;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - return value 0 = ok; non-zero = error code below, text via quipamd_last_error();
+ *   - calls are asynchronous on `stream` and thread-safe per stream.
+ */
+#ifndef QUIP_AMD_H
+#define QUIP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QUIPAMD_VERSION 100 /* 0.1.0 */
+
+enum quipamd_status {
+    QUIPAMD_OK = 0,
+    QUIPAMD_ERR_ARG = 1,         /* null pointer / bad enum */
+    QUIPAMD_ERR_SHAPE = 2,       /* dimension not supported by the kernel tiling */
+    QUIPAMD_ERR_LAUNCH = 3,      /* hip launch error */
+    QUIPAMD_ERR_UNSUPPORTED = 4  /* combination not implemented */
+};
+
+enum quipamd_dtype { QUIPAMD_F32 = 0, QUIPAMD_F16 = 1, QUIPAMD_BF16 = 2 };
+
+/* packed-weight layouts.
+ * CANONICAL: the reference's rule, zeroShot/models/quant.py:190-199, generalised from 4 to
+ *            2 bits: int32 [d/per, m], per = 32/bits, code of column i at bits
+ *            [bits*(i%per), +bits) of word [i/per, row].
+ * STREAM:    the permutation of it that the fused GEMM streams: 16-row x (512/bits)-column
+ *            tiles of 64 lanes x 16 B in MFMA A-fragment order (oracle/quip_oracle.py
+ *            pack_stream is the specification).  Requires m % 16 == 0, d % (512/bits) == 0. */
+enum quipamd_layout { QUIPAMD_LAYOUT_CANONICAL = 0, QUIPAMD_LAYOUT_STREAM = 1 };
+
+/* grid functions: quant.py:6-8 (a), quant.py:10-15 (b), quant.py:17-21 (c) */
+enum quipamd_qfn { QUIPAMD_QFN_A = 0, QUIPAMD_QFN_B = 1, QUIPAMD_QFN_C = 2 };
+
+int quipamd_version(void);
+const char *quipamd_last_error(void); /* host string, valid until the next failing call on this thread */
+
+/* ---- K1: integer pack / unpack (bit-exact) ------------------------------------------------
+ * Replaces the Python/numpy packing loops zeroShot/models/quant.py:198-199 and
+ * quant.py:199-217 ("TODO: perform packing on GPU", opt.py:302).
+ * codes: uint8 [m, d], one code per byte, values < 2^bits.  bits in {2, 4}.
+ * packed: int32, m*d*bits/32 words in `layout`. */
+int quipamd_pack(const uint8_t *codes, int bits, int layout, int32_t *packed, int64_t m, int64_t d, void *stream);
+int quipamd_unpack(const int32_t *packed, int bits, int layout, uint8_t *codes, int64_t m, int64_t d, void *stream);
+
+/* ---- K5: grid map / grid functions ---------------------------------------------------------
+ * quipamd_qfnb_scale: scale = 2.4*sqrt(mean(W^2)) + 1e-16 evaluated in W's dtype
+ *   (quant.py:150, vector_balance.py:522).  scale_out: device float[1].
+ *   workspace: device double[1] (zeroed by the call). */
+int quipamd_qfnb_scale(const void *W, int dtype, int64_t numel, float *scale_out, double *workspace, void *stream);
+
+/* quipamd_gridmap: real-valued grid coordinates handed to LDLQ (no rounding):
+ *   qfn a: clamp(w/scale[r] + zero[r], 0, maxq)            vector_balance.py:515  (fp32)
+ *   qfn b: clamp(((w/s + 1)/2)*maxq, 0, maxq) in W's dtype  vector_balance.py:523-524
+ * scale: device float[m] (a) or float[1] (b); zero: float[m] (a) or NULL (b). Wgrid: float [m,d]. */
+int quipamd_gridmap(const void *W, int dtype, int qfn, const float *scale, const float *zero, int maxq,
+                    float *Wgrid, int64_t m, int64_t d, void *stream);
+
+/* quipamd_quantize: round-to-nearest through the grid (Quantizer.quantize, quant.py:144-157).
+ *   codes_out: uint8 [m,d] or NULL; W_out: dequantised weights in `dtype` or NULL. */
+int quipamd_quantize(const void *W, int dtype, int qfn, const float *scale, const float *zero, int maxq,
+                     uint8_t *codes_out, void *W_out, int64_t m, int64_t d, void *stream);
+
+/* quipamd_codes_to_weight: integer codes -> weights (vector_balance.py:519-520, 528-530):
+ *   qfn a: scale[r]*(q - zero[r]);  qfn b: ((q/maxq)*2 - 1)*s;  fp32 math, stored as out_dtype. */
+int quipamd_codes_to_weight(const uint8_t *codes, int qfn, const float *scale, const float *zero, int maxq,
+                            void *W_out, int out_dtype, int64_t m, int64_t d, void *stream);
+
+/* ---- K2: fused dequant-GEMM ------------------------------------------------------------------
+ * Replaces quant_cuda.vecquant3matmul / vecquant4matmul (quant.py:229, zeroShot/models/quant.py:207):
+ *     y[b, r] (+)= bias[r] + sum_k What[r, k] * x[b, k]
+ * with What dequantised on the fly from `qweight` (STREAM layout):
+ *     qfn a: What = scale[r]*(q - zero[r])      (quant.py:186-191: zeros = zero*scale)
+ *     qfn b: What = ((q/maxq)*2 - 1)*scale[0]   (quant.py:13-14)
+ * x: [bs, d] bf16 (QUIPAMD_BF16) row-major; y: [bs, m] in y_dtype (BF16 or F32).
+ * accumulate != 0 (F32 y only): y += result, the reference's in-place contract (quant.py:226-230);
+ * bias: float[m] or NULL.  Unlike the reference (single token only, quant.py:233) any bs >= 1. */
+int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *qweight, int bits, int layout, int qfn,
+                         const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
+                         int accumulate, int64_t bs, int64_t m, int64_t d, void *stream);
+
+/* ---- K3: structured orthogonal (two-factor butterfly / Kronecker) apply ------------------------
+ * Replaces mul_ortho_butterfly (method.py:46-67) and the dense U @ W @ V^T, V @ H @ V^T products of
+ * QuantMethod.preproc/postproc (method.py:175-176, 202-203) without materialising U or V.
+ * Applies the n x n operator  Q = P_out * S1 * S0 * P_in  (or Q^T when transpose != 0) to every ROW of
+ * x: out[r, :] = Q * x[r, :].
+ *   n = p*q;  B0t: float [p, p, q] (blocked: B0t[a][a'][b] = B0[b][a][a']) or [p, p] (kron, blocked = 0);
+ *             B1t: float [q, q, p] (blocked: B1t[b][b'][a] = B1[a][b][b']) or [q, q];
+ *   load_idx / store_idx: int32 [n] permutations in "scatter on load / gather on store" form, with
+ *             perm_in, perm_out the torch.randperm values of method.py:35:
+ *               forward  (transpose = 0): load_idx = argsort(perm_in),  store_idx = perm_out
+ *               transpose (transpose = 1): load_idx = perm_out,          store_idx = argsort(perm_in)
+ *   colscale: float[n] or NULL -- x[r, k] is multiplied by colscale[k] on load (the x (/) s step of the
+ *             packed layer);
+ *   x: [rows, n] with leading dimension ldx, out: [rows, n] with ldo; dtypes F32 / F16 / BF16.
+ * One row (both LDS images, fp32) must fit in 160 KiB: n <= ~20000. */
+int quipamd_ortho_apply_rows(const float *B0t, const float *B1t, int blocked, const int32_t *load_idx,
+                             const int32_t *store_idx, int p, int q, int transpose, const float *colscale,
+                             const void *x, int x_dtype, int64_t ldx, void *out, int out_dtype, int64_t ldo,
+                             int64_t rows, void *stream);
+
+/* ---- K4: LDLQ rounding -------------------------------------------------------------------------
+ * Replaces round_ldl / round_ldl_block (vector_balance.py:155-199, 218-257; n_greedy_passes = 0):
+ *   for i = d-1 .. 0:  q_i = clamp(floor(w_i + sum_{j>i} (w_j - q_j) L[j,i] + eta_i), 0, 2^bits - 1)
+ * evaluated in 128-column lazy blocks (far field as an fp32-MFMA product, in-block error feedback
+ * broadcast lane to lane).  Rows are independent.
+ *   Wgrid: float [m, d] grid coordinates;  LT: float [d, d], LT[c][j] = L[j][c] for j > c where L is
+ *   the unit-lower Cholesky factor of H (vector_balance.py:171-173; see quipamd_unit_lower_t);
+ *   eta: float [m, d] or NULL (= 0.5, vector_balance.py:174-177);
+ *   codes: uint8 [m, d] out;  err_ws: float [m, d] workspace (holds w - q on return).
+ * Requires d % 16 == 0. */
+int quipamd_ldlq_round(const float *Wgrid, const float *LT, const float *eta, int bits, uint8_t *codes,
+                       float *err_ws, int64_t m, int64_t d, void *stream);
+
+/* quipamd_unit_lower_t: from the lower Cholesky factor C (H = C C^T, row-major [d,d]) build
+ *   LT[c][j] = C[j][c] * (1 / C[c][c]) for j > c, 0 elsewhere  (vector_balance.py:172-173). */
+int quipamd_unit_lower_t(const float *C, float *LT, int64_t d, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUIP_AMD_H */

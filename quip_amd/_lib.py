@@ -1,0 +1,64 @@
+"""ctypes loader for libquip_amd.so (the C ABI of include/quip_amd.h).
+
+The product path has no CPU fallback: if the shared library is missing or a symbol is absent, importing the
+ops fails loudly here.  Build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libquip_amd.so")
+
+c_i64, c_int, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+
+# name -> argtypes; must list every function declared in include/quip_amd.h (tests/test_abi.py checks)
+SIGNATURES = {
+    "quipamd_version": [],
+    "quipamd_last_error": [],
+    "quipamd_pack": [c_vp, c_int, c_int, c_vp, c_i64, c_i64, c_vp],
+    "quipamd_unpack": [c_vp, c_int, c_int, c_vp, c_i64, c_i64, c_vp],
+    "quipamd_qfnb_scale": [c_vp, c_int, c_i64, c_vp, c_vp, c_vp],
+    "quipamd_gridmap": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_vp],
+    "quipamd_quantize": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp],
+    "quipamd_codes_to_weight": [c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_i64, c_i64, c_vp],
+    "quipamd_dequant_gemm": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
+                             c_i64, c_i64, c_i64, c_vp],
+    "quipamd_ortho_apply_rows": [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_i64,
+                                 c_vp, c_int, c_i64, c_i64, c_vp],
+    "quipamd_ldlq_round": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp],
+    "quipamd_unit_lower_t": [c_vp, c_vp, c_i64, c_vp],
+}
+
+_lib = None
+
+
+class QuipAmdError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QuipAmdError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+            "(needs hipcc); there is no CPU fallback for the quip_amd hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise QuipAmdError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "quipamd_last_error" else c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.quipamd_last_error()
+        raise QuipAmdError(f"{name} failed (code {rc}): {msg.decode() if msg else '?'}")

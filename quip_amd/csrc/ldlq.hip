@@ -1,0 +1,222 @@
+// ldlq.hip -- K4: LDLQ adaptive rounding with lazy-batch block updates.
+//
+// Takes over round_ldl / round_ldl_block (vector_balance.py:155-199, 218-257; n_greedy_passes = 0):
+//     for i = d-1 .. 0:  q_i = clamp(floor(w_i + sum_{j>i} (w_j - q_j) L[j,i] + eta_i), 0, 2^b - 1)
+// L = unit-lower Cholesky factor of H (vector_balance.py:171-173).  Rows of W are independent, columns are a
+// length-d dependent chain, so:
+//   * one workgroup (4 waves) owns 16 rows for the WHOLE sweep -- no inter-workgroup communication, one launch;
+//   * columns are processed in 128-wide blocks from the top (the reference's `--lazy_batch` blocking,
+//     vector_balance.py:243-257).  For block [i1,i2):
+//       phase A  far[16 x 128] = Err[16 x (d-i2)] * L[i2:, i1:i2]  as fp32 MFMA (v_mfma_f32_16x16x4_f32, exact
+//                fp32 fmaf chains): the true lazy-batch GEMM (the reference re-does it per column, :254).
+//                A operand = this workgroup's error rows (global, written by itself), B operand = rows of
+//                LT = L^T streamed from L2 with 16-byte loads; wave w owns column tiles w and w+4.
+//       phase B  in-block error feedback, right-looking: wave w owns rows 4w..4w+3, lane = column (2 per lane).
+//                Step i: every lane rounds its own column (only lane i's value is final), the error of
+//                column i is broadcast with v_readlane, and acc[c] = fma(err_i, L[i][c], acc[c]) runs on all
+//                lanes with the L row read from an LDS image of the 128x128 diagonal block (zero above the
+//                diagonal, so finished columns are untouched).
+//   * summation order is fixed and documented in oracle/ldlq_oracle.c (oracle_round_ldl_kernel_order), which
+//     this kernel must match BIT-EXACTLY (tests/test_gpu_ldlq.py).
+//
+// Work: 2*m*d^2/2 far-field MACs on the fp32 MFMA pipe (157 TF peak) + m*d*64 in-block FMAs on VALU;
+// traffic: the LT panel is re-read by every workgroup from L2 (d^2/2*4 B each), W/E/codes once from HBM.
+#include "common.h"
+
+namespace {
+
+constexpr int BS = 128;        // column block (vector_balance.py:222 blocksize)
+constexpr int LDS_LD = BS + 1; // padded leading dimension of the diagonal-block image
+
+struct LdlqArgs {
+    const float *W;     // [m,d] grid coordinates
+    const float *LT;    // [d,d] LT[c][j] = L[j][c], j > c
+    const float *eta;   // [m,d] or null
+    uint8_t *codes;     // [m,d]
+    float *E;           // [m,d] workspace: w - q
+    int64_t m, d;
+    float maxq;
+};
+
+__device__ __forceinline__ float round_col(float w, float acc, float eta, float maxq)
+{
+    const float x = (w + acc) + eta;                      // vector_balance.py:180 / :253-256
+    return fminf(fmaxf(floorf(x), 0.0f), maxq);
+}
+
+__global__ __launch_bounds__(256) void ldlq_kernel(LdlqArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ldiag = smem;                       // [BS][LDS_LD]: Ldiag[i][c] = L[i1+i][i1+c] (c < i), else 0
+    float *Ftile = smem + BS * LDS_LD;         // [16][BS] far-field result
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t d = A.d;
+    const int64_t r0 = (int64_t)blockIdx.x * 16;
+    const int fr = lane & 15, kq = lane >> 4;              // MFMA fragment coordinates
+
+    for (int64_t i2 = d; i2 > 0; i2 -= BS) {
+        const int64_t i1 = i2 - BS > 0 ? i2 - BS : 0;
+        const int cnt = (int)(i2 - i1);
+        const int ntile = cnt / 16;
+
+        // ---- stage the diagonal block of L (strictly lower part) into LDS ----------------------------
+        for (int idx = threadIdx.x; idx < BS * BS; idx += 256) {
+            const int c = idx / BS, i = idx - c * BS;      // lanes along i: contiguous in LT row c
+            float v = 0.f;
+            if (c < cnt && i < cnt && c < i) v = A.LT[(i1 + c) * d + i1 + i];
+            Ldiag[i * LDS_LD + c] = v;
+        }
+
+        // ---- phase A: far field on the fp32 matrix pipe ---------------------------------------------------
+        {
+            const int64_t arow = r0 + fr;
+            const bool avalid = arow < A.m;
+            const float *ap = A.E + (avalid ? arow : 0) * d + 4 * kq;
+            const int t0 = wave, t1 = wave + 4;
+            const bool v0 = t0 < ntile, v1 = t1 < ntile;
+            const float *bp0 = A.LT + (i1 + (v0 ? t0 : 0) * 16 + fr) * d + 4 * kq;
+            const float *bp1 = A.LT + (i1 + (v1 ? t1 : 0) * 16 + fr) * d + 4 * kq;
+            f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if (v0) {
+#pragma unroll 2
+                for (int64_t j0 = i2; j0 < d; j0 += 16) {
+                    float4 a = *reinterpret_cast<const float4 *>(ap + j0);
+                    if (!avalid) a = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 b0 = *reinterpret_cast<const float4 *>(bp0 + j0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
+                    if (v1) {
+                        const float4 b1 = *reinterpret_cast<const float4 *>(bp1 + j0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+                    }
+                }
+            }
+            // D layout: col = lane & 15, row = 4*(lane>>4) + reg
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                if (v0) Ftile[(4 * kq + reg) * BS + t0 * 16 + fr] = acc0[reg];
+                if (v1) Ftile[(4 * kq + reg) * BS + t1 * 16 + fr] = acc1[reg];
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: in-block sequential error feedback -------------------------------------------------
+        {
+            float acc[4][2], wv[4][2], et[4][2];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int64_t row = r0 + 4 * wave + rr;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c = lane + 64 * h;
+                    const bool ok = (c < cnt) && (row < A.m);
+                    acc[rr][h] = (c < cnt) ? Ftile[(4 * wave + rr) * BS + c] : 0.f;
+                    wv[rr][h] = ok ? A.W[row * d + i1 + c] : 0.f;
+                    et[rr][h] = (ok && A.eta) ? A.eta[row * d + i1 + c] : 0.5f;
+                }
+            }
+            // columns 64..cnt-1 live in register half 1
+            for (int i = cnt - 1; i >= 64; --i) {
+                const int ln = __builtin_amdgcn_readfirstlane(i - 64);
+                const float l0 = Ldiag[i * LDS_LD + lane], l1 = Ldiag[i * LDS_LD + 64 + lane];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float q = round_col(wv[rr][1], acc[rr][1], et[rr][1], A.maxq);
+                    const float er = wv[rr][1] - q;
+                    const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, er), ln));
+                    acc[rr][0] = fmaf(e, l0, acc[rr][0]);
+                    acc[rr][1] = fmaf(e, l1, acc[rr][1]);
+                }
+            }
+            const int top0 = cnt < 64 ? cnt : 64;
+            for (int i = top0 - 1; i >= 0; --i) {
+                const int ln = __builtin_amdgcn_readfirstlane(i);
+                const float l0 = Ldiag[i * LDS_LD + lane];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float q = round_col(wv[rr][0], acc[rr][0], et[rr][0], A.maxq);
+                    const float er = wv[rr][0] - q;
+                    const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, er), ln));
+                    acc[rr][0] = fmaf(e, l0, acc[rr][0]);
+                }
+            }
+            // every column is final now (later steps only added err * 0): emit codes and errors
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int64_t row = r0 + 4 * wave + rr;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c = lane + 64 * h;
+                    if (c < cnt && row < A.m) {
+                        const float q = round_col(wv[rr][h], acc[rr][h], et[rr][h], A.maxq);
+                        A.codes[row * d + i1 + c] = (uint8_t)q;
+                        A.E[row * d + i1 + c] = wv[rr][h] - q;
+                    }
+                }
+            }
+        }
+        __syncthreads();   // E of this block visible to the whole workgroup before the next far field; LDS reuse
+    }
+}
+
+// LT[c][j] = C[j][c] * (1 / C[c][c]) for j > c, else 0   (vector_balance.py:172-173)
+__global__ __launch_bounds__(256) void unit_lower_t_kernel(const float *__restrict__ C, float *__restrict__ LT, int64_t d)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t j0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+    for (int jj = ty; jj < 32; jj += 8) {
+        const int64_t j = j0 + jj, c = c0 + tx;
+        tile[jj][tx] = (j < d && c < d) ? C[j * d + c] : 0.f;     // read rows of C, lanes along c
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 32; cc += 8) {
+        const int64_t c = c0 + cc, j = j0 + tx;
+        if (c < d && j < d) {
+            float v = 0.f;
+            if (j > c) v = __fmul_rn(tile[tx][cc], __fdiv_rn(1.0f, C[c * d + c]));
+            LT[c * d + j] = v;                                    // write rows of LT, lanes along j
+        }
+    }
+}
+
+}   // namespace
+
+extern "C" int quipamd_ldlq_round(const float *Wgrid, const float *LT, const float *eta, int bits, uint8_t *codes,
+                                  float *err_ws, int64_t m, int64_t d, void *stream)
+{
+    QA_REQUIRE(Wgrid && LT && codes && err_ws, QUIPAMD_ERR_ARG, "ldlq_round: null pointer");
+    QA_REQUIRE(bits >= 1 && bits <= 8, QUIPAMD_ERR_ARG, "ldlq_round: bits out of range");
+    QA_REQUIRE(d % 16 == 0, QUIPAMD_ERR_SHAPE, "ldlq_round: needs d %% 16 == 0 (d=%lld)", (long long)d);
+    if (m == 0 || d == 0) return QUIPAMD_OK;
+    LdlqArgs A;
+    A.W = Wgrid; A.LT = LT; A.eta = eta; A.codes = codes; A.E = err_ws; A.m = m; A.d = d;
+    A.maxq = (float)((1 << bits) - 1);
+    const size_t lds = (size_t)(BS * LDS_LD + 16 * BS) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)ldlq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "ldlq_round: cannot raise dynamic LDS to %zu", lds);
+        attr_set = true;
+    }
+    ldlq_kernel<<<(unsigned)((m + 15) / 16), 256, lds, (hipStream_t)stream>>>(A);
+    QA_LAUNCH_CHECK("quipamd_ldlq_round");
+    return QUIPAMD_OK;
+}
+
+extern "C" int quipamd_unit_lower_t(const float *C, float *LT, int64_t d, void *stream)
+{
+    QA_REQUIRE(C && LT, QUIPAMD_ERR_ARG, "unit_lower_t: null pointer");
+    if (d == 0) return QUIPAMD_OK;
+    dim3 grid(qa_div_up(d, 32), qa_div_up(d, 32));
+    unit_lower_t_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(C, LT, d);
+    QA_LAUNCH_CHECK("quipamd_unit_lower_t");
+    return QUIPAMD_OK;
+}

@@ -1,0 +1,212 @@
+"""`QuantMethod` and the structured random-orthogonal operators -- the surface of the reference's method.py
+(method.py:16-233).  Same class / function names, call order and side effects (opt.py:97-170 drives it as
+add_batch* -> post_batch -> preproc -> fasterquant -> free); what changes is how the work is done:
+
+  * the incoherence projection is applied in its factored (butterfly / Kronecker) form by
+    quip_amd/csrc/ortho.hip -- the dense n x n matrices U, V of method.py:162-176 are never built;
+  * `projU` / `projV` therefore hold the generator tuples (B, p_in, p_out), not dense matrices.
+
+Random state is consumed exactly like the reference (U then V; factors through
+scipy.stats.special_ortho_group / torch.rand, then two torch.randperm), so seeding numpy + torch the same way
+gives the same operators.
+"""
+import math
+
+import scipy.stats
+import torch
+import torch.nn as nn
+import transformers
+
+from . import ops
+
+DEBUG = False
+
+
+def _prime_factors(n):
+    """ascending prime factors (stands in for primefac.primefac, method.py:17; not installed here)."""
+    out, f = [], 2
+    while f * f <= n:
+        while n % f == 0:
+            out.append(f)
+            n //= f
+        f += 1 if f == 2 else 2
+    if n > 1:
+        out.append(n)
+    return out
+
+
+def butterfly_factors(n):
+    """n = p*q with p the product of the even-indexed prime factors, q of the odd-indexed (method.py:16-18)."""
+    pf = _prime_factors(n)
+    return (math.prod(pf[0::2]), math.prod(pf[1::2]))
+
+
+def gen_rand_orthos(m, p):
+    """m Haar-random SO(p) matrices as fp32 (method.py:20-31).  p == 2 draws rotation angles from torch.rand."""
+    if p != 2:
+        return torch.tensor(scipy.stats.special_ortho_group.rvs(p, size=m)).to(torch.float32)
+    theta = torch.rand(m) * (2 * math.pi)
+    c, s = torch.cos(theta), torch.sin(theta)
+    return torch.stack([torch.stack([c, s], -1), torch.stack([-s, c], -1)], -2)
+
+
+def gen_rand_ortho_butterfly(n):
+    """blocked two-factor butterfly + permutations (method.py:34-35)."""
+    return ([gen_rand_orthos(n // p, p) for p in butterfly_factors(n)], torch.randperm(n), torch.randperm(n))
+
+
+def gen_rand_ortho_butterfly_noblock(n):
+    """one factor per stage = Kronecker product (method.py:38-39)."""
+    return ([gen_rand_orthos(1, p) for p in butterfly_factors(n)], torch.randperm(n), torch.randperm(n))
+
+
+def gen_rand_ortho_butterfly_nopermute(n):
+    """blocked, identity permutations (method.py:42-43)."""
+    return ([gen_rand_orthos(n // p, p) for p in butterfly_factors(n)], torch.arange(n), torch.arange(n))
+
+
+def mul_ortho_butterfly(Bpp, x):
+    """Q @ x for x [n] or [n, c] (method.py:46-67), on the GPU through K3."""
+    one_d = x.dim() == 1
+    xc = x.reshape(x.shape[0], -1)
+    dev = xc.device if xc.is_cuda else torch.device('cuda:0')
+    y = ops.OrthoOp(Bpp, dev).apply_cols(xc.to(dev, torch.float32)).to(x.device)
+    return y.reshape(-1) if one_d else y
+
+
+def rand_ortho_butterfly(n):
+    """dense matrix of a fresh operator (method.py:71-72); kept for API parity -- preproc does not use it."""
+    return mul_ortho_butterfly(gen_rand_ortho_butterfly(n), torch.eye(n))
+
+
+def rand_ortho_butterfly_noblock(n):
+    return mul_ortho_butterfly(gen_rand_ortho_butterfly_noblock(n), torch.eye(n))
+
+
+def rand_ortho_butterfly_nopermute(n):
+    return mul_ortho_butterfly(gen_rand_ortho_butterfly_nopermute(n), torch.eye(n))
+
+
+_GENERATORS = {0: gen_rand_ortho_butterfly, 1: gen_rand_ortho_butterfly_noblock, 2: gen_rand_ortho_butterfly_nopermute}
+
+
+class QuantMethod:
+    """Base class for the rounding methods (method.py:80-233)."""
+
+    def __init__(self, layer):
+        self.layer = layer
+        self.dev = self.layer.weight.device
+        W = layer.weight.data
+        if isinstance(self.layer, nn.Conv2d):
+            W = W.flatten(1)
+        if isinstance(self.layer, transformers.Conv1D):
+            W = W.t()
+        self.rows, self.columns = W.shape[0], W.shape[1]
+        self.H = torch.zeros((self.columns, self.columns), dtype=torch.float64, device=self.dev)
+        self.nsamples = 0
+        self.preproc_done = False
+
+    # ---- Hessian accumulation (method.py:98-123): fp64 X X^T on the layer's device ------------------
+    def add_batch(self, inp, out):
+        if DEBUG:
+            self.inp1, self.out1 = inp, out
+        if inp.dim() == 2:
+            inp = inp.unsqueeze(0)
+        n_calls = inp.shape[0]                     # nsamples counts hook calls' batch dim, not tokens
+        if isinstance(self.layer, (nn.Linear, transformers.Conv1D)):
+            if inp.dim() == 3:
+                inp = inp.reshape(-1, inp.shape[-1])
+            inp = inp.t()
+        elif isinstance(self.layer, nn.Conv2d):
+            unfold = nn.Unfold(self.layer.kernel_size, dilation=self.layer.dilation, padding=self.layer.padding,
+                               stride=self.layer.stride)
+            inp = unfold(inp).permute(1, 0, 2).flatten(1)
+        self.nsamples += n_calls
+        inp = inp.to(torch.float64)
+        self.H.addmm_(inp, inp.t())
+
+    def post_batch(self):
+        self.H = (self.H / self.nsamples).to(torch.float32)
+
+    # ---- preprocessing (method.py:125-193) -------------------------------------------------------------
+    def preproc(self, preproc_gptqH=False, percdamp=.01, preproc_rescale=False, preproc_proj=False,
+                preproc_proj_extra=0):
+        """diagonal rescale, random orthogonal projection (extra: 0 blocked butterfly + permute, 1 Kronecker,
+        2 blocked without permutation), then the GPTQ dead-column / damping fix -- in that order.  W is
+        written back in the layer's dtype after every stage exactly like the reference (method.py:155,179,191)."""
+        self.preproc_gptqH, self.preproc_rescale, self.preproc_proj = preproc_gptqH, preproc_rescale, preproc_proj
+        wdtype = self.layer.weight.data.dtype
+        if preproc_rescale:
+            w = self.layer.weight.data.to(torch.float32)
+            H = self.H.to(torch.float32)
+            H = H / H.abs().max()
+            diagH = torch.diag(H).clamp(min=1e-8)
+            diagW2 = (w * w).sum(0).clamp(min=1e-8)             # = diag(w^T w) without the d x d product
+            s = (diagH / diagW2).sqrt().sqrt().to(torch.float32).clamp(min=1e-8)
+            w = w * s[None, :]
+            H = (H / s[None, :]) / s[:, None]
+            self.scaleWH = s.cpu()
+            self.layer.weight.data = w.to(wdtype)
+            self.H = H.to(torch.float32)
+        if preproc_proj:
+            w = self.layer.weight.data.to(torch.float32)
+            H = self.H.to(torch.float32)
+            gen = _GENERATORS[preproc_proj_extra]
+            self.projU = gen(w.shape[0])                         # rows first, then columns (method.py:162-163)
+            self.projV = gen(w.shape[1])
+            U, V = ops.OrthoOp(self.projU, w.device), ops.OrthoOp(self.projV, w.device)
+            self._U, self._V = U, V
+            n = H.shape[0]
+            H = H * (n / (torch.trace(H) + 1e-8)) + 1e-2 * torch.eye(n, device=w.device)
+            w = U.apply_cols(V.apply_rows(w))                    # U w V^T
+            H = V.apply_rows(V.apply_rows(H).t().contiguous())   # V H V^T (H symmetric)
+            self.layer.weight.data = w.to(wdtype)
+            self.H = H.to(torch.float32)
+        if preproc_gptqH:
+            w = self.layer.weight.data.clone()
+            H = self.H.clone()
+            dead = torch.diag(H) == 0
+            H[dead, dead] = 1
+            w[:, dead] = 0
+            idx = torch.arange(self.columns, device=self.dev)
+            H[idx, idx] += percdamp * torch.mean(torch.diag(H))
+            self.layer.weight.data = w.to(wdtype)
+            self.H = H
+        self.preproc_done = True
+
+    def postproc(self):
+        """exact inverse of the projection, then of the rescale (method.py:195-214)."""
+        assert self.preproc_done is True
+        wdtype = self.layer.weight.data.dtype
+        if self.preproc_proj:
+            w = self.layer.weight.data.to(torch.float32)
+            H = self.H.to(torch.float32)
+            U, V = self._U, self._V
+            w = U.apply_cols(V.apply_rows(w, transpose=True), transpose=True)                 # U^T w V
+            H = V.apply_rows(V.apply_rows(H, transpose=True).t().contiguous(), transpose=True)  # V^T H V
+            self.layer.weight.data = w.to(wdtype)
+            self.H = H
+        if self.preproc_rescale:
+            s = self.scaleWH.to(self.layer.weight.device)
+            w = self.layer.weight.data / s[None, :]               # fp16 tensor / fp32 tensor -> fp32
+            H = (self.H * s[:, None]) * s[None, :]
+            self.layer.weight.data = w.to(wdtype)
+            self.H = H
+
+    def free(self):
+        if DEBUG:
+            self.inp1 = self.out1 = None
+        self.H = None
+        self.Losses = None
+        self.Trace = None
+        self.scaleWH = None
+        self.projU = None
+        self.projV = None
+        self._U = self._V = None
+        torch.cuda.empty_cache()
+
+    def error_compute(self, full_W, quant_W):
+        """proxy loss tr(dW H dW^T) and max(H) (method.py:228-233)."""
+        dW = full_W.float() - quant_W.float()
+        self.error = ((dW @ self.H.float()) * dW).sum().item()
+        self.Hmag = self.H.max().item()

@@ -1,0 +1,203 @@
+"""Thin torch-tensor wrappers over the C ABI (include/quip_amd.h).
+
+torch is used for device memory and the current HIP stream only; every op below launches a hand-written
+gfx950 kernel from libquip_amd.so.  Inputs must live on a GPU -- there is no CPU fallback (a CPU tensor
+raises), and a missing library raises at first use (quip_amd/_lib.py).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+LAYOUT_CANONICAL, LAYOUT_STREAM = 0, 1
+QFN = {'a': 0, 'b': 1, 'c': 2}
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("quip_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dtype(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def stream_chunk(bits):
+    """columns per 16-row STREAM tile (include/quip_amd.h)."""
+    return 512 // bits
+
+
+# ------------------------------------------------------------------------------------------------- K1
+def pack(codes, bits, layout=LAYOUT_CANONICAL):
+    """codes uint8 [m,d] -> int32 words; CANONICAL returns [d*bits/32, m] (zeroShot/models/quant.py:190-199)."""
+    _need_gpu(codes)
+    assert codes.dtype == torch.uint8 and codes.dim() == 2
+    codes = codes.contiguous()
+    m, d = codes.shape
+    shape = (d * bits // 32, m) if layout == LAYOUT_CANONICAL else (m * d * bits // 32,)
+    out = torch.empty(shape, dtype=torch.int32, device=codes.device)
+    _lib.call("quipamd_pack", _p(codes), bits, layout, _p(out), m, d, _stream())
+    return out
+
+
+def unpack(packed, bits, layout, m, d):
+    _need_gpu(packed)
+    assert packed.dtype == torch.int32
+    packed = packed.contiguous()
+    assert packed.numel() == m * d * bits // 32
+    codes = torch.empty((m, d), dtype=torch.uint8, device=packed.device)
+    _lib.call("quipamd_unpack", _p(packed), bits, layout, _p(codes), m, d, _stream())
+    return codes
+
+
+# ------------------------------------------------------------------------------------------------- K5
+def qfnb_scale(W):
+    """2.4*rms(W)+1e-16 in W's dtype (quant.py:150); returns a float32 device tensor [1]."""
+    _need_gpu(W)
+    W = W.contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=W.device)
+    ws = torch.empty(1, dtype=torch.float64, device=W.device)
+    _lib.call("quipamd_qfnb_scale", _p(W), _dtype(W), W.numel(), _p(out), _p(ws), _stream())
+    return out
+
+
+def _f32vec(t, dev):
+    return None if t is None else t.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+
+
+def gridmap(W, qfn, scale, zero, maxq):
+    """grid coordinates float32 [m,d] (vector_balance.py:515, 522-524)."""
+    _need_gpu(W)
+    W = W.contiguous()
+    m, d = W.shape
+    scale, zero = _f32vec(scale, W.device), _f32vec(zero, W.device)
+    out = torch.empty((m, d), dtype=torch.float32, device=W.device)
+    _lib.call("quipamd_gridmap", _p(W), _dtype(W), QFN[qfn], _p(scale), _p(zero), int(maxq), _p(out), m, d, _stream())
+    return out
+
+
+def quantize(W, qfn, scale, zero, maxq, want_codes=False):
+    """round-to-nearest through the grid (quant.py:6-21).  Returns dequantised W (same dtype) [, codes]."""
+    _need_gpu(W)
+    W2 = W.contiguous().reshape(W.shape[0], -1)
+    m, d = W2.shape
+    scale, zero = _f32vec(scale, W.device), _f32vec(zero, W.device)
+    out = torch.empty_like(W2)
+    codes = torch.empty((m, d), dtype=torch.uint8, device=W.device) if want_codes else None
+    _lib.call("quipamd_quantize", _p(W2), _dtype(W2), QFN[qfn], _p(scale), _p(zero), int(maxq), _p(codes), _p(out),
+              m, d, _stream())
+    out = out.reshape(W.shape)
+    return (out, codes) if want_codes else out
+
+
+def codes_to_weight(codes, qfn, scale, zero, maxq, out_dtype=torch.float16):
+    _need_gpu(codes)
+    codes = codes.contiguous()
+    m, d = codes.shape
+    scale, zero = _f32vec(scale, codes.device), _f32vec(zero, codes.device)
+    out = torch.empty((m, d), dtype=out_dtype, device=codes.device)
+    _lib.call("quipamd_codes_to_weight", _p(codes), QFN[qfn], _p(scale), _p(zero), int(maxq), _p(out), _DT[out_dtype],
+              m, d, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- K2
+def dequant_gemm(x, qweight, bits, qfn, scale, zero, bias, out=None, out_dtype=torch.bfloat16, accumulate=False,
+                 m=None):
+    """y[bs,m] = x[bs,d] @ dequant(qweight)^T + bias; qweight in STREAM layout."""
+    _need_gpu(x, qweight)
+    assert x.dim() == 2 and x.dtype == torch.bfloat16
+    x = x.contiguous()
+    bs, d = x.shape
+    if m is None:
+        m = qweight.numel() * 32 // bits // d
+    dev = x.device
+    scale, zero, bias = _f32vec(scale, dev), _f32vec(zero, dev), _f32vec(bias, dev)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((bs, m), dtype=out_dtype, device=dev)
+    _lib.call("quipamd_dequant_gemm", _p(x), _dtype(x), _p(qweight), bits, LAYOUT_STREAM, QFN[qfn], _p(scale),
+              _p(zero), _p(bias), _p(out), _dtype(out), int(bool(accumulate)), bs, m, d, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- K3
+class OrthoOp:
+    """Device-resident structured orthogonal operator built from the reference's (B, p_in, p_out) tuple
+    (method.py:34-43).  apply_rows(x) computes Q x_r for every row x_r; transpose=True applies Q^T."""
+
+    def __init__(self, Bpp, device):
+        (B, p_in, p_out) = Bpp
+        B0, B1 = B[0].to(torch.float32), B[1].to(torch.float32)
+        B0 = B0.reshape(-1, B0.shape[-1], B0.shape[-1])
+        B1 = B1.reshape(-1, B1.shape[-1], B1.shape[-1])
+        self.p, self.q = B0.shape[-1], B1.shape[-1]
+        self.n = self.p * self.q
+        self.blocked = int(B0.shape[0] > 1 or B1.shape[0] > 1)
+        if self.blocked:
+            assert B0.shape[0] == self.q and B1.shape[0] == self.p
+            self.F0 = B0.permute(1, 2, 0).contiguous().to(device)      # [p,p,q]: B0t[a][a'][b] = B0[b][a][a']
+            self.F1 = B1.permute(1, 2, 0).contiguous().to(device)      # [q,q,p]
+        else:
+            self.F0 = B0[0].contiguous().to(device)
+            self.F1 = B1[0].contiguous().to(device)
+        p_in = torch.as_tensor(p_in).to(torch.int64).cpu()
+        p_out = torch.as_tensor(p_out).to(torch.int64).cpu()
+        self.inv_pin = torch.argsort(p_in).to(torch.int32).to(device)
+        self.pout = p_out.to(torch.int32).to(device)
+
+    def apply_rows(self, x, transpose=False, colscale=None, out_dtype=None):
+        _need_gpu(x)
+        assert x.dim() == 2 and x.shape[1] == self.n and x.stride(1) == 1
+        rows = x.shape[0]
+        out = torch.empty((rows, self.n), dtype=out_dtype or x.dtype, device=x.device)
+        load_idx, store_idx = (self.pout, self.inv_pin) if transpose else (self.inv_pin, self.pout)
+        cs = _f32vec(colscale, x.device)
+        _lib.call("quipamd_ortho_apply_rows", _p(self.F0), _p(self.F1), self.blocked, _p(load_idx), _p(store_idx),
+                  self.p, self.q, int(bool(transpose)), _p(cs), _p(x), _dtype(x), x.stride(0), _p(out), _dtype(out),
+                  out.stride(0), rows, _stream())
+        return out
+
+    def apply_cols(self, x, transpose=False):
+        """Q @ x for x [n, c] (the reference's mul_ortho_butterfly orientation)."""
+        return self.apply_rows(x.t().contiguous(), transpose=transpose).t().contiguous()
+
+
+# ------------------------------------------------------------------------------------------------- K4
+def unit_lower_t(C):
+    """LT[c][j] = C[j][c]/C[c][c] (j>c) from the lower Cholesky factor C (vector_balance.py:171-173)."""
+    _need_gpu(C)
+    assert C.dtype == torch.float32 and C.dim() == 2 and C.shape[0] == C.shape[1]
+    C = C.contiguous()
+    LT = torch.empty_like(C)
+    _lib.call("quipamd_unit_lower_t", _p(C), _p(LT), C.shape[0], _stream())
+    return LT
+
+
+def ldlq_round(Wgrid, LT, bits, eta=None, return_err=False):
+    """LDLQ codes uint8 [m,d] (vector_balance.py:155-199 / 218-257)."""
+    _need_gpu(Wgrid, LT)
+    assert Wgrid.dtype == torch.float32 and LT.dtype == torch.float32
+    Wgrid, LT = Wgrid.contiguous(), LT.contiguous()
+    m, d = Wgrid.shape
+    assert LT.shape == (d, d)
+    if eta is not None:
+        eta = eta.to(torch.float32).contiguous()
+    codes = torch.empty((m, d), dtype=torch.uint8, device=Wgrid.device)
+    err = torch.empty((m, d), dtype=torch.float32, device=Wgrid.device)
+    _lib.call("quipamd_ldlq_round", _p(Wgrid), _p(LT), _p(eta), bits, _p(codes), _p(err), m, d, _stream())
+    return (codes, err) if return_err else codes

@@ -1,0 +1,190 @@
+"""Grid functions, `Quantizer` and the packed low-bit Linear -- the surface of the reference's quant.py
+(quant.py:6-246) with the arithmetic in HIP kernels (quip_amd/csrc/gridmap.hip, dqgemm.hip, pack.hip).
+
+Same names / signatures / attribute semantics as the reference so `from quant import *` call sites
+(opt.py:10, gptq.py:9) keep working; what is new is `QuantLinear`, the packed 2/4-bit layer the reference
+never had a runnable kernel for (its Quant3Linear/Quant4Linear call an absent `quant_cuda`, quant.py:166-169).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _as_maxq(maxq):
+    return int(maxq.item()) if torch.is_tensor(maxq) else int(maxq)
+
+
+def quantize_qfna(x, scale, zero, maxq):
+    """quant.py:6-8  s*(clamp(round(x/s)+z, 0, maxq) - z), per-row scale/zero."""
+    return ops.quantize(x, 'a', scale, zero, _as_maxq(maxq))
+
+
+def quantize_qfnb(x, scale, maxq):
+    """quant.py:10-15  symmetric scalar-scale grid."""
+    s = scale if torch.is_tensor(scale) else torch.tensor([float(scale)])
+    return ops.quantize(x, 'b', s, None, _as_maxq(maxq))
+
+
+def quantize_qfnc(x, scale, zero, maxq):
+    """quant.py:17-21  clamp-then-round variant (OPTQ == LDLQ equivalence)."""
+    return ops.quantize(x, 'c', scale, zero, _as_maxq(maxq))
+
+
+class Quantizer(nn.Module):
+    """quant.py:23-163.  Buffers maxq / scale / zero; configure / find_params / quantize / enabled / ready."""
+
+    def __init__(self, shape=1):
+        super().__init__()
+        self.register_buffer('maxq', torch.tensor(0))
+        self.register_buffer('scale', torch.zeros(shape))
+        self.register_buffer('zero', torch.zeros(shape))
+
+    def configure(self, bits, perchannel=False, sym=True, qfn='a', mse=False, norm=2.4, grid=100, maxshrink=.8):
+        self.maxq = torch.tensor(2 ** bits - 1)
+        self.perchannel, self.sym, self.qfn, self.mse = perchannel, sym, qfn, mse
+        self.norm, self.grid, self.maxshrink = norm, grid, maxshrink
+
+    def find_params(self, x, weight=False):
+        if self.qfn in ('a', 'c'):
+            self.find_params_qfna(x, weight=weight)
+        elif self.qfn == 'b':
+            self.find_params_qfnb(x)
+
+    def find_params_qfna(self, x, weight=False):
+        """Per-row (perchannel) or per-tensor min/max grid, quant.py:57-136.  O(m) glue on the tensor's
+        device; the fp32 promotion of the reference (quant.py:76-78) is kept."""
+        if self.mse:
+            raise NotImplementedError("mse grid search is unreachable in the reference (quant.py:104 calls an "
+                                      "undefined `quantize`); every caller passes mse=False")
+        dev = x.device
+        self.maxq = self.maxq.to(dev)
+        shape = x.shape
+        if self.perchannel:
+            if weight:
+                flat = x.flatten(1)
+            elif len(shape) == 4:
+                flat = x.permute(1, 0, 2, 3).flatten(1)
+            elif len(shape) == 3:
+                flat = x.reshape(-1, shape[-1]).t()
+            else:
+                flat = x.t()
+        else:
+            flat = x.flatten().unsqueeze(0)
+        zeros = torch.zeros(flat.shape[0], device=dev)
+        lo = torch.minimum(flat.min(1)[0], zeros)          # fp32 from here on
+        hi = torch.maximum(flat.max(1)[0], zeros)
+        if self.sym:
+            hi = torch.maximum(lo.abs(), hi)
+            lo = torch.where(lo < 0, -hi, lo)
+        degenerate = (lo == 0) & (hi == 0)
+        lo = torch.where(degenerate, torch.full_like(lo, -1), lo)
+        hi = torch.where(degenerate, torch.full_like(hi, 1), hi)
+        self.scale = (hi - lo) / self.maxq
+        self.zero = torch.full_like(self.scale, (self.maxq + 1) / 2) if self.sym else torch.round(-lo / self.scale)
+        if not self.perchannel:
+            reps = shape[0] if weight else (shape[1] if len(shape) != 3 else shape[2])
+            self.scale, self.zero = self.scale.repeat(reps), self.zero.repeat(reps)
+        if weight:
+            view = [-1] + [1] * (len(shape) - 1)
+        elif len(shape) == 4:
+            view = (1, -1, 1, 1)
+        elif len(shape) == 3:
+            view = (1, 1, -1)
+        else:
+            view = (1, -1)
+        self.scale, self.zero = self.scale.reshape(view), self.zero.reshape(view)
+
+    def find_params_qfnb(self, x):
+        self.maxq = self.maxq.to(x.device)
+        self.scale = None       # recomputed from the tensor handed to quantize(), quant.py:138-142
+        self.zero = None
+
+    def quantize(self, x):
+        if self.qfn == 'a':
+            assert self.ready()
+            return quantize_qfna(x, self.scale, self.zero, self.maxq)
+        if self.qfn == 'b':
+            assert torch.all(self.maxq != 0)
+            s = ops.qfnb_scale(x)                               # 2.4*rms(x)+1e-16 in x's dtype, quant.py:150
+            self.scale = s.to(x.dtype).reshape(())
+            return ops.quantize(x, 'b', s, None, _as_maxq(self.maxq))
+        if self.qfn == 'c':
+            assert self.ready()
+            return quantize_qfnc(x, self.scale, self.zero, self.maxq)
+        return NotImplementedError()                            # sic: the reference returns it (quant.py:157)
+
+    def enabled(self):
+        return self.maxq > 0
+
+    def ready(self):
+        return self.scale is not None and bool(torch.all(self.scale != 0))
+
+
+class QuantLinear(nn.Module):
+    """Packed 2/4-bit Linear (the runnable successor of Quant3Linear / Quant4Linear, quant.py:173-233,
+    zeroShot/models/quant.py:183-212).  Holds codes in the STREAM layout plus, when the layer was quantised
+    with incoherence processing, the structured operators so that
+
+        y = U^T ( What2 ( V (x / s) ) ) + bias
+
+    where What2 = dequant(codes) lives in the projected basis.  forward() accepts any batch shape."""
+
+    def __init__(self, infeatures, outfeatures, bits=2, qfn='b'):
+        super().__init__()
+        assert bits in (2, 4)
+        self.infeatures, self.outfeatures, self.bits, self.qfn = infeatures, outfeatures, bits, qfn
+        self.register_buffer('qweight', torch.zeros(infeatures * outfeatures * bits // 32, dtype=torch.int32))
+        self.register_buffer('scales', torch.zeros(1 if qfn == 'b' else outfeatures))
+        self.register_buffer('zeros', torch.zeros(outfeatures) if qfn != 'b' else None)
+        self.register_buffer('bias', None)
+        self.register_buffer('inv_scaleWH', None)
+        self.U = None     # ops.OrthoOp over out features
+        self.V = None     # ops.OrthoOp over in features
+
+    @torch.no_grad()
+    def pack(self, codes, scale, zero=None, bias=None, scaleWH=None, U=None, V=None):
+        """codes uint8 [out,in] on the GPU; scale float[1] (qfn b) or [out] (qfn a); U/V reference-style
+        (B, p_in, p_out) tuples or ops.OrthoOp."""
+        dev = codes.device
+        self.qweight = ops.pack(codes, self.bits, ops.LAYOUT_STREAM)
+        self.scales = scale.to(dev, torch.float32).reshape(-1).clone()
+        self.zeros = None if zero is None else zero.to(dev, torch.float32).reshape(-1).clone()
+        self.bias = None if bias is None else bias.detach().to(dev, torch.float32).clone()
+        self.inv_scaleWH = None if scaleWH is None else (1.0 / scaleWH.to(dev, torch.float32))
+        self.U = U if (U is None or isinstance(U, ops.OrthoOp)) else ops.OrthoOp(U, dev)
+        self.V = V if (V is None or isinstance(V, ops.OrthoOp)) else ops.OrthoOp(V, dev)
+        return self
+
+    def forward(self, x):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        if self.V is not None:
+            xt = self.V.apply_rows(x2.contiguous(), colscale=self.inv_scaleWH, out_dtype=torch.bfloat16)
+        else:
+            xt = x2.to(torch.bfloat16)
+            if self.inv_scaleWH is not None:
+                xt = (x2.float() * self.inv_scaleWH).to(torch.bfloat16)
+        if self.U is None:
+            y = ops.dequant_gemm(xt, self.qweight, self.bits, self.qfn, self.scales, self.zeros, self.bias,
+                                 out_dtype=torch.float32, m=self.outfeatures)
+        else:
+            y = ops.dequant_gemm(xt, self.qweight, self.bits, self.qfn, self.scales, self.zeros, None,
+                                 out_dtype=torch.float32, m=self.outfeatures)
+            y = self.U.apply_rows(y, transpose=True)
+            if self.bias is not None:
+                y = y + self.bias
+        return y.to(x.dtype).reshape(*shape[:-1], self.outfeatures)
+
+
+def make_quant(module, layers, name=''):
+    """Swap the named nn.Linear modules for packed QuantLinear layers (the role of make_quant3 / make_quant4,
+    quant.py:236-246).  `layers`: {dotted name: QuantLinear already packed}."""
+    if isinstance(module, QuantLinear):
+        return
+    for child_name, child in list(module.named_children()):
+        full = f"{name}.{child_name}" if name else child_name
+        if full in layers:
+            setattr(module, child_name, layers[full])
+        else:
+            make_quant(child, layers, full)

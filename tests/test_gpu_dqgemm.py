@@ -1,0 +1,120 @@
+"""-m gpu: K2 fused dequant-GEMM through the C ABI vs the oracle (fp64 of the reference formula on the same
+bf16-rounded x).  Tolerance: 1e-3 relative (BASELINE.json north_star) for fp32 output; bf16 output adds its
+own output rounding (2^-9 relative per element), so those cases are gated at 3e-3."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL_F32 = 1e-3
+TOL_BF16 = 3e-3
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from quip_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import quip_oracle
+    return quip_oracle
+
+
+def _case(O, m, d, bs, bits, qfn, seed):
+    rng = np.random.default_rng(seed)
+    maxq = 2 ** bits - 1
+    W = (0.02 * rng.standard_normal((m, d))).astype(np.float32)
+    x = O.bf16_round(rng.standard_normal((bs, d)).astype(np.float32))
+    if qfn == "b":
+        scale = O.qfnb_scale(W)
+        codes = np.clip(np.round(((W / scale + 1) / 2) * maxq), 0, maxq).astype(np.uint8)
+        zero = None
+    else:
+        scale, zero = O.find_params_qfna(W, bits)
+        codes = np.clip(np.round(W / scale) + zero, 0, maxq).astype(np.uint8)
+    return W, x, codes, scale, zero, maxq
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+@pytest.mark.parametrize("qfn", ["a", "b"])
+@pytest.mark.parametrize("m,d,bs", [(16, 256, 1), (64, 512, 4), (128, 1024, 16), (48, 768, 17), (256, 512, 64),
+                                    (2048, 2048, 16)])
+def test_dequant_gemm_matches_oracle(ops, O, bits, qfn, m, d, bs):
+    W, x, codes, scale, zero, maxq = _case(O, m, d, bs, bits, qfn, seed=m + d + bs + bits)
+    rng = np.random.default_rng(1)
+    bias = rng.standard_normal(m).astype(np.float32)
+    y_ref = O.dequant_linear(x, codes, qfn, scale, zero, maxq, bias)
+    qs = ops.pack(torch.from_numpy(codes).to(DEV), bits, ops.LAYOUT_STREAM)
+    xd = torch.from_numpy(x).to(DEV).to(torch.bfloat16)
+    sc = torch.tensor(np.asarray(scale, np.float32).reshape(-1))
+    zr = None if zero is None else torch.from_numpy(zero)
+    y32 = ops.dequant_gemm(xd, qs, bits, qfn, sc, zr, torch.from_numpy(bias), out_dtype=torch.float32)
+    assert _rel(y32.cpu().numpy().astype(np.float64), y_ref) <= TOL_F32
+    y16 = ops.dequant_gemm(xd, qs, bits, qfn, sc, zr, torch.from_numpy(bias), out_dtype=torch.bfloat16)
+    assert _rel(y16.float().cpu().numpy().astype(np.float64), y_ref) <= TOL_BF16
+
+
+def test_one_hot_weights_detect_transposes(ops, O):
+    """asymmetric structure: code 3 only at (r, k = perm[r]) -> y[b, r] picks out x[b, perm[r]]."""
+    m, d, bs, bits = 64, 512, 16, 2
+    rng = np.random.default_rng(5)
+    codes = np.zeros((m, d), dtype=np.uint8)
+    cols = rng.permutation(d)[:m]
+    codes[np.arange(m), cols] = 3
+    x = O.bf16_round(rng.standard_normal((bs, d)).astype(np.float32))
+    # qfn a with scale 1, zero 0: What = q
+    y_ref = 3.0 * x[:, cols]
+    qs = ops.pack(torch.from_numpy(codes).to(DEV), bits, ops.LAYOUT_STREAM)
+    y = ops.dequant_gemm(torch.from_numpy(x).to(DEV).to(torch.bfloat16), qs, bits, "a", torch.ones(m), torch.zeros(m),
+                         None, out_dtype=torch.float32)
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref, rtol=0, atol=2e-4 * np.abs(x).sum(1, keepdims=True).max())
+
+
+def test_accumulate_contract_of_the_reference(ops, O):
+    """quant.py:226-230: y pre-filled with bias, kernel accumulates into it (fp32)."""
+    W, x, codes, scale, zero, maxq = _case(O, 64, 512, 1, 4, "a", seed=11)
+    rng = np.random.default_rng(2)
+    bias = rng.standard_normal(64).astype(np.float32)
+    qs = ops.pack(torch.from_numpy(codes).to(DEV), 4, ops.LAYOUT_STREAM)
+    y = torch.from_numpy(bias.copy()).reshape(1, -1).to(DEV)
+    ops.dequant_gemm(torch.from_numpy(x).to(DEV).to(torch.bfloat16), qs, 4, "a", torch.from_numpy(scale),
+                     torch.from_numpy(zero), None, out=y, accumulate=True)
+    y_ref = O.dequant_linear(x, codes, "a", scale, zero, maxq, bias)
+    assert _rel(y.cpu().numpy().astype(np.float64), y_ref) <= TOL_F32
+    # and it equals the C restatement of vecquant4matmul on the CANONICAL packing of the same codes
+    yc = bias.reshape(1, -1).copy()
+    O.packed_matmul_c(x, O.pack_canonical(codes, 4), yc, scale, zero * scale, 4)
+    assert _rel(y.cpu().numpy(), yc) <= TOL_F32
+
+
+def test_headline_shape_linearity_and_dense_agreement(ops, O):
+    """BASELINE config A: 4096x4096, w2 qfn b, bs=16.  Size-independent properties + dense fp32 matmul."""
+    m = d = 4096
+    bs, bits, maxq = 16, 2, 3
+    g = torch.Generator().manual_seed(0)
+    W = 0.02 * torch.randn(m, d, generator=g)
+    Wd = W.to(DEV)
+    s = ops.qfnb_scale(Wd)
+    _, codes = ops.quantize(Wd, "b", s, None, maxq, want_codes=True)
+    qs = ops.pack(codes, bits, ops.LAYOUT_STREAM)
+    What = ops.codes_to_weight(codes, "b", s, None, maxq, out_dtype=torch.float32)
+    x1 = torch.randn(bs, d, generator=g).to(torch.bfloat16).to(DEV)
+    x2 = torch.randn(bs, d, generator=g).to(torch.bfloat16).to(DEV)
+    f = lambda x: ops.dequant_gemm(x, qs, bits, "b", s, None, None, out_dtype=torch.float32)
+    y1, y2 = f(x1), f(x2)
+    dense = x1.float().double() @ What.double().T
+    assert float((y1.double() - dense).norm() / dense.norm()) <= TOL_F32
+    x3 = (x1.float() * 0.5).to(torch.bfloat16)                     # exact in bf16
+    assert float((f(x3) - 0.5 * y1).norm() / y1.norm()) <= 1e-5    # homogeneity
+    xs = (x1.float() + x2.float()).to(torch.bfloat16)
+    ys_ref = (xs.float().double() @ What.double().T)
+    assert float((f(xs).double() - ys_ref).norm() / ys_ref.norm()) <= TOL_F32
+    # determinism
+    assert torch.equal(f(x1), y1)

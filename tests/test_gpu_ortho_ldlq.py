@@ -1,0 +1,130 @@
+"""-m gpu: K3 (structured orthogonal apply) and K4 (LDLQ) through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from quip_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import quip_oracle
+    return quip_oracle
+
+
+def _bpp(g, k):
+    return ([torch.from_numpy(g[k + "_B0"]), torch.from_numpy(g[k + "_B1"])], torch.from_numpy(g[k + "_pin"]),
+            torch.from_numpy(g[k + "_pout"]))
+
+
+# --------------------------------------------------------------------------------------------- K3
+@pytest.mark.parametrize("n,gname", [(6, "blocked"), (6, "noblock"), (40, "blocked"), (40, "nopermute"),
+                                     (64, "blocked"), (64, "noblock"), (192, "blocked"), (192, "noblock"),
+                                     (768, "blocked")])
+def test_ortho_matches_reference_mul_ortho_butterfly(ops, O, n, gname):
+    g = load_golden("butterfly")
+    k = f"n{n}_{gname}"
+    op = ops.OrthoOp(_bpp(g, k), DEV)
+    X = torch.from_numpy(g[k + "_X"]).to(DEV)                        # [n, 5], reference orientation
+    Y = op.apply_cols(X)
+    ref = g[k + "_Y"]                                                # method.py:46-67 output
+    assert np.abs(Y.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max()      # north-star gate
+    assert np.abs(Y.cpu().numpy() - ref).max() <= 5e-6 * max(1.0, np.abs(ref).max())   # what fp32 really gives
+    back = op.apply_cols(Y, transpose=True)
+    np.testing.assert_allclose(back.cpu().numpy(), g[k + "_X"], atol=2e-5)
+    if k + "_dense" in g:
+        U = g[k + "_dense"]
+        Yt = op.apply_cols(X, transpose=True).cpu().numpy()
+        np.testing.assert_allclose(Yt, U.T @ g[k + "_X"], atol=2e-5)
+
+
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_ortho_large_orthogonality_and_oracle(ops, O, n):
+    from quip_amd import method as M
+    np.random.seed(0)
+    torch.manual_seed(0)
+    Bpp = M.gen_rand_ortho_butterfly(n)
+    op = ops.OrthoOp(Bpp, DEV)
+    X = torch.randn(24, n)
+    Y = op.apply_rows(X.to(DEV))
+    ref = O.mul_ortho_butterfly(([Bpp[0][0].numpy(), Bpp[0][1].numpy()], Bpp[1].numpy(), Bpp[2].numpy()),
+                                X.numpy().T.copy()).T
+    assert np.linalg.norm(Y.cpu().numpy() - ref) / np.linalg.norm(ref) <= 1e-5
+    # norm preservation and exact inverse
+    np.testing.assert_allclose(Y.norm(dim=1).cpu().numpy(), X.norm(dim=1).numpy(), rtol=1e-5)
+    back = op.apply_rows(Y, transpose=True)
+    assert float((back.cpu() - X).norm() / X.norm()) <= 1e-5
+    # colscale on load + bf16 in/out (the activation side of the packed layer)
+    cs = torch.rand(n) + 0.5
+    Yb = op.apply_rows(X.to(torch.bfloat16).to(DEV), colscale=cs.to(DEV))
+    ref_b = O.mul_ortho_butterfly(([Bpp[0][0].numpy(), Bpp[0][1].numpy()], Bpp[1].numpy(), Bpp[2].numpy()),
+                                  (X.to(torch.bfloat16).float() * cs).numpy().T.copy()).T
+    assert Yb.dtype == torch.bfloat16
+    assert np.linalg.norm(Yb.float().cpu().numpy() - ref_b) / np.linalg.norm(ref_b) <= 4e-3   # bf16 output rounding
+
+
+# --------------------------------------------------------------------------------------------- K4
+def test_unit_lower_t(ops, O):
+    g = load_golden("ldlq")
+    H = g["H"]
+    C = np.linalg.cholesky(H.astype(np.float64)).astype(np.float32)
+    LT = ops.unit_lower_t(torch.from_numpy(C).to(DEV)).cpu().numpy()
+    L = (C * (np.float32(1) / np.diag(C))[None, :]).astype(np.float32)
+    np.testing.assert_array_equal(LT, np.tril(L, -1).T)
+
+
+def _corr_H(d, seed):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(d, d, generator=g) / d ** 0.5
+    sv = torch.arange(1, d + 1, dtype=torch.float32) ** -0.75
+    X = (torch.randn(2 * d, d, generator=g) * sv) @ A
+    H = X.T @ X / (2 * d)
+    return (H + 0.01 * torch.diag(H).mean() * torch.eye(d)).float()
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+def test_ldlq_golden_bit_exact_vs_kernel_order_oracle_and_statistical_vs_reference(ops, O, bits):
+    g = load_golden("ldlq")
+    W, H = g[f"W{bits}"], g["H"]
+    C = np.linalg.cholesky(H.astype(np.float64)).astype(np.float32)
+    LT = ops.unit_lower_t(torch.from_numpy(C).to(DEV))
+    codes, err = ops.ldlq_round(torch.from_numpy(W).to(DEV), LT, bits, return_err=True)
+    got = codes.cpu().numpy()
+    want = O.round_ldl_kernel_order(W, LT.cpu().numpy(), bits)
+    np.testing.assert_array_equal(got, want)                         # documented evaluation order, bit-exact
+    np.testing.assert_array_equal(err.cpu().numpy(), W - got.astype(np.float32))
+    ref = g[f"ldl{bits}"]                                            # vector_balance.py:155-199 output
+    assert np.mean(got.astype(np.float32) != ref) <= 1e-3
+    p_got, p_ref = O.proxy_loss(got - W, H), O.proxy_loss(ref - W, H)
+    assert abs(p_got - p_ref) <= 1e-3 * p_ref
+    assert p_got < 0.5 * float(g[f"proxy_near{bits}"])
+    # unbiased rounding with the reference's eta draw
+    cu = ops.ldlq_round(torch.from_numpy(W).to(DEV), LT, bits, eta=torch.from_numpy(g[f"eta{bits}"]).to(DEV))
+    assert np.mean(cu.cpu().numpy().astype(np.float32) != g[f"ldl{bits}_unbiased"]) <= 1e-3
+
+
+@pytest.mark.parametrize("m,d,bits", [(100, 512, 2), (64, 1024, 4), (37, 336, 2), (512, 2048, 2)])
+def test_ldlq_bit_exact_at_larger_sizes(ops, O, m, d, bits):
+    H = _corr_H(d, seed=d)
+    gen = torch.Generator().manual_seed(m)
+    maxq = 2 ** bits - 1
+    W = (torch.rand(m, d, generator=gen) * (maxq + 0.6) - 0.3).clamp(0, maxq)
+    C = torch.linalg.cholesky(H.double()).float()
+    LT = ops.unit_lower_t(C.to(DEV))
+    got = ops.ldlq_round(W.to(DEV), LT, bits).cpu().numpy()
+    want = O.round_ldl_kernel_order(W.numpy(), LT.cpu().numpy(), bits)
+    np.testing.assert_array_equal(got, want)
+    if m * d <= 1 << 17:
+        ref = O.round_ldl(W.numpy(), H.numpy(), bits)                # reference-order restatement
+        assert np.mean(got.astype(np.float32) != ref) <= 1e-3
+    near = np.clip(np.floor(W.numpy() + 0.5), 0, maxq)
+    assert O.proxy_loss(got - W.numpy(), H.numpy()) < 0.5 * O.proxy_loss(near - W.numpy(), H.numpy())

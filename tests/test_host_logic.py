@@ -1,0 +1,61 @@
+"""CPU: host-side logic of the surface modules that needs no kernel (factorisation, RNG parity of the operator
+generators, module structure)."""
+import numpy as np
+import torch
+
+from conftest import load_golden
+
+
+def test_butterfly_factors_match_reference():
+    from quip_amd.method import butterfly_factors
+    g = load_golden("butterfly")
+    for n in (2, 6, 40, 64, 192, 768, 2048, 3072, 4096, 7168, 8192, 11008, 28672):
+        assert butterfly_factors(n) == tuple(g[f"factors_{n}"])
+
+
+def test_generators_consume_rng_like_the_reference():
+    """seeding numpy + torch as the golden script did must reproduce the reference's operators bit for bit."""
+    from quip_amd import method as M
+    g = load_golden("butterfly")
+    gens = {"blocked": M.gen_rand_ortho_butterfly, "noblock": M.gen_rand_ortho_butterfly_noblock,
+            "nopermute": M.gen_rand_ortho_butterfly_nopermute}
+    for n in (6, 40, 64, 192):
+        for name, gen in gens.items():
+            np.random.seed(100 + n)
+            torch.manual_seed(100 + n)
+            B, p_in, p_out = gen(n)
+            k = f"n{n}_{name}"
+            assert B[0].dtype == torch.float32
+            np.testing.assert_array_equal(B[0].numpy(), g[k + "_B0"])
+            np.testing.assert_array_equal(B[1].numpy(), g[k + "_B1"])
+            np.testing.assert_array_equal(p_in.numpy(), g[k + "_pin"])
+            np.testing.assert_array_equal(p_out.numpy(), g[k + "_pout"])
+
+
+def test_surface_names_exist():
+    import quip_amd.quant as q, quip_amd.method as m, quip_amd.vector_balance as vb
+    import quip_amd.bal as bal, quip_amd.gptq as gptq, quip_amd.near as near, quip_amd.modelutils as mu
+    for name in ("quantize_qfna", "quantize_qfnb", "quantize_qfnc", "Quantizer", "QuantLinear", "make_quant"):
+        assert hasattr(q, name)
+    for name in ("butterfly_factors", "gen_rand_orthos", "gen_rand_ortho_butterfly", "gen_rand_ortho_butterfly_noblock",
+                 "gen_rand_ortho_butterfly_nopermute", "mul_ortho_butterfly", "rand_ortho_butterfly", "QuantMethod"):
+        assert hasattr(m, name)
+    for name in ("round_ldl", "round_ldl_block", "quantize_weight_vecbal", "check_nbits"):
+        assert hasattr(vb, name)
+    assert issubclass(bal.Balance, m.QuantMethod) and issubclass(gptq.GPTQ, m.QuantMethod)
+    assert issubclass(near.Nearest, m.QuantMethod)
+    assert str(mu.DEV) == "cuda:0"
+    layer = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Sequential(torch.nn.ReLU(), torch.nn.Linear(4, 2)))
+    assert list(mu.find_layers(layer)) == ["0", "1.1"]
+
+
+def test_quantizer_configure_and_cpu_find_params():
+    """find_params_qfna is O(m) torch glue and runs wherever the tensor lives; the grid kernels do not."""
+    from quip_amd.quant import Quantizer
+    g = load_golden("grids")
+    q = Quantizer()
+    q.configure(4, perchannel=True, sym=False, qfn='a', mse=False)
+    assert int(q.maxq) == 15
+    q.find_params(torch.from_numpy(g["W32"]), weight=True)
+    np.testing.assert_array_equal(q.scale.numpy(), g["a4_f32_scale"])
+    np.testing.assert_array_equal(q.zero.numpy(), g["a4_f32_zero"])
