@@ -6,6 +6,11 @@ ops fails loudly here.  Build it with `python __graft_entry__.py` (hipcc --offlo
 import ctypes
 import os
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE
+# libquip_amd.so is dlopen'ed so that kernel registration and launches bind to the runtime that owns torch's
+# streams and allocations, not to a second copy from /opt/rocm.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libquip_amd.so")
 

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void unpack_stream_kernel(const uint4 *__restr
 
 int check_pack_args(const void *a, const void *b, int bits, int layout, int64_t m, int64_t d)
 {
-    QA_REQUIRE(a && b, QUIPAMD_ERR_ARG, "pack/unpack: null pointer");
+    QA_REQUIRE((a && b) || m == 0 || d == 0, QUIPAMD_ERR_ARG, "pack/unpack: null pointer");
     QA_REQUIRE(bits == 2 || bits == 4, QUIPAMD_ERR_UNSUPPORTED, "pack/unpack: bits must be 2 or 4 (got %d)", bits);
     QA_REQUIRE(m >= 0 && d >= 0, QUIPAMD_ERR_SHAPE, "pack/unpack: negative shape");
     if (layout == QUIPAMD_LAYOUT_CANONICAL) {

@@ -56,7 +56,7 @@ def test_pack_stream_is_the_declared_permutation(ops, O, bits, m, d):
     s2 = ops.pack(ops.unpack(c, bits, ops.LAYOUT_CANONICAL, m, d), bits, ops.LAYOUT_STREAM)
     assert torch.equal(s, s2)
     # same multiset of bits: population count is invariant under the permutation
-    pc = lambda t: int(torch.tensor(np.unpackbits(t.cpu().numpy().view(np.uint8)).sum()))
+    pc = lambda t: int(np.unpackbits(t.cpu().numpy().view(np.uint8)).sum())
     if m * d <= 1 << 20:
         assert pc(s) == pc(c)
 
