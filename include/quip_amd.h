@@ -97,6 +97,13 @@ int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *qweight, int
                          const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
                          int accumulate, int64_t bs, int64_t m, int64_t d, void *stream);
 
+/* Tuning hook for benchmarks: force the K2 workgroup shape (row tiles per workgroup, batch tiles per wave,
+ * waves per workgroup, k-slices over workgroups); 0 = leave that parameter to the built-in shape heuristic.
+ * bt != 0 selects the multi-batch-tile kernel also for bs <= 16; split > 1 only takes effect under the
+ * accumulate contract (fp32 atomics).  Process-wide, not thread-safe, never needed for correctness.  An
+ * unsupported combination makes quipamd_dequant_gemm fail with QUIPAMD_ERR_UNSUPPORTED. */
+int quipamd_tune_dequant_gemm(int rt, int bt, int nw, int split);
+
 /* ---- K3: structured orthogonal (two-factor butterfly / Kronecker) apply ------------------------
  * Replaces mul_ortho_butterfly (method.py:46-67) and the dense U @ W @ V^T, V @ H @ V^T products of
  * QuantMethod.preproc/postproc (method.py:175-176, 202-203) without materialising U or V.

@@ -7,8 +7,18 @@
 //   * The packed weights are the MFMA **A** operand (16 weight rows x 32 k), the activations the **B**
 //     operand (32 k x 16 batch columns): D[row][batch].  The STREAM layout stores each 16-row x KC-column
 //     tile as 64 lanes x 16 B in exactly the A-fragment order, so one coalesced global_load_dwordx4 per lane
-//     (1 KiB per wave) feeds NT = KC/32 MFMAs with no LDS round trip (cdna_hip_programming.md: "M <= 16
-//     decode weights: load straight to VGPRs").
+//     (1 KiB per wave) feeds NT = KC/32 MFMAs with no LDS round trip for the weight operand
+//     (cdna_hip_programming.md: "M <= 16 decode weights: load straight to VGPRs").
+//   * The kernel is a pure latency/ingest problem at the headline shape (4 MiB of weights = 16 KiB per CU,
+//     0.56 us at 8 TB/s): every byte a CU needs must be in flight at once.  A workgroup is NW waves (16 at
+//     the headline shape); wave w owns k-chunks w, w+NW, ... of the workgroup's RT row tiles, so at
+//     K = 4096 every wave issues its single weight load and its x stage in the first few cycles.
+//   * x goes through LDS in full lines (cdna_hip_programming.md: fragment-shaped x loads cost +18..45 %):
+//     each wave DMA-stages the 16 x KC slab of x its chunk needs with global_load_lds_dwordx4 (512 B
+//     contiguous per batch row) into a wave-PRIVATE LDS region -- no barrier, only the wave's own vmcnt --
+//     and reads B fragments back with ds_read_b128.  The LDS image is XOR-swizzled through the DMA's
+//     SOURCE address (16-B column c of batch row b lands at column c ^ b), which makes the fragment reads
+//     (lanes = 16 rows x 4 k-groups at one column) bank-conflict free.
 //   * In-register dequant, 2 VALU per bf16 pair: the code is shifted onto the TOP mantissa bits of a bf16
 //     with a fixed exponent:  2 bit -> 0x4080 | c<<5 = 4 + c,  4 bit -> 0x4180 | c<<3 = 16 + c   (exact),
 //     pair = ((w >> s) & MASK) | BASE  (v_lshrrev/v_lshlrev + v_and_or_b32).
@@ -17,46 +27,97 @@
 //         qfn b:  y = (2 s / maxq) * (acc - (OFF + maxq/2) * xsum)
 //         qfn a:  y = scale[r]     * (acc - (OFF + zero[r]) * xsum)
 //     xsum is accumulated beside the MFMAs with v_dot2_f32_bf16 against (1,1).
-//   * D layout (col = lane&15 = batch, row = 4*(lane>>4)+reg = weight row): a lane owns 4 consecutive
-//     output features of one batch row -> one 8-byte (bf16) / 16-byte (fp32) store.
+//   * The NW k-partials of a row tile meet in LDS (each wave parks its accumulators in its own, now dead,
+//     x region), one barrier, then wave rt reduces and stores.  D layout (col = lane&15 = batch,
+//     row = 4*(lane>>4)+reg = weight row): a lane owns 4 consecutive output features of one batch row
+//     -> one 8-byte (bf16) / 16-byte (fp32) store.
+//   * bs > 16: BT batch tiles per wave reuse every dequantised A fragment (weights are streamed once per
+//     BT*16 batch rows).
 //
-// Kernel `dqgemm_stream`: one workgroup = RT row tiles x KW k-slices (RT*KW waves); every wave streams its
-// own weight tiles and reads its x fragments straight from global/L2; K-slices are reduced through LDS.
 // Algorithmic bytes per call: m*d*bits/8 + 2*bs*d + (2|4)*bs*m.  FLOPs: 2*bs*m*d.
 #include "common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
+
+// (shifted & mask) | base in ONE VALU op: v_bfi_b32 D = (S0 & S1) | (~S0 & S2).  hipcc folds `base & ~mask` when
+// base is a literal and then emits v_and + v_or, so the base constant is passed through opaque() (an EMPTY asm:
+// it hides the value from the optimiser but contains no instruction).  The instruction itself must come from the
+// compiler: a hand-written `asm("v_bfi_b32 ...")` result fed to an MFMA misses the VALU-write -> MFMA-operand wait
+// states (cdna_hip_programming.md 5.7 item 2) and silently corrupts tiles -- caught by
+// tests/test_gpu_dqgemm.py::test_forced_workgroup_shapes_agree.
+__device__ __forceinline__ uint32_t opaque(uint32_t v)
+{
+    asm("" : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t shifted, uint32_t base)
+{
+    return (shifted & mask) | (base & ~mask);
+}
 
 template <int BITS> struct Deq;
 template <> struct Deq<2> {
     static constexpr int KC = 256, NT = 8;
+    // rolled form: column block cb (MFMA steps 2cb, 2cb+1) uses dword cb -> after each block rotate by 1
+    static __device__ __forceinline__ uint4 frag_lead(const uint4 &w, int tt)
+    {
+        const uint32_t base = opaque(0x40804080u);
+        uint32_t o[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int sh = 2 * (4 * tt + v) - 5;
+            const uint32_t shifted = sh >= 0 ? (w.x >> sh) : (w.x << (-sh));
+            o[v] = bfi(0x00600060u, shifted, base);
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    static __device__ __forceinline__ void rotate(uint4 &w) { w = make_uint4(w.y, w.z, w.w, w.x); }
     static constexpr float OFF = 4.0f;
     // A fragment (4 dwords = 8 bf16) of MFMA step t from the lane's 4 packed dwords
     static __device__ __forceinline__ uint4 frag(const uint4 &w, int t)
     {
         const uint32_t src = (t >> 1) == 0 ? w.x : (t >> 1) == 1 ? w.y : (t >> 1) == 2 ? w.z : w.w;
+        const uint32_t base = opaque(0x40804080u);
         uint32_t o[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int sh = 2 * (4 * (t & 1) + v) - 5;
             const uint32_t shifted = sh >= 0 ? (src >> sh) : (src << (-sh));
-            o[v] = (shifted & 0x00600060u) | 0x40804080u;
+            o[v] = bfi(0x00600060u, shifted, base);
         }
         return make_uint4(o[0], o[1], o[2], o[3]);
     }
 };
 template <> struct Deq<4> {
     static constexpr int KC = 128, NT = 4;
-    static constexpr float OFF = 16.0f;
-    static __device__ __forceinline__ uint4 frag(const uint4 &w, int t)
+    // rolled form: column block cb uses dwords 2cb, 2cb+1 -> after each block rotate the lane's 4 dwords by 2
+    static __device__ __forceinline__ uint4 frag_lead(const uint4 &w, int tt)
     {
-        const uint32_t src = t == 0 ? w.x : t == 1 ? w.y : t == 2 ? w.z : w.w;
+        const uint32_t src = tt == 0 ? w.x : w.y;
+        const uint32_t base = opaque(0x41804180u);
         uint32_t o[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int sh = 4 * v - 3;
             const uint32_t shifted = sh >= 0 ? (src >> sh) : (src << (-sh));
-            o[v] = (shifted & 0x00780078u) | 0x41804180u;
+            o[v] = bfi(0x00780078u, shifted, base);
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    static __device__ __forceinline__ void rotate(uint4 &w) { w = make_uint4(w.z, w.w, w.x, w.y); }
+    static constexpr float OFF = 16.0f;
+    static __device__ __forceinline__ uint4 frag(const uint4 &w, int t)
+    {
+        const uint32_t src = t == 0 ? w.x : t == 1 ? w.y : t == 2 ? w.z : w.w;
+        const uint32_t base = opaque(0x41804180u);
+        uint32_t o[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int sh = 4 * v - 3;
+            const uint32_t shifted = sh >= 0 ? (src >> sh) : (src << (-sh));
+            o[v] = bfi(0x00780078u, shifted, base);
         }
         return make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -88,28 +149,46 @@ struct EpiArgs {
     const float *bias;    // [m] or null
     void *y;
     int qfn, maxq, y_f32, accumulate;
+    float two_over_maxq;
     int64_t bs, m;
 };
 
-__device__ __forceinline__ void epilogue_store(const EpiArgs &e, const f32x4_t &acc, float xs, float off,
+// raw epilogue parameters of 4 consecutive output rows, FETCHED at kernel start (their memory latency hides
+// under the weight stream instead of extending the critical path after the reduction) and only turned into
+// coefficients in epilogue_store
+struct EpiRow {
+    float4 sc, zr, bi;
+};
+
+__device__ __forceinline__ EpiRow load_epi(const EpiArgs &e, int64_t r0)
+{
+    EpiRow c;
+    if (e.qfn == QUIPAMD_QFN_B) {
+        const float s = e.scale[0];
+        c.sc = make_float4(s, s, s, s);
+        c.zr = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        c.sc = *reinterpret_cast<const float4 *>(e.scale + r0);
+        c.zr = *reinterpret_cast<const float4 *>(e.zero + r0);
+    }
+    c.bi = e.bias ? *reinterpret_cast<const float4 *>(e.bias + r0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return c;
+}
+
+__device__ __forceinline__ void epilogue_store(const EpiArgs &e, const EpiRow &c, float off, const f32x4_t &acc, float xs,
                                                int64_t b, int64_t r0)
 {
     if (b >= e.bs) return;
+    const float sc[4] = {c.sc.x, c.sc.y, c.sc.z, c.sc.w}, zr[4] = {c.zr.x, c.zr.y, c.zr.z, c.zr.w};
+    const float bi[4] = {c.bi.x, c.bi.y, c.bi.z, c.bi.w};
     float out[4];
+    if (e.qfn == QUIPAMD_QFN_B) {
+        const float alpha = sc[0] * e.two_over_maxq, t = (off + 0.5f * (float)e.maxq) * xs;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t r = r0 + i;
-        float alpha, c0;
-        if (e.qfn == QUIPAMD_QFN_B) {
-            alpha = 2.0f * e.scale[0] / (float)e.maxq;
-            c0 = off + 0.5f * (float)e.maxq;
-        } else {
-            alpha = e.scale[r];
-            c0 = off + e.zero[r];
-        }
-        float v = alpha * (acc[i] - c0 * xs);
-        if (e.bias) v += e.bias[r];
-        out[i] = v;
+        for (int i = 0; i < 4; ++i) out[i] = alpha * (acc[i] - t) + bi[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = sc[i] * (acc[i] - (off + zr[i]) * xs) + bi[i];
     }
     if (e.y_f32) {
         float4 *dst = reinterpret_cast<float4 *>((float *)e.y + b * e.m + r0);
@@ -126,85 +205,461 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs &e, const f32x4_t &
     }
 }
 
-// RT row tiles (16 rows each) x KW k-slices per workgroup; grid = (m/16/RT, ceil(bs/16)).
-template <int BITS, int RT, int KW>
-__global__ __launch_bounds__(64 * RT * KW) void dqgemm_stream(const uint16_t *__restrict__ x,
-                                                              const uint4 *__restrict__ qw, EpiArgs e, int64_t d)
+#ifdef QA_PROBE
+// per-wave phase timestamps (s_memtime), kept in registers and flushed at the end: probe[(wg*NW + wave)*8 + phase]
+__device__ unsigned long long *g_probe = nullptr;
+#define QA_STAMP_DECL unsigned long long qa_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define QA_STAMP(ph) qa_t[ph] = __builtin_readcyclecounter()
+#define QA_STAMP_FLUSH(NWAVES, WAVE)                                                                     \
+    do {                                                                                                 \
+        if (g_probe && (threadIdx.x & 63) == 0)                                                          \
+            for (int i_ = 0; i_ < 8; ++i_)                                                               \
+                g_probe[((blockIdx.x + gridDim.x * blockIdx.y) * (NWAVES) + (WAVE)) * 8 + i_] = qa_t[i_]; \
+    } while (0)
+__device__ int g_ablate = 0;   // probe-only: bit0 no x DMA, bit1 no compute, bit2 no W load, bit3 no reduce+store, bit4 no store
+#define QA_ABL(bit) (g_ablate & (bit))
+#define QA_KEEP(v) asm volatile("" ::"v"(v))
+#else
+#define QA_ABL(bit) 0
+#define QA_KEEP(v) do { } while (0)
+#define QA_STAMP_DECL do { } while (0)
+#define QA_STAMP(ph) do { } while (0)
+#define QA_STAMP_FLUSH(NWAVES, WAVE) do { } while (0)
+#endif
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// counted vmcnt wait; n is a compile-time constant after unrolling, so the switch folds to one s_waitcnt
+__device__ __forceinline__ void wait_vmcnt(int n)
+{
+#define QA_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        QA_VMCNT_CASE(0) QA_VMCNT_CASE(2) QA_VMCNT_CASE(4) QA_VMCNT_CASE(6) QA_VMCNT_CASE(8) QA_VMCNT_CASE(10)
+        QA_VMCNT_CASE(12) QA_VMCNT_CASE(14) QA_VMCNT_CASE(16) QA_VMCNT_CASE(18) QA_VMCNT_CASE(20) QA_VMCNT_CASE(22)
+        QA_VMCNT_CASE(24)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef QA_VMCNT_CASE
+}
+
+// Workgroup = NW waves over RT row tiles (16 rows each) x BT batch tiles (16 batch rows each);
+// grid = (m/16/RT, ceil(bs/16/BT)).  LDS: NW wave-private regions of REGION bytes.
+//
+// x slab (16 batch rows x KC columns of one chunk) in LDS, in 16-byte units: the slab is NCB column blocks of
+// 128 B; DMA instruction i = 2*cb + rh moves column block cb of rows 8*rh .. 8*rh+7 -- one full 128-B line
+// per row -- and lane L of it lands at unit 64*i + L.  Lane L = 8*(row&7) + slot fetches logical 16-B column
+// w = slot ^ (row&7) of the block, so logical (row b, column c16) lives at
+//     unit(b, c16) = 64*(2*(c16>>3) + (b>>3)) + 8*(b&7) + ((c16&7) ^ (b&7)),
+// which spreads every ds_read_b128 lane group (8 rows x 2 k-groups) over all 16 slots of a 256-B bank row.
+// MFMA step t needs column block t>>1 only, so compute starts when the first two DMAs have landed.
+template <int BITS, int RT, int BT, int NW>
+__global__ __launch_bounds__(64 * NW) void dqgemm_kernel(const uint16_t *__restrict__ x,
+                                                         const uint4 *__restrict__ qw, EpiArgs e, int64_t d)
 {
     typedef Deq<BITS> Q;
     constexpr int KC = Q::KC, NT = Q::NT;
+    constexpr int ROWB = KC * 2;                 // bytes of one batch row of an x slab
+    constexpr int NCB = ROWB / 128;              // 128-B column blocks per slab (4 | 2)
+    constexpr int NI = 2 * NCB;                  // DMA instructions per slab (1 KiB each)
+    constexpr int XB = 16 * ROWB;                // one slab
+    constexpr int PART = RT * BT * 5 * 64 * 4;   // parked partials per wave
+    constexpr int REGION = (BT * XB > PART) ? BT * XB : PART;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    QA_STAMP_DECL;
+    QA_STAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ks = wave % KW, rtl = wave / KW;
     const int j = lane & 15, g = lane >> 4;
-    const int64_t nkc = d / KC;
-    const int64_t rt = (int64_t)blockIdx.x * RT + rtl;
-    const int64_t b = (int64_t)blockIdx.y * 16 + j;
-    const bool bvalid = b < e.bs;
-    const uint16_t *xrow = x + (bvalid ? b : 0) * d + 8 * g;
-    const uint4 *wt = qw + (rt * nkc) * 64 + lane;
+    const uint32_t nkc = (uint32_t)(d / KC);
+    const uint32_t rt0 = blockIdx.x * RT;
+    const uint32_t bt0 = blockIdx.y * BT;
+    const uint32_t rowbytes = (uint32_t)d * 2u;
+    char *myreg = smem + wave * REGION;
+
+    // epilogue coefficients for the first (row tile, batch tile) pair this wave will reduce
+    EpiRow epi;
+    if (wave < RT * BT) epi = load_epi(e, (int64_t)(rt0 + wave / BT) * 16 + 4 * g);
+
+    // buffer descriptor over the rows of x from this workgroup's first batch row on: rows >= bs are out of
+    // range and the DMA writes zeros for them (no clamping, no garbage columns)
+    const int64_t brow0 = (int64_t)bt0 * 16;
+    const int64_t rem = (e.bs - brow0) * (int64_t)rowbytes;
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + brow0 * d), 0, (int)rem, 0x00020000);
+    const uint32_t vrow = (lane >> 3), vslot = (lane & 7) ^ (lane >> 3);
+    const uint32_t voff_lo = vrow * rowbytes + (vslot << 4);          // rows 0..7 of a slab
+    const uint32_t voff_hi = voff_lo + 8u * rowbytes;                 // rows 8..15
+    // fragment read addresses: lane (j, g), step t -> unit(j, 4t+g)
+    const uint32_t rd_base = (j >> 3) * 1024 + (j & 7) * 128;
+    const uint32_t rd0 = rd_base + (((0 + g) ^ (j & 7)) << 4);        // t even
+    const uint32_t rd1 = rd_base + (((4 + g) ^ (j & 7)) << 4);        // t odd
+
+    f32x4_t acc[RT][BT];
+    float xs[BT];
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) {
+        xs[bt] = 0.f;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r][bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (uint32_t kc = wave; kc < nkc; kc += NW) {
+        // ---- issue everything this chunk needs: RT weight tiles to VGPRs, BT x slabs to LDS -------------------
+        uint4 w[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const uint4 *wt = qw + ((uint64_t)(rt0 + r) * nkc + kc) * 64;       // scalar base
+            w[r] = wt[lane];
+        }
+        const uint32_t soff = kc * ROWB;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t *)(myreg + bt * XB + (2 * cb + rh) * 1024), 16,
+                                                             (rh ? voff_hi : voff_lo) + bt * 16u * rowbytes,
+                                                             soff + cb * 128, 0, 0);
+        QA_STAMP(1);
+        // hipcc forces vmcnt(0) before any ds_read while an LDS-DMA is pending, so per-column-block counted
+        // waits would be drained anyway: one wait (wave-private data: no barrier needed)
+        wait_vmcnt(0);
+        QA_STAMP(2);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) {
+                uint4 xf[2];
+                xf[0] = *reinterpret_cast<const uint4 *>(myreg + bt * XB + cb * 2048 + rd0);
+                xf[1] = *reinterpret_cast<const uint4 *>(myreg + bt * XB + cb * 2048 + rd1);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int t = 2 * cb + tt;
+                    Frag bb;
+                    bb.u = xf[tt];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        Frag a;
+                        a.u = Q::frag(w[r], t);
+                        acc[r][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bb.v, acc[r][bt], 0, 0, 0);
+                    }
+                    xs[bt] = dot_ones(xf[tt], xs[bt]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // all slab reads retired before the next DMA lands
+    }
+    // the 4 lane groups hold disjoint k's of the same batch row: fold them so every lane has xsum[b=j]
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) {
+        xs[bt] += __shfl_xor(xs[bt], 16);
+        xs[bt] += __shfl_xor(xs[bt], 32);
+    }
+
+    if constexpr (NW > 1) {
+        float *park = reinterpret_cast<float *>(myreg);        // [RT][BT][5][64], the wave's own dead x region
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) {
+                float *p = park + ((r * BT + bt) * 5) * 64 + lane;
+                p[0] = acc[r][bt][0]; p[64] = acc[r][bt][1]; p[128] = acc[r][bt][2]; p[192] = acc[r][bt][3];
+                p[256] = xs[bt];
+            }
+        QA_STAMP(3);
+        __syncthreads();
+        QA_STAMP(4);
+        // wave u reduces the (r, bt) pairs u, u + NW, ...
+        for (int pr = wave; pr < RT * BT; pr += NW) {
+            f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < NW; ++v) {
+                const float *p = reinterpret_cast<const float *>(smem + v * REGION) + (pr * 5) * 64 + lane;
+                a[0] += p[0]; a[1] += p[64]; a[2] += p[128]; a[3] += p[192];
+                s += p[256];
+            }
+            const int r = pr / BT, bt = pr - r * BT;
+            const int64_t r0 = (int64_t)(rt0 + r) * 16 + 4 * g;
+            if (pr != wave) epi = load_epi(e, r0);
+            epilogue_store(e, epi, Q::OFF, a, s, (int64_t)(bt0 + bt) * 16 + j, r0);
+        }
+        QA_STAMP(5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        QA_STAMP(6);
+        QA_STAMP_FLUSH(NW, wave);
+    } else {
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) {
+                const int64_t r0 = (int64_t)(rt0 + r) * 16 + 4 * g;
+                if (r * BT + bt != 0) epi = load_epi(e, r0);
+                epilogue_store(e, epi, Q::OFF, acc[r][bt], xs[bt], (int64_t)(bt0 + bt) * 16 + j, r0);
+            }
+    }
+}
+
+// ---- bs <= 16: waves specialised per (k-chunk, row tile), x slabs shared through LDS, optional split-K ---------
+// Workgroup = CW x RT waves: wave (c, r) multiplies weight tile (row tile rt0 + r, chunk c of the current group)
+// by x slab c, which the RT waves of chunk c stage together (NI/RT DMA instructions each).  The workgroup walks
+// the chunks [z*cps, (z+1)*cps) of its k-slice z = blockIdx.z in groups of CW.  With S = gridDim.z > 1 slices the
+// partial results are added into y with fp32 atomics -- only legal under the reference's in-place-accumulate
+// contract (y fp32, pre-filled by the caller with the bias: quant.py:226-230), where it cuts the x bytes every
+// CU has to ingest by S (at m = 4096 a full-K workgroup ingests all 128 KiB of x for 16 KiB of weights).
+template <int BITS, int RT, int CW>
+__global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(const uint16_t *__restrict__ x,
+                                                                   const uint4 *__restrict__ qw, EpiArgs e, int64_t d,
+                                                                   uint32_t cps)
+{
+    // NOTE on code shape: the instruction cache is cold at every dispatch and a microsecond-scale kernel runs
+    // each instruction once, so it is bound by instruction FETCH (measured: ~1 cycle per byte of straight-line
+    // code).  Every loop below is therefore deliberately ROLLED (#pragma unroll 1) and the epilogue avoids
+    // IEEE division: the executed path is ~1.5 KiB instead of 5.6 KiB fully unrolled.
+    typedef Deq<BITS> Q;
+    constexpr int KC = Q::KC;
+    constexpr int ROWB = KC * 2, NCB = ROWB / 128, NI = 2 * NCB, XB = 16 * ROWB;
+    constexpr int DPW = NI / RT;                 // DMA instructions per wave per slab
+    static_assert(NI % RT == 0, "slab DMA must split evenly over the row-tile waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [CW] slabs, then the parking area
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = wave / RT, r = wave - c * RT;   // chunk slot, row tile
+    const int j = lane & 15, g = lane >> 4;
+    const uint32_t nkc = (uint32_t)(d / KC);
+    const uint32_t rt = blockIdx.x * RT + r;
+    const uint32_t rowbytes = (uint32_t)d * 2u;
+    const uint32_t k_lo = blockIdx.z * cps, k_hi = (k_lo + cps < nkc) ? k_lo + cps : nkc;
+    char *slab = smem + c * XB;
+    float *park = reinterpret_cast<float *>(smem + CW * XB);      // [CW][RT][4][64] acc, then [CW][64] xsum
+
+    // epilogue parameters of the one output row this wave will finish (reducer waves only), fetched NOW so their
+    // latency hides under the weight stream
+    float e_sc = 0.f, e_zr = 0.f, e_bi = 0.f;
+    if (wave < 4 * RT) {
+        const int64_t row0 = (int64_t)(blockIdx.x * RT + (wave >> 2)) * 16 + (lane & 15);
+        e_sc = e.qfn == QUIPAMD_QFN_B ? e.scale[0] : e.scale[row0];
+        if (e.qfn != QUIPAMD_QFN_B) e_zr = e.zero[row0];
+        if (e.bias) e_bi = e.bias[row0];
+    }
+
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)(e.bs * (int64_t)rowbytes), 0x00020000);
+    const uint32_t voff_lo = (lane >> 3) * rowbytes + ((uint32_t)((lane & 7) ^ (lane >> 3)) << 4);
+    const uint32_t voff_hi = voff_lo + 8u * rowbytes;
+    const uint32_t rd_base = (j >> 3) * 1024 + (j & 7) * 128;
+    const uint32_t rd0 = rd_base + (((0 + g) ^ (j & 7)) << 4);
+    const uint32_t rd1 = rd_base + (((4 + g) ^ (j & 7)) << 4);
 
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     float xs = 0.f;
-    for (int64_t kc = ks; kc < nkc; kc += KW) {
-        const uint4 w = wt[kc * 64];
-        uint4 xf[NT];
+#pragma unroll 1
+    for (uint32_t k0 = k_lo; k0 < k_hi; k0 += CW) {
+        const uint32_t kc = k0 + c;
+        const bool live = kc < k_hi;                               // wave-uniform
+        uint4 w = make_uint4(0, 0, 0, 0);
+        if (live) {
+            if (!QA_ABL(4)) w = (qw + ((uint64_t)rt * nkc + kc) * 64)[lane];
+            // this wave's share of slab c: DMA instructions i = r*DPW .. +DPW (i = 2*column block + row half)
+            if (!QA_ABL(1))
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            xf[t] = *reinterpret_cast<const uint4 *>(xrow + kc * KC + 32 * t);
-            if (!bvalid) xf[t] = make_uint4(0, 0, 0, 0);
+            for (int q = 0; q < DPW; ++q) {
+                const int i = r * DPW + q;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t *)(slab + i * 1024), 16, (i & 1) ? voff_hi : voff_lo,
+                                                         kc * ROWB + (i >> 1) * 128, 0, 0);
+            }
         }
+        wait_vmcnt(0);
+        if constexpr (RT > 1) __syncthreads();                     // slab c complete (RT waves contributed)
+        if (QA_ABL(2)) { QA_KEEP(w.x); QA_KEEP(w.y); QA_KEEP(w.z); QA_KEEP(w.w); }
+        else if (live) {
+            uint4 xf[Q::NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            Frag a, bb;
-            a.u = Q::frag(w, t);
-            bb.u = xf[t];
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bb.v, acc, 0, 0, 0);
-            xs = dot_ones(xf[t], xs);
+            for (int t = 0; t < Q::NT; ++t)
+                xf[t] = *reinterpret_cast<const uint4 *>(slab + (t >> 1) * 2048 + ((t & 1) ? rd1 : rd0));
+#pragma unroll
+            for (int t = 0; t < Q::NT; ++t) {
+                Frag a, bb;
+                a.u = Q::frag(w, t);
+                bb.u = xf[t];
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bb.v, acc, 0, 0, 0);
+                if (r == 0) xs = dot_ones(xf[t], xs);            // one wave per chunk keeps the row sums of x
+            }
+        }
+        if (k0 + CW < k_hi) {                                      // every read of the slabs retired before the next DMA
+            if constexpr (RT > 1) __syncthreads();
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
-    // the 4 lane groups hold disjoint k's of the same batch row: fold them so every lane has xsum[b=j]
-    xs += __shfl_xor(xs, 16);
-    xs += __shfl_xor(xs, 32);
 
-    if constexpr (KW > 1) {
-        __shared__ float red[RT][KW][5][64];
-        red[rtl][ks][0][lane] = acc[0];
-        red[rtl][ks][1][lane] = acc[1];
-        red[rtl][ks][2][lane] = acc[2];
-        red[rtl][ks][3][lane] = acc[3];
-        red[rtl][ks][4][lane] = xs;
-        __syncthreads();
-        if (ks != 0) return;
-#pragma unroll
-        for (int s = 1; s < KW; ++s) {
-            acc[0] += red[rtl][s][0][lane];
-            acc[1] += red[rtl][s][1][lane];
-            acc[2] += red[rtl][s][2][lane];
-            acc[3] += red[rtl][s][3][lane];
-            xs += red[rtl][s][4][lane];
+    // ---- meet in LDS: the CW chunk partials of each row tile ---------------------------------------------------------
+    // park[(c*RT + r)*4 + comp][lane] = accumulator component comp; xpark[c][lane] = row sums of x over chunk slot c
+    if (QA_ABL(8)) { QA_KEEP(acc[0]); QA_KEEP(acc[1]); QA_KEEP(acc[2]); QA_KEEP(acc[3]); QA_KEEP(xs); return; }
+    float *xpark = park + CW * RT * 256;
+    {
+        float *p = park + ((c * RT + r) * 4) * 64 + lane;
+        p[0] = acc[0]; p[64] = acc[1]; p[128] = acc[2]; p[192] = acc[3];
+        if (r == 0) {
+            xs += __shfl_xor(xs, 16);
+            xs += __shfl_xor(xs, 32);
+            xpark[c * 64 + lane] = xs;
         }
     }
-    epilogue_store(e, acc, xs, Q::OFF, b, rt * 16 + 4 * g);
+    __syncthreads();
+    // A single wave is a slow serial instruction stream, so the reduction is spread over 4*RT reducer waves.
+    // Reducer u = 4*r2 + q finishes the outputs (batch rows 4q .. 4q+3) x (all 16 weight rows of row tile r2):
+    // lane l -> batch row b = 4q + (l>>4), weight row l&15, i.e. 16 consecutive outputs of y per 16 lanes (64-B
+    // runs for the stores / atomics).  That output is accumulator component (l&3) of MFMA lane (j = b, g = (l&15)>>2).
+#pragma unroll 1
+    for (int u = wave; u < 4 * RT; u += RT * CW) {
+        const int r2 = u >> 2, q = u & 3;
+        const int b = 4 * q + (lane >> 4), wr = lane & 15;
+        const int src = ((wr & 3) * 64) + b + 16 * (wr >> 2);          // [comp][mfma lane]
+        float a = 0.f, xsum = 0.f;
+#pragma unroll
+        for (int v = 0; v < CW; ++v) {
+            a += park[(v * RT + r2) * 256 + src];
+            xsum += xpark[v * 64 + b];
+        }
+        const int64_t row = (int64_t)(blockIdx.x * RT + r2) * 16 + wr;
+        if (b < e.bs) {
+            if (u != wave) {                                        // only when there are fewer waves than reducer slots
+                e_sc = e.qfn == QUIPAMD_QFN_B ? e.scale[0] : e.scale[row];
+                e_zr = e.qfn == QUIPAMD_QFN_B ? 0.f : e.zero[row];
+                e_bi = e.bias ? e.bias[row] : 0.f;
+            }
+            const float alpha = e.qfn == QUIPAMD_QFN_B ? e_sc * e.two_over_maxq : e_sc;
+            const float c0 = e.qfn == QUIPAMD_QFN_B ? Q::OFF + 0.5f * (float)e.maxq : Q::OFF + e_zr;
+            float val = alpha * (a - c0 * xsum);
+            if (blockIdx.z == 0) val += e_bi;
+            const int64_t o = (int64_t)b * e.m + row;
+            if (QA_ABL(16)) { QA_KEEP(val); continue; }
+            if (gridDim.z > 1) unsafeAtomicAdd((float *)e.y + o, val);
+            else if (e.y_f32) ((float *)e.y)[o] = e.accumulate ? ((float *)e.y)[o] + val : val;
+            else ((uint16_t *)e.y)[o] = f32_to_bf16_bits(val);
+        }
+    }
 }
 
-template <int BITS>
-int launch(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, hipStream_t s)
+template <int BITS, int RT, int CW>
+int launch_tile(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, int S, hipStream_t s)
 {
-    const int64_t ntile = e.m / 16;
-    const int nb = qa_div_up(e.bs, 16);
-    QA_REQUIRE(nb <= 65535, QUIPAMD_ERR_SHAPE, "dequant_gemm: bs too large for this kernel (%lld)", (long long)e.bs);
-    // occupancy heuristic: enough workgroups for 256 CUs first, then more k-slices per workgroup
-    if (ntile * nb >= 512 && ntile % 4 == 0) {
-        dqgemm_stream<BITS, 4, 1><<<dim3((unsigned)(ntile / 4), nb), 256, 0, s>>>(x, qw, e, d);
-    } else {
-        dqgemm_stream<BITS, 1, 4><<<dim3((unsigned)ntile, nb), 256, 0, s>>>(x, qw, e, d);
+    typedef Deq<BITS> Q;
+    constexpr int XB = 16 * Q::KC * 2;
+    constexpr size_t lds = (size_t)CW * XB + (size_t)(CW * RT * 256 + CW * 64) * 4;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = dqgemm_tile_kernel<BITS, RT, CW>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "dequant_gemm: cannot raise dynamic LDS to %zu", lds);
+        attr_set = true;
     }
+    const uint32_t nkc = (uint32_t)(d / Q::KC);
+    const uint32_t cps = (nkc + S - 1) / S;
+    const unsigned gz = (nkc + cps - 1) / cps;
+    kern<<<dim3((unsigned)(e.m / 16 / RT), 1, gz), 64 * RT * CW, lds, s>>>(x, qw, e, d, cps);
     QA_LAUNCH_CHECK("quipamd_dequant_gemm");
     return QUIPAMD_OK;
 }
 
+template <int BITS, int RT, int BT, int NW>
+int launch_cfg(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, hipStream_t s)
+{
+    typedef Deq<BITS> Q;
+    constexpr int XB = 16 * Q::KC * 2;
+    constexpr int PART = RT * BT * 5 * 64 * 4;
+    constexpr int REGION = (BT * XB > PART) ? BT * XB : PART;
+    constexpr size_t lds = (size_t)NW * REGION;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = dqgemm_kernel<BITS, RT, BT, NW>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "dequant_gemm: cannot raise dynamic LDS to %zu", lds);
+        attr_set = true;
+    }
+    const int64_t nby = (e.bs + 16 * BT - 1) / (16 * BT);
+    QA_REQUIRE(nby <= 65535, QUIPAMD_ERR_SHAPE, "dequant_gemm: bs too large for this kernel (%lld)", (long long)e.bs);
+    kern<<<dim3((unsigned)(e.m / 16 / RT), (unsigned)nby), 64 * NW, lds, s>>>(x, qw, e, d);
+    QA_LAUNCH_CHECK("quipamd_dequant_gemm");
+    return QUIPAMD_OK;
+}
+
+// Tuning override (quipamd_tune_dequant_gemm): 0 = use the shape heuristic.
+int g_tune_rt = 0, g_tune_bt = 0, g_tune_nw = 0, g_tune_split = 0;
+
+#define QA_K2_CASE(RT_, BT_, NW_) \
+    if (rt == RT_ && bt == BT_ && nw == NW_) return launch_cfg<BITS, RT_, BT_, NW_>(x, qw, e, d, s)
+
+// Shape heuristic.  BT: as many batch tiles per wave as the batch has (weights streamed once per 64 batch
+// rows).  RT: row tiles per workgroup -- more rows per workgroup means fewer x bytes into the chip
+// (every workgroup ingests the whole x), but the grid must still cover the 256 CUs.
+template <int BITS>
+int launch(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, hipStream_t s)
+{
+    const int64_t ntile = e.m / 16;
+    const int64_t nb = (e.bs + 15) / 16;
+    if (nb == 1 && g_tune_bt == 0) {
+        // tile kernel.  rt: row tiles per workgroup (x slab reuse); cw: chunks in flight per workgroup;
+        // S: k-slices over workgroups (atomics; accumulate contract only).
+        const int64_t nkc = d / Deq<BITS>::KC;
+        const bool can_split = e.accumulate && e.y_f32;
+        int rt, cw, S = 1;
+        if (ntile % 4 == 0 && ntile / 4 >= 256) { rt = 4; cw = 4; }             // big m: 4 row tiles share every x slab
+        else if (can_split && ntile % 2 == 0) {
+            // small m under the accumulate contract: 8-wave workgroups (several resident per CU), k split over
+            // workgroups until there are ~512 of them (measured best at 4096x4096: rt 2, cw 4, S 4)
+            rt = 2; cw = 4;
+            S = (int)((512 + ntile / 2 - 1) / (ntile / 2));
+            if (S > nkc / cw) S = (int)(nkc / cw);
+            if (S < 1) S = 1;
+        }
+        else if (ntile % 2 == 0 && ntile / 2 >= 256) { rt = 2; cw = 8; }
+        else { rt = 1; cw = 8; }
+        if (g_tune_rt > 0 && ntile % g_tune_rt == 0) { rt = g_tune_rt; cw = 16 / rt; }
+        if (g_tune_nw > 0) cw = g_tune_nw / rt > 0 ? g_tune_nw / rt : 1;
+        if (g_tune_split > 0) S = can_split ? g_tune_split : 1;
+#define QA_K2T_CASE(RT_, CW_) if (rt == RT_ && cw == CW_) return launch_tile<BITS, RT_, CW_>(x, qw, e, d, S, s)
+        QA_K2T_CASE(1, 16); QA_K2T_CASE(1, 8); QA_K2T_CASE(1, 4); QA_K2T_CASE(1, 2); QA_K2T_CASE(1, 1); QA_K2T_CASE(2, 1);
+        QA_K2T_CASE(2, 8);  QA_K2T_CASE(2, 4); QA_K2T_CASE(2, 2);
+        QA_K2T_CASE(4, 4);  QA_K2T_CASE(4, 2); QA_K2T_CASE(4, 1);
+#undef QA_K2T_CASE
+        return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: no tile kernel for rt=%d cw=%d", rt, cw);
+    }
+    int rt, bt, nw;
+    if (nb >= 3) {
+        bt = 4; nw = 4;
+        rt = (ntile % 2 == 0 && ntile / 2 * ((nb + 3) / 4) >= 256) ? 2 : 1;
+    } else if (nb == 2) {
+        bt = 2; nw = 8;
+        rt = (ntile % 2 == 0 && ntile / 2 >= 256) ? 2 : 1;
+    } else {
+        bt = 1; nw = 16;
+        rt = (ntile % 4 == 0 && ntile / 4 >= 512) ? 4 : (ntile % 2 == 0 && ntile / 2 >= 256) ? 2 : 1;
+    }
+    if (g_tune_rt > 0 && ntile % g_tune_rt == 0) rt = g_tune_rt;
+    if (g_tune_bt > 0) bt = g_tune_bt;
+    if (g_tune_nw > 0) nw = g_tune_nw;
+    QA_K2_CASE(1, 1, 16); QA_K2_CASE(2, 1, 16); QA_K2_CASE(4, 1, 16);
+    QA_K2_CASE(1, 1, 8);  QA_K2_CASE(2, 1, 8);  QA_K2_CASE(4, 1, 8);
+    QA_K2_CASE(1, 1, 4);  QA_K2_CASE(2, 1, 4);  QA_K2_CASE(4, 1, 4);
+    QA_K2_CASE(1, 2, 8);  QA_K2_CASE(2, 2, 8);
+    QA_K2_CASE(1, 2, 4);  QA_K2_CASE(2, 2, 4);
+    QA_K2_CASE(1, 4, 4);  QA_K2_CASE(2, 4, 4);
+    return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: no kernel for rt=%d bt=%d nw=%d", rt, bt, nw);
+}
+#undef QA_K2_CASE
+
 }   // namespace
+
+extern "C" int quipamd_tune_dequant_gemm(int rt, int bt, int nw, int split)
+{
+    g_tune_rt = rt; g_tune_bt = bt; g_tune_nw = nw; g_tune_split = split;
+    return QUIPAMD_OK;
+}
 
 extern "C" int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *qweight, int bits, int layout, int qfn,
                                     const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
@@ -218,12 +673,14 @@ extern "C" int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *q
                "dequant_gemm: qweight must be in STREAM layout (repack with quipamd_unpack/quipamd_pack)");
     QA_REQUIRE(bits == 2 || bits == 4, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: bits must be 2 or 4");
     QA_REQUIRE(qfn == QUIPAMD_QFN_B || (qfn == QUIPAMD_QFN_A && zero), QUIPAMD_ERR_ARG, "dequant_gemm: qfn a needs zero; qfn must be a or b");
+    QA_REQUIRE(bs * d * 2 < ((int64_t)1 << 31) && m * d * bits / 8 < ((int64_t)1 << 40), QUIPAMD_ERR_SHAPE,
+               "dequant_gemm: x larger than 2 GiB is not supported by the 32-bit buffer offsets (bs=%lld d=%lld)", (long long)bs, (long long)d);
     QA_REQUIRE(m % 16 == 0 && d % (512 / bits) == 0, QUIPAMD_ERR_SHAPE,
                "dequant_gemm: needs m %% 16 == 0 and d %% %d == 0 (m=%lld d=%lld)", 512 / bits, (long long)m, (long long)d);
     if (bs == 0 || m == 0) return QUIPAMD_OK;
     EpiArgs e;
     e.scale = scale; e.zero = zero; e.bias = bias; e.y = y;
-    e.qfn = qfn; e.maxq = (1 << bits) - 1; e.y_f32 = (y_dtype == QUIPAMD_F32); e.accumulate = accumulate;
+    e.qfn = qfn; e.maxq = (1 << bits) - 1; e.two_over_maxq = 2.0f / (float)e.maxq; e.y_f32 = (y_dtype == QUIPAMD_F32); e.accumulate = accumulate;
     e.bs = bs; e.m = m;
     hipStream_t s = (hipStream_t)stream;
     if (bits == 2) return launch<2>((const uint16_t *)x, (const uint4 *)qweight, e, d, s);

@@ -118,3 +118,54 @@ def test_headline_shape_linearity_and_dense_agreement(ops, O):
     assert float((f(xs).double() - ys_ref).norm() / ys_ref.norm()) <= TOL_F32
     # determinism
     assert torch.equal(f(x1), y1)
+
+
+@pytest.mark.parametrize("qfn", ["a", "b"])
+@pytest.mark.parametrize("m,d,bs,bits", [(4096, 4096, 16, 2), (2048, 2048, 7, 2), (1024, 4096, 16, 4), (64, 512, 3, 2)])
+def test_accumulate_split_k_atomics(ops, O, qfn, m, d, bs, bits):
+    """Under the accumulate contract small-m shapes take the split-K path (fp32 atomics into the caller's y,
+    bias applied once): same answer as the oracle, and as every forced workgroup shape."""
+    from quip_amd import _lib
+    W, x, codes, scale, zero, maxq = _case(O, m, d, bs, bits, qfn, seed=3 * m + bs)
+    rng = np.random.default_rng(4)
+    bias = rng.standard_normal(m).astype(np.float32)
+    y0 = rng.standard_normal((bs, m)).astype(np.float32)               # what the caller already holds in y
+    y_ref = y0 + O.dequant_linear(x, codes, qfn, scale, zero, maxq, bias)
+    qs = ops.pack(torch.from_numpy(codes).to(DEV), bits, ops.LAYOUT_STREAM)
+    xd = torch.from_numpy(x).to(DEV).to(torch.bfloat16)
+    sc = torch.tensor(np.asarray(scale, np.float32).reshape(-1))
+    zr = None if zero is None else torch.from_numpy(zero)
+    lib = _lib.load()
+    try:
+        for (rt, nw, split) in [(0, 0, 0), (4, 16, 4), (4, 16, 2), (2, 16, 2), (1, 16, 1), (4, 8, 8), (2, 8, 3)]:
+            lib.quipamd_tune_dequant_gemm(rt, 0, nw, split)
+            y = torch.from_numpy(y0.copy()).to(DEV)
+            ops.dequant_gemm(xd, qs, bits, qfn, sc, zr, torch.from_numpy(bias), out=y, accumulate=True)
+            assert _rel(y.cpu().numpy().astype(np.float64), y_ref) <= TOL_F32, (rt, nw, split)
+    finally:
+        lib.quipamd_tune_dequant_gemm(0, 0, 0, 0)
+
+
+def test_forced_workgroup_shapes_agree(ops, O):
+    """every (row tiles, waves) shape of both K2 kernels gives the oracle's answer (bf16-free fp32 output)."""
+    from quip_amd import _lib
+    m, d, bs, bits = 512, 2048, 16, 2
+    W, x, codes, scale, zero, maxq = _case(O, m, d, bs, bits, "b", seed=9)
+    y_ref = O.dequant_linear(x, codes, "b", scale, None, maxq, None)
+    qs = ops.pack(torch.from_numpy(codes).to(DEV), bits, ops.LAYOUT_STREAM)
+    xd = torch.from_numpy(x).to(DEV).to(torch.bfloat16)
+    sc = torch.tensor(np.asarray(scale, np.float32).reshape(-1))
+    lib = _lib.load()
+    bad = []
+    try:
+        for cfg in [(1, 0, 16), (2, 0, 16), (4, 0, 16), (1, 0, 8), (2, 0, 8), (4, 0, 8), (1, 0, 4), (2, 0, 4), (4, 0, 4),
+                    (1, 0, 2), (1, 0, 1), (2, 0, 2),
+                    (1, 1, 16), (2, 1, 16), (4, 1, 16), (1, 1, 8), (2, 1, 8), (4, 1, 8), (1, 1, 4), (4, 1, 4), (1, 2, 8),
+                    (2, 2, 8), (1, 2, 4), (2, 2, 4), (1, 4, 4), (2, 4, 4)]:
+            lib.quipamd_tune_dequant_gemm(cfg[0], cfg[1], cfg[2], 0)
+            y = ops.dequant_gemm(xd, qs, bits, "b", sc, None, None, out_dtype=torch.float32)
+            if _rel(y.cpu().numpy().astype(np.float64), y_ref) > TOL_F32:
+                bad.append(cfg)
+    finally:
+        lib.quipamd_tune_dequant_gemm(0, 0, 0, 0)
+    assert not bad, f"workgroup shapes with wrong results: {bad}"
