@@ -11,6 +11,12 @@ launch-bound: a launch is ~2 us of GPU work):
          This is `value` and the `roofline` (bound "hbm").
   warm : the same 4 MiB weight every launch (L2 / Infinity-Cache resident) -> `warm` / `roofline_warm`
          (bound "mfma"), never presented as an HBM fraction.
+Besides `value` (bf16 y, SURVEY.md 8(d) byte formula) the line carries `accumulate_contract`: the same layer under
+the reference operator's own contract (fp32 y pre-filled by the caller, accumulated in place -- quant.py:226-230),
+where K2 may split K over workgroups with fp32 atomics; and, `sharded_ldlq`: one LDLQ rounding of an OPT-1.3B-fc2-sized
+Linear with its rows scattered over the N ranks (quip_amd/shard.py; N=1: the kernel alone).
+`roofline.traffic` is the PMC-measured HBM traffic per launch of the last committed rocprofv3 pass
+(profiles/k2_pmc_latest.json, FETCH_SIZE corrected x2 as MI355X_MICROARCH.md prescribes), or null.
 `cpu_baseline` = what the reference actually runs at inference (dense fake-quant nn.Linear: torch CPU
 F.linear, fp32) on the host cores, a bounded sample, rank 0 / N=1 only ("port": same library call, not
 the reference's files).
@@ -41,6 +47,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--ring", type=int, default=96, help="number of distinct weight copies for the cold regime")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ldlq", action="store_true", help="skip the sharded-LDLQ side measurement")
+    ap.add_argument("--profile-cold-only", action="store_true",
+                    help="for rocprofv3 passes: run only the cold bf16 regime (so per-kernel averages are the headline kernel's)")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of a hipGraph")
     return ap.parse_args()
 
@@ -95,7 +104,7 @@ def main():
         torch.cuda.synchronize()
 
     def timed(weights, steps, warmup):
-        """returns seconds for exactly `steps` launches (max over ranks)."""
+        """returns seconds for exactly `steps` launches (max over ranks).  `launch` is looked up at call time."""
         side = torch.cuda.Stream()
         nw = len(weights)
         if args.eager:
@@ -145,7 +154,34 @@ def main():
         return t
 
     t_cold = timed(ring, args.steps, args.warmup)
+    if args.profile_cold_only:
+        if rank == 0:
+            print(json.dumps({"profile_cold_only": True, "us_per_launch": t_cold / args.steps * 1e6}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     t_warm = timed([qs], args.steps, args.warmup)
+
+    # ---- the reference operator's own contract: y fp32, accumulated in place (quant.py:226-230) ---------------
+    yacc = torch.zeros(BS, M, dtype=torch.float32, device=dev)
+    launch_bf16 = launch
+
+    def launch_acc(qw, stream):
+        rc = fn(vp(x.data_ptr()), 2, vp(qw.data_ptr()), BITS, 1, 1, vp(scale.data_ptr()), vp(0), vp(0),
+                vp(yacc.data_ptr()), 0, 1, BS, M, D, stream)
+        if rc:
+            raise RuntimeError(lib.quipamd_last_error())
+    launch = launch_acc
+    t_acc_cold = timed(ring, args.steps, args.warmup)
+    t_acc_warm = timed([qs], args.steps, args.warmup)
+    launch = launch_bf16
+    BYTES_ACC = M * D * BITS // 8 + 2 * BS * D + 2 * 4 * BS * M      # y read + written as fp32
+
+    traffic = None
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "k2_pmc_latest.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
 
     us_cold = t_cold / args.steps * 1e6
     us_warm = t_warm / args.steps * 1e6
@@ -170,13 +206,56 @@ def main():
                    "launch": "eager" if args.eager else "hipGraph", "parallelism": f"dp{world} (replicas)"},
         "parity_rel_err": rel,
         "roofline": {"bound": "hbm", "achieved": round(gbs_cold, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(gbs_cold / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(gbs_cold / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": BYTES, "us_per_launch": round(us_cold, 3),
                      "pct_mfma_peak": round(100 * tf_cold / world / MFMA_PEAK_TF, 2)},
         "warm": {"value": round(tf_warm, 3), "unit": "TFLOP/s", "us_per_launch": round(us_warm, 3)},
         "roofline_warm": {"bound": "mfma", "achieved": round(tf_warm / world, 2), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
                           "frac": round(tf_warm / world / MFMA_PEAK_TF, 4)},
+        "accumulate_contract": {
+            "what": "same layer, y fp32 accumulated in place (the reference operator's contract, quant.py:226-230); "
+                    "K2 splits K over workgroups with fp32 atomics",
+            "us_per_launch_cold": round(t_acc_cold / args.steps * 1e6, 3), "us_per_launch_warm": round(t_acc_warm / args.steps * 1e6, 3),
+            "value": round(FLOPS * world / (t_acc_cold / args.steps) / 1e12, 3), "unit": "TFLOP/s",
+            "algorithmic_bytes_per_launch": BYTES_ACC,
+            "hbm_GBs": round(BYTES_ACC / (t_acc_cold / args.steps) / 1e9, 1),
+            "hbm_frac": round(BYTES_ACC / (t_acc_cold / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
+
+    # ---- sharded LDLQ: rows of one OPT-1.3B-fc2-sized Linear over the N ranks -----------------
+    if not args.no_ldlq:
+        from quip_amd import shard
+        lm, ld = 2048, 8192
+        if rank == 0:
+            g = torch.Generator().manual_seed(0)
+            Xc = torch.randn(ld + 256, ld, generator=g).to(dev)
+            Hh = Xc.T @ Xc / (ld + 256)
+            Hh += 0.01 * Hh.diag().mean() * torch.eye(ld, device=dev)
+            LT = ops.unit_lower_t(torch.linalg.cholesky(Hh))
+            wg = (torch.rand(lm, ld, generator=g) * 3.6 - 0.3).clamp(0, 3).to(dev)
+            del Xc, Hh
+        else:
+            LT = wg = None
+        reps = 3
+        ts = []
+        for it in range(reps + 1):
+            barrier()
+            t0 = time.perf_counter()
+            if world > 1:
+                codes_l = shard.ldlq_round_sharded(wg, LT, BITS)
+            else:
+                codes_l = ops.ldlq_round(wg, LT, BITS)
+            barrier()
+            if it:
+                ts.append(time.perf_counter() - t0)
+        tl = float(np.median(ts))
+        if dist is not None:
+            tt = torch.tensor([tl], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tl = float(tt.item())
+        out["sharded_ldlq"] = {"what": f"LDLQ codes of one {lm}x{ld} Linear (OPT-1.3B fc2 shape), w{BITS}, rows over {world} rank(s); "
+                                       "wall time incl. LT broadcast, row scatter, code gather",
+                               "ms": round(tl * 1e3, 3), "far_field_TFLOPs": round(lm * ld * ld / tl / 1e12, 2), "scaling": "strong"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         Wd = ops.codes_to_weight(codes, "b", scale, None, MAXQ, out_dtype=torch.float32).cpu()

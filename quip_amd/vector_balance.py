@@ -7,6 +7,7 @@ Out of scope (research variants): allbal, ldlqRG greedy
 import torch
 
 from . import ops
+from . import shard
 
 
 def check_nbits(wr, nbits):
@@ -33,7 +34,11 @@ def _round_ldl_codes(w, H, nbits, n_greedy_passes, unbiased):
         raise NotImplementedError("greedy post-passes (LDLQ-RG) are outside the quip_amd hot path; use npasses=0")
     w = w.to(torch.float32)
     eta = torch.rand(w.shape).to(w.device) if unbiased else None     # same CPU draw as vector_balance.py:174-175
-    return ops.ldlq_round(w, _ldl_transposed(H), nbits, eta=eta)
+    LT = _ldl_transposed(H)
+    sharded = shard.active()
+    if sharded is not None:                                           # rows split over the ranks of the node (shard.py)
+        return sharded.round(w, LT, nbits, eta=eta)
+    return ops.ldlq_round(w, LT, nbits, eta=eta)
 
 
 def round_ldl(w, H, nbits, n_greedy_passes=9, unbiased=False):

@@ -29,5 +29,29 @@ def main(paths):
         print()
 
 
+def k2_json(fetch_db, write_db, out_path, match="dqgemm"):
+    """HBM bytes per launch of the K2 kernel from two PMC passes: FETCH_SIZE (KB, reads 1/2 of a wide coalesced
+    stream on gfx950 -> x2, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (KB, 1:1)."""
+    import json
+
+    def avg(db, counter):
+        con = sqlite3.connect(db)
+        rows = con.execute("select kernel_name, count(*), avg(value), avg(duration) from counters_collection "
+                           "where counter_name = ? group by kernel_name", (counter,)).fetchall()
+        rows = [r for r in rows if match in r[0]]
+        rows.sort(key=lambda r: -r[1])
+        return rows[0] if rows else None
+    f, w = avg(fetch_db, "FETCH_SIZE"), avg(write_db, "WRITE_SIZE")
+    out = {"kernel": f[0][:120], "launches": f[1], "FETCH_SIZE_KB_avg": f[2], "WRITE_SIZE_KB_avg": w[2],
+           "fetch_correction": 2.0, "hbm_bytes_per_launch": int((2.0 * f[2] + w[2]) * 1024),
+           "avg_kernel_ns_under_pmc": f[3]}
+    with open(out_path, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    if len(sys.argv) > 1 and sys.argv[1] == "--k2-json":
+        k2_json(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        main(sys.argv[1:])
