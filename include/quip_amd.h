@@ -107,22 +107,27 @@ int quipamd_tune_dequant_gemm(int rt, int bt, int nw, int split);
 /* ---- K3: structured orthogonal (two-factor butterfly / Kronecker) apply ------------------------
  * Replaces mul_ortho_butterfly (method.py:46-67) and the dense U @ W @ V^T, V @ H @ V^T products of
  * QuantMethod.preproc/postproc (method.py:175-176, 202-203) without materialising U or V.
- * Applies the n x n operator  Q = P_out * S1 * S0 * P_in  (or Q^T when transpose != 0) to every ROW of
- * x: out[r, :] = Q * x[r, :].
- *   n = p*q;  B0t: float [p, p, q] (blocked: B0t[a][a'][b] = B0[b][a][a']) or [p, p] (kron, blocked = 0);
- *             B1t: float [q, q, p] (blocked: B1t[b][b'][a] = B1[a][b][b']) or [q, q];
- *   load_idx / store_idx: int32 [n] permutations in "scatter on load / gather on store" form, with
- *             perm_in, perm_out the torch.randperm values of method.py:35:
- *               forward  (transpose = 0): load_idx = argsort(perm_in),  store_idx = perm_out
- *               transpose (transpose = 1): load_idx = perm_out,          store_idx = argsort(perm_in)
- *   colscale: float[n] or NULL -- x[r, k] is multiplied by colscale[k] on load (the x (/) s step of the
- *             packed layer);
- *   x: [rows, n] with leading dimension ldx, out: [rows, n] with ldo; dtypes F32 / F16 / BF16.
- * One row (both LDS images, fp32) must fit in 160 KiB: n <= ~20000. */
-int quipamd_ortho_apply_rows(const float *B0t, const float *B1t, int blocked, const int32_t *load_idx,
-                             const int32_t *store_idx, int p, int q, int transpose, const float *colscale,
+ * Applies the n x n operator  Q = P_out * S1 * S0 * P_in  (or Q^T) to every ROW of x: out[r, :] = Q * x[r, :],
+ * n = p*q, z viewed as [p][q] (pos = a*q + b); S0 mixes a per b with B0[b] (p x p), S1 mixes b per a with B1[a] (q x q);
+ * blocked = 0: one B0 and one B1 for all b / a (Kronecker product, method.py:38-39).
+ * The call runs two "mix one index" stages (first, second) on the fp32 matrix pipe:
+ *   b_first = 0 (Q):   first = mix a with M_c = B0[c],   second = mix b with M_c = B1[c]
+ *   b_first = 1 (Q^T): first = mix b with M_c = B1[c]^T, second = mix a with M_c = B0[c]^T
+ *   frag_first / frag_second: the stage's matrices M_c[i][k] (out index i, in index k; P x P, P = p or q) in MFMA
+ *     B-fragment order: float [C][NT][NT][64][4], C = number of matrices (q|p if blocked else 1), NT = ceil(P/16),
+ *     element [c][nt][S][lane][s] = M_c[16*nt + (lane & 15)][16*S + 4*(lane >> 4) + s], zero outside P x P
+ *     (quip_amd/ops.py OrthoOp builds them);
+ *   gather_idx:  int32 [n] or NULL (identity): z[pos] = x[r, gather_idx[pos]]   (Q: perm_in;        Q^T: argsort(perm_out))
+ *   scatter_idx: int32 [n] or NULL:            out[r, scatter_idx[pos]] = z[pos] (Q: argsort(perm_out); Q^T: perm_in)
+ *     with perm_in, perm_out the torch.randperm values of method.py:35;
+ *   colscale: float[n] or NULL -- x[r, k] is multiplied by colscale[k] on load (the x (/) s step of the packed
+ *     layer);
+ *   x: [rows, n] leading dimension ldx, out: [rows, n] with ldo; dtypes F32 / F16 / BF16 (any pair);
+ *   workspace: float [16*ceil(rows/16), n], the fp32 intermediate between the two stages. */
+int quipamd_ortho_apply_rows(const float *frag_first, const float *frag_second, int blocked, const int32_t *gather_idx,
+                             const int32_t *scatter_idx, int p, int q, int b_first, const float *colscale,
                              const void *x, int x_dtype, int64_t ldx, void *out, int out_dtype, int64_t ldo,
-                             int64_t rows, void *stream);
+                             int64_t rows, float *workspace, void *stream);
 
 /* ---- K4: LDLQ rounding -------------------------------------------------------------------------
  * Replaces round_ldl / round_ldl_block (vector_balance.py:155-199, 218-257; n_greedy_passes = 0):

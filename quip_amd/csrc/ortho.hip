@@ -4,220 +4,300 @@
 // of QuantMethod.preproc / postproc (method.py:175-176,202-203): the operator is applied in its factored
 // form, never materialised (2 n c (p+q) flops instead of 2 n^2 c).
 //
-// For one length-n vector v (n = p*q), with z viewed as [p][q] (index i = a*q + b):
+// For one length-n vector v (n = p*q), with z viewed as [p][q] (index pos = a*q + b):
 //   forward   z = v[perm_in];  z[a][b] <- sum_a' B0[b][a][a'] z[a'][b];  z[a][b] <- sum_b' B1[a][b][b'] z[a][b'];
 //             out = z[perm_out]
 //   transpose z[perm_out] = v;  z[a][b] <- sum_b' B1[a][b'][b] z[a][b'];  z[a][b] <- sum_a' B0[b][a'][a] z[a'][b];
 //             out[perm_in] = z
 // (index form verified against the reference in tests/golden/butterfly.npz through the oracle).
 //
-// Kernel: one workgroup owns RT whole rows in LDS (fp32), two ping-pong images per row:
-//   image A: element (a,b) at a*QS + b  (QS = q|1)   -- read by "mix over a" with lanes along b (conflict free)
-//   image B: element (a,b) at b*PS + a  (PS = p|1)   -- read by "mix over b" with lanes along a (conflict free)
-// Each thread register-blocks 4 outputs x RT rows, so one factor value (global, L2 resident, coalesced along
-// the lane axis) feeds RT FMAs and one LDS read feeds 4.  Permutations are applied as an LDS scatter on the
-// coalesced global load and an LDS gather on the coalesced global store.
-// Algorithmic bytes: rows*n*(in+out element size) (+ factors, n*(p+q)*4 blocked); FLOPs: 2*rows*n*(p+q).
+// Design: the operator is two "mix ONE index" stages, each a batch of tiny GEMMs
+//       out[r][i][c] = sum_k M_c[i][k] * in[r][k][c]          (i, k over the mixed index, c the other index)
+// run as TWO launches of one stage kernel with an fp32 intermediate z[rows][n] in a caller workspace.  A workgroup
+// (4 waves) owns 16 rows x QB values of c:
+//   load   the [QB][16][Pm] input tile into LDS (first stage: permutation as a GATHER, optional column scale);
+//   mix    on the fp32 matrix pipe, v_mfma_f32_16x16x4_f32 (exact fmaf chains, 157 TF): the 16 ROWS are the MFMA M
+//          dimension (A operand = data, one ds_read_b128 per 4 MFMAs), the factor is the B operand, pre-arranged on
+//          the host in B-fragment order so a lane's 16-byte load feeds 4 MFMAs (coalesced 1 KiB per wave, L2 resident);
+//   store  the [QB][16][Pm] output tile (second stage: permutation as a SCATTER, conversion to the output dtype).
+// Tiling over c is what lets a 16-row activation batch (packed-layer forward) use hundreds of workgroups; QB shrinks
+// until the grid covers the chip.  K index order inside a group of 16 is permuted (lane group g, step s -> k = 4g + s)
+// identically for both operands, which a sum does not see.
+// Algorithmic bytes: rows*n*(in + out element size) (+ 8*rows*n for the intermediate); FLOPs: 2*rows*n*(p+q).
 #include "common.h"
 
 namespace {
 
-constexpr int OB = 4;   // outputs register-blocked per thread
-
-struct OrthoArgs {
-    const float *F0;        // blocked: [p][p][q]; kron: [p][p]
-    const float *F1;        // blocked: [q][q][p]; kron: [q][q]
-    const int32_t *load_idx;    // flat z index that input element k lands on
-    const int32_t *store_idx;   // flat z index that output element k is taken from
-    const float *colscale;      // [n] or null
-    int p, q, blocked, transpose;
-    int64_t ldx, ldo, rows;
+struct StageArgs {
+    const void *in;
+    void *out;
+    int64_t ldi, ldo, rows;
+    const int32_t *gidx;      // in position pos reads in[r][gidx[pos]] (null: pos)
+    const int32_t *sidx;      // out position pos is written to out[r][sidx[pos]] (null: pos)
+    const float *colscale;    // multiplies in[r][k] on load, indexed by the SOURCE column k (null: none)
+    const float4 *frag;       // [C][NT][KS][64] float4, C = Po (blocked) or 1 (Kronecker)
+    int blocked;
+    int Pm, Po, q;            // mixed / other index range, q of the [p][q] view
+    int mixa;                 // 1: mix a (pos = i*q + c), 0: mix b (pos = c*q + i)
+    int QB, NT, RS;           // c values per workgroup (power of 2 <= 16), ceil(Pm/16), LDS row stride (floats)
 };
 
-template <int RT>
-__device__ __forceinline__ void mix_a(const OrthoArgs &A, const float *__restrict__ src, float *__restrict__ dst,
-                                      int rowstride, int QS, int PS, bool dst_is_B)
-{
-    // out[a][b] = sum_a' F(a,a',b) in[a'][b];  src is image A.  forward: F = B0[b][a][a'], transpose: B0[b][a'][a]
-    const int p = A.p, q = A.q;
-    const int fs = A.blocked ? q : 1, fb = A.blocked ? 1 : 0;
-    const int nblk = (p + OB - 1) / OB;
-    for (int task = threadIdx.x; task < q * nblk; task += blockDim.x) {
-        const int b = task % q, a0 = (task / q) * OB;
-        float acc[OB][RT];
-#pragma unroll
-        for (int k = 0; k < OB; ++k)
-#pragma unroll
-            for (int r = 0; r < RT; ++r) acc[k][r] = 0.f;
-        for (int ap = 0; ap < p; ++ap) {
-            float f[OB];
-#pragma unroll
-            for (int k = 0; k < OB; ++k) {
-                const int a = a0 + k < p ? a0 + k : p - 1;
-                const int64_t fi = A.transpose ? ((int64_t)ap * p + a) : ((int64_t)a * p + ap);
-                f[k] = A.F0[fi * fs + (int64_t)b * fb];
-            }
-#pragma unroll
-            for (int r = 0; r < RT; ++r) {
-                const float z = src[r * rowstride + ap * QS + b];
-#pragma unroll
-                for (int k = 0; k < OB; ++k) acc[k][r] = fmaf(f[k], z, acc[k][r]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < OB; ++k) {
-            const int a = a0 + k;
-            if (a < p) {
-#pragma unroll
-                for (int r = 0; r < RT; ++r) dst[r * rowstride + (dst_is_B ? b * PS + a : a * QS + b)] = acc[k][r];
-            }
-        }
-    }
-}
-
-template <int RT>
-__device__ __forceinline__ void mix_b(const OrthoArgs &A, const float *__restrict__ src, float *__restrict__ dst,
-                                      int rowstride, int QS, int PS, bool dst_is_B)
-{
-    // out[a][b] = sum_b' F(b,b',a) in[a][b'];  src is image B.  forward: F = B1[a][b][b'], transpose: B1[a][b'][b]
-    const int p = A.p, q = A.q;
-    const int fs = A.blocked ? p : 1, fb = A.blocked ? 1 : 0;
-    const int nblk = (q + OB - 1) / OB;
-    for (int task = threadIdx.x; task < p * nblk; task += blockDim.x) {
-        const int a = task % p, b0 = (task / p) * OB;
-        float acc[OB][RT];
-#pragma unroll
-        for (int k = 0; k < OB; ++k)
-#pragma unroll
-            for (int r = 0; r < RT; ++r) acc[k][r] = 0.f;
-        for (int bp = 0; bp < q; ++bp) {
-            float f[OB];
-#pragma unroll
-            for (int k = 0; k < OB; ++k) {
-                const int b = b0 + k < q ? b0 + k : q - 1;
-                const int64_t fi = A.transpose ? ((int64_t)bp * q + b) : ((int64_t)b * q + bp);
-                f[k] = A.F1[fi * fs + (int64_t)a * fb];
-            }
-#pragma unroll
-            for (int r = 0; r < RT; ++r) {
-                const float z = src[r * rowstride + bp * PS + a];
-#pragma unroll
-                for (int k = 0; k < OB; ++k) acc[k][r] = fmaf(f[k], z, acc[k][r]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < OB; ++k) {
-            const int b = b0 + k;
-            if (b < q) {
-#pragma unroll
-                for (int r = 0; r < RT; ++r) dst[r * rowstride + (dst_is_B ? b * PS + a : a * QS + b)] = acc[k][r];
-            }
-        }
-    }
-}
-
-template <class TI, class TO, int RT>
-__global__ __launch_bounds__(256) void ortho_rows_kernel(OrthoArgs A, const void *__restrict__ x, void *__restrict__ out)
+template <class TI, class TO>
+__global__ __launch_bounds__(256) void ortho_stage_kernel(StageArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int p = A.p, q = A.q, n = p * q;
-    const int QS = q | 1, PS = p | 1;
-    const int imgA = p * QS, imgB = q * PS;
-    const int rowstride = imgA > imgB ? imgA : imgB;
-    float *buf0 = smem, *buf1 = smem + RT * rowstride;
-    const int64_t row0 = (int64_t)blockIdx.x * RT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int QB = A.QB, Pm = A.Pm, RS = A.RS, NT = A.NT, q = A.q;
+    float *T = smem;                        // [QB][16][RS] input tile
+    float *O = smem + QB * 16 * RS;         // [QB][16][RS] output tile
+    const int c0 = blockIdx.x * QB;
+    const int64_t r0 = (int64_t)blockIdx.y * 16;
 
-    // load: forward lands in image A (mix over a comes first), transpose in image B (mix over b first)
-    for (int idx = threadIdx.x; idx < n * RT; idx += blockDim.x) {
-        const int r = idx / n, k = idx - r * n;
-        const int64_t row = row0 + r;
-        float v = 0.f;
-        if (row < A.rows) {
-            v = DT<TI>::load(x, row * A.ldx + k);
-            if (A.colscale) v *= A.colscale[k];
+    // ---- load ------------------------------------------------------------------------------------------------------
+    // zero the K padding [Pm, 16*NT) of every (c, row)
+    const int kpad = 16 * NT - Pm;
+    if (kpad > 0)
+        for (int idx = threadIdx.x; idx < QB * 16 * kpad; idx += 256) {
+            const int line = idx / kpad, k = Pm + idx - line * kpad;
+            T[line * RS + k] = 0.f;
         }
-        const int i = A.load_idx[k];
-        const int a = i / q, b = i - a * q;
-        buf0[r * rowstride + (A.transpose ? b * PS + a : a * QS + b)] = v;
-    }
-    __syncthreads();
-    if (!A.transpose) {
-        mix_a<RT>(A, buf0, buf1, rowstride, QS, PS, true);     // A -> B
-        __syncthreads();
-        mix_b<RT>(A, buf1, buf0, rowstride, QS, PS, false);    // B -> A
+    // Both loops are written for memory-level parallelism: UNR independent (index -> data) chains per thread are
+    // issued before any is consumed (the scalar one-element-per-iteration form was latency-bound: 20x off).
+    constexpr int UNR = 8;
+    if (A.mixa) {
+        // runs (r, i) of QB consecutive c: pos = i*q + c0 + cl
+        const int rpw = 64 / QB;                               // runs per wave pass
+        const int cl = lane & (QB - 1), rl = lane / QB;
+        const int c = c0 + cl;
+        const int nrun = 16 * Pm;
+        for (int run0 = wave * rpw; run0 < nrun; run0 += 4 * rpw * UNR) {
+            int src[UNR];
+            float v[UNR];
+            bool ok[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int run = run0 + u * 4 * rpw + rl;
+                const int r = run & 15, i = run >> 4;
+                ok[u] = (run < nrun) && (r0 + r < A.rows) && (c < A.Po);
+                const int pos = i * q + c;
+                src[u] = ok[u] ? (A.gidx ? A.gidx[pos] : pos) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int run = run0 + u * 4 * rpw + rl;
+                const int r = run & 15;
+                v[u] = ok[u] ? DT<TI>::load(A.in, (r0 + r) * A.ldi + src[u]) : 0.f;
+                if (ok[u] && A.colscale) v[u] *= A.colscale[src[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int run = run0 + u * 4 * rpw + rl;
+                const int r = run & 15, i = run >> 4;
+                if (run < nrun) T[(cl * 16 + r) * RS + i] = v[u];
+            }
+        }
     } else {
-        mix_b<RT>(A, buf0, buf1, rowstride, QS, PS, false);    // B -> A
-        __syncthreads();
-        mix_a<RT>(A, buf1, buf0, rowstride, QS, PS, true);     // A -> B
+        // lines (cl, r) of Pm consecutive i: pos = (c0 + cl)*q + i; elements e = (line, ii) with i = lane + 64*ii
+        const int ipl = (Pm + 63) / 64;                        // lane passes per line
+        const int nel = 16 * QB * ipl;                         // (line, ii) pairs, split over the 4 waves
+        for (int e0 = wave; e0 < nel; e0 += 4 * UNR) {
+            int src[UNR];
+            float v[UNR];
+            bool ok[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int e = e0 + 4 * u;
+                const int line = e / ipl, i = lane + 64 * (e - line * ipl);
+                const int r = line & 15, c = c0 + (line >> 4);
+                ok[u] = (e < nel) && (i < Pm) && (r0 + r < A.rows) && (c < A.Po);
+                const int pos = c * q + i;
+                src[u] = ok[u] ? (A.gidx ? A.gidx[pos] : pos) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int e = e0 + 4 * u;
+                const int line = e / ipl;
+                const int r = line & 15;
+                v[u] = ok[u] ? DT<TI>::load(A.in, (r0 + r) * A.ldi + src[u]) : 0.f;
+                if (ok[u] && A.colscale) v[u] *= A.colscale[src[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int e = e0 + 4 * u;
+                const int line = e / ipl, i = lane + 64 * (e - line * ipl);
+                if (e < nel && i < Pm) T[line * RS + i] = v[u];
+            }
+        }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < n * RT; idx += blockDim.x) {
-        const int r = idx / n, k = idx - r * n;
-        const int64_t row = row0 + r;
-        if (row >= A.rows) continue;
-        const int i = A.store_idx[k];
-        const int a = i / q, b = i - a * q;
-        const float v = buf0[r * rowstride + (A.transpose ? b * PS + a : a * QS + b)];
-        DT<TO>::store(out, row * A.ldo + k, v);
+
+    // ---- mix: items (cl, nt) round-robin over the 4 waves; flattened (item, S) loop with a one-step prefetch ---------
+    {
+        const int row = lane & 15, g = lane >> 4;
+        const int nitems = QB * NT;
+        const int64_t cstride = A.blocked ? (int64_t)NT * NT * 64 : 0;
+        int item = wave;
+        if (item < nitems) {
+            int cl = item / NT, nt = item - cl * NT, S = 0;
+            const float4 *fp = A.frag + (c0 + cl < A.Po ? (c0 + cl) : 0) * cstride + ((int64_t)nt * NT) * 64 + lane;
+            const float *tp = T + (cl * 16 + row) * RS + 4 * g;
+            float4 b_nxt = fp[0];
+            float4 a_nxt = *reinterpret_cast<const float4 *>(tp);
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            while (true) {
+                const float4 a = a_nxt, b = b_nxt;
+                // advance the (item, S) cursor and prefetch its operands
+                int cl2 = cl, nt2 = nt, S2 = S + 1, item2 = item;
+                if (S2 == NT) {
+                    S2 = 0;
+                    item2 = item + 4;
+                    if (item2 < nitems) { cl2 = item2 / NT; nt2 = item2 - cl2 * NT; }
+                }
+                const bool more = item2 < nitems;
+                if (more) {
+                    const float4 *fp2 = A.frag + (c0 + cl2 < A.Po ? (c0 + cl2) : 0) * cstride + ((int64_t)nt2 * NT + S2) * 64 + lane;
+                    b_nxt = fp2[0];
+                    a_nxt = *reinterpret_cast<const float4 *>(T + (cl2 * 16 + row) * RS + 16 * S2 + 4 * g);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+                if (S2 == 0) {
+                    // item finished: D[row = 4g + reg][col = lane & 15] -> O[cl][4g + reg][16 nt + (lane & 15)]
+                    float *op = O + (cl * 16 + 4 * g) * RS + 16 * nt + row;
+                    op[0] = acc[0]; op[RS] = acc[1]; op[2 * RS] = acc[2]; op[3 * RS] = acc[3];
+                    acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+                if (!more) break;
+                cl = cl2; nt = nt2; S = S2; item = item2;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- store (same UNR-way batching: LDS reads + scatter-index loads first, then the stores) ------------------------
+    if (A.mixa) {
+        const int rpw = 64 / QB;
+        const int cl = lane & (QB - 1), rl = lane / QB;
+        const int c = c0 + cl;
+        const int nrun = 16 * Pm;
+        for (int run0 = wave * rpw; run0 < nrun; run0 += 4 * rpw * UNR) {
+            int dst[UNR];
+            float v[UNR];
+            bool ok[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int run = run0 + u * 4 * rpw + rl;
+                const int r = run & 15, i = run >> 4;
+                ok[u] = (run < nrun) && (r0 + r < A.rows) && (c < A.Po);
+                const int pos = i * q + c;
+                dst[u] = ok[u] ? (A.sidx ? A.sidx[pos] : pos) : 0;
+                v[u] = ok[u] ? O[(cl * 16 + r) * RS + i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int run = run0 + u * 4 * rpw + rl;
+                const int r = run & 15;
+                if (ok[u]) DT<TO>::store(A.out, (r0 + r) * A.ldo + dst[u], v[u]);
+            }
+        }
+    } else {
+        const int ipl = (Pm + 63) / 64;
+        const int nel = 16 * QB * ipl;
+        for (int e0 = wave; e0 < nel; e0 += 4 * UNR) {
+            int dst[UNR];
+            float v[UNR];
+            bool ok[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int e = e0 + 4 * u;
+                const int line = e / ipl, i = lane + 64 * (e - line * ipl);
+                const int r = line & 15, c = c0 + (line >> 4);
+                ok[u] = (e < nel) && (i < Pm) && (r0 + r < A.rows) && (c < A.Po);
+                const int pos = c * q + i;
+                dst[u] = ok[u] ? (A.sidx ? A.sidx[pos] : pos) : 0;
+                v[u] = ok[u] ? O[line * RS + i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int e = e0 + 4 * u;
+                const int r = (e / ipl) & 15;
+                if (ok[u]) DT<TO>::store(A.out, (r0 + r) * A.ldo + dst[u], v[u]);
+            }
+        }
     }
 }
 
 template <class TI, class TO>
-int launch_rows(const OrthoArgs &A, const void *x, void *out, hipStream_t s)
+int launch_stage(StageArgs A, hipStream_t s)
 {
-    const int p = A.p, q = A.q;
-    const int64_t imgA = (int64_t)p * (q | 1), imgB = (int64_t)q * (p | 1);
-    const int64_t rowbytes = 2 * (imgA > imgB ? imgA : imgB) * 4;
-    const int64_t budget = 160 * 1024;
-    QA_REQUIRE(rowbytes <= budget, QUIPAMD_ERR_SHAPE,
-               "ortho_apply_rows: n=%d needs %lld B of LDS per row (> 160 KiB)", p * q, (long long)rowbytes);
-    int rt = 8;
-    while (rt > 1 && rt * rowbytes > budget) rt >>= 1;                       // rows that fit in 160 KiB of LDS
-    while (rt > 1 && (A.rows + rt - 1) / rt < 256) rt >>= 1;                  // but keep >= 256 workgroups if we can
-    const int64_t grid = (A.rows + rt - 1) / rt;
-    const size_t lds = (size_t)(rt * rowbytes);
-#define QA_ORTHO_LAUNCH(RT)                                                                                   \
-    do {                                                                                                      \
-        auto kern = ortho_rows_kernel<TI, TO, RT>;                                                            \
-        if (lds > 64 * 1024)                                                                                   \
-            if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-                return qa_fail(QUIPAMD_ERR_LAUNCH, "ortho: cannot raise dynamic LDS to %zu", lds);             \
-        kern<<<(unsigned)grid, 256, lds, s>>>(A, x, out);                                                      \
-    } while (0)
-    switch (rt) {
-    case 8: QA_ORTHO_LAUNCH(8); break;
-    case 4: QA_ORTHO_LAUNCH(4); break;
-    case 2: QA_ORTHO_LAUNCH(2); break;
-    default: QA_ORTHO_LAUNCH(1); break;
-    }
-#undef QA_ORTHO_LAUNCH
+    A.NT = (A.Pm + 15) / 16;
+    A.RS = 16 * A.NT + 4;                                   // 16-byte aligned rows, consecutive rows 4 slots apart
+    const int64_t per_c = 2ll * 16 * A.RS * 4;              // bytes of LDS per value of c (input + output tile)
+    QA_REQUIRE(per_c <= 160 * 1024, QUIPAMD_ERR_SHAPE, "ortho_apply_rows: factor size %d needs %lld B of LDS", A.Pm, (long long)per_c);
+    int qb = 16;
+    while (qb > 1 && qb * per_c > 72 * 1024) qb >>= 1;      // two workgroups per CU when possible
+    const int64_t rgroups = (A.rows + 15) / 16;
+    while (qb > 1 && rgroups * ((A.Po + qb - 1) / qb) < 512) qb >>= 1;   // cover the chip
+    while (qb > 1 && qb / 2 >= A.Po) qb >>= 1;
+    A.QB = qb;
+    const size_t lds = (size_t)(qb * per_c);
+    auto kern = ortho_stage_kernel<TI, TO>;
+    if (lds > 64 * 1024)
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "ortho: cannot raise dynamic LDS to %zu", lds);
+    QA_REQUIRE(rgroups <= 65535, QUIPAMD_ERR_SHAPE, "ortho_apply_rows: too many rows (%lld)", (long long)A.rows);
+    kern<<<dim3((unsigned)((A.Po + qb - 1) / qb), (unsigned)rgroups), 256, lds, s>>>(A);
     QA_LAUNCH_CHECK("quipamd_ortho_apply_rows");
     return QUIPAMD_OK;
 }
 
+template <class TI>
+int launch_first(const StageArgs &A, hipStream_t s) { return launch_stage<TI, F32>(A, s); }
+
 }   // namespace
 
-extern "C" int quipamd_ortho_apply_rows(const float *B0t, const float *B1t, int blocked, const int32_t *load_idx,
-                                        const int32_t *store_idx, int p, int q, int transpose, const float *colscale,
+extern "C" int quipamd_ortho_apply_rows(const float *frag_first, const float *frag_second, int blocked, const int32_t *gather_idx,
+                                        const int32_t *scatter_idx, int p, int q, int b_first, const float *colscale,
                                         const void *x, int x_dtype, int64_t ldx, void *out, int out_dtype, int64_t ldo,
-                                        int64_t rows, void *stream)
+                                        int64_t rows, float *workspace, void *stream)
 {
-    QA_REQUIRE(B0t && B1t && load_idx && store_idx && x && out, QUIPAMD_ERR_ARG, "ortho_apply_rows: null pointer");
+    QA_REQUIRE(frag_first && frag_second && x && out && workspace, QUIPAMD_ERR_ARG, "ortho_apply_rows: null pointer");
     QA_REQUIRE(p >= 1 && q >= 1, QUIPAMD_ERR_SHAPE, "ortho_apply_rows: bad factors p=%d q=%d", p, q);
-    QA_REQUIRE(ldx >= (int64_t)p * q && ldo >= (int64_t)p * q, QUIPAMD_ERR_SHAPE, "ortho_apply_rows: leading dimension < n");
+    const int64_t n = (int64_t)p * q;
+    QA_REQUIRE(ldx >= n && ldo >= n, QUIPAMD_ERR_SHAPE, "ortho_apply_rows: leading dimension < n");
+    QA_REQUIRE(n < ((int64_t)1 << 31), QUIPAMD_ERR_SHAPE, "ortho_apply_rows: n too large");
     if (rows == 0) return QUIPAMD_OK;
-    OrthoArgs A;
-    A.F0 = B0t; A.F1 = B1t; A.load_idx = load_idx; A.store_idx = store_idx; A.colscale = colscale;
-    A.p = p; A.q = q; A.blocked = blocked; A.transpose = transpose; A.ldx = ldx; A.ldo = ldo; A.rows = rows;
     hipStream_t s = (hipStream_t)stream;
-    if (x_dtype == QUIPAMD_F32 && out_dtype == QUIPAMD_F32) return launch_rows<F32, F32>(A, x, out, s);
-    if (x_dtype == QUIPAMD_BF16 && out_dtype == QUIPAMD_BF16) return launch_rows<BF16, BF16>(A, x, out, s);
-    if (x_dtype == QUIPAMD_F16 && out_dtype == QUIPAMD_F16) return launch_rows<F16, F16>(A, x, out, s);
-    if (x_dtype == QUIPAMD_F16 && out_dtype == QUIPAMD_BF16) return launch_rows<F16, BF16>(A, x, out, s);
-    if (x_dtype == QUIPAMD_BF16 && out_dtype == QUIPAMD_F16) return launch_rows<BF16, F16>(A, x, out, s);
-    if (x_dtype == QUIPAMD_F32 && out_dtype == QUIPAMD_BF16) return launch_rows<F32, BF16>(A, x, out, s);
-    if (x_dtype == QUIPAMD_BF16 && out_dtype == QUIPAMD_F32) return launch_rows<BF16, F32>(A, x, out, s);
-    if (x_dtype == QUIPAMD_F32 && out_dtype == QUIPAMD_F16) return launch_rows<F32, F16>(A, x, out, s);
-    if (x_dtype == QUIPAMD_F16 && out_dtype == QUIPAMD_F32) return launch_rows<F16, F32>(A, x, out, s);
-    return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "ortho_apply_rows: dtype pair %d -> %d", x_dtype, out_dtype);
+    // stage 1: x -> workspace (fp32, ld = n), gather + colscale on load
+    StageArgs A1;
+    A1.in = x; A1.out = workspace; A1.ldi = ldx; A1.ldo = n; A1.rows = rows;
+    A1.gidx = gather_idx; A1.sidx = nullptr; A1.colscale = colscale;
+    A1.frag = (const float4 *)frag_first; A1.blocked = blocked; A1.q = q;
+    A1.mixa = b_first ? 0 : 1;
+    A1.Pm = b_first ? q : p; A1.Po = b_first ? p : q;
+    A1.QB = A1.NT = A1.RS = 0;
+    int rc;
+    switch (x_dtype) {
+    case QUIPAMD_F32: rc = launch_stage<F32, F32>(A1, s); break;
+    case QUIPAMD_F16: rc = launch_stage<F16, F32>(A1, s); break;
+    case QUIPAMD_BF16: rc = launch_stage<BF16, F32>(A1, s); break;
+    default: return qa_fail(QUIPAMD_ERR_ARG, "ortho_apply_rows: bad x dtype %d", x_dtype);
+    }
+    if (rc) return rc;
+    // stage 2: workspace -> out, scatter on store
+    StageArgs A2 = A1;
+    A2.in = workspace; A2.out = out; A2.ldi = n; A2.ldo = ldo;
+    A2.gidx = nullptr; A2.sidx = scatter_idx; A2.colscale = nullptr;
+    A2.frag = (const float4 *)frag_second;
+    A2.mixa = b_first ? 1 : 0;
+    A2.Pm = b_first ? p : q; A2.Po = b_first ? q : p;
+    switch (out_dtype) {
+    case QUIPAMD_F32: return launch_stage<F32, F32>(A2, s);
+    case QUIPAMD_F16: return launch_stage<F32, F16>(A2, s);
+    case QUIPAMD_BF16: return launch_stage<F32, BF16>(A2, s);
+    default: return qa_fail(QUIPAMD_ERR_ARG, "ortho_apply_rows: bad out dtype %d", out_dtype);
+    }
 }

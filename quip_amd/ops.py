@@ -136,6 +136,17 @@ def dequant_gemm(x, qweight, bits, qfn, scale, zero, bias, out=None, out_dtype=t
 
 
 # ------------------------------------------------------------------------------------------------- K3
+def _mfma_b_frags(M):
+    """M [C, P, P] (out index i, in index k) -> float [C, NT, NT, 64, 4] in v_mfma_f32_16x16x4_f32 B-fragment order
+    (include/quip_amd.h): element [c][nt][S][lane][s] = M[c][16 nt + (lane & 15)][16 S + 4 (lane >> 4) + s]."""
+    C, P, _ = M.shape
+    NT = (P + 15) // 16
+    Mp = torch.zeros((C, 16 * NT, 16 * NT), dtype=torch.float32, device=M.device)
+    Mp[:, :P, :P] = M
+    F = Mp.view(C, NT, 16, NT, 4, 4)               # [c, nt, j, S, g, s]
+    return F.permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)   # [c, nt, S, g, j, s] : lane = 16 g + j
+
+
 class OrthoOp:
     """Device-resident structured orthogonal operator built from the reference's (B, p_in, p_out) tuple
     (method.py:34-43).  apply_rows(x) computes Q x_r for every row x_r; transpose=True applies Q^T."""
@@ -143,33 +154,43 @@ class OrthoOp:
     def __init__(self, Bpp, device):
         (B, p_in, p_out) = Bpp
         B0, B1 = B[0].to(torch.float32), B[1].to(torch.float32)
-        B0 = B0.reshape(-1, B0.shape[-1], B0.shape[-1])
-        B1 = B1.reshape(-1, B1.shape[-1], B1.shape[-1])
+        B0 = B0.reshape(-1, B0.shape[-1], B0.shape[-1]).to(device)
+        B1 = B1.reshape(-1, B1.shape[-1], B1.shape[-1]).to(device)
         self.p, self.q = B0.shape[-1], B1.shape[-1]
         self.n = self.p * self.q
         self.blocked = int(B0.shape[0] > 1 or B1.shape[0] > 1)
         if self.blocked:
             assert B0.shape[0] == self.q and B1.shape[0] == self.p
-            self.F0 = B0.permute(1, 2, 0).contiguous().to(device)      # [p,p,q]: B0t[a][a'][b] = B0[b][a][a']
-            self.F1 = B1.permute(1, 2, 0).contiguous().to(device)      # [q,q,p]
-        else:
-            self.F0 = B0[0].contiguous().to(device)
-            self.F1 = B1[0].contiguous().to(device)
+        self._B0, self._B1 = B0, B1
+        self._frags = {}
         p_in = torch.as_tensor(p_in).to(torch.int64).cpu()
         p_out = torch.as_tensor(p_out).to(torch.int64).cpu()
-        self.inv_pin = torch.argsort(p_in).to(torch.int32).to(device)
-        self.pout = p_out.to(torch.int32).to(device)
+        ident = torch.arange(self.n)
+        self.pin = None if torch.equal(p_in, ident) else p_in.to(torch.int32).to(device)
+        self.inv_pout = None if torch.equal(p_out, ident) else torch.argsort(p_out).to(torch.int32).to(device)
+        self.device = device
+
+    def _stage_frags(self, transpose):
+        """(first, second) stage matrices in B-fragment order; built once per orientation, kept on the device."""
+        if transpose not in self._frags:
+            if transpose:
+                self._frags[True] = (_mfma_b_frags(self._B1.transpose(1, 2)), _mfma_b_frags(self._B0.transpose(1, 2)))
+            else:
+                self._frags[False] = (_mfma_b_frags(self._B0), _mfma_b_frags(self._B1))
+        return self._frags[transpose]
 
     def apply_rows(self, x, transpose=False, colscale=None, out_dtype=None):
         _need_gpu(x)
         assert x.dim() == 2 and x.shape[1] == self.n and x.stride(1) == 1
         rows = x.shape[0]
         out = torch.empty((rows, self.n), dtype=out_dtype or x.dtype, device=x.device)
-        load_idx, store_idx = (self.pout, self.inv_pin) if transpose else (self.inv_pin, self.pout)
+        ws = torch.empty((16 * ((rows + 15) // 16), self.n), dtype=torch.float32, device=x.device)
+        f1, f2 = self._stage_frags(bool(transpose))
+        gather, scatter = (self.inv_pout, self.pin) if transpose else (self.pin, self.inv_pout)
         cs = _f32vec(colscale, x.device)
-        _lib.call("quipamd_ortho_apply_rows", _p(self.F0), _p(self.F1), self.blocked, _p(load_idx), _p(store_idx),
+        _lib.call("quipamd_ortho_apply_rows", _p(f1), _p(f2), self.blocked, _p(gather), _p(scatter),
                   self.p, self.q, int(bool(transpose)), _p(cs), _p(x), _dtype(x), x.stride(0), _p(out), _dtype(out),
-                  out.stride(0), rows, _stream())
+                  out.stride(0), rows, _p(ws), _stream())
         return out
 
     def apply_cols(self, x, transpose=False):

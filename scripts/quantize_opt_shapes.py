@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Whole-model LDLQ quantisation time at OPT-1.3B Linear shapes (BASELINE.json config "B"), synthetic W / H, one GPU:
+for each of the 24 x {4 x 2048x2048, 8192x2048, 2048x8192} Linears run the reference call sequence
+post_batch -> preproc(gptqH, rescale, proj) -> Balance.fasterquant (LDLQ w2 qfn b) -> free, all on the MI355X.
+Prints per-shape and total wall time next to the reference's CPU figures recorded in BASELINE.md section 2.
+--blocks N limits the run to N transformer blocks (per-block time is constant; total is extrapolated)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quip_amd import bal, quant  # noqa: E402
+
+CPU_REF_S = {"2048x2048": (1.5, 1.0), "8192x2048": (10.4, 4.5), "2048x8192": (52.1, 29.3)}   # (round_ldl, lazy) BASELINE.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--blocks", type=int, default=2)
+    ap.add_argument("--bits", type=int, default=2)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    shapes = [(2048, 2048)] * 4 + [(8192, 2048), (2048, 8192)]
+    Hs = {}
+    for d in (2048, 8192):
+        g = torch.Generator().manual_seed(d)
+        X = torch.randn(d + 256, d, generator=g).to(dev)
+        Hs[d] = (X.T @ X / (d + 256)).double()
+    np.random.seed(0)
+    torch.manual_seed(0)
+    per_shape = {}
+    t_all0 = time.perf_counter()
+    for blk in range(args.blocks):
+        for (m, d) in shapes:
+            layer = torch.nn.Linear(d, m, bias=False).to(dev).half()
+            layer.weight.data = (0.02 * torch.randn(m, d)).to(dev).half()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            b = bal.Balance(layer)
+            b.configure('ldlq', args.bits, 0, False)
+            b.quantizer = quant.Quantizer()
+            b.quantizer.configure(args.bits, perchannel=True, sym=False, qfn='b', mse=False)
+            b.H = Hs[d].clone()
+            b.nsamples = 1
+            b.post_batch()
+            b.preproc(preproc_gptqH=True, percdamp=0.01, preproc_rescale=True, preproc_proj=True, preproc_proj_extra=0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            b.fasterquant(lazy_batch=False)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            b.free()
+            k = f"{m}x{d}"
+            e = per_shape.setdefault(k, {"n": 0, "preproc_s": 0.0, "fasterquant_s": 0.0})
+            if blk > 0 or args.blocks == 1:                  # first block pays one-off allocator / solver warm-up
+                e["n"] += 1
+                e["preproc_s"] += t1 - t0
+                e["fasterquant_s"] += t2 - t1
+    wall = time.perf_counter() - t_all0
+    out = {"blocks_run": args.blocks, "wall_s": wall, "per_layer": {}}
+    tot = tot_cpu = tot_cpu_lazy = 0.0
+    counts = {"2048x2048": 4, "8192x2048": 1, "2048x8192": 1}
+    for k, e in per_shape.items():
+        n = max(e["n"], 1)
+        p, f = e["preproc_s"] / n, e["fasterquant_s"] / n
+        out["per_layer"][k] = {"preproc_s": round(p, 4), "fasterquant_s": round(f, 4), "cpu_ref_fasterquant_s": CPU_REF_S[k][0],
+                               "cpu_ref_lazy_s": CPU_REF_S[k][1], "speedup_fasterquant": round(CPU_REF_S[k][0] / f, 1)}
+        tot += 24 * counts[k] * (p + f)
+        tot_cpu += 24 * counts[k] * CPU_REF_S[k][0]
+        tot_cpu_lazy += 24 * counts[k] * CPU_REF_S[k][1]
+    out["opt1p3b_total_s_extrapolated_24_blocks"] = round(tot, 2)
+    out["cpu_reference_ldlq_only_s"] = {"round_ldl": tot_cpu, "lazy_batch": tot_cpu_lazy, "source": "BASELINE.md section 2, 8 cores"}
+    out["speedup_vs_cpu_round_ldl_incl_our_preproc"] = round(tot_cpu / tot, 1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
