@@ -129,6 +129,18 @@ int quipamd_ortho_apply_rows(const float *frag_first, const float *frag_second, 
                              const void *x, int x_dtype, int64_t ldx, void *out, int out_dtype, int64_t ldo,
                              int64_t rows, float *workspace, void *stream);
 
+/* quipamd_ortho_apply_small: the same operator for a FEW rows (activation side of the packed layer, batch 1..64) with
+ * one factor per stage (blocked = 0, the Kronecker form) in ONE launch: a workgroup keeps the row and both factor
+ * matrices in LDS.  M0: float [p][p] (out a, in a'), M1: float [q][q] -- pass B0, B1 for Q and B0^T, B1^T with
+ * b_first = 1 for Q^T.  load_idx: int32 [n] or NULL, input element k lands at z position load_idx[k]
+ * (Q: argsort(perm_in); Q^T: perm_out); store_idx: int32 [n] or NULL, output element k is z[store_idx[k]]
+ * (Q: perm_out; Q^T: argsort(perm_in)).  colscale / bias: float [n] or NULL (input scale, output offset).
+ * Requires p, q multiples of 16 and (p*p + q*q + 2*p*(q+4))*4 bytes <= 160 KiB; otherwise use quipamd_ortho_apply_rows. */
+int quipamd_ortho_apply_small(const float *M0, const float *M1, const int32_t *load_idx, const int32_t *store_idx,
+                              int p, int q, int b_first, const float *colscale, const float *bias,
+                              const void *x, int x_dtype, int64_t ldx, void *out, int out_dtype, int64_t ldo,
+                              int64_t rows, void *stream);
+
 /* ---- K4: LDLQ rounding -------------------------------------------------------------------------
  * Replaces round_ldl / round_ldl_block (vector_balance.py:155-199, 218-257; n_greedy_passes = 0):
  *   for i = d-1 .. 0:  q_i = clamp(floor(w_i + sum_{j>i} (w_j - q_j) L[j,i] + eta_i), 0, 2^bits - 1)

@@ -31,6 +31,8 @@ SIGNATURES = {
     "quipamd_tune_dequant_gemm": [c_int, c_int, c_int, c_int],
     "quipamd_ortho_apply_rows": [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_i64,
                                  c_vp, c_int, c_i64, c_i64, c_vp, c_vp],
+    "quipamd_ortho_apply_small": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_int,
+                                  c_i64, c_i64, c_vp],
     "quipamd_ldlq_round": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp],
     "quipamd_unit_lower_t": [c_vp, c_vp, c_i64, c_vp],
 }

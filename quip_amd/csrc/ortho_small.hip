@@ -1,0 +1,160 @@
+// ortho_small.hip -- K3, activation side: the Kronecker (noblock) structured orthogonal operator applied to a FEW rows
+// (the x-side V (x (/) s) and the y-side U^T y of the packed layer's forward; batch 1..64) in ONE launch.
+//
+// Same operator as ortho.hip (method.py:46-67 with the one-factor-per-stage generator method.py:38-39):
+//     z = scatter(x * colscale);  two mix stages;  out = gather(z) (+ bias)
+// but here a whole row (n = p*q floats) and both factor matrices (p*p + q*q floats) fit in one workgroup's LDS, so the
+// two stages need no intermediate in memory and no second launch: one workgroup (16 waves) per row.
+//   stage "a":  z1[a][b] = sum_a' M0[a][a'] z[a'][b]      D[a][b]: A = M0 tile (16 x 4, ds_read_b128), B = z (4 x 16 b's)
+//   stage "b":  z2[a][b] = sum_b' M1[b][b'] z1[a][b']     D[b][a]: A = M1 tile, B = z1^T (ds_read_b128 along b')
+// on v_mfma_f32_16x16x4_f32 (exact fp32).  With one factor matrix per stage the MFMA N dimension is the OTHER index
+// (16 b's or 16 a's of the same row), so a single row already fills the tile.  M0 / M1 are passed already transposed
+// for Q^T, and b_first selects the stage order.  Requires p, q multiples of 16 and (p*p + q*q + 2*n_padded)*4 B <= 160 KiB.
+// A decode step is launch-latency bound: this turns 2 launches + allocations per apply into 1.
+#include "common.h"
+
+namespace {
+
+struct SmallArgs {
+    const float *M0;          // [p][p]  out a, in a'
+    const float *M1;          // [q][q]  out b, in b'
+    const int32_t *ld_idx;    // input element k lands at z position ld_idx[k]      (null: k)
+    const int32_t *st_idx;    // output element k is taken from z position st_idx[k] (null: k)
+    const float *colscale;    // [n] or null, applied to the input
+    const float *bias;        // [n] or null, added to the output
+    const void *x;
+    void *out;
+    int64_t ldx, ldo;
+    int p, q, b_first;
+};
+
+// image layout: z[a][b] at a*QS + b, QS = q + 4 (16-byte aligned rows, spreads the ds_read_b128 of stage b over banks)
+template <class TI, class TO>
+__global__ __launch_bounds__(1024) void ortho_small_kernel(SmallArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int p = A.p, q = A.q, n = p * q, QS = q + 4;
+    float *F0 = smem;                    // [p][p]
+    float *F1 = F0 + p * p;              // [q][q]
+    float *Z0 = F1 + q * q;              // [p][QS]
+    float *Z1 = Z0 + p * QS;             // [p][QS]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t row = blockIdx.x;
+
+    // ---- load: factors (coalesced float4) and the row (coalesced, scattered into the image) ------------------------
+    for (int i = tid; i < p * p / 4; i += 1024) reinterpret_cast<float4 *>(F0)[i] = reinterpret_cast<const float4 *>(A.M0)[i];
+    for (int i = tid; i < q * q / 4; i += 1024) reinterpret_cast<float4 *>(F1)[i] = reinterpret_cast<const float4 *>(A.M1)[i];
+    for (int k = tid; k < n; k += 1024) {
+        float v = DT<TI>::load(A.x, row * A.ldx + k);
+        if (A.colscale) v *= A.colscale[k];
+        const int pos = A.ld_idx ? A.ld_idx[k] : k;
+        const int a = pos / q, b = pos - a * q;
+        Z0[a * QS + b] = v;
+    }
+    __syncthreads();
+
+    const int j = lane & 15, g = lane >> 4;
+    float *src = Z0, *dst = Z1;
+    for (int st = 0; st < 2; ++st) {
+        const bool mix_a = (st == 0) != (A.b_first != 0);
+        if (mix_a) {
+            // tiles (at, bt): D[a = 16at + 4g + reg][b = 16bt + j]
+            const int nat = p / 16, nbt = q / 16;
+            for (int tile = wave; tile < nat * nbt; tile += 16) {
+                const int at = tile / nbt, bt = tile - at * nbt;
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                const float *fa = F0 + (16 * at + j) * p + 4 * g;                // A[i = j][k = 16S + 4g + s]
+                const float *zb = src + (4 * g) * QS + 16 * bt + j;              // B[k][j] = z[a' = 16S + 4g + s][b]
+                for (int S = 0; S < p / 16; ++S) {
+                    const float4 a4 = *reinterpret_cast<const float4 *>(fa + 16 * S);
+                    const float *zs = zb + 16 * S * QS;
+                    const float b0 = zs[0], b1 = zs[QS], b2 = zs[2 * QS], b3 = zs[3 * QS];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b3, acc, 0, 0, 0);
+                }
+                float *o = dst + (16 * at + 4 * g) * QS + 16 * bt + j;
+                o[0] = acc[0]; o[QS] = acc[1]; o[2 * QS] = acc[2]; o[3 * QS] = acc[3];
+            }
+        } else {
+            // tiles (bt, at): D[b = 16bt + 4g + reg][a = 16at + j]
+            const int nat = p / 16, nbt = q / 16;
+            for (int tile = wave; tile < nat * nbt; tile += 16) {
+                const int bt = tile / nat, at = tile - bt * nat;
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                const float *fa = F1 + (16 * bt + j) * q + 4 * g;                // A[i = b][k = b']
+                const float *zb = src + (16 * at + j) * QS + 4 * g;              // B[k = b'][j = a] = z1[a][b'], 4 consecutive b'
+                for (int S = 0; S < q / 16; ++S) {
+                    const float4 a4 = *reinterpret_cast<const float4 *>(fa + 16 * S);
+                    const float4 b4 = *reinterpret_cast<const float4 *>(zb + 16 * S);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+                }
+                // rows of D are 4 consecutive b of one a: one 16-byte store
+                *reinterpret_cast<float4 *>(dst + (16 * at + j) * QS + 16 * bt + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            }
+        }
+        __syncthreads();
+        float *t = src; src = dst; dst = t;
+    }
+
+    // ---- store: gather from the image, bias, convert ------------------------------------------------------------------
+    for (int k = tid; k < n; k += 1024) {
+        const int pos = A.st_idx ? A.st_idx[k] : k;
+        const int a = pos / q, b = pos - a * q;
+        float v = src[a * QS + b];
+        if (A.bias) v += A.bias[k];
+        DT<TO>::store(A.out, row * A.ldo + k, v);
+    }
+}
+
+template <class TI, class TO>
+int launch_small(const SmallArgs &A, int64_t rows, hipStream_t s)
+{
+    const size_t lds = ((size_t)A.p * A.p + (size_t)A.q * A.q + 2 * (size_t)A.p * (A.q + 4)) * 4;
+    auto kern = ortho_small_kernel<TI, TO>;
+    if (lds > 64 * 1024)
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "ortho_apply_small: cannot raise dynamic LDS to %zu", lds);
+    kern<<<(unsigned)rows, 1024, lds, s>>>(A);
+    QA_LAUNCH_CHECK("quipamd_ortho_apply_small");
+    return QUIPAMD_OK;
+}
+
+}   // namespace
+
+extern "C" int quipamd_ortho_apply_small(const float *M0, const float *M1, const int32_t *load_idx, const int32_t *store_idx,
+                                         int p, int q, int b_first, const float *colscale, const float *bias,
+                                         const void *x, int x_dtype, int64_t ldx, void *out, int out_dtype, int64_t ldo,
+                                         int64_t rows, void *stream)
+{
+    QA_REQUIRE(M0 && M1 && x && out, QUIPAMD_ERR_ARG, "ortho_apply_small: null pointer");
+    QA_REQUIRE(p >= 16 && q >= 16 && p % 16 == 0 && q % 16 == 0, QUIPAMD_ERR_SHAPE,
+               "ortho_apply_small: p and q must be multiples of 16 (p=%d q=%d); use quipamd_ortho_apply_rows", p, q);
+    const size_t lds = ((size_t)p * p + (size_t)q * q + 2 * (size_t)p * (q + 4)) * 4;
+    QA_REQUIRE(lds <= 160 * 1024, QUIPAMD_ERR_SHAPE, "ortho_apply_small: factors + row need %zu B of LDS (> 160 KiB)", lds);
+    QA_REQUIRE(ldx >= (int64_t)p * q && ldo >= (int64_t)p * q, QUIPAMD_ERR_SHAPE, "ortho_apply_small: leading dimension < n");
+    QA_REQUIRE(rows <= 65535, QUIPAMD_ERR_SHAPE, "ortho_apply_small: too many rows");
+    if (rows == 0) return QUIPAMD_OK;
+    SmallArgs A;
+    A.M0 = M0; A.M1 = M1; A.ld_idx = load_idx; A.st_idx = store_idx; A.colscale = colscale; A.bias = bias;
+    A.x = x; A.out = out; A.ldx = ldx; A.ldo = ldo; A.p = p; A.q = q; A.b_first = b_first;
+    hipStream_t s = (hipStream_t)stream;
+#define QA_SMALL_CASE(XI, TI, XO, TO) if (x_dtype == XI && out_dtype == XO) return launch_small<TI, TO>(A, rows, s)
+    QA_SMALL_CASE(QUIPAMD_F32, F32, QUIPAMD_F32, F32);
+    QA_SMALL_CASE(QUIPAMD_F32, F32, QUIPAMD_F16, F16);
+    QA_SMALL_CASE(QUIPAMD_F32, F32, QUIPAMD_BF16, BF16);
+    QA_SMALL_CASE(QUIPAMD_F16, F16, QUIPAMD_BF16, BF16);
+    QA_SMALL_CASE(QUIPAMD_F16, F16, QUIPAMD_F16, F16);
+    QA_SMALL_CASE(QUIPAMD_F16, F16, QUIPAMD_F32, F32);
+    QA_SMALL_CASE(QUIPAMD_BF16, BF16, QUIPAMD_BF16, BF16);
+    QA_SMALL_CASE(QUIPAMD_BF16, BF16, QUIPAMD_F16, F16);
+    QA_SMALL_CASE(QUIPAMD_BF16, BF16, QUIPAMD_F32, F32);
+#undef QA_SMALL_CASE
+    return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "ortho_apply_small: dtype pair %d -> %d", x_dtype, out_dtype);
+}

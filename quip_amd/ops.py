@@ -166,9 +166,18 @@ class OrthoOp:
         p_in = torch.as_tensor(p_in).to(torch.int64).cpu()
         p_out = torch.as_tensor(p_out).to(torch.int64).cpu()
         ident = torch.arange(self.n)
-        self.pin = None if torch.equal(p_in, ident) else p_in.to(torch.int32).to(device)
-        self.inv_pout = None if torch.equal(p_out, ident) else torch.argsort(p_out).to(torch.int32).to(device)
+        i32 = lambda t: t.to(torch.int32).to(device)
+        self.pin = None if torch.equal(p_in, ident) else i32(p_in)
+        self.inv_pin = None if torch.equal(p_in, ident) else i32(torch.argsort(p_in))
+        self.pout = None if torch.equal(p_out, ident) else i32(p_out)
+        self.inv_pout = None if torch.equal(p_out, ident) else i32(torch.argsort(p_out))
         self.device = device
+        # single-launch small-batch path (quipamd_ortho_apply_small): Kronecker factors that fit one workgroup's LDS
+        lds = (self.p * self.p + self.q * self.q + 2 * self.p * (self.q + 4)) * 4
+        self.small_ok = (not self.blocked) and self.p % 16 == 0 and self.q % 16 == 0 and lds <= 160 * 1024
+        if self.small_ok:
+            self._M = {False: (B0[0].contiguous(), B1[0].contiguous()),
+                       True: (B0[0].t().contiguous(), B1[0].t().contiguous())}
 
     def _stage_frags(self, transpose):
         """(first, second) stage matrices in B-fragment order; built once per orientation, kept on the device."""
@@ -179,18 +188,30 @@ class OrthoOp:
                 self._frags[False] = (_mfma_b_frags(self._B0), _mfma_b_frags(self._B1))
         return self._frags[transpose]
 
-    def apply_rows(self, x, transpose=False, colscale=None, out_dtype=None):
+    SMALL_ROWS = 64
+
+    def apply_rows(self, x, transpose=False, colscale=None, out_dtype=None, bias=None):
+        """out[r] = Q x[r] (Q^T if transpose) with x[r] multiplied elementwise by colscale first and bias added last."""
         _need_gpu(x)
         assert x.dim() == 2 and x.shape[1] == self.n and x.stride(1) == 1
         rows = x.shape[0]
         out = torch.empty((rows, self.n), dtype=out_dtype or x.dtype, device=x.device)
+        cs = _f32vec(colscale, x.device)
+        if self.small_ok and rows <= self.SMALL_ROWS:
+            M0, M1 = self._M[bool(transpose)]
+            ld, st = (self.pout, self.inv_pin) if transpose else (self.inv_pin, self.pout)
+            _lib.call("quipamd_ortho_apply_small", _p(M0), _p(M1), _p(ld), _p(st), self.p, self.q, int(bool(transpose)),
+                      _p(cs), _p(_f32vec(bias, x.device)), _p(x), _dtype(x), x.stride(0), _p(out), _dtype(out), out.stride(0),
+                      rows, _stream())
+            return out
         ws = torch.empty((16 * ((rows + 15) // 16), self.n), dtype=torch.float32, device=x.device)
         f1, f2 = self._stage_frags(bool(transpose))
         gather, scatter = (self.inv_pout, self.pin) if transpose else (self.pin, self.inv_pout)
-        cs = _f32vec(colscale, x.device)
         _lib.call("quipamd_ortho_apply_rows", _p(f1), _p(f2), self.blocked, _p(gather), _p(scatter),
                   self.p, self.q, int(bool(transpose)), _p(cs), _p(x), _dtype(x), x.stride(0), _p(out), _dtype(out),
                   out.stride(0), rows, _p(ws), _stream())
+        if bias is not None:
+            out += _f32vec(bias, x.device).to(out.dtype)
         return out
 
     def apply_cols(self, x, transpose=False):

@@ -171,9 +171,7 @@ class QuantLinear(nn.Module):
         else:
             y = ops.dequant_gemm(xt, self.qweight, self.bits, self.qfn, self.scales, self.zeros, None,
                                  out_dtype=torch.float32, m=self.outfeatures)
-            y = self.U.apply_rows(y, transpose=True)
-            if self.bias is not None:
-                y = y + self.bias
+            y = self.U.apply_rows(y, transpose=True, out_dtype=x.dtype, bias=self.bias)   # fp32 in, caller's dtype out
         return y.to(x.dtype).reshape(*shape[:-1], self.outfeatures)
 
 

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""OPT-1.3B w2 decode throughput on one MI355X (BASELINE.json configs[2]; SURVEY.md 8(d) "B decode").
+
+A random-init decoder of the OPT-1.3B architecture (hidden 2048, ffn 8192, 24 blocks, 32 heads, vocab 50272, pre-LN,
+ReLU, learned positions offset 2, tied lm_head -- transformers' OPTConfig defaults for that size; no checkpoint is
+available offline) whose 144 decoder Linears (what opt.py quantises: find_layers over model.decoder.layers) are
+replaced by packed 2-bit QuantLinear layers in the incoherence-processed form
+        y = U^T ( What2 ( V (x (/) s) ) ) + bias                                        
+with codes from round-to-nearest on the qfn-b grid (fast; LDLQ gives different codes, same kernels and bytes), random
+Kronecker U / V (method.gen_rand_ortho_butterfly_noblock) and a random positive scaleWH.
+The single-token step (all 24 blocks + head + greedy argmax, static KV cache, position on the device) is captured in
+ONE hipGraph and replayed per token, the measurement the reference's dead benchmark() (opt.py:431-482) describes:
+median per-token latency, batch 1.  For context the same harness times the dense fp16 model (what the reference
+actually runs at inference).  A logits check against the dense model built from the SAME dequantised weights with
+the transforms folded in guards the packed path.
+
+usage: python scripts/decode_opt.py [--layers 24] [--tokens 128] [--prompt 128] [--eager]"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quip_amd import ops, method  # noqa: E402
+from quip_amd.quant import QuantLinear  # noqa: E402
+
+
+class Block(nn.Module):
+    def __init__(self, h, ffn, heads, dtype):
+        super().__init__()
+        self.h, self.heads, self.hd = h, heads, h // heads
+        self.ln1, self.ln2 = nn.LayerNorm(h, dtype=dtype), nn.LayerNorm(h, dtype=dtype)
+        mk = lambda i, o: nn.Linear(i, o, bias=True, dtype=dtype)
+        self.k_proj, self.v_proj, self.q_proj, self.out_proj = mk(h, h), mk(h, h), mk(h, h), mk(h, h)
+        self.fc1, self.fc2 = mk(h, ffn), mk(ffn, h)
+
+    def forward(self, x, kc, vc, pos, mask):
+        """x [bs, h]; kc / vc [bs, heads, maxlen, hd]; pos int64 [1] on the device; mask [maxlen] additive."""
+        bs = x.shape[0]
+        hn = self.ln1(x)
+        q = self.q_proj(hn).view(bs, self.heads, 1, self.hd)
+        k = self.k_proj(hn).view(bs, self.heads, 1, self.hd)
+        v = self.v_proj(hn).view(bs, self.heads, 1, self.hd)
+        kc.index_copy_(2, pos, k)
+        vc.index_copy_(2, pos, v)
+        att = torch.matmul(q, kc.transpose(2, 3)) * (1.0 / math.sqrt(self.hd)) + mask        # [bs, heads, 1, maxlen]
+        att = torch.softmax(att.float(), -1).to(x.dtype)
+        o = torch.matmul(att, vc).reshape(bs, self.h)
+        x = x + self.out_proj(o)
+        x = x + self.fc2(F.relu(self.fc1(self.ln2(x))))
+        return x
+
+
+class Decoder(nn.Module):
+    def __init__(self, layers=24, h=2048, ffn=8192, heads=32, vocab=50272, maxpos=2048, dtype=torch.float16):
+        super().__init__()
+        self.h, self.layers_n, self.heads = h, layers, heads
+        self.tok = nn.Embedding(vocab, h, dtype=dtype)
+        self.posemb = nn.Embedding(maxpos + 2, h, dtype=dtype)
+        self.blocks = nn.ModuleList([Block(h, ffn, heads, dtype) for _ in range(layers)])
+        self.lnf = nn.LayerNorm(h, dtype=dtype)
+
+    def step(self, ids, pos, caches, arange):
+        """one token for every batch row: ids int64 [bs], pos int64 [1]; returns logits [bs, vocab]."""
+        x = self.tok(ids) + self.posemb(pos + 2)
+        mask = torch.where(arange <= pos, 0.0, float("-inf")).to(x.dtype)
+        for blk, (kc, vc) in zip(self.blocks, caches):
+            x = blk(x, kc, vc, pos, mask)
+        return F.linear(self.lnf(x), self.tok.weight)
+
+
+def pack_model(model, bits, dev, seed=0):
+    """replace the 6 Linears of every block by packed QuantLinear; returns a dense twin state for the logits check."""
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    maxq = 2 ** bits - 1
+    dense_twin = {}
+    nbytes = 0
+    for li, blk in enumerate(model.blocks):
+        for name in ["k_proj", "v_proj", "q_proj", "out_proj", "fc1", "fc2"]:
+            lin = getattr(blk, name)
+            m, d = lin.weight.shape
+            W = lin.weight.data                                                  # plays the role of the PROJECTED weights
+            s = ops.qfnb_scale(W)
+            What, codes = ops.quantize(W, 'b', s, None, maxq, want_codes=True)
+            U = ops.OrthoOp(method.gen_rand_ortho_butterfly_noblock(m), dev)
+            V = ops.OrthoOp(method.gen_rand_ortho_butterfly_noblock(d), dev)
+            sWH = (0.5 + torch.rand(d)).to(dev)
+            ql = QuantLinear(d, m, bits=bits, qfn='b').to(dev)
+            ql.pack(codes, s, None, bias=lin.bias, scaleWH=sWH, U=U, V=V)
+            setattr(blk, name, ql)
+            nbytes += ql.qweight.numel() * 4
+            # dense equivalent: W_dense = U^T What V diag(1/s)   (rows of What V^T... computed with the same operators)
+            Wd = U.apply_cols(V.apply_rows(What.float(), transpose=True), transpose=True) / sWH[None, :]
+            dense_twin[(li, name)] = (Wd.to(W.dtype), lin.bias.data.clone())
+    return dense_twin, nbytes
+
+
+def time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager):
+    heads, hd = model.heads, model.h // model.heads
+    caches = [(torch.zeros(bs, heads, maxlen, hd, dtype=dtype, device=dev), torch.zeros(bs, heads, maxlen, hd, dtype=dtype, device=dev))
+              for _ in range(model.layers_n)]
+    arange = torch.arange(maxlen, device=dev)
+    ids = torch.randint(0, 50000, (bs,), device=dev)
+    pos = torch.zeros(1, dtype=torch.int64, device=dev)
+    logits_out = torch.zeros(bs, model.tok.weight.shape[0], dtype=dtype, device=dev)
+
+    def one():
+        lg = model.step(ids, pos, caches, arange)
+        logits_out.copy_(lg)
+        ids.copy_(lg.argmax(-1))
+        pos.add_(1)
+
+    with torch.no_grad():
+        one()                                            # warm-up (allocator, attribute calls)
+        pos.zero_()
+        graph = None
+        if not eager:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                one()
+                pos.zero_()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                one()
+            pos.zero_()
+        run = graph.replay if graph is not None else one
+        for _ in range(prompt):                          # "prompt": fills the cache token by token (untimed)
+            run()
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(tokens):
+            t0 = time.perf_counter()
+            run()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+    if not lat:
+        lat = [0.0]
+    return float(np.median(lat)), float(np.mean(lat)), logits_out.float().clone()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--bits", type=int, default=2)
+    ap.add_argument("--bs", type=int, default=1)
+    ap.add_argument("--prompt", type=int, default=128)
+    ap.add_argument("--tokens", type=int, default=128)
+    ap.add_argument("--eager", action="store_true")
+    args = ap.parse_args()
+    dev, dtype = torch.device("cuda:0"), torch.float16
+    maxlen = args.prompt + args.tokens + 8
+    torch.manual_seed(0)
+    model = Decoder(layers=args.layers, dtype=dtype).to(dev).eval()
+    for p_ in model.parameters():                         # OPT-like init scale keeps activations finite in fp16
+        if p_.dim() > 1:
+            p_.data.normal_(0, 0.02)
+    out = {"config": {"arch": "OPT-1.3B (hidden 2048, ffn 8192, heads 32, vocab 50272)", "layers": args.layers, "bits": args.bits,
+                      "bs": args.bs, "prompt": args.prompt, "tokens": args.tokens, "launch": "eager" if args.eager else "hipGraph",
+                      "weights": "random init, nearest-rounded qfn-b codes, Kronecker U/V, random scaleWH"}}
+    med, mean, _ = time_decode(model, args.bs, args.prompt, args.tokens, maxlen, dev, dtype, args.eager)
+    out["dense_fp16"] = {"ms_per_token_median": med * 1e3, "tok_per_s": args.bs / med}
+
+    twin, nbytes = pack_model(model, args.bits, dev)
+    med, mean, logits_q = time_decode(model, args.bs, args.prompt, args.tokens, maxlen, dev, dtype, args.eager)
+    out["packed_w%d" % args.bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": args.bs / med, "packed_weight_MB": nbytes / 1e6,
+                                      "hbm_bound_tok_per_s": 8e12 / (nbytes + model.tok.weight.numel() * 2)}
+    del twin
+    print(json.dumps(out))
+
+
+def decode_check(layers=2, bits=2):
+    """packed model vs its dense twin (transforms folded into fp16 weights) on the same first token: relative logits error."""
+    dev, dtype = torch.device("cuda:0"), torch.float16
+    torch.manual_seed(0)
+    model = Decoder(layers=layers, dtype=dtype).to(dev).eval()
+    for p_ in model.parameters():
+        if p_.dim() > 1:
+            p_.data.normal_(0, 0.02)
+    twin, _ = pack_model(model, bits, dev)
+    torch.manual_seed(1)
+    _, _, lq = time_decode(model, 2, 0, 0, 32, dev, dtype, True)
+    for (li, name), (Wd, b) in twin.items():
+        lin = nn.Linear(Wd.shape[1], Wd.shape[0], bias=True, dtype=dtype, device=dev)
+        lin.weight.data, lin.bias.data = Wd, b
+        setattr(model.blocks[li], name, lin)
+    torch.manual_seed(1)
+    _, _, ld = time_decode(model, 2, 0, 0, 32, dev, dtype, True)
+    return float((lq - ld).norm() / ld.norm())
+
+
+if __name__ == "__main__":
+    if "--check" in sys.argv:
+        print(json.dumps({"decode_logits_rel_err_packed_vs_dense_twin": decode_check()}))
+    else:
+        main()

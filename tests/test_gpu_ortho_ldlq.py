@@ -128,3 +128,41 @@ def test_ldlq_bit_exact_at_larger_sizes(ops, O, m, d, bits):
         assert np.mean(got.astype(np.float32) != ref) <= 1e-3
     near = np.clip(np.floor(W.numpy() + 0.5), 0, maxq)
     assert O.proxy_loss(got - W.numpy(), H.numpy()) < 0.5 * O.proxy_loss(near - W.numpy(), H.numpy())
+
+
+@pytest.mark.parametrize("n", [2048, 4096, 8192])
+@pytest.mark.parametrize("rows", [1, 3, 16])
+def test_ortho_small_batch_single_launch_path(ops, O, n, rows):
+    """quipamd_ortho_apply_small (Kronecker factors, few rows, one launch) == oracle mul_ortho_butterfly, forward and
+    transpose, with the input column scale and output bias the packed layer folds in; fp16 in / bf16 out pairs too."""
+    from quip_amd import method
+    np.random.seed(n + rows)
+    torch.manual_seed(n + rows)
+    Bpp = method.gen_rand_ortho_butterfly_noblock(n)
+    op = ops.OrthoOp(Bpp, DEV)
+    assert op.small_ok and rows <= op.SMALL_ROWS
+    Bnp = ([b.numpy() for b in Bpp[0]], Bpp[1].numpy(), Bpp[2].numpy())
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((rows, n)).astype(np.float32)
+    cs = (0.5 + rng.random(n)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    xd = torch.from_numpy(x).to(DEV)
+    for tr in (False, True):
+        want = O.mul_ortho_butterfly(Bnp, (x * cs).T.astype(np.float64), transpose=tr).T + bias
+        got = op.apply_rows(xd, transpose=tr, colscale=torch.from_numpy(cs), bias=torch.from_numpy(bias)).cpu().numpy()
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-5
+        # and it agrees with the general two-stage path
+        old, op.SMALL_ROWS = op.SMALL_ROWS, 0
+        try:
+            gen = op.apply_rows(xd, transpose=tr, colscale=torch.from_numpy(cs), bias=torch.from_numpy(bias)).cpu().numpy()
+        finally:
+            op.SMALL_ROWS = old
+        assert np.linalg.norm(got - gen) / np.linalg.norm(gen) <= 1e-5
+    # dtype pairs of the packed forward: fp16 activations in -> bf16 out (V side), fp32 in -> fp16 out (U side)
+    x16 = torch.from_numpy(x).to(DEV).half()
+    want = O.mul_ortho_butterfly(Bnp, x16.float().cpu().numpy().T.astype(np.float64)).T
+    got = op.apply_rows(x16, out_dtype=torch.bfloat16).float().cpu().numpy()
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 6e-3          # bf16 output rounding
+    got = op.apply_rows(xd, transpose=True, out_dtype=torch.float16).float().cpu().numpy()
+    want = O.mul_ortho_butterfly(Bnp, x.T.astype(np.float64), transpose=True).T
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-3
