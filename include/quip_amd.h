@@ -99,8 +99,9 @@ int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *qweight, int
 
 /* Tuning hook for benchmarks: force the K2 workgroup shape (row tiles per workgroup, batch tiles per wave,
  * waves per workgroup, k-slices over workgroups); 0 = leave that parameter to the built-in shape heuristic.
- * bt != 0 selects the multi-batch-tile kernel also for bs <= 16; split > 1 only takes effect under the
- * accumulate contract (fp32 atomics).  Process-wide, not thread-safe, never needed for correctness.  An
+ * bt != 0 selects the multi-batch-tile kernel also for bs <= 16; `split` carries two fields, split % 100 = k-slices
+ * (> 1 only takes effect under the accumulate contract: fp32 atomics) and split / 100 = chunk groups in flight per
+ * workgroup (1, 2 or 4).  Process-wide, not thread-safe, never needed for correctness.  An
  * unsupported combination makes quipamd_dequant_gemm fail with QUIPAMD_ERR_UNSUPPORTED. */
 int quipamd_tune_dequant_gemm(int rt, int bt, int nw, int split);
 

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(64 * NW) void dqgemm_kernel(const uint16_t *__restr
 // partial results are added into y with fp32 atomics -- only legal under the reference's in-place-accumulate
 // contract (y fp32, pre-filled by the caller with the bias: quant.py:226-230), where it cuts the x bytes every
 // CU has to ingest by S (at m = 4096 a full-K workgroup ingests all 128 KiB of x for 16 KiB of weights).
-template <int BITS, int RT, int CW>
+template <int BITS, int RT, int CW, int DEPTH>
 __global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(const uint16_t *__restrict__ x,
                                                                    const uint4 *__restrict__ qw, EpiArgs e, int64_t d,
                                                                    uint32_t cps)
@@ -433,8 +433,9 @@ __global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(const uint16_
     const uint32_t rt = blockIdx.x * RT + r;
     const uint32_t rowbytes = (uint32_t)d * 2u;
     const uint32_t k_lo = blockIdx.z * cps, k_hi = (k_lo + cps < nkc) ? k_lo + cps : nkc;
+    // DEPTH chunk groups are in flight per workgroup: chunk slot c of group dd uses slab (dd*CW + c)
     char *slab = smem + c * XB;
-    float *park = reinterpret_cast<float *>(smem + CW * XB);      // [CW][RT][4][64] acc, then [CW][64] xsum
+    float *park = reinterpret_cast<float *>(smem + CW * DEPTH * XB);   // [CW][RT][4][64] acc, then [CW][64] xsum
 
     // epilogue parameters of the one output row this wave will finish (reducer waves only), fetched NOW so their
     // latency hides under the weight stream
@@ -456,39 +457,49 @@ __global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(const uint16_
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     float xs = 0.f;
 #pragma unroll 1
-    for (uint32_t k0 = k_lo; k0 < k_hi; k0 += CW) {
-        const uint32_t kc = k0 + c;
-        const bool live = kc < k_hi;                               // wave-uniform
-        uint4 w = make_uint4(0, 0, 0, 0);
-        if (live) {
-            if (!QA_ABL(4)) w = (qw + ((uint64_t)rt * nkc + kc) * 64)[lane];
-            // this wave's share of slab c: DMA instructions i = r*DPW .. +DPW (i = 2*column block + row half)
-            if (!QA_ABL(1))
+    for (uint32_t k0 = k_lo; k0 < k_hi; k0 += CW * DEPTH) {
+        // ---- issue the loads of DEPTH chunks (weights to VGPRs, x slabs to LDS) before consuming any -------------------
+        uint4 w[DEPTH];
+        bool live[DEPTH];
 #pragma unroll
-            for (int q = 0; q < DPW; ++q) {
-                const int i = r * DPW + q;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t *)(slab + i * 1024), 16, (i & 1) ? voff_hi : voff_lo,
-                                                         kc * ROWB + (i >> 1) * 128, 0, 0);
+        for (int dd = 0; dd < DEPTH; ++dd) {
+            const uint32_t kc = k0 + dd * CW + c;
+            live[dd] = kc < k_hi;                                  // wave-uniform
+            w[dd] = make_uint4(0, 0, 0, 0);
+            if (live[dd]) {
+                if (!QA_ABL(4)) w[dd] = (qw + ((uint64_t)rt * nkc + kc) * 64)[lane];
+                // this wave's share of the slab: DMA instructions i = r*DPW .. +DPW (i = 2*column block + row half)
+                if (!QA_ABL(1))
+#pragma unroll
+                for (int q = 0; q < DPW; ++q) {
+                    const int i = r * DPW + q;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t *)(slab + dd * CW * XB + i * 1024), 16,
+                                                             (i & 1) ? voff_hi : voff_lo, kc * ROWB + (i >> 1) * 128, 0, 0);
+                }
             }
         }
         wait_vmcnt(0);
-        if constexpr (RT > 1) __syncthreads();                     // slab c complete (RT waves contributed)
-        if (QA_ABL(2)) { QA_KEEP(w.x); QA_KEEP(w.y); QA_KEEP(w.z); QA_KEEP(w.w); }
-        else if (live) {
-            uint4 xf[Q::NT];
+        if constexpr (RT > 1) __syncthreads();                     // slabs complete (RT waves contributed to each)
 #pragma unroll
-            for (int t = 0; t < Q::NT; ++t)
-                xf[t] = *reinterpret_cast<const uint4 *>(slab + (t >> 1) * 2048 + ((t & 1) ? rd1 : rd0));
+        for (int dd = 0; dd < DEPTH; ++dd) {
+            if (QA_ABL(2)) { QA_KEEP(w[dd].x); QA_KEEP(w[dd].y); QA_KEEP(w[dd].z); QA_KEEP(w[dd].w); }
+            else if (live[dd]) {
+                const char *sl = slab + dd * CW * XB;
+                uint4 xf[Q::NT];
 #pragma unroll
-            for (int t = 0; t < Q::NT; ++t) {
-                Frag a, bb;
-                a.u = Q::frag(w, t);
-                bb.u = xf[t];
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bb.v, acc, 0, 0, 0);
-                if (r == 0) xs = dot_ones(xf[t], xs);            // one wave per chunk keeps the row sums of x
+                for (int t = 0; t < Q::NT; ++t)
+                    xf[t] = *reinterpret_cast<const uint4 *>(sl + (t >> 1) * 2048 + ((t & 1) ? rd1 : rd0));
+#pragma unroll
+                for (int t = 0; t < Q::NT; ++t) {
+                    Frag a, bb;
+                    a.u = Q::frag(w[dd], t);
+                    bb.u = xf[t];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bb.v, acc, 0, 0, 0);
+                    if (r == 0) xs = dot_ones(xf[t], xs);        // one wave per chunk keeps the row sums of x
+                }
             }
         }
-        if (k0 + CW < k_hi) {                                      // every read of the slabs retired before the next DMA
+        if (k0 + CW * DEPTH < k_hi) {                              // every read of the slabs retired before the next DMA
             if constexpr (RT > 1) __syncthreads();
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -543,14 +554,14 @@ __global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(const uint16_
     }
 }
 
-template <int BITS, int RT, int CW>
+template <int BITS, int RT, int CW, int DEPTH>
 int launch_tile(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, int S, hipStream_t s)
 {
     typedef Deq<BITS> Q;
     constexpr int XB = 16 * Q::KC * 2;
-    constexpr size_t lds = (size_t)CW * XB + (size_t)(CW * RT * 256 + CW * 64) * 4;
+    constexpr size_t lds = (size_t)CW * DEPTH * XB + (size_t)(CW * RT * 256 + CW * 64) * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = dqgemm_tile_kernel<BITS, RT, CW>;
+    auto kern = dqgemm_tile_kernel<BITS, RT, CW, DEPTH>;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -589,7 +600,7 @@ int launch_cfg(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, 
 }
 
 // Tuning override (quipamd_tune_dequant_gemm): 0 = use the shape heuristic.
-int g_tune_rt = 0, g_tune_bt = 0, g_tune_nw = 0, g_tune_split = 0;
+int g_tune_rt = 0, g_tune_bt = 0, g_tune_nw = 0, g_tune_split = 0, g_tune_depth = 0;
 
 #define QA_K2_CASE(RT_, BT_, NW_) \
     if (rt == RT_ && bt == BT_ && nw == NW_) return launch_cfg<BITS, RT_, BT_, NW_>(x, qw, e, d, s)
@@ -607,9 +618,10 @@ int launch(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, hipS
         // S: k-slices over workgroups (atomics; accumulate contract only).
         const int64_t nkc = d / Deq<BITS>::KC;
         const bool can_split = e.accumulate && e.y_f32;
+        // Choices below are the winners of the shape sweep profiles/r01f_k2_shape_sweep.jsonl (2-bit, bs 1 and 16).
         int rt, cw, S = 1;
-        if (ntile % 4 == 0 && ntile / 4 >= 256) { rt = 4; cw = 4; }             // big m: 4 row tiles share every x slab
-        else if (can_split && ntile % 2 == 0) {
+        if (ntile % 4 == 0 && ntile >= 1024) { rt = 4; cw = 4; }               // big m: 4 row tiles share every x slab
+        else if (can_split && ntile % 2 == 0 && ntile / 2 < 256) {
             // small m under the accumulate contract: 8-wave workgroups (several resident per CU), k split over
             // workgroups until there are ~512 of them (measured best at 4096x4096: rt 2, cw 4, S 4)
             rt = 2; cw = 4;
@@ -617,29 +629,36 @@ int launch(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, hipS
             if (S > nkc / cw) S = (int)(nkc / cw);
             if (S < 1) S = 1;
         }
-        else if (ntile % 2 == 0 && ntile / 2 >= 256) { rt = 2; cw = 8; }
+        else if (g_tune_rt == 0 && g_tune_nw == 0 && ntile % 2 == 0 && ntile >= 384 && nkc >= 24)
+            return launch_cfg<BITS, 2, 1, 16>(x, qw, e, d, s);                  // long K, mid m: per-wave private slabs, 2 row tiles
         else { rt = 1; cw = 8; }
         if (g_tune_rt > 0 && ntile % g_tune_rt == 0) { rt = g_tune_rt; cw = 16 / rt; }
         if (g_tune_nw > 0) cw = g_tune_nw / rt > 0 ? g_tune_nw / rt : 1;
         if (g_tune_split > 0) S = can_split ? g_tune_split : 1;
-#define QA_K2T_CASE(RT_, CW_) if (rt == RT_ && cw == CW_) return launch_tile<BITS, RT_, CW_>(x, qw, e, d, S, s)
-        QA_K2T_CASE(1, 16); QA_K2T_CASE(1, 8); QA_K2T_CASE(1, 4); QA_K2T_CASE(1, 2); QA_K2T_CASE(1, 1); QA_K2T_CASE(2, 1);
-        QA_K2T_CASE(2, 8);  QA_K2T_CASE(2, 4); QA_K2T_CASE(2, 2);
-        QA_K2T_CASE(4, 4);  QA_K2T_CASE(4, 2); QA_K2T_CASE(4, 1);
+        // chunks in flight per wave: enough to cover the workgroup's k-slice in one go when LDS allows (<= 128 KiB of slabs)
+        const int64_t slice = (nkc + S - 1) / S;
+        (void)slice;
+        int depth = 1;                       // measured: 2 or 4 groups in flight buy nothing at 4096^2 (profiles/r01f)
+        if (g_tune_depth > 0) depth = g_tune_depth;
+#define QA_K2T_CASE(RT_, CW_) \
+        if (rt == RT_ && cw == CW_) { \
+            if (depth == 1) return launch_tile<BITS, RT_, CW_, 1>(x, qw, e, d, S, s); \
+            if constexpr ((size_t)CW_ * 2 * 16 * Deq<BITS>::KC * 2 <= 128 * 1024) { if (depth == 2) return launch_tile<BITS, RT_, CW_, 2>(x, qw, e, d, S, s); } \
+            if constexpr ((size_t)CW_ * 4 * 16 * Deq<BITS>::KC * 2 <= 128 * 1024) { if (depth == 4) return launch_tile<BITS, RT_, CW_, 4>(x, qw, e, d, S, s); } \
+            return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: depth %d does not fit LDS for cw=%d", depth, cw); \
+        }
+        QA_K2T_CASE(1, 16) QA_K2T_CASE(1, 8) QA_K2T_CASE(1, 4) QA_K2T_CASE(1, 2) QA_K2T_CASE(1, 1) QA_K2T_CASE(2, 1)
+        QA_K2T_CASE(2, 8)  QA_K2T_CASE(2, 4) QA_K2T_CASE(2, 2)
+        QA_K2T_CASE(4, 4)  QA_K2T_CASE(4, 2) QA_K2T_CASE(4, 1)
 #undef QA_K2T_CASE
         return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: no tile kernel for rt=%d cw=%d", rt, cw);
     }
-    int rt, bt, nw;
-    if (nb >= 3) {
-        bt = 4; nw = 4;
-        rt = (ntile % 2 == 0 && ntile / 2 * ((nb + 3) / 4) >= 256) ? 2 : 1;
-    } else if (nb == 2) {
-        bt = 2; nw = 8;
-        rt = (ntile % 2 == 0 && ntile / 2 >= 256) ? 2 : 1;
-    } else {
-        bt = 1; nw = 16;
-        rt = (ntile % 4 == 0 && ntile / 4 >= 512) ? 4 : (ntile % 2 == 0 && ntile / 2 >= 256) ? 2 : 1;
-    }
+    // bs > 16: one batch tile per workgroup (grid.y walks the batch tiles, weights re-streamed from L2 / Infinity Cache)
+    // with as many row tiles per wave as the grid allows beat the BT > 1 variants at every swept shape.
+    int rt, bt = 1, nw = 16;
+    if (ntile % 4 == 0 && (ntile / 4) * nb >= 128) rt = 4;
+    else if (ntile % 2 == 0 && (ntile / 2) * nb >= 128) rt = 2;
+    else rt = 1;
     if (g_tune_rt > 0 && ntile % g_tune_rt == 0) rt = g_tune_rt;
     if (g_tune_bt > 0) bt = g_tune_bt;
     if (g_tune_nw > 0) nw = g_tune_nw;
@@ -657,7 +676,9 @@ int launch(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, hipS
 
 extern "C" int quipamd_tune_dequant_gemm(int rt, int bt, int nw, int split)
 {
-    g_tune_rt = rt; g_tune_bt = bt; g_tune_nw = nw; g_tune_split = split;
+    g_tune_rt = rt; g_tune_bt = bt; g_tune_nw = nw;
+    g_tune_split = split % 100;            // split + 100*depth: depth = chunk groups in flight per workgroup (0 = heuristic)
+    g_tune_depth = split / 100;
     return QUIPAMD_OK;
 }
 

@@ -53,13 +53,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--shapes", default="")
+    ap.add_argument("--default-only", action="store_true", help="only the heuristic configuration")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
-    shapes = [(4096, 4096)] if args.quick else [(4096, 4096), (2048, 2048), (8192, 2048), (2048, 8192), (11008, 4096),
-                                                 (4096, 11008), (8192, 8192)]
+    shapes = [(4096, 4096)] if args.quick else [(2048, 2048), (8192, 2048), (2048, 8192), (4096, 4096), (11008, 4096),
+                                                 (4096, 11008), (8192, 8192), (28672, 7168), (7168, 28672)]
+    if args.shapes:
+        shapes = [tuple(int(v) for v in sh.split("x")) for sh in args.shapes.split(",")]
     for (m, d) in shapes:
-        for bits in ([2] if args.quick else [2, 4]):
+        for bits in ([2] if (args.quick or args.default_only) else [2, 4]):
             if d % (512 // bits):
                 continue
             codes, scale, qs = make_layer(m, d, bits, dev)
@@ -67,7 +71,7 @@ def main():
             wbytes = m * d * bits // 8
             nring = max(2, min(96, (400 << 20) // wbytes + 1))
             ring = [qs] + [qs.clone() for _ in range(nring - 1)]
-            for bs in ([1, 16] if args.quick else [1, 4, 16, 64, 256]):
+            for bs in ([1, 16] if args.quick else [1, 16, 64, 256]):
                 x = torch.randn(bs, d, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).to(dev)
                 y = torch.empty(bs, m, dtype=torch.bfloat16, device=dev)
                 ref = x.double() @ What.T
@@ -78,6 +82,8 @@ def main():
                     cfgs = [(0, 0, 0), (1, 2, 8), (2, 2, 8), (1, 2, 4), (2, 2, 4), (1, 1, 16), (2, 1, 16)]
                 else:
                     cfgs = [(0, 0, 0), (1, 4, 4), (2, 4, 4), (1, 2, 8), (2, 2, 8), (1, 1, 16), (2, 1, 16), (4, 1, 16)]
+                if args.default_only:
+                    cfgs = [(0, 0, 0)]
                 for (rt, bt, nw) in cfgs:
                     if rt and (m // 16) % rt:
                         continue

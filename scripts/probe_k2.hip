@@ -68,17 +68,18 @@ int main(int argc, char **argv)
     }
     for (int cold = 0; cold < 2; ++cold) {
         run("old", 1, 1, 16, 0, false, cold, false);
-        run("tile", 1, 0, 16, 0, false, cold, false);
-        run("tile", 1, 0, 8, 0, false, cold, false);
+        // bf16 y (no split): rt x cw x depth
+        const int cfg1[][3] = {{1, 16, 1}, {1, 8, 1}, {1, 8, 2}, {1, 4, 2}, {1, 4, 4}, {1, 2, 4}, {2, 8, 1}, {2, 4, 2}, {2, 4, 4}, {2, 2, 4}, {4, 4, 1}, {4, 2, 2}, {4, 1, 4}};
+        for (auto &c : cfg1) run("tile", c[0], 0, c[0] * c[1], 100 * c[2], false, cold, false);
         if (!sweep) continue;
-        const int rts[3] = {1, 2, 4}, cws[4] = {1, 2, 4, 8}, sps[5] = {1, 2, 4, 8, 16};
-        for (int a = 0; a < 3; ++a) for (int b = 0; b < 4; ++b) for (int c = 0; c < 5; ++c) {
-            const int rt = rts[a], cw = cws[b], sp = sps[c];
+        const int rts[3] = {1, 2, 4}, cws[4] = {1, 2, 4, 8}, sps[4] = {2, 4, 8, 16}, dps[3] = {1, 2, 4};
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 4; ++b) for (int c = 0; c < 4; ++c) for (int e = 0; e < 3; ++e) {
+            const int rt = rts[a], cw = cws[b], sp = sps[c], dp = dps[e];
             if (rt * cw > 16) continue;
             const long nkc = d / 256;
-            if (sp * cw > nkc) continue;
+            if (sp * cw * dp > nkc) continue;                 // slice must need at least this depth
             if ((m / 16 / rt) * sp < 128) continue;
-            run("tile", rt, 0, rt * cw, sp, true, cold, false);
+            run("tile", rt, 0, rt * cw, sp + 100 * dp, true, cold, false);
         }
     }
     return 0;
