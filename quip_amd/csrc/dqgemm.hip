@@ -60,21 +60,6 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t shifted, uint32_
 template <int BITS> struct Deq;
 template <> struct Deq<2> {
     static constexpr int KC = 256, NT = 8;
-    // rolled form: column block cb (MFMA steps 2cb, 2cb+1) uses dword cb -> after each block rotate by 1
-    static __device__ __forceinline__ uint4 frag_lead(const uint4 &w, int tt)
-    {
-        const uint32_t base = opaque(0x40804080u);
-        uint32_t o[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int sh = 2 * (4 * tt + v) - 5;
-            const uint32_t shifted = sh >= 0 ? (w.x >> sh) : (w.x << (-sh));
-            o[v] = bfi(0x00600060u, shifted, base);
-        }
-        return make_uint4(o[0], o[1], o[2], o[3]);
-    }
-    static __device__ __forceinline__ void rotate(uint4 &w) { w = make_uint4(w.y, w.z, w.w, w.x); }
-    static constexpr float OFF = 4.0f;
     // A fragment (4 dwords = 8 bf16) of MFMA step t from the lane's 4 packed dwords
     static __device__ __forceinline__ uint4 frag(const uint4 &w, int t)
     {
@@ -92,22 +77,6 @@ template <> struct Deq<2> {
 };
 template <> struct Deq<4> {
     static constexpr int KC = 128, NT = 4;
-    // rolled form: column block cb uses dwords 2cb, 2cb+1 -> after each block rotate the lane's 4 dwords by 2
-    static __device__ __forceinline__ uint4 frag_lead(const uint4 &w, int tt)
-    {
-        const uint32_t src = tt == 0 ? w.x : w.y;
-        const uint32_t base = opaque(0x41804180u);
-        uint32_t o[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int sh = 4 * v - 3;
-            const uint32_t shifted = sh >= 0 ? (src >> sh) : (src << (-sh));
-            o[v] = bfi(0x00780078u, shifted, base);
-        }
-        return make_uint4(o[0], o[1], o[2], o[3]);
-    }
-    static __device__ __forceinline__ void rotate(uint4 &w) { w = make_uint4(w.z, w.w, w.x, w.y); }
-    static constexpr float OFF = 16.0f;
     static __device__ __forceinline__ uint4 frag(const uint4 &w, int t)
     {
         const uint32_t src = t == 0 ? w.x : t == 1 ? w.y : t == 2 ? w.z : w.w;
@@ -414,10 +383,10 @@ __global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(const uint16_
                                                                    const uint4 *__restrict__ qw, EpiArgs e, int64_t d,
                                                                    uint32_t cps)
 {
-    // NOTE on code shape: the instruction cache is cold at every dispatch and a microsecond-scale kernel runs
-    // each instruction once, so it is bound by instruction FETCH (measured: ~1 cycle per byte of straight-line
-    // code).  Every loop below is therefore deliberately ROLLED (#pragma unroll 1) and the epilogue avoids
-    // IEEE division: the executed path is ~1.5 KiB instead of 5.6 KiB fully unrolled.
+    // NOTE on code shape (measured with scripts/probe_k2.hip): a wave issues roughly one instruction per 5 cycles, so
+    // the per-wave instruction count of each phase is what a microsecond-scale launch pays for; rolling the loops to
+    // shrink code did NOT help (instruction fetch is not the limit) and serialised LDS latency, so the compute is
+    // unrolled, the tail is spread over reducer waves and the epilogue avoids IEEE division.
     typedef Deq<BITS> Q;
     constexpr int KC = Q::KC;
     constexpr int ROWB = KC * 2, NCB = ROWB / 128, NI = 2 * NCB, XB = 16 * ROWB;
@@ -433,7 +402,7 @@ __global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(const uint16_
     const uint32_t rt = blockIdx.x * RT + r;
     const uint32_t rowbytes = (uint32_t)d * 2u;
     const uint32_t k_lo = blockIdx.z * cps, k_hi = (k_lo + cps < nkc) ? k_lo + cps : nkc;
-    // DEPTH chunk groups are in flight per workgroup: chunk slot c of group dd uses slab (dd*CW + c)
+    // DEPTH slab sets: chunk slot c of set `buf` is slab (buf*CW + c)
     char *slab = smem + c * XB;
     float *park = reinterpret_cast<float *>(smem + CW * DEPTH * XB);   // [CW][RT][4][64] acc, then [CW][64] xsum
 
@@ -456,52 +425,65 @@ __global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(const uint16_
 
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     float xs = 0.f;
+    // DEPTH == 1: issue a chunk group, wait, compute, repeat (everything in flight at once when the k-slice is one group).
+    // DEPTH == 2: software pipeline over two slab sets -- the NEXT group's weight load and slab DMA are issued after the
+    //             current group's fragments have been read into registers and BEFORE its MFMAs, so they fly under the
+    //             dequant + MFMA work (hipcc only forces vmcnt(0) in front of the next ds_read, which is where we need it).
+    auto issue = [&](uint32_t kgrp, int buf, uint4 &wdst) -> bool {
+        const uint32_t kc = kgrp + c;
+        const bool lv = kc < k_hi;                                 // wave-uniform
+        wdst = make_uint4(0, 0, 0, 0);
+        if (lv) {
+            if (!QA_ABL(4)) wdst = (qw + ((uint64_t)rt * nkc + kc) * 64)[lane];
+            // this wave's share of the slab: DMA instructions i = r*DPW .. +DPW (i = 2*column block + row half)
+            if (!QA_ABL(1))
+#pragma unroll
+            for (int q = 0; q < DPW; ++q) {
+                const int i = r * DPW + q;
+                if ((i & 1) && e.bs <= 8) continue;                 // rows 8..15 of the slab feed batch columns that are never stored
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t *)(slab + buf * CW * XB + i * 1024), 16,
+                                                         (i & 1) ? voff_hi : voff_lo, kc * ROWB + (i >> 1) * 128, 0, 0);
+            }
+        }
+        return lv;
+    };
+    int buf = 0;
+    uint4 w_nxt;
+    bool live_nxt = issue(k_lo, 0, w_nxt);
 #pragma unroll 1
-    for (uint32_t k0 = k_lo; k0 < k_hi; k0 += CW * DEPTH) {
-        // ---- issue the loads of DEPTH chunks (weights to VGPRs, x slabs to LDS) before consuming any -------------------
-        uint4 w[DEPTH];
-        bool live[DEPTH];
-#pragma unroll
-        for (int dd = 0; dd < DEPTH; ++dd) {
-            const uint32_t kc = k0 + dd * CW + c;
-            live[dd] = kc < k_hi;                                  // wave-uniform
-            w[dd] = make_uint4(0, 0, 0, 0);
-            if (live[dd]) {
-                if (!QA_ABL(4)) w[dd] = (qw + ((uint64_t)rt * nkc + kc) * 64)[lane];
-                // this wave's share of the slab: DMA instructions i = r*DPW .. +DPW (i = 2*column block + row half)
-                if (!QA_ABL(1))
-#pragma unroll
-                for (int q = 0; q < DPW; ++q) {
-                    const int i = r * DPW + q;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t *)(slab + dd * CW * XB + i * 1024), 16,
-                                                             (i & 1) ? voff_hi : voff_lo, kc * ROWB + (i >> 1) * 128, 0, 0);
-                }
-            }
-        }
+    for (uint32_t k0 = k_lo; k0 < k_hi; k0 += CW) {
         wait_vmcnt(0);
-        if constexpr (RT > 1) __syncthreads();                     // slabs complete (RT waves contributed to each)
+        if constexpr (RT > 1) __syncthreads();                     // slab complete (RT waves contributed)
+        const uint4 w = w_nxt;
+        const bool live = live_nxt;
+        const char *sl = slab + buf * CW * XB;
+        uint4 xf[Q::NT];
+        if (live && !QA_ABL(2)) {
 #pragma unroll
-        for (int dd = 0; dd < DEPTH; ++dd) {
-            if (QA_ABL(2)) { QA_KEEP(w[dd].x); QA_KEEP(w[dd].y); QA_KEEP(w[dd].z); QA_KEEP(w[dd].w); }
-            else if (live[dd]) {
-                const char *sl = slab + dd * CW * XB;
-                uint4 xf[Q::NT];
+            for (int t = 0; t < Q::NT; ++t)
+                xf[t] = *reinterpret_cast<const uint4 *>(sl + (t >> 1) * 2048 + ((t & 1) ? rd1 : rd0));
+        }
+        const bool more = k0 + CW < k_hi;
+        if constexpr (DEPTH == 2) {
+            if (more) { live_nxt = issue(k0 + CW, buf ^ 1, w_nxt); buf ^= 1; }
+        }
+        if (QA_ABL(2)) { QA_KEEP(w.x); QA_KEEP(w.y); QA_KEEP(w.z); QA_KEEP(w.w); }
+        else if (live) {
 #pragma unroll
-                for (int t = 0; t < Q::NT; ++t)
-                    xf[t] = *reinterpret_cast<const uint4 *>(sl + (t >> 1) * 2048 + ((t & 1) ? rd1 : rd0));
-#pragma unroll
-                for (int t = 0; t < Q::NT; ++t) {
-                    Frag a, bb;
-                    a.u = Q::frag(w[dd], t);
-                    bb.u = xf[t];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bb.v, acc, 0, 0, 0);
-                    if (r == 0) xs = dot_ones(xf[t], xs);        // one wave per chunk keeps the row sums of x
-                }
+            for (int t = 0; t < Q::NT; ++t) {
+                Frag a, bb;
+                a.u = Q::frag(w, t);
+                bb.u = xf[t];
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bb.v, acc, 0, 0, 0);
+                if (r == 0) xs = dot_ones(xf[t], xs);            // one wave per chunk keeps the row sums of x
             }
         }
-        if (k0 + CW * DEPTH < k_hi) {                              // every read of the slabs retired before the next DMA
-            if constexpr (RT > 1) __syncthreads();
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (DEPTH == 1) {
+            if (more) {                                            // every read of the slab retired before the next DMA lands
+                if constexpr (RT > 1) __syncthreads();
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                live_nxt = issue(k0 + CW, 0, w_nxt);
+            }
         }
     }
 
@@ -618,10 +600,15 @@ int launch(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, hipS
         // S: k-slices over workgroups (atomics; accumulate contract only).
         const int64_t nkc = d / Deq<BITS>::KC;
         const bool can_split = e.accumulate && e.y_f32;
-        // Choices below are the winners of the shape sweep profiles/r01f_k2_shape_sweep.jsonl (2-bit, bs 1 and 16).
-        int rt, cw, S = 1;
-        if (ntile % 4 == 0 && ntile >= 1024) { rt = 4; cw = 4; }               // big m: 4 row tiles share every x slab
-        else if (can_split && ntile % 2 == 0 && ntile / 2 < 256) {
+        // Choices below are the winners of the shape sweeps under profiles/r01f_* (2-bit, bs 1 and 16).  Large m / long K:
+        // the per-wave kernel (every wave streams RT weight tiles per chunk: more bytes in flight per wave, private slabs);
+        // small m: the tile kernel (all of a CU's bytes in flight at once, parallel reducers, optional split-K).
+        const bool tuned = g_tune_rt != 0 || g_tune_nw != 0 || g_tune_split != 0 || g_tune_depth != 0;
+        int rt = 1, cw = 8, S = 1;
+        if (!tuned && ntile % 4 == 0 && ntile >= 1024) return launch_cfg<BITS, 4, 1, 8>(x, qw, e, d, s);
+        if (!tuned && ntile % 4 == 0 && ntile >= 640 && nkc >= 16) return launch_cfg<BITS, 4, 1, 16>(x, qw, e, d, s);
+        if (!tuned && ntile % 2 == 0 && ntile >= 384 && nkc >= 24) return launch_cfg<BITS, 2, 1, 16>(x, qw, e, d, s);
+        if (can_split && ntile % 2 == 0 && ntile / 2 < 256) {
             // small m under the accumulate contract: 8-wave workgroups (several resident per CU), k split over
             // workgroups until there are ~512 of them (measured best at 4096x4096: rt 2, cw 4, S 4)
             rt = 2; cw = 4;
@@ -629,9 +616,6 @@ int launch(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, hipS
             if (S > nkc / cw) S = (int)(nkc / cw);
             if (S < 1) S = 1;
         }
-        else if (g_tune_rt == 0 && g_tune_nw == 0 && ntile % 2 == 0 && ntile >= 384 && nkc >= 24)
-            return launch_cfg<BITS, 2, 1, 16>(x, qw, e, d, s);                  // long K, mid m: per-wave private slabs, 2 row tiles
-        else { rt = 1; cw = 8; }
         if (g_tune_rt > 0 && ntile % g_tune_rt == 0) { rt = g_tune_rt; cw = 16 / rt; }
         if (g_tune_nw > 0) cw = g_tune_nw / rt > 0 ? g_tune_nw / rt : 1;
         if (g_tune_split > 0) S = can_split ? g_tune_split : 1;
@@ -644,12 +628,12 @@ int launch(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, hipS
         if (rt == RT_ && cw == CW_) { \
             if (depth == 1) return launch_tile<BITS, RT_, CW_, 1>(x, qw, e, d, S, s); \
             if constexpr ((size_t)CW_ * 2 * 16 * Deq<BITS>::KC * 2 <= 128 * 1024) { if (depth == 2) return launch_tile<BITS, RT_, CW_, 2>(x, qw, e, d, S, s); } \
-            if constexpr ((size_t)CW_ * 4 * 16 * Deq<BITS>::KC * 2 <= 128 * 1024) { if (depth == 4) return launch_tile<BITS, RT_, CW_, 4>(x, qw, e, d, S, s); } \
             return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: depth %d does not fit LDS for cw=%d", depth, cw); \
         }
         QA_K2T_CASE(1, 16) QA_K2T_CASE(1, 8) QA_K2T_CASE(1, 4) QA_K2T_CASE(1, 2) QA_K2T_CASE(1, 1) QA_K2T_CASE(2, 1)
         QA_K2T_CASE(2, 8)  QA_K2T_CASE(2, 4) QA_K2T_CASE(2, 2)
         QA_K2T_CASE(4, 4)  QA_K2T_CASE(4, 2) QA_K2T_CASE(4, 1)
+        if constexpr (BITS == 2) { QA_K2T_CASE(8, 2) QA_K2T_CASE(8, 1) }
 #undef QA_K2T_CASE
         return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: no tile kernel for rt=%d cw=%d", rt, cw);
     }

@@ -77,17 +77,21 @@ def main():
                 ref = x.double() @ What.T
                 nb = (bs + 15) // 16
                 if nb == 1:
-                    cfgs = [(0, 0, 0), (1, 0, 16), (2, 0, 16), (4, 0, 16), (1, 0, 8), (2, 0, 8), (4, 0, 8), (1, 1, 16), (2, 1, 16)]
+                    cfgs = [(0, 0, 0), (1, 0, 16), (2, 0, 16), (4, 0, 16), (1, 0, 8), (2, 0, 8), (4, 0, 8), (1, 1, 16), (2, 1, 16),
+                            (1, 0, 8, 200), (2, 0, 16, 200), (4, 0, 16, 200), (2, 0, 8, 200), (4, 0, 8, 200), (1, 0, 4, 200),
+                            (8, 0, 16), (8, 0, 16, 200), (8, 0, 8), (8, 0, 8, 200), (4, 1, 16), (4, 1, 8), (2, 1, 8), (4, 1, 4)]
                 elif nb == 2:
                     cfgs = [(0, 0, 0), (1, 2, 8), (2, 2, 8), (1, 2, 4), (2, 2, 4), (1, 1, 16), (2, 1, 16)]
                 else:
                     cfgs = [(0, 0, 0), (1, 4, 4), (2, 4, 4), (1, 2, 8), (2, 2, 8), (1, 1, 16), (2, 1, 16), (4, 1, 16)]
                 if args.default_only:
                     cfgs = [(0, 0, 0)]
-                for (rt, bt, nw) in cfgs:
+                for cfg in cfgs:
+                    rt, bt, nw = cfg[:3]
+                    sp = cfg[3] if len(cfg) > 3 else 0
                     if rt and (m // 16) % rt:
                         continue
-                    lib.quipamd_tune_dequant_gemm(rt, bt, nw, 0)
+                    lib.quipamd_tune_dequant_gemm(rt, bt, nw, sp)
 
                     def launch(qw, st):
                         rc = lib.quipamd_dequant_gemm(vp(x.data_ptr()), 2, vp(qw.data_ptr()), bits, 1, 1,
@@ -99,13 +103,13 @@ def main():
                         launch(qs, vp(torch.cuda.current_stream().cuda_stream))
                         torch.cuda.synchronize()
                     except RuntimeError as ex:
-                        print(json.dumps({"m": m, "d": d, "bits": bits, "bs": bs, "cfg": [rt, bt, nw], "error": str(ex)}), flush=True)
+                        print(json.dumps({"m": m, "d": d, "bits": bits, "bs": bs, "cfg": list(cfg), "error": str(ex)}), flush=True)
                         continue
                     rel = float((y.double() - ref).norm() / ref.norm())
                     t_cold = time_graph(launch, ring, args.steps)
                     t_warm = time_graph(launch, [qs], args.steps)
                     byts = wbytes + 2 * bs * d + 2 * bs * m
-                    print(json.dumps({"m": m, "d": d, "bits": bits, "bs": bs, "cfg": [rt, bt, nw], "rel": round(rel, 6),
+                    print(json.dumps({"m": m, "d": d, "bits": bits, "bs": bs, "cfg": list(cfg), "rel": round(rel, 6),
                                       "us_cold": round(t_cold, 3), "us_warm": round(t_warm, 3),
                                       "GBs_cold": round(byts / t_cold / 1e3, 1), "TF_cold": round(2 * bs * m * d / t_cold / 1e6, 2),
                                       "TF_warm": round(2 * bs * m * d / t_warm / 1e6, 2)}), flush=True)

@@ -159,10 +159,10 @@ def test_forced_workgroup_shapes_agree(ops, O):
     bad = []
     try:
         for cfg in [(1, 0, 16), (2, 0, 16), (4, 0, 16), (1, 0, 8), (2, 0, 8), (4, 0, 8), (1, 0, 4), (2, 0, 4), (4, 0, 4),
-                    (1, 0, 2), (1, 0, 1), (2, 0, 2),
+                    (1, 0, 2), (1, 0, 1), (2, 0, 2), (8, 0, 16), (8, 0, 8), (1, 0, 8, 200), (2, 0, 8, 200), (4, 0, 16, 200), (8, 0, 16, 200),
                     (1, 1, 16), (2, 1, 16), (4, 1, 16), (1, 1, 8), (2, 1, 8), (4, 1, 8), (1, 1, 4), (4, 1, 4), (1, 2, 8),
                     (2, 2, 8), (1, 2, 4), (2, 2, 4), (1, 4, 4), (2, 4, 4)]:
-            lib.quipamd_tune_dequant_gemm(cfg[0], cfg[1], cfg[2], 0)
+            lib.quipamd_tune_dequant_gemm(cfg[0], cfg[1], cfg[2], cfg[3] if len(cfg) > 3 else 0)
             y = ops.dequant_gemm(xd, qs, bits, "b", sc, None, None, out_dtype=torch.float32)
             if _rel(y.cpu().numpy().astype(np.float64), y_ref) > TOL_F32:
                 bad.append(cfg)
