@@ -60,6 +60,7 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t shifted, uint32_
 template <int BITS> struct Deq;
 template <> struct Deq<2> {
     static constexpr int KC = 256, NT = 8;
+    static constexpr float OFF = 4.0f;           // dequantised value = OFF + code
     // A fragment (4 dwords = 8 bf16) of MFMA step t from the lane's 4 packed dwords
     static __device__ __forceinline__ uint4 frag(const uint4 &w, int t)
     {
@@ -77,6 +78,7 @@ template <> struct Deq<2> {
 };
 template <> struct Deq<4> {
     static constexpr int KC = 128, NT = 4;
+    static constexpr float OFF = 16.0f;
     static __device__ __forceinline__ uint4 frag(const uint4 &w, int t)
     {
         const uint32_t src = t == 0 ? w.x : t == 1 ? w.y : t == 2 ? w.z : w.w;
