@@ -165,6 +165,7 @@ class OrthoOp:
         self._frags = {}
         p_in = torch.as_tensor(p_in).to(torch.int64).cpu()
         p_out = torch.as_tensor(p_out).to(torch.int64).cpu()
+        self._p_in, self._p_out = p_in, p_out
         ident = torch.arange(self.n)
         i32 = lambda t: t.to(torch.int32).to(device)
         self.pin = None if torch.equal(p_in, ident) else i32(p_in)
@@ -178,6 +179,12 @@ class OrthoOp:
         if self.small_ok:
             self._M = {False: (B0[0].contiguous(), B1[0].contiguous()),
                        True: (B0[0].t().contiguous(), B1[0].t().contiguous())}
+
+    def state(self):
+        """the reference-style generator tuple ([B0, B1], p_in, p_out) on the CPU -- what a packed checkpoint stores."""
+        B0 = self._B0.cpu() if self.blocked else self._B0[0].cpu()
+        B1 = self._B1.cpu() if self.blocked else self._B1[0].cpu()
+        return ([B0, B1], self._p_in.clone(), self._p_out.clone())
 
     def _stage_frags(self, transpose):
         """(first, second) stage matrices in B-fragment order; built once per orientation, kept on the device."""

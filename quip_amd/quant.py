@@ -156,6 +156,41 @@ class QuantLinear(nn.Module):
         self.V = V if (V is None or isinstance(V, ops.OrthoOp)) else ops.OrthoOp(V, dev)
         return self
 
+    @classmethod
+    @torch.no_grad()
+    def from_method(cls, method, layer):
+        """Packed layer from a Balance (or any QuantMethod that kept integer codes) AFTER fasterquant() and BEFORE
+        free(): codes + grid parameters in the projected basis, plus the rescale vector and the structured operators
+        of QuantMethod.preproc -- the state the reference throws away (vector_balance.py:528-530, method.py:223-225)."""
+        codes = method.codes
+        bits = int(torch.log2(method.quantizer.maxq.float() + 1).round().item())
+        qfn = method.quantizer.qfn if method.quantizer.qfn in ('a', 'b') else 'a'
+        ql = cls(codes.shape[1], codes.shape[0], bits=bits, qfn=qfn)
+        U = getattr(method, '_U', None) if getattr(method, 'preproc_proj', False) else None
+        V = getattr(method, '_V', None) if getattr(method, 'preproc_proj', False) else None
+        sWH = method.scaleWH if getattr(method, 'preproc_rescale', False) else None
+        bias = None if getattr(layer, 'bias', None) is None else layer.bias.data
+        return ql.pack(codes, method.qscale, method.qzero, bias=bias, scaleWH=sWH, U=U, V=V)
+
+    def packed_state(self):
+        """everything needed to rebuild the layer, as CPU tensors / plain Python (the packed checkpoint record):
+        STREAM-layout codes, grid parameters, bias, 1/scaleWH and the generator tuples of U and V."""
+        cpu = lambda t: None if t is None else t.detach().cpu()
+        return {"infeatures": self.infeatures, "outfeatures": self.outfeatures, "bits": self.bits, "qfn": self.qfn,
+                "qweight": cpu(self.qweight), "scales": cpu(self.scales), "zeros": cpu(self.zeros), "bias": cpu(self.bias),
+                "inv_scaleWH": cpu(self.inv_scaleWH),
+                "U": None if self.U is None else self.U.state(), "V": None if self.V is None else self.V.state()}
+
+    @classmethod
+    def from_packed_state(cls, st, device):
+        ql = cls(st["infeatures"], st["outfeatures"], bits=st["bits"], qfn=st["qfn"])
+        dev = lambda t: None if t is None else t.to(device)
+        ql.qweight, ql.scales, ql.zeros = dev(st["qweight"]), dev(st["scales"]), dev(st["zeros"])
+        ql.bias, ql.inv_scaleWH = dev(st["bias"]), dev(st["inv_scaleWH"])
+        ql.U = None if st["U"] is None else ops.OrthoOp(st["U"], device)
+        ql.V = None if st["V"] is None else ops.OrthoOp(st["V"], device)
+        return ql
+
     def forward(self, x):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
@@ -173,6 +208,17 @@ class QuantLinear(nn.Module):
                                  out_dtype=torch.float32, m=self.outfeatures)
             y = self.U.apply_rows(y, transpose=True, out_dtype=x.dtype, bias=self.bias)   # fp32 in, caller's dtype out
         return y.to(x.dtype).reshape(*shape[:-1], self.outfeatures)
+
+
+def save_packed(layers, path):
+    """Packed checkpoint: {dotted module name: QuantLinear} -> one torch file of CPU tensors (replaces the dense fp16
+    `torch.save(model.state_dict())` of opt.py:644-646 for the quantised Linears; 2 bits/weight + factors)."""
+    torch.save({name: ql.packed_state() for name, ql in layers.items()}, path)
+
+
+def load_packed(path, device):
+    """inverse of save_packed: {name: QuantLinear on `device`}, ready for make_quant(model, layers)."""
+    return {name: QuantLinear.from_packed_state(st, device) for name, st in torch.load(path, weights_only=False).items()}
 
 
 def make_quant(module, layers, name=''):

@@ -169,3 +169,19 @@ def test_forced_workgroup_shapes_agree(ops, O):
     finally:
         lib.quipamd_tune_dequant_gemm(0, 0, 0, 0)
     assert not bad, f"workgroup shapes with wrong results: {bad}"
+
+
+@pytest.mark.parametrize("m,d,bs", [(11008, 4096, 5), (4096, 11008, 16)])
+def test_llama2_7b_mlp_shapes(ops, O, m, d, bs):
+    """BASELINE configs[3]: Llama-2-7B gate/up (11008x4096) and down (4096x11008) projections, w2 qfn b (11008 = 43*256
+    chunks: not a power of two, odd chunk count per wave)."""
+    W, x, codes, scale, zero, maxq = _case(O, m, d, bs, 2, "b", seed=m + bs)
+    y_ref = O.dequant_linear(x, codes, "b", scale, None, maxq, None)
+    qs = ops.pack(torch.from_numpy(codes).to(DEV), 2, ops.LAYOUT_STREAM)
+    xd = torch.from_numpy(x).to(DEV).to(torch.bfloat16)
+    sc = torch.tensor(np.asarray(scale, np.float32).reshape(-1))
+    y = ops.dequant_gemm(xd, qs, 2, "b", sc, None, None, out_dtype=torch.float32)
+    assert _rel(y.cpu().numpy().astype(np.float64), y_ref) <= TOL_F32
+    yacc = torch.zeros(bs, m, device=DEV)
+    ops.dequant_gemm(xd, qs, 2, "b", sc, None, None, out=yacc, accumulate=True)
+    assert _rel(yacc.cpu().numpy().astype(np.float64), y_ref) <= TOL_F32

@@ -173,9 +173,20 @@ def test_packed_layer_equals_fake_quant_dense_layer(Q, bits, incoh):
     # composite tolerance: bf16 rounding of the projected activations (2^-9 per element) + fp16 re-rounding of
     # the dense weights after postproc; the GEMM itself is gated at 1e-3 in test_gpu_dqgemm.py
     assert float((y.float() - y_ref).norm() / y_ref.norm()) <= 1e-2
+    # the same layer straight from the method object, and through a packed checkpoint round trip: bit-identical
+    ql2 = Q.QuantLinear.from_method(meth, lin)
+    assert torch.equal(ql2(x), y)
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "packed.pt")
+        Q.save_packed({"0": ql2}, path)
+        dense_bytes = lin.weight.numel() * 2
+        loaded = Q.load_packed(path, DEV)
+    assert torch.equal(loaded["0"](x), y)
+    assert loaded["0"].qweight.numel() * 4 * (16 // bits) == dense_bytes           # 2 or 4 bits per weight
     # module swap helper
     holder = torch.nn.Sequential(lin)
-    Q.make_quant(holder, {"0": ql})
+    Q.make_quant(holder, loaded)
     assert isinstance(holder[0], Q.QuantLinear)
 
 

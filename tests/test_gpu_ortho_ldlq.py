@@ -166,3 +166,25 @@ def test_ortho_small_batch_single_launch_path(ops, O, n, rows):
     got = op.apply_rows(xd, transpose=True, out_dtype=torch.float16).float().cpu().numpy()
     want = O.mul_ortho_butterfly(Bnp, x.T.astype(np.float64), transpose=True).T
     assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-3
+
+
+def test_ortho_llama_mlp_dimension_688x16(ops, O):
+    """n = 11008 = 688 * 16 (Llama-2-7B ffn, SURVEY.md section 7): a factor far too large for the single-launch path;
+    the two-stage kernel pads 688 = 43*16 exactly and 16 to one tile.  Kronecker generator (2 Haar matrices) keeps the
+    host-side sampling cheap; forward + transpose vs the oracle, and Q^T Q = I."""
+    from quip_amd import method
+    n = 11008
+    np.random.seed(7)
+    torch.manual_seed(7)
+    Bpp = method.gen_rand_ortho_butterfly_noblock(n)
+    op = ops.OrthoOp(Bpp, DEV)
+    assert (op.p, op.q) == (688, 16) and not op.small_ok
+    Bnp = ([b.numpy() for b in Bpp[0]], Bpp[1].numpy(), Bpp[2].numpy())
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((9, n)).astype(np.float32)
+    xd = torch.from_numpy(x).to(DEV)
+    y = op.apply_rows(xd)
+    want = O.mul_ortho_butterfly(Bnp, x.T.astype(np.float64)).T
+    assert np.linalg.norm(y.cpu().numpy() - want) / np.linalg.norm(want) <= 1e-5
+    back = op.apply_rows(y, transpose=True).cpu().numpy()
+    assert np.abs(back - x).max() <= 1e-4
