@@ -188,3 +188,28 @@ def test_ortho_llama_mlp_dimension_688x16(ops, O):
     assert np.linalg.norm(y.cpu().numpy() - want) / np.linalg.norm(want) <= 1e-5
     back = op.apply_rows(y, transpose=True).cpu().numpy()
     assert np.abs(back - x).max() <= 1e-4
+
+
+def test_ldlq_full_size_properties_4096(ops):
+    """BASELINE config A size (4096x4096, w2), where the CPU oracle would take minutes: size-independent properties.
+    (1) codes on the grid; (2) ROW INDEPENDENCE, bit-exact: rounding any row chunk alone gives the same codes as
+    the whole matrix -- the property the multi-GPU row sharding rests on (quip_amd/shard.py); (3) error workspace
+    = w - q; (4) the proxy loss beats nearest rounding by far on a correlated Hessian."""
+    d = m = 4096
+    bits, maxq = 2, 3
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(d, d, generator=g) / d ** 0.5
+    X = (torch.randn(2 * d, d, generator=g) * torch.arange(1, d + 1) ** -0.75) @ A
+    H = (X.T @ X / (2 * d)).to(DEV)
+    H = H + 0.01 * H.diag().mean() * torch.eye(d, device=DEV)
+    W = (torch.rand(m, d, generator=g) * (maxq + 0.6) - 0.3).clamp(0, maxq).to(DEV)
+    LT = ops.unit_lower_t(torch.linalg.cholesky(H))
+    codes, err = ops.ldlq_round(W, LT, bits, return_err=True)
+    assert int(codes.max()) <= maxq
+    for (a, b) in [(0, 64), (1000, 1016), (4032, 4096), (2048, 3072)]:
+        assert torch.equal(ops.ldlq_round(W[a:b].contiguous(), LT, bits), codes[a:b])
+    assert torch.equal(err, W - codes.float())
+    Hd = H.double()
+    proxy = lambda dw: float(((dw.double() @ Hd) * dw.double()).sum())
+    near = torch.clamp(torch.floor(W + 0.5), 0, maxq)
+    assert proxy(codes.float() - W) < 0.2 * proxy(near - W)
