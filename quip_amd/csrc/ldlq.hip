@@ -10,7 +10,9 @@
 //       phase A  far[16 x 128] = Err[16 x (d-i2)] * L[i2:, i1:i2]  as fp32 MFMA (v_mfma_f32_16x16x4_f32, exact
 //                fp32 fmaf chains): the true lazy-batch GEMM (the reference re-does it per column, :254).
 //                A operand = this workgroup's error rows (global, written by itself), B operand = rows of
-//                LT = L^T streamed from L2 with 16-byte loads; wave w owns column tiles w and w+4.
+//                LT = L^T; both staged per 64-k step into wave-private, XOR-swizzled LDS slabs by full-line buffer
+//                DMA, the next step's DMA in flight under the current step's 32 MFMAs; wave w owns column tiles
+//                w and w+4.
 //       phase B  in-block error feedback, right-looking: wave w owns rows 4w..4w+3, lane = column (2 per lane).
 //                Step i: every lane rounds its own column (only lane i's value is final), the error of
 //                column i is broadcast with v_readlane, and acc[c] = fma(err_i, L[i][c], acc[c]) runs on all
@@ -27,6 +29,8 @@ namespace {
 
 constexpr int BS = 128;        // column block (vector_balance.py:222 blocksize)
 constexpr int LDS_LD = BS + 1; // padded leading dimension of the diagonal-block image
+constexpr int SLAB = 16 * 64 * 4;   // one 16-row x 64-k fp32 operand slab of the far field (4 KiB)
+typedef __attribute__((address_space(3))) void lds_void_t;
 
 struct LdlqArgs {
     const float *W;     // [m,d] grid coordinates
@@ -49,6 +53,7 @@ __global__ __launch_bounds__(256) void ldlq_kernel(LdlqArgs A)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ldiag = smem;                       // [BS][LDS_LD]: Ldiag[i][c] = L[i1+i][i1+c] (c < i), else 0
     float *Ftile = smem + BS * LDS_LD;         // [16][BS] far-field result
+    char *slabs = reinterpret_cast<char *>(smem + BS * LDS_LD + 16 * BS);   // 4 waves x 3 slabs x 4 KiB (16-byte aligned)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -88,31 +93,73 @@ __global__ __launch_bounds__(256) void ldlq_kernel(LdlqArgs A)
         }
 
         // ---- phase A: far field on the fp32 matrix pipe ---------------------------------------------------
+        // far[16 x 128] = Err[16 x (d - i2)] * L[i2:, i1:i2]; wave w owns column tiles w and w + 4 (16 columns each).
+        // Operands go through wave-private LDS slabs filled by buffer DMA in FULL 256-byte row segments (fragment-shaped
+        // global loads -- 16 rows x 64 B per instruction -- kept this phase at 2.0 ms of 2.6 at 4096^2, request-rate
+        // bound; deeper register prefetch made it worse).  Per 64-k step a wave stages three 16 x 64 slabs (its copy
+        // of the error rows, LT rows of tile 0, of tile 1), XOR-swizzled through the DMA's source address so the
+        // ds_read_b128 fragment reads are conflict free; the fragments of a step are read into registers, THEN the next
+        // step's DMA is issued, so it flies under the 32 MFMAs.  k order inside the accumulation is unchanged
+        // (sub-step ss, lane group kq, element s -> k = k0 + 16 ss + 4 kq + s): still bit-exact with the oracle.
         {
-            const int64_t arow = r0 + fr;
-            const bool avalid = arow < A.m;
-            const float *ap = A.E + (avalid ? arow : 0) * d + 4 * kq;
             const int t0 = wave, t1 = wave + 4;
             const bool v0 = t0 < ntile, v1 = t1 < ntile;
-            const float *bp0 = A.LT + (i1 + (v0 ? t0 : 0) * 16 + fr) * d + 4 * kq;
-            const float *bp1 = A.LT + (i1 + (v1 ? t1 : 0) * 16 + fr) * d + 4 * kq;
             f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            if (v0) {
-#pragma unroll 2
-                for (int64_t j0 = i2; j0 < d; j0 += 16) {
-                    float4 a = *reinterpret_cast<const float4 *>(ap + j0);
-                    if (!avalid) a = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float4 b0 = *reinterpret_cast<const float4 *>(bp0 + j0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
-                    if (v1) {
-                        const float4 b1 = *reinterpret_cast<const float4 *>(bp1 + j0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+            if (v0 && i2 < d) {
+                char *sl = slabs + wave * (3 * SLAB);                               // [A | B0 | B1], 4 KiB each
+                // buffer descriptors: error rows of this workgroup; LT rows of the block (offsets stay < 2^32)
+                const int64_t erows = (A.m - r0) < 16 ? (A.m - r0) : 16;
+                __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc((void *)(A.E + r0 * d), 0, (int)(erows * d * 4), 0x00020000);
+                __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void *)(A.LT + i1 * d), 0, (int)((int64_t)cnt * d * 4), 0x00020000);
+                // DMA instruction q (0..3) moves rows 4q .. 4q+3: lane L -> row 4q + (L >> 4), physical 16-B column L & 15,
+                // logical column (L & 15) ^ row  (k = k0 + 4 * logical column)
+                const uint32_t drow = lane >> 4, dpc = lane & 15;
+                // fragment read: lane (n = fr, kq), sub-step ss -> logical column 4 ss + kq at row n
+                uint32_t rd[4];
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss) rd[ss] = fr * 256 + ((((4 * ss + kq) ^ fr) & 15) << 4);
+                const uint32_t OOB = 0xfffffff0u;
+                auto issue = [&](int64_t k0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t row = 4 * q + drow;
+                        const uint32_t kcol = (uint32_t)k0 + 4 * ((dpc ^ row) & 15);
+                        const bool kin = kcol < (uint32_t)d;
+                        const uint32_t off = kin ? (row * (uint32_t)d + kcol) * 4u : OOB;      // out of range reads 0
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ers, (lds_void_t *)(sl + q * 1024), 16, off, 0, 0, 0);
+                        const uint32_t off0 = kin ? ((16 * t0 + row) * (uint32_t)d + kcol) * 4u : OOB;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void_t *)(sl + SLAB + q * 1024), 16, off0, 0, 0, 0);
+                        if (v1) {
+                            const uint32_t off1 = kin ? ((16 * t1 + row) * (uint32_t)d + kcol) * 4u : OOB;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void_t *)(sl + 2 * SLAB + q * 1024), 16, off1, 0, 0, 0);
+                        }
+                    }
+                };
+                issue(i2);
+                for (int64_t k0 = i2; k0 < d; k0 += 64) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // wave-private slabs: no barrier
+                    float4 fa[4], fb0[4], fb1[4];
+#pragma unroll
+                    for (int ss = 0; ss < 4; ++ss) {
+                        fa[ss] = *reinterpret_cast<const float4 *>(sl + rd[ss]);
+                        fb0[ss] = *reinterpret_cast<const float4 *>(sl + SLAB + rd[ss]);
+                        fb1[ss] = v1 ? *reinterpret_cast<const float4 *>(sl + 2 * SLAB + rd[ss]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // slab reads retired before it is refilled
+                    if (k0 + 64 < d) issue(k0 + 64);
+#pragma unroll
+                    for (int ss = 0; ss < 4; ++ss) {
+                        if (k0 + 16 * ss >= d) break;                               // wave-uniform; padded k would only add 0*0
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].x, fb0[ss].x, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].y, fb0[ss].y, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].z, fb0[ss].z, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].w, fb0[ss].w, acc0, 0, 0, 0);
+                        if (v1) {
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].x, fb1[ss].x, acc1, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].y, fb1[ss].y, acc1, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].z, fb1[ss].z, acc1, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].w, fb1[ss].w, acc1, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -217,7 +264,7 @@ extern "C" int quipamd_ldlq_round(const float *Wgrid, const float *LT, const flo
     LdlqArgs A;
     A.W = Wgrid; A.LT = LT; A.eta = eta; A.codes = codes; A.E = err_ws; A.m = m; A.d = d;
     A.maxq = (float)((1 << bits) - 1);
-    const size_t lds = (size_t)(BS * LDS_LD + 16 * BS) * sizeof(float);
+    const size_t lds = (size_t)(BS * LDS_LD + 16 * BS) * sizeof(float) + 4 * 3 * SLAB;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)ldlq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
