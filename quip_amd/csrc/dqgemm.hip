@@ -449,6 +449,48 @@ __global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(const uint16_
         }
         return lv;
     };
+    if constexpr (DEPTH == 1) {
+        // straight form (measured 6 % faster than the generic pipelined loop below when HBM latency is exposed:
+        // scripts/_ab_k2.py A/B, 5.26 vs 5.60 us at 4096^2 cold)
+#pragma unroll 1
+        for (uint32_t k0 = k_lo; k0 < k_hi; k0 += CW) {
+            const uint32_t kc = k0 + c;
+            const bool live = kc < k_hi;                               // wave-uniform
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (live) {
+                if (!QA_ABL(4)) w = (qw + ((uint64_t)rt * nkc + kc) * 64)[lane];
+                if (!QA_ABL(1))
+#pragma unroll
+                for (int q = 0; q < DPW; ++q) {
+                    const int i = r * DPW + q;
+                    if ((i & 1) && e.bs <= 8) continue;             // rows 8..15 feed batch columns that are never stored
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t *)(slab + i * 1024), 16, (i & 1) ? voff_hi : voff_lo,
+                                                             kc * ROWB + (i >> 1) * 128, 0, 0);
+                }
+            }
+            wait_vmcnt(0);
+            if constexpr (RT > 1) __syncthreads();                     // slab c complete (RT waves contributed)
+            if (QA_ABL(2)) { QA_KEEP(w.x); QA_KEEP(w.y); QA_KEEP(w.z); QA_KEEP(w.w); }
+            else if (live) {
+                uint4 xf[Q::NT];
+#pragma unroll
+                for (int t = 0; t < Q::NT; ++t)
+                    xf[t] = *reinterpret_cast<const uint4 *>(slab + (t >> 1) * 2048 + ((t & 1) ? rd1 : rd0));
+#pragma unroll
+                for (int t = 0; t < Q::NT; ++t) {
+                    Frag a, bb;
+                    a.u = Q::frag(w, t);
+                    bb.u = xf[t];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bb.v, acc, 0, 0, 0);
+                    if (r == 0) xs = dot_ones(xf[t], xs);            // one wave per chunk keeps the row sums of x
+                }
+            }
+            if (k0 + CW < k_hi) {                                      // every read of the slabs retired before the next DMA
+                if constexpr (RT > 1) __syncthreads();
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+    } else {
     int buf = 0;
     uint4 w_nxt;
     bool live_nxt = issue(k_lo, 0, w_nxt);
@@ -466,9 +508,7 @@ __global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(const uint16_
                 xf[t] = *reinterpret_cast<const uint4 *>(sl + (t >> 1) * 2048 + ((t & 1) ? rd1 : rd0));
         }
         const bool more = k0 + CW < k_hi;
-        if constexpr (DEPTH == 2) {
-            if (more) { live_nxt = issue(k0 + CW, buf ^ 1, w_nxt); buf ^= 1; }
-        }
+        if (more) { live_nxt = issue(k0 + CW, buf ^ 1, w_nxt); buf ^= 1; }
         if (QA_ABL(2)) { QA_KEEP(w.x); QA_KEEP(w.y); QA_KEEP(w.z); QA_KEEP(w.w); }
         else if (live) {
 #pragma unroll
@@ -480,13 +520,7 @@ __global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(const uint16_
                 if (r == 0) xs = dot_ones(xf[t], xs);            // one wave per chunk keeps the row sums of x
             }
         }
-        if constexpr (DEPTH == 1) {
-            if (more) {                                            // every read of the slab retired before the next DMA lands
-                if constexpr (RT > 1) __syncthreads();
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                live_nxt = issue(k0 + CW, 0, w_nxt);
-            }
-        }
+    }
     }
 
     // ---- meet in LDS: the CW chunk partials of each row tile ---------------------------------------------------------
