@@ -97,6 +97,14 @@ int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *qweight, int
                          const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
                          int accumulate, int64_t bs, int64_t m, int64_t d, void *stream);
 
+/* quipamd_dequant_gemm_grouped: ngroups (1..4) independent problems of IDENTICAL shape (bs, m, d, bits, qfn, dtypes) in
+ * one launch -- the q / k / v projections of a decoder block.  Every pointer argument of quipamd_dequant_gemm becomes a
+ * HOST array of ngroups device pointers (zero / bias may be NULL arrays or hold NULL entries as in the single call). */
+int quipamd_dequant_gemm_grouped(int ngroups, const void *const *x, int x_dtype, const int32_t *const *qweight, int bits,
+                                 int layout, int qfn, const float *const *scale, const float *const *zero,
+                                 const float *const *bias, void *const *y, int y_dtype, int accumulate, int64_t bs,
+                                 int64_t m, int64_t d, void *stream);
+
 /* Tuning hook for benchmarks: force the K2 workgroup shape (row tiles per workgroup, batch tiles per wave,
  * waves per workgroup, k-slices over workgroups); 0 = leave that parameter to the built-in shape heuristic.
  * bt != 0 selects the multi-batch-tile kernel also for bs <= 16; `split` carries two fields, split % 100 = k-slices
@@ -141,6 +149,33 @@ int quipamd_ortho_apply_small(const float *M0, const float *M1, const int32_t *l
                               int p, int q, int b_first, const float *colscale, const float *bias,
                               const void *x, int x_dtype, int64_t ldx, void *out, int out_dtype, int64_t ldo,
                               int64_t rows, void *stream);
+
+/* One small-batch operator application with the elementwise work of its neighbours in the decoder block fused in
+ * (a decode step is launch-latency bound):  out = [relu]( Q . ( colscale * [LayerNorm](x) ) + bias + residual ).
+ * Fields as in quipamd_ortho_apply_small; ln_gamma / ln_beta (dtype ln_dtype, NULL = no LayerNorm, statistics in
+ * fp32 over the row with ln_eps); residual ([rows, n], leading dimension ldo, dtype res_dtype, NULL = none). */
+typedef struct quipamd_small_op {
+    const float *M0, *M1;
+    const int32_t *load_idx, *store_idx;
+    int p, q, b_first;
+    const float *colscale, *bias;
+    const void *ln_gamma, *ln_beta;
+    float ln_eps;
+    int ln_dtype;
+    const void *residual;
+    int res_dtype;
+    int relu;
+    const void *x;
+    int x_dtype;
+    int64_t ldx;
+    void *out;
+    int out_dtype;
+    int64_t ldo;
+} quipamd_small_op;
+#define QUIPAMD_SMALL_MAX_OPS 4
+/* nops (1..4) independent ops in ONE launch (the q / k / v projections of a block share their input): `ops` is a HOST
+ * array; all ops must share p, q and the dtypes; every op is applied to `rows` rows. */
+int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int nops, int64_t rows, void *stream);
 
 /* ---- K4: LDLQ rounding -------------------------------------------------------------------------
  * Replaces round_ldl / round_ldl_block (vector_balance.py:155-199, 218-257; n_greedy_passes = 0):

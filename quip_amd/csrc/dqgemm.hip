@@ -380,11 +380,22 @@ __global__ __launch_bounds__(64 * NW) void dqgemm_kernel(const uint16_t *__restr
 // partial results are added into y with fp32 atomics -- only legal under the reference's in-place-accumulate
 // contract (y fp32, pre-filled by the caller with the bias: quant.py:226-230), where it cuts the x bytes every
 // CU has to ingest by S (at m = 4096 a full-K workgroup ingests all 128 KiB of x for 16 KiB of weights).
+// up to 4 independent problems of identical shape in one launch (blockIdx.y): the q / k / v projections of a block
+struct TileGroup {
+    const uint16_t *x[4];
+    const uint4 *qw[4];
+    const float *scale[4], *zero[4], *bias[4];
+    void *y[4];
+};
+
 template <int BITS, int RT, int CW, int DEPTH>
-__global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(const uint16_t *__restrict__ x,
-                                                                   const uint4 *__restrict__ qw, EpiArgs e, int64_t d,
-                                                                   uint32_t cps)
+__global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(TileGroup G, EpiArgs e0, int64_t d, uint32_t cps)
 {
+    const int gi = blockIdx.y;
+    const uint16_t *__restrict__ x = G.x[gi];
+    const uint4 *__restrict__ qw = G.qw[gi];
+    EpiArgs e = e0;
+    e.scale = G.scale[gi]; e.zero = G.zero[gi]; e.bias = G.bias[gi]; e.y = G.y[gi];
     // NOTE on code shape (measured with scripts/probe_k2.hip): a wave issues roughly one instruction per 5 cycles, so
     // the per-wave instruction count of each phase is what a microsecond-scale launch pays for; rolling the loops to
     // shrink code did NOT help (instruction fetch is not the limit) and serialised LDS latency, so the compute is
@@ -573,7 +584,7 @@ __global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(const uint16_
 }
 
 template <int BITS, int RT, int CW, int DEPTH>
-int launch_tile(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, int S, hipStream_t s)
+int launch_tile(const TileGroup &G, int ngroups, const EpiArgs &e, int64_t d, int S, hipStream_t s)
 {
     typedef Deq<BITS> Q;
     constexpr int XB = 16 * Q::KC * 2;
@@ -589,7 +600,7 @@ int launch_tile(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d,
     const uint32_t nkc = (uint32_t)(d / Q::KC);
     const uint32_t cps = (nkc + S - 1) / S;
     const unsigned gz = (nkc + cps - 1) / cps;
-    kern<<<dim3((unsigned)(e.m / 16 / RT), 1, gz), 64 * RT * CW, lds, s>>>(x, qw, e, d, cps);
+    kern<<<dim3((unsigned)(e.m / 16 / RT), (unsigned)ngroups, gz), 64 * RT * CW, lds, s>>>(G, e, d, cps);
     QA_LAUNCH_CHECK("quipamd_dequant_gemm");
     return QUIPAMD_OK;
 }
@@ -621,13 +632,29 @@ int launch_cfg(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, 
 int g_tune_rt = 0, g_tune_bt = 0, g_tune_nw = 0, g_tune_split = 0, g_tune_depth = 0;
 
 #define QA_K2_CASE(RT_, BT_, NW_) \
-    if (rt == RT_ && bt == BT_ && nw == NW_) return launch_cfg<BITS, RT_, BT_, NW_>(x, qw, e, d, s)
+    if (rt == RT_ && bt == BT_ && nw == NW_) return launch_cfg_each<BITS, RT_, BT_, NW_>(G, ngroups, e, d, s)
 
 // Shape heuristic.  BT: as many batch tiles per wave as the batch has (weights streamed once per 64 batch
 // rows).  RT: row tiles per workgroup -- more rows per workgroup means fewer x bytes into the chip
 // (every workgroup ingests the whole x), but the grid must still cover the 256 CUs.
 template <int BITS>
-int launch(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, hipStream_t s)
+int launch(const TileGroup &G, int ngroups, const EpiArgs &e0, int64_t d, hipStream_t s);
+
+// one problem of a group through the non-grouped kernels
+template <int BITS, int RT, int BT, int NW>
+int launch_cfg_each(const TileGroup &G, int ngroups, const EpiArgs &e0, int64_t d, hipStream_t s)
+{
+    for (int gi = 0; gi < ngroups; ++gi) {
+        EpiArgs e = e0;
+        e.scale = G.scale[gi]; e.zero = G.zero[gi]; e.bias = G.bias[gi]; e.y = G.y[gi];
+        const int rc = launch_cfg<BITS, RT, BT, NW>(G.x[gi], G.qw[gi], e, d, s);
+        if (rc) return rc;
+    }
+    return QUIPAMD_OK;
+}
+
+template <int BITS>
+int launch(const TileGroup &G, int ngroups, const EpiArgs &e, int64_t d, hipStream_t s)
 {
     const int64_t ntile = e.m / 16;
     const int64_t nb = (e.bs + 15) / 16;
@@ -641,9 +668,9 @@ int launch(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, hipS
         // small m: the tile kernel (all of a CU's bytes in flight at once, parallel reducers, optional split-K).
         const bool tuned = g_tune_rt != 0 || g_tune_nw != 0 || g_tune_split != 0 || g_tune_depth != 0;
         int rt = 1, cw = 8, S = 1;
-        if (!tuned && ntile % 4 == 0 && ntile >= 1024) return launch_cfg<BITS, 4, 1, 8>(x, qw, e, d, s);
-        if (!tuned && ntile % 4 == 0 && ntile >= 640 && nkc >= 16) return launch_cfg<BITS, 4, 1, 16>(x, qw, e, d, s);
-        if (!tuned && ntile % 2 == 0 && ntile >= 384 && nkc >= 24) return launch_cfg<BITS, 2, 1, 16>(x, qw, e, d, s);
+        if (!tuned && ntile % 4 == 0 && ntile >= 1024) return launch_cfg_each<BITS, 4, 1, 8>(G, ngroups, e, d, s);
+        if (!tuned && ntile % 4 == 0 && ntile >= 640 && nkc >= 16) return launch_cfg_each<BITS, 4, 1, 16>(G, ngroups, e, d, s);
+        if (!tuned && ntile % 2 == 0 && ntile >= 384 && nkc >= 24) return launch_cfg_each<BITS, 2, 1, 16>(G, ngroups, e, d, s);
         if (can_split && ntile % 2 == 0 && ntile / 2 < 256) {
             // small m under the accumulate contract: 8-wave workgroups (several resident per CU), k split over
             // workgroups until there are ~512 of them (measured best at 4096x4096: rt 2, cw 4, S 4)
@@ -662,8 +689,8 @@ int launch(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, hipS
         if (g_tune_depth > 0) depth = g_tune_depth;
 #define QA_K2T_CASE(RT_, CW_) \
         if (rt == RT_ && cw == CW_) { \
-            if (depth == 1) return launch_tile<BITS, RT_, CW_, 1>(x, qw, e, d, S, s); \
-            if constexpr ((size_t)CW_ * 2 * 16 * Deq<BITS>::KC * 2 <= 128 * 1024) { if (depth == 2) return launch_tile<BITS, RT_, CW_, 2>(x, qw, e, d, S, s); } \
+            if (depth == 1) return launch_tile<BITS, RT_, CW_, 1>(G, ngroups, e, d, S, s); \
+            if constexpr ((size_t)CW_ * 2 * 16 * Deq<BITS>::KC * 2 <= 128 * 1024) { if (depth == 2) return launch_tile<BITS, RT_, CW_, 2>(G, ngroups, e, d, S, s); } \
             return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: depth %d does not fit LDS for cw=%d", depth, cw); \
         }
         QA_K2T_CASE(1, 16) QA_K2T_CASE(1, 8) QA_K2T_CASE(1, 4) QA_K2T_CASE(1, 2) QA_K2T_CASE(1, 1) QA_K2T_CASE(2, 1)
@@ -702,28 +729,53 @@ extern "C" int quipamd_tune_dequant_gemm(int rt, int bt, int nw, int split)
     return QUIPAMD_OK;
 }
 
-extern "C" int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *qweight, int bits, int layout, int qfn,
-                                    const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
-                                    int accumulate, int64_t bs, int64_t m, int64_t d, void *stream)
+static int dequant_gemm_impl(int ngroups, const void *const *x, int x_dtype, const int32_t *const *qweight, int bits, int layout, int qfn,
+                             const float *const *scale, const float *const *zero, const float *const *bias, void *const *y, int y_dtype,
+                             int accumulate, int64_t bs, int64_t m, int64_t d, void *stream)
 {
-    QA_REQUIRE(x && qweight && scale && y, QUIPAMD_ERR_ARG, "dequant_gemm: null pointer");
+    QA_REQUIRE(ngroups >= 1 && ngroups <= 4, QUIPAMD_ERR_ARG, "dequant_gemm: 1..4 problems per call");
     QA_REQUIRE(x_dtype == QUIPAMD_BF16, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: x must be bf16");
     QA_REQUIRE(y_dtype == QUIPAMD_BF16 || y_dtype == QUIPAMD_F32, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: y must be bf16 or f32");
     QA_REQUIRE(!accumulate || y_dtype == QUIPAMD_F32, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: accumulate needs f32 y");
     QA_REQUIRE(layout == QUIPAMD_LAYOUT_STREAM, QUIPAMD_ERR_UNSUPPORTED,
                "dequant_gemm: qweight must be in STREAM layout (repack with quipamd_unpack/quipamd_pack)");
     QA_REQUIRE(bits == 2 || bits == 4, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: bits must be 2 or 4");
-    QA_REQUIRE(qfn == QUIPAMD_QFN_B || (qfn == QUIPAMD_QFN_A && zero), QUIPAMD_ERR_ARG, "dequant_gemm: qfn a needs zero; qfn must be a or b");
+    QA_REQUIRE(qfn == QUIPAMD_QFN_B || qfn == QUIPAMD_QFN_A, QUIPAMD_ERR_ARG, "dequant_gemm: qfn must be a or b");
     QA_REQUIRE(bs * d * 2 < ((int64_t)1 << 31) && m * d * bits / 8 < ((int64_t)1 << 40), QUIPAMD_ERR_SHAPE,
                "dequant_gemm: x larger than 2 GiB is not supported by the 32-bit buffer offsets (bs=%lld d=%lld)", (long long)bs, (long long)d);
     QA_REQUIRE(m % 16 == 0 && d % (512 / bits) == 0, QUIPAMD_ERR_SHAPE,
                "dequant_gemm: needs m %% 16 == 0 and d %% %d == 0 (m=%lld d=%lld)", 512 / bits, (long long)m, (long long)d);
+    TileGroup G;
+    for (int gi = 0; gi < 4; ++gi) {
+        const int k = gi < ngroups ? gi : 0;
+        QA_REQUIRE(x[k] && qweight[k] && scale[k] && y[k], QUIPAMD_ERR_ARG, "dequant_gemm: null pointer (problem %d)", k);
+        QA_REQUIRE(qfn == QUIPAMD_QFN_B || (zero && zero[k]), QUIPAMD_ERR_ARG, "dequant_gemm: qfn a needs zero");
+        G.x[gi] = (const uint16_t *)x[k]; G.qw[gi] = (const uint4 *)qweight[k];
+        G.scale[gi] = scale[k]; G.zero[gi] = zero ? zero[k] : nullptr; G.bias[gi] = bias ? bias[k] : nullptr; G.y[gi] = y[k];
+    }
     if (bs == 0 || m == 0) return QUIPAMD_OK;
     EpiArgs e;
-    e.scale = scale; e.zero = zero; e.bias = bias; e.y = y;
+    e.scale = G.scale[0]; e.zero = G.zero[0]; e.bias = G.bias[0]; e.y = G.y[0];
     e.qfn = qfn; e.maxq = (1 << bits) - 1; e.two_over_maxq = 2.0f / (float)e.maxq; e.y_f32 = (y_dtype == QUIPAMD_F32); e.accumulate = accumulate;
     e.bs = bs; e.m = m;
     hipStream_t s = (hipStream_t)stream;
-    if (bits == 2) return launch<2>((const uint16_t *)x, (const uint4 *)qweight, e, d, s);
-    return launch<4>((const uint16_t *)x, (const uint4 *)qweight, e, d, s);
+    if (bits == 2) return launch<2>(G, ngroups, e, d, s);
+    return launch<4>(G, ngroups, e, d, s);
+}
+
+extern "C" int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *qweight, int bits, int layout, int qfn,
+                                    const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
+                                    int accumulate, int64_t bs, int64_t m, int64_t d, void *stream)
+{
+    QA_REQUIRE(x && qweight && scale && y, QUIPAMD_ERR_ARG, "dequant_gemm: null pointer");
+    return dequant_gemm_impl(1, &x, x_dtype, &qweight, bits, layout, qfn, &scale, &zero, &bias, &y, y_dtype, accumulate, bs, m, d, stream);
+}
+
+extern "C" int quipamd_dequant_gemm_grouped(int ngroups, const void *const *x, int x_dtype, const int32_t *const *qweight, int bits,
+                                            int layout, int qfn, const float *const *scale, const float *const *zero,
+                                            const float *const *bias, void *const *y, int y_dtype, int accumulate, int64_t bs,
+                                            int64_t m, int64_t d, void *stream)
+{
+    QA_REQUIRE(x && qweight && scale && y, QUIPAMD_ERR_ARG, "dequant_gemm_grouped: null pointer array");
+    return dequant_gemm_impl(ngroups, x, x_dtype, qweight, bits, layout, qfn, scale, zero, bias, y, y_dtype, accumulate, bs, m, d, stream);
 }

@@ -15,29 +15,44 @@
 
 namespace {
 
-struct SmallArgs {
-    const float *M0;          // [p][p]  out a, in a'
-    const float *M1;          // [q][q]  out b, in b'
-    const int32_t *ld_idx;    // input element k lands at z position ld_idx[k]      (null: k)
-    const int32_t *st_idx;    // output element k is taken from z position st_idx[k] (null: k)
-    const float *colscale;    // [n] or null, applied to the input
-    const float *bias;        // [n] or null, added to the output
-    const void *x;
-    void *out;
-    int64_t ldx, ldo;
-    int p, q, b_first;
+typedef quipamd_small_op SmallArgs;        // include/quip_amd.h
+
+struct SmallBatch {
+    SmallArgs op[QUIPAMD_SMALL_MAX_OPS];        // blockIdx.y selects the op; all ops share p, q and the dtypes
 };
+
+__device__ __forceinline__ float load_any(const void *p, int dt, int64_t i)
+{
+    return dt == QUIPAMD_F32 ? ((const float *)p)[i] : dt == QUIPAMD_F16 ? f16_bits_to_f32(((const uint16_t *)p)[i])
+                                                                         : bf16_bits_to_f32(((const uint16_t *)p)[i]);
+}
+
+// block-wide sum over 1024 threads (16 waves): wave shuffle + one LDS round
+__device__ __forceinline__ float block_sum(float v, float *red /* [16] */)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = red[threadIdx.x & 15];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    __syncthreads();
+    return t;
+}
 
 // image layout: z[a][b] at a*QS + b, QS = q + 4 (16-byte aligned rows, spreads the ds_read_b128 of stage b over banks)
 template <class TI, class TO>
-__global__ __launch_bounds__(1024) void ortho_small_kernel(SmallArgs A)
+__global__ __launch_bounds__(1024) void ortho_small_kernel(SmallBatch Bt)
 {
+    const SmallArgs &A = Bt.op[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int p = A.p, q = A.q, n = p * q, QS = q + 4;
     float *F0 = smem;                    // [p][p]
     float *F1 = F0 + p * p;              // [q][q]
     float *Z0 = F1 + q * q;              // [p][QS]
     float *Z1 = Z0 + p * QS;             // [p][QS]
+    float *red = Z1 + p * QS;            // [16] block reduction scratch
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -46,12 +61,44 @@ __global__ __launch_bounds__(1024) void ortho_small_kernel(SmallArgs A)
     // ---- load: factors (coalesced float4) and the row (coalesced, scattered into the image) ------------------------
     for (int i = tid; i < p * p / 4; i += 1024) reinterpret_cast<float4 *>(F0)[i] = reinterpret_cast<const float4 *>(A.M0)[i];
     for (int i = tid; i < q * q / 4; i += 1024) reinterpret_cast<float4 *>(F1)[i] = reinterpret_cast<const float4 *>(A.M1)[i];
-    for (int k = tid; k < n; k += 1024) {
-        float v = DT<TI>::load(A.x, row * A.ldx + k);
-        if (A.colscale) v *= A.colscale[k];
-        const int pos = A.ld_idx ? A.ld_idx[k] : k;
-        const int a = pos / q, b = pos - a * q;
-        Z0[a * QS + b] = v;
+    // row elements k = tid + 1024*u live in registers (n <= 16384 -> at most 16 per thread) so that an optional
+    // LayerNorm (fp32 statistics over the row, like torch) can run before the scale + scatter
+    constexpr int MAXE = 16;
+    float xv[MAXE];
+#pragma unroll
+    for (int u = 0; u < MAXE; ++u) {
+        const int k = tid + 1024 * u;
+        xv[u] = k < n ? DT<TI>::load(A.x, row * A.ldx + k) : 0.f;
+    }
+    if (A.ln_gamma) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) s1 += xv[u];
+        const float mean = block_sum(s1, red) / (float)n;
+        float s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) {
+            const int k = tid + 1024 * u;
+            const float dlt = k < n ? xv[u] - mean : 0.f;
+            s2 += dlt * dlt;
+        }
+        const float rstd = rsqrtf(block_sum(s2, red) / (float)n + A.ln_eps);
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) {
+            const int k = tid + 1024 * u;
+            if (k < n) xv[u] = (xv[u] - mean) * rstd * load_any(A.ln_gamma, A.ln_dtype, k) + load_any(A.ln_beta, A.ln_dtype, k);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXE; ++u) {
+        const int k = tid + 1024 * u;
+        if (k < n) {
+            float v = xv[u];
+            if (A.colscale) v *= A.colscale[k];
+            const int pos = A.load_idx ? A.load_idx[k] : k;
+            const int a = pos / q, b = pos - a * q;
+            Z0[a * QS + b] = v;
+        }
     }
     __syncthreads();
 
@@ -105,47 +152,56 @@ __global__ __launch_bounds__(1024) void ortho_small_kernel(SmallArgs A)
 
     // ---- store: gather from the image, bias, convert ------------------------------------------------------------------
     for (int k = tid; k < n; k += 1024) {
-        const int pos = A.st_idx ? A.st_idx[k] : k;
+        const int pos = A.store_idx ? A.store_idx[k] : k;
         const int a = pos / q, b = pos - a * q;
         float v = src[a * QS + b];
         if (A.bias) v += A.bias[k];
+        if (A.residual) v += load_any(A.residual, A.res_dtype, row * A.ldo + k);
+        if (A.relu) v = fmaxf(v, 0.f);
         DT<TO>::store(A.out, row * A.ldo + k, v);
     }
 }
 
+size_t small_lds(int p, int q) { return ((size_t)p * p + (size_t)q * q + 2 * (size_t)p * (q + 4) + 16) * 4; }
+
 template <class TI, class TO>
-int launch_small(const SmallArgs &A, int64_t rows, hipStream_t s)
+int launch_small(const SmallBatch &B, int nops, int64_t rows, hipStream_t s)
 {
-    const size_t lds = ((size_t)A.p * A.p + (size_t)A.q * A.q + 2 * (size_t)A.p * (A.q + 4)) * 4;
+    const size_t lds = small_lds(B.op[0].p, B.op[0].q);
     auto kern = ortho_small_kernel<TI, TO>;
     if (lds > 64 * 1024)
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "ortho_apply_small: cannot raise dynamic LDS to %zu", lds);
-    kern<<<(unsigned)rows, 1024, lds, s>>>(A);
+    kern<<<dim3((unsigned)rows, (unsigned)nops), 1024, lds, s>>>(B);
     QA_LAUNCH_CHECK("quipamd_ortho_apply_small");
     return QUIPAMD_OK;
 }
 
 }   // namespace
 
-extern "C" int quipamd_ortho_apply_small(const float *M0, const float *M1, const int32_t *load_idx, const int32_t *store_idx,
-                                         int p, int q, int b_first, const float *colscale, const float *bias,
-                                         const void *x, int x_dtype, int64_t ldx, void *out, int out_dtype, int64_t ldo,
-                                         int64_t rows, void *stream)
+extern "C" int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int nops, int64_t rows, void *stream)
 {
-    QA_REQUIRE(M0 && M1 && x && out, QUIPAMD_ERR_ARG, "ortho_apply_small: null pointer");
+    QA_REQUIRE(ops && nops >= 1 && nops <= QUIPAMD_SMALL_MAX_OPS, QUIPAMD_ERR_ARG, "ortho_apply_small: 1..%d ops", QUIPAMD_SMALL_MAX_OPS);
+    const int p = ops[0].p, q = ops[0].q, x_dtype = ops[0].x_dtype, out_dtype = ops[0].out_dtype;
     QA_REQUIRE(p >= 16 && q >= 16 && p % 16 == 0 && q % 16 == 0, QUIPAMD_ERR_SHAPE,
                "ortho_apply_small: p and q must be multiples of 16 (p=%d q=%d); use quipamd_ortho_apply_rows", p, q);
-    const size_t lds = ((size_t)p * p + (size_t)q * q + 2 * (size_t)p * (q + 4)) * 4;
-    QA_REQUIRE(lds <= 160 * 1024, QUIPAMD_ERR_SHAPE, "ortho_apply_small: factors + row need %zu B of LDS (> 160 KiB)", lds);
-    QA_REQUIRE(ldx >= (int64_t)p * q && ldo >= (int64_t)p * q, QUIPAMD_ERR_SHAPE, "ortho_apply_small: leading dimension < n");
+    QA_REQUIRE(small_lds(p, q) <= 160 * 1024, QUIPAMD_ERR_SHAPE, "ortho_apply_small: factors + row need %zu B of LDS (> 160 KiB)", small_lds(p, q));
+    QA_REQUIRE((int64_t)p * q <= 16 * 1024, QUIPAMD_ERR_SHAPE, "ortho_apply_small: n = %d > 16384", p * q);
     QA_REQUIRE(rows <= 65535, QUIPAMD_ERR_SHAPE, "ortho_apply_small: too many rows");
+    SmallBatch B;
+    for (int i = 0; i < nops; ++i) {
+        const quipamd_small_op &o = ops[i];
+        QA_REQUIRE(o.M0 && o.M1 && o.x && o.out, QUIPAMD_ERR_ARG, "ortho_apply_small: null pointer in op %d", i);
+        QA_REQUIRE(o.p == p && o.q == q && o.x_dtype == x_dtype && o.out_dtype == out_dtype, QUIPAMD_ERR_ARG,
+                   "ortho_apply_small: ops of one launch must share p, q and dtypes (op %d differs)", i);
+        QA_REQUIRE(o.ldx >= (int64_t)p * q && o.ldo >= (int64_t)p * q, QUIPAMD_ERR_SHAPE, "ortho_apply_small: leading dimension < n");
+        QA_REQUIRE(!o.ln_gamma || o.ln_beta, QUIPAMD_ERR_ARG, "ortho_apply_small: LayerNorm needs gamma and beta");
+        B.op[i] = o;
+    }
+    for (int i = nops; i < QUIPAMD_SMALL_MAX_OPS; ++i) B.op[i] = ops[0];
     if (rows == 0) return QUIPAMD_OK;
-    SmallArgs A;
-    A.M0 = M0; A.M1 = M1; A.ld_idx = load_idx; A.st_idx = store_idx; A.colscale = colscale; A.bias = bias;
-    A.x = x; A.out = out; A.ldx = ldx; A.ldo = ldo; A.p = p; A.q = q; A.b_first = b_first;
     hipStream_t s = (hipStream_t)stream;
-#define QA_SMALL_CASE(XI, TI, XO, TO) if (x_dtype == XI && out_dtype == XO) return launch_small<TI, TO>(A, rows, s)
+#define QA_SMALL_CASE(XI, TI, XO, TO) if (x_dtype == XI && out_dtype == XO) return launch_small<TI, TO>(B, nops, rows, s)
     QA_SMALL_CASE(QUIPAMD_F32, F32, QUIPAMD_F32, F32);
     QA_SMALL_CASE(QUIPAMD_F32, F32, QUIPAMD_F16, F16);
     QA_SMALL_CASE(QUIPAMD_F32, F32, QUIPAMD_BF16, BF16);
@@ -157,4 +213,17 @@ extern "C" int quipamd_ortho_apply_small(const float *M0, const float *M1, const
     QA_SMALL_CASE(QUIPAMD_BF16, BF16, QUIPAMD_F32, F32);
 #undef QA_SMALL_CASE
     return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "ortho_apply_small: dtype pair %d -> %d", x_dtype, out_dtype);
+}
+
+extern "C" int quipamd_ortho_apply_small(const float *M0, const float *M1, const int32_t *load_idx, const int32_t *store_idx,
+                                         int p, int q, int b_first, const float *colscale, const float *bias,
+                                         const void *x, int x_dtype, int64_t ldx, void *out, int out_dtype, int64_t ldo,
+                                         int64_t rows, void *stream)
+{
+    quipamd_small_op o;
+    o.M0 = M0; o.M1 = M1; o.load_idx = load_idx; o.store_idx = store_idx; o.p = p; o.q = q; o.b_first = b_first;
+    o.colscale = colscale; o.bias = bias; o.ln_gamma = nullptr; o.ln_beta = nullptr; o.ln_eps = 0.f; o.ln_dtype = QUIPAMD_F32;
+    o.residual = nullptr; o.res_dtype = QUIPAMD_F32; o.relu = 0;
+    o.x = x; o.x_dtype = x_dtype; o.ldx = ldx; o.out = out; o.out_dtype = out_dtype; o.ldo = ldo;
+    return quipamd_ortho_apply_small_ops(&o, 1, rows, stream);
 }

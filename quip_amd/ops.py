@@ -135,7 +135,40 @@ def dequant_gemm(x, qweight, bits, qfn, scale, zero, bias, out=None, out_dtype=t
     return out
 
 
+def dequant_gemm_grouped(xs, qweights, bits, qfn, scales, zeros, outs, m):
+    """ngroups <= 4 problems of identical shape in one launch: xs[i] [bs,d] bf16, outs[i] [bs,m] (fp32 or bf16)."""
+    n = len(xs)
+    bs, d = xs[0].shape
+    vp = ctypes.c_void_p
+    arr = lambda ts: (vp * n)(*[vp(0 if t is None else t.data_ptr()) for t in ts])
+    zs = arr(zeros) if zeros is not None and zeros[0] is not None else None
+    _lib.call("quipamd_dequant_gemm_grouped", n, arr(xs), _dtype(xs[0]), arr(qweights), bits, LAYOUT_STREAM, QFN[qfn], arr(scales),
+              zs, None, arr(outs), _dtype(outs[0]), 0, bs, m, d, _stream())
+    return outs
+
+
 # ------------------------------------------------------------------------------------------------- K3
+class SmallOp(ctypes.Structure):
+    """mirror of `quipamd_small_op` (include/quip_amd.h)."""
+    _fields_ = [("M0", ctypes.c_void_p), ("M1", ctypes.c_void_p), ("load_idx", ctypes.c_void_p), ("store_idx", ctypes.c_void_p),
+                ("p", ctypes.c_int), ("q", ctypes.c_int), ("b_first", ctypes.c_int),
+                ("colscale", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p), ("ln_eps", ctypes.c_float), ("ln_dtype", ctypes.c_int),
+                ("residual", ctypes.c_void_p), ("res_dtype", ctypes.c_int), ("relu", ctypes.c_int),
+                ("x", ctypes.c_void_p), ("x_dtype", ctypes.c_int), ("ldx", ctypes.c_int64),
+                ("out", ctypes.c_void_p), ("out_dtype", ctypes.c_int), ("ldo", ctypes.c_int64)]
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def ortho_small_ops(op_list, rows):
+    """up to 4 fused small-batch operator applications in ONE launch (quipamd_ortho_apply_small_ops)."""
+    arr = (SmallOp * len(op_list))(*op_list)
+    _lib.call("quipamd_ortho_apply_small_ops", ctypes.cast(arr, ctypes.c_void_p), len(op_list), rows, _stream())
+
+
 def _mfma_b_frags(M):
     """M [C, P, P] (out index i, in index k) -> float [C, NT, NT, 64, 4] in v_mfma_f32_16x16x4_f32 B-fragment order
     (include/quip_amd.h): element [c][nt][S][lane][s] = M[c][16 nt + (lane & 15)][16 S + 4 (lane >> 4) + s]."""
@@ -220,6 +253,18 @@ class OrthoOp:
         if bias is not None:
             out += _f32vec(bias, x.device).to(out.dtype)
         return out
+
+    def small_op(self, x, out, transpose=False, colscale=None, bias=None, ln=None, residual=None, relu=False):
+        """descriptor of  out = [relu](Q (colscale * [LayerNorm](x)) + bias + residual)  for ortho_small_ops().
+        ln = (gamma, beta, eps) tensors on the device; every tensor argument must outlive the launch call."""
+        assert self.small_ok and x.stride(1) == 1 and out.stride(1) == 1
+        M0, M1 = self._M[bool(transpose)]
+        ld, st = (self.pout, self.inv_pin) if transpose else (self.inv_pin, self.pout)
+        g, b, eps = ln if ln is not None else (None, None, 0.0)
+        return SmallOp(_ptr(M0), _ptr(M1), _ptr(ld), _ptr(st), self.p, self.q, int(bool(transpose)),
+                       _ptr(colscale), _ptr(bias), _ptr(g), _ptr(b), float(eps), 0 if g is None else _dtype(g),
+                       _ptr(residual), 0 if residual is None else _dtype(residual), int(bool(relu)),
+                       _ptr(x), _dtype(x), x.stride(0), _ptr(out), _dtype(out), out.stride(0))
 
     def apply_cols(self, x, transpose=False):
         """Q @ x for x [n, c] (the reference's mul_ortho_butterfly orientation)."""

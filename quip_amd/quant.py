@@ -210,6 +210,46 @@ class QuantLinear(nn.Module):
         return y.to(x.dtype).reshape(*shape[:-1], self.outfeatures)
 
 
+def _ln_params(ln):
+    return None if ln is None else (ln.weight, ln.bias, ln.eps)
+
+
+def _fusable(ql, rows):
+    return (ql.U is not None and ql.V is not None and ql.U.small_ok and ql.V.small_ok and rows <= ops.OrthoOp.SMALL_ROWS
+            and ql.qfn == 'b')
+
+
+def packed_forward_fused(qls, x, ln=None, residual=None, relu=False):
+    """Forward of 1..4 packed layers that share the input x [rows, d] (q / k / v of a block, or a single layer) in THREE
+    launches total, with the neighbouring elementwise work of the decoder block folded in (a decode step is
+    launch-latency bound):
+        launch 1   xt_i = V_i ( LayerNorm(x) (/) s_i )                     ln: an nn.LayerNorm or None
+        launch 2   y_i  = What_i xt_i                                      grouped fused dequant-GEMM
+        launch 3   out_i = [relu]( U_i^T y_i + bias_i + residual )
+    Returns the list of outputs in x's dtype.  Falls back to the plain forward when a layer has no small-batch
+    operators (then ln / residual / relu are applied with torch ops)."""
+    rows = x.shape[0]
+    assert x.dim() == 2
+    if not all(_fusable(q, rows) for q in qls) or len({(q.infeatures, q.outfeatures, q.bits) for q in qls}) != 1:
+        h = x if ln is None else ln(x)
+        outs = [q(h) for q in qls]
+        if residual is not None:
+            outs = [o + residual for o in outs]
+        return [torch.relu(o) for o in outs] if relu else outs
+    dev, m, d = x.device, qls[0].outfeatures, qls[0].infeatures
+    x = x.contiguous()
+    xts = [torch.empty((rows, d), dtype=torch.bfloat16, device=dev) for _ in qls]
+    lnp = _ln_params(ln)
+    ops.ortho_small_ops([q.V.small_op(x, xt, colscale=q.inv_scaleWH, ln=lnp) for q, xt in zip(qls, xts)], rows)
+    ys = [torch.empty((rows, m), dtype=torch.float32, device=dev) for _ in qls]
+    ops.dequant_gemm_grouped(xts, [q.qweight for q in qls], qls[0].bits, 'b', [q.scales for q in qls], None, ys, m)
+    outs = [torch.empty((rows, m), dtype=x.dtype, device=dev) for _ in qls]
+    res = None if residual is None else residual.contiguous()
+    ops.ortho_small_ops([q.U.small_op(y, o, transpose=True, bias=q.bias, residual=res, relu=relu) for q, y, o in zip(qls, ys, outs)],
+                        rows)
+    return outs
+
+
 def save_packed(layers, path):
     """Packed checkpoint: {dotted module name: QuantLinear} -> one torch file of CPU tensors (replaces the dense fp16
     `torch.save(model.state_dict())` of opt.py:644-646 for the quantised Linears; 2 bits/weight + factors)."""

@@ -29,7 +29,7 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quip_amd import ops, method  # noqa: E402
-from quip_amd.quant import QuantLinear  # noqa: E402
+from quip_amd.quant import QuantLinear, packed_forward_fused  # noqa: E402
 
 
 class Block(nn.Module):
@@ -40,19 +40,26 @@ class Block(nn.Module):
         mk = lambda i, o: nn.Linear(i, o, bias=True, dtype=dtype)
         self.k_proj, self.v_proj, self.q_proj, self.out_proj = mk(h, h), mk(h, h), mk(h, h), mk(h, h)
         self.fc1, self.fc2 = mk(h, ffn), mk(ffn, h)
+        self.fused = False      # packed layers: q/k/v grouped, LayerNorm / residual / ReLU folded into the operator launches
 
     def forward(self, x, kc, vc, pos, mask):
         """x [bs, h]; kc / vc [bs, heads, maxlen, hd]; pos int64 [1] on the device; mask [maxlen] additive."""
         bs = x.shape[0]
-        hn = self.ln1(x)
-        q = self.q_proj(hn).view(bs, self.heads, 1, self.hd)
-        k = self.k_proj(hn).view(bs, self.heads, 1, self.hd)
-        v = self.v_proj(hn).view(bs, self.heads, 1, self.hd)
+        if self.fused:
+            q, k, v = packed_forward_fused([self.q_proj, self.k_proj, self.v_proj], x, ln=self.ln1)
+        else:
+            hn = self.ln1(x)
+            q, k, v = self.q_proj(hn), self.k_proj(hn), self.v_proj(hn)
+        q, k, v = (t.view(bs, self.heads, 1, self.hd) for t in (q, k, v))
         kc.index_copy_(2, pos, k)
         vc.index_copy_(2, pos, v)
         att = torch.matmul(q, kc.transpose(2, 3)) * (1.0 / math.sqrt(self.hd)) + mask        # [bs, heads, 1, maxlen]
         att = torch.softmax(att.float(), -1).to(x.dtype)
         o = torch.matmul(att, vc).reshape(bs, self.h)
+        if self.fused:
+            x = packed_forward_fused([self.out_proj], o, residual=x)[0]
+            hmid = packed_forward_fused([self.fc1], x, ln=self.ln2, relu=True)[0]
+            return packed_forward_fused([self.fc2], hmid, residual=x)[0]
         x = x + self.out_proj(o)
         x = x + self.fc2(F.relu(self.fc1(self.ln2(x))))
         return x
@@ -174,6 +181,11 @@ def main():
     med, mean, logits_q = time_decode(model, args.bs, args.prompt, args.tokens, maxlen, dev, dtype, args.eager)
     out["packed_w%d" % args.bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": args.bs / med, "packed_weight_MB": nbytes / 1e6,
                                       "hbm_bound_tok_per_s": 8e12 / (nbytes + model.tok.weight.numel() * 2)}
+    for blk in model.blocks:
+        blk.fused = True
+    med, mean, logits_f = time_decode(model, args.bs, args.prompt, args.tokens, maxlen, dev, dtype, args.eager)
+    out["packed_w%d_fused" % args.bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": args.bs / med,
+                                            "what": "q/k/v grouped; LayerNorm folded into V(x/s); bias + residual + ReLU folded into U^T y"}
     del twin
     print(json.dumps(out))
 
@@ -189,17 +201,24 @@ def decode_check(layers=2, bits=2):
     twin, _ = pack_model(model, bits, dev)
     torch.manual_seed(1)
     _, _, lq = time_decode(model, 2, 0, 0, 32, dev, dtype, True)
+    for blk in model.blocks:
+        blk.fused = True
+    torch.manual_seed(1)
+    _, _, lf = time_decode(model, 2, 0, 0, 32, dev, dtype, True)
+    for blk in model.blocks:
+        blk.fused = False
     for (li, name), (Wd, b) in twin.items():
         lin = nn.Linear(Wd.shape[1], Wd.shape[0], bias=True, dtype=dtype, device=dev)
         lin.weight.data, lin.bias.data = Wd, b
         setattr(model.blocks[li], name, lin)
     torch.manual_seed(1)
     _, _, ld = time_decode(model, 2, 0, 0, 32, dev, dtype, True)
-    return float((lq - ld).norm() / ld.norm())
+    return float((lq - ld).norm() / ld.norm()), float((lf - ld).norm() / ld.norm())
 
 
 if __name__ == "__main__":
     if "--check" in sys.argv:
-        print(json.dumps({"decode_logits_rel_err_packed_vs_dense_twin": decode_check()}))
+        e1, e2 = decode_check()
+        print(json.dumps({"decode_logits_rel_err_packed_vs_dense_twin": e1, "fused_packed_vs_dense_twin": e2}))
     else:
         main()

@@ -220,3 +220,36 @@ def test_gptq_runs_and_beats_nearest(Q):
         errs[cls.__name__] = meth.error
         assert len(torch.unique(lin.weight.data[0])) <= 16
     assert errs["GPTQ"] < errs["Nearest"]
+
+
+@pytest.mark.parametrize("rows", [1, 5])
+def test_packed_forward_fused_matches_unfused(Q, rows):
+    """q/k/v grouped + LayerNorm-in / residual+ReLU-out fusion (3 launches) == the same maths with separate ops."""
+    from quip_amd import ops, method
+    torch.manual_seed(3)
+    np.random.seed(3)
+    d, m, bits = 2048, 2048, 2
+    qls = []
+    for i in range(3):
+        W = (0.02 * torch.randn(m, d)).half().to(DEV)
+        s = ops.qfnb_scale(W)
+        _, codes = ops.quantize(W, 'b', s, None, 3, want_codes=True)
+        ql = Q.QuantLinear(d, m, bits=bits, qfn='b').to(DEV)
+        ql.pack(codes, s, None, bias=torch.randn(m).to(DEV), scaleWH=(0.5 + torch.rand(d)).to(DEV),
+                U=method.gen_rand_ortho_butterfly_noblock(m), V=method.gen_rand_ortho_butterfly_noblock(d))
+        qls.append(ql)
+    ln = torch.nn.LayerNorm(d).half().to(DEV)
+    ln.weight.data = (1 + 0.1 * torch.randn(d)).half().to(DEV)
+    ln.bias.data = (0.1 * torch.randn(d)).half().to(DEV)
+    x = torch.randn(rows, d).half().to(DEV)
+    res = torch.randn(rows, m).half().to(DEV)
+    with torch.no_grad():
+        fused = Q.packed_forward_fused(qls, x, ln=ln, residual=res, relu=True)
+        h = ln(x)
+        for ql, f in zip(qls, fused):
+            ref = torch.relu(ql(h).float() + res.float())
+            assert f.dtype == x.dtype and f.shape == (rows, m)
+            # the fused path skips the fp16 rounding of the LayerNorm output and of the pre-residual sum
+            assert float((f.float() - ref).norm() / ref.norm()) <= 5e-3
+        single = Q.packed_forward_fused(qls[:1], x)[0]
+        assert float((single.float() - qls[0](x).float()).norm() / qls[0](x).float().norm()) <= 2e-3
