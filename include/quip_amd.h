@@ -144,7 +144,8 @@ int quipamd_ortho_apply_rows(const float *frag_first, const float *frag_second, 
  * b_first = 1 for Q^T.  load_idx: int32 [n] or NULL, input element k lands at z position load_idx[k]
  * (Q: argsort(perm_in); Q^T: perm_out); store_idx: int32 [n] or NULL, output element k is z[store_idx[k]]
  * (Q: perm_out; Q^T: argsort(perm_in)).  colscale / bias: float [n] or NULL (input scale, output offset).
- * Requires p, q multiples of 16 and (p*p + q*q + 2*p*(q+4))*4 bytes <= 160 KiB; otherwise use quipamd_ortho_apply_rows. */
+ * Requires p, q multiples of 16, n <= 16384 and (p*(p+4) + q*(q+4) + 2*p*(q+4) + 16)*4 bytes <= 160 KiB; otherwise use
+ * quipamd_ortho_apply_rows. */
 int quipamd_ortho_apply_small(const float *M0, const float *M1, const int32_t *load_idx, const int32_t *store_idx,
                               int p, int q, int b_first, const float *colscale, const float *bias,
                               const void *x, int x_dtype, int64_t ldx, void *out, int out_dtype, int64_t ldo,

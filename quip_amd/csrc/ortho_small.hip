@@ -9,7 +9,7 @@
 //   stage "b":  z2[a][b] = sum_b' M1[b][b'] z1[a][b']     D[b][a]: A = M1 tile, B = z1^T (ds_read_b128 along b')
 // on v_mfma_f32_16x16x4_f32 (exact fp32).  With one factor matrix per stage the MFMA N dimension is the OTHER index
 // (16 b's or 16 a's of the same row), so a single row already fills the tile.  M0 / M1 are passed already transposed
-// for Q^T, and b_first selects the stage order.  Requires p, q multiples of 16 and (p*p + q*q + 2*n_padded)*4 B <= 160 KiB.
+// for Q^T, and b_first selects the stage order.  Requires p, q multiples of 16 and (p*(p+4) + q*(q+4) + 2*p*(q+4) + 16)*4 B <= 160 KiB.
 // A decode step is launch-latency bound: this turns 2 launches + allocations per apply into 1.
 #include "common.h"
 
@@ -25,6 +25,40 @@ __device__ __forceinline__ float load_any(const void *p, int dt, int64_t i)
 {
     return dt == QUIPAMD_F32 ? ((const float *)p)[i] : dt == QUIPAMD_F16 ? f16_bits_to_f32(((const uint16_t *)p)[i])
                                                                          : bf16_bits_to_f32(((const uint16_t *)p)[i]);
+}
+
+// 4 consecutive elements at element index i (multiple of 4) as fp32
+template <class T> __device__ __forceinline__ float4 load4(const void *p, int64_t i);
+template <> __device__ __forceinline__ float4 load4<F32>(const void *p, int64_t i) { return *reinterpret_cast<const float4 *>((const float *)p + i); }
+template <> __device__ __forceinline__ float4 load4<F16>(const void *p, int64_t i)
+{
+    const uint2 u = *reinterpret_cast<const uint2 *>((const uint16_t *)p + i);
+    return make_float4(f16_bits_to_f32(u.x & 0xffff), f16_bits_to_f32(u.x >> 16), f16_bits_to_f32(u.y & 0xffff), f16_bits_to_f32(u.y >> 16));
+}
+template <> __device__ __forceinline__ float4 load4<BF16>(const void *p, int64_t i)
+{
+    const uint2 u = *reinterpret_cast<const uint2 *>((const uint16_t *)p + i);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float4 load4_any(const void *p, int dt, int64_t i)
+{
+    return dt == QUIPAMD_F32 ? load4<F32>(p, i) : dt == QUIPAMD_F16 ? load4<F16>(p, i) : load4<BF16>(p, i);
+}
+template <class T> __device__ __forceinline__ void store4(void *p, int64_t i, const float4 &v);
+template <> __device__ __forceinline__ void store4<F32>(void *p, int64_t i, const float4 &v) { *reinterpret_cast<float4 *>((float *)p + i) = v; }
+template <> __device__ __forceinline__ void store4<F16>(void *p, int64_t i, const float4 &v)
+{
+    uint2 u;
+    u.x = (uint32_t)f32_to_f16_bits(v.x) | ((uint32_t)f32_to_f16_bits(v.y) << 16);
+    u.y = (uint32_t)f32_to_f16_bits(v.z) | ((uint32_t)f32_to_f16_bits(v.w) << 16);
+    *reinterpret_cast<uint2 *>((uint16_t *)p + i) = u;
+}
+template <> __device__ __forceinline__ void store4<BF16>(void *p, int64_t i, const float4 &v)
+{
+    uint2 u;
+    u.x = (uint32_t)f32_to_bf16_bits(v.x) | ((uint32_t)f32_to_bf16_bits(v.y) << 16);
+    u.y = (uint32_t)f32_to_bf16_bits(v.z) | ((uint32_t)f32_to_bf16_bits(v.w) << 16);
+    *reinterpret_cast<uint2 *>((uint16_t *)p + i) = u;
 }
 
 // block-wide sum over 1024 threads (16 waves): wave shuffle + one LDS round
@@ -48,9 +82,12 @@ __global__ __launch_bounds__(1024) void ortho_small_kernel(SmallBatch Bt)
     const SmallArgs &A = Bt.op[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int p = A.p, q = A.q, n = p * q, QS = q + 4;
-    float *F0 = smem;                    // [p][p]
-    float *F1 = F0 + p * p;              // [q][q]
-    float *Z0 = F1 + q * q;              // [p][QS]
+    // factor rows are PADDED by 4 floats: with the natural strides (256 / 512 B) the 16 rows of every ds_read_b128
+    // A-fragment read sat on one bank group -- a 16-way conflict that made this kernel 19-23 us at n = 8192
+    const int PS0 = p + 4, PS1 = q + 4;
+    float *F0 = smem;                    // [p][PS0]
+    float *F1 = F0 + p * PS0;            // [q][PS1]
+    float *Z0 = F1 + q * PS1;            // [p][QS]
     float *Z1 = Z0 + p * QS;             // [p][QS]
     float *red = Z1 + p * QS;            // [16] block reduction scratch
     const int tid = threadIdx.x;
@@ -59,51 +96,73 @@ __global__ __launch_bounds__(1024) void ortho_small_kernel(SmallBatch Bt)
     const int64_t row = blockIdx.x;
 
     // ---- load: factors (coalesced float4) and the row (coalesced, scattered into the image) ------------------------
-    for (int i = tid; i < p * p / 4; i += 1024) reinterpret_cast<float4 *>(F0)[i] = reinterpret_cast<const float4 *>(A.M0)[i];
-    for (int i = tid; i < q * q / 4; i += 1024) reinterpret_cast<float4 *>(F1)[i] = reinterpret_cast<const float4 *>(A.M1)[i];
-    // row elements k = tid + 1024*u live in registers (n <= 16384 -> at most 16 per thread) so that an optional
-    // LayerNorm (fp32 statistics over the row, like torch) can run before the scale + scatter
-    constexpr int MAXE = 16;
-    float xv[MAXE];
+    for (int i = tid; i < p * p / 4; i += 1024) {
+        const int rr = i / (p / 4), c4 = i - rr * (p / 4);
+        *reinterpret_cast<float4 *>(F0 + rr * PS0 + 4 * c4) = reinterpret_cast<const float4 *>(A.M0)[i];
+    }
+    for (int i = tid; i < q * q / 4; i += 1024) {
+        const int rr = i / (q / 4), c4 = i - rr * (q / 4);
+        *reinterpret_cast<float4 *>(F1 + rr * PS1 + 4 * c4) = reinterpret_cast<const float4 *>(A.M1)[i];
+    }
+    // The row is handled 4 consecutive elements at a time (16-byte loads of x, column scale, LayerNorm parameters and
+    // the permutation): one CU issues every memory instruction of this kernel, so instruction COUNT is the cost
+    // (the element-wise form spent 8 us on ~3000 narrow loads/stores).  Element group v = tid + 1024*u covers
+    // k = 4v .. 4v+3; n <= 16384 -> at most 4 groups per thread.  q is a power of two: pos -> (a, b) by shift / mask.
+    constexpr int MAXV = 4;
+    const int qsh = __builtin_ctz(q), qmask = q - 1, n4 = n >> 2;
+    float4 xv[MAXV];
 #pragma unroll
-    for (int u = 0; u < MAXE; ++u) {
-        const int k = tid + 1024 * u;
-        xv[u] = k < n ? DT<TI>::load(A.x, row * A.ldx + k) : 0.f;
+    for (int u = 0; u < MAXV; ++u) {
+        const int v4 = tid + 1024 * u;
+        xv[u] = v4 < n4 ? load4<TI>(A.x, row * A.ldx + 4 * v4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (A.ln_gamma) {
         float s1 = 0.f;
 #pragma unroll
-        for (int u = 0; u < MAXE; ++u) s1 += xv[u];
+        for (int u = 0; u < MAXV; ++u) s1 += (xv[u].x + xv[u].y) + (xv[u].z + xv[u].w);
         const float mean = block_sum(s1, red) / (float)n;
         float s2 = 0.f;
 #pragma unroll
-        for (int u = 0; u < MAXE; ++u) {
-            const int k = tid + 1024 * u;
-            const float dlt = k < n ? xv[u] - mean : 0.f;
-            s2 += dlt * dlt;
+        for (int u = 0; u < MAXV; ++u) {
+            if (tid + 1024 * u < n4) {
+                const float d0 = xv[u].x - mean, d1 = xv[u].y - mean, d2 = xv[u].z - mean, d3 = xv[u].w - mean;
+                s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
         }
         const float rstd = rsqrtf(block_sum(s2, red) / (float)n + A.ln_eps);
 #pragma unroll
-        for (int u = 0; u < MAXE; ++u) {
-            const int k = tid + 1024 * u;
-            if (k < n) xv[u] = (xv[u] - mean) * rstd * load_any(A.ln_gamma, A.ln_dtype, k) + load_any(A.ln_beta, A.ln_dtype, k);
+        for (int u = 0; u < MAXV; ++u) {
+            const int v4 = tid + 1024 * u;
+            if (v4 < n4) {
+                const float4 gm = load4_any(A.ln_gamma, A.ln_dtype, 4 * v4), bt = load4_any(A.ln_beta, A.ln_dtype, 4 * v4);
+                xv[u] = make_float4((xv[u].x - mean) * rstd * gm.x + bt.x, (xv[u].y - mean) * rstd * gm.y + bt.y,
+                                    (xv[u].z - mean) * rstd * gm.z + bt.z, (xv[u].w - mean) * rstd * gm.w + bt.w);
+            }
         }
     }
 #pragma unroll
-    for (int u = 0; u < MAXE; ++u) {
-        const int k = tid + 1024 * u;
-        if (k < n) {
-            float v = xv[u];
-            if (A.colscale) v *= A.colscale[k];
-            const int pos = A.load_idx ? A.load_idx[k] : k;
-            const int a = pos / q, b = pos - a * q;
-            Z0[a * QS + b] = v;
+    for (int u = 0; u < MAXV; ++u) {
+        const int v4 = tid + 1024 * u;
+        if (v4 < n4) {
+            float4 v = xv[u];
+            if (A.colscale) {
+                const float4 c = *reinterpret_cast<const float4 *>(A.colscale + 4 * v4);
+                v = make_float4(v.x * c.x, v.y * c.y, v.z * c.z, v.w * c.w);
+            }
+            int4 pos = make_int4(4 * v4, 4 * v4 + 1, 4 * v4 + 2, 4 * v4 + 3);
+            if (A.load_idx) pos = *reinterpret_cast<const int4 *>(A.load_idx + 4 * v4);
+            Z0[(pos.x >> qsh) * QS + (pos.x & qmask)] = v.x;
+            Z0[(pos.y >> qsh) * QS + (pos.y & qmask)] = v.y;
+            Z0[(pos.z >> qsh) * QS + (pos.z & qmask)] = v.z;
+            Z0[(pos.w >> qsh) * QS + (pos.w & qmask)] = v.w;
         }
     }
     __syncthreads();
 
     const int j = lane & 15, g = lane >> 4;
     float *src = Z0, *dst = Z1;
+    // NOTE: one row is 2 n (p + q) flops of fp32 MFMA on ONE CU (614 GFLOP/s): 5.1 us at n = 8192 -- the measured floor of
+    // this kernel (ablation: skeleton 4.2 us, stages 8.6 us).  Next step: split-bf16 operands (hi + lo) on the bf16 pipe.
     for (int st = 0; st < 2; ++st) {
         const bool mix_a = (st == 0) != (A.b_first != 0);
         if (mix_a) {
@@ -112,7 +171,7 @@ __global__ __launch_bounds__(1024) void ortho_small_kernel(SmallBatch Bt)
             for (int tile = wave; tile < nat * nbt; tile += 16) {
                 const int at = tile / nbt, bt = tile - at * nbt;
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-                const float *fa = F0 + (16 * at + j) * p + 4 * g;                // A[i = j][k = 16S + 4g + s]
+                const float *fa = F0 + (16 * at + j) * PS0 + 4 * g;              // A[i = j][k = 16S + 4g + s]
                 const float *zb = src + (4 * g) * QS + 16 * bt + j;              // B[k][j] = z[a' = 16S + 4g + s][b]
                 for (int S = 0; S < p / 16; ++S) {
                     const float4 a4 = *reinterpret_cast<const float4 *>(fa + 16 * S);
@@ -132,7 +191,7 @@ __global__ __launch_bounds__(1024) void ortho_small_kernel(SmallBatch Bt)
             for (int tile = wave; tile < nat * nbt; tile += 16) {
                 const int bt = tile / nat, at = tile - bt * nat;
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-                const float *fa = F1 + (16 * bt + j) * q + 4 * g;                // A[i = b][k = b']
+                const float *fa = F1 + (16 * bt + j) * PS1 + 4 * g;              // A[i = b][k = b']
                 const float *zb = src + (16 * at + j) * QS + 4 * g;              // B[k = b'][j = a] = z1[a][b'], 4 consecutive b'
                 for (int S = 0; S < q / 16; ++S) {
                     const float4 a4 = *reinterpret_cast<const float4 *>(fa + 16 * S);
@@ -151,18 +210,30 @@ __global__ __launch_bounds__(1024) void ortho_small_kernel(SmallBatch Bt)
     }
 
     // ---- store: gather from the image, bias, convert ------------------------------------------------------------------
-    for (int k = tid; k < n; k += 1024) {
-        const int pos = A.store_idx ? A.store_idx[k] : k;
-        const int a = pos / q, b = pos - a * q;
-        float v = src[a * QS + b];
-        if (A.bias) v += A.bias[k];
-        if (A.residual) v += load_any(A.residual, A.res_dtype, row * A.ldo + k);
-        if (A.relu) v = fmaxf(v, 0.f);
-        DT<TO>::store(A.out, row * A.ldo + k, v);
+    // epilogue, 4 outputs per step: gather from the image, bias, residual, ReLU, one 8/16-byte store
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int v4 = tid + 1024 * u;
+        if (v4 < n4) {
+            int4 pos = make_int4(4 * v4, 4 * v4 + 1, 4 * v4 + 2, 4 * v4 + 3);
+            if (A.store_idx) pos = *reinterpret_cast<const int4 *>(A.store_idx + 4 * v4);
+            float4 v = make_float4(src[(pos.x >> qsh) * QS + (pos.x & qmask)], src[(pos.y >> qsh) * QS + (pos.y & qmask)],
+                                   src[(pos.z >> qsh) * QS + (pos.z & qmask)], src[(pos.w >> qsh) * QS + (pos.w & qmask)]);
+            if (A.bias) {
+                const float4 c = *reinterpret_cast<const float4 *>(A.bias + 4 * v4);
+                v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
+            }
+            if (A.residual) {
+                const float4 c = load4_any(A.residual, A.res_dtype, row * A.ldo + 4 * v4);
+                v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
+            }
+            if (A.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            store4<TO>(A.out, row * A.ldo + 4 * v4, v);
+        }
     }
 }
 
-size_t small_lds(int p, int q) { return ((size_t)p * p + (size_t)q * q + 2 * (size_t)p * (q + 4) + 16) * 4; }
+size_t small_lds(int p, int q) { return ((size_t)p * (p + 4) + (size_t)q * (q + 4) + 2 * (size_t)p * (q + 4) + 16) * 4; }
 
 template <class TI, class TO>
 int launch_small(const SmallBatch &B, int nops, int64_t rows, hipStream_t s)
@@ -187,6 +258,7 @@ extern "C" int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int no
                "ortho_apply_small: p and q must be multiples of 16 (p=%d q=%d); use quipamd_ortho_apply_rows", p, q);
     QA_REQUIRE(small_lds(p, q) <= 160 * 1024, QUIPAMD_ERR_SHAPE, "ortho_apply_small: factors + row need %zu B of LDS (> 160 KiB)", small_lds(p, q));
     QA_REQUIRE((int64_t)p * q <= 16 * 1024, QUIPAMD_ERR_SHAPE, "ortho_apply_small: n = %d > 16384", p * q);
+    QA_REQUIRE((q & (q - 1)) == 0, QUIPAMD_ERR_SHAPE, "ortho_apply_small: q = %d must be a power of two; use quipamd_ortho_apply_rows", q);
     QA_REQUIRE(rows <= 65535, QUIPAMD_ERR_SHAPE, "ortho_apply_small: too many rows");
     SmallBatch B;
     for (int i = 0; i < nops; ++i) {
@@ -194,7 +266,8 @@ extern "C" int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int no
         QA_REQUIRE(o.M0 && o.M1 && o.x && o.out, QUIPAMD_ERR_ARG, "ortho_apply_small: null pointer in op %d", i);
         QA_REQUIRE(o.p == p && o.q == q && o.x_dtype == x_dtype && o.out_dtype == out_dtype, QUIPAMD_ERR_ARG,
                    "ortho_apply_small: ops of one launch must share p, q and dtypes (op %d differs)", i);
-        QA_REQUIRE(o.ldx >= (int64_t)p * q && o.ldo >= (int64_t)p * q, QUIPAMD_ERR_SHAPE, "ortho_apply_small: leading dimension < n");
+        QA_REQUIRE(o.ldx >= (int64_t)p * q && o.ldo >= (int64_t)p * q && o.ldx % 4 == 0 && o.ldo % 4 == 0, QUIPAMD_ERR_SHAPE,
+                   "ortho_apply_small: leading dimensions must be >= n and multiples of 4");
         QA_REQUIRE(!o.ln_gamma || o.ln_beta, QUIPAMD_ERR_ARG, "ortho_apply_small: LayerNorm needs gamma and beta");
         B.op[i] = o;
     }

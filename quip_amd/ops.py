@@ -207,8 +207,8 @@ class OrthoOp:
         self.inv_pout = None if torch.equal(p_out, ident) else i32(torch.argsort(p_out))
         self.device = device
         # single-launch small-batch path (quipamd_ortho_apply_small): Kronecker factors that fit one workgroup's LDS
-        lds = (self.p * self.p + self.q * self.q + 2 * self.p * (self.q + 4)) * 4
-        self.small_ok = (not self.blocked) and self.p % 16 == 0 and self.q % 16 == 0 and lds <= 160 * 1024
+        lds = (self.p * (self.p + 4) + self.q * (self.q + 4) + 2 * self.p * (self.q + 4) + 16) * 4
+        self.small_ok = (not self.blocked) and self.p % 16 == 0 and self.q % 16 == 0 and lds <= 160 * 1024 and self.n <= 16384 and (self.q & (self.q - 1)) == 0
         if self.small_ok:
             self._M = {False: (B0[0].contiguous(), B1[0].contiguous()),
                        True: (B0[0].t().contiguous(), B1[0].t().contiguous())}
