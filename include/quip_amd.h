@@ -172,6 +172,10 @@ typedef struct quipamd_small_op {
     void *out;
     int out_dtype;
     int64_t ldo;
+    /* optional split-bf16 factors: M0 = M0_hi + M0_lo, M1 = M1_hi + M1_lo as bf16 [p][p] / [q][q] (all four or none).
+     * When given (p, q multiples of 32, q >= p/2) the mix stages run on the bf16 matrix pipe as hi*hi + hi*lo + lo*hi
+     * with fp32 accumulation: ~1e-5 relative error, ~5x the fp32-MFMA rate. */
+    const void *M0_hi, *M0_lo, *M1_hi, *M1_lo;
 } quipamd_small_op;
 #define QUIPAMD_SMALL_MAX_OPS 4
 /* nops (1..4) independent ops in ONE launch (the q / k / v projections of a block share their input): `ops` is a HOST

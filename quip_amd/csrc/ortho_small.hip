@@ -233,11 +233,229 @@ __global__ __launch_bounds__(1024) void ortho_small_kernel(SmallBatch Bt)
     }
 }
 
+// ---- split-bf16 variant ------------------------------------------------------------------------------------------------
+// One row is 2 n (p + q) flops on ONE CU; on the fp32 matrix pipe (614 GFLOP/s per CU) that is 5.1 us at n = 8192, the
+// measured floor of the kernel above.  Here every operand is carried as bf16 hi + lo (v ~ hi + lo to 2^-17): factors are
+// pre-split on the host, the row is split when it is written to LDS, and each 32-deep step is three
+// v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate) -- ~5x the fp32 MFMA rate at ~1e-5 relative error,
+// two orders inside the 1e-3 contract of the projection.  Requires p, q multiples of 32.
+// LDS images (bf16, rows padded by 8 elements = one 16-byte slot):
+//   F0h/F0l [p][p+8], F1h/F1l [q][q+8];  ZA h/l = z^T [q][p+8] (input of "mix a": 8 consecutive a' per lane);
+//   ZB h/l = z [p][q+8] (input of "mix b");  ZF fp32 [p][q+4] (final image) aliases the first stage's input.
+union Frag8 {
+    uint4 u;
+    bf16x8_t v;
+};
+
+__device__ __forceinline__ void split_bf16(float v, uint16_t &hi, uint16_t &lo)
+{
+    hi = f32_to_bf16_bits(v);
+    lo = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));
+}
+
+template <class TI, class TO>
+__global__ __launch_bounds__(1024) void ortho_small_split_kernel(SmallBatch Bt)
+{
+    const SmallArgs &A = Bt.op[blockIdx.y];
+    extern __shared__ __attribute__((aligned(16))) char smemc[];
+    const int p = A.p, q = A.q, n = p * q;
+    const int P8 = p + 8, Q8 = q + 8, QS = q + 4;
+    uint16_t *F0h = reinterpret_cast<uint16_t *>(smemc), *F0l = F0h + p * P8;
+    uint16_t *F1h = F0l + p * P8, *F1l = F1h + q * Q8;
+    uint16_t *ZAh = F1l + q * Q8, *ZAl = ZAh + q * P8;             // [q][P8]
+    uint16_t *ZBh = ZAl + q * P8, *ZBl = ZBh + p * Q8;             // [p][Q8]
+    float *red = reinterpret_cast<float *>(ZBl + p * Q8);          // [16]
+    const bool a_first = A.b_first == 0;
+    float *ZF = reinterpret_cast<float *>(a_first ? ZAh : ZBh);    // final fp32 image over the dead first-stage input
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t row = blockIdx.x;
+
+    // ---- factors: bf16 hi / lo, 8 elements (16 B) per thread step, into padded rows --------------------------------
+    for (int i = tid; i < p * p / 8; i += 1024) {
+        const int rr = i / (p / 8), c8 = i - rr * (p / 8);
+        *reinterpret_cast<uint4 *>(F0h + rr * P8 + 8 * c8) = reinterpret_cast<const uint4 *>(A.M0_hi)[i];
+        *reinterpret_cast<uint4 *>(F0l + rr * P8 + 8 * c8) = reinterpret_cast<const uint4 *>(A.M0_lo)[i];
+    }
+    for (int i = tid; i < q * q / 8; i += 1024) {
+        const int rr = i / (q / 8), c8 = i - rr * (q / 8);
+        *reinterpret_cast<uint4 *>(F1h + rr * Q8 + 8 * c8) = reinterpret_cast<const uint4 *>(A.M1_hi)[i];
+        *reinterpret_cast<uint4 *>(F1l + rr * Q8 + 8 * c8) = reinterpret_cast<const uint4 *>(A.M1_lo)[i];
+    }
+    // ---- row: 4 consecutive elements per step, optional LayerNorm, scale, split, scatter --------------------------------
+    constexpr int MAXV = 4;
+    const int qsh = __builtin_ctz(q), qmask = q - 1, n4 = n >> 2;
+    float4 xv[MAXV];
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int v4 = tid + 1024 * u;
+        xv[u] = v4 < n4 ? load4<TI>(A.x, row * A.ldx + 4 * v4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (A.ln_gamma) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < MAXV; ++u) s1 += (xv[u].x + xv[u].y) + (xv[u].z + xv[u].w);
+        const float mean = block_sum(s1, red) / (float)n;
+        float s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < MAXV; ++u) {
+            if (tid + 1024 * u < n4) {
+                const float d0 = xv[u].x - mean, d1 = xv[u].y - mean, d2 = xv[u].z - mean, d3 = xv[u].w - mean;
+                s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+        const float rstd = rsqrtf(block_sum(s2, red) / (float)n + A.ln_eps);
+#pragma unroll
+        for (int u = 0; u < MAXV; ++u) {
+            const int v4 = tid + 1024 * u;
+            if (v4 < n4) {
+                const float4 gm = load4_any(A.ln_gamma, A.ln_dtype, 4 * v4), bt = load4_any(A.ln_beta, A.ln_dtype, 4 * v4);
+                xv[u] = make_float4((xv[u].x - mean) * rstd * gm.x + bt.x, (xv[u].y - mean) * rstd * gm.y + bt.y,
+                                    (xv[u].z - mean) * rstd * gm.z + bt.z, (xv[u].w - mean) * rstd * gm.w + bt.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int v4 = tid + 1024 * u;
+        if (v4 < n4) {
+            float4 v = xv[u];
+            if (A.colscale) {
+                const float4 c = *reinterpret_cast<const float4 *>(A.colscale + 4 * v4);
+                v = make_float4(v.x * c.x, v.y * c.y, v.z * c.z, v.w * c.w);
+            }
+            int4 pos = make_int4(4 * v4, 4 * v4 + 1, 4 * v4 + 2, 4 * v4 + 3);
+            if (A.load_idx) pos = *reinterpret_cast<const int4 *>(A.load_idx + 4 * v4);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            const int pp[4] = {pos.x, pos.y, pos.z, pos.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = pp[e] >> qsh, b = pp[e] & qmask;
+                uint16_t hi, lo;
+                split_bf16(vv[e], hi, lo);
+                const int off = a_first ? b * P8 + a : a * Q8 + b;       // z^T for "mix a" first, z for "mix b" first
+                (a_first ? ZAh : ZBh)[off] = hi;
+                (a_first ? ZAl : ZBl)[off] = lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int j = lane & 15, g = lane >> 4;
+    const int nat = p / 16, nbt = q / 16;
+    for (int st = 0; st < 2; ++st) {
+        const bool mix_a = (st == 0) == a_first;
+        const bool last = st == 1;
+        if (mix_a) {
+            // D[a = 16at + 4g + reg][b = 16bt + j] = sum_a' M0[a][a'] z[a'][b];  A = F0 rows, B = z^T rows (ZA)
+            for (int tile = wave; tile < nat * nbt; tile += 16) {
+                const int at = tile / nbt, bt = tile - at * nbt;
+                // three independent accumulator chains (one per product), summed small-to-large at the end
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+                const int fo = (16 * at + j) * P8 + 8 * g, zo = (16 * bt + j) * P8 + 8 * g;
+#pragma unroll 4
+                for (int S = 0; S < p / 32; ++S) {
+                    Frag8 ah, al, bh, bl;
+                    ah.u = *reinterpret_cast<const uint4 *>(F0h + fo + 32 * S);
+                    al.u = *reinterpret_cast<const uint4 *>(F0l + fo + 32 * S);
+                    bh.u = *reinterpret_cast<const uint4 *>(ZAh + zo + 32 * S);
+                    bl.u = *reinterpret_cast<const uint4 *>(ZAl + zo + 32 * S);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, bh.v, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bl.v, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bh.v, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[reg] += acc1[reg] + acc2[reg];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int a = 16 * at + 4 * g + reg, b = 16 * bt + j;
+                    if (last) ZF[a * QS + b] = acc[reg];
+                    else {
+                        uint16_t hi, lo;
+                        split_bf16(acc[reg], hi, lo);
+                        ZBh[a * Q8 + b] = hi;
+                        ZBl[a * Q8 + b] = lo;
+                    }
+                }
+            }
+        } else {
+            // D[b = 16bt + 4g + reg][a = 16at + j] = sum_b' M1[b][b'] z[a][b'];  A = F1 rows, B = z rows (ZB)
+            for (int tile = wave; tile < nat * nbt; tile += 16) {
+                const int bt = tile / nat, at = tile - bt * nat;
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+                const int fo = (16 * bt + j) * Q8 + 8 * g, zo = (16 * at + j) * Q8 + 8 * g;
+#pragma unroll 4
+                for (int S = 0; S < q / 32; ++S) {
+                    Frag8 ah, al, bh, bl;
+                    ah.u = *reinterpret_cast<const uint4 *>(F1h + fo + 32 * S);
+                    al.u = *reinterpret_cast<const uint4 *>(F1l + fo + 32 * S);
+                    bh.u = *reinterpret_cast<const uint4 *>(ZBh + zo + 32 * S);
+                    bl.u = *reinterpret_cast<const uint4 *>(ZBl + zo + 32 * S);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, bh.v, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bl.v, acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bh.v, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[reg] += acc1[reg] + acc2[reg];
+                const int a = 16 * at + j, b0 = 16 * bt + 4 * g;
+                if (last) *reinterpret_cast<float4 *>(ZF + a * QS + b0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                else {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        uint16_t hi, lo;
+                        split_bf16(acc[reg], hi, lo);
+                        ZAh[(b0 + reg) * P8 + a] = hi;
+                        ZAl[(b0 + reg) * P8 + a] = lo;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue, 4 outputs per step ---------------------------------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int v4 = tid + 1024 * u;
+        if (v4 < n4) {
+            int4 pos = make_int4(4 * v4, 4 * v4 + 1, 4 * v4 + 2, 4 * v4 + 3);
+            if (A.store_idx) pos = *reinterpret_cast<const int4 *>(A.store_idx + 4 * v4);
+            float4 v = make_float4(ZF[(pos.x >> qsh) * QS + (pos.x & qmask)], ZF[(pos.y >> qsh) * QS + (pos.y & qmask)],
+                                   ZF[(pos.z >> qsh) * QS + (pos.z & qmask)], ZF[(pos.w >> qsh) * QS + (pos.w & qmask)]);
+            if (A.bias) {
+                const float4 c = *reinterpret_cast<const float4 *>(A.bias + 4 * v4);
+                v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
+            }
+            if (A.residual) {
+                const float4 c = load4_any(A.residual, A.res_dtype, row * A.ldo + 4 * v4);
+                v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
+            }
+            if (A.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            store4<TO>(A.out, row * A.ldo + 4 * v4, v);
+        }
+    }
+}
+
+size_t small_split_lds(int p, int q)
+{
+    return (size_t)2 * (2 * ((size_t)p * (p + 8) + (size_t)q * (q + 8)) + 2 * (size_t)q * (p + 8) + 2 * (size_t)p * (q + 8)) + 64;
+}
+
 size_t small_lds(int p, int q) { return ((size_t)p * (p + 4) + (size_t)q * (q + 4) + 2 * (size_t)p * (q + 4) + 16) * 4; }
 
 template <class TI, class TO>
 int launch_small(const SmallBatch &B, int nops, int64_t rows, hipStream_t s)
 {
+    if (B.op[0].M0_hi) {
+        const size_t lds = small_split_lds(B.op[0].p, B.op[0].q);
+        auto kern = ortho_small_split_kernel<TI, TO>;
+        if (lds > 64 * 1024)
+            if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return qa_fail(QUIPAMD_ERR_LAUNCH, "ortho_apply_small: cannot raise dynamic LDS to %zu", lds);
+        kern<<<dim3((unsigned)rows, (unsigned)nops), 1024, lds, s>>>(B);
+        QA_LAUNCH_CHECK("quipamd_ortho_apply_small");
+        return QUIPAMD_OK;
+    }
     const size_t lds = small_lds(B.op[0].p, B.op[0].q);
     auto kern = ortho_small_kernel<TI, TO>;
     if (lds > 64 * 1024)
@@ -260,9 +478,17 @@ extern "C" int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int no
     QA_REQUIRE((int64_t)p * q <= 16 * 1024, QUIPAMD_ERR_SHAPE, "ortho_apply_small: n = %d > 16384", p * q);
     QA_REQUIRE((q & (q - 1)) == 0, QUIPAMD_ERR_SHAPE, "ortho_apply_small: q = %d must be a power of two; use quipamd_ortho_apply_rows", q);
     QA_REQUIRE(rows <= 65535, QUIPAMD_ERR_SHAPE, "ortho_apply_small: too many rows");
+    const bool split = ops[0].M0_hi != nullptr;
+    if (split) {
+        QA_REQUIRE(p % 32 == 0 && q % 32 == 0, QUIPAMD_ERR_SHAPE, "ortho_apply_small: split-bf16 factors need p, q multiples of 32");
+        QA_REQUIRE(small_split_lds(p, q) <= 160 * 1024 && 2 * q >= p, QUIPAMD_ERR_SHAPE,
+                   "ortho_apply_small: split-bf16 images need %zu B of LDS and q >= p/2", small_split_lds(p, q));
+    }
     SmallBatch B;
     for (int i = 0; i < nops; ++i) {
         const quipamd_small_op &o = ops[i];
+        QA_REQUIRE((o.M0_hi != nullptr) == split && (!split || (o.M0_lo && o.M1_hi && o.M1_lo)), QUIPAMD_ERR_ARG,
+                   "ortho_apply_small: ops of one launch must all carry (or all omit) the four split-bf16 factor arrays");
         QA_REQUIRE(o.M0 && o.M1 && o.x && o.out, QUIPAMD_ERR_ARG, "ortho_apply_small: null pointer in op %d", i);
         QA_REQUIRE(o.p == p && o.q == q && o.x_dtype == x_dtype && o.out_dtype == out_dtype, QUIPAMD_ERR_ARG,
                    "ortho_apply_small: ops of one launch must share p, q and dtypes (op %d differs)", i);
@@ -297,6 +523,7 @@ extern "C" int quipamd_ortho_apply_small(const float *M0, const float *M1, const
     o.M0 = M0; o.M1 = M1; o.load_idx = load_idx; o.store_idx = store_idx; o.p = p; o.q = q; o.b_first = b_first;
     o.colscale = colscale; o.bias = bias; o.ln_gamma = nullptr; o.ln_beta = nullptr; o.ln_eps = 0.f; o.ln_dtype = QUIPAMD_F32;
     o.residual = nullptr; o.res_dtype = QUIPAMD_F32; o.relu = 0;
+    o.M0_hi = o.M0_lo = o.M1_hi = o.M1_lo = nullptr;
     o.x = x; o.x_dtype = x_dtype; o.ldx = ldx; o.out = out; o.out_dtype = out_dtype; o.ldo = ldo;
     return quipamd_ortho_apply_small_ops(&o, 1, rows, stream);
 }

@@ -156,7 +156,8 @@ class SmallOp(ctypes.Structure):
                 ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p), ("ln_eps", ctypes.c_float), ("ln_dtype", ctypes.c_int),
                 ("residual", ctypes.c_void_p), ("res_dtype", ctypes.c_int), ("relu", ctypes.c_int),
                 ("x", ctypes.c_void_p), ("x_dtype", ctypes.c_int), ("ldx", ctypes.c_int64),
-                ("out", ctypes.c_void_p), ("out_dtype", ctypes.c_int), ("ldo", ctypes.c_int64)]
+                ("out", ctypes.c_void_p), ("out_dtype", ctypes.c_int), ("ldo", ctypes.c_int64),
+                ("M0_hi", ctypes.c_void_p), ("M0_lo", ctypes.c_void_p), ("M1_hi", ctypes.c_void_p), ("M1_lo", ctypes.c_void_p)]
 
 
 def _ptr(t):
@@ -208,10 +209,19 @@ class OrthoOp:
         self.device = device
         # single-launch small-batch path (quipamd_ortho_apply_small): Kronecker factors that fit one workgroup's LDS
         lds = (self.p * (self.p + 4) + self.q * (self.q + 4) + 2 * self.p * (self.q + 4) + 16) * 4
+        self.split_ok = False
         self.small_ok = (not self.blocked) and self.p % 16 == 0 and self.q % 16 == 0 and lds <= 160 * 1024 and self.n <= 16384 and (self.q & (self.q - 1)) == 0
         if self.small_ok:
             self._M = {False: (B0[0].contiguous(), B1[0].contiguous()),
                        True: (B0[0].t().contiguous(), B1[0].t().contiguous())}
+            # split-bf16 copies of the factors (hi + lo) for the bf16-pipe variant of the small-batch kernel
+            split_lds = 2 * (2 * (self.p * (self.p + 8) + self.q * (self.q + 8)) + 2 * self.q * (self.p + 8) + 2 * self.p * (self.q + 8)) + 64
+            self.split_ok = self.p % 32 == 0 and self.q % 32 == 0 and 2 * self.q >= self.p and split_lds <= 160 * 1024
+            if self.split_ok:
+                def hl(M):
+                    hi = M.to(torch.bfloat16)
+                    return hi.contiguous(), (M - hi.float()).to(torch.bfloat16).contiguous()
+                self._Msplit = {k: hl(m0) + hl(m1) for k, (m0, m1) in self._M.items()}
 
     def state(self):
         """the reference-style generator tuple ([B0, B1], p_in, p_out) on the CPU -- what a packed checkpoint stores."""
@@ -229,6 +239,7 @@ class OrthoOp:
         return self._frags[transpose]
 
     SMALL_ROWS = 64
+    use_split = True      # small-batch path: split-bf16 factors on the bf16 matrix pipe (~1e-5 rel.) when the shape allows
 
     def apply_rows(self, x, transpose=False, colscale=None, out_dtype=None, bias=None):
         """out[r] = Q x[r] (Q^T if transpose) with x[r] multiplied elementwise by colscale first and bias added last."""
@@ -237,12 +248,8 @@ class OrthoOp:
         rows = x.shape[0]
         out = torch.empty((rows, self.n), dtype=out_dtype or x.dtype, device=x.device)
         cs = _f32vec(colscale, x.device)
-        if self.small_ok and rows <= self.SMALL_ROWS:
-            M0, M1 = self._M[bool(transpose)]
-            ld, st = (self.pout, self.inv_pin) if transpose else (self.inv_pin, self.pout)
-            _lib.call("quipamd_ortho_apply_small", _p(M0), _p(M1), _p(ld), _p(st), self.p, self.q, int(bool(transpose)),
-                      _p(cs), _p(_f32vec(bias, x.device)), _p(x), _dtype(x), x.stride(0), _p(out), _dtype(out), out.stride(0),
-                      rows, _stream())
+        if self.small_ok and rows <= self.SMALL_ROWS and x.stride(0) % 4 == 0:
+            ortho_small_ops([self.small_op(x, out, transpose=transpose, colscale=cs, bias=_f32vec(bias, x.device))], rows)
             return out
         ws = torch.empty((16 * ((rows + 15) // 16), self.n), dtype=torch.float32, device=x.device)
         f1, f2 = self._stage_frags(bool(transpose))
@@ -261,10 +268,12 @@ class OrthoOp:
         M0, M1 = self._M[bool(transpose)]
         ld, st = (self.pout, self.inv_pin) if transpose else (self.inv_pin, self.pout)
         g, b, eps = ln if ln is not None else (None, None, 0.0)
+        sp = self._Msplit[bool(transpose)] if (self.split_ok and self.use_split) else (None, None, None, None)
         return SmallOp(_ptr(M0), _ptr(M1), _ptr(ld), _ptr(st), self.p, self.q, int(bool(transpose)),
                        _ptr(colscale), _ptr(bias), _ptr(g), _ptr(b), float(eps), 0 if g is None else _dtype(g),
                        _ptr(residual), 0 if residual is None else _dtype(residual), int(bool(relu)),
-                       _ptr(x), _dtype(x), x.stride(0), _ptr(out), _dtype(out), out.stride(0))
+                       _ptr(x), _dtype(x), x.stride(0), _ptr(out), _dtype(out), out.stride(0),
+                       _ptr(sp[0]), _ptr(sp[1]), _ptr(sp[2]), _ptr(sp[3]))
 
     def apply_cols(self, x, transpose=False):
         """Q @ x for x [n, c] (the reference's mul_ortho_butterfly orientation)."""

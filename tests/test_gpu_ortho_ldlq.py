@@ -147,17 +147,24 @@ def test_ortho_small_batch_single_launch_path(ops, O, n, rows):
     cs = (0.5 + rng.random(n)).astype(np.float32)
     bias = rng.standard_normal(n).astype(np.float32)
     xd = torch.from_numpy(x).to(DEV)
+    assert op.split_ok
     for tr in (False, True):
         want = O.mul_ortho_butterfly(Bnp, (x * cs).T.astype(np.float64), transpose=tr).T + bias
+        # fp32-MFMA variant: fp32 roundoff; split-bf16 variant (default): hi*hi + hi*lo + lo*hi, ~1e-5
+        op.use_split = False
+        got32 = op.apply_rows(xd, transpose=tr, colscale=torch.from_numpy(cs), bias=torch.from_numpy(bias)).cpu().numpy()
+        op.use_split = True
+        assert np.linalg.norm(got32 - want) / np.linalg.norm(want) <= 1e-5
         got = op.apply_rows(xd, transpose=tr, colscale=torch.from_numpy(cs), bias=torch.from_numpy(bias)).cpu().numpy()
-        assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-5
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 5e-5
+        assert not np.array_equal(got, got32)                     # really a different arithmetic path
         # and it agrees with the general two-stage path
         old, op.SMALL_ROWS = op.SMALL_ROWS, 0
         try:
             gen = op.apply_rows(xd, transpose=tr, colscale=torch.from_numpy(cs), bias=torch.from_numpy(bias)).cpu().numpy()
         finally:
             op.SMALL_ROWS = old
-        assert np.linalg.norm(got - gen) / np.linalg.norm(gen) <= 1e-5
+        assert np.linalg.norm(got - gen) / np.linalg.norm(gen) <= 5e-5
     # dtype pairs of the packed forward: fp16 activations in -> bf16 out (V side), fp32 in -> fp16 out (U side)
     x16 = torch.from_numpy(x).to(DEV).half()
     want = O.mul_ortho_butterfly(Bnp, x16.float().cpu().numpy().T.astype(np.float64)).T
