@@ -13,7 +13,8 @@ launch-bound: a launch is ~2 us of GPU work):
          (bound "mfma"), never presented as an HBM fraction.
 Besides `value` (bf16 y, SURVEY.md 8(d) byte formula) the line carries `accumulate_contract`: the same layer under
 the reference operator's own contract (fp32 y pre-filled by the caller, accumulated in place -- quant.py:226-230),
-where K2 may split K over workgroups with fp32 atomics; and, `sharded_ldlq`: one LDLQ rounding of an OPT-1.3B-fc2-sized
+where K2 may split K over workgroups with fp32 atomics; `decode`: the other half of BASELINE.json's metric, OPT-1.3B w2
+decode tok/s at batch 1 (scripts/decode_opt.py, N=1 only); and `sharded_ldlq`: one LDLQ rounding of an OPT-1.3B-fc2-sized
 Linear with its rows scattered over the N ranks (quip_amd/shard.py; N=1: the kernel alone).
 `roofline.traffic` is the PMC-measured HBM traffic per launch of the last committed rocprofv3 pass
 (profiles/k2_pmc_latest.json, FETCH_SIZE corrected x2 as MI355X_MICROARCH.md prescribes), or null.
@@ -48,6 +49,7 @@ def parse():
     ap.add_argument("--ring", type=int, default=96, help="number of distinct weight copies for the cold regime")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ldlq", action="store_true", help="skip the sharded-LDLQ side measurement")
+    ap.add_argument("--no-decode", action="store_true", help="skip the OPT-1.3B w2 decode tok/s side measurement")
     ap.add_argument("--profile-cold-only", action="store_true",
                     help="for rocprofv3 passes: run only the cold bf16 regime (so per-kernel averages are the headline kernel's)")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of a hipGraph")
@@ -256,6 +258,25 @@ def main():
         out["sharded_ldlq"] = {"what": f"LDLQ codes of one {lm}x{ld} Linear (OPT-1.3B fc2 shape), w{BITS}, rows over {world} rank(s); "
                                        "wall time incl. LT broadcast, row scatter, code gather",
                                "ms": round(tl * 1e3, 3), "far_field_TFLOPs": round(lm * ld * ld / tl / 1e12, 2), "scaling": "strong"}
+
+    # ---- the other half of BASELINE.json's metric: OPT-1.3B w2 decode tok/s on one GPU (configs[2]) -----------------
+    if rank == 0 and world == 1 and not args.no_decode:
+        import importlib.util
+        del ring
+        torch.cuda.empty_cache()
+        spec = importlib.util.spec_from_file_location(
+            "decode_opt", os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "decode_opt.py"))
+        dmod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(dmod)
+        dres = dmod.run(layers=24, bits=BITS, bs=1, prompt=64, tokens=64)
+        out["decode"] = {"metric": "OPT-1.3B w2 (incoherence-processed, packed) decode tok/s, batch 1, one hipGraph per token",
+                         "value": round(dres["packed_w2_fused"]["tok_per_s"], 1), "unit": "tok/s",
+                         "ms_per_token": round(dres["packed_w2_fused"]["ms_per_token_median"], 3),
+                         "unfused_tok_per_s": round(dres["packed_w2"]["tok_per_s"], 1),
+                         "dense_fp16_same_harness_tok_per_s": round(dres["dense_fp16"]["tok_per_s"], 1),
+                         "packed_weight_MB": round(dres["packed_w2"]["packed_weight_MB"], 1),
+                         "hbm_bound_tok_per_s": round(dres["packed_w2"]["hbm_bound_tok_per_s"]),
+                         "data": "random-init OPT-1.3B architecture, nearest-rounded qfn-b codes (scripts/decode_opt.py)"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         Wd = ops.codes_to_weight(codes, "b", scale, None, MAXQ, out_dtype=torch.float32).cpu()

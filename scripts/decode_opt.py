@@ -155,6 +155,36 @@ def time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager):
     return float(np.median(lat)), float(np.mean(lat)), logits_out.float().clone()
 
 
+def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense=True):
+    """build the model, time dense fp16 (optional), packed, and fused-packed decode; returns a dict."""
+    dev, dtype = torch.device("cuda:0"), torch.float16
+    maxlen = prompt + tokens + 8
+    torch.manual_seed(0)
+    model = Decoder(layers=layers, dtype=dtype).to(dev).eval()
+    for p_ in model.parameters():                         # OPT-like init scale keeps activations finite in fp16
+        if p_.dim() > 1:
+            p_.data.normal_(0, 0.02)
+    out = {"config": {"arch": "OPT-1.3B (hidden 2048, ffn 8192, heads 32, vocab 50272)", "layers": layers, "bits": bits,
+                      "bs": bs, "prompt": prompt, "tokens": tokens, "launch": "eager" if eager else "hipGraph",
+                      "weights": "random init, nearest-rounded qfn-b codes, Kronecker U/V, random scaleWH"}}
+    if with_dense:
+        med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+        out["dense_fp16"] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med}
+    twin, nbytes = pack_model(model, bits, dev)
+    del twin
+    med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+    out["packed_w%d" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med, "packed_weight_MB": nbytes / 1e6,
+                                "hbm_bound_tok_per_s": 8e12 / (nbytes + model.tok.weight.numel() * 2)}
+    for blk in model.blocks:
+        blk.fused = True
+    med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+    out["packed_w%d_fused" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+                                      "what": "q/k/v grouped; LayerNorm folded into V(x/s); bias + residual + ReLU folded into U^T y"}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=24)
@@ -164,30 +194,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=128)
     ap.add_argument("--eager", action="store_true")
     args = ap.parse_args()
-    dev, dtype = torch.device("cuda:0"), torch.float16
-    maxlen = args.prompt + args.tokens + 8
-    torch.manual_seed(0)
-    model = Decoder(layers=args.layers, dtype=dtype).to(dev).eval()
-    for p_ in model.parameters():                         # OPT-like init scale keeps activations finite in fp16
-        if p_.dim() > 1:
-            p_.data.normal_(0, 0.02)
-    out = {"config": {"arch": "OPT-1.3B (hidden 2048, ffn 8192, heads 32, vocab 50272)", "layers": args.layers, "bits": args.bits,
-                      "bs": args.bs, "prompt": args.prompt, "tokens": args.tokens, "launch": "eager" if args.eager else "hipGraph",
-                      "weights": "random init, nearest-rounded qfn-b codes, Kronecker U/V, random scaleWH"}}
-    med, mean, _ = time_decode(model, args.bs, args.prompt, args.tokens, maxlen, dev, dtype, args.eager)
-    out["dense_fp16"] = {"ms_per_token_median": med * 1e3, "tok_per_s": args.bs / med}
-
-    twin, nbytes = pack_model(model, args.bits, dev)
-    med, mean, logits_q = time_decode(model, args.bs, args.prompt, args.tokens, maxlen, dev, dtype, args.eager)
-    out["packed_w%d" % args.bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": args.bs / med, "packed_weight_MB": nbytes / 1e6,
-                                      "hbm_bound_tok_per_s": 8e12 / (nbytes + model.tok.weight.numel() * 2)}
-    for blk in model.blocks:
-        blk.fused = True
-    med, mean, logits_f = time_decode(model, args.bs, args.prompt, args.tokens, maxlen, dev, dtype, args.eager)
-    out["packed_w%d_fused" % args.bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": args.bs / med,
-                                            "what": "q/k/v grouped; LayerNorm folded into V(x/s); bias + residual + ReLU folded into U^T y"}
-    del twin
-    print(json.dumps(out))
+    print(json.dumps(run(args.layers, args.bits, args.bs, args.prompt, args.tokens, args.eager)))
 
 
 def decode_check(layers=2, bits=2):
