@@ -14,8 +14,8 @@ launch-bound: a launch is ~2 us of GPU work):
 Besides `value` (bf16 y, SURVEY.md 8(d) byte formula) the line carries `accumulate_contract`: the same layer under
 the reference operator's own contract (fp32 y pre-filled by the caller, accumulated in place -- quant.py:226-230),
 where K2 may split K over workgroups with fp32 atomics; `decode`: the other half of BASELINE.json's metric, OPT-1.3B w2
-decode tok/s at batch 1 (scripts/decode_opt.py, N=1 only); and `sharded_ldlq`: one LDLQ rounding of an OPT-1.3B-fc2-sized
-Linear with its rows scattered over the N ranks (quip_amd/shard.py; N=1: the kernel alone).
+decode tok/s at batch 1 (scripts/decode_opt.py, N=1 only); and `sharded_ldlq`: one LDLQ rounding of an OPT-30B-fc1-sized
+Linear (28672x7168) with its rows scattered over the N ranks (quip_amd/shard.py; N=1: the kernel alone).
 `roofline.traffic` is the PMC-measured HBM traffic per launch of the last committed rocprofv3 pass
 (profiles/k2_pmc_latest.json, FETCH_SIZE corrected x2 as MI355X_MICROARCH.md prescribes), or null.
 `cpu_baseline` = what the reference actually runs at inference (dense fake-quant nn.Linear: torch CPU
@@ -226,38 +226,41 @@ def main():
 
     # ---- sharded LDLQ: rows of one OPT-1.3B-fc2-sized Linear over the N ranks -----------------
     if not args.no_ldlq:
-        from quip_amd import shard
-        lm, ld = 2048, 8192
-        if rank == 0:
-            g = torch.Generator().manual_seed(0)
-            Xc = torch.randn(ld + 256, ld, generator=g).to(dev)
-            Hh = Xc.T @ Xc / (ld + 256)
-            Hh += 0.01 * Hh.diag().mean() * torch.eye(ld, device=dev)
-            LT = ops.unit_lower_t(torch.linalg.cholesky(Hh))
-            wg = (torch.rand(lm, ld, generator=g) * 3.6 - 0.3).clamp(0, 3).to(dev)
-            del Xc, Hh
-        else:
-            LT = wg = None
-        reps = 3
-        ts = []
-        for it in range(reps + 1):
-            barrier()
-            t0 = time.perf_counter()
-            if world > 1:
-                codes_l = shard.ldlq_round_sharded(wg, LT, BITS)
+        try:
+            from quip_amd import shard
+            lm, ld = 28672, 7168          # OPT-30B fc1 (BASELINE configs[4]); 1792 row groups: enough to fill 8 GPUs
+            if rank == 0:
+                g = torch.Generator().manual_seed(0)
+                Xc = torch.randn(ld + 256, ld, generator=g).to(dev)
+                Hh = Xc.T @ Xc / (ld + 256)
+                Hh += 0.01 * Hh.diag().mean() * torch.eye(ld, device=dev)
+                LT = ops.unit_lower_t(torch.linalg.cholesky(Hh))
+                wg = (torch.rand(lm, ld, generator=g) * 3.6 - 0.3).clamp(0, 3).to(dev)
+                del Xc, Hh
             else:
-                codes_l = ops.ldlq_round(wg, LT, BITS)
-            barrier()
-            if it:
-                ts.append(time.perf_counter() - t0)
-        tl = float(np.median(ts))
-        if dist is not None:
-            tt = torch.tensor([tl], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tl = float(tt.item())
-        out["sharded_ldlq"] = {"what": f"LDLQ codes of one {lm}x{ld} Linear (OPT-1.3B fc2 shape), w{BITS}, rows over {world} rank(s); "
-                                       "wall time incl. LT broadcast, row scatter, code gather",
-                               "ms": round(tl * 1e3, 3), "far_field_TFLOPs": round(lm * ld * ld / tl / 1e12, 2), "scaling": "strong"}
+                LT = wg = None
+            reps = 3
+            ts = []
+            for it in range(reps + 1):
+                barrier()
+                t0 = time.perf_counter()
+                if world > 1:
+                    codes_l = shard.ldlq_round_sharded(wg, LT, BITS)
+                else:
+                    codes_l = ops.ldlq_round(wg, LT, BITS)
+                barrier()
+                if it:
+                    ts.append(time.perf_counter() - t0)
+            tl = float(np.median(ts))
+            if dist is not None:
+                tt = torch.tensor([tl], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tl = float(tt.item())
+            out["sharded_ldlq"] = {"what": f"LDLQ codes of one {lm}x{ld} Linear (OPT-30B fc1 shape), w{BITS}, rows over {world} rank(s); "
+                                           "wall time incl. LT broadcast, row scatter, code gather",
+                                   "ms": round(tl * 1e3, 3), "far_field_TFLOPs": round(lm * ld * ld / tl / 1e12, 2), "scaling": "strong"}
+        except Exception as ex:                       # a side measurement must never take the headline line down
+            out["sharded_ldlq"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     # ---- the other half of BASELINE.json's metric: OPT-1.3B w2 decode tok/s on one GPU (configs[2]) -----------------
     if rank == 0 and world == 1 and not args.no_decode:
@@ -268,7 +271,12 @@ def main():
             "decode_opt", os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "decode_opt.py"))
         dmod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(dmod)
-        dres = dmod.run(layers=24, bits=BITS, bs=1, prompt=64, tokens=64)
+        try:
+            dres = dmod.run(layers=24, bits=BITS, bs=1, prompt=64, tokens=64)
+        except Exception as ex:
+            dres = None
+            out["decode"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    if rank == 0 and world == 1 and not args.no_decode and dres is not None:
         out["decode"] = {"metric": "OPT-1.3B w2 (incoherence-processed, packed) decode tok/s, batch 1, one hipGraph per token",
                          "value": round(dres["packed_w2_fused"]["tok_per_s"], 1), "unit": "tok/s",
                          "ms_per_token": round(dres["packed_w2_fused"]["ms_per_token_median"], 3),

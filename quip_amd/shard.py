@@ -11,7 +11,7 @@ What shards and why
         broadcast  LT      [d, d]        fp32   (owner -> all)
         scatter    Wgrid   [m/k, d]      fp32   (owner -> rank r)
         (scatter   eta     [m/k, d]      fp32   only with --unbiased)
-        gather     codes   [m/k, d]      uint8  (rank r -> owner)
+        gather     codes   [m/k, d]      2/4-bit STREAM-packed words (uint8 on the gloo test path)  (rank r -> owner)
     and no all-reduce exists on the path.  xGMI is point-to-point, so scatter/gather from the owner run over
     all 7 links at once; only the LT broadcast is ring/tree-shaped.
   * blocks of the transformer stay sequential (opt.py:172-181), so the owner keeps the model and the block
@@ -56,8 +56,21 @@ def _default_compute(wgrid, LT, bits, eta):
     return ops.ldlq_round(wgrid, LT, bits, eta=eta)
 
 
-def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=None):
+def _pack_chunk(codes, bits):
+    from . import ops
+    return ops.pack(codes, bits, ops.LAYOUT_STREAM)
+
+
+def _unpack_all(words, bits, m, d):
+    from . import ops
+    return ops.unpack(words, bits, ops.LAYOUT_STREAM, m, d)
+
+
+def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=None, gather_packed=None):
     """LDLQ codes of one Linear with its rows split over the ranks of `group`.
+    gather_packed: return the codes to the owner as STREAM-packed words (bits/8 bytes per code instead of 1; the
+    STREAM layout is row-tile-major, so the per-rank chunks concatenate into the whole matrix's packing).  Default:
+    on for the RCCL backend when the shape packs (bits in {2,4}, d a multiple of 512/bits), off otherwise.
 
     Collective: every rank calls it.  On `src`: wgrid float32 [m,d] grid coordinates, LT float32 [d,d]
     (ops.unit_lower_t of the Cholesky factor), eta float32 [m,d] or None; returns codes uint8 [m,d].
@@ -76,6 +89,8 @@ def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=Non
     m, d, bits, has_eta = (int(v) for v in hdr.tolist())
     if world == 1:
         return compute(wgrid, LT, bits, eta)
+    if gather_packed is None:
+        gather_packed = dist.get_backend(group) == "nccl" and bits in (2, 4) and d % (512 // bits) == 0
 
     c = row_chunk(m, world)
     pad = c * world - m
@@ -105,6 +120,13 @@ def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=Non
     if n_real > 0:                                                    # padded rows are never rounded
         codes[:n_real] = compute(mine[:n_real], LT, bits, None if eta_mine is None else eta_mine[:n_real])
 
+    if gather_packed:
+        words = _pack_chunk(codes, bits)                               # c*d*bits/32 int32 words, whole 16-row tiles
+        parts = [torch.empty_like(words) for _ in range(world)] if rank == src else None
+        dist.gather(words, parts, dst=src, group=group)
+        if rank != src:
+            return None
+        return _unpack_all(torch.cat(parts, 0), bits, c * world, d)[:m].contiguous()
     parts = [torch.empty(c, d, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == src else None
     dist.gather(codes, parts, dst=src, group=group)
     if rank != src:

@@ -123,3 +123,18 @@ def test_gridmap_and_codes_to_weight(ops, O, tag, bits):
     np.testing.assert_array_equal(wb.cpu().numpy(), O.codes_to_weight_qfnb(codes, s_ref, maxq))
     wq = ops.codes_to_weight(cd, "a", torch.from_numpy(scale), torch.from_numpy(zero), maxq)
     np.testing.assert_array_equal(wq.cpu().numpy(), O.codes_to_weight_qfna(codes, scale, zero))
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+def test_stream_packing_of_row_chunks_concatenates(ops, bits):
+    """quip_amd/shard.py gathers per-rank STREAM-packed code chunks: packing row chunks (multiples of 16 rows)
+    separately and concatenating must equal packing the whole matrix (STREAM is row-tile-major)."""
+    m, d = 208, 1024
+    g = torch.Generator().manual_seed(bits)
+    codes = torch.randint(0, 2 ** bits, (m, d), generator=g, dtype=torch.uint8).to(DEV)
+    whole = ops.pack(codes, bits, ops.LAYOUT_STREAM)
+    for cuts in ([0, 112, 208], [0, 16, 48, 208], [0, 64, 128, 192, 208]):
+        parts = [ops.pack(codes[a:b].contiguous(), bits, ops.LAYOUT_STREAM) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert torch.equal(torch.cat(parts), whole)
+    from quip_amd import shard
+    assert torch.equal(shard._unpack_all(torch.cat(parts), bits, m, d), codes)
