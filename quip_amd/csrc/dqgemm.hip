@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64 * RT * CW) void dqgemm_tile_kernel(TileGroup G, 
     };
     if constexpr (DEPTH == 1) {
         // straight form (measured 6 % faster than the generic pipelined loop below when HBM latency is exposed:
-        // scripts/_ab_k2.py A/B, 5.26 vs 5.60 us at 4096^2 cold)
+        // same-process A/B against the round-1c source, 5.26 vs 5.60 us at 4096^2 cold)
 #pragma unroll 1
         for (uint32_t k0 = k_lo; k0 < k_hi; k0 += CW) {
             const uint32_t kc = k0 + c;
