@@ -628,6 +628,126 @@ int launch_cfg(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, 
     return QUIPAMD_OK;
 }
 
+// ---- bs >= 32: batched kernel ---------------------------------------------------------------------------------------
+// Workgroup = 4 waves as 2 row groups x 2 batch groups; wave (rg, bg) owns RT row tiles x 2 batch tiles of the
+// (2*RT*16 rows) x (64 batch rows) workgroup tile and walks ALL k-chunks.  Per chunk the 64 x KC slab of x is staged
+// once for the workgroup (each wave DMAs a quarter) into one of two LDS buffers; a wave reads its 2 x NT B fragments into
+// registers, THEN issues its share of the next chunk's DMA (other buffer) and its next weight loads, THEN runs the
+// RT*2*NT MFMAs -- the next chunk flies under the compute, one barrier per chunk.  Every dequantised A fragment feeds 2
+// MFMAs (batch tiles), every B fragment RT MFMAs (row tiles); weights are re-streamed once per 64 batch rows (grid.y).
+template <int BITS, int RT>
+__global__ __launch_bounds__(256) void dqgemm_mb_kernel(const uint16_t *__restrict__ x, const uint4 *__restrict__ qw, EpiArgs e, int64_t d)
+{
+    typedef Deq<BITS> Q;
+    constexpr int KC = Q::KC, NT = Q::NT;
+    constexpr int ROWB = KC * 2, NCB = ROWB / 128, NI = 2 * NCB, XB = 16 * ROWB;   // one 16-batch-row slab
+    constexpr int SLABS = 4;                                                       // 64 batch rows per workgroup
+    extern __shared__ __attribute__((aligned(16))) char smem[];                    // 2 buffers x 4 slabs
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rg = wave >> 1, bg = wave & 1;
+    const int j = lane & 15, g = lane >> 4;
+    const uint32_t nkc = (uint32_t)(d / KC);
+    const uint32_t rt0 = (blockIdx.x * 2 + rg) * RT;               // first row tile of this wave
+    const int64_t brow0 = (int64_t)blockIdx.y * 64;                // first batch row of the workgroup
+    const uint32_t rowbytes = (uint32_t)d * 2u;
+
+    const int64_t rem = (e.bs - brow0) * (int64_t)rowbytes;
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + brow0 * d), 0, (int)rem, 0x00020000);
+    const uint32_t voff_lo = (lane >> 3) * rowbytes + ((uint32_t)((lane & 7) ^ (lane >> 3)) << 4) + (uint32_t)wave * 16u * rowbytes;
+    const uint32_t voff_hi = voff_lo + 8u * rowbytes;
+    const uint32_t rd_base = (j >> 3) * 1024 + (j & 7) * 128;
+    const uint32_t rd0 = rd_base + (((0 + g) ^ (j & 7)) << 4);
+    const uint32_t rd1 = rd_base + (((4 + g) ^ (j & 7)) << 4);
+
+    f32x4_t acc[RT][2];
+    float xs[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < RT; ++r) { acc[r][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[r][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+    // wave `wave` stages slab `wave` (batch rows 16*wave .. +15 of the workgroup) of every chunk
+    auto issue_x = [&](uint32_t kc, int buf) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t *)(smem + (buf * SLABS + wave) * XB + i * 1024), 16,
+                                                     (i & 1) ? voff_hi : voff_lo, kc * ROWB + (i >> 1) * 128, 0, 0);
+    };
+    uint4 w_nxt[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) w_nxt[r] = (qw + ((uint64_t)(rt0 + r) * nkc) * 64)[lane];
+    issue_x(0, 0);
+    int buf = 0;
+#pragma unroll 1
+    for (uint32_t kc = 0; kc < nkc; ++kc) {
+        wait_vmcnt(0);
+        __syncthreads();                                           // chunk kc staged by all 4 waves; buffer buf^1 is free
+        uint4 w[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) w[r] = w_nxt[r];
+        uint4 xf[2][NT];
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt) {
+            const char *sl = smem + (buf * SLABS + 2 * bg + bt) * XB;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xf[bt][t] = *reinterpret_cast<const uint4 *>(sl + (t >> 1) * 2048 + ((t & 1) ? rd1 : rd0));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // fragments are in registers
+        if (kc + 1 < nkc) {                                        // next chunk flies under the MFMAs below
+#pragma unroll
+            for (int r = 0; r < RT; ++r) w_nxt[r] = (qw + ((uint64_t)(rt0 + r) * nkc + kc + 1) * 64)[lane];
+            issue_x(kc + 1, buf ^ 1);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                Frag a, b0, b1;
+                a.u = Q::frag(w[r], t);
+                b0.u = xf[0][t];
+                b1.u = xf[1][t];
+                acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b0.v, acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b1.v, acc[r][1], 0, 0, 0);
+            }
+            if (rg == 0) { xs[0] = dot_ones(xf[0][t], xs[0]); xs[1] = dot_ones(xf[1][t], xs[1]); }
+        }
+        buf ^= 1;
+    }
+    // row sums of x: computed by the rg == 0 waves, handed to their rg == 1 partners through LDS
+    __syncthreads();                                               // all slab reads done: LDS is free
+    float *xsh = reinterpret_cast<float *>(smem);                  // [bg][bt][64]
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt) {
+        xs[bt] += __shfl_xor(xs[bt], 16);
+        xs[bt] += __shfl_xor(xs[bt], 32);
+        if (rg == 0) xsh[(bg * 2 + bt) * 64 + lane] = xs[bt];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt) {
+        const float xsum = xsh[(bg * 2 + bt) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int64_t r0 = (int64_t)(rt0 + r) * 16 + 4 * g;
+            const EpiRow epi = load_epi(e, r0);
+            epilogue_store(e, epi, Q::OFF, acc[r][bt], xsum, brow0 + (2 * bg + bt) * 16 + j, r0);
+        }
+    }
+}
+
+template <int BITS, int RT>
+int launch_mb(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, hipStream_t s)
+{
+    typedef Deq<BITS> Q;
+    constexpr size_t lds = (size_t)2 * 4 * 16 * Q::KC * 2;                          // 64 KiB (2-bit) / 32 KiB (4-bit)
+    auto kern = dqgemm_mb_kernel<BITS, RT>;
+    const int64_t nby = (e.bs + 63) / 64;
+    QA_REQUIRE(nby <= 65535, QUIPAMD_ERR_SHAPE, "dequant_gemm: bs too large for this kernel (%lld)", (long long)e.bs);
+    kern<<<dim3((unsigned)(e.m / 16 / (2 * RT)), (unsigned)nby), 256, lds, s>>>(x, qw, e, d);
+    QA_LAUNCH_CHECK("quipamd_dequant_gemm");
+    return QUIPAMD_OK;
+}
+
 // Tuning override (quipamd_tune_dequant_gemm): 0 = use the shape heuristic.
 int g_tune_rt = 0, g_tune_bt = 0, g_tune_nw = 0, g_tune_split = 0, g_tune_depth = 0;
 
@@ -702,6 +822,22 @@ int launch(const TileGroup &G, int ngroups, const EpiArgs &e, int64_t d, hipStre
     }
     // bs > 16: one batch tile per workgroup (grid.y walks the batch tiles, weights re-streamed from L2 / Infinity Cache)
     // with as many row tiles per wave as the grid allows beat the BT > 1 variants at every swept shape.
+    const int64_t nby64 = (e.bs + 63) / 64;
+    if (g_tune_bt == 0 && g_tune_rt == 0 && g_tune_nw == 0 && ngroups == 1 && !g_tune_depth && ((nby64 >= 2 && ntile >= 512) || (nb >= 3 && ntile >= 1024))) {
+        // batched kernel: (2*RT*16 rows) x 64 batch rows per workgroup; RT by how many workgroups the grid then has.
+        // Wins for bs > 64 on m >= 8192 (or one 64-row batch tile on m >= 16384); on shorter matrices the per-wave kernel,
+        // whose 16 waves split K, is faster (profiles/r01h_k2_batched_sweep.jsonl, r01h_k2_default_config_all_shapes.jsonl).
+        const int64_t nby = nby64;
+        if (ntile % 8 == 0 && (ntile / 8) * nby >= 512) return launch_mb<BITS, 4>(G.x[0], G.qw[0], e, d, s);
+        if (ntile % 4 == 0 && (ntile / 4) * nby >= 256) return launch_mb<BITS, 2>(G.x[0], G.qw[0], e, d, s);
+        if (ntile % 2 == 0) return launch_mb<BITS, 1>(G.x[0], G.qw[0], e, d, s);
+    }
+    if (g_tune_depth == 9 && ngroups == 1) {                      // tuning: force the batched kernel, RT = g_tune_rt
+        if (g_tune_rt == 4 && ntile % 8 == 0) return launch_mb<BITS, 4>(G.x[0], G.qw[0], e, d, s);
+        if (g_tune_rt == 2 && ntile % 4 == 0) return launch_mb<BITS, 2>(G.x[0], G.qw[0], e, d, s);
+        if (g_tune_rt == 1 && ntile % 2 == 0) return launch_mb<BITS, 1>(G.x[0], G.qw[0], e, d, s);
+        return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: batched kernel needs rt in {1,2,4} dividing the row tiles");
+    }
     int rt, bt = 1, nw = 16;
     if (ntile % 4 == 0 && (ntile / 4) * nb >= 128) rt = 4;
     else if (ntile % 2 == 0 && (ntile / 2) * nb >= 128) rt = 2;

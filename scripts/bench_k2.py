@@ -81,15 +81,15 @@ def main():
                             (1, 0, 8, 200), (2, 0, 16, 200), (4, 0, 16, 200), (2, 0, 8, 200), (4, 0, 8, 200), (1, 0, 4, 200),
                             (8, 0, 16), (8, 0, 16, 200), (8, 0, 8), (8, 0, 8, 200), (4, 1, 16), (4, 1, 8), (2, 1, 8), (4, 1, 4)]
                 elif nb == 2:
-                    cfgs = [(0, 0, 0), (1, 2, 8), (2, 2, 8), (1, 2, 4), (2, 2, 4), (1, 1, 16), (2, 1, 16)]
+                    cfgs = [(0, 0, 0), (1, 2, 8), (2, 2, 8), (1, 1, 16), (2, 1, 16), (1, 0, 0, 900), (2, 0, 0, 900), (4, 0, 0, 900)]
                 else:
-                    cfgs = [(0, 0, 0), (1, 4, 4), (2, 4, 4), (1, 2, 8), (2, 2, 8), (1, 1, 16), (2, 1, 16), (4, 1, 16)]
+                    cfgs = [(0, 0, 0), (2, 4, 4), (2, 1, 16), (4, 1, 16), (1, 0, 0, 900), (2, 0, 0, 900), (4, 0, 0, 900)]
                 if args.default_only:
                     cfgs = [(0, 0, 0)]
                 for cfg in cfgs:
                     rt, bt, nw = cfg[:3]
                     sp = cfg[3] if len(cfg) > 3 else 0
-                    if rt and (m // 16) % rt:
+                    if rt and (m // 16) % (rt * (2 if sp == 900 else 1)):
                         continue
                     lib.quipamd_tune_dequant_gemm(rt, bt, nw, sp)
 

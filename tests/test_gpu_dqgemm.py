@@ -185,3 +185,34 @@ def test_llama2_7b_mlp_shapes(ops, O, m, d, bs):
     yacc = torch.zeros(bs, m, device=DEV)
     ops.dequant_gemm(xd, qs, 2, "b", sc, None, None, out=yacc, accumulate=True)
     assert _rel(yacc.cpu().numpy().astype(np.float64), y_ref) <= TOL_F32
+
+
+@pytest.mark.parametrize("bits,qfn", [(2, "b"), (4, "a")])
+@pytest.mark.parametrize("m,d,bs", [(256, 1024, 64), (128, 512, 33), (512, 2048, 100), (1024, 1024, 256)])
+def test_batched_kernel_bs_over_16(ops, O, bits, qfn, m, d, bs):
+    """bs > 16 goes through the batched kernel (shared x slabs, 64 batch rows per workgroup); every RT variant and the
+    default agree with the oracle, ragged batch sizes included."""
+    from quip_amd import _lib
+    W, x, codes, scale, zero, maxq = _case(O, m, d, bs, bits, qfn, seed=m + d + bs)
+    rng = np.random.default_rng(8)
+    bias = rng.standard_normal(m).astype(np.float32)
+    y_ref = O.dequant_linear(x, codes, qfn, scale, zero, maxq, bias)
+    qs = ops.pack(torch.from_numpy(codes).to(DEV), bits, ops.LAYOUT_STREAM)
+    xd = torch.from_numpy(x).to(DEV).to(torch.bfloat16)
+    sc = torch.tensor(np.asarray(scale, np.float32).reshape(-1))
+    zr = None if zero is None else torch.from_numpy(zero)
+    lib = _lib.load()
+    bad = []
+    try:
+        for (rt, sp) in [(0, 0), (1, 900), (2, 900), (4, 900)]:
+            if rt and (m // 16) % (2 * rt):
+                continue
+            lib.quipamd_tune_dequant_gemm(rt, 0, 0, sp)
+            y = ops.dequant_gemm(xd, qs, bits, qfn, sc, zr, torch.from_numpy(bias), out_dtype=torch.float32)
+            if _rel(y.cpu().numpy().astype(np.float64), y_ref) > TOL_F32:
+                bad.append((rt, sp))
+    finally:
+        lib.quipamd_tune_dequant_gemm(0, 0, 0, 0)
+    assert not bad, f"batched-kernel variants with wrong results: {bad}"
+    y16 = ops.dequant_gemm(xd, qs, bits, qfn, sc, zr, torch.from_numpy(bias), out_dtype=torch.bfloat16)
+    assert _rel(y16.float().cpu().numpy().astype(np.float64), y_ref) <= TOL_BF16
