@@ -903,6 +903,7 @@ extern "C" int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *q
                                     const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
                                     int accumulate, int64_t bs, int64_t m, int64_t d, void *stream)
 {
+    if (bs == 0 || m == 0) return QUIPAMD_OK;                      // empty batch: nothing to do (its pointers may be null)
     QA_REQUIRE(x && qweight && scale && y, QUIPAMD_ERR_ARG, "dequant_gemm: null pointer");
     return dequant_gemm_impl(1, &x, x_dtype, &qweight, bits, layout, qfn, &scale, &zero, &bias, &y, y_dtype, accumulate, bs, m, d, stream);
 }
@@ -912,6 +913,7 @@ extern "C" int quipamd_dequant_gemm_grouped(int ngroups, const void *const *x, i
                                             const float *const *bias, void *const *y, int y_dtype, int accumulate, int64_t bs,
                                             int64_t m, int64_t d, void *stream)
 {
+    if (bs == 0 || m == 0) return QUIPAMD_OK;
     QA_REQUIRE(x && qweight && scale && y, QUIPAMD_ERR_ARG, "dequant_gemm_grouped: null pointer array");
     return dequant_gemm_impl(ngroups, x, x_dtype, qweight, bits, layout, qfn, scale, zero, bias, y, y_dtype, accumulate, bs, m, d, stream);
 }

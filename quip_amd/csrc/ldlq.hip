@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void unit_lower_t_kernel(const float *__restri
 extern "C" int quipamd_ldlq_round(const float *Wgrid, const float *LT, const float *eta, int bits, uint8_t *codes,
                                   float *err_ws, int64_t m, int64_t d, void *stream)
 {
+    if (m == 0 || d == 0) return QUIPAMD_OK;
     QA_REQUIRE(Wgrid && LT && codes && err_ws, QUIPAMD_ERR_ARG, "ldlq_round: null pointer");
     QA_REQUIRE(bits >= 1 && bits <= 8, QUIPAMD_ERR_ARG, "ldlq_round: bits out of range");
     QA_REQUIRE(d % 16 == 0, QUIPAMD_ERR_SHAPE, "ldlq_round: needs d %% 16 == 0 (d=%lld)", (long long)d);

@@ -264,6 +264,7 @@ extern "C" int quipamd_ortho_apply_rows(const float *frag_first, const float *fr
                                         const void *x, int x_dtype, int64_t ldx, void *out, int out_dtype, int64_t ldo,
                                         int64_t rows, float *workspace, void *stream)
 {
+    if (rows == 0) return QUIPAMD_OK;
     QA_REQUIRE(frag_first && frag_second && x && out && workspace, QUIPAMD_ERR_ARG, "ortho_apply_rows: null pointer");
     QA_REQUIRE(p >= 1 && q >= 1, QUIPAMD_ERR_SHAPE, "ortho_apply_rows: bad factors p=%d q=%d", p, q);
     const int64_t n = (int64_t)p * q;

@@ -138,3 +138,30 @@ def test_stream_packing_of_row_chunks_concatenates(ops, bits):
         assert torch.equal(torch.cat(parts), whole)
     from quip_amd import shard
     assert torch.equal(shard._unpack_all(torch.cat(parts), bits, m, d), codes)
+
+
+def test_degenerate_and_rejected_calls(ops):
+    """empty batches / zero rows are no-ops, unsupported shapes fail loudly (no silent fallback)."""
+    from quip_amd import method
+    from quip_amd._lib import QuipAmdError
+    codes = torch.randint(0, 4, (32, 512), dtype=torch.uint8).to(DEV)
+    qs = ops.pack(codes, 2, ops.LAYOUT_STREAM)
+    sc = torch.tensor([0.05])
+    y = ops.dequant_gemm(torch.empty(0, 512, dtype=torch.bfloat16, device=DEV), qs, 2, 'b', sc, None, None, m=32)
+    assert y.shape == (0, 32)
+    with pytest.raises(QuipAmdError):                                  # d not a multiple of the 2-bit chunk (256)
+        ops.dequant_gemm(torch.zeros(4, 384, dtype=torch.bfloat16, device=DEV), qs, 2, 'b', sc, None, None, m=32)
+    with pytest.raises(AssertionError):                                # fp16 activations must be converted by the caller
+        ops.dequant_gemm(torch.zeros(4, 512, dtype=torch.float16, device=DEV), qs, 2, 'b', sc, None, None, m=32)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    op = ops.OrthoOp(method.gen_rand_ortho_butterfly(40), DEV)
+    assert op.apply_rows(torch.empty(0, 40, device=DEV)).shape == (0, 40)
+    H = torch.eye(64, device=DEV)
+    LT = ops.unit_lower_t(torch.linalg.cholesky(H))
+    assert ops.ldlq_round(torch.empty(0, 64, device=DEV), LT, 2).shape == (0, 64)
+    with pytest.raises(QuipAmdError):                                  # d must be a multiple of 16
+        ops.ldlq_round(torch.zeros(4, 40, device=DEV), torch.zeros(40, 40, device=DEV), 2)
+    # identity Hessian: LDLQ degenerates to round-to-nearest (no error feedback)
+    W = (torch.rand(8, 64, device=DEV) * 3.6 - 0.3).clamp(0, 3)
+    assert torch.equal(ops.ldlq_round(W, LT, 2).float(), torch.clamp(torch.floor(W + 0.5), 0, 3))
