@@ -84,7 +84,10 @@ void oracle_round_ldl_forward(const float *w, const float *Lf, const float *eta,
  *
  *   for each column block [i1,i2) descending (i1 = max(i2-bs,0)):
  *     far[c]  = fmaf-chain over the already-rounded columns j >= i2.  The chain
- *               visits j in groups of 16 starting at i2; inside a group the
+ *               first visits the columns BEYOND the previous block (j >= i2 + bs,
+ *               which the kernel accumulates while the previous block is still
+ *               being rounded), then the previous block's own columns
+ *               i2 <= j < i2 + bs; both in groups of 16; inside a group the
  *               kernel issues four 16x16x4 fp32 MFMAs u=0..3, MFMA u consuming
  *               k = 4*kq+u for kq=0..3 in that order (an fmaf chain, see
  *               cdna_hip_programming.md "FP32-input MFMA ... Numerics").
@@ -108,12 +111,16 @@ void oracle_round_ldl_kernel_order(const float *w, const float *LT, const float 
             for (int64_t c = 0; c < cnt; ++c) {
                 float f = 0.0f;
                 const float *lt = LT + (i1 + c) * d;
-                for (int64_t j0 = i2; j0 < d; j0 += 16)
-                    for (int u = 0; u < 4; ++u)
-                        for (int kq = 0; kq < 4; ++kq) {
-                            const int64_t j = j0 + 4 * kq + u;
-                            f = fmaf(err[j], lt[j], f);
-                        }
+                const int64_t iprev = i2 + bs < d ? i2 + bs : d;    /* end of the previous block */
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int64_t jb = pass == 0 ? iprev : i2, je = pass == 0 ? d : iprev;
+                    for (int64_t j0 = jb; j0 < je; j0 += 16)
+                        for (int u = 0; u < 4; ++u)
+                            for (int kq = 0; kq < 4; ++kq) {
+                                const int64_t j = j0 + 4 * kq + u;
+                                f = fmaf(err[j], lt[j], f);
+                            }
+                }
                 acc[c] = f;
             }
             for (int64_t i = cnt - 1; i >= 0; --i) {

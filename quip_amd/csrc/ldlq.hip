@@ -4,7 +4,8 @@
 //     for i = d-1 .. 0:  q_i = clamp(floor(w_i + sum_{j>i} (w_j - q_j) L[j,i] + eta_i), 0, 2^b - 1)
 // L = unit-lower Cholesky factor of H (vector_balance.py:171-173).  Rows of W are independent, columns are a
 // length-d dependent chain, so:
-//   * one workgroup (4 waves) owns 16 rows for the WHOLE sweep -- no inter-workgroup communication, one launch;
+//   * one workgroup (8 waves: 4 'chain' + 4 'far') owns 16 rows for the WHOLE sweep -- no inter-workgroup communication,
+//     one launch; the in-block chain of block k overlaps the far field of block k+1;
 //   * columns are processed in 128-wide blocks from the top (the reference's `--lazy_batch` blocking,
 //     vector_balance.py:243-257).  For block [i1,i2):
 //       phase A  far[16 x 128] = Err[16 x (d-i2)] * L[i2:, i1:i2]  as fp32 MFMA (v_mfma_f32_16x16x4_f32, exact
@@ -48,186 +49,209 @@ __device__ __forceinline__ float round_col(float w, float acc, float eta, float 
     return fminf(fmaxf(floorf(x), 0.0f), maxq);
 }
 
-__global__ __launch_bounds__(256) void ldlq_kernel(LdlqArgs A)
+// 8 waves: waves 0-3 ("chain") run the in-block error feedback of block k, waves 4-7 ("far") accumulate the far field
+// of block k+1 at the same time (the part that does not depend on block k: columns >= i2), one VALU-bound and one
+// MFMA-bound job per SIMD.  After a barrier the far waves add block k's own 128 columns and publish Ftile for block k+1
+// while the chain waves stage the next diagonal block of L.  Two barriers per block.
+__global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ldiag = smem;                       // [BS][LDS_LD]: Ldiag[i][c] = L[i1+i][i1+c] (c < i), else 0
-    float *Ftile = smem + BS * LDS_LD;         // [16][BS] far-field result
-    char *slabs = reinterpret_cast<char *>(smem + BS * LDS_LD + 16 * BS);   // 4 waves x 3 slabs x 4 KiB (16-byte aligned)
+    float *Ftile2 = smem + BS * LDS_LD;        // 2 x [16][BS] far-field results (block k is read while k+1 is produced)
+    char *slabs = reinterpret_cast<char *>(smem + BS * LDS_LD + 2 * 16 * BS);   // 4 far waves x 3 slabs x 4 KiB
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool is_chain = wave < 4;
+    const int cw = wave & 3;                               // chain: row group; far: column-tile pair
     const int64_t d = A.d;
     const int64_t r0 = (int64_t)blockIdx.x * 16;
     const int fr = lane & 15, kq = lane >> 4;              // MFMA fragment coordinates
 
+    // ---- diagonal block of L (strictly lower part) -> LDS, by the 256 threads of the chain waves ----------------------
+    // 128 x 128 floats = 16 float4 per thread, all 16 loads issued before the first is consumed (the scalar
+    // one-element-per-iteration form was a 64-deep chain of L2 round trips: 0.53 ms of the 3.0 ms at 4096^2).
+    auto stage_diag = [&](int64_t i1, int cnt) {
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = u * 256 + (int)threadIdx.x;            // 0 .. 4095 = c * 32 + i4  (threadIdx.x < 256 here)
+            const int c = idx >> 5, i = (idx & 31) * 4;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < cnt && i < cnt)                               // cnt is a multiple of 16: a float4 never straddles it
+                v[u] = *reinterpret_cast<const float4 *>(A.LT + (i1 + c) * d + i1 + i);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = u * 256 + (int)threadIdx.x;
+            const int c = idx >> 5, i = (idx & 31) * 4;
+            Ldiag[(i + 0) * LDS_LD + c] = (c < i + 0) ? v[u].x : 0.f;
+            Ldiag[(i + 1) * LDS_LD + c] = (c < i + 1) ? v[u].y : 0.f;
+            Ldiag[(i + 2) * LDS_LD + c] = (c < i + 2) ? v[u].z : 0.f;
+            Ldiag[(i + 3) * LDS_LD + c] = (c < i + 3) ? v[u].w : 0.f;
+        }
+    };
+
+    // ---- far field on the fp32 matrix pipe: acc{0,1}[16 x 16] += Err[16 x (kend - kbeg)] * L[kbeg:kend, columns] --------
+    // for the column block whose LT rows start at nb1 (nbcnt rows); far wave cw owns column tiles cw and cw + 4.
+    // Operands go through wave-private LDS slabs filled by buffer DMA in FULL 256-byte row segments (fragment-shaped
+    // global loads -- 16 rows x 64 B per instruction -- kept this phase request-rate bound; deeper register prefetch made it
+    // worse).  Per 64-k step a wave stages three 16 x 64 slabs (its copy of the error rows, LT rows of tile 0, of tile 1),
+    // XOR-swizzled through the DMA's source address so the ds_read_b128 fragment reads are conflict free; the fragments
+    // of a step are read into registers, THEN the next step's DMA is issued, so it flies under the 32 MFMAs.
+    // k order: step k0 (64 wide), sub-step ss, lane group kq, element s -> k = k0 + 16 ss + 4 kq + s (oracle: ldlq_oracle.c).
+    auto far_accumulate = [&](f32x4_t &acc0, f32x4_t &acc1, int64_t kbeg, int64_t kend, int64_t nb1, int nbcnt) {
+        const int t0 = cw, t1 = cw + 4, nt = nbcnt / 16;
+        const bool v0 = t0 < nt, v1 = t1 < nt;
+        if (!v0 || kbeg >= kend) return;
+        char *sl = slabs + cw * (3 * SLAB);                                         // [A | B0 | B1], 4 KiB each
+        const int64_t erows = (A.m - r0) < 16 ? (A.m - r0) : 16;
+        __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc((void *)(A.E + r0 * d), 0, (int)(erows * d * 4), 0x00020000);
+        __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void *)(A.LT + nb1 * d), 0, (int)((int64_t)nbcnt * d * 4), 0x00020000);
+        // DMA instruction q (0..3) moves rows 4q .. 4q+3: lane L -> row 4q + (L >> 4), physical 16-B column L & 15,
+        // logical column (L & 15) ^ row  (k = k0 + 4 * logical column)
+        const uint32_t drow = lane >> 4, dpc = lane & 15;
+        uint32_t rd[4];
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) rd[ss] = fr * 256 + ((((4 * ss + kq) ^ fr) & 15) << 4);
+        const uint32_t OOB = 0xfffffff0u;
+        auto issue = [&](int64_t k0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t row = 4 * q + drow;
+                const uint32_t kcol = (uint32_t)k0 + 4 * ((dpc ^ row) & 15);
+                const bool kin = kcol < (uint32_t)kend;
+                const uint32_t off = kin ? (row * (uint32_t)d + kcol) * 4u : OOB;          // out of range reads 0
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ers, (lds_void_t *)(sl + q * 1024), 16, off, 0, 0, 0);
+                const uint32_t off0 = kin ? ((16 * t0 + row) * (uint32_t)d + kcol) * 4u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void_t *)(sl + SLAB + q * 1024), 16, off0, 0, 0, 0);
+                if (v1) {
+                    const uint32_t off1 = kin ? ((16 * t1 + row) * (uint32_t)d + kcol) * 4u : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void_t *)(sl + 2 * SLAB + q * 1024), 16, off1, 0, 0, 0);
+                }
+            }
+        };
+        issue(kbeg);
+        for (int64_t k0 = kbeg; k0 < kend; k0 += 64) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // wave-private slabs: no barrier
+            float4 fa[4], fb0[4], fb1[4];
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+                fa[ss] = *reinterpret_cast<const float4 *>(sl + rd[ss]);
+                fb0[ss] = *reinterpret_cast<const float4 *>(sl + SLAB + rd[ss]);
+                fb1[ss] = v1 ? *reinterpret_cast<const float4 *>(sl + 2 * SLAB + rd[ss]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // slab reads retired before it is refilled
+            if (k0 + 64 < kend) issue(k0 + 64);
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+                if (k0 + 16 * ss >= kend) break;                                    // wave-uniform; padded k would only add 0*0
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].x, fb0[ss].x, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].y, fb0[ss].y, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].z, fb0[ss].z, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].w, fb0[ss].w, acc0, 0, 0, 0);
+                if (v1) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].x, fb1[ss].x, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].y, fb1[ss].y, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].z, fb1[ss].z, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].w, fb1[ss].w, acc1, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- in-block sequential error feedback of block [i1, i1 + cnt), chain wave cw = rows 4cw .. 4cw+3 --------------------
+    auto chain = [&](int64_t i1, int cnt, const float *Ftile) {
+        float acc[4][2], wv[4][2], et[4][2];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t row = r0 + 4 * cw + rr;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = lane + 64 * h;
+                const bool ok = (c < cnt) && (row < A.m);
+                acc[rr][h] = (c < cnt) ? Ftile[(4 * cw + rr) * BS + c] : 0.f;
+                wv[rr][h] = ok ? A.W[row * d + i1 + c] : 0.f;
+                et[rr][h] = (ok && A.eta) ? A.eta[row * d + i1 + c] : 0.5f;
+            }
+        }
+        // columns 64..cnt-1 live in register half 1
+        for (int i = cnt - 1; i >= 64; --i) {
+            const int ln = __builtin_amdgcn_readfirstlane(i - 64);
+            const float l0 = Ldiag[i * LDS_LD + lane], l1 = Ldiag[i * LDS_LD + 64 + lane];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float q = round_col(wv[rr][1], acc[rr][1], et[rr][1], A.maxq);
+                const float er = wv[rr][1] - q;
+                const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, er), ln));
+                acc[rr][0] = fmaf(e, l0, acc[rr][0]);
+                acc[rr][1] = fmaf(e, l1, acc[rr][1]);
+            }
+        }
+        const int top0 = cnt < 64 ? cnt : 64;
+        for (int i = top0 - 1; i >= 0; --i) {
+            const int ln = __builtin_amdgcn_readfirstlane(i);
+            const float l0 = Ldiag[i * LDS_LD + lane];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float q = round_col(wv[rr][0], acc[rr][0], et[rr][0], A.maxq);
+                const float er = wv[rr][0] - q;
+                const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, er), ln));
+                acc[rr][0] = fmaf(e, l0, acc[rr][0]);
+            }
+        }
+        // every column is final now (later steps only added err * 0): emit codes and errors
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t row = r0 + 4 * cw + rr;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = lane + 64 * h;
+                if (c < cnt && row < A.m) {
+                    const float q = round_col(wv[rr][h], acc[rr][h], et[rr][h], A.maxq);
+                    A.codes[row * d + i1 + c] = (uint8_t)q;
+                    A.E[row * d + i1 + c] = wv[rr][h] - q;
+                }
+            }
+        }
+    };
+
+    // ---- prologue: first block has no far field -------------------------------------------------------------------------------
+    {
+        const int64_t i1 = d - BS > 0 ? d - BS : 0;
+        if (is_chain) stage_diag(i1, (int)(d - i1));
+        else for (int idx = (int)threadIdx.x - 256; idx < 16 * BS; idx += 256) Ftile2[idx] = 0.f;
+    }
+    __syncthreads();
+    int buf = 0;
     for (int64_t i2 = d; i2 > 0; i2 -= BS) {
         const int64_t i1 = i2 - BS > 0 ? i2 - BS : 0;
         const int cnt = (int)(i2 - i1);
-        const int ntile = cnt / 16;
-
-        // ---- stage the diagonal block of L (strictly lower part) into LDS ----------------------------
-        // 128 x 128 floats = 16 float4 per thread, all 16 loads issued before the first is consumed (the scalar
-        // one-element-per-iteration form was a 64-deep chain of L2 round trips: 0.53 ms of the 3.0 ms at 4096^2).
-        // Thread (c = LT row, i4 = float4 index along i): rows of LT are contiguous, so a wave reads 2 rows x 512 B.
-        {
-            float4 v[16];
+        const bool has_next = i1 > 0;
+        const int64_t n1 = i1 - BS > 0 ? i1 - BS : 0;              // next block [n1, i1)
+        const int ncnt = (int)(i1 - n1);
+        f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // phase X: chain(k)  ||  far(k+1) over the columns that are already final (>= i2)
+        if (is_chain) chain(i1, cnt, Ftile2 + buf * 16 * BS);
+        else if (has_next) far_accumulate(acc0, acc1, i2, d, n1, ncnt);
+        __syncthreads();                                           // block k's errors are written; Ldiag is free
+        // phase Y: stage the next diagonal block  ||  add block k's own columns to far(k+1) and publish it
+        if (has_next) {
+            if (is_chain) stage_diag(n1, ncnt);
+            else {
+                far_accumulate(acc0, acc1, i1, i2, n1, ncnt);
+                float *Fn = Ftile2 + (buf ^ 1) * 16 * BS;
+                const int t0 = cw, t1 = cw + 4, nt = ncnt / 16;
+                // D layout: col = lane & 15, row = 4*(lane>>4) + reg
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int idx = u * 256 + threadIdx.x;             // 0 .. 4095 = c * 32 + i4
-                const int c = idx >> 5, i = (idx & 31) * 4;
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < cnt && i < cnt)                           // cnt is a multiple of 16: a float4 never straddles it
-                    v[u] = *reinterpret_cast<const float4 *>(A.LT + (i1 + c) * d + i1 + i);
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int idx = u * 256 + threadIdx.x;
-                const int c = idx >> 5, i = (idx & 31) * 4;
-                // Ldiag[i][c] = L[i1+i][i1+c] for c < i (strictly lower), else 0
-                Ldiag[(i + 0) * LDS_LD + c] = (c < i + 0) ? v[u].x : 0.f;
-                Ldiag[(i + 1) * LDS_LD + c] = (c < i + 1) ? v[u].y : 0.f;
-                Ldiag[(i + 2) * LDS_LD + c] = (c < i + 2) ? v[u].z : 0.f;
-                Ldiag[(i + 3) * LDS_LD + c] = (c < i + 3) ? v[u].w : 0.f;
-            }
-        }
-
-        // ---- phase A: far field on the fp32 matrix pipe ---------------------------------------------------
-        // far[16 x 128] = Err[16 x (d - i2)] * L[i2:, i1:i2]; wave w owns column tiles w and w + 4 (16 columns each).
-        // Operands go through wave-private LDS slabs filled by buffer DMA in FULL 256-byte row segments (fragment-shaped
-        // global loads -- 16 rows x 64 B per instruction -- kept this phase at 2.0 ms of 2.6 at 4096^2, request-rate
-        // bound; deeper register prefetch made it worse).  Per 64-k step a wave stages three 16 x 64 slabs (its copy
-        // of the error rows, LT rows of tile 0, of tile 1), XOR-swizzled through the DMA's source address so the
-        // ds_read_b128 fragment reads are conflict free; the fragments of a step are read into registers, THEN the next
-        // step's DMA is issued, so it flies under the 32 MFMAs.  k order inside the accumulation is unchanged
-        // (sub-step ss, lane group kq, element s -> k = k0 + 16 ss + 4 kq + s): still bit-exact with the oracle.
-        {
-            const int t0 = wave, t1 = wave + 4;
-            const bool v0 = t0 < ntile, v1 = t1 < ntile;
-            f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            if (v0 && i2 < d) {
-                char *sl = slabs + wave * (3 * SLAB);                               // [A | B0 | B1], 4 KiB each
-                // buffer descriptors: error rows of this workgroup; LT rows of the block (offsets stay < 2^32)
-                const int64_t erows = (A.m - r0) < 16 ? (A.m - r0) : 16;
-                __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc((void *)(A.E + r0 * d), 0, (int)(erows * d * 4), 0x00020000);
-                __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void *)(A.LT + i1 * d), 0, (int)((int64_t)cnt * d * 4), 0x00020000);
-                // DMA instruction q (0..3) moves rows 4q .. 4q+3: lane L -> row 4q + (L >> 4), physical 16-B column L & 15,
-                // logical column (L & 15) ^ row  (k = k0 + 4 * logical column)
-                const uint32_t drow = lane >> 4, dpc = lane & 15;
-                // fragment read: lane (n = fr, kq), sub-step ss -> logical column 4 ss + kq at row n
-                uint32_t rd[4];
-#pragma unroll
-                for (int ss = 0; ss < 4; ++ss) rd[ss] = fr * 256 + ((((4 * ss + kq) ^ fr) & 15) << 4);
-                const uint32_t OOB = 0xfffffff0u;
-                auto issue = [&](int64_t k0) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t row = 4 * q + drow;
-                        const uint32_t kcol = (uint32_t)k0 + 4 * ((dpc ^ row) & 15);
-                        const bool kin = kcol < (uint32_t)d;
-                        const uint32_t off = kin ? (row * (uint32_t)d + kcol) * 4u : OOB;      // out of range reads 0
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ers, (lds_void_t *)(sl + q * 1024), 16, off, 0, 0, 0);
-                        const uint32_t off0 = kin ? ((16 * t0 + row) * (uint32_t)d + kcol) * 4u : OOB;
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void_t *)(sl + SLAB + q * 1024), 16, off0, 0, 0, 0);
-                        if (v1) {
-                            const uint32_t off1 = kin ? ((16 * t1 + row) * (uint32_t)d + kcol) * 4u : OOB;
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void_t *)(sl + 2 * SLAB + q * 1024), 16, off1, 0, 0, 0);
-                        }
-                    }
-                };
-                issue(i2);
-                for (int64_t k0 = i2; k0 < d; k0 += 64) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // wave-private slabs: no barrier
-                    float4 fa[4], fb0[4], fb1[4];
-#pragma unroll
-                    for (int ss = 0; ss < 4; ++ss) {
-                        fa[ss] = *reinterpret_cast<const float4 *>(sl + rd[ss]);
-                        fb0[ss] = *reinterpret_cast<const float4 *>(sl + SLAB + rd[ss]);
-                        fb1[ss] = v1 ? *reinterpret_cast<const float4 *>(sl + 2 * SLAB + rd[ss]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // slab reads retired before it is refilled
-                    if (k0 + 64 < d) issue(k0 + 64);
-#pragma unroll
-                    for (int ss = 0; ss < 4; ++ss) {
-                        if (k0 + 16 * ss >= d) break;                               // wave-uniform; padded k would only add 0*0
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].x, fb0[ss].x, acc0, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].y, fb0[ss].y, acc0, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].z, fb0[ss].z, acc0, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].w, fb0[ss].w, acc0, 0, 0, 0);
-                        if (v1) {
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].x, fb1[ss].x, acc1, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].y, fb1[ss].y, acc1, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].z, fb1[ss].z, acc1, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].w, fb1[ss].w, acc1, 0, 0, 0);
-                        }
-                    }
+                for (int reg = 0; reg < 4; ++reg) {
+                    if (t0 < nt) Fn[(4 * kq + reg) * BS + t0 * 16 + fr] = acc0[reg];
+                    if (t1 < nt) Fn[(4 * kq + reg) * BS + t1 * 16 + fr] = acc1[reg];
                 }
-            }
-            // D layout: col = lane & 15, row = 4*(lane>>4) + reg
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                if (v0) Ftile[(4 * kq + reg) * BS + t0 * 16 + fr] = acc0[reg];
-                if (v1) Ftile[(4 * kq + reg) * BS + t1 * 16 + fr] = acc1[reg];
             }
         }
         __syncthreads();
-
-        // ---- phase B: in-block sequential error feedback -------------------------------------------------
-        {
-            float acc[4][2], wv[4][2], et[4][2];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int64_t row = r0 + 4 * wave + rr;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int c = lane + 64 * h;
-                    const bool ok = (c < cnt) && (row < A.m);
-                    acc[rr][h] = (c < cnt) ? Ftile[(4 * wave + rr) * BS + c] : 0.f;
-                    wv[rr][h] = ok ? A.W[row * d + i1 + c] : 0.f;
-                    et[rr][h] = (ok && A.eta) ? A.eta[row * d + i1 + c] : 0.5f;
-                }
-            }
-            // columns 64..cnt-1 live in register half 1
-            for (int i = cnt - 1; i >= 64; --i) {
-                const int ln = __builtin_amdgcn_readfirstlane(i - 64);
-                const float l0 = Ldiag[i * LDS_LD + lane], l1 = Ldiag[i * LDS_LD + 64 + lane];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const float q = round_col(wv[rr][1], acc[rr][1], et[rr][1], A.maxq);
-                    const float er = wv[rr][1] - q;
-                    const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, er), ln));
-                    acc[rr][0] = fmaf(e, l0, acc[rr][0]);
-                    acc[rr][1] = fmaf(e, l1, acc[rr][1]);
-                }
-            }
-            const int top0 = cnt < 64 ? cnt : 64;
-            for (int i = top0 - 1; i >= 0; --i) {
-                const int ln = __builtin_amdgcn_readfirstlane(i);
-                const float l0 = Ldiag[i * LDS_LD + lane];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const float q = round_col(wv[rr][0], acc[rr][0], et[rr][0], A.maxq);
-                    const float er = wv[rr][0] - q;
-                    const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, er), ln));
-                    acc[rr][0] = fmaf(e, l0, acc[rr][0]);
-                }
-            }
-            // every column is final now (later steps only added err * 0): emit codes and errors
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int64_t row = r0 + 4 * wave + rr;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int c = lane + 64 * h;
-                    if (c < cnt && row < A.m) {
-                        const float q = round_col(wv[rr][h], acc[rr][h], et[rr][h], A.maxq);
-                        A.codes[row * d + i1 + c] = (uint8_t)q;
-                        A.E[row * d + i1 + c] = wv[rr][h] - q;
-                    }
-                }
-            }
-        }
-        __syncthreads();   // E of this block visible to the whole workgroup before the next far field; LDS reuse
+        buf ^= 1;
     }
 }
 
@@ -265,14 +289,14 @@ extern "C" int quipamd_ldlq_round(const float *Wgrid, const float *LT, const flo
     LdlqArgs A;
     A.W = Wgrid; A.LT = LT; A.eta = eta; A.codes = codes; A.E = err_ws; A.m = m; A.d = d;
     A.maxq = (float)((1 << bits) - 1);
-    const size_t lds = (size_t)(BS * LDS_LD + 16 * BS) * sizeof(float) + 4 * 3 * SLAB;
+    const size_t lds = (size_t)(BS * LDS_LD + 2 * 16 * BS) * sizeof(float) + 4 * 3 * SLAB;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)ldlq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "ldlq_round: cannot raise dynamic LDS to %zu", lds);
         attr_set = true;
     }
-    ldlq_kernel<<<(unsigned)((m + 15) / 16), 256, lds, (hipStream_t)stream>>>(A);
+    ldlq_kernel<<<(unsigned)((m + 15) / 16), 512, lds, (hipStream_t)stream>>>(A);
     QA_LAUNCH_CHECK("quipamd_ldlq_round");
     return QUIPAMD_OK;
 }
