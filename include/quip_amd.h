@@ -199,6 +199,18 @@ int quipamd_ldlq_round(const float *Wgrid, const float *LT, const float *eta, in
  *   LT[c][j] = C[j][c] * (1 / C[c][c]) for j > c, 0 elsewhere  (vector_balance.py:172-173). */
 int quipamd_unit_lower_t(const float *C, float *LT, int64_t d, void *stream);
 
+/* ---- K7: Hessian accumulation ------------------------------------------
+ * Replaces QuantMethod.add_batch's  `inp = inp.to(float64); H += inp.matmul(inp.t())`  (method.py:98-120) and
+ * post_batch's  `H = (H / nsamples).to(float32)`  (method.py:122-123).
+ *   quipamd_hessian_accum:  Hacc[i][j] += sum_t x[t][i] * x[t][j]  in fp64 on the fp64 matrix pipe, for the tiles of
+ *     the block-lower triangle only (tiles of 64 or 128 columns with tile row >= tile column; the tiles above it are
+ *     left untouched).  x: [tokens, d] f16 / bf16 / f32 with row stride ldx (elements), token-major exactly as the
+ *     forward hook receives it (no transpose); Hacc: double [d, d], zero-initialised by the caller.
+ *   quipamd_hessian_finish: H[i][j] = (float)(Hacc[max(i,j)][min(i,j)] / nsamples)  -- mirrors the triangle, divides
+ *     in fp64 and narrows, like post_batch.  H: float [d, d], must not alias Hacc. */
+int quipamd_hessian_accum(const void *x, int x_dtype, int64_t ldx, int64_t tokens, int64_t d, double *Hacc, void *stream);
+int quipamd_hessian_finish(const double *Hacc, double nsamples, float *H, int64_t d, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

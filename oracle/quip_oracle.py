@@ -410,6 +410,25 @@ def quantize_weight_vecbal(w, H, nbits, scale, zero, qfn):
     return codes_to_weight_qfnb(codes, s, maxq), codes
 
 
+# --------------------------------------------------------------------------- Hessian accumulation
+def hessian_add_batch(H, inp):
+    """method.py:98-120 for nn.Linear / Conv1D layers: a 2-D input counts as one call, a 3-D input as inp.shape[0];
+    tokens are flattened, widened to fp64 and `H += inp^T inp` (the reference forms inp.t() first and multiplies
+    inp.matmul(inp.t())).  H: float64 [d,d], updated in place.  Returns the increment of nsamples."""
+    inp = np.asarray(inp)
+    if inp.ndim == 2:
+        inp = inp[None]
+    n_calls = inp.shape[0]
+    x = inp.reshape(-1, inp.shape[-1]).astype(np.float64)
+    H += x.T @ x
+    return n_calls
+
+
+def hessian_post_batch(H, nsamples):
+    """method.py:122-123: fp64 division, then narrowing to fp32."""
+    return (np.asarray(H, np.float64) / nsamples).astype(np.float32)
+
+
 # --------------------------------------------------------------------------- preproc / postproc
 def preproc(W, H, layer_dtype, rescale, proj, gptqH, percdamp=0.01, U=None, V=None):
     """method.py:125-193 with the orthogonal operators injected as (factors, p_in, p_out)

@@ -1,0 +1,282 @@
+// hessian.hip -- K7: Hessian accumulation  Hacc += X^T X  in fp64, and its finish  H = fp32(sym(Hacc) / nsamples)
+//
+// Replaces QuantMethod.add_batch / post_batch (reference method.py:98-123): the reference casts the layer input
+// [tokens, d] to fp64 and adds the full d x d product X^T X with a dense fp64 GEMM, once per calibration sample
+// (opt.py:141-143) -- 2 * tokens * d^2 flops per call, 35 TFLOP of fp64 per OPT-1.3B fc2.
+//
+// gfx950 design
+//   * X^T X is symmetric: only the block-lower triangle (tiles I >= J) is computed -- half the flops of the GEMM.
+//     The accumulator Hacc holds valid data in those tiles only; quipamd_hessian_finish mirrors it while it divides
+//     by nsamples and narrows to fp32 (the reference's post_batch), so the mirror costs no extra pass.
+//   * the products run on the fp64 matrix pipe (v_mfma_f64_16x16x4_f64): fp16/bf16/fp32 inputs widen to fp64 exactly,
+//     every product and every accumulation is an fp64 fma like the reference's dgemm -- same arithmetic, different
+//     summation order only (differences ~1e-16 relative, invisible after the fp32 narrowing except on rounding ties).
+//   * both MFMA operands are "row = token, 16 consecutive columns" fragments of the SAME matrix X, so the token-major
+//     activations need no transpose: a workgroup stages KT=16 tokens x BN columns of the I side and of the J side in
+//     LDS as fp64 (converted once per stage, not once per use), double buffered, one barrier per stage.
+//     Row stride = BN*8 + 128 B puts the four 16-lane groups of a ds_read_b64 on alternating bank halves.
+//   * 4 waves = 2 x 2, each owns WT x WT accumulator tiles (WT=4: 128 x 128 workgroup tile, 128 accumulator
+//     registers; WT=2: 64 x 64 for small d so the triangle still fills 256 CUs x 2 workgroups).
+//   * no split over tokens, no atomics: the result is deterministic.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) double f64x4_t;
+
+namespace {
+
+constexpr int KT = 16;   // tokens per LDS stage
+
+// element e of a run held as packed 32-bit words (the registers stay whole dwords until the LDS store, so nothing
+// has to touch -- and wait for -- the loaded data before the MFMAs of the current stage)
+template <class TI> __device__ __forceinline__ double widen(const uint32_t *w, int e);
+template <> __device__ __forceinline__ double widen<F32>(const uint32_t *w, int e) { return (double)__uint_as_float(w[e]); }
+template <> __device__ __forceinline__ double widen<F16>(const uint32_t *w, int e)
+{
+    return (double)f16_bits_to_f32((uint16_t)(w[e >> 1] >> (16 * (e & 1))));
+}
+template <> __device__ __forceinline__ double widen<BF16>(const uint32_t *w, int e)
+{
+    return (double)__uint_as_float((e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16));
+}
+
+// EPT consecutive columns of one token row, still in the storage type: the widening to fp64 happens when the stage is
+// written to LDS, AFTER the MFMAs of the current stage, so the load's latency hides under them (converting at the load
+// made the compiler wait for it on the spot).  VEC (16-byte aligned rows, d % 8 == 0): one unconditional vector load
+// from a clamped address, zeroed later if it was out of range -- no branch between the load and the MFMAs.
+template <class TI, int EPT, bool VEC>
+__device__ __forceinline__ bool load_run(const typename DT<TI>::storage *X, int64_t ldx, int64_t tok, int64_t tokens,
+                                         int64_t col, int64_t d, uint32_t (&raw)[EPT * sizeof(typename DT<TI>::storage) / 4])
+{
+    typedef typename DT<TI>::storage S;
+    constexpr int NW = EPT * (int)sizeof(S) / 4;
+    const bool ok = tok < tokens && col < d;
+    if constexpr (VEC) {
+        const S *p = X + (ok ? tok * ldx + col : 0);
+        if constexpr (NW == 1) {
+            raw[0] = *reinterpret_cast<const uint32_t *>(p);
+        } else if constexpr (NW == 2) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(p);
+            raw[0] = v.x; raw[1] = v.y;
+        } else {
+#pragma unroll
+            for (int b = 0; b < NW / 4; ++b) {
+                const uint4 v = reinterpret_cast<const uint4 *>(p)[b];
+                raw[4 * b] = v.x; raw[4 * b + 1] = v.y; raw[4 * b + 2] = v.z; raw[4 * b + 3] = v.w;
+            }
+        }
+        return ok;
+    } else {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            if constexpr (sizeof(S) == 4) {
+                raw[w] = (ok && col + w < d) ? reinterpret_cast<const uint32_t *>(X)[tok * ldx + col + w] : 0u;
+            } else {
+                const uint32_t lo = (ok && col + 2 * w < d) ? (uint32_t)X[tok * ldx + col + 2 * w] : 0u;
+                const uint32_t hi = (ok && col + 2 * w + 1 < d) ? (uint32_t)X[tok * ldx + col + 2 * w + 1] : 0u;
+                raw[w] = lo | (hi << 16);
+            }
+        }
+        return true;
+    }
+}
+
+// lower-triangle tile (I >= J) from a linear index: t = I (I + 1) / 2 + J
+__device__ __forceinline__ void tri_tile(int t, int &I, int &J)
+{
+    I = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while (I * (I + 1) / 2 > t) --I;
+    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+    J = t - I * (I + 1) / 2;
+}
+
+// one (32 WT) x (32 WT) tile of Hacc, tile coordinates (I, J) in units of 32 WT columns
+template <class TI, int WT, bool VEC>
+__device__ __forceinline__ void tile_body(const typename DT<TI>::storage *X, int64_t ldx, int64_t tokens, int64_t d, double *H,
+                                          int I, int J, double *hs)
+{
+    constexpr int BN = 32 * WT, LDW = BN + 16, EPT = KT * BN / 256;
+    static_assert(BN / EPT == 16, "staging map: 16 threads per token row");
+    const bool diag = I == J;
+    const int64_t i0 = (int64_t)I * BN, j0 = (int64_t)J * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int stok = tid >> 4, scol = (tid & 15) * EPT;
+
+    uint32_t ri[EPT * sizeof(typename DT<TI>::storage) / 4], rj[EPT * sizeof(typename DT<TI>::storage) / 4];
+    bool oki = true, okj = true;
+    auto gload = [&](int64_t t0) {
+        oki = load_run<TI, EPT, VEC>(X, ldx, t0 + stok, tokens, i0 + scol, d, ri);
+        if (!diag) okj = load_run<TI, EPT, VEC>(X, ldx, t0 + stok, tokens, j0 + scol, d, rj);
+    };
+    auto sstore = [&](int buf) {
+        double *pi = hs + ((buf * 2 + 0) * KT + stok) * LDW + scol;
+#pragma unroll
+        for (int e = 0; e < EPT; e += 2)
+            *reinterpret_cast<double2 *>(pi + e) = oki ? make_double2(widen<TI>(ri, e), widen<TI>(ri, e + 1)) : make_double2(0.0, 0.0);
+        if (!diag) {
+            double *pj = hs + ((buf * 2 + 1) * KT + stok) * LDW + scol;
+#pragma unroll
+            for (int e = 0; e < EPT; e += 2)
+                *reinterpret_cast<double2 *>(pj + e) = okj ? make_double2(widen<TI>(rj, e), widen<TI>(rj, e + 1)) : make_double2(0.0, 0.0);
+        }
+    };
+
+    f64x4_t acc[WT][WT];
+#pragma unroll
+    for (int x = 0; x < WT; ++x)
+#pragma unroll
+        for (int y = 0; y < WT; ++y) acc[x][y] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+
+    const int64_t nchunks = (tokens + KT - 1) / KT;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int64_t c = 0; c < nchunks; ++c) {
+        const int cur = (int)(c & 1);
+        const bool more = c + 1 < nchunks;
+        if (more) gload((c + 1) * KT);
+        // A[row = column of the I side][k = token], B[k = token][col = column of the J side]: lane (l & 15, l >> 4)
+        const double *As = hs + (cur * 2 + 0) * KT * LDW + wi * (WT * 16) + (lane & 15);
+        const double *Bs = hs + (cur * 2 + (diag ? 0 : 1)) * KT * LDW + wj * (WT * 16) + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < KT / 4; ++ks) {
+            const int row = ks * 4 + (lane >> 4);
+            double a[WT], b[WT];
+#pragma unroll
+            for (int x = 0; x < WT; ++x) a[x] = As[row * LDW + x * 16];
+#pragma unroll
+            for (int y = 0; y < WT; ++y) b[y] = Bs[row * LDW + y * 16];
+#pragma unroll
+            for (int x = 0; x < WT; ++x)
+#pragma unroll
+                for (int y = 0; y < WT; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+        if (more) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int x = 0; x < WT; ++x)
+#pragma unroll
+        for (int y = 0; y < WT; ++y)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t r = i0 + wi * (WT * 16) + x * 16 + (lane >> 4) + 4 * reg;
+                const int64_t cidx = j0 + wj * (WT * 16) + y * 16 + (lane & 15);
+                if (r < d && cidx < d) H[r * d + cidx] += acc[x][y][reg];
+            }
+}
+
+// Workgroups [0, nbig) own whole (32 WT)^2 tiles; the tiles past nbig -- the remainder that would otherwise run as a
+// nearly empty last round on the 256 CUs x 2 workgroup slots -- are cut into four quarter tiles each, scheduled last
+// (longest-processing-time-first: the tail of the launch is a quarter as long).  The upper quarter of a diagonal tile is
+// never read by quipamd_hessian_finish and is skipped.
+template <class TI, int WT, bool VEC>
+__global__ __launch_bounds__(256, 2) void hsyrk_kernel(const typename DT<TI>::storage *X, int64_t ldx, int64_t tokens,
+                                                      int64_t d, double *H, int nbig)
+{
+    extern __shared__ __attribute__((aligned(16))) double hs[];        // [2 buffers][2 sides][KT][LDW]
+    const int b = blockIdx.x;
+    int I, J;
+    if (b < nbig) {
+        tri_tile(b, I, J);
+        tile_body<TI, WT, VEC>(X, ldx, tokens, d, H, I, J, hs);
+    } else if constexpr (WT > 1) {
+        const int r = b - nbig;
+        tri_tile(nbig + (r >> 2), I, J);
+        const int si = (r >> 1) & 1, sj = r & 1;
+        if (I == J && si == 0 && sj == 1) return;
+        if ((int64_t)(2 * I + si) * (16 * WT) >= d || (int64_t)(2 * J + sj) * (16 * WT) >= d) return;
+        tile_body<TI, WT / 2, VEC>(X, ldx, tokens, d, H, 2 * I + si, 2 * J + sj, hs);
+    }
+}
+
+// H[i][j] = fp32( Hacc[max(i,j)][min(i,j)] / nsamples ): 32 x 32 tiles, upper tiles read their mirror through LDS
+__global__ __launch_bounds__(256) void hfinish_kernel(const double *Hacc, double n, float *out, int64_t d)
+{
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x, by = blockIdx.y;             // column tile, row tile
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    if (by >= bx) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t r = (int64_t)by * 32 + ty + 8 * k, c = (int64_t)bx * 32 + tx;
+            if (r < d && c < d) out[r * d + c] = (float)(Hacc[r * d + c] / n);
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                            // mirror tile: rows of column-tile bx, columns of row-tile by
+        const int64_t r = (int64_t)bx * 32 + ty + 8 * k, c = (int64_t)by * 32 + tx;
+        tile[ty + 8 * k][tx] = (r < d && c < d) ? Hacc[r * d + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t r = (int64_t)by * 32 + ty + 8 * k, c = (int64_t)bx * 32 + tx;
+        if (r < d && c < d) out[r * d + c] = (float)(tile[tx][ty + 8 * k] / n);
+    }
+}
+
+template <class TI, int WT, bool VEC>
+int launch_syrk(const void *x, int64_t ldx, int64_t tokens, int64_t d, double *H, hipStream_t s)
+{
+    constexpr int BN = 32 * WT, LDW = BN + 16, SLOTS = 512;               // 256 CUs x 2 resident workgroups
+    const size_t lds = (size_t)2 * 2 * KT * LDW * sizeof(double);
+    const int64_t T = (d + BN - 1) / BN, N = T * (T + 1) / 2;
+    int64_t nbig = N;
+    if (WT > 1 && N > SLOTS && N % SLOTS) nbig = N / SLOTS * SLOTS;
+    auto kern = hsyrk_kernel<TI, WT, VEC>;
+    static bool attr_done = false;                         // per instantiation
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "hessian_accum: cannot reserve %zu B of LDS", lds);
+        attr_done = true;
+    }
+    kern<<<(unsigned)(nbig + 4 * (N - nbig)), 256, lds, s>>>((const typename DT<TI>::storage *)x, ldx, tokens, d, H, (int)nbig);
+    QA_LAUNCH_CHECK("hessian_accum");
+    return QUIPAMD_OK;
+}
+
+// largest tile whose triangle still gives every CU work: 128 (WT 4), 64 (WT 2) or 32 (WT 1) columns
+template <class TI, bool VEC>
+int pick_syrk(const void *x, int64_t ldx, int64_t tokens, int64_t d, double *H, hipStream_t s)
+{
+    auto ntiles = [&](int64_t bn) { const int64_t T = (d + bn - 1) / bn; return T * (T + 1) / 2; };
+    if (ntiles(128) >= 384) return launch_syrk<TI, 4, VEC>(x, ldx, tokens, d, H, s);
+    if (ntiles(64) >= 384) return launch_syrk<TI, 2, VEC>(x, ldx, tokens, d, H, s);
+    return launch_syrk<TI, 1, VEC>(x, ldx, tokens, d, H, s);
+}
+
+}   // namespace
+
+extern "C" int quipamd_hessian_accum(const void *x, int x_dtype, int64_t ldx, int64_t tokens, int64_t d, double *Hacc,
+                                     void *stream)
+{
+    QA_REQUIRE(tokens >= 0 && d >= 0 && ldx >= d, QUIPAMD_ERR_SHAPE, "hessian_accum: bad shape tokens=%lld d=%lld ldx=%lld",
+               (long long)tokens, (long long)d, (long long)ldx);
+    if (tokens == 0 || d == 0) return QUIPAMD_OK;
+    QA_REQUIRE(x && Hacc, QUIPAMD_ERR_ARG, "hessian_accum: null pointer");
+    QA_REQUIRE(d <= (1 << 20), QUIPAMD_ERR_SHAPE, "hessian_accum: d too large");
+    const int esz = x_dtype == QUIPAMD_F32 ? 4 : 2;
+    const bool vec = ((uintptr_t)x & 15) == 0 && (ldx * esz) % 16 == 0 && d % 8 == 0;
+    hipStream_t s = (hipStream_t)stream;
+    QA_DISPATCH_DTYPE(x_dtype, TI, return vec ? pick_syrk<TI, true>(x, ldx, tokens, d, Hacc, s)
+                                              : pick_syrk<TI, false>(x, ldx, tokens, d, Hacc, s));
+    return QUIPAMD_OK;
+}
+
+extern "C" int quipamd_hessian_finish(const double *Hacc, double nsamples, float *H, int64_t d, void *stream)
+{
+    QA_REQUIRE(d >= 0, QUIPAMD_ERR_SHAPE, "hessian_finish: bad d");
+    if (d == 0) return QUIPAMD_OK;
+    QA_REQUIRE(Hacc && H, QUIPAMD_ERR_ARG, "hessian_finish: null pointer");
+    QA_REQUIRE((const void *)Hacc != (const void *)H, QUIPAMD_ERR_ARG, "hessian_finish: in-place not supported");
+    const unsigned nt = (unsigned)((d + 31) / 32);
+    hfinish_kernel<<<dim3(nt, nt), 256, 0, (hipStream_t)stream>>>(Hacc, nsamples, H, d);
+    QA_LAUNCH_CHECK("hessian_finish");
+    return QUIPAMD_OK;
+}

@@ -106,16 +106,29 @@ class QuantMethod:
         self.nsamples = 0
         self.preproc_done = False
 
-    # ---- Hessian accumulation (method.py:98-123): fp64 X X^T on the layer's device ------------------
+    # ---- Hessian accumulation (method.py:98-123) ------------------------------------------------------
+    # On the GPU, Linear / Conv1D inputs go through K7 (quip_amd/csrc/hessian.hip): fp64 X^T X of the block-lower
+    # triangle on the fp64 matrix pipe straight from the token-major hook input (no transpose, no fp64 copy of X);
+    # `H` then holds the triangle only until post_batch mirrors it.  `_tri` records that state; assigning `.H` from
+    # outside (optq_ldlq_equiv.py:24,35) leaves it False, and post_batch then takes the reference's dense route.
     def add_batch(self, inp, out):
         if DEBUG:
             self.inp1, self.out1 = inp, out
         if inp.dim() == 2:
             inp = inp.unsqueeze(0)
         n_calls = inp.shape[0]                     # nsamples counts hook calls' batch dim, not tokens
-        if isinstance(self.layer, (nn.Linear, transformers.Conv1D)):
-            if inp.dim() == 3:
-                inp = inp.reshape(-1, inp.shape[-1])
+        linear = isinstance(self.layer, (nn.Linear, transformers.Conv1D))
+        if linear and inp.dim() == 3:
+            inp = inp.reshape(-1, inp.shape[-1])
+        if (linear and inp.is_cuda and inp.dim() == 2 and inp.dtype in ops._DT and self.H.dtype == torch.float64
+                and (self.nsamples == 0 or getattr(self, "_tri", False))):
+            self.nsamples += n_calls
+            self._tri = True
+            ops.hessian_accum(self.H, inp)          # raises if the HIP library is missing: no fallback on the GPU
+            return
+        if getattr(self, "_tri", False):
+            raise RuntimeError("add_batch: Hessian accumulation started on the HIP path; cannot mix input kinds")
+        if linear:
             inp = inp.t()
         elif isinstance(self.layer, nn.Conv2d):
             unfold = nn.Unfold(self.layer.kernel_size, dilation=self.layer.dilation, padding=self.layer.padding,
@@ -126,6 +139,10 @@ class QuantMethod:
         self.H.addmm_(inp, inp.t())
 
     def post_batch(self):
+        if getattr(self, "_tri", False):
+            self.H = ops.hessian_finish(self.H, self.nsamples)
+            self._tri = False
+            return
         self.H = (self.H / self.nsamples).to(torch.float32)
 
     # ---- preprocessing (method.py:125-193) -------------------------------------------------------------

@@ -304,3 +304,29 @@ def ldlq_round(Wgrid, LT, bits, eta=None, return_err=False):
     err = torch.empty((m, d), dtype=torch.float32, device=Wgrid.device)
     _lib.call("quipamd_ldlq_round", _p(Wgrid), _p(LT), _p(eta), bits, _p(codes), _p(err), m, d, _stream())
     return (codes, err) if return_err else codes
+
+
+# ------------------------------------------------------------------------------------------------- K7
+def hessian_accum(Hacc, x):
+    """Hacc += x^T x in fp64 for the block-lower triangle (method.py:98-120).  x: [tokens, d] f16/bf16/f32, last dim
+    contiguous; Hacc: float64 [d, d] (zero-initialised by the caller, finished by hessian_finish)."""
+    _need_gpu(Hacc, x)
+    assert Hacc.dtype == torch.float64 and Hacc.dim() == 2 and Hacc.shape[0] == Hacc.shape[1] and Hacc.is_contiguous()
+    assert x.dim() == 2 and x.shape[1] == Hacc.shape[0]
+    if x.numel() and x.stride(1) != 1:
+        x = x.contiguous()
+    ldx = x.stride(0) if x.shape[0] > 1 else x.shape[1]
+    if ldx < x.shape[1]:                       # expanded / overlapping rows
+        x = x.contiguous()
+        ldx = x.shape[1]
+    _lib.call("quipamd_hessian_accum", _p(x), _dtype(x), ldx, x.shape[0], x.shape[1], _p(Hacc), _stream())
+    return Hacc
+
+
+def hessian_finish(Hacc, nsamples):
+    """fp32 [d,d] = mirror(Hacc) / nsamples  (post_batch, method.py:122-123)."""
+    _need_gpu(Hacc)
+    assert Hacc.dtype == torch.float64 and Hacc.dim() == 2 and Hacc.shape[0] == Hacc.shape[1] and Hacc.is_contiguous()
+    H = torch.empty(Hacc.shape, dtype=torch.float32, device=Hacc.device)
+    _lib.call("quipamd_hessian_finish", _p(Hacc), float(nsamples), _p(H), Hacc.shape[0], _stream())
+    return H

@@ -45,12 +45,30 @@ def main():
     ap.add_argument("--shapes", default="4096x4096,2048x2048,8192x2048,2048x8192")
     ap.add_argument("--bits", type=int, default=2)
     ap.add_argument("--no-balance", action="store_true")
+    ap.add_argument("--only-k7", action="store_true", help="Hessian accumulation only")
+    ap.add_argument("--tokens", type=int, default=2048, help="tokens per add_batch call (opt.py: seqlen 2048)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     bits, maxq = args.bits, 2 ** args.bits - 1
     for shp in args.shapes.split(","):
         m, d = (int(v) for v in shp.split("x"))
         torch.manual_seed(0)
+        # ---- K7: one add_batch call (tokens x d fp16 activations) next to the reference's op, a dense fp64 GEMM
+        xh = torch.randn(args.tokens, d, device=dev).half()
+        Hacc = torch.zeros(d, d, dtype=torch.float64, device=dev)
+        t = timeit(lambda: ops.hessian_accum(Hacc, xh), reps=5, warm=1)
+
+        def ref_add():
+            x64 = xh.t().to(torch.float64)
+            Hacc.addmm_(x64, x64.t())
+        t_ref = timeit(ref_add, reps=3, warm=1)
+        t_fin = timeit(lambda: ops.hessian_finish(Hacc, 1.0), reps=3, warm=1)
+        emit(kernel="K7 hessian_accum f16", tokens=args.tokens, d=d, ms=t * 1e3,
+             dense_equiv_fp64_TFLOPs=2 * args.tokens * d * d / t / 1e12, torch_fp64_addmm_ms=t_ref * 1e3,
+             speedup=t_ref / t, finish_ms=t_fin * 1e3)
+        del Hacc, xh
+        if args.only_k7:
+            continue
         W = (0.02 * torch.randn(m, d)).to(dev)
         W16 = W.half()
         # ---- K5

@@ -197,10 +197,15 @@ def _bpp(g, case, side):
 
 def test_hessian_accumulation():
     g = load_golden("method")
-    X = f16(g["X"]).astype(np.float64)                         # [6, 64, d]
-    H = sum(x.T @ x for x in X)                                # method.py:115-120 (inp.t() convention)
+    X = f16(g["X"])                                            # [6, 64, d] fp16, one add_batch call per sample
+    H = np.zeros((X.shape[-1],) * 2, np.float64)
+    n = sum(O.hessian_add_batch(H, x[None]) for x in X)        # method.py:98-120
+    assert n == X.shape[0]
     np.testing.assert_allclose(H, g["H64"], rtol=1e-12)
-    np.testing.assert_allclose((H / X.shape[0]).astype(np.float32), g["Hraw"], rtol=1e-6)
+    np.testing.assert_allclose(O.hessian_post_batch(H, n), g["Hraw"], rtol=1e-6)
+    H2 = np.zeros_like(H)
+    assert O.hessian_add_batch(H2, X) == X.shape[0]            # one 3-D call counts its batch dimension
+    np.testing.assert_allclose(H2, H, rtol=1e-12)
 
 
 @pytest.mark.parametrize("case", ["incoh_w2", "incoh_w4_noblock_lazy"])
