@@ -12,11 +12,18 @@
 //     every product and every accumulation is an fp64 fma like the reference's dgemm -- same arithmetic, different
 //     summation order only (differences ~1e-16 relative, invisible after the fp32 narrowing except on rounding ties).
 //   * both MFMA operands are "row = token, 16 consecutive columns" fragments of the SAME matrix X, so the token-major
-//     activations need no transpose: a workgroup stages KT=16 tokens x BN columns of the I side and of the J side in
-//     LDS as fp64 (converted once per stage, not once per use), double buffered, one barrier per stage.
-//     Row stride = BN*8 + 128 B puts the four 16-lane groups of a ds_read_b64 on alternating bank halves.
+//     activations need no transpose: a workgroup stages KT=32 tokens x BN columns of the I side and of the J side in
+//     LDS as fp32 (f16 / bf16 widen to it exactly), double buffered, one barrier per stage; a fragment element widens
+//     to fp64 (one v_cvt_f64_f32, VALU under the 64-cycle MFMAs) when it is read.  fp32 instead of fp64 staging
+//     halves the LDS writes and lets a stage hold twice the tokens in the same 72 KiB -- half the barriers: 2.41 ->
+//     2.19 ms at 2048 x 8192 (the loop with staging and barriers compiled out runs 2.04 ms).
+//     Row stride = BN*4 + 64 B puts the four 16-lane token groups of a ds_read_b32 on four different bank quarters.
+//     The global loads of stage c+1 are issued before the MFMAs of stage c and stay packed dwords until they are
+//     written to LDS after them, so their latency is hidden (unpacking at the load made hipcc wait on the spot).
 //   * 4 waves = 2 x 2, each owns WT x WT accumulator tiles (WT=4: 128 x 128 workgroup tile, 128 accumulator
-//     registers; WT=2: 64 x 64 for small d so the triangle still fills 256 CUs x 2 workgroups).
+//     registers; WT=2 / 1: 64 / 32 columns for small d so the triangle still fills 256 CUs x 2 workgroups).
+//   * the triangle rarely divides by the 512 workgroup slots (d=8192: 2080 tiles = 4 x 512 + 32, a fifth round at 6 %
+//     occupancy): the remainder tiles are cut into quarter tiles scheduled last, so the tail is a quarter as long.
 //   * no split over tokens, no atomics: the result is deterministic.
 #include "common.h"
 
@@ -24,19 +31,20 @@ typedef __attribute__((ext_vector_type(4))) double f64x4_t;
 
 namespace {
 
-constexpr int KT = 16;   // tokens per LDS stage
+constexpr int KT = 32;    // tokens per LDS stage
+constexpr int NPASS = KT / 16;   // a workgroup loads 16 token rows per pass (16 threads per row)
 
 // element e of a run held as packed 32-bit words (the registers stay whole dwords until the LDS store, so nothing
-// has to touch -- and wait for -- the loaded data before the MFMAs of the current stage)
-template <class TI> __device__ __forceinline__ double widen(const uint32_t *w, int e);
-template <> __device__ __forceinline__ double widen<F32>(const uint32_t *w, int e) { return (double)__uint_as_float(w[e]); }
-template <> __device__ __forceinline__ double widen<F16>(const uint32_t *w, int e)
+// has to touch -- and wait for -- the loaded data before the MFMAs of the current stage); f16 / bf16 -> f32 is exact
+template <class TI> __device__ __forceinline__ float widen(const uint32_t *w, int e);
+template <> __device__ __forceinline__ float widen<F32>(const uint32_t *w, int e) { return __uint_as_float(w[e]); }
+template <> __device__ __forceinline__ float widen<F16>(const uint32_t *w, int e)
 {
-    return (double)f16_bits_to_f32((uint16_t)(w[e >> 1] >> (16 * (e & 1))));
+    return f16_bits_to_f32((uint16_t)(w[e >> 1] >> (16 * (e & 1))));
 }
-template <> __device__ __forceinline__ double widen<BF16>(const uint32_t *w, int e)
+template <> __device__ __forceinline__ float widen<BF16>(const uint32_t *w, int e)
 {
-    return (double)__uint_as_float((e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16));
+    return __uint_as_float((e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16));
 }
 
 // EPT consecutive columns of one token row, still in the storage type: the widening to fp64 happens when the stage is
@@ -92,10 +100,9 @@ __device__ __forceinline__ void tri_tile(int t, int &I, int &J)
 // one (32 WT) x (32 WT) tile of Hacc, tile coordinates (I, J) in units of 32 WT columns
 template <class TI, int WT, bool VEC>
 __device__ __forceinline__ void tile_body(const typename DT<TI>::storage *X, int64_t ldx, int64_t tokens, int64_t d, double *H,
-                                          int I, int J, double *hs)
+                                          int I, int J, float *hs)
 {
-    constexpr int BN = 32 * WT, LDW = BN + 16, EPT = KT * BN / 256;
-    static_assert(BN / EPT == 16, "staging map: 16 threads per token row");
+    constexpr int BN = 32 * WT, LDW = BN + 16, EPT = BN / 16, NW = EPT * (int)sizeof(typename DT<TI>::storage) / 4;
     const bool diag = I == J;
     const int64_t i0 = (int64_t)I * BN, j0 = (int64_t)J * BN;
 
@@ -103,22 +110,30 @@ __device__ __forceinline__ void tile_body(const typename DT<TI>::storage *X, int
     const int wi = wave >> 1, wj = wave & 1;
     const int stok = tid >> 4, scol = (tid & 15) * EPT;
 
-    uint32_t ri[EPT * sizeof(typename DT<TI>::storage) / 4], rj[EPT * sizeof(typename DT<TI>::storage) / 4];
-    bool oki = true, okj = true;
+    uint32_t ri[NPASS][NW], rj[NPASS][NW];
+    bool oki[NPASS], okj[NPASS];
     auto gload = [&](int64_t t0) {
-        oki = load_run<TI, EPT, VEC>(X, ldx, t0 + stok, tokens, i0 + scol, d, ri);
-        if (!diag) okj = load_run<TI, EPT, VEC>(X, ldx, t0 + stok, tokens, j0 + scol, d, rj);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            oki[ps] = load_run<TI, EPT, VEC>(X, ldx, t0 + 16 * ps + stok, tokens, i0 + scol, d, ri[ps]);
+            if (!diag) okj[ps] = load_run<TI, EPT, VEC>(X, ldx, t0 + 16 * ps + stok, tokens, j0 + scol, d, rj[ps]);
+        }
+    };
+    auto put = [&](float *dst, const uint32_t *raw, bool ok) {
+        if constexpr (EPT >= 4) {
+#pragma unroll
+            for (int e = 0; e < EPT; e += 4)
+                *reinterpret_cast<float4 *>(dst + e) = ok ? make_float4(widen<TI>(raw, e), widen<TI>(raw, e + 1), widen<TI>(raw, e + 2), widen<TI>(raw, e + 3))
+                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            *reinterpret_cast<float2 *>(dst) = ok ? make_float2(widen<TI>(raw, 0), widen<TI>(raw, 1)) : make_float2(0.f, 0.f);
+        }
     };
     auto sstore = [&](int buf) {
-        double *pi = hs + ((buf * 2 + 0) * KT + stok) * LDW + scol;
 #pragma unroll
-        for (int e = 0; e < EPT; e += 2)
-            *reinterpret_cast<double2 *>(pi + e) = oki ? make_double2(widen<TI>(ri, e), widen<TI>(ri, e + 1)) : make_double2(0.0, 0.0);
-        if (!diag) {
-            double *pj = hs + ((buf * 2 + 1) * KT + stok) * LDW + scol;
-#pragma unroll
-            for (int e = 0; e < EPT; e += 2)
-                *reinterpret_cast<double2 *>(pj + e) = okj ? make_double2(widen<TI>(rj, e), widen<TI>(rj, e + 1)) : make_double2(0.0, 0.0);
+        for (int ps = 0; ps < NPASS; ++ps) {
+            put(hs + ((buf * 2 + 0) * KT + 16 * ps + stok) * LDW + scol, ri[ps], oki[ps]);
+            if (!diag) put(hs + ((buf * 2 + 1) * KT + 16 * ps + stok) * LDW + scol, rj[ps], okj[ps]);
         }
     };
 
@@ -137,16 +152,16 @@ __device__ __forceinline__ void tile_body(const typename DT<TI>::storage *X, int
         const bool more = c + 1 < nchunks;
         if (more) gload((c + 1) * KT);
         // A[row = column of the I side][k = token], B[k = token][col = column of the J side]: lane (l & 15, l >> 4)
-        const double *As = hs + (cur * 2 + 0) * KT * LDW + wi * (WT * 16) + (lane & 15);
-        const double *Bs = hs + (cur * 2 + (diag ? 0 : 1)) * KT * LDW + wj * (WT * 16) + (lane & 15);
+        const float *As = hs + (cur * 2 + 0) * KT * LDW + wi * (WT * 16) + (lane & 15);
+        const float *Bs = hs + (cur * 2 + (diag ? 0 : 1)) * KT * LDW + wj * (WT * 16) + (lane & 15);
 #pragma unroll
         for (int ks = 0; ks < KT / 4; ++ks) {
             const int row = ks * 4 + (lane >> 4);
             double a[WT], b[WT];
 #pragma unroll
-            for (int x = 0; x < WT; ++x) a[x] = As[row * LDW + x * 16];
+            for (int x = 0; x < WT; ++x) a[x] = (double)As[row * LDW + x * 16];
 #pragma unroll
-            for (int y = 0; y < WT; ++y) b[y] = Bs[row * LDW + y * 16];
+            for (int y = 0; y < WT; ++y) b[y] = (double)Bs[row * LDW + y * 16];
 #pragma unroll
             for (int x = 0; x < WT; ++x)
 #pragma unroll
@@ -178,7 +193,7 @@ template <class TI, int WT, bool VEC>
 __global__ __launch_bounds__(256, 2) void hsyrk_kernel(const typename DT<TI>::storage *X, int64_t ldx, int64_t tokens,
                                                       int64_t d, double *H, int nbig)
 {
-    extern __shared__ __attribute__((aligned(16))) double hs[];        // [2 buffers][2 sides][KT][LDW]
+    extern __shared__ __attribute__((aligned(16))) float hs[];         // [2 buffers][2 sides][KT][LDW]
     const int b = blockIdx.x;
     int I, J;
     if (b < nbig) {
@@ -225,7 +240,7 @@ template <class TI, int WT, bool VEC>
 int launch_syrk(const void *x, int64_t ldx, int64_t tokens, int64_t d, double *H, hipStream_t s)
 {
     constexpr int BN = 32 * WT, LDW = BN + 16, SLOTS = 512;               // 256 CUs x 2 resident workgroups
-    const size_t lds = (size_t)2 * 2 * KT * LDW * sizeof(double);
+    const size_t lds = (size_t)2 * 2 * KT * LDW * sizeof(float);
     const int64_t T = (d + BN - 1) / BN, N = T * (T + 1) / 2;
     int64_t nbig = N;
     if (WT > 1 && N > SLOTS && N % SLOTS) nbig = N / SLOTS * SLOTS;
