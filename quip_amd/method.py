@@ -12,6 +12,7 @@ gives the same operators.
 """
 import math
 
+import numpy as np
 import scipy.stats
 import torch
 import torch.nn as nn
@@ -41,9 +42,45 @@ def butterfly_factors(n):
     return (math.prod(pf[0::2]), math.prod(pf[1::2]))
 
 
+def _special_ortho_group_gpu(p, m, dev):
+    """scipy.stats.special_ortho_group.rvs(p, size=m) with the Householder accumulation on the GPU.
+
+    scipy (1.15, unpinned by the reference) builds each sample as H = D * prod_n (I - x_n x_n^T): for n = 0 .. p-2 it
+    draws x_n ~ N(0, I_{p-n}) from the global numpy RandomState, turns it into the Householder vector of the reflection
+    sending x_n to -sign(x_n[0]) |x_n| e_0, applies it to columns n: of H, and finally scales the rows by D (signs, last
+    one chosen so that det = +1).  Its Python loop over n with numpy broadcasting takes 0.5 s for 64 x SO(128) -- most
+    of QuantMethod.preproc's time once the projection itself runs on K3.  Here the SAME normals are drawn from the
+    SAME stream in the same order (so seeding numpy reproduces the reference's operators), the vector preparation is
+    done for all n at once, and only the p-1 rank-one updates stay sequential (two batched fp64 GEMM launches each).
+    Differences to scipy are fp64 summation order only (~1e-16), invisible after the fp32 narrowing of method.py:22."""
+    shape = (m,) if m > 1 else ()
+    xs = np.zeros((p - 1, max(m, 1), p))
+    for n in range(p - 1):
+        xs[n, :, n:] = np.random.normal(size=shape + (p - n,)).reshape(max(m, 1), p - n)    # same calls as scipy
+    x = torch.from_numpy(xs).to(dev)                                    # [p-1, m, p], x_n zero-padded below column n
+    norm2 = (x * x).sum(-1)
+    idx = torch.arange(p - 1, device=dev)
+    x0 = x[idx, :, idx].clone()                                         # [p-1, m]: leading element of every x_n
+    D = torch.where(x0 != 0, torch.sign(x0), torch.ones_like(x0))
+    lead = x0 + D * norm2.sqrt()
+    x[idx, :, idx] = lead
+    x = x / ((norm2 - x0 * x0 + lead * lead) / 2.).sqrt()[..., None]
+    H = torch.eye(p, dtype=torch.float64, device=dev).repeat(max(m, 1), 1, 1)
+    for n in range(p - 1):
+        xn = x[n]                                                       # [m, p]
+        H = torch.baddbmm(H, torch.bmm(H, xn[:, :, None]), xn[:, None, :], alpha=-1.0)
+    Dlast = (-1) ** (p - 1) * D.prod(0)
+    H = H * torch.cat([D, Dlast[None]], 0).t()[:, :, None]
+    return H if m > 1 else H[0]
+
+
 def gen_rand_orthos(m, p):
-    """m Haar-random SO(p) matrices as fp32 (method.py:20-31).  p == 2 draws rotation angles from torch.rand."""
+    """m Haar-random SO(p) matrices as fp32 (method.py:20-31).  p == 2 draws rotation angles from torch.rand.
+    The random stream is consumed exactly like the reference; with a GPU present the accumulation of scipy's
+    Householder factors runs there (_special_ortho_group_gpu), otherwise scipy itself is called."""
     if p != 2:
+        if torch.cuda.is_available() and p > 2:
+            return _special_ortho_group_gpu(p, m, torch.device('cuda', torch.cuda.current_device())).to(torch.float32).cpu()
         return torch.tensor(scipy.stats.special_ortho_group.rvs(p, size=m)).to(torch.float32)
     theta = torch.rand(m) * (2 * math.pi)
     c, s = torch.cos(theta), torch.sin(theta)

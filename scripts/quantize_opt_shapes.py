@@ -23,6 +23,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--blocks", type=int, default=2)
     ap.add_argument("--bits", type=int, default=2)
+    ap.add_argument("--nsamples", type=int, default=128, help="calibration samples per Linear for the Hessian leg (opt.py default)")
+    ap.add_argument("--seqlen", type=int, default=2048)
+    ap.add_argument("--no-hessian", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     shapes = [(2048, 2048)] * 4 + [(8192, 2048), (2048, 8192)]
@@ -62,6 +65,35 @@ def main():
                 e["preproc_s"] += t1 - t0
                 e["fasterquant_s"] += t2 - t1
     wall = time.perf_counter() - t_all0
+    # Hessian accumulation as opt.py drives it: nsamples add_batch calls of [1, seqlen, d] fp16 per Linear, then
+    # post_batch (method.py:98-123) -- K7 on the GPU; the reference's op (fp64 GEMM per call) timed next to it
+    hess = {}
+    if not args.no_hessian:
+        from quip_amd import method
+        for d in (2048, 8192):
+            layer = torch.nn.Linear(d, 16, bias=False).to(dev).half()
+            x = torch.randn(1, args.seqlen, d, device=dev).half()
+            qm = method.QuantMethod(layer)
+            qm.add_batch(x, None)
+            torch.cuda.synchronize()
+            qm = method.QuantMethod(layer)
+            t0 = time.perf_counter()
+            for _ in range(args.nsamples):
+                qm.add_batch(x, None)
+            qm.post_batch()
+            torch.cuda.synchronize()
+            t_k7 = time.perf_counter() - t0
+            Href = torch.zeros(d, d, dtype=torch.float64, device=dev)
+            reps = max(args.nsamples // 8, 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                x64 = x[0].t().to(torch.float64)
+                Href.add_(x64.matmul(x64.t()))
+            torch.cuda.synchronize()
+            t_ref = (time.perf_counter() - t0) * args.nsamples / reps
+            hess[str(d)] = {"k7_s": round(t_k7, 4), "fp64_gemm_s": round(t_ref, 4)}
+            del Href, qm
     out = {"blocks_run": args.blocks, "wall_s": wall, "per_layer": {}}
     tot = tot_cpu = tot_cpu_lazy = 0.0
     counts = {"2048x2048": 4, "8192x2048": 1, "2048x8192": 1}
@@ -74,6 +106,14 @@ def main():
         tot_cpu += 24 * counts[k] * CPU_REF_S[k][0]
         tot_cpu_lazy += 24 * counts[k] * CPU_REF_S[k][1]
     out["opt1p3b_total_s_extrapolated_24_blocks"] = round(tot, 2)
+    if hess:
+        # per block: q, k, v, out, fc1 see d = 2048 inputs, fc2 sees d = 8192 (the reference accumulates q/k/v separately)
+        hb = 5 * hess["2048"]["k7_s"] + hess["8192"]["k7_s"]
+        hb_ref = 5 * hess["2048"]["fp64_gemm_s"] + hess["8192"]["fp64_gemm_s"]
+        out["hessian"] = {"nsamples": args.nsamples, "seqlen": args.seqlen, "per_linear": hess,
+                          "per_block_s": round(hb, 3), "per_block_fp64_gemm_s": round(hb_ref, 3),
+                          "opt1p3b_24_blocks_s": round(24 * hb, 2), "opt1p3b_24_blocks_fp64_gemm_s": round(24 * hb_ref, 2)}
+        out["opt1p3b_total_incl_hessian_s"] = round(tot + 24 * hb, 2)
     out["cpu_reference_ldlq_only_s"] = {"round_ldl": tot_cpu, "lazy_batch": tot_cpu_lazy, "source": "BASELINE.md section 2, 8 cores"}
     out["speedup_vs_cpu_round_ldl_incl_our_preproc"] = round(tot_cpu / tot, 1)
     print(json.dumps(out))

@@ -61,6 +61,28 @@ def test_quantizer_sym_per_tensor(Q):
     np.testing.assert_array_equal(q.zero.cpu().numpy(), g["a4_sym_tensor_zero"])
 
 
+def test_generators_on_gpu_reproduce_reference_operators():
+    """with a GPU present gen_rand_orthos accumulates scipy's Householder factors on it; seeded like the golden
+    script, the fp32 factors equal the reference's up to fp64 summation order (a rare last-bit fp32 difference)."""
+    from quip_amd import method as M
+    g = load_golden("butterfly")
+    gens = {"blocked": M.gen_rand_ortho_butterfly, "noblock": M.gen_rand_ortho_butterfly_noblock,
+            "nopermute": M.gen_rand_ortho_butterfly_nopermute}
+    for n in (6, 40, 64, 192):
+        for name, gen in gens.items():
+            np.random.seed(100 + n)
+            torch.manual_seed(100 + n)
+            B, p_in, p_out = gen(n)
+            k = f"n{n}_{name}"
+            for i in (0, 1):
+                got, want = B[i].numpy(), g[f"{k}_B{i}"]
+                assert got.shape == want.shape and B[i].dtype == torch.float32 and not B[i].is_cuda
+                np.testing.assert_allclose(got, want, rtol=0, atol=2e-7)
+                assert (got != want).mean() < 0.01
+            np.testing.assert_array_equal(p_in.numpy(), g[k + "_pin"])
+            np.testing.assert_array_equal(p_out.numpy(), g[k + "_pout"])
+
+
 def test_add_batch_post_batch():
     from quip_amd.method import QuantMethod
     g = load_golden("method")

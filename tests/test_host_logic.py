@@ -32,6 +32,22 @@ def test_generators_consume_rng_like_the_reference():
             np.testing.assert_array_equal(p_out.numpy(), g[k + "_pout"])
 
 
+def test_gpu_sampler_is_scipys_algorithm_on_the_same_stream():
+    """method._special_ortho_group_gpu (run here on the CPU device) restates scipy.stats.special_ortho_group.rvs:
+    same numpy draws in the same order, same matrices up to fp64 summation order, same shape rule for size 1."""
+    import scipy.stats
+    from quip_amd import method as M
+    for p, m in [(3, 1), (5, 4), (43, 2), (64, 8)]:
+        np.random.seed(7)
+        want = scipy.stats.special_ortho_group.rvs(p, size=m)
+        after_ref = np.random.normal()
+        np.random.seed(7)
+        got = M._special_ortho_group_gpu(p, m, torch.device("cpu")).numpy()
+        after = np.random.normal()
+        assert got.shape == want.shape and after == after_ref
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-13)
+
+
 def test_surface_names_exist():
     import quip_amd.quant as q, quip_amd.method as m, quip_amd.vector_balance as vb
     import quip_amd.bal as bal, quip_amd.gptq as gptq, quip_amd.near as near, quip_amd.modelutils as mu
