@@ -15,7 +15,8 @@ Besides `value` (bf16 y, SURVEY.md 8(d) byte formula) the line carries `accumula
 the reference operator's own contract (fp32 y pre-filled by the caller, accumulated in place -- quant.py:226-230),
 where K2 may split K over workgroups with fp32 atomics; `decode`: the other half of BASELINE.json's metric, OPT-1.3B w2
 decode tok/s at batch 1 (scripts/decode_opt.py, N=1 only); and `sharded_ldlq`: one LDLQ rounding of an OPT-30B-fc1-sized
-Linear (28672x7168) with its rows scattered over the N ranks (quip_amd/shard.py; N=1: the kernel alone).
+Linear (28672x7168) with its rows scattered over the N ranks (quip_amd/shard.py; N=1: the kernel alone); `hessian`: one
+add_batch call of the calibration pass (K7, fp64 X^T X at the OPT-1.3B fc2 input shape) next to the reference's op.
 `roofline.traffic` is the PMC-measured HBM traffic per launch of the last committed rocprofv3 pass
 (profiles/k2_pmc_latest.json, FETCH_SIZE corrected x2 as MI355X_MICROARCH.md prescribes), or null.
 `cpu_baseline` = what the reference actually runs at inference (dense fake-quant nn.Linear: torch CPU
@@ -261,6 +262,37 @@ def main():
                                    "ms": round(tl * 1e3, 3), "far_field_TFLOPs": round(lm * ld * ld / tl / 1e12, 2), "scaling": "strong"}
         except Exception as ex:                       # a side measurement must never take the headline line down
             out["sharded_ldlq"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
+    # ---- K7 Hessian accumulation: one add_batch call at the OPT-1.3B fc2 input shape -----------------
+    if rank == 0 and world == 1 and not args.no_ldlq:
+        try:
+            ht, hd = 2048, 8192
+            xh = torch.randn(ht, hd, device=dev).half()
+            Hacc = torch.zeros(hd, hd, dtype=torch.float64, device=dev)
+
+            def ev_time(fn, reps):
+                fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                e1.synchronize()
+                return e0.elapsed_time(e1) / reps
+
+            def ref_add():                                           # the reference's op sequence (method.py:115-120)
+                x64 = xh.t().to(torch.float64)
+                Hacc.add_(x64.matmul(x64.t()))
+            t_k7 = ev_time(lambda: ops.hessian_accum(Hacc, xh), 5)
+            t_ref = ev_time(ref_add, 2)
+            tiles = (hd // 128) * (hd // 128 + 1) // 2
+            out["hessian"] = {"what": f"H += X^T X in fp64, X = [{ht} tokens, {hd}] fp16 (one add_batch call, OPT-1.3B fc2 input)",
+                              "ms": round(t_k7, 3), "fp64_mfma_TFLOPs": round(2.0 * ht * tiles * 128 * 128 / t_k7 / 1e9, 1),
+                              "fp64_mfma_peak_TFLOPs": 78.6, "dense_equiv_TFLOPs": round(2.0 * ht * hd * hd / t_k7 / 1e9, 1),
+                              "reference_op_fp64_gemm_ms": round(t_ref, 3)}
+            del xh, Hacc
+        except Exception as ex:
+            out["hessian"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     # ---- the other half of BASELINE.json's metric: OPT-1.3B w2 decode tok/s on one GPU (configs[2]) -----------------
     if rank == 0 and world == 1 and not args.no_decode:

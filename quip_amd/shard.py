@@ -169,6 +169,44 @@ def serve(group=None, src=0, compute=None):
         jobs += 1
 
 
+# ------------------------------------------------------------------------------------- calibration-sample sharding
+def sample_partition(nsamples, world):
+    """[(start, stop)] of the calibration samples each rank feeds through add_batch (contiguous, sizes differ by <= 1)."""
+    base, rem = divmod(nsamples, world)
+    out, a = [], 0
+    for r in range(world):
+        b = a + base + (1 if r < rem else 0)
+        out.append((a, b))
+        a = b
+    return out
+
+
+def all_reduce_hessians(methods, group=None):
+    """SURVEY.md 8(e) "alternative/extra": the 128 calibration samples of the H pass (opt.py:141-143) split over the
+    ranks -- every rank runs the block forward on ITS samples (sample_partition) and accumulates its partial
+    fp64 X^T X per Linear (QuantMethod.add_batch -> K7), then ONE exchange step per block: a SUM all-reduce of each
+    Linear's accumulator (fp64, d x d; direct reduce-scatter + all-gather over the 7 xGMI links inside RCCL) and of
+    the sample counts.  Call between the last add_batch and post_batch, with the same list order on every rank.
+    The K7 accumulator holds the block-lower triangle only (the rest is zero on every rank), so the sum of the
+    partials is again a valid accumulator; summing partials changes the fp64 summation order only."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    dev = _comm_device(group)
+    counts = torch.tensor([float(m.nsamples) for m in methods], dtype=torch.float64, device=dev)
+    dist.all_reduce(counts, group=group)
+    tri = torch.tensor([1.0 if getattr(m, "_tri", False) else 0.0 for m in methods], dtype=torch.float64, device=dev)
+    dist.all_reduce(tri, op=dist.ReduceOp.MAX, group=group)
+    for m, n, t in zip(methods, counts.tolist(), tri.tolist()):
+        assert m.H.dtype == torch.float64, "all_reduce_hessians: call before post_batch"
+        H = m.H if m.H.device == dev else m.H.to(dev)
+        dist.all_reduce(H, group=group)
+        if H is not m.H:
+            m.H.copy_(H)
+        m.nsamples = int(round(n))
+        if t:                         # a rank that saw no sample still has to mirror the triangle in post_batch
+            m._tri = True
+
+
 _active = None
 
 

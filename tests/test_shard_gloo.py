@@ -108,3 +108,45 @@ def test_world_size_one_is_a_plain_call():
         h.shutdown()
     finally:
         dist.destroy_process_group()
+
+
+def _hessian_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quip_amd import shard
+    from quip_amd.method import QuantMethod
+    try:
+        torch.manual_seed(0)
+        d_in, nsamp = (48, 80), 5
+        layers = [torch.nn.Linear(d, 8) for d in d_in]
+        X = [torch.randn(nsamp, 12, d).half() for d in d_in]
+        qms = [QuantMethod(l) for l in layers]
+        a, b = shard.sample_partition(nsamp, world)[rank]
+        for qm, x in zip(qms, X):
+            for j in range(a, b):
+                qm.add_batch(x[j].unsqueeze(0), None)
+        shard.all_reduce_hessians(qms)
+        for qm in qms:
+            qm.post_batch()
+        if rank == 0:
+            ok = True
+            for qm, x, l in zip(qms, X, layers):
+                ref = QuantMethod(l)
+                for j in range(nsamp):
+                    ref.add_batch(x[j].unsqueeze(0), None)
+                ref.post_batch()
+                ok = ok and qm.nsamples == nsamp and torch.allclose(qm.H, ref.H, rtol=1e-6, atol=0)
+            torch.save({"ok": bool(ok)}, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_calibration_samples_split_over_ranks(tmp_path):
+    """DP over the calibration samples: partial Hessians all-reduced once per block == the single-process Hessian."""
+    from quip_amd import shard
+    assert shard.sample_partition(128, 8) == [(16 * r, 16 * r + 16) for r in range(8)]
+    assert shard.sample_partition(5, 2) == [(0, 3), (3, 5)] and shard.sample_partition(1, 3) == [(0, 1), (1, 1), (1, 1)]
+    out = str(tmp_path / "h.pt")
+    mp.spawn(_hessian_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert torch.load(out)["ok"]
