@@ -211,6 +211,15 @@ int quipamd_unit_lower_t(const float *C, float *LT, int64_t d, void *stream);
 int quipamd_hessian_accum(const void *x, int x_dtype, int64_t ldx, int64_t tokens, int64_t d, double *Hacc, void *stream);
 int quipamd_hessian_finish(const double *Hacc, double nsamples, float *H, int64_t d, void *stream);
 
+/* ---- K8: LDL factor for LDLQ ---------------------------------------------------------------------------
+ * Replaces `L = torch.linalg.cholesky(H); L = L @ diag(1/diag(L))` (vector_balance.py:171-173) plus the transpose K4
+ * wants:  LT[c][j] = U[c][j] * (1 / U[c][c]) for j > c, 0 elsewhere, where H = U^T U (U upper = C^T).
+ * Blocked right-looking fp32 factorisation of the upper triangle, in place in LT (H is copied first; H == LT allowed).
+ *   H: float [d, d] symmetric positive definite (only the upper triangle is read);  LT: float [d, d] out;
+ *   info: DEVICE int, 0 on success, else 1 + the first column whose pivot was not positive (LAPACK potrf convention) --
+ *   the factor is then meaningless. */
+int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *info, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

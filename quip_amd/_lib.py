@@ -38,6 +38,7 @@ SIGNATURES = {
                                   c_i64, c_i64, c_vp],
     "quipamd_ldlq_round": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp],
     "quipamd_unit_lower_t": [c_vp, c_vp, c_i64, c_vp],
+    "quipamd_cholesky_lt": [c_vp, c_vp, c_i64, c_vp, c_vp],
     "quipamd_hessian_accum": [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp],
     "quipamd_hessian_finish": [c_vp, c_double, c_vp, c_i64, c_vp],
 }

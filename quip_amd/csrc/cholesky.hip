@@ -1,0 +1,298 @@
+// cholesky.hip -- K8: the LDL factor of the Hessian for LDLQ, LT = D^-1 U strictly upper, H = U^T U
+//
+// Replaces  `L = torch.linalg.cholesky(H); L = L @ diag(1/diag(L))`  and the L[j][c] column walks of round_ldl
+// (reference vector_balance.py:171-173, 179-180): K4 wants row c of LT = column c of the unit-lower factor, i.e.
+// LT = D^-1 U with U = C^T the UPPER Cholesky factor, rows contiguous.  rocSOLVER's potrf behind torch.linalg takes
+// 6.0 / 12.8 / 28.5 ms at d = 2048 / 4096 / 8192 on MI355X -- linear in d, 3.5 us per column of pure latency -- and had
+// become the largest part of Balance.fasterquant once the rounding itself (K4) took 0.4 - 4 ms.
+//
+// Blocked right-looking factorisation in fp32, in place in the LT buffer, upper triangle, NB = 64 rows per step:
+//   diag   one wavefront factors the 64 x 64 diagonal block in registers: lane = column, 64 registers = rows; the pivot
+//          row reaches the other lanes with v_readlane (scalar broadcast), no LDS, no barrier: ~8 us per block instead
+//          of 64 x 3.5 us.
+//   panel  U_kk^T X = A_k,rest by forward substitution, one thread per column (64 registers), the entries of U_kk
+//          arrive as wave-uniform scalar loads; exact substitution, no explicit inverse.
+//   syrk   A_ij -= sum_t X[t][i] X[t][j] for the upper tiles i <= j of the trailing matrix on the fp32 matrix pipe
+//          (v_mfma_f32_16x16x4_f32 is an exact fp32 fma chain): both operands are "row = t, 16 consecutive columns"
+//          fragments of the same row panel, so the structure is K7's (hessian.hip) with fp32 in place of fp64 and
+//          C -= in place of H +=; one 64-row LDS stage, 128/64/32-column tiles by how many tiles there are.
+//   finish LT[c][j] = U[c][j] * (1 / U[c][c]) for j > c, 0 elsewhere  (the reciprocal-multiply of vector_balance.py:172).
+// A non-positive pivot sets *info = column + 1 (LAPACK convention); the host wrapper raises like torch does.
+#include "common.h"
+
+namespace {
+
+constexpr int NB = 64;
+
+__device__ __forceinline__ float lane_bcast(float v, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// ---- diag: A[k0:k0+64, k0:k0+64] (upper part valid) -> U_kk in place ------------------------------------------------
+// a[i] -= U[j][i] * a[j] for four rows i: the four v_readlane (scalar broadcast of U[j][i] out of lane i of row j) and
+// their four fma as ONE asm block.  Written with the builtin, hipcc clusters all 63 v_readlane of a row ahead of the
+// fmas and spills ~1900 SGPRs through v_writelane.  Wait states: gfx950 needs 2 between a VALU writing an SGPR and a
+// VALU reading it (hipcc itself puts `s_nop 1` between v_cmp and v_cndmask) -- three instructions separate each pair
+// here; the leading s_nop covers a[j] having been written by the instruction right before the block.
+template <int J, int I> __device__ __forceinline__ void upd4(float (&a)[NB])
+{
+    float t0, t1, t2, t3;
+    asm volatile("s_nop 1\n\t"
+                 "v_readlane_b32 %4, %8, %9\n\t"
+                 "v_readlane_b32 %5, %8, %10\n\t"
+                 "v_readlane_b32 %6, %8, %11\n\t"
+                 "v_readlane_b32 %7, %8, %12\n\t"
+                 "v_fma_f32 %0, -%4, %8, %0\n\t"
+                 "v_fma_f32 %1, -%5, %8, %1\n\t"
+                 "v_fma_f32 %2, -%6, %8, %2\n\t"
+                 "v_fma_f32 %3, -%7, %8, %3"
+                 : "+v"(a[I]), "+v"(a[I + 1]), "+v"(a[I + 2]), "+v"(a[I + 3]), "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3)
+                 : "v"(a[J]), "n"(I), "n"(I + 1), "n"(I + 2), "n"(I + 3));
+}
+template <int J, int I> __device__ __forceinline__ void upd1(float (&a)[NB])
+{
+    float t0;
+    asm volatile("s_nop 1\n\t"
+                 "v_readlane_b32 %1, %2, %3\n\t"
+                 "s_nop 1\n\t"
+                 "v_fma_f32 %0, -%1, %2, %0"
+                 : "+v"(a[I]), "=&s"(t0)
+                 : "v"(a[J]), "n"(I));
+}
+template <int J, int I> __device__ __forceinline__ void row_update(float (&a)[NB])
+{
+    if constexpr (I + 4 <= NB) {
+        upd4<J, I>(a);
+        row_update<J, I + 4>(a);
+    } else if constexpr (I < NB) {
+        upd1<J, I>(a);
+        row_update<J, I + 1>(a);
+    }
+}
+template <int J> __device__ __forceinline__ void factor_rows(float (&a)[NB], int l, int64_t k0, int *info)
+{
+    if constexpr (J < NB) {
+        const float piv = lane_bcast(a[J], J);
+        if (!(piv > 0.f) && l == 0) atomicCAS(info, 0, (int)(k0 + J + 1));
+        const float ujj = sqrtf(piv);
+        a[J] = (l >= J) ? a[J] / ujj : 0.f;                       // row J of U (lane J holds u_JJ); lanes < J: 0
+        row_update<J, J + 1>(a);                                 // only lanes >= i of row i are read later
+        factor_rows<J + 1>(a, l, k0, info);
+    }
+}
+
+// FULL: the block lies inside the matrix (every step but a ragged last one): unconditional loads, no per-row branches.
+template <bool FULL>
+__global__ __launch_bounds__(64) void chol_diag_kernel(float *A, int64_t d, int64_t k0, int *info)
+{
+    const int l = threadIdx.x;
+    const int64_t c = k0 + l;
+    float *Ac = A + k0 * d + (FULL ? c : (c < d ? c : k0));
+    float a[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        if constexpr (FULL) {
+            a[r] = Ac[(int64_t)r * d];
+        } else {                                                    // outside the matrix: identity
+            const bool in = (k0 + r < d) && (c < d);
+            const float v = Ac[(k0 + r < d ? (int64_t)r : 0) * d];
+            a[r] = in ? v : (r == l ? 1.f : 0.f);
+        }
+    }
+    factor_rows<0>(a, l, k0, info);
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        if constexpr (FULL) {
+            if (l >= r) Ac[(int64_t)r * d] = a[r];
+        } else {
+            if (k0 + r < d && c < d && l >= r) Ac[(int64_t)r * d] = a[r];
+        }
+    }
+}
+
+// ---- panel: X = U_kk^-T A[k0:k0+64, c] for the columns c >= k0+64, one thread per column ----------------------------------
+// (only launched when columns remain, so the 64 rows of the step are always inside the matrix).  U_kk sits in LDS and
+// is read as broadcast float4s: 2080 wave-uniform scalar loads made hipcc hoist them all and spill 700 SGPRs.
+__global__ __launch_bounds__(256) void chol_panel_kernel(float *A, int64_t d, int64_t k0)
+{
+    __shared__ __attribute__((aligned(16))) float Us[NB][NB + 4];
+    {
+        const float *U = A + k0 * d + k0;
+#pragma unroll
+        for (int u = 0; u < NB * NB / 256; ++u) {
+            const int idx = u * 256 + threadIdx.x, r = idx >> 6, cc = idx & 63;
+            Us[r][cc] = U[(int64_t)r * d + cc];
+        }
+    }
+    __syncthreads();
+    const int64_t c = k0 + NB + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float *Ac = A + k0 * d + (c < d ? c : k0 + NB);
+    float b[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) b[r] = Ac[(int64_t)r * d];
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+        const float x = b[s] / Us[s][s];
+        b[s] = x;
+#pragma unroll
+        for (int r4 = ((s + 1) & ~3); r4 < NB; r4 += 4) {
+            const float4 u = *reinterpret_cast<const float4 *>(&Us[s][r4]);
+            if (r4 + 0 > s) b[r4 + 0] = fmaf(-u.x, x, b[r4 + 0]);
+            if (r4 + 1 > s) b[r4 + 1] = fmaf(-u.y, x, b[r4 + 1]);
+            if (r4 + 2 > s) b[r4 + 2] = fmaf(-u.z, x, b[r4 + 2]);
+            if (r4 + 3 > s) b[r4 + 3] = fmaf(-u.w, x, b[r4 + 3]);
+        }
+    }
+    if (c < d) {
+#pragma unroll
+        for (int r = 0; r < NB; ++r) Ac[(int64_t)r * d] = b[r];
+    }
+}
+
+// ---- syrk: trailing update of the upper tiles ------------------------------------------------------------------------------
+__device__ __forceinline__ void tri_tile(int t, int &I, int &J)     // t = J (J + 1) / 2 + I with I <= J
+{
+    J = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while (J * (J + 1) / 2 > t) --J;
+    while ((J + 1) * (J + 2) / 2 <= t) ++J;
+    I = t - J * (J + 1) / 2;
+}
+
+template <int WT>
+__global__ __launch_bounds__(256, 2) void chol_syrk_kernel(float *A, int64_t d, int64_t k0)
+{
+    constexpr int BN = 32 * WT, LDW = BN + 16, EPT = BN / 16;       // EPT floats per thread per token row (16 threads/row)
+    extern __shared__ __attribute__((aligned(16))) float cs[];     // [2 sides][NB][LDW]
+    int I, J;
+    tri_tile(blockIdx.x, I, J);
+    const bool diag = I == J;
+    const int64_t base = k0 + NB;                                   // first trailing column
+    const int64_t i0 = base + (int64_t)I * BN, j0 = base + (int64_t)J * BN;
+    const float *P = A + k0 * d;                                    // the row panel X of this step: P[t][c]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int stok = tid >> 4, scol = (tid & 15) * EPT;
+    const bool vec = (d % 4 == 0) && ((base & 3) == 0);
+
+    auto stage = [&](int side, int64_t c0) {
+#pragma unroll
+        for (int ps = 0; ps < NB / 16; ++ps) {
+            const int t = 16 * ps + stok;
+            float *dst = cs + (side * NB + t) * LDW + scol;
+            const int64_t c = c0 + scol;
+            if constexpr (EPT >= 4) {
+#pragma unroll
+                for (int e = 0; e < EPT; e += 4) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (vec && c + e + 4 <= d) {
+                        v = *reinterpret_cast<const float4 *>(P + (int64_t)t * d + c + e);
+                    } else {
+                        if (c + e + 0 < d) v.x = P[(int64_t)t * d + c + e + 0];
+                        if (c + e + 1 < d) v.y = P[(int64_t)t * d + c + e + 1];
+                        if (c + e + 2 < d) v.z = P[(int64_t)t * d + c + e + 2];
+                        if (c + e + 3 < d) v.w = P[(int64_t)t * d + c + e + 3];
+                    }
+                    *reinterpret_cast<float4 *>(dst + e) = v;
+                }
+            } else {
+                float2 v = make_float2(0.f, 0.f);
+                if (c + 0 < d) v.x = P[(int64_t)t * d + c + 0];
+                if (c + 1 < d) v.y = P[(int64_t)t * d + c + 1];
+                *reinterpret_cast<float2 *>(dst) = v;
+            }
+        }
+    };
+    stage(0, i0);
+    if (!diag) stage(1, j0);
+    __syncthreads();
+
+    f32x4_t acc[WT][WT];
+#pragma unroll
+    for (int x = 0; x < WT; ++x)
+#pragma unroll
+        for (int y = 0; y < WT; ++y) acc[x][y] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const float *As = cs + wi * (WT * 16) + (lane & 15);
+    const float *Bs = cs + (diag ? 0 : 1) * NB * LDW + wj * (WT * 16) + (lane & 15);
+#pragma unroll 4
+    for (int ks = 0; ks < NB / 4; ++ks) {
+        const int row = ks * 4 + (lane >> 4);
+        float a[WT], b[WT];
+#pragma unroll
+        for (int x = 0; x < WT; ++x) a[x] = As[row * LDW + x * 16];
+#pragma unroll
+        for (int y = 0; y < WT; ++y) b[y] = Bs[row * LDW + y * 16];
+#pragma unroll
+        for (int x = 0; x < WT; ++x)
+#pragma unroll
+            for (int y = 0; y < WT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b[y], acc[x][y], 0, 0, 0);
+    }
+    // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+    for (int x = 0; x < WT; ++x)
+#pragma unroll
+        for (int y = 0; y < WT; ++y)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t r = i0 + wi * (WT * 16) + x * 16 + 4 * (lane >> 4) + reg;
+                const int64_t c = j0 + wj * (WT * 16) + y * 16 + (lane & 15);
+                if (r < d && c < d) A[r * d + c] -= acc[x][y][reg];
+            }
+}
+
+template <int WT> int launch_syrk(float *A, int64_t d, int64_t k0, hipStream_t s)
+{
+    constexpr int BN = 32 * WT, LDW = BN + 16;
+    const size_t lds = (size_t)2 * NB * LDW * sizeof(float);
+    const int64_t rem = d - k0 - NB, T = (rem + BN - 1) / BN;
+    auto kern = chol_syrk_kernel<WT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: cannot reserve %zu B of LDS", lds);
+        attr_done = true;
+    }
+    kern<<<(unsigned)(T * (T + 1) / 2), 256, lds, s>>>(A, d, k0);
+    return QUIPAMD_OK;
+}
+
+// ---- finish: LT[c][j] = U[c][j] * (1 / U[c][c]) for j > c, else 0, in place -------------------------------------------------
+__global__ __launch_bounds__(256) void chol_finish_kernel(float *A, int64_t d)
+{
+    const int64_t c = blockIdx.x;
+    const float rinv = 1.f / A[c * d + c];
+    __syncthreads();                                             // every thread has the pivot before it is overwritten
+    for (int64_t j = threadIdx.x; j < d; j += 256) A[c * d + j] = (j > c) ? A[c * d + j] * rinv : 0.f;
+}
+
+}   // namespace
+
+extern "C" int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *info, void *stream)
+{
+    QA_REQUIRE(d >= 0, QUIPAMD_ERR_SHAPE, "cholesky_lt: bad d");
+    if (d == 0) return QUIPAMD_OK;
+    QA_REQUIRE(H && LT && info, QUIPAMD_ERR_ARG, "cholesky_lt: null pointer");
+    QA_REQUIRE(d <= (1 << 17), QUIPAMD_ERR_SHAPE, "cholesky_lt: d too large");
+    hipStream_t s = (hipStream_t)stream;
+    if ((const void *)H != (const void *)LT &&
+        hipMemcpyAsync(LT, H, (size_t)d * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: copy failed");
+    if (hipMemsetAsync(info, 0, sizeof(int), s) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: memset failed");
+    for (int64_t k0 = 0; k0 < d; k0 += NB) {
+        if (k0 + NB <= d) chol_diag_kernel<true><<<1, 64, 0, s>>>(LT, d, k0, info);
+        else chol_diag_kernel<false><<<1, 64, 0, s>>>(LT, d, k0, info);
+        const int64_t rem = d - k0 - NB;
+        if (rem <= 0) break;
+        chol_panel_kernel<<<(unsigned)((rem + 255) / 256), 256, 0, s>>>(LT, d, k0);
+        auto ntiles = [&](int64_t bn) { const int64_t T = (rem + bn - 1) / bn; return T * (T + 1) / 2; };
+        int rc;
+        if (ntiles(128) >= 384) rc = launch_syrk<4>(LT, d, k0, s);
+        else if (ntiles(64) >= 384) rc = launch_syrk<2>(LT, d, k0, s);
+        else rc = launch_syrk<1>(LT, d, k0, s);
+        if (rc != QUIPAMD_OK) return rc;
+    }
+    chol_finish_kernel<<<(unsigned)d, 256, 0, s>>>(LT, d);
+    QA_LAUNCH_CHECK("cholesky_lt");
+    return QUIPAMD_OK;
+}

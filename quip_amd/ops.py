@@ -291,6 +291,24 @@ def unit_lower_t(C):
     return LT
 
 
+def cholesky_lt(H, check=True):
+    """LT = D^-1 U strictly upper with H = U^T U: the unit-lower LDL factor of vector_balance.py:171-173, transposed,
+    by the blocked fp32 factorisation of quip_amd/csrc/cholesky.hip (K8).  Raises torch.linalg.LinAlgError like
+    torch.linalg.cholesky when a pivot is not positive (check=False skips the device read-back)."""
+    _need_gpu(H)
+    assert H.dtype == torch.float32 and H.dim() == 2 and H.shape[0] == H.shape[1]
+    H = H.contiguous()
+    LT = torch.empty_like(H)
+    info = torch.zeros(1, dtype=torch.int32, device=H.device)
+    _lib.call("quipamd_cholesky_lt", _p(H), _p(LT), H.shape[0], _p(info), _stream())
+    if check:
+        bad = int(info.item())
+        if bad:
+            raise torch.linalg.LinAlgError(
+                f"quip_amd.cholesky_lt: the leading minor of order {bad} is not positive-definite")
+    return LT
+
+
 def ldlq_round(Wgrid, LT, bits, eta=None, return_err=False):
     """LDLQ codes uint8 [m,d] (vector_balance.py:155-199 / 218-257)."""
     _need_gpu(Wgrid, LT)

@@ -23,10 +23,9 @@ def hessian_loss(dw, H):
 
 
 def _ldl_transposed(H):
-    """unit-lower LDL factor of H as LT = L^T - strict (vector_balance.py:171-173).  The Cholesky itself stays on
-    rocSOLVER through torch.linalg; scaling + transpose is one HIP kernel."""
-    C = torch.linalg.cholesky(H.to(torch.float32))
-    return ops.unit_lower_t(C)
+    """unit-lower LDL factor of H as LT = L^T - strict (vector_balance.py:171-173): blocked fp32 Cholesky of the upper
+    triangle + row scaling in quip_amd/csrc/cholesky.hip (K8); raises LinAlgError like torch.linalg.cholesky."""
+    return ops.cholesky_lt(H.to(torch.float32))
 
 
 def _round_ldl_codes(w, H, nbits, n_greedy_passes, unbiased):

@@ -220,3 +220,60 @@ def test_ldlq_full_size_properties_4096(ops):
     proxy = lambda dw: float(((dw.double() @ Hd) * dw.double()).sum())
     near = torch.clamp(torch.floor(W + 0.5), 0, maxq)
     assert proxy(codes.float() - W) < 0.2 * proxy(near - W)
+
+
+# --------------------------------------------------------------------------------------------- K8
+def _spd(d, seed, damp=0.01):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(d, d, generator=g) / d ** 0.5
+    sv = torch.arange(1, d + 1, dtype=torch.float32) ** -0.75
+    X = (torch.randn(2 * d, d, generator=g) * sv) @ A                      # SURVEY.md 8(d) correlated fixture
+    H = X.T @ X / (2 * d)
+    return H + damp * H.diag().mean() * torch.eye(d)
+
+
+@pytest.mark.parametrize("d", [16, 48, 64, 80, 128, 200, 512, 1000, 2048])
+def test_cholesky_lt_matches_fp64_factor(ops, d):
+    """K8 against the reference's definition evaluated in fp64 (vector_balance.py:171-173): forward error of the
+    normalised factor no worse than rocSOLVER's fp32 potrf on the same matrix, backward error ||U^T U - H|| at fp32 level."""
+    H = _spd(d, seed=d).to(DEV)
+    LT = ops.cholesky_lt(H)
+    C64 = torch.linalg.cholesky(H.double())
+    want = torch.triu((C64 / C64.diag()[None, :]).t(), diagonal=1)
+    assert torch.equal(torch.tril(LT), torch.zeros_like(LT))               # diagonal and below: exact zeros
+    err = ((LT.double() - want).norm() / want.norm().clamp(min=1e-30)).item()
+    C32 = torch.linalg.cholesky(H)
+    ref = torch.triu((C32 / C32.diag()[None, :]).t(), diagonal=1)
+    err_ref = ((ref.double() - want).norm() / want.norm().clamp(min=1e-30)).item()
+    assert err <= 4 * err_ref + 1e-6, (err, err_ref)
+    assert (LT.double() - want).abs().max().item() <= 1e-4
+    # it must be usable exactly where torch's factor was: LDLQ codes are sensitive to the last bits of L (a flipped
+    # rounding propagates down the row), so measure both fp32 factors against the codes of the fp64 factor
+    if d % 16 == 0:
+        g = torch.Generator().manual_seed(1)
+        w = (torch.rand(64, d, generator=g) * 3.6 - 0.3).clamp(0, 3).to(DEV)
+        truth = ops.ldlq_round(w, want.float().contiguous(), 2)
+        mine = (ops.ldlq_round(w, LT, 2) != truth).float().mean().item()
+        theirs = (ops.ldlq_round(w, ops.unit_lower_t(C32), 2) != truth).float().mean().item()
+        assert mine <= 2 * theirs + 1e-3, (mine, theirs)
+
+
+def test_cholesky_lt_backward_error_large(ops):
+    d = 4096
+    H = _spd(d, seed=3).to(DEV)
+    LT = ops.cholesky_lt(H)
+    C64 = torch.linalg.cholesky(H.double())
+    D = C64.diag()
+    U = (LT.double() + torch.eye(d, device=DEV, dtype=torch.float64)) * D[:, None]     # U = D (LT + I)
+    resid = (U.t() @ U - H.double()).abs().max().item() / H.abs().max().item()
+    assert resid < 5e-6, resid
+    want = torch.triu((C64 / D[None, :]).t(), diagonal=1)
+    assert (LT.double() - want).abs().max().item() < 5e-4
+
+
+def test_cholesky_lt_not_positive_definite(ops):
+    H = _spd(128, seed=9).to(DEV)
+    H[70, 70] = -1.0
+    with pytest.raises(torch.linalg.LinAlgError):
+        ops.cholesky_lt(H)
+    assert ops.cholesky_lt(torch.zeros(0, 0, device=DEV)).shape == (0, 0)
