@@ -75,8 +75,11 @@ template <int J> __device__ __forceinline__ void factor_rows(float (&a)[NB], int
     if constexpr (J < NB) {
         const float piv = lane_bcast(a[J], J);
         if (!(piv > 0.f) && l == 0) atomicCAS(info, 0, (int)(k0 + J + 1));
-        const float ujj = sqrtf(piv);
-        a[J] = (l >= J) ? a[J] / ujj : 0.f;                       // row J of U (lane J holds u_JJ); lanes < J: 0
+        // 1/sqrt(piv): v_rsq_f32 (1 ulp) + one Newton step -- the libm sqrtf + IEEE division pair costs ~40 instructions
+        // per row, a third of this single-wave kernel (17.5 -> 11 us per block); row J = a * r, u_JJ = piv * r
+        float r = __builtin_amdgcn_rsqf(piv);
+        r = fmaf(0.5f * r, fmaf(-piv * r, r, 1.f), r);
+        a[J] = (l >= J) ? a[J] * r : 0.f;                         // row J of U (lane J holds u_JJ); lanes < J: 0
         row_update<J, J + 1>(a);                                 // only lanes >= i of row i are read later
         factor_rows<J + 1>(a, l, k0, info);
     }
@@ -113,7 +116,10 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(float *A, int64_t d, int6
 
 // ---- panel: X = U_kk^-T A[k0:k0+64, c] for the columns c >= k0+64, one thread per column ----------------------------------
 // (only launched when columns remain, so the 64 rows of the step are always inside the matrix).  U_kk sits in LDS and
-// is read as broadcast float4s: 2080 wave-uniform scalar loads made hipcc hoist them all and spill 700 SGPRs.
+// is read as broadcast float4s: 2080 wave-uniform scalar loads made hipcc hoist them all and spill 700 SGPRs (and a
+// compiler-level fence per row to pin them turns them into vector loads).  A broadcast read still moves 16 B to each
+// of 64 lanes, so this kernel is LDS-bandwidth bound (21 us); two columns per thread to halve the reads per column
+// ran out of registers (hipcc moves every row's reads to the top) -- left as is.
 __global__ __launch_bounds__(256) void chol_panel_kernel(float *A, int64_t d, int64_t k0)
 {
     __shared__ __attribute__((aligned(16))) float Us[NB][NB + 4];
