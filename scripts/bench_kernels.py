@@ -113,11 +113,13 @@ def main():
         t_chol = timeit(lambda: torch.linalg.cholesky(H), reps=3, warm=1)
         C = torch.linalg.cholesky(H)
         t_ult = timeit(lambda: ops.unit_lower_t(C))
-        LT = ops.unit_lower_t(C)
+        t_k8 = timeit(lambda: ops.cholesky_lt(H, check=False), reps=3, warm=1)
+        LT = ops.cholesky_lt(H)
         wg = ops.gridmap(W16, 'b', s, None, maxq)
         t = timeit(lambda: ops.ldlq_round(wg, LT, bits), reps=3, warm=1)
         emit(kernel="K4 ldlq_round", m=m, d=d, ms=t * 1e3, far_field_TFLOPs=m * d * d / t / 1e12,
-             us_per_column=t / d * 1e6, cholesky_ms=t_chol * 1e3, unit_lower_t_ms=t_ult * 1e3)
+             us_per_column=t / d * 1e6, k8_cholesky_lt_ms=t_k8 * 1e3, rocsolver_cholesky_ms=t_chol * 1e3,
+             unit_lower_t_ms=t_ult * 1e3)
         # ---- whole Balance path on the GPU: preproc (rescale + blocked projection + damping) and fasterquant
         if not args.no_balance:
             from quip_amd import bal, quant
