@@ -19,6 +19,75 @@ from quip_amd import bal, quant  # noqa: E402
 CPU_REF_S = {"2048x2048": (1.5, 1.0), "8192x2048": (10.4, 4.5), "2048x8192": (52.1, 29.3)}   # (round_ldl, lazy) BASELINE.md
 
 
+def llama(args, dev):
+    """Llama-2-7B Linear shapes (llama.py:87-156 quantises q,k,v,o, gate, up, down per block), same call sequence."""
+    from quip_amd import method
+    shapes = [(4096, 4096)] * 4 + [(11008, 4096)] * 2 + [(4096, 11008)]
+    Hs = {}
+    for d in (4096, 11008):
+        g = torch.Generator().manual_seed(d)
+        X = torch.randn(d + 256, d, generator=g).to(dev)
+        Hs[d] = (X.T @ X / (d + 256)).double()
+        del X
+    np.random.seed(0)
+    torch.manual_seed(0)
+    per = {}
+    for blk in range(args.blocks):
+        for (m, d) in shapes:
+            layer = torch.nn.Linear(d, m, bias=False).to(dev).half()
+            layer.weight.data = (0.02 * torch.randn(m, d)).to(dev).half()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            b = bal.Balance(layer)
+            b.configure('ldlq', args.bits, 0, False)
+            b.quantizer = quant.Quantizer()
+            b.quantizer.configure(args.bits, perchannel=True, sym=False, qfn='b', mse=False)
+            b.H = Hs[d].clone()
+            b.nsamples = 1
+            b.post_batch()
+            b.preproc(preproc_gptqH=True, percdamp=0.01, preproc_rescale=True, preproc_proj=True, preproc_proj_extra=0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            b.fasterquant(lazy_batch=False)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            b.free()
+            if blk > 0 or args.blocks == 1:
+                e = per.setdefault(f"{m}x{d}", {"n": 0, "preproc_s": 0.0, "fasterquant_s": 0.0})
+                e["n"] += 1
+                e["preproc_s"] += t1 - t0
+                e["fasterquant_s"] += t2 - t1
+    counts = {"4096x4096": 4, "11008x4096": 2, "4096x11008": 1}
+    out = {"model": "llama-2-7b shapes, synthetic W / H", "blocks_run": args.blocks, "per_layer": {}}
+    tot = 0.0
+    for k, e in per.items():
+        n = max(e["n"], 1)
+        out["per_layer"][k] = {"preproc_s": round(e["preproc_s"] / n, 4), "fasterquant_s": round(e["fasterquant_s"] / n, 4)}
+        tot += 32 * counts[k] * (e["preproc_s"] + e["fasterquant_s"]) / n
+    out["total_s_extrapolated_32_blocks"] = round(tot, 2)
+    hess = {}
+    if not args.no_hessian:
+        for d in (4096, 11008):
+            layer = torch.nn.Linear(d, 16, bias=False).to(dev).half()
+            x = torch.randn(1, args.seqlen, d, device=dev).half()
+            qm = method.QuantMethod(layer)
+            qm.add_batch(x, None)
+            torch.cuda.synchronize()
+            qm = method.QuantMethod(layer)
+            t0 = time.perf_counter()
+            for _ in range(args.nsamples):
+                qm.add_batch(x, None)
+            qm.post_batch()
+            torch.cuda.synchronize()
+            hess[str(d)] = round(time.perf_counter() - t0, 4)
+            del qm
+        hb = 6 * hess["4096"] + hess["11008"]                    # q,k,v,o,gate,up see 4096 features; down sees 11008
+        out["hessian"] = {"nsamples": args.nsamples, "seqlen": args.seqlen, "per_linear_k7_s": hess, "per_block_s": round(hb, 3),
+                          "32_blocks_s": round(32 * hb, 2)}
+        out["total_incl_hessian_s"] = round(tot + 32 * hb, 2)
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--blocks", type=int, default=2)
@@ -26,8 +95,12 @@ def main():
     ap.add_argument("--nsamples", type=int, default=128, help="calibration samples per Linear for the Hessian leg (opt.py default)")
     ap.add_argument("--seqlen", type=int, default=2048)
     ap.add_argument("--no-hessian", action="store_true")
+    ap.add_argument("--model", default="opt1p3b", choices=["opt1p3b", "llama7b"],
+                    help="llama7b: BASELINE configs[3] shapes (32 blocks x {4 x 4096^2, 2 x 11008x4096, 4096x11008}); no CPU figures exist")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.model == "llama7b":
+        return llama(args, dev)
     shapes = [(2048, 2048)] * 4 + [(8192, 2048), (2048, 8192)]
     Hs = {}
     for d in (2048, 8192):
