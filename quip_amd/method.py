@@ -148,12 +148,24 @@ class QuantMethod:
     # triangle on the fp64 matrix pipe straight from the token-major hook input (no transpose, no fp64 copy of X);
     # `H` then holds the triangle only until post_batch mirrors it.  `_tri` records that state; assigning `.H` from
     # outside (optq_ldlq_equiv.py:24,35) leaves it False, and post_batch then takes the reference's dense route.
+    def share_hessian_from(self, leader):
+        """This layer sees the SAME input as `leader` (q/k/v of an attention block, gate/up of a gated MLP): the
+        reference accumulates the identical X^T X once per Linear (opt.py:131-145); after this call
+        add_batch here only counts samples and post_batch takes its own fp32 copy of the leader's Hessian (preproc
+        then modifies it per layer, method.py:139-176).  Call before the first add_batch."""
+        assert leader is not self and self.nsamples == 0 and leader.columns == self.columns
+        self._leader = leader
+        self.H = None
+
     def add_batch(self, inp, out):
         if DEBUG:
             self.inp1, self.out1 = inp, out
         if inp.dim() == 2:
             inp = inp.unsqueeze(0)
         n_calls = inp.shape[0]                     # nsamples counts hook calls' batch dim, not tokens
+        if getattr(self, "_leader", None) is not None:
+            self.nsamples += n_calls
+            return
         linear = isinstance(self.layer, (nn.Linear, transformers.Conv1D))
         if linear and inp.dim() == 3:
             inp = inp.reshape(-1, inp.shape[-1])
@@ -176,6 +188,16 @@ class QuantMethod:
         self.H.addmm_(inp, inp.t())
 
     def post_batch(self):
+        leader = getattr(self, "_leader", None)
+        if leader is not None:
+            assert leader.nsamples == self.nsamples, "share_hessian_from: leader and follower saw different samples"
+            if leader.H.dtype == torch.float64:                 # leader not finished yet: finish a copy from its accumulator
+                self.H = (ops.hessian_finish(leader.H, leader.nsamples) if getattr(leader, "_tri", False)
+                          else (leader.H / leader.nsamples).to(torch.float32))
+            else:
+                self.H = leader.H.clone()
+            self._leader = None
+            return
         if getattr(self, "_tri", False):
             self.H = ops.hessian_finish(self.H, self.nsamples)
             self._tri = False

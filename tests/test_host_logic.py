@@ -75,3 +75,26 @@ def test_quantizer_configure_and_cpu_find_params():
     q.find_params(torch.from_numpy(g["W32"]), weight=True)
     np.testing.assert_array_equal(q.scale.numpy(), g["a4_f32_scale"])
     np.testing.assert_array_equal(q.zero.numpy(), g["a4_f32_zero"])
+
+
+def test_share_hessian_between_layers_with_the_same_input():
+    """q/k/v see one input: a follower takes the leader's Hessian instead of accumulating its own copy."""
+    from quip_amd.method import QuantMethod
+    torch.manual_seed(0)
+    lq, lk, lv = (torch.nn.Linear(24, 8) for _ in range(3))
+    X = torch.randn(4, 10, 24)
+    ref = QuantMethod(lk)
+    lead, f1, f2 = QuantMethod(lq), QuantMethod(lk), QuantMethod(lv)
+    f1.share_hessian_from(lead)
+    f2.share_hessian_from(lead)
+    for j in range(4):
+        for qm in (ref, lead, f1, f2):
+            qm.add_batch(X[j:j + 1], None)
+    ref.post_batch()
+    f1.post_batch()                                   # before the leader: finishes from the fp64 accumulator
+    lead.post_batch()
+    f2.post_batch()                                   # after the leader: copies the finished matrix
+    for qm in (lead, f1, f2):
+        assert qm.nsamples == 4 and qm.H.dtype == torch.float32
+        assert torch.equal(qm.H, ref.H)
+    assert f1.H.data_ptr() != lead.H.data_ptr() and f2.H.data_ptr() != lead.H.data_ptr()
