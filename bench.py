@@ -225,6 +225,22 @@ def main():
             "hbm_frac": round(BYTES_ACC / (t_acc_cold / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
 
+    # The side measurements below must never cost the headline line: exceptions are caught per leg, and a watchdog on
+    # every rank covers a hang (a collective that never completes cannot be caught): when it fires, rank 0 prints the
+    # line it has -- the headline is complete at this point -- and every rank leaves.
+    import threading
+    printed = threading.Lock()
+
+    def emit_and_exit():
+        if printed.acquire(blocking=False):
+            if rank == 0:
+                out.setdefault("side_measurements", "watchdog fired: a side leg did not finish within 420 s")
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+    watchdog = threading.Timer(420.0, emit_and_exit)
+    watchdog.daemon = True
+    watchdog.start()
+
     # ---- sharded LDLQ: rows of one OPT-1.3B-fc2-sized Linear over the N ranks -----------------
     if not args.no_ldlq:
         try:
@@ -334,8 +350,11 @@ def main():
                                "sample": f"{n} calls of torch CPU F.linear fp32 x[16,4096] @ What[4096,4096]^T "
                                          f"(dense fake-quant weights, what the reference runs at inference), "
                                          f"{dt * 1e3:.3f} ms/call"}
+    watchdog.cancel()
+    if not printed.acquire(blocking=False):
+        return                                   # the watchdog is printing
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
