@@ -220,6 +220,17 @@ int quipamd_hessian_finish(const double *Hacc, double nsamples, float *H, int64_
  *   the factor is then meaningless. */
 int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *info, void *stream);
 
+/* ---- single-token decode attention (the decode loop of benchmark(), opt.py:431-482) -------------
+ * Replaces the eager HF attention chain of one decode step (cache append, q K^T, scale + causal mask, softmax, p V --
+ * nine launches per block) with one launch:
+ *   kcache/vcache[b, head, *pos, :] = k/v[b, head*hd : (head+1)*hd];   out[b, head*hd + :] = softmax(scale q.K[0..*pos]^T) V[0..*pos]
+ *   q, k, v, out: [bs, heads*hd] f16 / bf16 with row stride ld (elements, multiple of 8); kcache, vcache: [bs, heads, maxlen, hd]
+ *   contiguous; pos: DEVICE int64 (so the launch can be replayed from a hipGraph while the position advances);
+ *   hd 64 or 128; fp32 scores, softmax and accumulation.  A position outside [0, maxlen) makes the launch a no-op. */
+int quipamd_decode_attention(const void *q, const void *k, const void *v, void *kcache, void *vcache, const int64_t *pos,
+                             void *out, int dtype, int64_t bs, int heads, int hd, int64_t maxlen, float scale, int64_t ld,
+                             void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libquip_amd.so")
 
-c_i64, c_int, c_vp, c_double = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_double
+c_i64, c_int, c_vp, c_double, c_float = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_float
 
 # name -> argtypes; must list every function declared in include/quip_amd.h (tests/test_abi.py checks)
 SIGNATURES = {
@@ -38,6 +38,7 @@ SIGNATURES = {
                                   c_i64, c_i64, c_vp],
     "quipamd_ldlq_round": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp],
     "quipamd_unit_lower_t": [c_vp, c_vp, c_i64, c_vp],
+    "quipamd_decode_attention": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_i64, c_float, c_i64, c_vp],
     "quipamd_cholesky_lt": [c_vp, c_vp, c_i64, c_vp, c_vp],
     "quipamd_hessian_accum": [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp],
     "quipamd_hessian_finish": [c_vp, c_double, c_vp, c_i64, c_vp],

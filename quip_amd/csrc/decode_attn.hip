@@ -1,0 +1,149 @@
+// decode_attn.hip -- single-token attention for the decode loop (benchmark(), opt.py:431-482)
+//
+// One generated token per sequence: append this step's k, v to the static KV cache at position *pos, then
+//   o[b, head] = softmax(scale * q . K[0..pos]^T) V[0..pos].
+// In the reference's benchmark() this is HF OPTAttention in eager PyTorch -- nine launches per block (two index_copy,
+// matmul, scale + mask, cast, softmax, cast, matmul, reshape), ~45 us of the ~130 us a packed block took once the
+// Linears ran on K2 / K3, i.e. the decode loop's tok/s measured attention glue, not the low-bit path.  Here: one launch.
+//   grid = bs * heads workgroups of 256 threads; `pos` is read from DEVICE memory so the launch can sit in a hipGraph
+//   that is replayed for every token (the position advances on the device).
+//   phase 1  scores: thread t (+256, ...) owns cache position t: 128-byte row of K (8 x 16 B), q in registers, fp32 dot;
+//            scores and the running max go through LDS, exp in fp32.
+//   phase 2  lane = output dimension (hd = 64 -> one wave per row, 128 B coalesced per V row), the 4 waves take
+//            positions t = w, w+4, ...; partial sums meet in LDS; normalised, written in the activation dtype.
+// fp32 throughout (the eager chain rounds scores and probabilities to fp16); the result differs from it by that rounding.
+#include "common.h"
+
+namespace {
+
+template <class TI, int HD>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>::storage *q, const typename DT<TI>::storage *k,
+                                                         const typename DT<TI>::storage *v, typename DT<TI>::storage *kc,
+                                                         typename DT<TI>::storage *vc, const int64_t *pos_p,
+                                                         typename DT<TI>::storage *out, int heads, int64_t maxlen, float scale,
+                                                         int64_t ldq)
+{
+    typedef typename DT<TI>::storage S;
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // scores[maxlen] | red[8] | part[4][HD]
+    float *scores = sm, *red = sm + maxlen, *part = sm + maxlen + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / heads, head = blockIdx.x % heads;
+    const int64_t pos = *pos_p, T = pos + 1;
+    const S *qh = q + (int64_t)b * ldq + head * HD, *kh = k + (int64_t)b * ldq + head * HD, *vh = v + (int64_t)b * ldq + head * HD;
+    S *kcb = kc + ((int64_t)b * heads + head) * maxlen * HD, *vcb = vc + ((int64_t)b * heads + head) * maxlen * HD;
+
+    if (pos < 0 || pos >= maxlen) return;                           // uniform; a full cache is the caller's error
+    // append this token; the barrier (workgroup-scope fence) makes it visible to the reads below
+    if (tid < HD) kcb[pos * HD + tid] = kh[tid];
+    else if (tid < 2 * HD) vcb[pos * HD + tid - HD] = vh[tid - HD];
+    __syncthreads();
+
+    float qr[HD];
+#pragma unroll
+    for (int e = 0; e < HD; ++e) qr[e] = DT<TI>::load(qh, e) * scale;
+
+    // ---- phase 1: scores --------------------------------------------------------------------------------------------
+    float mx = -INFINITY;
+    for (int64_t t = tid; t < T; t += 256) {
+        const S *row = kcb + t * HD;
+        float acc = 0.f;
+#pragma unroll
+        for (int e8 = 0; e8 < HD; e8 += 8) {
+            S raw[8];
+            *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(row + e8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(qr[e8 + e], DT<TI>::load(raw, e), acc);
+        }
+        scores[t] = acc;
+        mx = fmaxf(mx, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int64_t t = tid; t < T; t += 256) {
+        const float p = __expf(scores[t] - mx);
+        scores[t] = p;
+        sum += p;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+
+    // ---- phase 2: o = p V ---------------------------------------------------------------------------------------------
+    constexpr int NL = HD / 64;                                      // output dims per lane (hd = 64: 1, hd = 128: 2)
+    float o[NL];
+#pragma unroll
+    for (int n = 0; n < NL; ++n) o[n] = 0.f;
+    // 8 rows in flight per wave: one 128-byte row per iteration would be a chain of L2 round trips
+    int64_t t = wave;
+    for (; t + 28 < T; t += 32) {
+        float vv[8][NL];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int n = 0; n < NL; ++n) vv[u][n] = DT<TI>::load(vcb + (t + 4 * u) * HD, lane + 64 * n);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int n = 0; n < NL; ++n) o[n] = fmaf(scores[t + 4 * u], vv[u][n], o[n]);
+    }
+    for (; t < T; t += 4) {
+        const float p = scores[t];
+#pragma unroll
+        for (int n = 0; n < NL; ++n) o[n] = fmaf(p, DT<TI>::load(vcb + t * HD, lane + 64 * n), o[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NL; ++n) part[wave * HD + lane + 64 * n] = o[n];
+    __syncthreads();
+    if (tid < HD) {
+        const float r = (part[tid] + part[HD + tid]) + (part[2 * HD + tid] + part[3 * HD + tid]);
+        DT<TI>::store(out + (int64_t)b * ldq + head * HD, tid, r * inv);
+    }
+}
+
+template <class TI, int HD>
+int launch_attn(const void *q, const void *k, const void *v, void *kc, void *vc, const int64_t *pos, void *out, int64_t bs,
+                int heads, int64_t maxlen, float scale, int64_t ldq, hipStream_t s)
+{
+    typedef typename DT<TI>::storage S;
+    const size_t lds = (size_t)(maxlen + 8 + 4 * HD) * sizeof(float);
+    auto kern = decode_attn_kernel<TI, HD>;
+    static size_t reserved = 0;
+    if (lds > reserved && lds > 48 * 1024) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_attention: cannot reserve %zu B of LDS", lds);
+        reserved = lds;
+    }
+    kern<<<(unsigned)(bs * heads), 256, lds, s>>>((const S *)q, (const S *)k, (const S *)v, (S *)kc, (S *)vc, pos, (S *)out, heads,
+                                                  maxlen, scale, ldq);
+    QA_LAUNCH_CHECK("decode_attention");
+    return QUIPAMD_OK;
+}
+
+}   // namespace
+
+extern "C" int quipamd_decode_attention(const void *q, const void *k, const void *v, void *kcache, void *vcache, const int64_t *pos,
+                                        void *out, int dtype, int64_t bs, int heads, int hd, int64_t maxlen, float scale,
+                                        int64_t ld, void *stream)
+{
+    QA_REQUIRE(bs >= 0 && heads > 0 && maxlen > 0, QUIPAMD_ERR_SHAPE, "decode_attention: bad shape");
+    if (bs == 0) return QUIPAMD_OK;
+    QA_REQUIRE(q && k && v && kcache && vcache && pos && out, QUIPAMD_ERR_ARG, "decode_attention: null pointer");
+    QA_REQUIRE(hd == 64 || hd == 128, QUIPAMD_ERR_UNSUPPORTED, "decode_attention: head_dim %d (64 or 128)", hd);
+    QA_REQUIRE(dtype == QUIPAMD_F16 || dtype == QUIPAMD_BF16, QUIPAMD_ERR_UNSUPPORTED, "decode_attention: f16 / bf16 only");
+    QA_REQUIRE(ld >= (int64_t)heads * hd && ld % 8 == 0, QUIPAMD_ERR_SHAPE, "decode_attention: row stride %lld", (long long)ld);
+    QA_REQUIRE(maxlen <= 32768, QUIPAMD_ERR_SHAPE, "decode_attention: maxlen %lld > 32768", (long long)maxlen);
+    QA_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)kcache | (uintptr_t)vcache) & 15) == 0, QUIPAMD_ERR_ARG,
+               "decode_attention: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == QUIPAMD_F16)
+        return hd == 64 ? launch_attn<F16, 64>(q, k, v, kcache, vcache, pos, out, bs, heads, maxlen, scale, ld, s)
+                        : launch_attn<F16, 128>(q, k, v, kcache, vcache, pos, out, bs, heads, maxlen, scale, ld, s);
+    return hd == 64 ? launch_attn<BF16, 64>(q, k, v, kcache, vcache, pos, out, bs, heads, maxlen, scale, ld, s)
+                    : launch_attn<BF16, 128>(q, k, v, kcache, vcache, pos, out, bs, heads, maxlen, scale, ld, s);
+}

@@ -348,3 +348,25 @@ def hessian_finish(Hacc, nsamples):
     H = torch.empty(Hacc.shape, dtype=torch.float32, device=Hacc.device)
     _lib.call("quipamd_hessian_finish", _p(Hacc), float(nsamples), _p(H), Hacc.shape[0], _stream())
     return H
+
+
+# ------------------------------------------------------------------------------------------------- decode attention
+def decode_attention(q, k, v, kcache, vcache, pos, scale=None):
+    """one decode step of causal attention with a static KV cache, one launch (quip_amd/csrc/decode_attn.hip).
+    q, k, v: [bs, heads*hd] f16/bf16; kcache, vcache: [bs, heads, maxlen, hd] contiguous (updated in place at *pos);
+    pos: int64 [1] ON THE DEVICE.  Returns out [bs, heads*hd]."""
+    _need_gpu(q, k, v, kcache, vcache, pos)
+    bs, heads, maxlen, hd = kcache.shape
+    assert q.shape == (bs, heads * hd) and k.shape == q.shape and v.shape == q.shape
+    assert kcache.is_contiguous() and vcache.is_contiguous() and vcache.shape == kcache.shape
+    assert pos.dtype == torch.int64 and pos.numel() == 1
+    assert q.dtype == k.dtype == v.dtype == kcache.dtype == vcache.dtype
+    ld = q.stride(0) if bs > 1 else heads * hd
+    assert all(t.stride(-1) == 1 and (bs == 1 or t.stride(0) == ld) for t in (q, k, v))
+    out = torch.empty((bs, heads * hd), dtype=q.dtype, device=q.device)
+    if bs > 1 and ld != heads * hd:
+        out = torch.empty((bs, ld), dtype=q.dtype, device=q.device)[:, :heads * hd]
+    sc = float(scale) if scale is not None else 1.0 / (hd ** 0.5)
+    _lib.call("quipamd_decode_attention", _p(q), _p(k), _p(v), _p(kcache), _p(vcache), _p(pos), _p(out), _dtype(q), bs,
+              heads, hd, maxlen, ctypes.c_float(sc), ld, _stream())
+    return out

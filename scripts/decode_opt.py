@@ -41,6 +41,7 @@ class Block(nn.Module):
         self.k_proj, self.v_proj, self.q_proj, self.out_proj = mk(h, h), mk(h, h), mk(h, h), mk(h, h)
         self.fc1, self.fc2 = mk(h, ffn), mk(ffn, h)
         self.fused = False      # packed layers: q/k/v grouped, LayerNorm / residual / ReLU folded into the operator launches
+        self.fused_attn = False  # cache append + q K^T + softmax + p V as one launch (quip_amd/csrc/decode_attn.hip)
 
     def forward(self, x, kc, vc, pos, mask):
         """x [bs, h]; kc / vc [bs, heads, maxlen, hd]; pos int64 [1] on the device; mask [maxlen] additive."""
@@ -50,12 +51,15 @@ class Block(nn.Module):
         else:
             hn = self.ln1(x)
             q, k, v = self.q_proj(hn), self.k_proj(hn), self.v_proj(hn)
-        q, k, v = (t.view(bs, self.heads, 1, self.hd) for t in (q, k, v))
-        kc.index_copy_(2, pos, k)
-        vc.index_copy_(2, pos, v)
-        att = torch.matmul(q, kc.transpose(2, 3)) * (1.0 / math.sqrt(self.hd)) + mask        # [bs, heads, 1, maxlen]
-        att = torch.softmax(att.float(), -1).to(x.dtype)
-        o = torch.matmul(att, vc).reshape(bs, self.h)
+        if self.fused_attn:
+            o = ops.decode_attention(q, k, v, kc, vc, pos)
+        else:                                               # the eager chain of HF's attention: nine launches
+            q, k, v = (t.view(bs, self.heads, 1, self.hd) for t in (q, k, v))
+            kc.index_copy_(2, pos, k)
+            vc.index_copy_(2, pos, v)
+            att = torch.matmul(q, kc.transpose(2, 3)) * (1.0 / math.sqrt(self.hd)) + mask    # [bs, heads, 1, maxlen]
+            att = torch.softmax(att.float(), -1).to(x.dtype)
+            o = torch.matmul(att, vc).reshape(bs, self.h)
         if self.fused:
             x = packed_forward_fused([self.out_proj], o, residual=x)[0]
             hmid = packed_forward_fused([self.fc1], x, ln=self.ln2, relu=True)[0]
@@ -167,9 +171,16 @@ def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense
     out = {"config": {"arch": "OPT-1.3B (hidden 2048, ffn 8192, heads 32, vocab 50272)", "layers": layers, "bits": bits,
                       "bs": bs, "prompt": prompt, "tokens": tokens, "launch": "eager" if eager else "hipGraph",
                       "weights": "random init, nearest-rounded qfn-b codes, Kronecker U/V, random scaleWH"}}
+    def set_attn(flag):
+        for blk in model.blocks:
+            blk.fused_attn = flag
     if with_dense:
         med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
         out["dense_fp16"] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med}
+        set_attn(True)
+        med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+        out["dense_fp16_fused_attn"] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med}
+        set_attn(False)
     twin, nbytes = pack_model(model, bits, dev)
     del twin
     med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
@@ -180,6 +191,10 @@ def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense
     med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
     out["packed_w%d_fused" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
                                       "what": "q/k/v grouped; LayerNorm folded into V(x/s); bias + residual + ReLU folded into U^T y"}
+    set_attn(True)
+    med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+    out["packed_w%d_fused_attn" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+                                           "what": "as packed_fused + single-launch decode attention (13 launches per block)"}
     del model
     torch.cuda.empty_cache()
     return out
@@ -213,19 +228,25 @@ def decode_check(layers=2, bits=2):
     torch.manual_seed(1)
     _, _, lf = time_decode(model, 2, 0, 0, 32, dev, dtype, True)
     for blk in model.blocks:
+        blk.fused_attn = True
+    torch.manual_seed(1)
+    _, _, la = time_decode(model, 2, 0, 0, 32, dev, dtype, True)
+    for blk in model.blocks:
         blk.fused = False
+        blk.fused_attn = False
     for (li, name), (Wd, b) in twin.items():
         lin = nn.Linear(Wd.shape[1], Wd.shape[0], bias=True, dtype=dtype, device=dev)
         lin.weight.data, lin.bias.data = Wd, b
         setattr(model.blocks[li], name, lin)
     torch.manual_seed(1)
     _, _, ld = time_decode(model, 2, 0, 0, 32, dev, dtype, True)
-    return float((lq - ld).norm() / ld.norm()), float((lf - ld).norm() / ld.norm())
+    return float((lq - ld).norm() / ld.norm()), float((lf - ld).norm() / ld.norm()), float((la - ld).norm() / ld.norm())
 
 
 if __name__ == "__main__":
     if "--check" in sys.argv:
-        e1, e2 = decode_check()
-        print(json.dumps({"decode_logits_rel_err_packed_vs_dense_twin": e1, "fused_packed_vs_dense_twin": e2}))
+        e1, e2, e3 = decode_check()
+        print(json.dumps({"decode_logits_rel_err_packed_vs_dense_twin": e1, "fused_packed_vs_dense_twin": e2,
+                          "fused_packed_fused_attn_vs_dense_twin": e3}))
     else:
         main()
