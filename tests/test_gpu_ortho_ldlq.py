@@ -277,3 +277,13 @@ def test_cholesky_lt_not_positive_definite(ops):
     with pytest.raises(torch.linalg.LinAlgError):
         ops.cholesky_lt(H)
     assert ops.cholesky_lt(torch.zeros(0, 0, device=DEV)).shape == (0, 0)
+
+
+@pytest.mark.parametrize("d", [32, 96, 160])
+def test_cholesky_lt_against_oracle_factor(ops, O, d):
+    """K8 against the oracle's restatement of vector_balance.py:171-173 (numpy), transposed."""
+    H = _spd(d, seed=100 + d)
+    L = O.ldl_factor(H.numpy())                                  # unit-lower minus identity, as round_ldl uses it
+    want = np.ascontiguousarray(L.T)
+    got = ops.cholesky_lt(H.to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)          # fp32 forward error on the correlated fixture
