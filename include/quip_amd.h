@@ -195,6 +195,18 @@ int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int nops, int64_t
 int quipamd_ldlq_round(const float *Wgrid, const float *LT, const float *eta, int bits, uint8_t *codes,
                        float *err_ws, int64_t m, int64_t d, void *stream);
 
+/* ---- OPTQ / GPTQ rounding on the K4 machinery -----------------------------------
+ * Replaces the column loop + lazy block update of GPTQ.fasterquant (gptq.py:56-93, groupsize = -1):
+ *   for i = 0 .. d-1:  q_i = clamp(round(w'_i), 0, 2^bits-1);  e_i = (w'_i - q_i) / Hinv[i][i];  w'_j -= e_i Hinv[i][j]  (j > i)
+ * in grid coordinates (the per-row scale cancels).  With the raw residual r_i = w'_i - q_i this is the LDLQ kernel's
+ * recurrence run over the REVERSED columns with the updated-weight residual fed back through
+ *   FT[c'][i'] = -Hinv[i][c] / Hinv[i][i]   (c' = d-1-c, i' = d-1-i, i < c; 0 elsewhere),
+ * so the caller passes  Wgrid_rev = Wgrid[:, ::-1],  FT as above (float [d, d], strictly upper), and gets codes_rev
+ * (uint8 [m, d], reversed columns) and err_ws (float [m, d], the residuals r, reversed).  Ties round half up
+ * (torch.round in the reference rounds half to even).  Requires d % 16 == 0. */
+int quipamd_gptq_round(const float *Wgrid_rev, const float *FT, int bits, uint8_t *codes_rev, float *err_ws, int64_t m,
+                       int64_t d, void *stream);
+
 /* quipamd_unit_lower_t: from the lower Cholesky factor C (H = C C^T, row-major [d,d]) build
  *   LT[c][j] = C[j][c] * (1 / C[c][c]) for j > c, 0 elsewhere  (vector_balance.py:172-173). */
 int quipamd_unit_lower_t(const float *C, float *LT, int64_t d, void *stream);

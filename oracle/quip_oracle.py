@@ -410,6 +410,34 @@ def quantize_weight_vecbal(w, H, nbits, scale, zero, qfn):
     return codes_to_weight_qfnb(codes, s, maxq), codes
 
 
+# --------------------------------------------------------------------------- OPTQ / GPTQ
+def gptq_round(W, H, scale, zero, maxq, blocksize=128):
+    """gptq.py:51-93 (groupsize -1, qfn a): upper Cholesky factor of H^-1, then column by column
+    q = quantize_qfna(w); e = (w - q) / Hinv[i][i]; W[:, i:] -= e Hinv[i][i:], lazily across 128-column blocks.
+    fp32 like the reference.  Returns (Q fp32 [m,d], codes)."""
+    W = np.array(W, np.float32)
+    m, d = W.shape
+    Hinv = np.linalg.cholesky(np.linalg.inv(np.asarray(H, np.float64))).T.astype(np.float32)   # upper: H^-1 = Hinv^T Hinv
+    Q = np.zeros_like(W)
+    codes = np.zeros((m, d), np.float32)
+    s, z = np.asarray(scale, np.float32).reshape(-1, 1), np.asarray(zero, np.float32).reshape(-1, 1)
+    for i1 in range(0, d, blocksize):
+        i2 = min(i1 + blocksize, d)
+        Wb = W[:, i1:i2].copy()
+        Eb = np.zeros_like(Wb)
+        Hb = Hinv[i1:i2, i1:i2]
+        for i in range(i2 - i1):
+            col = Wb[:, i:i + 1]
+            c = np.clip(np.round(col / s) + z, 0, maxq).astype(np.float32)          # quant.py:6-8 (np.round: half to even)
+            q = (s * (c - z)).astype(np.float32)
+            Q[:, i1 + i], codes[:, i1 + i] = q[:, 0], c[:, 0]
+            e = ((col - q) / Hb[i, i]).astype(np.float32)
+            Wb[:, i:] -= e * Hb[i:i + 1, i:]
+            Eb[:, i] = e[:, 0]
+        W[:, i2:] -= Eb @ Hinv[i1:i2, i2:]
+    return Q, codes
+
+
 # --------------------------------------------------------------------------- Hessian accumulation
 def hessian_add_batch(H, inp):
     """method.py:98-120 for nn.Linear / Conv1D layers: a 2-D input counts as one call, a 3-D input as inp.shape[0];

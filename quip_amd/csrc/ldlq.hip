@@ -53,6 +53,10 @@ __device__ __forceinline__ float round_col(float w, float acc, float eta, float 
 // of block k+1 at the same time (the part that does not depend on block k: columns >= i2), one VALU-bound and one
 // MFMA-bound job per SIMD.  After a barrier the far waves add block k's own 128 columns and publish Ftile for block k+1
 // while the chain waves stage the next diagonal block of L.  Two barriers per block.
+// UPD: which error a rounded column feeds back.  false = LDLQ, w - q with the ORIGINAL w (vector_balance.py:179);
+// true = OPTQ/GPTQ, (w + acc) - q with the UPDATED w (gptq.py:80-87) -- the only difference between the two recurrences
+// once the feedback matrix is prepared accordingly (quipamd_gptq_round).
+template <bool UPD>
 __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const float q = round_col(wv[rr][1], acc[rr][1], et[rr][1], A.maxq);
-                const float er = wv[rr][1] - q;
+                const float er = (UPD ? wv[rr][1] + acc[rr][1] : wv[rr][1]) - q;
                 const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, er), ln));
                 acc[rr][0] = fmaf(e, l0, acc[rr][0]);
                 acc[rr][1] = fmaf(e, l1, acc[rr][1]);
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const float q = round_col(wv[rr][0], acc[rr][0], et[rr][0], A.maxq);
-                const float er = wv[rr][0] - q;
+                const float er = (UPD ? wv[rr][0] + acc[rr][0] : wv[rr][0]) - q;
                 const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, er), ln));
                 acc[rr][0] = fmaf(e, l0, acc[rr][0]);
             }
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
                 if (c < cnt && row < A.m) {
                     const float q = round_col(wv[rr][h], acc[rr][h], et[rr][h], A.maxq);
                     A.codes[row * d + i1 + c] = (uint8_t)q;
-                    A.E[row * d + i1 + c] = wv[rr][h] - q;
+                    A.E[row * d + i1 + c] = (UPD ? wv[rr][h] + acc[rr][h] : wv[rr][h]) - q;
                 }
             }
         }
@@ -278,27 +282,39 @@ __global__ __launch_bounds__(256) void unit_lower_t_kernel(const float *__restri
 
 }   // namespace
 
-extern "C" int quipamd_ldlq_round(const float *Wgrid, const float *LT, const float *eta, int bits, uint8_t *codes,
-                                  float *err_ws, int64_t m, int64_t d, void *stream)
+template <bool UPD>
+static int launch_ldlq(const float *Wgrid, const float *LT, const float *eta, int bits, uint8_t *codes, float *err_ws, int64_t m,
+                       int64_t d, void *stream, const char *who)
 {
     if (m == 0 || d == 0) return QUIPAMD_OK;
-    QA_REQUIRE(Wgrid && LT && codes && err_ws, QUIPAMD_ERR_ARG, "ldlq_round: null pointer");
-    QA_REQUIRE(bits >= 1 && bits <= 8, QUIPAMD_ERR_ARG, "ldlq_round: bits out of range");
-    QA_REQUIRE(d % 16 == 0, QUIPAMD_ERR_SHAPE, "ldlq_round: needs d %% 16 == 0 (d=%lld)", (long long)d);
-    if (m == 0 || d == 0) return QUIPAMD_OK;
+    QA_REQUIRE(Wgrid && LT && codes && err_ws, QUIPAMD_ERR_ARG, "%s: null pointer", who);
+    QA_REQUIRE(bits >= 1 && bits <= 8, QUIPAMD_ERR_ARG, "%s: bits out of range", who);
+    QA_REQUIRE(d % 16 == 0, QUIPAMD_ERR_SHAPE, "%s: needs d %% 16 == 0 (d=%lld)", who, (long long)d);
     LdlqArgs A;
     A.W = Wgrid; A.LT = LT; A.eta = eta; A.codes = codes; A.E = err_ws; A.m = m; A.d = d;
     A.maxq = (float)((1 << bits) - 1);
     const size_t lds = (size_t)(BS * LDS_LD + 2 * 16 * BS) * sizeof(float) + 4 * 3 * SLAB;
-    static bool attr_set = false;
+    static bool attr_set = false;                                  // per instantiation
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)ldlq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return qa_fail(QUIPAMD_ERR_LAUNCH, "ldlq_round: cannot raise dynamic LDS to %zu", lds);
+        if (hipFuncSetAttribute((const void *)ldlq_kernel<UPD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "%s: cannot raise dynamic LDS to %zu", who, lds);
         attr_set = true;
     }
-    ldlq_kernel<<<(unsigned)((m + 15) / 16), 512, lds, (hipStream_t)stream>>>(A);
-    QA_LAUNCH_CHECK("quipamd_ldlq_round");
+    ldlq_kernel<UPD><<<(unsigned)((m + 15) / 16), 512, lds, (hipStream_t)stream>>>(A);
+    QA_LAUNCH_CHECK(who);
     return QUIPAMD_OK;
+}
+
+extern "C" int quipamd_gptq_round(const float *Wgrid_rev, const float *FT, int bits, uint8_t *codes_rev, float *err_ws, int64_t m,
+                                  int64_t d, void *stream)
+{
+    return launch_ldlq<true>(Wgrid_rev, FT, nullptr, bits, codes_rev, err_ws, m, d, stream, "gptq_round");
+}
+
+extern "C" int quipamd_ldlq_round(const float *Wgrid, const float *LT, const float *eta, int bits, uint8_t *codes,
+                                  float *err_ws, int64_t m, int64_t d, void *stream)
+{
+    return launch_ldlq<false>(Wgrid, LT, eta, bits, codes, err_ws, m, d, stream, "ldlq_round");
 }
 
 extern "C" int quipamd_unit_lower_t(const float *C, float *LT, int64_t d, void *stream)

@@ -1,9 +1,12 @@
 """`GPTQ` (OPTQ) behind the QuantMethod protocol -- reference gptq.py:17-115.
 
 Surface row of SURVEY.md 8(a) a13: `--quant gptq` must keep working next to LDLQ.  The column quantiser is
-the HIP grid kernel (ops.quantize via Quantizer.quantize); the Cholesky-inverse and the lazy block update
-W[:, i2:] -= Err @ Hinv[i1:i2, i2:] (gptq.py:90) are plain library calls on the device (rocSOLVER / rocBLAS
-through torch), listed under "next" in DESIGN.md for a fused kernel on the K4 machinery.
+the HIP grid kernel (ops.quantize via Quantizer.quantize); the Cholesky-inverse stays on rocSOLVER through torch.
+For the common case (nn.Linear, groupsize -1, qfn a, width a multiple of 16) the d-step column loop and the lazy
+block update W[:, i2:] -= Err @ Hinv[i1:i2, i2:] (gptq.py:56-93) run as ONE launch of the K4 kernel in its
+updated-weight feedback mode (ops.gptq_round, include/quip_amd.h): the loop below is ~8 launches per column
+(0.5 s for d = 8192), the kernel a few ms.  Everything else (groupsize, Conv layers, qfn c, debug_equiv) takes the
+reference-order loop.
 """
 import time
 
@@ -15,6 +18,7 @@ from .method import QuantMethod
 from .quant import *  # noqa: F401,F403  (the reference star-imports quant here, gptq.py:9)
 
 DEBUG = False
+USE_KERNEL = True        # False: always take the reference-order column loop
 
 torch.backends.cuda.matmul.allow_tf32 = False
 torch.backends.cudnn.allow_tf32 = False
@@ -38,7 +42,21 @@ class GPTQ(QuantMethod):
         Q = torch.zeros_like(W)
         # upper Cholesky factor of H^-1 (gptq.py:51-54)
         Hinv = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)
-        for i1 in range(0, self.columns, blocksize):
+        qz = self.quantizer
+        fast = (USE_KERNEL and groupsize == -1 and not debug_equiv and isinstance(self.layer, nn.Linear) and W.is_cuda
+                and qz.qfn == 'a' and self.columns % 16 == 0 and float(qz.maxq) in (1.0, 3.0, 7.0, 15.0, 255.0))
+        if fast:
+            from . import ops
+            mq = int(qz.maxq.item()) if torch.is_tensor(qz.maxq) else int(qz.maxq)
+            bits = (mq + 1).bit_length() - 1
+            # qfn b is excluded: Quantizer.quantize recomputes its scalar scale from every (updated) column it is handed
+            # grid coordinates WITHOUT the clamp of the LDLQ grid map (vector_balance.py:515 clamps, quantize_qfna does
+            # not: OPTQ feeds the unclamped residual back)
+            wg = (W.float() / qz.scale.reshape(-1, 1).float() + qz.zero.reshape(-1, 1).float()).contiguous()
+            codes = ops.gptq_round(wg, Hinv.float().contiguous(), bits)
+            Q = ops.codes_to_weight(codes, 'a', qz.scale, qz.zero, mq, out_dtype=torch.float32).to(W.dtype)
+            self.codes, self.qscale, self.qzero = codes, qz.scale.reshape(-1).float(), qz.zero.reshape(-1).float()
+        for i1 in range(0, self.columns if not fast else 0, blocksize):
             i2 = min(i1 + blocksize, self.columns)
             Wb = W[:, i1:i2].clone()
             Qb = torch.zeros_like(Wb)

@@ -291,6 +291,28 @@ def unit_lower_t(C):
     return LT
 
 
+def gptq_feedback_matrix(Hinv):
+    """FT for gptq_round from the upper Cholesky factor of H^-1 (gptq.py:51-54): reversed, transposed, each row of Hinv
+    divided by its diagonal, negated, strictly upper (include/quip_amd.h)."""
+    Hn = Hinv / Hinv.diagonal()[:, None]
+    return torch.triu((-Hn.t()).flip(0, 1), diagonal=1).contiguous()
+
+
+def gptq_round(Wgrid, Hinv, bits, return_err=False):
+    """OPTQ codes uint8 [m,d] of grid coordinates Wgrid given Hinv = chol(H^-1, upper) (gptq.py:56-93, groupsize -1)."""
+    _need_gpu(Wgrid, Hinv)
+    assert Wgrid.dtype == torch.float32 and Hinv.dtype == torch.float32
+    m, d = Wgrid.shape
+    assert Hinv.shape == (d, d)
+    FT = gptq_feedback_matrix(Hinv)
+    wrev = Wgrid.flip(1).contiguous()
+    codes = torch.empty((m, d), dtype=torch.uint8, device=Wgrid.device)
+    err = torch.empty((m, d), dtype=torch.float32, device=Wgrid.device)
+    _lib.call("quipamd_gptq_round", _p(wrev), _p(FT), bits, _p(codes), _p(err), m, d, _stream())
+    codes = codes.flip(1).contiguous()
+    return (codes, err.flip(1).contiguous()) if return_err else codes
+
+
 def cholesky_lt(H, check=True):
     """LT = D^-1 U strictly upper with H = U^T U: the unit-lower LDL factor of vector_balance.py:171-173, transposed,
     by the blocked fp32 factorisation of quip_amd/csrc/cholesky.hip (K8).  Raises torch.linalg.LinAlgError like
