@@ -222,6 +222,13 @@ int quipamd_unit_lower_t(const float *C, float *LT, int64_t d, void *stream);
  *     in fp64 and narrows, like post_batch.  H: float [d, d], must not alias Hacc. */
 int quipamd_hessian_accum(const void *x, int x_dtype, int64_t ldx, int64_t tokens, int64_t d, double *Hacc, void *stream);
 int quipamd_hessian_finish(const double *Hacc, double nsamples, float *H, int64_t d, void *stream);
+/* Opt-in fast variant of quipamd_hessian_accum for f16 / bf16 inputs: exact products on the 16-bit matrix pipe,
+ * fp32 partial sums over runs of 128 tokens, fp64 across runs (error ~1e-9 of sqrt(H_ii H_jj) over a calibration pass
+ * instead of fp64 round-off; NOT the reference's arithmetic).  Same accumulator contract (block-lower triangle).
+ * workspace: quipamd_hessian_fast_workspace(tokens, d) elements of x's dtype, 16-byte aligned (holds x transposed). */
+int64_t quipamd_hessian_fast_workspace(int64_t tokens, int64_t d);
+int quipamd_hessian_accum_fast(const void *x, int x_dtype, int64_t ldx, int64_t tokens, int64_t d, double *Hacc,
+                               void *workspace, void *stream);
 
 /* ---- K8: LDL factor for LDLQ ---------------------------------------------------------------------------
  * Replaces `L = torch.linalg.cholesky(H); L = L @ diag(1/diag(L))` (vector_balance.py:171-173) plus the transpose K4

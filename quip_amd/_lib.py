@@ -43,6 +43,8 @@ SIGNATURES = {
     "quipamd_cholesky_lt": [c_vp, c_vp, c_i64, c_vp, c_vp],
     "quipamd_hessian_accum": [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp],
     "quipamd_hessian_finish": [c_vp, c_double, c_vp, c_i64, c_vp],
+    "quipamd_hessian_fast_workspace": [c_i64, c_i64],
+    "quipamd_hessian_accum_fast": [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
 }
 
 _lib = None
@@ -67,7 +69,8 @@ def load():
         except AttributeError as e:
             raise QuipAmdError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "quipamd_last_error" else c_int
+        fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else
+                      c_i64 if name == "quipamd_hessian_fast_workspace" else c_int)
     _lib = lib
     return lib
 

@@ -295,3 +295,187 @@ extern "C" int quipamd_hessian_finish(const double *Hacc, double nsamples, float
     QA_LAUNCH_CHECK("hessian_finish");
     return QUIPAMD_OK;
 }
+
+// =====================================================================================================================
+// Opt-in fast mode: exact products on the 16-bit matrix pipe, fp32 partial sums over FLUSH tokens, fp64 across them.
+// f16 x f16 and bf16 x bf16 products are exact in fp32, so the only rounding that the fp64 path does not have is the
+// fp32 accumulation inside a FLUSH-token run (|err| <= FLUSH * 2^-24 * sum|x_i x_j| worst case, ~1e-7 of the run
+// typically); the runs are then summed in fp64, which averages those errors down: ~1e-9 of sqrt(H_ii H_jj) over a
+// 262144-token calibration pass -- below the fp32 narrowing of post_batch (6e-8), but NOT the reference's arithmetic,
+// hence opt-in (quip_amd.method.HESSIAN_FAST).  v_mfma_f32_16x16x32 wants 8 consecutive k (= tokens) per lane for a
+// fixed output row (= column of X): X is transposed once per call into the caller's workspace (tokens padded to 32
+// with zeros), after which a stage row is 64 contiguous bytes and fragments are single ds_read_b128.
+namespace {
+
+constexpr int FKT = 32;          // tokens per stage (one MFMA k-step)
+constexpr int FRS = 40;          // LDS row stride in 16-bit elements: 64 B of tokens + 16 B pad (conflict-free b128 reads)
+constexpr int FLUSH = 128;       // tokens per fp32 run
+
+template <class TI> struct Mfma16;
+template <> struct Mfma16<F16> {
+    typedef _Float16 __attribute__((ext_vector_type(8))) frag;
+    static __device__ __forceinline__ f32x4_t run(frag a, frag b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma16<BF16> {
+    typedef bf16x8_t frag;
+    static __device__ __forceinline__ f32x4_t run(frag a, frag b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+// Xt[c][t] = X[t][c] for t < tokens, 0 for tokens <= t < tpad; 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void htranspose_kernel(const uint16_t *X, int64_t ldx, int64_t tokens, int64_t d, uint16_t *Xt,
+                                                        int64_t tpad)
+{
+    __shared__ uint16_t tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t t0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t t = t0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (t < tokens && c < d) ? X[t * ldx + c] : (uint16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t c = c0 + ty + 8 * k, t = t0 + tx;
+        if (c < d && t < tpad) Xt[c * tpad + t] = tile[tx][ty + 8 * k];
+    }
+}
+
+template <class TI, int WT>
+__global__ __launch_bounds__(256, 2) void hsyrk_fast_kernel(const uint16_t *Xt, int64_t tpad, int64_t d, double *H)
+{
+    constexpr int BN = 32 * WT;
+    typedef typename Mfma16<TI>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) uint16_t fs[];     // [2 buffers][2 sides][BN][FRS]
+    int I, J;
+    tri_tile(blockIdx.x, I, J);
+    const bool diag = I == J;
+    const int64_t i0 = (int64_t)I * BN, j0 = (int64_t)J * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+
+    // staging: a side is BN rows x 4 chunks of 16 B; thread -> chunks tid, tid + 256, ... (BN * 4 / 256 = WT / 2 ... >= 1)
+    constexpr int CH = BN * 4, PER = (CH + 255) / 256;
+    uint4 ri[PER], rj[PER];
+    auto gload = [&](int64_t t0) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + 256 * u, row = idx >> 2, ch = idx & 3;
+            ri[u] = make_uint4(0, 0, 0, 0);
+            rj[u] = make_uint4(0, 0, 0, 0);
+            if (idx < CH) {
+                if (i0 + row < d) ri[u] = *reinterpret_cast<const uint4 *>(Xt + (i0 + row) * tpad + t0 + 8 * ch);
+                if (!diag && j0 + row < d) rj[u] = *reinterpret_cast<const uint4 *>(Xt + (j0 + row) * tpad + t0 + 8 * ch);
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = tid + 256 * u, row = idx >> 2, ch = idx & 3;
+            if (idx < CH) {
+                *reinterpret_cast<uint4 *>(fs + ((buf * 2 + 0) * BN + row) * FRS + 8 * ch) = ri[u];
+                if (!diag) *reinterpret_cast<uint4 *>(fs + ((buf * 2 + 1) * BN + row) * FRS + 8 * ch) = rj[u];
+            }
+        }
+    };
+
+    f32x4_t acc[WT][WT];
+    f64x4_t sum[WT][WT];
+#pragma unroll
+    for (int x = 0; x < WT; ++x)
+#pragma unroll
+        for (int y = 0; y < WT; ++y) {
+            acc[x][y] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            sum[x][y] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+        }
+    auto flush = [&]() {
+#pragma unroll
+        for (int x = 0; x < WT; ++x)
+#pragma unroll
+            for (int y = 0; y < WT; ++y) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[x][y][r] += (double)acc[x][y][r];
+                acc[x][y] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+    };
+
+    const int64_t nst = tpad / FKT;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int64_t c = 0; c < nst; ++c) {
+        const int cur = (int)(c & 1);
+        const bool more = c + 1 < nst;
+        if (more) gload((c + 1) * FKT);
+        const uint16_t *As = fs + ((cur * 2 + 0) * BN + wi * (WT * 16) + (lane & 15)) * FRS + 8 * (lane >> 4);
+        const uint16_t *Bs = fs + ((cur * 2 + (diag ? 0 : 1)) * BN + wj * (WT * 16) + (lane & 15)) * FRS + 8 * (lane >> 4);
+        frag a[WT], b[WT];
+#pragma unroll
+        for (int x = 0; x < WT; ++x) a[x] = *reinterpret_cast<const frag *>(As + x * 16 * FRS);
+#pragma unroll
+        for (int y = 0; y < WT; ++y) b[y] = *reinterpret_cast<const frag *>(Bs + y * 16 * FRS);
+#pragma unroll
+        for (int x = 0; x < WT; ++x)
+#pragma unroll
+            for (int y = 0; y < WT; ++y) acc[x][y] = Mfma16<TI>::run(a[x], b[y], acc[x][y]);
+        if (((c + 1) % (FLUSH / FKT)) == 0) flush();
+        if (more) sstore(cur ^ 1);
+        __syncthreads();
+    }
+    flush();
+    // D layout of the f32 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+    for (int x = 0; x < WT; ++x)
+#pragma unroll
+        for (int y = 0; y < WT; ++y)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t r = i0 + wi * (WT * 16) + x * 16 + 4 * (lane >> 4) + reg;
+                const int64_t cidx = j0 + wj * (WT * 16) + y * 16 + (lane & 15);
+                if (r < d && cidx < d) H[r * d + cidx] += sum[x][y][reg];
+            }
+}
+
+template <class TI, int WT> int launch_fast(const uint16_t *Xt, int64_t tpad, int64_t d, double *H, hipStream_t s)
+{
+    constexpr int BN = 32 * WT;
+    const size_t lds = (size_t)2 * 2 * BN * FRS * sizeof(uint16_t);
+    const int64_t T = (d + BN - 1) / BN;
+    hsyrk_fast_kernel<TI, WT><<<(unsigned)(T * (T + 1) / 2), 256, lds, s>>>(Xt, tpad, d, H);
+    QA_LAUNCH_CHECK("hessian_accum_fast");
+    return QUIPAMD_OK;
+}
+
+template <class TI> int pick_fast(const uint16_t *Xt, int64_t tpad, int64_t d, double *H, hipStream_t s)
+{
+    auto ntiles = [&](int64_t bn) { const int64_t T = (d + bn - 1) / bn; return T * (T + 1) / 2; };
+    if (ntiles(128) >= 384) return launch_fast<TI, 4>(Xt, tpad, d, H, s);
+    if (ntiles(64) >= 384) return launch_fast<TI, 2>(Xt, tpad, d, H, s);
+    return launch_fast<TI, 1>(Xt, tpad, d, H, s);
+}
+
+}   // namespace
+
+extern "C" int64_t quipamd_hessian_fast_workspace(int64_t tokens, int64_t d)
+{
+    return d * ((tokens + FKT - 1) / FKT * FKT);          // elements of x's dtype
+}
+
+extern "C" int quipamd_hessian_accum_fast(const void *x, int x_dtype, int64_t ldx, int64_t tokens, int64_t d, double *Hacc,
+                                          void *workspace, void *stream)
+{
+    QA_REQUIRE(tokens >= 0 && d >= 0 && ldx >= d, QUIPAMD_ERR_SHAPE, "hessian_accum_fast: bad shape");
+    if (tokens == 0 || d == 0) return QUIPAMD_OK;
+    QA_REQUIRE(x && Hacc && workspace, QUIPAMD_ERR_ARG, "hessian_accum_fast: null pointer");
+    QA_REQUIRE(x_dtype == QUIPAMD_F16 || x_dtype == QUIPAMD_BF16, QUIPAMD_ERR_UNSUPPORTED,
+               "hessian_accum_fast: f16 / bf16 inputs only (f32 products are not exact in fp32)");
+    QA_REQUIRE(((uintptr_t)workspace & 15) == 0, QUIPAMD_ERR_ARG, "hessian_accum_fast: workspace must be 16-byte aligned");
+    QA_REQUIRE(d <= (1 << 20), QUIPAMD_ERR_SHAPE, "hessian_accum_fast: d too large");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t tpad = (tokens + FKT - 1) / FKT * FKT;
+    uint16_t *Xt = (uint16_t *)workspace;
+    htranspose_kernel<<<dim3((unsigned)(tpad / 32), (unsigned)((d + 31) / 32)), 256, 0, s>>>((const uint16_t *)x, ldx, tokens, d, Xt, tpad);
+    QA_LAUNCH_CHECK("hessian_accum_fast (transpose)");
+    return x_dtype == QUIPAMD_F16 ? pick_fast<F16>(Xt, tpad, d, Hacc, s) : pick_fast<BF16>(Xt, tpad, d, Hacc, s);
+}

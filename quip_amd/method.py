@@ -21,6 +21,7 @@ import transformers
 from . import ops
 
 DEBUG = False
+HESSIAN_FAST = False     # True: K7's opt-in 16-bit-MFMA mode for add_batch (f16 / bf16 inputs; see include/quip_amd.h)
 
 
 def _prime_factors(n):
@@ -173,7 +174,7 @@ class QuantMethod:
                 and (self.nsamples == 0 or getattr(self, "_tri", False))):
             self.nsamples += n_calls
             self._tri = True
-            ops.hessian_accum(self.H, inp)          # raises if the HIP library is missing: no fallback on the GPU
+            ops.hessian_accum(self.H, inp, fast=HESSIAN_FAST)   # raises if the HIP library is missing: no fallback on the GPU
             return
         if getattr(self, "_tri", False):
             raise RuntimeError("add_batch: Hessian accumulation started on the HIP path; cannot mix input kinds")

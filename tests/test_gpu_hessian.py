@@ -132,3 +132,47 @@ def test_degenerate(ops):
     assert ops.hessian_finish(H0, 1).shape == (0, 0)
     with pytest.raises(RuntimeError):
         ops.hessian_accum(torch.zeros(4, 4, dtype=torch.float64), torch.zeros(2, 4))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tokens,d", [(1, 16), (37, 96), (300, 520), (1000, 203), (257, 4096)])
+def test_fast_mode_error_model(ops, O, dtype, tokens, d):
+    """opt-in fast mode: exact products, fp32 runs of 128 tokens, fp64 across runs.  Bound: 128 * 2^-24 of the
+    absolute-value product sum (worst case of one run); observed error is orders of magnitude below it."""
+    g = torch.Generator().manual_seed(tokens + d)
+    x = (torch.randn(tokens, d, generator=g) * torch.linspace(0.1, 3.0, d)).to(dtype)
+    ref = np.zeros((d, d), np.float64)
+    O.hessian_add_batch(ref, x.float().numpy())
+    Hacc = torch.zeros(d, d, dtype=torch.float64, device=DEV)
+    ops.hessian_accum(Hacc, x.to(DEV), fast=True)
+    ax = np.abs(x.float().numpy().astype(np.float64))
+    bound = 128 * 2.0 ** -24 * (ax.T @ ax)
+    lo = _lower(d)
+    err = np.abs(Hacc.cpu().numpy() - ref)
+    assert (err[lo] <= bound[lo] + 1e-300).all()
+    dg = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+    assert (err[lo] / dg[lo]).max() < 2e-6                       # single call; shrinks ~1/sqrt(#runs) over a calibration pass
+    H = ops.hessian_finish(Hacc, 1.0).cpu().numpy()
+    np.testing.assert_array_equal(H, H.T)
+
+
+def test_fast_mode_through_quantmethod_and_f32_inputs_stay_exact(ops):
+    from quip_amd import method
+    d = 256
+    lin = torch.nn.Linear(d, 8).half().to(DEV)
+    X = torch.randn(6, 64, d, generator=torch.Generator().manual_seed(2)).half().to(DEV)
+    want = ((X.reshape(-1, d).double().t() @ X.reshape(-1, d).double()) / 6).float()
+    method.HESSIAN_FAST = True
+    try:
+        qm = method.QuantMethod(lin)
+        for j in range(6):
+            qm.add_batch(X[j:j + 1], None)
+        qm.post_batch()
+        torch.testing.assert_close(qm.H, want, rtol=2e-6, atol=2e-6 * float(want.diagonal().max()))
+        Hacc = torch.zeros(d, d, dtype=torch.float64, device=DEV)
+        ops.hessian_accum(Hacc, X[0].float(), fast=True)         # f32 input: silently the exact path
+        x64 = X[0].double()
+        lo = torch.tril(torch.ones(d, d, dtype=torch.bool, device=DEV))
+        assert ((Hacc - x64.t() @ x64).abs()[lo]).max().item() < 1e-10
+    finally:
+        method.HESSIAN_FAST = False
