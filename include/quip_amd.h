@@ -181,6 +181,13 @@ typedef struct quipamd_small_op {
 /* nops (1..4) independent ops in ONE launch (the q / k / v projections of a block share their input): `ops` is a HOST
  * array; all ops must share p, q and the dtypes; every op is applied to `rows` rows. */
 int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int nops, int64_t rows, void *stream);
+/* Chain of two operator applications in ONE launch (decode: U^T y + bias + residual -> [LayerNorm] -> V (x (/) s) of two
+ * consecutive packed layers):  t = epilogue_first(Q_first x_first)  is stored to first->out (when not NULL) in
+ * first->out_dtype and, rounded to that dtype, is the input of every second[i] (1..3 ops that share it, e.g. the q / k / v
+ * projections), whose `x` / `x_dtype` / `ldx` fields are ignored.  All ops share p, q (split-bf16 factors required); first->x
+ * must be f32; the second ops share the output dtype.  Bit-identical to the two separate launches. */
+int quipamd_ortho_apply_small_chain(const quipamd_small_op *first, const quipamd_small_op *second, int nsecond, int64_t rows,
+                                    void *stream);
 
 /* ---- K4: LDLQ rounding -------------------------------------------------------------------------
  * Replaces round_ldl / round_ldl_block (vector_balance.py:155-199, 218-257; n_greedy_passes = 0):

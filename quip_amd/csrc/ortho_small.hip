@@ -60,6 +60,19 @@ template <> __device__ __forceinline__ void store4<BF16>(void *p, int64_t i, con
     u.y = (uint32_t)f32_to_bf16_bits(v.z) | ((uint32_t)f32_to_bf16_bits(v.w) << 16);
     *reinterpret_cast<uint2 *>((uint16_t *)p + i) = u;
 }
+__device__ __forceinline__ void store4_any(void *p, int dt, int64_t i, const float4 &v)
+{
+    if (dt == QUIPAMD_F32) store4<F32>(p, i, v);
+    else if (dt == QUIPAMD_F16) store4<F16>(p, i, v);
+    else store4<BF16>(p, i, v);
+}
+// the value a reader of the stored element would see
+__device__ __forceinline__ float4 round4_any(int dt, const float4 &v)
+{
+    if (dt == QUIPAMD_F16) return make_float4(DT<F16>::rnd(v.x), DT<F16>::rnd(v.y), DT<F16>::rnd(v.z), DT<F16>::rnd(v.w));
+    if (dt == QUIPAMD_BF16) return make_float4(DT<BF16>::rnd(v.x), DT<BF16>::rnd(v.y), DT<BF16>::rnd(v.z), DT<BF16>::rnd(v.w));
+    return v;
+}
 
 // block-wide sum over 1024 threads (16 waves): wave shuffle + one LDS round
 __device__ __forceinline__ float block_sum(float v, float *red /* [16] */)
@@ -253,10 +266,18 @@ __device__ __forceinline__ void split_bf16(float v, uint16_t &hi, uint16_t &lo)
     lo = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));
 }
 
-template <class TI, class TO>
+// NPASS = 2 ("chain"): op[0] is applied to the row first (x from memory, bias / residual / relu epilogue, result stored
+// to op[0].out by the blockIdx.y == 0 workgroup when that pointer is set), then op[1 + blockIdx.y] is applied to the
+// result straight from registers (LayerNorm / colscale on the way in): U^T y + residual -> LayerNorm -> V (x (/) s) of
+// two consecutive packed layers in ONE launch instead of two.  The hand-over value is rounded
+// to op[0].out_dtype, so the chain computes exactly what the two separate launches compute.
+template <class TI, class TO, int NPASS>
 __global__ __launch_bounds__(1024) void ortho_small_split_kernel(SmallBatch Bt)
 {
-    const SmallArgs &A = Bt.op[blockIdx.y];
+    constexpr int MAXV = 4;
+    float4 xv[MAXV];
+    for (int pass = 0; pass < NPASS; ++pass) {
+    const SmallArgs &A = NPASS == 1 ? Bt.op[blockIdx.y] : (pass == 0 ? Bt.op[0] : Bt.op[1 + blockIdx.y]);
     extern __shared__ __attribute__((aligned(16))) char smemc[];
     const int p = A.p, q = A.q, n = p * q;
     const int P8 = p + 8, Q8 = q + 8, QS = q + 4;
@@ -283,13 +304,37 @@ __global__ __launch_bounds__(1024) void ortho_small_split_kernel(SmallBatch Bt)
         *reinterpret_cast<uint4 *>(F1l + rr * Q8 + 8 * c8) = reinterpret_cast<const uint4 *>(A.M1_lo)[i];
     }
     // ---- row: 4 consecutive elements per step, optional LayerNorm, scale, split, scatter --------------------------------
-    constexpr int MAXV = 4;
     const int qsh = __builtin_ctz(q), qmask = q - 1, n4 = n >> 2;
-    float4 xv[MAXV];
+    if (pass == 0) {
 #pragma unroll
-    for (int u = 0; u < MAXV; ++u) {
+        for (int u = 0; u < MAXV; ++u) {
+            const int v4 = tid + 1024 * u;
+            xv[u] = v4 < n4 ? load4<TI>(A.x, row * A.ldx + 4 * v4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // every operand of the scatter and of the epilogue is requested NOW, before the LayerNorm reductions and the two
+    // mix stages: fetched where they are used they were 2-3 exposed L2 round trips per launch (a decode step is a chain
+    // of these launches; rocprof: 6-9 us each).  PF = 2 covers n <= 8192; larger rows load the rest in place.
+    constexpr int PF = 2;
+    float4 pgm[PF], pbt[PF], pcs[PF], pbias[PF], pres[PF];
+    int4 pld[PF], pst[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
         const int v4 = tid + 1024 * u;
-        xv[u] = v4 < n4 ? load4<TI>(A.x, row * A.ldx + 4 * v4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        pgm[u] = pbt[u] = pbias[u] = pres[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pcs[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+        pld[u] = pst[u] = make_int4(4 * v4, 4 * v4 + 1, 4 * v4 + 2, 4 * v4 + 3);
+        if (v4 < n4) {
+            if (A.ln_gamma) {
+                pgm[u] = load4_any(A.ln_gamma, A.ln_dtype, 4 * v4);
+                pbt[u] = load4_any(A.ln_beta, A.ln_dtype, 4 * v4);
+            }
+            if (A.colscale) pcs[u] = *reinterpret_cast<const float4 *>(A.colscale + 4 * v4);
+            if (A.load_idx) pld[u] = *reinterpret_cast<const int4 *>(A.load_idx + 4 * v4);
+            if (A.store_idx) pst[u] = *reinterpret_cast<const int4 *>(A.store_idx + 4 * v4);
+            if (A.bias) pbias[u] = *reinterpret_cast<const float4 *>(A.bias + 4 * v4);
+            if (A.residual) pres[u] = load4_any(A.residual, A.res_dtype, row * A.ldo + 4 * v4);
+        }
     }
     if (A.ln_gamma) {
         float s1 = 0.f;
@@ -309,7 +354,8 @@ __global__ __launch_bounds__(1024) void ortho_small_split_kernel(SmallBatch Bt)
         for (int u = 0; u < MAXV; ++u) {
             const int v4 = tid + 1024 * u;
             if (v4 < n4) {
-                const float4 gm = load4_any(A.ln_gamma, A.ln_dtype, 4 * v4), bt = load4_any(A.ln_beta, A.ln_dtype, 4 * v4);
+                const float4 gm = u < PF ? pgm[u < PF ? u : 0] : load4_any(A.ln_gamma, A.ln_dtype, 4 * v4);
+                const float4 bt = u < PF ? pbt[u < PF ? u : 0] : load4_any(A.ln_beta, A.ln_dtype, 4 * v4);
                 xv[u] = make_float4((xv[u].x - mean) * rstd * gm.x + bt.x, (xv[u].y - mean) * rstd * gm.y + bt.y,
                                     (xv[u].z - mean) * rstd * gm.z + bt.z, (xv[u].w - mean) * rstd * gm.w + bt.w);
             }
@@ -321,11 +367,11 @@ __global__ __launch_bounds__(1024) void ortho_small_split_kernel(SmallBatch Bt)
         if (v4 < n4) {
             float4 v = xv[u];
             if (A.colscale) {
-                const float4 c = *reinterpret_cast<const float4 *>(A.colscale + 4 * v4);
+                const float4 c = u < PF ? pcs[u < PF ? u : 0] : *reinterpret_cast<const float4 *>(A.colscale + 4 * v4);
                 v = make_float4(v.x * c.x, v.y * c.y, v.z * c.z, v.w * c.w);
             }
             int4 pos = make_int4(4 * v4, 4 * v4 + 1, 4 * v4 + 2, 4 * v4 + 3);
-            if (A.load_idx) pos = *reinterpret_cast<const int4 *>(A.load_idx + 4 * v4);
+            if (A.load_idx) pos = u < PF ? pld[u < PF ? u : 0] : *reinterpret_cast<const int4 *>(A.load_idx + 4 * v4);
             const float vv[4] = {v.x, v.y, v.z, v.w};
             const int pp[4] = {pos.x, pos.y, pos.z, pos.w};
 #pragma unroll
@@ -419,20 +465,26 @@ __global__ __launch_bounds__(1024) void ortho_small_split_kernel(SmallBatch Bt)
         const int v4 = tid + 1024 * u;
         if (v4 < n4) {
             int4 pos = make_int4(4 * v4, 4 * v4 + 1, 4 * v4 + 2, 4 * v4 + 3);
-            if (A.store_idx) pos = *reinterpret_cast<const int4 *>(A.store_idx + 4 * v4);
+            if (A.store_idx) pos = u < PF ? pst[u < PF ? u : 0] : *reinterpret_cast<const int4 *>(A.store_idx + 4 * v4);
             float4 v = make_float4(ZF[(pos.x >> qsh) * QS + (pos.x & qmask)], ZF[(pos.y >> qsh) * QS + (pos.y & qmask)],
                                    ZF[(pos.z >> qsh) * QS + (pos.z & qmask)], ZF[(pos.w >> qsh) * QS + (pos.w & qmask)]);
             if (A.bias) {
-                const float4 c = *reinterpret_cast<const float4 *>(A.bias + 4 * v4);
+                const float4 c = u < PF ? pbias[u < PF ? u : 0] : *reinterpret_cast<const float4 *>(A.bias + 4 * v4);
                 v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
             }
             if (A.residual) {
-                const float4 c = load4_any(A.residual, A.res_dtype, row * A.ldo + 4 * v4);
+                const float4 c = u < PF ? pres[u < PF ? u : 0] : load4_any(A.residual, A.res_dtype, row * A.ldo + 4 * v4);
                 v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
             }
             if (A.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-            store4<TO>(A.out, row * A.ldo + 4 * v4, v);
+            if (pass == NPASS - 1) store4<TO>(A.out, row * A.ldo + 4 * v4, v);
+            else {
+                if (A.out && blockIdx.y == 0) store4_any(A.out, A.out_dtype, row * A.ldo + 4 * v4, v);
+                xv[u] = round4_any(A.out_dtype, v);
+            }
         }
+    }
+    if (pass < NPASS - 1) __syncthreads();                       // ZF is read above, rewritten by the next pass
     }
 }
 
@@ -448,7 +500,7 @@ int launch_small(const SmallBatch &B, int nops, int64_t rows, hipStream_t s)
 {
     if (B.op[0].M0_hi) {
         const size_t lds = small_split_lds(B.op[0].p, B.op[0].q);
-        auto kern = ortho_small_split_kernel<TI, TO>;
+        auto kern = ortho_small_split_kernel<TI, TO, 1>;
         if (lds > 64 * 1024)
             if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return qa_fail(QUIPAMD_ERR_LAUNCH, "ortho_apply_small: cannot raise dynamic LDS to %zu", lds);
@@ -512,6 +564,52 @@ extern "C" int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int no
     QA_SMALL_CASE(QUIPAMD_BF16, BF16, QUIPAMD_F32, F32);
 #undef QA_SMALL_CASE
     return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "ortho_apply_small: dtype pair %d -> %d", x_dtype, out_dtype);
+}
+
+extern "C" int quipamd_ortho_apply_small_chain(const quipamd_small_op *first, const quipamd_small_op *second, int nsecond,
+                                               int64_t rows, void *stream)
+{
+    QA_REQUIRE(first && second && nsecond >= 1 && nsecond <= QUIPAMD_SMALL_MAX_OPS - 1, QUIPAMD_ERR_ARG,
+               "ortho_apply_small_chain: 1..%d second ops", QUIPAMD_SMALL_MAX_OPS - 1);
+    const int p = first->p, q = first->q;
+    QA_REQUIRE(p >= 32 && q >= 32 && p % 32 == 0 && q % 32 == 0 && (q & (q - 1)) == 0 && 2 * q >= p && (int64_t)p * q <= 16 * 1024 &&
+                   small_split_lds(p, q) <= 160 * 1024,
+               QUIPAMD_ERR_SHAPE, "ortho_apply_small_chain: p=%d q=%d not supported by the split-bf16 single-launch kernel", p, q);
+    QA_REQUIRE(first->M0_hi && first->M0_lo && first->M1_hi && first->M1_lo && first->x, QUIPAMD_ERR_ARG,
+               "ortho_apply_small_chain: first op needs x and the four split-bf16 factor arrays");
+    QA_REQUIRE(first->ldx >= (int64_t)p * q && first->ldx % 4 == 0 && first->ldo >= (int64_t)p * q && first->ldo % 4 == 0, QUIPAMD_ERR_SHAPE,
+               "ortho_apply_small_chain: leading dimensions");
+    QA_REQUIRE(rows <= 65535, QUIPAMD_ERR_SHAPE, "ortho_apply_small_chain: too many rows");
+    SmallBatch B;
+    B.op[0] = *first;
+    const int out_dtype = second[0].out_dtype;
+    for (int i = 0; i < nsecond; ++i) {
+        const quipamd_small_op &o = second[i];
+        QA_REQUIRE(o.p == p && o.q == q && o.out_dtype == out_dtype && o.out && o.M0_hi && o.M0_lo && o.M1_hi && o.M1_lo, QUIPAMD_ERR_ARG,
+                   "ortho_apply_small_chain: second op %d must share p, q, the output dtype and carry split-bf16 factors", i);
+        QA_REQUIRE(o.ldo >= (int64_t)p * q && o.ldo % 4 == 0, QUIPAMD_ERR_SHAPE, "ortho_apply_small_chain: leading dimensions");
+        QA_REQUIRE(!o.ln_gamma || o.ln_beta, QUIPAMD_ERR_ARG, "ortho_apply_small_chain: LayerNorm needs gamma and beta");
+        QA_REQUIRE(!o.residual, QUIPAMD_ERR_UNSUPPORTED, "ortho_apply_small_chain: residual on a second op");
+        B.op[1 + i] = o;
+    }
+    for (int i = 1 + nsecond; i < QUIPAMD_SMALL_MAX_OPS; ++i) B.op[i] = second[0];
+    if (rows == 0) return QUIPAMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = small_split_lds(p, q);
+#define QA_CHAIN_CASE(XI, TI, XO, TO)                                                                                              \
+    if (first->x_dtype == XI && out_dtype == XO) {                                                                                 \
+        auto kern = ortho_small_split_kernel<TI, TO, 2>;                                                                           \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "ortho_apply_small_chain: cannot raise dynamic LDS to %zu", lds);                   \
+        kern<<<dim3((unsigned)rows, (unsigned)nsecond), 1024, lds, s>>>(B);                                                          \
+        QA_LAUNCH_CHECK("quipamd_ortho_apply_small_chain");                                                                        \
+        return QUIPAMD_OK;                                                                                                         \
+    }
+    QA_CHAIN_CASE(QUIPAMD_F32, F32, QUIPAMD_BF16, BF16)
+    QA_CHAIN_CASE(QUIPAMD_F32, F32, QUIPAMD_F16, F16)
+    QA_CHAIN_CASE(QUIPAMD_F32, F32, QUIPAMD_F32, F32)
+#undef QA_CHAIN_CASE
+    return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "ortho_apply_small_chain: dtype pair %d -> %d (first x must be f32)", first->x_dtype, out_dtype);
 }
 
 extern "C" int quipamd_ortho_apply_small(const float *M0, const float *M1, const int32_t *load_idx, const int32_t *store_idx,

@@ -170,6 +170,14 @@ def ortho_small_ops(op_list, rows):
     _lib.call("quipamd_ortho_apply_small_ops", ctypes.cast(arr, ctypes.c_void_p), len(op_list), rows, _stream())
 
 
+def ortho_small_chain(first, seconds, rows):
+    """`first` then each of `seconds` (1..3 SmallOp sharing its result) in ONE launch (quipamd_ortho_apply_small_chain)."""
+    one = (SmallOp * 1)(first)
+    arr = (SmallOp * len(seconds))(*seconds)
+    _lib.call("quipamd_ortho_apply_small_chain", ctypes.cast(one, ctypes.c_void_p), ctypes.cast(arr, ctypes.c_void_p),
+              len(seconds), rows, _stream())
+
+
 def _mfma_b_frags(M):
     """M [C, P, P] (out index i, in index k) -> float [C, NT, NT, 64, 4] in v_mfma_f32_16x16x4_f32 B-fragment order
     (include/quip_amd.h): element [c][nt][S][lane][s] = M[c][16 nt + (lane & 15)][16 S + 4 (lane >> 4) + s]."""
@@ -261,10 +269,26 @@ class OrthoOp:
             out += _f32vec(bias, x.device).to(out.dtype)
         return out
 
-    def small_op(self, x, out, transpose=False, colscale=None, bias=None, ln=None, residual=None, relu=False):
+    def small_op(self, x, out, transpose=False, colscale=None, bias=None, ln=None, residual=None, relu=False,
+                 out_dtype=None, ld=None):
         """descriptor of  out = [relu](Q (colscale * [LayerNorm](x)) + bias + residual)  for ortho_small_ops().
-        ln = (gamma, beta, eps) tensors on the device; every tensor argument must outlive the launch call."""
-        assert self.small_ok and x.stride(1) == 1 and out.stride(1) == 1
+        ln = (gamma, beta, eps) tensors on the device; every tensor argument must outlive the launch call.
+        For ortho_small_chain: x may be None (a second op) and out may be None with out_dtype / ld given (a first op whose
+        result is only handed over)."""
+        assert self.small_ok and (x is None or x.stride(1) == 1) and (out is None or out.stride(1) == 1)
+        if x is None or out is None:
+            n = self.p * self.q
+            M0, M1 = self._M[bool(transpose)]
+            ldv, st = (self.pout, self.inv_pin) if transpose else (self.inv_pin, self.pout)
+            g, b, eps = ln if ln is not None else (None, None, 0.0)
+            sp = self._Msplit[bool(transpose)] if (self.split_ok and self.use_split) else (None, None, None, None)
+            odt = _dtype(out) if out is not None else _DT[out_dtype]
+            return SmallOp(_ptr(M0), _ptr(M1), _ptr(ldv), _ptr(st), self.p, self.q, int(bool(transpose)),
+                           _ptr(colscale), _ptr(bias), _ptr(g), _ptr(b), float(eps), 0 if g is None else _dtype(g),
+                           _ptr(residual), 0 if residual is None else _dtype(residual), int(bool(relu)),
+                           _ptr(x), 0 if x is None else _dtype(x), n if x is None else x.stride(0),
+                           _ptr(out), odt, (ld or n) if out is None else out.stride(0),
+                           _ptr(sp[0]), _ptr(sp[1]), _ptr(sp[2]), _ptr(sp[3]))
         M0, M1 = self._M[bool(transpose)]
         ld, st = (self.pout, self.inv_pin) if transpose else (self.inv_pin, self.pout)
         g, b, eps = ln if ln is not None else (None, None, 0.0)

@@ -250,6 +250,51 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False):
     return outs
 
 
+def _chainable(qa, qbs, rows):
+    return (_fusable(qa, rows) and all(_fusable(q, rows) for q in qbs) and qa.U.split_ok and qa.U.use_split
+            and all(q.V.split_ok and q.V.use_split and q.infeatures == qa.outfeatures for q in qbs)
+            and len({(q.infeatures, q.outfeatures, q.bits) for q in qbs}) == 1 and 1 <= len(qbs) <= 3)
+
+
+def packed_v_stage(qls, x, ln=None):
+    """launch 1 of packed_forward_fused on its own: xt_i = V_i (LayerNorm(x) (/) s_i), bf16."""
+    rows, d = x.shape[0], qls[0].infeatures
+    xts = [torch.empty((rows, d), dtype=torch.bfloat16, device=x.device) for _ in qls]
+    ops.ortho_small_ops([q.V.small_op(x.contiguous(), xt, colscale=q.inv_scaleWH, ln=_ln_params(ln)) for q, xt in zip(qls, xts)], rows)
+    return xts
+
+
+def packed_gemm_stage(qls, xts):
+    """launch 2: y_i = What_i xt_i (grouped fused dequant-GEMM, fp32)."""
+    rows, m = xts[0].shape[0], qls[0].outfeatures
+    ys = [torch.empty((rows, m), dtype=torch.float32, device=xts[0].device) for _ in qls]
+    ops.dequant_gemm_grouped(xts, [q.qweight for q in qls], qls[0].bits, 'b', [q.scales for q in qls], None, ys, m)
+    return ys
+
+
+def packed_u_stage(qls, ys, dtype, residual=None, relu=False):
+    """launch 3: out_i = [relu](U_i^T y_i + bias_i + residual)."""
+    rows, m = ys[0].shape
+    outs = [torch.empty((rows, m), dtype=dtype, device=ys[0].device) for _ in qls]
+    res = None if residual is None else residual.contiguous()
+    ops.ortho_small_ops([q.U.small_op(y, o, transpose=True, bias=q.bias, residual=res, relu=relu) for q, y, o in zip(qls, ys, outs)], rows)
+    return outs
+
+
+def packed_u_then_v(qa, y, dtype, qbs, residual=None, relu=False, ln=None, store=True):
+    """launch 3 of layer `qa` and launch 1 of the layers `qbs` that consume its output, as ONE launch
+    (quipamd_ortho_apply_small_chain):  t = [relu](U_a^T y + bias_a + residual);  xt_i = V_i (LayerNorm(t) (/) s_i).
+    Returns (t or None when store=False, [xt_i]); bit-identical to packed_u_stage followed by packed_v_stage."""
+    rows, m = y.shape
+    t = torch.empty((rows, m), dtype=dtype, device=y.device) if store else None
+    xts = [torch.empty((rows, m), dtype=torch.bfloat16, device=y.device) for _ in qbs]
+    res = None if residual is None else residual.contiguous()
+    first = qa.U.small_op(y, t, transpose=True, bias=qa.bias, residual=res, relu=relu, out_dtype=dtype, ld=m)
+    seconds = [q.V.small_op(None, xt, colscale=q.inv_scaleWH, ln=_ln_params(ln)) for q, xt in zip(qbs, xts)]
+    ops.ortho_small_chain(first, seconds, rows)
+    return t, xts
+
+
 def save_packed(layers, path):
     """Packed checkpoint: {dotted module name: QuantLinear} -> one torch file of CPU tensors (replaces the dense fp16
     `torch.save(model.state_dict())` of opt.py:644-646 for the quantised Linears; 2 bits/weight + factors)."""

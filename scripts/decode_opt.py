@@ -29,7 +29,8 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quip_amd import ops, method  # noqa: E402
-from quip_amd.quant import QuantLinear, packed_forward_fused  # noqa: E402
+from quip_amd.quant import (QuantLinear, packed_forward_fused, packed_v_stage, packed_gemm_stage, packed_u_stage,  # noqa: E402
+                            packed_u_then_v)
 
 
 class Block(nn.Module):
@@ -78,9 +79,35 @@ class Decoder(nn.Module):
         self.blocks = nn.ModuleList([Block(h, ffn, heads, dtype) for _ in range(layers)])
         self.lnf = nn.LayerNorm(h, dtype=dtype)
 
+    chained = False          # packed + fused attention + U^T->LN->V chains across layers: 10 launches per block
+
+    def step_chained(self, x, pos, caches):
+        """the packed block sequence with every `U^T y + residual -> LayerNorm -> V (x (/) s)` hand-over between two
+        consecutive packed layers done in one launch (quant.packed_u_then_v), including across block boundaries."""
+        dt = x.dtype
+        b0 = self.blocks[0]
+        xts = packed_v_stage([b0.q_proj, b0.k_proj, b0.v_proj], x, ln=b0.ln1)
+        for i, (blk, (kc, vc)) in enumerate(zip(self.blocks, caches)):
+            qkv = [blk.q_proj, blk.k_proj, blk.v_proj]
+            q, k, v = packed_u_stage(qkv, packed_gemm_stage(qkv, xts), dt)
+            o = ops.decode_attention(q, k, v, kc, vc, pos)
+            yo = packed_gemm_stage([blk.out_proj], packed_v_stage([blk.out_proj], o))[0]
+            x, xt1 = packed_u_then_v(blk.out_proj, yo, dt, [blk.fc1], residual=x, ln=blk.ln2)
+            y1 = packed_gemm_stage([blk.fc1], xt1)[0]
+            _, xt2 = packed_u_then_v(blk.fc1, y1, dt, [blk.fc2], relu=True, store=False)
+            y2 = packed_gemm_stage([blk.fc2], xt2)[0]
+            if i + 1 < len(self.blocks):
+                nb = self.blocks[i + 1]
+                x, xts = packed_u_then_v(blk.fc2, y2, dt, [nb.q_proj, nb.k_proj, nb.v_proj], residual=x, ln=nb.ln1)
+            else:
+                x = packed_u_stage([blk.fc2], [y2], dt, residual=x)[0]
+        return x
+
     def step(self, ids, pos, caches, arange):
         """one token for every batch row: ids int64 [bs], pos int64 [1]; returns logits [bs, vocab]."""
         x = self.tok(ids) + self.posemb(pos + 2)
+        if self.chained:
+            return F.linear(self.lnf(self.step_chained(x, pos, caches)), self.tok.weight)
         mask = torch.where(arange <= pos, 0.0, float("-inf")).to(x.dtype)
         for blk, (kc, vc) in zip(self.blocks, caches):
             x = blk(x, kc, vc, pos, mask)
@@ -195,6 +222,10 @@ def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense
     med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
     out["packed_w%d_fused_attn" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
                                            "what": "as packed_fused + single-launch decode attention (13 launches per block)"}
+    model.chained = True
+    med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+    out["packed_w%d_chained" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+                                        "what": "as packed_fused_attn + U^T->LN->V hand-overs chained in one launch (10 launches per block)"}
     del model
     torch.cuda.empty_cache()
     return out
@@ -231,6 +262,13 @@ def decode_check(layers=2, bits=2):
         blk.fused_attn = True
     torch.manual_seed(1)
     _, _, la = time_decode(model, 2, 0, 0, 32, dev, dtype, True)
+    model.chained = True
+    torch.manual_seed(1)
+    _, _, lc = time_decode(model, 2, 0, 3, 32, dev, dtype, True)
+    model.chained = False
+    torch.manual_seed(1)
+    _, _, la3 = time_decode(model, 2, 0, 3, 32, dev, dtype, True)
+    chain_equal = bool(torch.equal(lc, la3))
     for blk in model.blocks:
         blk.fused = False
         blk.fused_attn = False
@@ -240,13 +278,15 @@ def decode_check(layers=2, bits=2):
         setattr(model.blocks[li], name, lin)
     torch.manual_seed(1)
     _, _, ld = time_decode(model, 2, 0, 0, 32, dev, dtype, True)
-    return float((lq - ld).norm() / ld.norm()), float((lf - ld).norm() / ld.norm()), float((la - ld).norm() / ld.norm())
+    return (float((lq - ld).norm() / ld.norm()), float((lf - ld).norm() / ld.norm()), float((la - ld).norm() / ld.norm()),
+            chain_equal)
 
 
 if __name__ == "__main__":
     if "--check" in sys.argv:
-        e1, e2, e3 = decode_check()
+        e1, e2, e3, ceq = decode_check()
         print(json.dumps({"decode_logits_rel_err_packed_vs_dense_twin": e1, "fused_packed_vs_dense_twin": e2,
-                          "fused_packed_fused_attn_vs_dense_twin": e3}))
+                          "fused_packed_fused_attn_vs_dense_twin": e3,
+                          "chained_logits_bit_identical_to_fused_attn_after_4_tokens": ceq}))
     else:
         main()

@@ -276,3 +276,38 @@ def test_packed_forward_fused_matches_unfused(Q, rows):
             assert float((f.float() - ref).norm() / ref.norm()) <= 5e-3
         single = Q.packed_forward_fused(qls[:1], x)[0]
         assert float((single.float() - qls[0](x).float()).norm() / qls[0](x).float().norm()) <= 2e-3
+
+
+@pytest.mark.parametrize("rows,nb,relu,with_res,with_ln,store", [(1, 1, False, True, True, True), (2, 3, False, True, True, True),
+                                                               (1, 1, True, False, False, False), (5, 2, True, True, False, True)])
+def test_chained_u_then_v_is_bit_identical_to_two_launches(Q, rows, nb, relu, with_res, with_ln, store):
+    """quipamd_ortho_apply_small_chain: U^T y + bias + residual -> [LayerNorm] -> V (x (/) s) of consecutive packed
+    layers in one launch == packed_u_stage followed by packed_v_stage."""
+    from quip_amd import ops, method
+    torch.manual_seed(11)
+    np.random.seed(11)
+    n, bits = 2048, 2
+
+    def mk():
+        W = (0.02 * torch.randn(n, n)).half().to(DEV)
+        s = ops.qfnb_scale(W)
+        _, codes = ops.quantize(W, 'b', s, None, 3, want_codes=True)
+        ql = Q.QuantLinear(n, n, bits=bits, qfn='b').to(DEV)
+        ql.pack(codes, s, None, bias=torch.randn(n).to(DEV), scaleWH=(0.5 + torch.rand(n)).to(DEV),
+                U=method.gen_rand_ortho_butterfly_noblock(n), V=method.gen_rand_ortho_butterfly_noblock(n))
+        return ql
+    qa, qbs = mk(), [mk() for _ in range(nb)]
+    y = torch.randn(rows, n, device=DEV)
+    res = torch.randn(rows, n, device=DEV).half() if with_res else None
+    ln = torch.nn.LayerNorm(n, dtype=torch.float16).to(DEV) if with_ln else None
+    if ln is not None:
+        ln.weight.data.normal_(1, 0.1)
+        ln.bias.data.normal_(0, 0.1)
+    t_ref = Q.packed_u_stage([qa], [y], torch.float16, residual=res, relu=relu)[0]
+    x_ref = Q.packed_v_stage(qbs, t_ref, ln=ln)
+    t, xs = Q.packed_u_then_v(qa, y, torch.float16, qbs, residual=res, relu=relu, ln=ln, store=store)
+    assert (t is None) == (not store)
+    if store:
+        assert torch.equal(t, t_ref)
+    for a, b in zip(xs, x_ref):
+        assert torch.equal(a, b)
