@@ -214,6 +214,16 @@ int quipamd_ldlq_round(const float *Wgrid, const float *LT, const float *eta, in
 int quipamd_gptq_round(const float *Wgrid_rev, const float *FT, int bits, uint8_t *codes_rev, float *err_ws, int64_t m,
                        int64_t d, void *stream);
 
+/* One greedy coordinate-descent pass of LDLQ's post-processing (round_ldl / round_ldl_block with n_greedy_passes > 0,
+ * vector_balance.py:186-196, 263-288), same kernel as quipamd_ldlq_round in its third mode.  For i = d-1 .. 0:
+ *   Hs_i = sH[:, i] - sum_{j > i} eps_j H[j][i];   new_i = round(wr_i - Hs_i / H[i][i]);   eps_i = wr_i - new_i
+ * where sH = s @ H is the caller's GEMM of the current error s = wr - w with the normalised H (H / max diag H).
+ *   wr, sH: float [m, d];  negH_upper: float [d, d], -H[i][j] for j > i, 0 elsewhere;  hdiag: float [d] = diag H;
+ *   wr_out: float [m, d] the updated values, NOT clamped (the reference clamps after the pass);  eps: float [m, d] out
+ *   (the caller updates s -= eps).  torch.round semantics (half to even).  Requires d % 16 == 0. */
+int quipamd_ldlq_greedy_pass(const float *wr, const float *sH, const float *negH_upper, const float *hdiag, float *wr_out,
+                             float *eps, int64_t m, int64_t d, void *stream);
+
 /* quipamd_unit_lower_t: from the lower Cholesky factor C (H = C C^T, row-major [d,d]) build
  *   LT[c][j] = C[j][c] * (1 / C[c][c]) for j > c, 0 elsewhere  (vector_balance.py:172-173). */
 int quipamd_unit_lower_t(const float *C, float *LT, int64_t d, void *stream);

@@ -362,6 +362,28 @@ def round_ldl(w, H, nbits, eta=None, L=None):
     return out
 
 
+def greedy_passes(w, w_hat, H, nbits, n_greedy_passes):
+    """vector_balance.py:182-196: coordinate descent over the integer grid after round_ldl.  fp32 like the reference;
+    np.round and torch.round both round half to even.  Returns the final codes (fp32)."""
+    w = np.asarray(w, np.float32)
+    w_hat = np.array(w_hat, np.float32)
+    d = w.shape[1]
+    wr = w_hat.copy()
+    s = (w_hat - w).astype(np.float32)
+    H = (np.asarray(H, np.float32) / np.float32(np.diag(H).max())).astype(np.float32)
+    for _ in range(n_greedy_passes):
+        for i in range(d - 1, -1, -1):
+            Hs = (s @ H[:, i]).astype(np.float32)
+            eps = (wr[:, i] - np.round(wr[:, i] - Hs / H[i, i])).astype(np.float32)
+            wr[:, i] -= eps
+            s[:, i] -= eps
+        wr = np.clip(wr, 0, 2 ** nbits - 1).astype(np.float32)
+        if (w_hat == wr).all():
+            break
+        w_hat = wr.copy()
+    return wr
+
+
 def round_ldl_gptqequiv(w, H, nbits, eta=None):
     """vector_balance.py:381-422."""
     w = np.ascontiguousarray(w, np.float32)

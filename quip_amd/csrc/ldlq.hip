@@ -37,10 +37,12 @@ struct LdlqArgs {
     const float *W;     // [m,d] grid coordinates
     const float *LT;    // [d,d] LT[c][j] = L[j][c], j > c
     const float *eta;   // [m,d] or null
-    uint8_t *codes;     // [m,d]
+    uint8_t *codes;     // [m,d]   (modes 0, 1)
     float *E;           // [m,d] workspace: w - q
     int64_t m, d;
     float maxq;
+    const float *hd;    // [d]    mode 2: diagonal of the normalised H
+    float *Wout;        // [m,d]  mode 2: the updated (unclamped) values
 };
 
 __device__ __forceinline__ float round_col(float w, float acc, float eta, float maxq)
@@ -53,10 +55,15 @@ __device__ __forceinline__ float round_col(float w, float acc, float eta, float 
 // of block k+1 at the same time (the part that does not depend on block k: columns >= i2), one VALU-bound and one
 // MFMA-bound job per SIMD.  After a barrier the far waves add block k's own 128 columns and publish Ftile for block k+1
 // while the chain waves stage the next diagonal block of L.  Two barriers per block.
-// UPD: which error a rounded column feeds back.  false = LDLQ, w - q with the ORIGINAL w (vector_balance.py:179);
-// true = OPTQ/GPTQ, (w + acc) - q with the UPDATED w (gptq.py:80-87) -- the only difference between the two recurrences
+// MODE: which error a rounded column feeds back.  0 = LDLQ, w - q with the ORIGINAL w (vector_balance.py:179);
+// 1 = OPTQ/GPTQ, (w + acc) - q with the UPDATED w (gptq.py:80-87) -- the only difference between the two recurrences
 // once the feedback matrix is prepared accordingly (quipamd_gptq_round).
-template <bool UPD>
+// MODE 2 = one greedy coordinate-descent pass of LDLQ's post-processing (vector_balance.py:186-196, 263-288):
+//   Hs_i = (s H)_i - sum_{j > i} eps_j H[j][i];  new_i = round(wr_i - Hs_i / H[i][i]);  eps_i = wr_i - new_i
+// -- the same right-to-left recurrence with (s H) precomputed by a GEMM (passed in the eta slot), the feedback matrix
+// -H (strictly upper) and eps as the quantity fed back; values are written as floats, unclamped (the reference clamps
+// after the whole pass).
+template <int MODE>
 __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -167,6 +174,17 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
     // ---- in-block sequential error feedback of block [i1, i1 + cnt), chain wave cw = rows 4cw .. 4cw+3 --------------------
     auto chain = [&](int64_t i1, int cnt, const float *Ftile) {
         float acc[4][2], wv[4][2], et[4][2];
+        constexpr bool UPD = MODE == 1;
+        float hdv[2] = {1.f, 1.f};                            // mode 2: H[i][i] of this lane's two columns
+        if constexpr (MODE == 2) {
+            hdv[0] = lane < cnt ? A.hd[i1 + lane] : 1.f;
+            hdv[1] = lane + 64 < cnt ? A.hd[i1 + lane + 64] : 1.f;
+        }
+        // the value a column takes given its accumulated feedback
+        auto decide = [&](float w, float a, float g, float hd) -> float {
+            if constexpr (MODE == 2) return rintf(w - __fdiv_rn(g + a, hd));          // torch.round(wr - Hs / H[i,i])
+            else return round_col(w, a, g, A.maxq);
+        };
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int64_t row = r0 + 4 * cw + rr;
@@ -176,7 +194,7 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
                 const bool ok = (c < cnt) && (row < A.m);
                 acc[rr][h] = (c < cnt) ? Ftile[(4 * cw + rr) * BS + c] : 0.f;
                 wv[rr][h] = ok ? A.W[row * d + i1 + c] : 0.f;
-                et[rr][h] = (ok && A.eta) ? A.eta[row * d + i1 + c] : 0.5f;
+                et[rr][h] = (ok && A.eta) ? A.eta[row * d + i1 + c] : (MODE == 2 ? 0.f : 0.5f);
             }
         }
         // columns 64..cnt-1 live in register half 1
@@ -185,7 +203,7 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
             const float l0 = Ldiag[i * LDS_LD + lane], l1 = Ldiag[i * LDS_LD + 64 + lane];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const float q = round_col(wv[rr][1], acc[rr][1], et[rr][1], A.maxq);
+                const float q = decide(wv[rr][1], acc[rr][1], et[rr][1], hdv[1]);
                 const float er = (UPD ? wv[rr][1] + acc[rr][1] : wv[rr][1]) - q;
                 const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, er), ln));
                 acc[rr][0] = fmaf(e, l0, acc[rr][0]);
@@ -198,7 +216,7 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
             const float l0 = Ldiag[i * LDS_LD + lane];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const float q = round_col(wv[rr][0], acc[rr][0], et[rr][0], A.maxq);
+                const float q = decide(wv[rr][0], acc[rr][0], et[rr][0], hdv[0]);
                 const float er = (UPD ? wv[rr][0] + acc[rr][0] : wv[rr][0]) - q;
                 const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, er), ln));
                 acc[rr][0] = fmaf(e, l0, acc[rr][0]);
@@ -212,8 +230,9 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
             for (int h = 0; h < 2; ++h) {
                 const int c = lane + 64 * h;
                 if (c < cnt && row < A.m) {
-                    const float q = round_col(wv[rr][h], acc[rr][h], et[rr][h], A.maxq);
-                    A.codes[row * d + i1 + c] = (uint8_t)q;
+                    const float q = decide(wv[rr][h], acc[rr][h], et[rr][h], hdv[h]);
+                    if constexpr (MODE == 2) A.Wout[row * d + i1 + c] = q;
+                    else A.codes[row * d + i1 + c] = (uint8_t)q;
                     A.E[row * d + i1 + c] = (UPD ? wv[rr][h] + acc[rr][h] : wv[rr][h]) - q;
                 }
             }
@@ -282,25 +301,26 @@ __global__ __launch_bounds__(256) void unit_lower_t_kernel(const float *__restri
 
 }   // namespace
 
-template <bool UPD>
+template <int MODE>
 static int launch_ldlq(const float *Wgrid, const float *LT, const float *eta, int bits, uint8_t *codes, float *err_ws, int64_t m,
-                       int64_t d, void *stream, const char *who)
+                       int64_t d, void *stream, const char *who, const float *hd = nullptr, float *wout = nullptr)
 {
     if (m == 0 || d == 0) return QUIPAMD_OK;
-    QA_REQUIRE(Wgrid && LT && codes && err_ws, QUIPAMD_ERR_ARG, "%s: null pointer", who);
+    QA_REQUIRE(Wgrid && LT && (codes || wout) && err_ws, QUIPAMD_ERR_ARG, "%s: null pointer", who);
     QA_REQUIRE(bits >= 1 && bits <= 8, QUIPAMD_ERR_ARG, "%s: bits out of range", who);
     QA_REQUIRE(d % 16 == 0, QUIPAMD_ERR_SHAPE, "%s: needs d %% 16 == 0 (d=%lld)", who, (long long)d);
     LdlqArgs A;
     A.W = Wgrid; A.LT = LT; A.eta = eta; A.codes = codes; A.E = err_ws; A.m = m; A.d = d;
     A.maxq = (float)((1 << bits) - 1);
+    A.hd = hd; A.Wout = wout;
     const size_t lds = (size_t)(BS * LDS_LD + 2 * 16 * BS) * sizeof(float) + 4 * 3 * SLAB;
     static bool attr_set = false;                                  // per instantiation
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)ldlq_kernel<UPD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)ldlq_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "%s: cannot raise dynamic LDS to %zu", who, lds);
         attr_set = true;
     }
-    ldlq_kernel<UPD><<<(unsigned)((m + 15) / 16), 512, lds, (hipStream_t)stream>>>(A);
+    ldlq_kernel<MODE><<<(unsigned)((m + 15) / 16), 512, lds, (hipStream_t)stream>>>(A);
     QA_LAUNCH_CHECK(who);
     return QUIPAMD_OK;
 }
@@ -308,13 +328,20 @@ static int launch_ldlq(const float *Wgrid, const float *LT, const float *eta, in
 extern "C" int quipamd_gptq_round(const float *Wgrid_rev, const float *FT, int bits, uint8_t *codes_rev, float *err_ws, int64_t m,
                                   int64_t d, void *stream)
 {
-    return launch_ldlq<true>(Wgrid_rev, FT, nullptr, bits, codes_rev, err_ws, m, d, stream, "gptq_round");
+    return launch_ldlq<1>(Wgrid_rev, FT, nullptr, bits, codes_rev, err_ws, m, d, stream, "gptq_round");
+}
+
+extern "C" int quipamd_ldlq_greedy_pass(const float *wr, const float *sH, const float *negH_upper, const float *hdiag, float *wr_out,
+                                        float *eps, int64_t m, int64_t d, void *stream)
+{
+    QA_REQUIRE(m == 0 || d == 0 || (sH && hdiag && wr_out), QUIPAMD_ERR_ARG, "ldlq_greedy_pass: null pointer");
+    return launch_ldlq<2>(wr, negH_upper, sH, 1, nullptr, eps, m, d, stream, "ldlq_greedy_pass", hdiag, wr_out);
 }
 
 extern "C" int quipamd_ldlq_round(const float *Wgrid, const float *LT, const float *eta, int bits, uint8_t *codes,
                                   float *err_ws, int64_t m, int64_t d, void *stream)
 {
-    return launch_ldlq<false>(Wgrid, LT, eta, bits, codes, err_ws, m, d, stream, "ldlq_round");
+    return launch_ldlq<0>(Wgrid, LT, eta, bits, codes, err_ws, m, d, stream, "ldlq_round");
 }
 
 extern "C" int quipamd_unit_lower_t(const float *C, float *LT, int64_t d, void *stream)

@@ -315,6 +315,19 @@ def unit_lower_t(C):
     return LT
 
 
+def ldlq_greedy_pass(wr, sH, negH_upper, hdiag):
+    """one greedy pass (vector_balance.py:186-196): returns (wr_new float [m,d] unclamped, eps float [m,d])."""
+    _need_gpu(wr, sH, negH_upper, hdiag)
+    m, d = wr.shape
+    assert wr.dtype == sH.dtype == negH_upper.dtype == hdiag.dtype == torch.float32
+    assert sH.shape == (m, d) and negH_upper.shape == (d, d) and hdiag.shape == (d,)
+    out = torch.empty_like(wr)
+    eps = torch.empty_like(wr)
+    _lib.call("quipamd_ldlq_greedy_pass", _p(wr.contiguous()), _p(sH.contiguous()), _p(negH_upper.contiguous()),
+              _p(hdiag.contiguous()), _p(out), _p(eps), m, d, _stream())
+    return out, eps
+
+
 def gptq_feedback_matrix(Hinv):
     """FT for gptq_round from the upper Cholesky factor of H^-1 (gptq.py:51-54): reversed, transposed, each row of Hinv
     divided by its diagonal, negated, strictly upper (include/quip_amd.h)."""

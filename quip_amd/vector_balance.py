@@ -2,7 +2,9 @@
 (round_ldl :155-199, round_ldl_block :218-291, dispatcher quantize_weight_vecbal :500-532), backed by
 quip_amd/csrc/ldlq.hip (K4) and gridmap.hip (K5).
 
-Out of scope (research variants): allbal, ldlqRG greedy passes, ADMM.
+n_greedy_passes > 0 (the LDLQ-RG post-processing, :186-196 / :263-288) runs as one fp32 GEMM s @ H plus one launch of
+K4's third mode per pass; `ldlqRG` adds the diag(H) sort of :139-153 / :202-217.
+Out of scope (research variants): allbal, ADMM.
 """
 import torch
 
@@ -28,10 +30,35 @@ def _ldl_transposed(H):
     return ops.cholesky_lt(H.to(torch.float32))
 
 
+def _greedy_passes(w, codes, H, nbits, n_greedy_passes):
+    """vector_balance.py:182-196 (and the block form :259-288, identical up to fp summation order): coordinate descent
+    on tr((wr - w) H (wr - w)^T) over the integer grid, right to left, clamp after every pass, stop at a fixed point."""
+    import sys
+    w_hat = codes.to(torch.float32)
+    wr = w_hat.clone()
+    s = w_hat - w
+    Hn = (H / H.diag().max()).to(torch.float32).contiguous()
+    negU = (-torch.triu(Hn, diagonal=1)).contiguous()
+    hd = Hn.diag().contiguous()
+    maxq = float(2 ** nbits - 1)
+    for igp in range(n_greedy_passes):
+        wr_new, eps = ops.ldlq_greedy_pass(wr, s @ Hn, negU, hd)
+        s -= eps
+        wr = torch.clamp(wr_new, min=0, max=maxq)
+        if bool((w_hat == wr).all()):
+            sys.stderr.write(f"breaking after {igp+1} greedy passes found fixed point")
+            break
+        w_hat.copy_(wr)
+    return wr.to(torch.uint8)
+
+
 def _round_ldl_codes(w, H, nbits, n_greedy_passes, unbiased):
-    if n_greedy_passes != 0:
-        raise NotImplementedError("greedy post-passes (LDLQ-RG) are outside the quip_amd hot path; use npasses=0")
+    assert (not unbiased) or (n_greedy_passes == 0), "greedy passes are incompatible with unbiased LDL rounding"
     w = w.to(torch.float32)
+    if n_greedy_passes != 0:
+        assert shard.active() is None, "greedy passes are not row-sharded (they need s @ H on the owner)"
+        codes = ops.ldlq_round(w, _ldl_transposed(H), nbits, eta=None)
+        return _greedy_passes(w, codes, H.to(torch.float32), nbits, n_greedy_passes)
     eta = torch.rand(w.shape).to(w.device) if unbiased else None     # same CPU draw as vector_balance.py:174-175
     LT = _ldl_transposed(H)
     sharded = shard.active()
@@ -55,24 +82,48 @@ def round_ldl_block(w, H, nbits, blocksize=128, n_greedy_passes=9, unbiased=Fals
     return round_ldl(w, H, nbits, n_greedy_passes=n_greedy_passes, unbiased=unbiased)
 
 
+def round_sorted_ldlqRG(w, H, nbits, n_greedy_passes=9, unbiased=False, pivot=None):
+    """LDLQ-RG: columns sorted by diag(H) ascending, then round_ldl (vector_balance.py:139-153)."""
+    p = torch.argsort(torch.diag(H))
+    wr = torch.zeros(w.shape, device=w.device)
+    wr[:, p] = round_ldl(w[:, p].contiguous(), H[p, :][:, p].contiguous(), nbits, n_greedy_passes, unbiased)
+    return wr
+
+
+def round_sorted_ldlqRG_block(w, H, nbits, n_greedy_passes=9, unbiased=False, pivot=None):
+    """vector_balance.py:202-217; shares the kernel with round_sorted_ldlqRG like round_ldl_block does with round_ldl."""
+    return round_sorted_ldlqRG(w, H, nbits, n_greedy_passes, unbiased, pivot)
+
+
 @torch.no_grad()
 def quantize_weight_vecbal(w, H, nbits, npasses, scale, zero, maxq, unbiased=False, qfn='a', qmethod='bitbal',
                            lazy_batch=False, return_codes=False):
     """grid map -> LDLQ -> weights, returned as fp16 like the reference (vector_balance.py:500-532).
     return_codes=True additionally returns (codes uint8 [m,d], scale fp32, zero fp32|None): the integer state
     the reference throws away and a packed layer needs (SURVEY.md section 7 "hard parts")."""
-    if qmethod != 'ldlq':
-        raise NotImplementedError(f"qmethod {qmethod!r} is outside the quip_amd hot path (only 'ldlq')")
+    if qmethod not in ('ldlq', 'ldlqRG'):
+        raise NotImplementedError(f"qmethod {qmethod!r} is outside the quip_amd hot path (only 'ldlq' / 'ldlqRG')")
     mq = int(maxq.item()) if torch.is_tensor(maxq) else int(maxq)
+    if qmethod == 'ldlqRG':                       # sort the columns by diag(H), round, undo the sort (:139-153)
+        perm = torch.argsort(torch.diag(H))
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel(), device=perm.device)
+        Hs = H[perm, :][:, perm].contiguous()
+
+        def rounder(wgrid):
+            return _round_ldl_codes(wgrid[:, perm].contiguous(), Hs, nbits, npasses, unbiased)[:, inv].contiguous()
+    else:
+        def rounder(wgrid):
+            return _round_ldl_codes(wgrid, H, nbits, npasses, unbiased)
     if qfn == 'a':
         wgrid = ops.gridmap(w, 'a', scale, zero, mq)
-        codes = _round_ldl_codes(wgrid, H, nbits, npasses, unbiased)
+        codes = rounder(wgrid)
         out = ops.codes_to_weight(codes, 'a', scale, zero, mq, out_dtype=torch.float16)
         s_out, z_out = scale.reshape(-1).float(), zero.reshape(-1).float()
     elif qfn == 'b':
         s = ops.qfnb_scale(w)                                    # 2.4*rms(w)+1e-16 in w's dtype (:522)
         wgrid = ops.gridmap(w, 'b', s, None, mq)
-        codes = _round_ldl_codes(wgrid, H, nbits, npasses, unbiased)
+        codes = rounder(wgrid)
         out = ops.codes_to_weight(codes, 'b', s, None, mq, out_dtype=torch.float16)
         s_out, z_out = s, None
     else:
