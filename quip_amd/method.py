@@ -22,6 +22,9 @@ from . import ops
 
 DEBUG = False
 HESSIAN_FAST = False     # True: K7's opt-in 16-bit-MFMA mode for add_batch (f16 / bf16 inputs; see include/quip_amd.h)
+DEVICE_RNG = False       # True: draw the Gaussians of the SO(p) sampler with torch's device generator instead of numpy's
+                         # legacy stream -- same distribution (Haar), NOT the reference's seeded operators; removes the
+                         # host RNG that bounds preproc (0.8 M / 3.8 M normals per n = 8192 / 11008 operator)
 
 
 def _prime_factors(n):
@@ -55,10 +58,14 @@ def _special_ortho_group_gpu(p, m, dev):
     done for all n at once, and only the p-1 rank-one updates stay sequential (two batched fp64 GEMM launches each).
     Differences to scipy are fp64 summation order only (~1e-16), invisible after the fp32 narrowing of method.py:22."""
     shape = (m,) if m > 1 else ()
-    xs = np.zeros((p - 1, max(m, 1), p))
-    for n in range(p - 1):
-        xs[n, :, n:] = np.random.normal(size=shape + (p - n,)).reshape(max(m, 1), p - n)    # same calls as scipy
-    x = torch.from_numpy(xs).to(dev)                                    # [p-1, m, p], x_n zero-padded below column n
+    if DEVICE_RNG and dev.type == 'cuda':
+        x = torch.randn(p - 1, max(m, 1), p, dtype=torch.float64, device=dev)
+        x = x * (torch.arange(p, device=dev)[None, None, :] >= torch.arange(p - 1, device=dev)[:, None, None])
+    else:
+        xs = np.zeros((p - 1, max(m, 1), p))
+        for n in range(p - 1):
+            xs[n, :, n:] = np.random.normal(size=shape + (p - n,)).reshape(max(m, 1), p - n)    # same calls as scipy
+        x = torch.from_numpy(xs).to(dev)                                # [p-1, m, p], x_n zero-padded below column n
     norm2 = (x * x).sum(-1)
     idx = torch.arange(p - 1, device=dev)
     x0 = x[idx, :, idx].clone()                                         # [p-1, m]: leading element of every x_n

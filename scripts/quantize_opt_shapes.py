@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--seqlen", type=int, default=2048)
     ap.add_argument("--no-hessian", action="store_true")
     ap.add_argument("--fast-hessian", action="store_true", help="K7's opt-in 16-bit-MFMA mode (method.HESSIAN_FAST)")
+    ap.add_argument("--device-rng", action="store_true", help="opt-in method.DEVICE_RNG: operator sampling without the host RNG")
     ap.add_argument("--model", default="opt1p3b", choices=["opt1p3b", "llama7b"],
                     help="llama7b: BASELINE configs[3] shapes (32 blocks x {4 x 4096^2, 2 x 11008x4096, 4096x11008}); no CPU figures exist")
     args = ap.parse_args()
@@ -103,6 +104,9 @@ def main():
     if args.fast_hessian:
         from quip_amd import method as _m
         _m.HESSIAN_FAST = True
+    if args.device_rng:
+        from quip_amd import method as _m
+        _m.DEVICE_RNG = True
     if args.model == "llama7b":
         return llama(args, dev)
     shapes = [(2048, 2048)] * 4 + [(8192, 2048), (2048, 8192)]

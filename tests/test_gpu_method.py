@@ -311,3 +311,21 @@ def test_chained_u_then_v_is_bit_identical_to_two_launches(Q, rows, nb, relu, wi
         assert torch.equal(t, t_ref)
     for a, b in zip(xs, x_ref):
         assert torch.equal(a, b)
+
+
+def test_device_rng_sampler_gives_special_orthogonal_factors():
+    """opt-in method.DEVICE_RNG: same Householder construction, Gaussians from the device generator."""
+    from quip_amd import method as M
+    M.DEVICE_RNG = True
+    try:
+        torch.manual_seed(0)
+        for m, p in [(4, 64), (1, 33), (3, 128)]:
+            B = M.gen_rand_orthos(m, p).double()
+            B = B.reshape(-1, p, p)
+            eye = torch.eye(p, dtype=torch.float64)
+            assert float((B @ B.transpose(1, 2) - eye).abs().max()) < 1e-5
+            assert float((torch.linalg.det(B) - 1).abs().max()) < 1e-4
+        a, b = M.gen_rand_orthos(2, 16), M.gen_rand_orthos(2, 16)
+        assert not torch.equal(a, b)
+    finally:
+        M.DEVICE_RNG = False
