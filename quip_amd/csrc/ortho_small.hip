@@ -271,15 +271,19 @@ __device__ __forceinline__ void split_bf16(float v, uint16_t &hi, uint16_t &lo)
 // result straight from registers (LayerNorm / colscale on the way in): U^T y + residual -> LayerNorm -> V (x (/) s) of
 // two consecutive packed layers in ONE launch instead of two.  The hand-over value is rounded
 // to op[0].out_dtype, so the chain computes exactly what the two separate launches compute.
-template <class TI, class TO, int NPASS>
+// CP, CQ: compile-time factor sizes for the shapes a decode step uses (0 = take them from the op).  A phase-stamp probe
+// showed every phase of this kernel at 1500-3000 cycles for a few dozen MFMAs' worth of work: instruction count at 16
+// waves per CU is the cost, and with p, q known the address arithmetic folds and the k loops unroll.  The op descriptor
+// is copied by value once per pass (one batch of scalar loads instead of a kernarg round trip per field on first use).
+template <class TI, class TO, int NPASS, int CP, int CQ>
 __global__ __launch_bounds__(1024) void ortho_small_split_kernel(SmallBatch Bt)
 {
     constexpr int MAXV = 4;
     float4 xv[MAXV];
     for (int pass = 0; pass < NPASS; ++pass) {
-    const SmallArgs &A = NPASS == 1 ? Bt.op[blockIdx.y] : (pass == 0 ? Bt.op[0] : Bt.op[1 + blockIdx.y]);
+    const SmallArgs A = NPASS == 1 ? Bt.op[blockIdx.y] : (pass == 0 ? Bt.op[0] : Bt.op[1 + blockIdx.y]);
     extern __shared__ __attribute__((aligned(16))) char smemc[];
-    const int p = A.p, q = A.q, n = p * q;
+    const int p = CP ? CP : A.p, q = CQ ? CQ : A.q, n = p * q;
     const int P8 = p + 8, Q8 = q + 8, QS = q + 4;
     uint16_t *F0h = reinterpret_cast<uint16_t *>(smemc), *F0l = F0h + p * P8;
     uint16_t *F1h = F0l + p * P8, *F1l = F1h + q * Q8;
@@ -495,19 +499,41 @@ size_t small_split_lds(int p, int q)
 
 size_t small_lds(int p, int q) { return ((size_t)p * (p + 4) + (size_t)q * (q + 4) + 2 * (size_t)p * (q + 4) + 16) * 4; }
 
+template <class TI, class TO, int NPASS, int CP, int CQ>
+int launch_split_pq(const SmallBatch &B, int ny, int64_t rows, hipStream_t s, const char *who)
+{
+    const size_t lds = small_split_lds(B.op[0].p, B.op[0].q);
+    auto kern = ortho_small_split_kernel<TI, TO, NPASS, CP, CQ>;
+    if (lds > 64 * 1024)
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "%s: cannot raise dynamic LDS to %zu", who, lds);
+    kern<<<dim3((unsigned)rows, (unsigned)ny), 1024, lds, s>>>(B);
+    QA_LAUNCH_CHECK(who);
+    return QUIPAMD_OK;
+}
+
+template <class A, class B> struct SameT { static constexpr bool v = false; };
+template <class A> struct SameT<A, A> { static constexpr bool v = true; };
+
+// the dtype pairs of a decode step get the shape-specialised instantiations: V side f16 -> bf16, U side f32 -> f16, chain f32 -> bf16
+template <class TI, class TO, int NPASS>
+int launch_split(const SmallBatch &B, int ny, int64_t rows, hipStream_t s, const char *who)
+{
+    constexpr bool decode_pair = NPASS == 1 ? ((SameT<TI, F16>::v && SameT<TO, BF16>::v) || (SameT<TI, F32>::v && SameT<TO, F16>::v))
+                                            : (SameT<TI, F32>::v && SameT<TO, BF16>::v);
+    if constexpr (decode_pair) {
+        const int p = B.op[0].p, q = B.op[0].q;
+        if (p == 64 && q == 32) return launch_split_pq<TI, TO, NPASS, 64, 32>(B, ny, rows, s, who);      // n = 2048
+        if (p == 64 && q == 64) return launch_split_pq<TI, TO, NPASS, 64, 64>(B, ny, rows, s, who);      // n = 4096
+        if (p == 128 && q == 64) return launch_split_pq<TI, TO, NPASS, 128, 64>(B, ny, rows, s, who);    // n = 8192
+    }
+    return launch_split_pq<TI, TO, NPASS, 0, 0>(B, ny, rows, s, who);
+}
+
 template <class TI, class TO>
 int launch_small(const SmallBatch &B, int nops, int64_t rows, hipStream_t s)
 {
-    if (B.op[0].M0_hi) {
-        const size_t lds = small_split_lds(B.op[0].p, B.op[0].q);
-        auto kern = ortho_small_split_kernel<TI, TO, 1>;
-        if (lds > 64 * 1024)
-            if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return qa_fail(QUIPAMD_ERR_LAUNCH, "ortho_apply_small: cannot raise dynamic LDS to %zu", lds);
-        kern<<<dim3((unsigned)rows, (unsigned)nops), 1024, lds, s>>>(B);
-        QA_LAUNCH_CHECK("quipamd_ortho_apply_small");
-        return QUIPAMD_OK;
-    }
+    if (B.op[0].M0_hi) return launch_split<TI, TO, 1>(B, nops, rows, s, "quipamd_ortho_apply_small");
     const size_t lds = small_lds(B.op[0].p, B.op[0].q);
     auto kern = ortho_small_kernel<TI, TO>;
     if (lds > 64 * 1024)
@@ -595,16 +621,8 @@ extern "C" int quipamd_ortho_apply_small_chain(const quipamd_small_op *first, co
     for (int i = 1 + nsecond; i < QUIPAMD_SMALL_MAX_OPS; ++i) B.op[i] = second[0];
     if (rows == 0) return QUIPAMD_OK;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = small_split_lds(p, q);
-#define QA_CHAIN_CASE(XI, TI, XO, TO)                                                                                              \
-    if (first->x_dtype == XI && out_dtype == XO) {                                                                                 \
-        auto kern = ortho_small_split_kernel<TI, TO, 2>;                                                                           \
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-            return qa_fail(QUIPAMD_ERR_LAUNCH, "ortho_apply_small_chain: cannot raise dynamic LDS to %zu", lds);                   \
-        kern<<<dim3((unsigned)rows, (unsigned)nsecond), 1024, lds, s>>>(B);                                                          \
-        QA_LAUNCH_CHECK("quipamd_ortho_apply_small_chain");                                                                        \
-        return QUIPAMD_OK;                                                                                                         \
-    }
+#define QA_CHAIN_CASE(XI, TI, XO, TO) \
+    if (first->x_dtype == XI && out_dtype == XO) return launch_split<TI, TO, 2>(B, nsecond, rows, s, "quipamd_ortho_apply_small_chain");
     QA_CHAIN_CASE(QUIPAMD_F32, F32, QUIPAMD_BF16, BF16)
     QA_CHAIN_CASE(QUIPAMD_F32, F32, QUIPAMD_F16, F16)
     QA_CHAIN_CASE(QUIPAMD_F32, F32, QUIPAMD_F32, F32)

@@ -186,7 +186,7 @@ def time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager):
     return float(np.median(lat)), float(np.mean(lat)), logits_out.float().clone()
 
 
-def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense=True):
+def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense=True, only_chained=False):
     """build the model, time dense fp16 (optional), packed, and fused-packed decode; returns a dict."""
     dev, dtype = torch.device("cuda:0"), torch.float16
     maxlen = prompt + tokens + 8
@@ -210,6 +210,14 @@ def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense
         set_attn(False)
     twin, nbytes = pack_model(model, bits, dev)
     del twin
+    if only_chained:                                      # for kernel traces: just the best variant
+        for blk in model.blocks:
+            blk.fused = True
+        set_attn(True)
+        model.chained = True
+        med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+        out["packed_w%d_chained" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med}
+        return out
     med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
     out["packed_w%d" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med, "packed_weight_MB": nbytes / 1e6,
                                 "hbm_bound_tok_per_s": 8e12 / (nbytes + model.tok.weight.numel() * 2)}
@@ -239,8 +247,10 @@ def main():
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--tokens", type=int, default=128)
     ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--only-chained", action="store_true", help="time only the chained packed variant (for kernel traces)")
     args = ap.parse_args()
-    print(json.dumps(run(args.layers, args.bits, args.bs, args.prompt, args.tokens, args.eager)))
+    print(json.dumps(run(args.layers, args.bits, args.bs, args.prompt, args.tokens, args.eager,
+                         with_dense=not args.only_chained, only_chained=args.only_chained)))
 
 
 def decode_check(layers=2, bits=2):
