@@ -398,64 +398,90 @@ __global__ __launch_bounds__(1024) void ortho_small_split_kernel(SmallBatch Bt)
         const bool last = st == 1;
         if (mix_a) {
             // D[a = 16at + 4g + reg][b = 16bt + j] = sum_a' M0[a][a'] z[a'][b];  A = F0 rows, B = z^T rows (ZA)
-            for (int tile = wave; tile < nat * nbt; tile += 16) {
-                const int at = tile / nbt, bt = tile - at * nbt;
+            // n = 8192 (32 tiles on 16 waves): a wave takes two tiles that SHARE their factor rows, so the A fragments are
+            // read once -- the stage is LDS-bandwidth bound (every tile re-read 16 KiB of fragments: 512 KiB = 4096 cycles)
+            constexpr int TPW = (CP / 16) * (CQ / 16) == 32 ? 2 : 1;
+            for (int tile = wave * TPW; tile < nat * nbt; tile += 16 * TPW) {
+                const int at = tile / nbt, bt0 = tile - at * nbt;
                 // three independent accumulator chains (one per product), summed small-to-large at the end
-                f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-                const int fo = (16 * at + j) * P8 + 8 * g, zo = (16 * bt + j) * P8 + 8 * g;
+                f32x4_t acc[TPW], acc1[TPW], acc2[TPW];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) acc[t] = acc1[t] = acc2[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                const int fo = (16 * at + j) * P8 + 8 * g;
 #pragma unroll 4
                 for (int S = 0; S < p / 32; ++S) {
-                    Frag8 ah, al, bh, bl;
+                    Frag8 ah, al;
                     ah.u = *reinterpret_cast<const uint4 *>(F0h + fo + 32 * S);
                     al.u = *reinterpret_cast<const uint4 *>(F0l + fo + 32 * S);
-                    bh.u = *reinterpret_cast<const uint4 *>(ZAh + zo + 32 * S);
-                    bl.u = *reinterpret_cast<const uint4 *>(ZAl + zo + 32 * S);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, bh.v, acc1, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bl.v, acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bh.v, acc, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) {
+                        const int zo = (16 * (bt0 + t) + j) * P8 + 8 * g;
+                        Frag8 bh, bl;
+                        bh.u = *reinterpret_cast<const uint4 *>(ZAh + zo + 32 * S);
+                        bl.u = *reinterpret_cast<const uint4 *>(ZAl + zo + 32 * S);
+                        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, bh.v, acc1[t], 0, 0, 0);
+                        acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bl.v, acc2[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bh.v, acc[t], 0, 0, 0);
+                    }
                 }
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) acc[reg] += acc1[reg] + acc2[reg];
+                for (int t = 0; t < TPW; ++t) {
+                    const int bt = bt0 + t;
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int a = 16 * at + 4 * g + reg, b = 16 * bt + j;
-                    if (last) ZF[a * QS + b] = acc[reg];
-                    else {
-                        uint16_t hi, lo;
-                        split_bf16(acc[reg], hi, lo);
-                        ZBh[a * Q8 + b] = hi;
-                        ZBl[a * Q8 + b] = lo;
+                    for (int reg = 0; reg < 4; ++reg) acc[t][reg] += acc1[t][reg] + acc2[t][reg];
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int a = 16 * at + 4 * g + reg, b = 16 * bt + j;
+                        if (last) ZF[a * QS + b] = acc[t][reg];
+                        else {
+                            uint16_t hi, lo;
+                            split_bf16(acc[t][reg], hi, lo);
+                            ZBh[a * Q8 + b] = hi;
+                            ZBl[a * Q8 + b] = lo;
+                        }
                     }
                 }
             }
         } else {
             // D[b = 16bt + 4g + reg][a = 16at + j] = sum_b' M1[b][b'] z[a][b'];  A = F1 rows, B = z rows (ZB)
-            for (int tile = wave; tile < nat * nbt; tile += 16) {
-                const int bt = tile / nat, at = tile - bt * nat;
-                f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-                const int fo = (16 * bt + j) * Q8 + 8 * g, zo = (16 * at + j) * Q8 + 8 * g;
+            constexpr int TPW = (CP / 16) * (CQ / 16) == 32 ? 2 : 1;
+            for (int tile = wave * TPW; tile < nat * nbt; tile += 16 * TPW) {
+                const int bt = tile / nat, at0 = tile - bt * nat;
+                f32x4_t acc[TPW], acc1[TPW], acc2[TPW];
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) acc[t] = acc1[t] = acc2[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                const int fo = (16 * bt + j) * Q8 + 8 * g;
 #pragma unroll 4
                 for (int S = 0; S < q / 32; ++S) {
-                    Frag8 ah, al, bh, bl;
+                    Frag8 ah, al;
                     ah.u = *reinterpret_cast<const uint4 *>(F1h + fo + 32 * S);
                     al.u = *reinterpret_cast<const uint4 *>(F1l + fo + 32 * S);
-                    bh.u = *reinterpret_cast<const uint4 *>(ZBh + zo + 32 * S);
-                    bl.u = *reinterpret_cast<const uint4 *>(ZBl + zo + 32 * S);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, bh.v, acc1, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bl.v, acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bh.v, acc, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) {
+                        const int zo = (16 * (at0 + t) + j) * Q8 + 8 * g;
+                        Frag8 bh, bl;
+                        bh.u = *reinterpret_cast<const uint4 *>(ZBh + zo + 32 * S);
+                        bl.u = *reinterpret_cast<const uint4 *>(ZBl + zo + 32 * S);
+                        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, bh.v, acc1[t], 0, 0, 0);
+                        acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bl.v, acc2[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah.v, bh.v, acc[t], 0, 0, 0);
+                    }
                 }
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) acc[reg] += acc1[reg] + acc2[reg];
-                const int a = 16 * at + j, b0 = 16 * bt + 4 * g;
-                if (last) *reinterpret_cast<float4 *>(ZF + a * QS + b0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                else {
+                for (int t = 0; t < TPW; ++t) {
+                    const int at = at0 + t;
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        uint16_t hi, lo;
-                        split_bf16(acc[reg], hi, lo);
-                        ZAh[(b0 + reg) * P8 + a] = hi;
-                        ZAl[(b0 + reg) * P8 + a] = lo;
+                    for (int reg = 0; reg < 4; ++reg) acc[t][reg] += acc1[t][reg] + acc2[t][reg];
+                    const int a = 16 * at + j, b0 = 16 * bt + 4 * g;
+                    if (last) *reinterpret_cast<float4 *>(ZF + a * QS + b0) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+                    else {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            uint16_t hi, lo;
+                            split_bf16(acc[t][reg], hi, lo);
+                            ZAh[(b0 + reg) * P8 + a] = hi;
+                            ZAl[(b0 + reg) * P8 + a] = lo;
+                        }
                     }
                 }
             }
