@@ -278,15 +278,16 @@ def test_packed_forward_fused_matches_unfused(Q, rows):
         assert float((single.float() - qls[0](x).float()).norm() / qls[0](x).float().norm()) <= 2e-3
 
 
-@pytest.mark.parametrize("rows,nb,relu,with_res,with_ln,store", [(1, 1, False, True, True, True), (2, 3, False, True, True, True),
-                                                               (1, 1, True, False, False, False), (5, 2, True, True, False, True)])
-def test_chained_u_then_v_is_bit_identical_to_two_launches(Q, rows, nb, relu, with_res, with_ln, store):
+@pytest.mark.parametrize("n,rows,nb,relu,with_res,with_ln,store", [(2048, 1, 1, False, True, True, True), (2048, 2, 3, False, True, True, True),
+                                                                 (2048, 1, 1, True, False, False, False), (2048, 5, 2, True, True, False, True),
+                                                                 (8192, 1, 1, True, False, False, False), (4096, 2, 1, False, True, True, True)])
+def test_chained_u_then_v_is_bit_identical_to_two_launches(Q, n, rows, nb, relu, with_res, with_ln, store):
     """quipamd_ortho_apply_small_chain: U^T y + bias + residual -> [LayerNorm] -> V (x (/) s) of consecutive packed
     layers in one launch == packed_u_stage followed by packed_v_stage."""
     from quip_amd import ops, method
     torch.manual_seed(11)
     np.random.seed(11)
-    n, bits = 2048, 2
+    bits = 2
 
     def mk():
         W = (0.02 * torch.randn(n, n)).half().to(DEV)
