@@ -9,8 +9,9 @@
 //   that is replayed for every token (the position advances on the device).
 //   phase 1  scores: thread t (+256, ...) owns cache position t: 128-byte row of K (8 x 16 B), q in registers, fp32 dot;
 //            scores and the running max go through LDS, exp in fp32.
-//   phase 2  lane = output dimension (hd = 64 -> one wave per row, 128 B coalesced per V row), the 4 waves take
-//            positions t = w, w+4, ...; partial sums meet in LDS; normalised, written in the activation dtype.
+//   phase 2  lane = (row slot, 8-dimension chunk): 16-byte loads, 8 rows of V per instruction and 8 instructions in
+//            flight per wave; row slots fold with shuffles, the 4 waves meet in LDS; normalised, written in the
+//            activation dtype.
 // fp32 throughout (the eager chain rounds scores and probabilities to fp16); the result differs from it by that rounding.
 #include "common.h"
 
@@ -75,30 +76,39 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
 
     // ---- phase 2: o = p V ---------------------------------------------------------------------------------------------
-    constexpr int NL = HD / 64;                                      // output dims per lane (hd = 64: 1, hd = 128: 2)
-    float o[NL];
+    // lane = (row slot, 8-dim chunk): one 16-byte load per lane covers 64 / CH rows per instruction, up to 8 such loads
+    // in flight, so a ~130-position context is ONE round trip per wave (one 128-byte row per instruction was five).
+    constexpr int CH = HD / 8, RS = 64 / CH;                         // chunks per row, rows per instruction (hd 64: 8, 8)
+    const int ch = lane % CH, rsub = lane / CH;
+    float o[8];
 #pragma unroll
-    for (int n = 0; n < NL; ++n) o[n] = 0.f;
-    // 8 rows in flight per wave: one 128-byte row per iteration would be a chain of L2 round trips
-    int64_t t = wave;
-    for (; t + 28 < T; t += 32) {
-        float vv[8][NL];
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    for (int64_t tb = (int64_t)wave * RS; tb < T; tb += 4 * RS * 8) {
+        uint4 raw[8];
+        float pw[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 8; ++u) {
+            const int64_t t = tb + (int64_t)u * 4 * RS + rsub;
+            const bool ok = t < T;
+            raw[u] = ok ? *reinterpret_cast<const uint4 *>(vcb + t * HD + 8 * ch) : make_uint4(0, 0, 0, 0);
+            pw[u] = ok ? scores[t] : 0.f;
+        }
 #pragma unroll
-            for (int n = 0; n < NL; ++n) vv[u][n] = DT<TI>::load(vcb + (t + 4 * u) * HD, lane + 64 * n);
+        for (int u = 0; u < 8; ++u) {
+            const S *rv = reinterpret_cast<const S *>(&raw[u]);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int n = 0; n < NL; ++n) o[n] = fmaf(scores[t + 4 * u], vv[u][n], o[n]);
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(pw[u], DT<TI>::load(rv, e), o[e]);
+        }
     }
-    for (; t < T; t += 4) {
-        const float p = scores[t];
+    // rows of one chunk sit CH lanes apart: fold the row slots, then the 4 waves through LDS
 #pragma unroll
-        for (int n = 0; n < NL; ++n) o[n] = fmaf(p, DT<TI>::load(vcb + t * HD, lane + 64 * n), o[n]);
+    for (int off = CH; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += __shfl_xor(o[e], off);
+    if (rsub == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[wave * HD + 8 * ch + e] = o[e];
     }
-#pragma unroll
-    for (int n = 0; n < NL; ++n) part[wave * HD + lane + 64 * n] = o[n];
     __syncthreads();
     if (tid < HD) {
         const float r = (part[tid] + part[HD + tid]) + (part[2 * HD + tid] + part[3 * HD + tid]);
