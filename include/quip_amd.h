@@ -45,6 +45,8 @@ enum quipamd_dtype { QUIPAMD_F32 = 0, QUIPAMD_F16 = 1, QUIPAMD_BF16 = 2 };
  * STREAM:    the permutation of it that the fused GEMM streams: 16-row x (512/bits)-column
  *            tiles of 64 lanes x 16 B in MFMA A-fragment order (oracle/quip_oracle.py
  *            pack_stream is the specification).  Requires m % 16 == 0, d % (512/bits) == 0. */
+/* bits = 3 with the STREAM layout: codes 0..7 stored in the 4-bit container (K2 dequantises nibbles; the 3-bit grid,
+ * maxq = 7, is applied in its epilogue).  The reference's 32-codes-in-3-words rule (quant.py:185-220) has no GPU kernel. */
 enum quipamd_layout { QUIPAMD_LAYOUT_CANONICAL = 0, QUIPAMD_LAYOUT_STREAM = 1 };
 
 /* grid functions: quant.py:6-8 (a), quant.py:10-15 (b), quant.py:17-21 (c) */

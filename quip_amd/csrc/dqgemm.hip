@@ -875,7 +875,9 @@ static int dequant_gemm_impl(int ngroups, const void *const *x, int x_dtype, con
     QA_REQUIRE(!accumulate || y_dtype == QUIPAMD_F32, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: accumulate needs f32 y");
     QA_REQUIRE(layout == QUIPAMD_LAYOUT_STREAM, QUIPAMD_ERR_UNSUPPORTED,
                "dequant_gemm: qweight must be in STREAM layout (repack with quipamd_unpack/quipamd_pack)");
-    QA_REQUIRE(bits == 2 || bits == 4, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: bits must be 2 or 4");
+    QA_REQUIRE(bits == 2 || bits == 3 || bits == 4, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: bits must be 2, 3 or 4");
+    const int grid_maxq = (1 << bits) - 1;             // 3-bit codes (maxq 7) ride in the 4-bit container (pack.hip)
+    if (bits == 3) bits = 4;
     QA_REQUIRE(qfn == QUIPAMD_QFN_B || qfn == QUIPAMD_QFN_A, QUIPAMD_ERR_ARG, "dequant_gemm: qfn must be a or b");
     QA_REQUIRE(bs * d * 2 < ((int64_t)1 << 31) && m * d * bits / 8 < ((int64_t)1 << 40), QUIPAMD_ERR_SHAPE,
                "dequant_gemm: x larger than 2 GiB is not supported by the 32-bit buffer offsets (bs=%lld d=%lld)", (long long)bs, (long long)d);
@@ -892,7 +894,7 @@ static int dequant_gemm_impl(int ngroups, const void *const *x, int x_dtype, con
     if (bs == 0 || m == 0) return QUIPAMD_OK;
     EpiArgs e;
     e.scale = G.scale[0]; e.zero = G.zero[0]; e.bias = G.bias[0]; e.y = G.y[0];
-    e.qfn = qfn; e.maxq = (1 << bits) - 1; e.two_over_maxq = 2.0f / (float)e.maxq; e.y_f32 = (y_dtype == QUIPAMD_F32); e.accumulate = accumulate;
+    e.qfn = qfn; e.maxq = grid_maxq; e.two_over_maxq = 2.0f / (float)e.maxq; e.y_f32 = (y_dtype == QUIPAMD_F32); e.accumulate = accumulate;
     e.bs = bs; e.m = m;
     hipStream_t s = (hipStream_t)stream;
     if (bits == 2) return launch<2>(G, ngroups, e, d, s);

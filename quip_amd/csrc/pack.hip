@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void unpack_stream_kernel(const uint4 *__restr
 int check_pack_args(const void *a, const void *b, int bits, int layout, int64_t m, int64_t d)
 {
     QA_REQUIRE((a && b) || m == 0 || d == 0, QUIPAMD_ERR_ARG, "pack/unpack: null pointer");
-    QA_REQUIRE(bits == 2 || bits == 4, QUIPAMD_ERR_UNSUPPORTED, "pack/unpack: bits must be 2 or 4 (got %d)", bits);
+    QA_REQUIRE(bits == 2 || bits == 4, QUIPAMD_ERR_UNSUPPORTED, "pack/unpack: container bits must be 2 or 4 (got %d)", bits);
     QA_REQUIRE(m >= 0 && d >= 0, QUIPAMD_ERR_SHAPE, "pack/unpack: negative shape");
     if (layout == QUIPAMD_LAYOUT_CANONICAL) {
         QA_REQUIRE(d % (32 / bits) == 0 && d % 16 == 0, QUIPAMD_ERR_SHAPE,
@@ -169,9 +169,14 @@ int check_pack_args(const void *a, const void *b, int bits, int layout, int64_t 
 
 }   // namespace
 
+// 3-bit codes (--wbits 3) ride in the 4-bit STREAM container: K2 dequantises nibbles, the grid (maxq = 7) lives in its
+// epilogue.  The reference's 32-codes-in-3-words rule (quant.py:185-220) is restated in the oracle only.
+static inline int container_bits(int bits, int layout) { return (bits == 3 && layout == QUIPAMD_LAYOUT_STREAM) ? 4 : bits; }
+
 extern "C" int quipamd_pack(const uint8_t *codes, int bits, int layout, int32_t *packed, int64_t m, int64_t d,
                             void *stream)
 {
+    bits = container_bits(bits, layout);
     int rc = check_pack_args(codes, packed, bits, layout, m, d);
     if (rc) return rc;
     if (m == 0 || d == 0) return QUIPAMD_OK;
@@ -193,6 +198,7 @@ extern "C" int quipamd_pack(const uint8_t *codes, int bits, int layout, int32_t 
 extern "C" int quipamd_unpack(const int32_t *packed, int bits, int layout, uint8_t *codes, int64_t m, int64_t d,
                               void *stream)
 {
+    bits = container_bits(bits, layout);
     int rc = check_pack_args(packed, codes, bits, layout, m, d);
     if (rc) return rc;
     if (m == 0 || d == 0) return QUIPAMD_OK;

@@ -36,9 +36,14 @@ def _dtype(t):
         raise TypeError(f"unsupported dtype {t.dtype}")
 
 
+def container_bits(bits):
+    """storage bits per code in the STREAM layout: 3-bit codes ride in the 4-bit container."""
+    return 4 if bits == 3 else bits
+
+
 def stream_chunk(bits):
     """columns per 16-row STREAM tile (include/quip_amd.h)."""
-    return 512 // bits
+    return 512 // container_bits(bits)
 
 
 # ------------------------------------------------------------------------------------------------- K1
@@ -48,7 +53,7 @@ def pack(codes, bits, layout=LAYOUT_CANONICAL):
     assert codes.dtype == torch.uint8 and codes.dim() == 2
     codes = codes.contiguous()
     m, d = codes.shape
-    shape = (d * bits // 32, m) if layout == LAYOUT_CANONICAL else (m * d * bits // 32,)
+    shape = (d * bits // 32, m) if layout == LAYOUT_CANONICAL else (m * d * container_bits(bits) // 32,)
     out = torch.empty(shape, dtype=torch.int32, device=codes.device)
     _lib.call("quipamd_pack", _p(codes), bits, layout, _p(out), m, d, _stream())
     return out
@@ -58,7 +63,7 @@ def unpack(packed, bits, layout, m, d):
     _need_gpu(packed)
     assert packed.dtype == torch.int32
     packed = packed.contiguous()
-    assert packed.numel() == m * d * bits // 32
+    assert packed.numel() == m * d * (bits if layout == LAYOUT_CANONICAL else container_bits(bits)) // 32
     codes = torch.empty((m, d), dtype=torch.uint8, device=packed.device)
     _lib.call("quipamd_unpack", _p(packed), bits, layout, _p(codes), m, d, _stream())
     return codes
@@ -124,7 +129,7 @@ def dequant_gemm(x, qweight, bits, qfn, scale, zero, bias, out=None, out_dtype=t
     x = x.contiguous()
     bs, d = x.shape
     if m is None:
-        m = qweight.numel() * 32 // bits // d
+        m = qweight.numel() * 32 // container_bits(bits) // d
     dev = x.device
     scale, zero, bias = _f32vec(scale, dev), _f32vec(zero, dev), _f32vec(bias, dev)
     if out is None:

@@ -132,9 +132,9 @@ class QuantLinear(nn.Module):
 
     def __init__(self, infeatures, outfeatures, bits=2, qfn='b'):
         super().__init__()
-        assert bits in (2, 4)
+        assert bits in (2, 3, 4)                  # 3-bit codes (--wbits 3) are stored in the 4-bit container
         self.infeatures, self.outfeatures, self.bits, self.qfn = infeatures, outfeatures, bits, qfn
-        self.register_buffer('qweight', torch.zeros(infeatures * outfeatures * bits // 32, dtype=torch.int32))
+        self.register_buffer('qweight', torch.zeros(infeatures * outfeatures * ops.container_bits(bits) // 32, dtype=torch.int32))
         self.register_buffer('scales', torch.zeros(1 if qfn == 'b' else outfeatures))
         self.register_buffer('zeros', torch.zeros(outfeatures) if qfn != 'b' else None)
         self.register_buffer('bias', None)
@@ -208,6 +208,45 @@ class QuantLinear(nn.Module):
                                  out_dtype=torch.float32, m=self.outfeatures)
             y = self.U.apply_rows(y, transpose=True, out_dtype=x.dtype, bias=self.bias)   # fp32 in, caller's dtype out
         return y.to(x.dtype).reshape(*shape[:-1], self.outfeatures)
+
+
+class Quant3Linear(QuantLinear):
+    """The reference's packed 3-bit layer (quant.py:173-233) by name and call protocol:
+    `Quant3Linear(infeatures, outfeatures)`, `.pack(linear, scales, zeros)` from a fake-quantised nn.Linear and its
+    per-row grid (qfn a), `forward(x)` = bias + sum (scales q - zeros scales) x.  Differences: the codes live on the GPU
+    in the 4-bit STREAM container that K2 reads (the reference's 32-codes-in-3-words array had no runnable kernel,
+    quant.py:166-169), and forward() accepts any batch, not only a single token (quant.py:233)."""
+
+    def __init__(self, infeatures, outfeatures):
+        super().__init__(infeatures, outfeatures, bits=3, qfn='a')
+
+    @torch.no_grad()
+    def pack(self, linear, scales, zeros, **kw):
+        if not isinstance(linear, nn.Module):            # QuantLinear.pack(codes, scale, zero, ...) protocol
+            return super().pack(linear, scales, zeros, **kw)
+        dev = linear.weight.device if linear.weight.is_cuda else torch.device(_DEV)
+        sc = scales.to(dev, torch.float32).reshape(-1, 1)
+        zr = zeros.to(dev, torch.float32).reshape(-1, 1)
+        W = linear.weight.data.to(dev, torch.float32)
+        codes = torch.round((W + zr * sc) / sc).clamp_(0, 7).to(torch.uint8)          # quant.py:186-191
+        bias = None if linear.bias is None else linear.bias.data
+        return super().pack(codes, sc, zr, bias=bias)
+
+
+_DEV = 'cuda:0'
+
+
+def make_quant3(module, names, name=''):
+    """replace the named nn.Linear children by (empty) Quant3Linear layers, to be filled by .pack() or a state dict
+    (quant.py:236-246)."""
+    if isinstance(module, Quant3Linear):
+        return
+    for attr, tmp in list(module.named_children()):       # the reference walks dir(module); children cover containers too
+        name1 = name + '.' + attr if name != '' else attr
+        if name1 in names:
+            setattr(module, attr, Quant3Linear(tmp.in_features, tmp.out_features))
+    for name1, child in module.named_children():
+        make_quant3(child, names, name + '.' + name1 if name != '' else name1)
 
 
 def _ln_params(ln):

@@ -216,3 +216,37 @@ def test_batched_kernel_bs_over_16(ops, O, bits, qfn, m, d, bs):
     assert not bad, f"batched-kernel variants with wrong results: {bad}"
     y16 = ops.dequant_gemm(xd, qs, bits, qfn, sc, zr, torch.from_numpy(bias), out_dtype=torch.bfloat16)
     assert _rel(y16.float().cpu().numpy().astype(np.float64), y_ref) <= TOL_BF16
+
+
+def test_three_bit_codes_in_the_four_bit_container_and_quant3linear():
+    """--wbits 3: codes 0..7 ride in the 4-bit STREAM container; K2 applies the 3-bit grid (maxq 7) in its epilogue.
+    Quant3Linear / make_quant3 keep the reference's names and pack(linear, scales, zeros) protocol (quant.py:173-246)."""
+    from quip_amd import ops, quant as Q
+    from oracle import quip_oracle as O
+    m, d, bs = 64, 256, 5
+    g = torch.Generator().manual_seed(0)
+    W = 0.02 * torch.randn(m, d, generator=g)
+    x = torch.randn(bs, d, generator=g)
+    # qfn b with maxq 7
+    s = ops.qfnb_scale(W.to(DEV))
+    What, codes = ops.quantize(W.to(DEV), 'b', s, None, 7, want_codes=True)
+    assert int(codes.max()) <= 7 and int(codes.max()) > 3
+    pk = ops.pack(codes, 3, ops.LAYOUT_STREAM)
+    assert pk.numel() == m * d * 4 // 32 and torch.equal(ops.unpack(pk, 3, ops.LAYOUT_STREAM, m, d), codes)
+    y = ops.dequant_gemm(x.to(DEV).bfloat16(), pk, 3, 'b', s, None, None, out_dtype=torch.float32, m=m)
+    want = x.bfloat16().double() @ What.double().cpu().T
+    assert float((y.double().cpu() - want).norm() / want.norm()) < 1e-3
+    # the reference's layer by name: fake-quantised Linear + per-row grid -> packed forward
+    sc, zr = O.find_params_qfna(W.numpy(), 3)
+    Wq = torch.from_numpy(O.quantize_qfna(W.numpy(), sc, zr, 7))
+    lin = torch.nn.Linear(d, m)
+    lin.weight.data = Wq.clone()
+    holder = torch.nn.Sequential(lin).to(DEV)
+    Q.make_quant3(holder, ["0"])
+    assert isinstance(holder[0], Q.Quant3Linear) and holder[0].bits == 3
+    holder[0].pack(lin.to(DEV), torch.from_numpy(sc), torch.from_numpy(zr))
+    got = holder[0](x.to(DEV))
+    want = x.bfloat16().double() @ Wq.double().T + lin.bias.detach().double().cpu()
+    assert float((got.double().cpu() - want).norm() / want.norm()) < 2e-3
+    codes_ref = np.clip(np.round((Wq.numpy() + zr * sc) / sc), 0, 7)
+    np.testing.assert_array_equal(ops.unpack(holder[0].qweight, 3, ops.LAYOUT_STREAM, m, d).cpu().numpy(), codes_ref)

@@ -51,13 +51,18 @@ def test_gpu_sampler_is_scipys_algorithm_on_the_same_stream():
 def test_surface_names_exist():
     import quip_amd.quant as q, quip_amd.method as m, quip_amd.vector_balance as vb
     import quip_amd.bal as bal, quip_amd.gptq as gptq, quip_amd.near as near, quip_amd.modelutils as mu
-    for name in ("quantize_qfna", "quantize_qfnb", "quantize_qfnc", "Quantizer", "QuantLinear", "make_quant"):
+    for name in ("quantize_qfna", "quantize_qfnb", "quantize_qfnc", "Quantizer", "QuantLinear", "make_quant", "Quant3Linear",
+                 "make_quant3"):
         assert hasattr(q, name)
     for name in ("butterfly_factors", "gen_rand_orthos", "gen_rand_ortho_butterfly", "gen_rand_ortho_butterfly_noblock",
                  "gen_rand_ortho_butterfly_nopermute", "mul_ortho_butterfly", "rand_ortho_butterfly", "QuantMethod"):
         assert hasattr(m, name)
-    for name in ("round_ldl", "round_ldl_block", "quantize_weight_vecbal", "check_nbits"):
+    for name in ("round_ldl", "round_ldl_block", "round_sorted_ldlqRG", "round_sorted_ldlqRG_block", "quantize_weight_vecbal",
+                 "check_nbits"):
         assert hasattr(vb, name)
+    holder = torch.nn.Sequential(torch.nn.Linear(512, 32))
+    q.make_quant3(holder, ["0"])                                  # module swap needs no GPU (quant.py:236-246)
+    assert isinstance(holder[0], q.Quant3Linear) and holder[0].qweight.numel() == 512 * 32 * 4 // 32
     assert issubclass(bal.Balance, m.QuantMethod) and issubclass(gptq.GPTQ, m.QuantMethod)
     assert issubclass(near.Nearest, m.QuantMethod)
     assert str(mu.DEV) == "cuda:0"
