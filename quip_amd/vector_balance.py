@@ -82,6 +82,17 @@ def round_ldl_block(w, H, nbits, blocksize=128, n_greedy_passes=9, unbiased=Fals
     return round_ldl(w, H, nbits, n_greedy_passes=n_greedy_passes, unbiased=unbiased)
 
 
+def round_ldl_gptqequiv(w, H, nbits, unbiased=False):
+    """LDLQ in OPTQ's column order (vector_balance.py:381-422, used by optq_ldlq_equiv.py): Cholesky of the flipped H,
+    factor flipped back, columns rounded left to right -- i.e. round_ldl on the column-reversed problem."""
+    w = w.to(torch.float32)
+    eta = torch.rand(w.shape).to(w.device).flip(1).contiguous() if unbiased else None      # eta[:, i] belongs to column i
+    LT = _ldl_transposed(torch.flip(H.to(torch.float32), [0, 1]).contiguous())
+    codes = ops.ldlq_round(w.flip(1).contiguous(), LT, nbits, eta=eta).flip(1).contiguous().to(torch.float32)
+    check_nbits(codes, nbits)
+    return codes
+
+
 def round_sorted_ldlqRG(w, H, nbits, n_greedy_passes=9, unbiased=False, pivot=None):
     """LDLQ-RG: columns sorted by diag(H) ascending, then round_ldl (vector_balance.py:139-153)."""
     p = torch.argsort(torch.diag(H))

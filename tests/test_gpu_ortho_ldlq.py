@@ -337,3 +337,17 @@ def test_round_ldl_api_with_greedy_passes_and_ldlqRG(ops):
     out = VB.quantize_weight_vecbal(w=(0.02 * torch.randn(m, d, generator=g)).half().to(DEV), H=H, nbits=bits, npasses=3,
                                     scale=None, zero=None, maxq=torch.tensor(3), qfn='b', qmethod='ldlqRG')
     assert out.dtype == torch.float16 and out.shape == (m, d)
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+def test_round_ldl_gptqequiv_matches_reference_golden(ops, bits):
+    """vector_balance.round_ldl_gptqequiv (LDLQ in OPTQ's column order, vector_balance.py:381-422) against the
+    reference-generated golden codes (tests/golden/ldlq.npz)."""
+    from quip_amd import vector_balance as VB
+    g = load_golden("ldlq")
+    W = torch.from_numpy(g[f"W{bits}"].astype(np.float32)).to(DEV)
+    H = torch.from_numpy(g["H"].astype(np.float32)).to(DEV)
+    if H.shape[0] % 16:
+        pytest.skip("K4 needs d % 16 == 0")
+    got = VB.round_ldl_gptqequiv(W, H, bits).cpu().numpy()
+    assert np.mean(got != g[f"gptqequiv{bits}"]) <= 2e-3

@@ -57,7 +57,7 @@ def test_surface_names_exist():
     for name in ("butterfly_factors", "gen_rand_orthos", "gen_rand_ortho_butterfly", "gen_rand_ortho_butterfly_noblock",
                  "gen_rand_ortho_butterfly_nopermute", "mul_ortho_butterfly", "rand_ortho_butterfly", "QuantMethod"):
         assert hasattr(m, name)
-    for name in ("round_ldl", "round_ldl_block", "round_sorted_ldlqRG", "round_sorted_ldlqRG_block", "quantize_weight_vecbal",
+    for name in ("round_ldl", "round_ldl_block", "round_ldl_gptqequiv", "round_sorted_ldlqRG", "round_sorted_ldlqRG_block", "quantize_weight_vecbal",
                  "check_nbits"):
         assert hasattr(vb, name)
     holder = torch.nn.Sequential(torch.nn.Linear(512, 32))
