@@ -191,6 +191,15 @@ int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int nops, int64_t
 int quipamd_ortho_apply_small_chain(const quipamd_small_op *first, const quipamd_small_op *second, int nsecond, int64_t rows,
                                     void *stream);
 
+/* Decode: the dequant-GEMM with the activation-side operator in its prologue (one launch instead of
+ * quipamd_ortho_apply_small_ops + quipamd_dequant_gemm_grouped):
+ *   y[i][b, :] = What_i ( V_i ( [LayerNorm](x[b, :]) (/) s_i ) ) + bias_i      i < ngroups <= 3, 2-bit STREAM codes, qfn b,
+ * for d = 2048 (the operator must be 64 x 32 with split-bf16 factors), bs <= 8, m % 32 == 0, fp32 y [bs, m].
+ * vops[i]: the V-side descriptor (x f16 / bf16, ln_*, colscale, factors, index vectors; out / bias / residual unused).
+ * Bit-identical to the two separate launches. */
+int quipamd_dequant_gemm_vop(const quipamd_small_op *vops, const int32_t *const *qweight, const float *const *scale,
+                             const float *const *bias, float *const *y, int ngroups, int bits, int64_t bs, int64_t m, void *stream);
+
 /* ---- K4: LDLQ rounding -------------------------------------------------------------------------
  * Replaces round_ldl / round_ldl_block (vector_balance.py:155-199, 218-257; n_greedy_passes = 0):
  *   for i = d-1 .. 0:  q_i = clamp(floor(w_i + sum_{j>i} (w_j - q_j) L[j,i] + eta_i), 0, 2^bits - 1)

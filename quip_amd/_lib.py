@@ -36,6 +36,7 @@ SIGNATURES = {
                                  c_vp, c_int, c_i64, c_i64, c_vp, c_vp],
     "quipamd_ortho_apply_small": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_int,
                                   c_i64, c_i64, c_vp],
+    "quipamd_dequant_gemm_vop": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_i64, c_vp],
     "quipamd_ortho_apply_small_chain": [c_vp, c_vp, c_int, c_i64, c_vp],
     "quipamd_ldlq_round": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp],
     "quipamd_unit_lower_t": [c_vp, c_vp, c_i64, c_vp],

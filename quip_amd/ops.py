@@ -183,6 +183,15 @@ def ortho_small_chain(first, seconds, rows):
               len(seconds), rows, _stream())
 
 
+def dequant_gemm_vop(vops, qweights, scales, biases, ys, bs, m, bits=2):
+    """V-side operator + grouped 2-bit dequant-GEMM in ONE launch (quipamd_dequant_gemm_vop; d = 2048, bs <= 8)."""
+    n = len(vops)
+    arr = (SmallOp * n)(*vops)
+    vp = lambda ts: (ctypes.c_void_p * n)(*[0 if t is None else t.data_ptr() for t in ts])
+    _lib.call("quipamd_dequant_gemm_vop", ctypes.cast(arr, ctypes.c_void_p), vp(qweights), vp(scales),
+              vp(biases if biases is not None else [None] * n), vp(ys), n, bits, bs, m, _stream())
+
+
 def _mfma_b_frags(M):
     """M [C, P, P] (out index i, in index k) -> float [C, NT, NT, 64, 4] in v_mfma_f32_16x16x4_f32 B-fragment order
     (include/quip_amd.h): element [c][nt][S][lane][s] = M[c][16 nt + (lane & 15)][16 S + 4 (lane >> 4) + s]."""

@@ -303,6 +303,26 @@ def packed_v_stage(qls, x, ln=None):
     return xts
 
 
+def vgemm_fusable(qls, rows):
+    """can launches 1 + 2 run as one (quipamd_dequant_gemm_vop)?  d = 2048 (64 x 32 operator), 2-bit, a few rows."""
+    q0 = qls[0]
+    return (all(_fusable(q, rows) and q.V.split_ok and q.V.use_split and q.bits == 2 for q in qls) and rows <= 8
+            and q0.infeatures == 2048 and (q0.V.p, q0.V.q) == (64, 32) and q0.outfeatures % 32 == 0 and len(qls) <= 3
+            and len({(q.infeatures, q.outfeatures) for q in qls}) == 1)
+
+
+def packed_vgemm_stage(qls, x, ln=None):
+    """launches 1 + 2 as ONE: y_i = What_i V_i (LayerNorm(x) (/) s_i), fp32 -- the operator runs in the prologue of every
+    workgroup of the dequant-GEMM while its weights are in flight; xt never exists in memory.  Bit-identical to
+    packed_v_stage + packed_gemm_stage."""
+    rows, m = x.shape[0], qls[0].outfeatures
+    x = x.contiguous()
+    ys = [torch.empty((rows, m), dtype=torch.float32, device=x.device) for _ in qls]
+    vops = [q.V.small_op(x, None, colscale=q.inv_scaleWH, ln=_ln_params(ln), out_dtype=torch.bfloat16) for q in qls]
+    ops.dequant_gemm_vop(vops, [q.qweight for q in qls], [q.scales for q in qls], None, ys, rows, m)
+    return ys
+
+
 def packed_gemm_stage(qls, xts):
     """launch 2: y_i = What_i xt_i (grouped fused dequant-GEMM, fp32)."""
     rows, m = xts[0].shape[0], qls[0].outfeatures

@@ -330,3 +330,32 @@ def test_device_rng_sampler_gives_special_orthogonal_factors():
         assert not torch.equal(a, b)
     finally:
         M.DEVICE_RNG = False
+
+
+@pytest.mark.parametrize("rows,ngroups,with_ln,m", [(1, 3, True, 2048), (1, 1, False, 2048), (3, 1, True, 8192), (8, 2, False, 2048)])
+def test_operator_fused_dequant_gemm_is_bit_identical_to_two_launches(Q, rows, ngroups, with_ln, m):
+    """quipamd_dequant_gemm_vop: V (LayerNorm(x) (/) s) in the prologue of the 2-bit dequant-GEMM (d = 2048) ==
+    packed_v_stage followed by packed_gemm_stage."""
+    from quip_amd import ops, method
+    torch.manual_seed(5)
+    np.random.seed(5)
+    d = 2048
+    qls = []
+    for _ in range(ngroups):
+        W = (0.02 * torch.randn(m, d)).half().to(DEV)
+        s = ops.qfnb_scale(W)
+        _, codes = ops.quantize(W, 'b', s, None, 3, want_codes=True)
+        ql = Q.QuantLinear(d, m, bits=2, qfn='b').to(DEV)
+        ql.pack(codes, s, None, bias=torch.randn(m).to(DEV), scaleWH=(0.5 + torch.rand(d)).to(DEV),
+                U=method.gen_rand_ortho_butterfly_noblock(m), V=method.gen_rand_ortho_butterfly_noblock(d))
+        qls.append(ql)
+    assert Q.vgemm_fusable(qls, rows)
+    x = torch.randn(rows, d).half().to(DEV)
+    ln = torch.nn.LayerNorm(d, dtype=torch.float16).to(DEV) if with_ln else None
+    if ln is not None:
+        ln.weight.data.normal_(1, 0.1)
+        ln.bias.data.normal_(0, 0.1)
+    want = Q.packed_gemm_stage(qls, Q.packed_v_stage(qls, x, ln=ln))
+    got = Q.packed_vgemm_stage(qls, x, ln=ln)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
