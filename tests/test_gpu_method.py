@@ -359,3 +359,24 @@ def test_operator_fused_dequant_gemm_is_bit_identical_to_two_launches(Q, rows, n
     got = Q.packed_vgemm_stage(qls, x, ln=ln)
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("argv", [["--quant", "ldlq", "--incoh", "--pack"], ["--quant", "gptq", "--wbits", "4"],
+                                  ["--quant", "ldlqRG", "--npasses", "1", "--incoh"], ["--quant", "ldlq", "--wbits", "3", "--incoh", "--pack"]])
+def test_reference_driver_sequence_end_to_end(argv, monkeypatch):
+    """scripts/quantize_opt.py: the call sequence of the reference's opt_sequential (opt.py:29-190: hooks -> add_batch ->
+    post_batch -> preproc -> fasterquant -> free, layer by layer) on a small random-init Hugging Face OPT model, then the
+    packed layers swapped in."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "quantize_opt.py")
+    spec = importlib.util.spec_from_file_location("quantize_opt", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["quantize_opt.py", "--hidden", "256", "--ffn", "1024", "--heads", "4", "--layers", "2",
+                                      "--nsamples", "4", "--seqlen", "64", "--vocab", "512"] + argv)
+    out = mod.main()
+    assert out["linears"] == 12 and np.isfinite(out["mean_proxy_error"]) and np.isfinite(out["logits_rel_change_fake_quant"])
+    if "--pack" in argv:
+        assert out["packed_layers"] == 12 and out["logits_rel_diff_packed_vs_fake_quant"] < 2e-2
