@@ -27,6 +27,15 @@ from quip_amd.modelutils import find_layers  # noqa: E402
 
 
 def build_model(args, dev):
+    if args.arch == "llama":                                       # llama.py:87-156 drives the same sequence over model.model.layers
+        from transformers import LlamaConfig, LlamaForCausalLM
+        cfg = LlamaConfig(hidden_size=args.hidden, intermediate_size=args.ffn, num_hidden_layers=args.layers,
+                          num_attention_heads=args.heads, num_key_value_heads=args.heads, vocab_size=args.vocab,
+                          max_position_embeddings=args.seqlen)
+        torch.manual_seed(0)
+        model = LlamaForCausalLM(cfg).half().to(dev).eval()
+        model.seqlen = args.seqlen
+        return model
     from transformers import OPTConfig, OPTForCausalLM
     cfg = OPTConfig(hidden_size=args.hidden, ffn_dim=args.ffn, num_hidden_layers=args.layers, num_attention_heads=args.heads,
                     word_embed_proj_dim=args.hidden, vocab_size=args.vocab, max_position_embeddings=args.seqlen)
@@ -40,7 +49,8 @@ def build_model(args, dev):
 def opt_sequential(model, batches, dev, args):
     """opt.py:29-190 with the quantisation classes of quip_amd; everything stays on the GPU."""
     model.config.use_cache = False
-    layers = model.model.decoder.layers
+    layers = model.model.layers if args.arch == 'llama' else model.model.decoder.layers
+    prefix = 'model.layers' if args.arch == 'llama' else 'model.decoder.layers'
     dtype = next(iter(model.parameters())).dtype
     inps = torch.zeros((args.nsamples, model.seqlen, model.config.hidden_size), dtype=dtype, device=dev)
     cache = {'i': 0, 'kwargs': None}
@@ -106,7 +116,7 @@ def opt_sequential(model, batches, dev, args):
             report.append({"layer": i, "name": name, "error": float(m.error), "Hmag": float(m.Hmag),
                            "seconds": round(time.perf_counter() - t0, 4)})
             if args.pack and hasattr(m, 'codes') and args.quant != 'gptq':
-                packed[f"model.decoder.layers.{i}.{name}"] = quant.QuantLinear.from_method(m, subset[name])
+                packed[f"{prefix}.{i}.{name}"] = quant.QuantLinear.from_method(m, subset[name])
             m.free()
         for j in range(args.nsamples):                            # opt.py:172-174: next layer sees the quantised block
             outs[j] = run_layer(layer, j)
@@ -116,6 +126,7 @@ def opt_sequential(model, batches, dev, args):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--arch", default="opt", choices=["opt", "llama"])
     ap.add_argument("--hidden", type=int, default=768)
     ap.add_argument("--ffn", type=int, default=3072)
     ap.add_argument("--heads", type=int, default=12)

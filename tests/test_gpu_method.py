@@ -362,6 +362,7 @@ def test_operator_fused_dequant_gemm_is_bit_identical_to_two_launches(Q, rows, n
 
 
 @pytest.mark.parametrize("argv", [["--quant", "ldlq", "--incoh", "--pack"], ["--quant", "gptq", "--wbits", "4"],
+                                  ["--arch", "llama", "--quant", "ldlq", "--incoh", "--pack"],
                                   ["--quant", "ldlqRG", "--npasses", "1", "--incoh"], ["--quant", "ldlq", "--wbits", "3", "--incoh", "--pack"]])
 def test_reference_driver_sequence_end_to_end(argv, monkeypatch):
     """scripts/quantize_opt.py: the call sequence of the reference's opt_sequential (opt.py:29-190: hooks -> add_batch ->
@@ -377,6 +378,7 @@ def test_reference_driver_sequence_end_to_end(argv, monkeypatch):
     monkeypatch.setattr(sys, "argv", ["quantize_opt.py", "--hidden", "256", "--ffn", "1024", "--heads", "4", "--layers", "2",
                                       "--nsamples", "4", "--seqlen", "64", "--vocab", "512"] + argv)
     out = mod.main()
-    assert out["linears"] == 12 and np.isfinite(out["mean_proxy_error"]) and np.isfinite(out["logits_rel_change_fake_quant"])
+    nlin = 14 if "llama" in argv else 12
+    assert out["linears"] == nlin and np.isfinite(out["mean_proxy_error"]) and np.isfinite(out["logits_rel_change_fake_quant"])
     if "--pack" in argv:
-        assert out["packed_layers"] == 12 and out["logits_rel_diff_packed_vs_fake_quant"] < 2e-2
+        assert out["packed_layers"] == nlin and out["logits_rel_diff_packed_vs_fake_quant"] < 2e-2
