@@ -35,7 +35,6 @@ __global__ __launch_bounds__(1024) void ortho_small_kernel(SmallBatch Bt)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t row = blockIdx.x;
 
     // ---- load: factors (coalesced float4) and the row (coalesced, scattered into the image) ------------------------
     for (int i = tid; i < p * p / 4; i += 1024) {
@@ -52,6 +51,8 @@ __global__ __launch_bounds__(1024) void ortho_small_kernel(SmallBatch Bt)
     // k = 4v .. 4v+3; n <= 16384 -> at most 4 groups per thread.  q is a power of two: pos -> (a, b) by shift / mask.
     constexpr int MAXV = 4;
     const int qsh = __builtin_ctz(q), qmask = q - 1, n4 = n >> 2;
+    // a workgroup walks rows blockIdx.x, + gridDim.x, ... : the factors above are loaded once per workgroup, not per row
+    for (int64_t row = blockIdx.x; row < Bt.rows; row += gridDim.x) {
     float4 xv[MAXV];
 #pragma unroll
     for (int u = 0; u < MAXV; ++u) {
@@ -173,6 +174,8 @@ __global__ __launch_bounds__(1024) void ortho_small_kernel(SmallBatch Bt)
             store4<TO>(A.out, row * A.ldo + 4 * v4, v);
         }
     }
+    __syncthreads();                                             // the image is rewritten by the next row
+    }
 }
 
 // NPASS = 2 ("chain"): op[0] is applied to the row first (x from memory, bias / residual / relu epilogue, result stored
@@ -189,18 +192,31 @@ __global__ __launch_bounds__(1024) void ortho_small_split_kernel(SmallBatch Bt)
 {
     constexpr int MAXV = 4;
     float4 xv[MAXV];
-    for (int pass = 0; pass < NPASS; ++pass) {
-    const SmallArgs A = NPASS == 1 ? Bt.op[blockIdx.y] : (pass == 0 ? Bt.op[0] : Bt.op[1 + blockIdx.y]);
     extern __shared__ __attribute__((aligned(16))) char smemc[];
-    const int64_t row = blockIdx.x;
-    small_split_pass<TI, CP, CQ>(A, row, pass == 0, xv, smemc, [&](int u, int v4, const float4 &v) {
-        if (pass == NPASS - 1) store4<TO>(A.out, row * A.ldo + 4 * v4, v);
-        else {
-            if (A.out && blockIdx.y == 0) store4_any(A.out, A.out_dtype, row * A.ldo + 4 * v4, v);
-            xv[u] = round4_any(A.out_dtype, v);
+    if constexpr (NPASS == 1) {
+        // many rows (weight side, prefill): a workgroup walks rows blockIdx.x, + gridDim.x, ... with the factor images
+        // loaded once -- per row the factors (24 - 80 KiB) were most of the traffic
+        const SmallArgs A = Bt.op[blockIdx.y];
+        bool first = true;
+        for (int64_t row = blockIdx.x; row < Bt.rows; row += gridDim.x) {
+            if (!first) __syncthreads();                             // the previous row's final image is still being read
+            small_split_pass<TI, CP, CQ>(A, row, true, xv, smemc,
+                                         [&](int, int v4, const float4 &v) { store4<TO>(A.out, row * A.ldo + 4 * v4, v); }, first);
+            first = false;
         }
-    });
-    if (pass < NPASS - 1) __syncthreads();                       // ZF is read above, rewritten by the next pass
+    } else {
+        const int64_t row = blockIdx.x;
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const SmallArgs A = pass == 0 ? Bt.op[0] : Bt.op[1 + blockIdx.y];
+            small_split_pass<TI, CP, CQ>(A, row, pass == 0, xv, smemc, [&](int u, int v4, const float4 &v) {
+                if (pass == NPASS - 1) store4<TO>(A.out, row * A.ldo + 4 * v4, v);
+                else {
+                    if (A.out && blockIdx.y == 0) store4_any(A.out, A.out_dtype, row * A.ldo + 4 * v4, v);
+                    xv[u] = round4_any(A.out_dtype, v);
+                }
+            });
+            if (pass < NPASS - 1) __syncthreads();                   // ZF is read above, rewritten by the next pass
+        }
     }
 }
 
@@ -214,7 +230,9 @@ int launch_split_pq(const SmallBatch &B, int ny, int64_t rows, hipStream_t s, co
     if (lds > 64 * 1024)
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "%s: cannot raise dynamic LDS to %zu", who, lds);
-    kern<<<dim3((unsigned)rows, (unsigned)ny), 1024, lds, s>>>(B);
+    // NPASS == 1: workgroups walk the rows (factors loaded once each); a chain keeps one workgroup per row
+    const unsigned gx = (unsigned)(NPASS == 1 && rows > 1024 ? 1024 : rows);
+    kern<<<dim3(gx, (unsigned)ny), 1024, lds, s>>>(B);
     QA_LAUNCH_CHECK(who);
     return QUIPAMD_OK;
 }
@@ -246,7 +264,7 @@ int launch_small(const SmallBatch &B, int nops, int64_t rows, hipStream_t s)
     if (lds > 64 * 1024)
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "ortho_apply_small: cannot raise dynamic LDS to %zu", lds);
-    kern<<<dim3((unsigned)rows, (unsigned)nops), 1024, lds, s>>>(B);
+    kern<<<dim3((unsigned)(rows > 1024 ? 1024 : rows), (unsigned)nops), 1024, lds, s>>>(B);
     QA_LAUNCH_CHECK("quipamd_ortho_apply_small");
     return QUIPAMD_OK;
 }
@@ -262,7 +280,7 @@ extern "C" int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int no
     QA_REQUIRE(small_lds(p, q) <= 160 * 1024, QUIPAMD_ERR_SHAPE, "ortho_apply_small: factors + row need %zu B of LDS (> 160 KiB)", small_lds(p, q));
     QA_REQUIRE((int64_t)p * q <= 16 * 1024, QUIPAMD_ERR_SHAPE, "ortho_apply_small: n = %d > 16384", p * q);
     QA_REQUIRE((q & (q - 1)) == 0, QUIPAMD_ERR_SHAPE, "ortho_apply_small: q = %d must be a power of two; use quipamd_ortho_apply_rows", q);
-    QA_REQUIRE(rows <= 65535, QUIPAMD_ERR_SHAPE, "ortho_apply_small: too many rows");
+    QA_REQUIRE(rows >= 0 && rows < ((int64_t)1 << 31), QUIPAMD_ERR_SHAPE, "ortho_apply_small: bad row count");
     const bool split = ops[0].M0_hi != nullptr;
     if (split) {
         QA_REQUIRE(p % 32 == 0 && q % 32 == 0, QUIPAMD_ERR_SHAPE, "ortho_apply_small: split-bf16 factors need p, q multiples of 32");
@@ -283,6 +301,7 @@ extern "C" int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int no
         B.op[i] = o;
     }
     for (int i = nops; i < QUIPAMD_SMALL_MAX_OPS; ++i) B.op[i] = ops[0];
+    B.rows = rows;
     if (rows == 0) return QUIPAMD_OK;
     hipStream_t s = (hipStream_t)stream;
 #define QA_SMALL_CASE(XI, TI, XO, TO) if (x_dtype == XI && out_dtype == XO) return launch_small<TI, TO>(B, nops, rows, s)
@@ -326,6 +345,7 @@ extern "C" int quipamd_ortho_apply_small_chain(const quipamd_small_op *first, co
         B.op[1 + i] = o;
     }
     for (int i = 1 + nsecond; i < QUIPAMD_SMALL_MAX_OPS; ++i) B.op[i] = second[0];
+    B.rows = rows;
     if (rows == 0) return QUIPAMD_OK;
     hipStream_t s = (hipStream_t)stream;
 #define QA_CHAIN_CASE(XI, TI, XO, TO) \

@@ -9,6 +9,7 @@ typedef quipamd_small_op SmallArgs;        // include/quip_amd.h
 
 struct SmallBatch {
     SmallArgs op[QUIPAMD_SMALL_MAX_OPS];        // blockIdx.y selects the op; all ops share p, q and the dtypes
+    int64_t rows;                               // rows per op (workgroups stride over them)
 };
 
 __device__ __forceinline__ float load_any(const void *p, int dt, int64_t i)
@@ -108,8 +109,10 @@ inline size_t small_split_lds(int p, int q)
 //   [x from memory | xv handed over] -> [LayerNorm] -> colscale -> scatter -> mix, mix -> gather + bias + residual + relu
 // and every group of 4 consecutive results is passed to epi(u, v4, value) (element index 4 * v4; u = register slot).
 // smemc: small_split_lds(p, q) bytes.  All threads must call it; it ends after the epilogue WITHOUT a barrier.
+// load_factors = false: the factor images of A are still in LDS from the previous call (same A, next row).
 template <class TI, int CP, int CQ, class Epi>
-__device__ __forceinline__ void small_split_pass(const SmallArgs &A, int64_t row, bool load_x, float4 (&xv)[4], char *smemc, Epi &&epi)
+__device__ __forceinline__ void small_split_pass(const SmallArgs &A, int64_t row, bool load_x, float4 (&xv)[4], char *smemc, Epi &&epi,
+                                                 bool load_factors = true)
 {
     constexpr int MAXV = 4;
     const int p = CP ? CP : A.p, q = CQ ? CQ : A.q, n = p * q;
@@ -125,15 +128,17 @@ __device__ __forceinline__ void small_split_pass(const SmallArgs &A, int64_t row
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- factors: bf16 hi / lo, 8 elements (16 B) per thread step, into padded rows --------------------------------
-    for (int i = tid; i < p * p / 8; i += 1024) {
-        const int rr = i / (p / 8), c8 = i - rr * (p / 8);
-        *reinterpret_cast<uint4 *>(F0h + rr * P8 + 8 * c8) = reinterpret_cast<const uint4 *>(A.M0_hi)[i];
-        *reinterpret_cast<uint4 *>(F0l + rr * P8 + 8 * c8) = reinterpret_cast<const uint4 *>(A.M0_lo)[i];
-    }
-    for (int i = tid; i < q * q / 8; i += 1024) {
-        const int rr = i / (q / 8), c8 = i - rr * (q / 8);
-        *reinterpret_cast<uint4 *>(F1h + rr * Q8 + 8 * c8) = reinterpret_cast<const uint4 *>(A.M1_hi)[i];
-        *reinterpret_cast<uint4 *>(F1l + rr * Q8 + 8 * c8) = reinterpret_cast<const uint4 *>(A.M1_lo)[i];
+    if (load_factors) {
+        for (int i = tid; i < p * p / 8; i += 1024) {
+            const int rr = i / (p / 8), c8 = i - rr * (p / 8);
+            *reinterpret_cast<uint4 *>(F0h + rr * P8 + 8 * c8) = reinterpret_cast<const uint4 *>(A.M0_hi)[i];
+            *reinterpret_cast<uint4 *>(F0l + rr * P8 + 8 * c8) = reinterpret_cast<const uint4 *>(A.M0_lo)[i];
+        }
+        for (int i = tid; i < q * q / 8; i += 1024) {
+            const int rr = i / (q / 8), c8 = i - rr * (q / 8);
+            *reinterpret_cast<uint4 *>(F1h + rr * Q8 + 8 * c8) = reinterpret_cast<const uint4 *>(A.M1_hi)[i];
+            *reinterpret_cast<uint4 *>(F1l + rr * Q8 + 8 * c8) = reinterpret_cast<const uint4 *>(A.M1_lo)[i];
+        }
     }
     // ---- row: 4 consecutive elements per step, optional LayerNorm, scale, split, scatter --------------------------------
     const int qsh = __builtin_ctz(q), qmask = q - 1, n4 = n >> 2;

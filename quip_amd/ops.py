@@ -270,8 +270,17 @@ class OrthoOp:
         rows = x.shape[0]
         out = torch.empty((rows, self.n), dtype=out_dtype or x.dtype, device=x.device)
         cs = _f32vec(colscale, x.device)
-        if self.small_ok and rows <= self.SMALL_ROWS and x.stride(0) % 4 == 0:
-            ortho_small_ops([self.small_op(x, out, transpose=transpose, colscale=cs, bias=_f32vec(bias, x.device))], rows)
+        if self.small_ok and x.stride(0) % 4 == 0:
+            # Kronecker operator: the single-launch kernel for any number of rows (its workgroups walk the rows with the
+            # factors resident in LDS).  Few rows (decode) and 16-bit activations (prefill) take the split-bf16 arithmetic
+            # (~1e-5); many fp32 rows are the weight side (W, H in preproc / postproc) and stay on the exact fp32 MFMA.
+            split = self.use_split
+            if rows > self.SMALL_ROWS and x.dtype == torch.float32:
+                self.use_split = False
+            try:
+                ortho_small_ops([self.small_op(x, out, transpose=transpose, colscale=cs, bias=_f32vec(bias, x.device))], rows)
+            finally:
+                self.use_split = split
             return out
         ws = torch.empty((16 * ((rows + 15) // 16), self.n), dtype=torch.float32, device=x.device)
         f1, f2 = self._stage_frags(bool(transpose))
