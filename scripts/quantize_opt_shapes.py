@@ -45,7 +45,7 @@ def llama(args, dev):
             b.H = Hs[d].clone()
             b.nsamples = 1
             b.post_batch()
-            b.preproc(preproc_gptqH=True, percdamp=0.01, preproc_rescale=True, preproc_proj=True, preproc_proj_extra=0)
+            b.preproc(preproc_gptqH=True, percdamp=0.01, preproc_rescale=True, preproc_proj=True, preproc_proj_extra=args.proj_extra)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             b.fasterquant(lazy_batch=False)
@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--nsamples", type=int, default=128, help="calibration samples per Linear for the Hessian leg (opt.py default)")
     ap.add_argument("--seqlen", type=int, default=2048)
     ap.add_argument("--no-hessian", action="store_true")
+    ap.add_argument("--proj-extra", type=int, default=0, choices=[0, 1, 2],
+                    help="preproc_proj_extra: 0 = blocked butterfly (what opt.py --incoh_processing effectively runs, it sets the "
+                         "unused `proj_extra`), 1 = Kronecker (the paper's operator; single-launch row-walking K3)")
     ap.add_argument("--fast-hessian", action="store_true", help="K7's opt-in 16-bit-MFMA mode (method.HESSIAN_FAST)")
     ap.add_argument("--device-rng", action="store_true", help="opt-in method.DEVICE_RNG: operator sampling without the host RNG")
     ap.add_argument("--model", default="opt1p3b", choices=["opt1p3b", "llama7b"],
@@ -132,7 +135,7 @@ def main():
             b.H = Hs[d].clone()
             b.nsamples = 1
             b.post_batch()
-            b.preproc(preproc_gptqH=True, percdamp=0.01, preproc_rescale=True, preproc_proj=True, preproc_proj_extra=0)
+            b.preproc(preproc_gptqH=True, percdamp=0.01, preproc_rescale=True, preproc_proj=True, preproc_proj_extra=args.proj_extra)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             b.fasterquant(lazy_batch=False)
