@@ -322,10 +322,53 @@ def gen_counter():
          "(round_ldl_gptqequiv vs nearest on the constructed (W,H))", **arrs)
 
 
+# ---------------------------------------------------------------- I. greedy passes, LDLQ-RG, GPTQ
+def gen_rounders():
+    import gptq as ref_gptq
+    arrs = {}
+    d, m = 192, 40
+    H = correlated_H(d, 3)
+    arrs["H"] = H
+    g = torch.Generator().manual_seed(12)
+    W = (torch.rand(m, d, generator=g) * 3.6 - 0.3).clamp(0, 3).float()
+    arrs["W2"] = W
+    arrs["ldl2_greedy3"] = ref_vb.round_ldl(W, H, 2, n_greedy_passes=3)                   # vector_balance.py:155-199
+    arrs["ldlblock2_greedy3"] = ref_vb.round_ldl_block(W, H, 2, n_greedy_passes=3)        # :218-291
+    arrs["ldlqRG2_greedy2"] = ref_vb.round_sorted_ldlqRG(W, H, 2, n_greedy_passes=2)      # :139-153
+    # GPTQ.fasterquant (gptq.py:19-115) on CPU: its only CUDA call is a synchronize
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(d, m, bias=False)
+    lin.weight.data = (0.02 * torch.randn(m, d)).float()
+    arrs["gptq_W0"] = lin.weight.data.clone()
+    meth = ref_gptq.GPTQ(lin)
+    meth.quantizer = ref_quant.Quantizer()
+    meth.quantizer.configure(4, perchannel=True, sym=False, qfn='a', mse=False)
+    meth.H = H.clone()
+    meth.preproc(preproc_gptqH=True, percdamp=.01)
+    arrs["gptq_Hdamped"] = meth.H.clone()
+    sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        meth.fasterquant(copy_H=True)
+    finally:
+        torch.cuda.synchronize = sync
+    arrs["gptq_w4_Q"] = lin.weight.data.clone()
+    arrs["gptq_w4_scale"] = meth.quantizer.scale.clone()
+    arrs["gptq_w4_zero"] = meth.quantizer.zero.clone()
+    arrs["gptq_w4_error"] = meth.error
+    save("rounders", "vector_balance.py:155-199 / 218-291 round_ldl(_block) with n_greedy_passes=3; :139-153 "
+         "round_sorted_ldlqRG with 2 passes; gptq.py:19-115 GPTQ.fasterquant (w4, qfn a, groupsize -1, preproc_gptqH) run on CPU "
+         "with torch.cuda.synchronize stubbed.  H = correlated fixture, d=192, m=40", **arrs)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rounders":
+        gen_rounders()
+        sys.exit(0)
     gen_grids()
     gen_pack()
     gen_butterfly()
     gen_ldlq()
     gen_method()
     gen_counter()
+    gen_rounders()

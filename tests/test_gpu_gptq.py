@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import load_golden
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -94,3 +96,22 @@ def test_full_size_is_one_launch_fast():
     # residuals stay within half a grid step unless clamped
     inside = (codes > 0) & (codes < 3)
     assert float(err[inside].abs().max()) <= 0.5 + 1e-5
+
+
+def test_gptq_class_against_reference_golden():
+    """GPTQ.fasterquant (kernel path) against the reference's own run (tests/golden/rounders.npz: gptq.py:19-115 on CPU)."""
+    from quip_amd import gptq as G, quant as Q
+    g = load_golden("rounders")
+    W0 = torch.from_numpy(g["gptq_W0"].copy())
+    m, d = W0.shape
+    lin = torch.nn.Linear(d, m, bias=False).to(DEV)
+    lin.weight.data = W0.to(DEV)
+    meth = G.GPTQ(lin)
+    meth.quantizer = Q.Quantizer()
+    meth.quantizer.configure(4, perchannel=True, sym=False, qfn='a', mse=False)
+    meth.H = torch.from_numpy(g["H"].copy()).to(DEV)
+    meth.preproc(preproc_gptqH=True, percdamp=.01)
+    meth.fasterquant()
+    got = lin.weight.data.float().cpu().numpy()
+    assert np.mean(got != g["gptq_w4_Q"]) <= 5e-3
+    assert abs(meth.error - float(g["gptq_w4_error"])) <= 5e-3 * float(g["gptq_w4_error"])

@@ -351,3 +351,18 @@ def test_round_ldl_gptqequiv_matches_reference_golden(ops, bits):
         pytest.skip("K4 needs d % 16 == 0")
     got = VB.round_ldl_gptqequiv(W, H, bits).cpu().numpy()
     assert np.mean(got != g[f"gptqequiv{bits}"]) <= 2e-3
+
+
+def test_greedy_passes_and_ldlqRG_against_reference_golden(ops):
+    """round_ldl / round_ldl_block with 3 greedy passes and round_sorted_ldlqRG with 2, against the reference's own outputs
+    (tests/golden/rounders.npz, d = 192: one full and one ragged 128-column block)."""
+    from quip_amd import vector_balance as VB
+    g = load_golden("rounders")
+    W = torch.from_numpy(g["W2"].copy()).to(DEV)
+    H = torch.from_numpy(g["H"].copy()).to(DEV)
+    got = VB.round_ldl(W, H, 2, n_greedy_passes=3).cpu().numpy()
+    assert np.mean(got != g["ldl2_greedy3"]) <= 5e-3
+    got = VB.round_ldl_block(W, H, 2, n_greedy_passes=3).cpu().numpy()
+    assert np.mean(got != g["ldlblock2_greedy3"]) <= 5e-3
+    got = VB.round_sorted_ldlqRG(W, H, 2, n_greedy_passes=2).cpu().numpy()
+    assert np.mean(got != g["ldlqRG2_greedy2"]) <= 1e-2

@@ -259,3 +259,34 @@ def test_balance_fasterquant_end_to_end(case, bits, qfn):
     assert abs(err - float(g[case + "_error"])) <= 2e-2 * abs(float(g[case + "_error"]))
     if case == "incoh_w2":
         np.testing.assert_allclose(Hpost, g[case + "_Hpost"], atol=2e-5 * np.abs(g[case + "_Hpost"]).max())
+
+
+# ----------------------------------------------------------------------------- greedy passes, LDLQ-RG, GPTQ
+def test_greedy_passes_match_reference():
+    """oracle greedy_passes (vector_balance.py:182-196) after oracle round_ldl == the reference's round_ldl / round_ldl_block
+    with n_greedy_passes = 3 (tests/golden/rounders.npz)."""
+    g = load_golden("rounders")
+    start = O.round_ldl(g["W2"], g["H"], 2)
+    got = O.greedy_passes(g["W2"], start, g["H"], 2, 3)
+    assert _mismatch(got, g["ldl2_greedy3"]) <= 2e-3
+    assert _mismatch(got, g["ldlblock2_greedy3"]) <= 2e-3
+
+
+def test_ldlqRG_matches_reference():
+    g = load_golden("rounders")
+    H, W = g["H"], g["W2"]
+    p = np.argsort(np.diag(H), kind="stable")                   # vector_balance.py:147 torch.argsort
+    Hp, Wp = H[p][:, p], W[:, p]
+    got = np.zeros_like(W)
+    got[:, p] = O.greedy_passes(Wp, O.round_ldl(Wp, Hp, 2), Hp, 2, 2)
+    assert _mismatch(got, g["ldlqRG2_greedy2"]) <= 5e-3
+
+
+def test_gptq_round_matches_reference():
+    """oracle gptq_round (gptq.py:51-93) against the reference's GPTQ.fasterquant run on CPU (rounders.npz)."""
+    g = load_golden("rounders")
+    Q, codes = O.gptq_round(g["gptq_W0"], g["gptq_Hdamped"], g["gptq_w4_scale"], g["gptq_w4_zero"], 15)
+    assert np.mean(Q != g["gptq_w4_Q"]) <= 2e-3
+    dw = (Q - g["gptq_W0"]).astype(np.float64)
+    err = float(((dw @ g["gptq_Hdamped"].astype(np.float64)) * dw).sum())
+    assert abs(err - float(g["gptq_w4_error"])) <= 1e-3 * float(g["gptq_w4_error"])
