@@ -12,7 +12,10 @@
 //          of 64 x 3.5 us.
 //   panel  U_kk^T X = A_k,rest by forward substitution, one thread per column (64 registers), the entries of U_kk
 //          arrive as wave-uniform scalar loads; exact substitution, no explicit inverse.
-//   syrk   A_ij -= sum_t X[t][i] X[t][j] for the upper tiles i <= j of the trailing matrix on the fp32 matrix pipe
+//   syrk   (panels are factored in PAIRS: a 64-row strip update lets the second panel of a pair be factored, then one
+//          rank-128 update covers everything behind the pair -- the rank-64 form re-read and re-wrote the trailing
+//          matrix every 64 columns and was HBM-bound at d >= 4096)
+//          A_ij -= sum_t X[t][i] X[t][j] for the upper tiles i <= j of the trailing matrix on the fp32 matrix pipe
 //          (v_mfma_f32_16x16x4_f32 is an exact fp32 fma chain): both operands are "row = t, 16 consecutive columns"
 //          fragments of the same row panel, so the structure is K7's (hessian.hip) with fp32 in place of fp64 and
 //          C -= in place of H +=; one 64-row LDS stage, 128/64/32-column tiles by how many tiles there are.
@@ -165,17 +168,21 @@ __device__ __forceinline__ void tri_tile(int t, int &I, int &J)     // t = J (J 
     I = t - J * (J + 1) / 2;
 }
 
+// prow0: first row of the panel(s) the update is made of; nk: 64-row panels (1 or 2) accumulated before the single
+// read-modify-write of the tile (rank-128 trailing updates halve the HBM traffic the rank-64 form was bound by);
+// base: first column / row of the region updated; strip: only the first 64-row tile row of it (the rows the second
+// panel of a pair needs before it can be factored).
 template <int WT>
-__global__ __launch_bounds__(256, 2) void chol_syrk_kernel(float *A, int64_t d, int64_t k0)
+__global__ __launch_bounds__(256, 2) void chol_syrk_kernel(float *A, int64_t d, int64_t prow0, int nk, int64_t base, int strip)
 {
     constexpr int BN = 32 * WT, LDW = BN + 16, EPT = BN / 16;       // EPT floats per thread per token row (16 threads/row)
     extern __shared__ __attribute__((aligned(16))) float cs[];     // [2 sides][NB][LDW]
     int I, J;
-    tri_tile(blockIdx.x, I, J);
+    if (strip) { I = 0; J = blockIdx.x; }
+    else tri_tile(blockIdx.x, I, J);
     const bool diag = I == J;
-    const int64_t base = k0 + NB;                                   // first trailing column
     const int64_t i0 = base + (int64_t)I * BN, j0 = base + (int64_t)J * BN;
-    const float *P = A + k0 * d;                                    // the row panel X of this step: P[t][c]
+    const float *P = A + prow0 * d;                                 // the row panel X of the current stage: P[t][c]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
@@ -210,10 +217,6 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(float *A, int64_t d, 
             }
         }
     };
-    stage(0, i0);
-    if (!diag) stage(1, j0);
-    __syncthreads();
-
     f32x4_t acc[WT][WT];
 #pragma unroll
     for (int x = 0; x < WT; ++x)
@@ -221,6 +224,14 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(float *A, int64_t d, 
         for (int y = 0; y < WT; ++y) acc[x][y] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const float *As = cs + wi * (WT * 16) + (lane & 15);
     const float *Bs = cs + (diag ? 0 : 1) * NB * LDW + wj * (WT * 16) + (lane & 15);
+    for (int sg = 0; sg < nk; ++sg) {
+    if (sg) {
+        __syncthreads();                                            // every read of the previous panel's stage retired
+        P += (int64_t)NB * d;
+    }
+    stage(0, i0);
+    if (!diag) stage(1, j0);
+    __syncthreads();
 #pragma unroll 4
     for (int ks = 0; ks < NB / 4; ++ks) {
         const int row = ks * 4 + (lane >> 4);
@@ -233,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(float *A, int64_t d, 
         for (int x = 0; x < WT; ++x)
 #pragma unroll
             for (int y = 0; y < WT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b[y], acc[x][y], 0, 0, 0);
+    }
     }
     // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
@@ -247,11 +259,11 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(float *A, int64_t d, 
             }
 }
 
-template <int WT> int launch_syrk(float *A, int64_t d, int64_t k0, hipStream_t s)
+template <int WT> int launch_syrk(float *A, int64_t d, int64_t prow0, int nk, int64_t base, bool strip, hipStream_t s)
 {
     constexpr int BN = 32 * WT, LDW = BN + 16;
     const size_t lds = (size_t)2 * NB * LDW * sizeof(float);
-    const int64_t rem = d - k0 - NB, T = (rem + BN - 1) / BN;
+    const int64_t rem = d - base, T = (rem + BN - 1) / BN;
     auto kern = chol_syrk_kernel<WT>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -259,8 +271,18 @@ template <int WT> int launch_syrk(float *A, int64_t d, int64_t k0, hipStream_t s
             return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: cannot reserve %zu B of LDS", lds);
         attr_done = true;
     }
-    kern<<<(unsigned)(T * (T + 1) / 2), 256, lds, s>>>(A, d, k0);
+    kern<<<(unsigned)(strip ? T : T * (T + 1) / 2), 256, lds, s>>>(A, d, prow0, nk, base, strip ? 1 : 0);
     return QUIPAMD_OK;
+}
+
+// trailing update of the region starting at `base` with nk panels from row prow0: tile size by how many tiles there are
+static int trailing_update(float *A, int64_t d, int64_t prow0, int nk, int64_t base, hipStream_t s)
+{
+    const int64_t rem = d - base;
+    auto ntiles = [&](int64_t bn) { const int64_t T = (rem + bn - 1) / bn; return T * (T + 1) / 2; };
+    if (ntiles(128) >= 384) return launch_syrk<4>(A, d, prow0, nk, base, false, s);
+    if (ntiles(64) >= 384) return launch_syrk<2>(A, d, prow0, nk, base, false, s);
+    return launch_syrk<1>(A, d, prow0, nk, base, false, s);
 }
 
 // ---- finish: LT[c][j] = U[c][j] * (1 / U[c][c]) for j > c, else 0, in place -------------------------------------------------
@@ -285,17 +307,22 @@ extern "C" int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *in
         hipMemcpyAsync(LT, H, (size_t)d * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: copy failed");
     if (hipMemsetAsync(info, 0, sizeof(int), s) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: memset failed");
-    for (int64_t k0 = 0; k0 < d; k0 += NB) {
+    auto diag = [&](int64_t k0) {
         if (k0 + NB <= d) chol_diag_kernel<true><<<1, 64, 0, s>>>(LT, d, k0, info);
         else chol_diag_kernel<false><<<1, 64, 0, s>>>(LT, d, k0, info);
-        const int64_t rem = d - k0 - NB;
-        if (rem <= 0) break;
-        chol_panel_kernel<<<(unsigned)((rem + 255) / 256), 256, 0, s>>>(LT, d, k0);
-        auto ntiles = [&](int64_t bn) { const int64_t T = (rem + bn - 1) / bn; return T * (T + 1) / 2; };
-        int rc;
-        if (ntiles(128) >= 384) rc = launch_syrk<4>(LT, d, k0, s);
-        else if (ntiles(64) >= 384) rc = launch_syrk<2>(LT, d, k0, s);
-        else rc = launch_syrk<1>(LT, d, k0, s);
+    };
+    // two 64-row panels per trailing update: diag, panel, [64-row strip update so the second panel can be factored],
+    // diag, panel, then ONE rank-128 update of everything behind the pair
+    for (int64_t k0 = 0; k0 < d; k0 += 2 * NB) {
+        diag(k0);
+        if (d - k0 - NB <= 0) break;
+        chol_panel_kernel<<<(unsigned)((d - k0 - NB + 255) / 256), 256, 0, s>>>(LT, d, k0);
+        int rc = launch_syrk<2>(LT, d, k0, 1, k0 + NB, true, s);                  // rows k0+64 .. k0+127, all columns behind
+        if (rc != QUIPAMD_OK) return rc;
+        diag(k0 + NB);
+        if (d - k0 - 2 * NB <= 0) break;
+        chol_panel_kernel<<<(unsigned)((d - k0 - 2 * NB + 255) / 256), 256, 0, s>>>(LT, d, k0 + NB);
+        rc = trailing_update(LT, d, k0, 2, k0 + 2 * NB, s);
         if (rc != QUIPAMD_OK) return rc;
     }
     chol_finish_kernel<<<(unsigned)d, 256, 0, s>>>(LT, d);
