@@ -366,3 +366,32 @@ def test_greedy_passes_and_ldlqRG_against_reference_golden(ops):
     assert np.mean(got != g["ldlblock2_greedy3"]) <= 5e-3
     got = VB.round_sorted_ldlqRG(W, H, 2, n_greedy_passes=2).cpu().numpy()
     assert np.mean(got != g["ldlqRG2_greedy2"]) <= 1e-2
+
+
+@pytest.mark.parametrize("n,rows", [(2048, 1500), (4096, 2300), (2048, 65)])
+def test_row_walking_kronecker_apply_equals_two_stage_kernel(ops, n, rows):
+    """more rows than workgroups (grid capped at 1024): every workgroup of the single-launch kernel walks several rows with
+    its factors resident; fp32 rows take the exact fp32-MFMA variant and must equal the general two-stage kernel bit for bit;
+    16-bit rows take the split-bf16 variant (~1e-5)."""
+    from quip_amd import method
+    np.random.seed(n + rows)
+    torch.manual_seed(n + rows)
+    op = ops.OrthoOp(method.gen_rand_ortho_butterfly_noblock(n), DEV)
+    x = torch.randn(rows, n, device=DEV)
+    cs = (0.5 + torch.rand(n)).to(DEV)
+    for tr in (False, True):
+        got = op.apply_rows(x, transpose=tr, colscale=cs)
+        ok, op.small_ok = op.small_ok, False
+        try:
+            want = op.apply_rows(x, transpose=tr, colscale=cs)
+        finally:
+            op.small_ok = ok
+        assert torch.equal(got, want)
+        got16 = op.apply_rows(x.half(), transpose=tr, colscale=cs, out_dtype=torch.float32)
+        ref16 = x.half().float()
+        ok, op.small_ok = op.small_ok, False
+        try:
+            want16 = op.apply_rows(ref16, transpose=tr, colscale=cs)
+        finally:
+            op.small_ok = ok
+        assert float((got16 - want16).norm() / want16.norm()) < 5e-5
