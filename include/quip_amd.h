@@ -92,12 +92,22 @@ int quipamd_codes_to_weight(const uint8_t *codes, int qfn, const float *scale, c
  * with What dequantised on the fly from `qweight` (STREAM layout):
  *     qfn a: What = scale[r]*(q - zero[r])      (quant.py:186-191: zeros = zero*scale)
  *     qfn b: What = ((q/maxq)*2 - 1)*scale[0]   (quant.py:13-14)
- * x: [bs, d] bf16 (QUIPAMD_BF16) row-major; y: [bs, m] in y_dtype (BF16 or F32).
+ * x: [bs, d] bf16 or fp16 row-major (the reference widens x to fp32, quant.py:226-229: an fp16 model keeps its
+ *    activation bits on the fp16 MFMA pipe, bf16 is for bf16 models); y: [bs, m] in y_dtype (x's dtype or F32).
  * accumulate != 0 (F32 y only): y += result, the reference's in-place contract (quant.py:226-230);
  * bias: float[m] or NULL.  Unlike the reference (single token only, quant.py:233) any bs >= 1. */
 int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *qweight, int bits, int layout, int qfn,
                          const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
                          int accumulate, int64_t bs, int64_t m, int64_t d, void *stream);
+
+/* quipamd_dequant_gemm_cfg: the same call with the kernel chosen by the caller instead of the shape heuristic -- for
+ * benchmarks and the forced-kernel parity tests; never needed for correctness.  cfg = int32[4] {family, p1, p2, 0}
+ * (NULL or all 0 = heuristic): family 1 = round-1 kernels; 2 = "h" (bs <= 16, d <= 4096: p1 = waves, p2 = chunks per
+ * wave); 3 = "s" (bs <= 16 weight stream: p1 = row tiles per workgroup, p2 = k-split); 4 = "mb" (bs > 16: p1 = 44 | 22,
+ * the tile shape).  An unsupported combination fails with QUIPAMD_ERR_UNSUPPORTED.  Per call, thread safe. */
+int quipamd_dequant_gemm_cfg(const void *x, int x_dtype, const int32_t *qweight, int bits, int layout, int qfn,
+                             const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
+                             int accumulate, int64_t bs, int64_t m, int64_t d, const int32_t *cfg, void *stream);
 
 /* quipamd_dequant_gemm_grouped: ngroups (1..4) independent problems of IDENTICAL shape (bs, m, d, bits, qfn, dtypes) in
  * one launch -- the q / k / v projections of a decoder block.  Every pointer argument of quipamd_dequant_gemm becomes a
@@ -111,7 +121,7 @@ int quipamd_dequant_gemm_grouped(int ngroups, const void *const *x, int x_dtype,
  * waves per workgroup, k-slices over workgroups); 0 = leave that parameter to the built-in shape heuristic.
  * bt != 0 selects the multi-batch-tile kernel also for bs <= 16; `split` carries two fields, split % 100 = k-slices
  * (> 1 only takes effect under the accumulate contract: fp32 atomics) and split / 100 = chunk groups in flight per
- * workgroup (1, 2 or 4).  Process-wide, not thread-safe, never needed for correctness.  An
+ * workgroup (1, 2 or 4).  Applies to the round-1 kernels and to the CALLING THREAD only; never needed for correctness.  An
  * unsupported combination makes quipamd_dequant_gemm fail with QUIPAMD_ERR_UNSUPPORTED. */
 int quipamd_tune_dequant_gemm(int rt, int bt, int nw, int split);
 

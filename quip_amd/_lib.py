@@ -28,6 +28,8 @@ SIGNATURES = {
     "quipamd_codes_to_weight": [c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_i64, c_i64, c_vp],
     "quipamd_dequant_gemm": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
                              c_i64, c_i64, c_i64, c_vp],
+    "quipamd_dequant_gemm_cfg": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
+                                 c_i64, c_i64, c_i64, c_vp, c_vp],
     "quipamd_dequant_gemm_grouped": [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
                                      c_i64, c_i64, c_i64, c_vp],
     "quipamd_ortho_apply_small_ops": [c_vp, c_int, c_i64, c_vp],

@@ -37,93 +37,17 @@
 // Algorithmic bytes per call: m*d*bits/8 + 2*bs*d + (2|4)*bs*m.  FLOPs: 2*bs*m*d.
 #include "common.h"
 #include "dq_common.h"
+#include "k2_dispatch.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
 
-struct EpiArgs {
-    const float *scale;   // [1] (qfn b) or [m] (qfn a)
-    const float *zero;    // [m] or null
-    const float *bias;    // [m] or null
-    void *y;
-    int qfn, maxq, y_f32, accumulate;
-    float two_over_maxq;
-    int64_t bs, m;
-};
-
-// raw epilogue parameters of 4 consecutive output rows, FETCHED at kernel start (their memory latency hides
-// under the weight stream instead of extending the critical path after the reduction) and only turned into
-// coefficients in epilogue_store
-struct EpiRow {
-    float4 sc, zr, bi;
-};
-
-__device__ __forceinline__ EpiRow load_epi(const EpiArgs &e, int64_t r0)
-{
-    EpiRow c;
-    if (e.qfn == QUIPAMD_QFN_B) {
-        const float s = e.scale[0];
-        c.sc = make_float4(s, s, s, s);
-        c.zr = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-        c.sc = *reinterpret_cast<const float4 *>(e.scale + r0);
-        c.zr = *reinterpret_cast<const float4 *>(e.zero + r0);
-    }
-    c.bi = e.bias ? *reinterpret_cast<const float4 *>(e.bias + r0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    return c;
-}
-
-__device__ __forceinline__ void epilogue_store(const EpiArgs &e, const EpiRow &c, float off, const f32x4_t &acc, float xs,
-                                               int64_t b, int64_t r0)
-{
-    if (b >= e.bs) return;
-    const float sc[4] = {c.sc.x, c.sc.y, c.sc.z, c.sc.w}, zr[4] = {c.zr.x, c.zr.y, c.zr.z, c.zr.w};
-    const float bi[4] = {c.bi.x, c.bi.y, c.bi.z, c.bi.w};
-    float out[4];
-    if (e.qfn == QUIPAMD_QFN_B) {
-        const float alpha = sc[0] * e.two_over_maxq, t = (off + 0.5f * (float)e.maxq) * xs;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) out[i] = alpha * (acc[i] - t) + bi[i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) out[i] = sc[i] * (acc[i] - (off + zr[i]) * xs) + bi[i];
-    }
-    if (e.y_f32) {
-        float4 *dst = reinterpret_cast<float4 *>((float *)e.y + b * e.m + r0);
-        if (e.accumulate) {
-            const float4 old = *dst;
-            out[0] += old.x; out[1] += old.y; out[2] += old.z; out[3] += old.w;
-        }
-        *dst = make_float4(out[0], out[1], out[2], out[3]);
-    } else {
-        uint2 pk;
-        pk.x = (uint32_t)f32_to_bf16_bits(out[0]) | ((uint32_t)f32_to_bf16_bits(out[1]) << 16);
-        pk.y = (uint32_t)f32_to_bf16_bits(out[2]) | ((uint32_t)f32_to_bf16_bits(out[3]) << 16);
-        *reinterpret_cast<uint2 *>((uint16_t *)e.y + b * e.m + r0) = pk;
-    }
-}
-
-#ifdef QA_PROBE
-// per-wave phase timestamps (s_memtime), kept in registers and flushed at the end: probe[(wg*NW + wave)*8 + phase]
-__device__ unsigned long long *g_probe = nullptr;
-#define QA_STAMP_DECL unsigned long long qa_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define QA_STAMP(ph) qa_t[ph] = __builtin_readcyclecounter()
-#define QA_STAMP_FLUSH(NWAVES, WAVE)                                                                     \
-    do {                                                                                                 \
-        if (g_probe && (threadIdx.x & 63) == 0)                                                          \
-            for (int i_ = 0; i_ < 8; ++i_)                                                               \
-                g_probe[((blockIdx.x + gridDim.x * blockIdx.y) * (NWAVES) + (WAVE)) * 8 + i_] = qa_t[i_]; \
-    } while (0)
-__device__ int g_ablate = 0;   // probe-only: bit0 no x DMA, bit1 no compute, bit2 no W load, bit3 no reduce+store, bit4 no store
-#define QA_ABL(bit) (g_ablate & (bit))
-#define QA_KEEP(v) asm volatile("" ::"v"(v))
-#else
+// (the s_memtime phase probe and its ablation switches live in scripts/probe_k2.hip, not in the product kernel)
 #define QA_ABL(bit) 0
 #define QA_KEEP(v) do { } while (0)
 #define QA_STAMP_DECL do { } while (0)
 #define QA_STAMP(ph) do { } while (0)
 #define QA_STAMP_FLUSH(NWAVES, WAVE) do { } while (0)
-#endif
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -675,8 +599,11 @@ int launch_mb(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, h
     return QUIPAMD_OK;
 }
 
-// Tuning override (quipamd_tune_dequant_gemm): 0 = use the shape heuristic.
-int g_tune_rt = 0, g_tune_bt = 0, g_tune_nw = 0, g_tune_split = 0, g_tune_depth = 0;
+// Tuning override of the round-1 kernels (quipamd_tune_dequant_gemm): 0 = use the shape heuristic.  Per THREAD: the
+// library's promise is thread safety per stream, and a benchmark thread forcing a shape must not change another's calls.
+thread_local int g_tune_rt = 0, g_tune_bt = 0, g_tune_nw = 0, g_tune_split = 0, g_tune_depth = 0;
+// per-call kernel selection (quipamd_dequant_gemm_cfg): family + parameters, all 0 = heuristic
+thread_local int g_k2_cfg[4] = {0, 0, 0, 0};
 
 #define QA_K2_CASE(RT_, BT_, NW_) \
     if (rt == RT_ && bt == BT_ && nw == NW_) return launch_cfg_each<BITS, RT_, BT_, NW_>(G, ngroups, e, d, s)
@@ -797,8 +724,9 @@ static int dequant_gemm_impl(int ngroups, const void *const *x, int x_dtype, con
                              int accumulate, int64_t bs, int64_t m, int64_t d, void *stream)
 {
     QA_REQUIRE(ngroups >= 1 && ngroups <= 4, QUIPAMD_ERR_ARG, "dequant_gemm: 1..4 problems per call");
-    QA_REQUIRE(x_dtype == QUIPAMD_BF16, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: x must be bf16");
-    QA_REQUIRE(y_dtype == QUIPAMD_BF16 || y_dtype == QUIPAMD_F32, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: y must be bf16 or f32");
+    QA_REQUIRE(x_dtype == QUIPAMD_BF16 || x_dtype == QUIPAMD_F16, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: x must be bf16 or fp16");
+    QA_REQUIRE(y_dtype == x_dtype || y_dtype == QUIPAMD_F32, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: y must be f32 or x's dtype");
+    QA_REQUIRE(x_dtype == QUIPAMD_BF16 || ngroups == 1, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm_grouped: x must be bf16");
     QA_REQUIRE(!accumulate || y_dtype == QUIPAMD_F32, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: accumulate needs f32 y");
     QA_REQUIRE(layout == QUIPAMD_LAYOUT_STREAM, QUIPAMD_ERR_UNSUPPORTED,
                "dequant_gemm: qweight must be in STREAM layout (repack with quipamd_unpack/quipamd_pack)");
@@ -819,9 +747,21 @@ static int dequant_gemm_impl(int ngroups, const void *const *x, int x_dtype, con
         G.scale[gi] = scale[k]; G.zero[gi] = zero ? zero[k] : nullptr; G.bias[gi] = bias ? bias[k] : nullptr; G.y[gi] = y[k];
     }
     if (bs == 0 || m == 0) return QUIPAMD_OK;
+    const bool tuned_old = g_tune_rt || g_tune_bt || g_tune_nw || g_tune_split || g_tune_depth;
+    if (ngroups == 1 && !(tuned_old && g_k2_cfg[0] == 0)) {
+        // second-generation kernels first (dqgemm_v2.hip); they decline the shapes the kernels below serve better
+        K2Call c;
+        c.x = x[0]; c.x_dtype = x_dtype; c.qweight = qweight[0]; c.bits = bits; c.qfn = qfn; c.maxq = grid_maxq;
+        c.scale = G.scale[0]; c.zero = G.zero[0]; c.bias = G.bias[0]; c.y = y[0]; c.y_dtype = y_dtype; c.accumulate = accumulate;
+        c.bs = bs; c.m = m; c.d = d;
+        for (int i = 0; i < 4; ++i) c.cfg[i] = g_k2_cfg[i];
+        const int rc = k2v2_launch(c, stream);
+        if (rc != K2V2_NOT_TAKEN) return rc;
+    }
+    QA_REQUIRE(x_dtype == QUIPAMD_BF16, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: the round-1 kernels are bf16 only");
     EpiArgs e;
     e.scale = G.scale[0]; e.zero = G.zero[0]; e.bias = G.bias[0]; e.y = G.y[0];
-    e.qfn = qfn; e.maxq = grid_maxq; e.two_over_maxq = 2.0f / (float)e.maxq; e.y_f32 = (y_dtype == QUIPAMD_F32); e.accumulate = accumulate;
+    e.qfn = qfn; e.maxq = grid_maxq; e.two_over_maxq = 2.0f / (float)e.maxq; e.y_f32 = (y_dtype == QUIPAMD_F32); e.y_f16 = 0; e.accumulate = accumulate;
     e.bs = bs; e.m = m;
     hipStream_t s = (hipStream_t)stream;
     if (bits == 2) return launch<2>(G, ngroups, e, d, s);
@@ -835,6 +775,16 @@ extern "C" int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *q
     if (bs == 0 || m == 0) return QUIPAMD_OK;                      // empty batch: nothing to do (its pointers may be null)
     QA_REQUIRE(x && qweight && scale && y, QUIPAMD_ERR_ARG, "dequant_gemm: null pointer");
     return dequant_gemm_impl(1, &x, x_dtype, &qweight, bits, layout, qfn, &scale, &zero, &bias, &y, y_dtype, accumulate, bs, m, d, stream);
+}
+
+extern "C" int quipamd_dequant_gemm_cfg(const void *x, int x_dtype, const int32_t *qweight, int bits, int layout, int qfn,
+                                        const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
+                                        int accumulate, int64_t bs, int64_t m, int64_t d, const int32_t *cfg, void *stream)
+{
+    for (int i = 0; i < 4; ++i) g_k2_cfg[i] = cfg ? cfg[i] : 0;
+    const int rc = quipamd_dequant_gemm(x, x_dtype, qweight, bits, layout, qfn, scale, zero, bias, y, y_dtype, accumulate, bs, m, d, stream);
+    for (int i = 0; i < 4; ++i) g_k2_cfg[i] = 0;
+    return rc;
 }
 
 extern "C" int quipamd_dequant_gemm_grouped(int ngroups, const void *const *x, int x_dtype, const int32_t *const *qweight, int bits,

@@ -1,0 +1,655 @@
+// dqgemm_v2.h -- K2, second generation: three kernels that share one idea -- every byte a wave needs is REQUESTED
+// up front and consumed behind COUNTED waits, so compute follows the data as it lands instead of waiting for all of it.
+//
+//   dq_h_kernel   small layers, bs <= 16 (the 4096 x 4096 headline): one workgroup per 16-row tile, the whole of x
+//                 staged once into LDS (wave-private slabs, no barrier before compute), k-partials meet in LDS.
+//   dq_s_kernel   big layers, bs <= 16: a pure weight stream.  One row tile per wave, x slabs staged ONCE per workgroup
+//                 in an LDS ring (x ingest = weight bytes / (NW/8)), weight tiles prefetched P stages deep in registers.
+//   dq_mb_kernel  bs > 16: (WR x WB) waves, each RTw row tiles x BTw batch tiles of accumulators; x staged 64 k at a
+//                 time through a 3-deep LDS ring, every dequantised A fragment feeds BTw MFMAs, every B fragment RTw.
+//
+// hipcc (ROCm 7.2) waits vmcnt(0) in front of any ds_read it can see, and at the first use of any ordinary load result,
+// while an LDS-DMA of the same wave is pending (cdna_hip_programming.md 5: "three .s-level traps") -- which turns a
+// pipeline into "wait for everything".  dq_h_kernel (straight-line, one shot) hides its ds_reads and weight loads in
+// inline asm (5.7 form (ii)); the two streaming kernels split the roles by wave instead (loader waves own the DMA queue).
+#pragma once
+#include "dq_common.h"
+#include <type_traits>
+#include <utility>
+
+// Probe hooks: scripts/k2lab.hip defines K2_PROBE before including this file and gets s_memtime stamps / wait accounting;
+// in the library they expand to nothing.
+#ifndef K2_PROBE
+#define K2_STAMP(i) do { } while (0)
+#define K2_STAMP_FLUSH() do { } while (0)
+#define K2_ACC_DECL do { } while (0)
+#define K2_ACC(slot, stmt) stmt
+#define K2_ACC_FLUSH() do { } while (0)
+#endif
+
+namespace {
+
+// compile-time unrolled loop: f(std::integral_constant<int, 0>) ... f(<N-1>) -- asm immediates need constants
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+typedef __attribute__((address_space(3))) void lds_void2_t;
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+template <int N> __device__ __forceinline__ void wait_vm()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// the same wait, naming weight registers written by an asm load (form (ii))
+template <int N> __device__ __forceinline__ void wait_vm(u32x4 &a)
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm(u32x4 &a, u32x4 &b)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
+// 16 bytes per lane, non-temporal (a weight tile is read by exactly one wave, once)
+__device__ __forceinline__ void load_w_nt(u32x4 &dst, const u32x4 *p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void lds_read16(u32x4 &dst, uint32_t addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset is 16 bit");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void wait_lgkm(u32x4 (&f)[8])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])::"memory");
+}
+__device__ __forceinline__ void wait_lgkm(u32x4 (&f)[4])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])::"memory");
+}
+__device__ __forceinline__ void wait_lgkm(u32x4 (&f)[2])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1])::"memory");
+}
+
+struct K2Args {
+    const uint16_t *x;
+    const u32x4 *qw;
+    EpiArgs e;
+    int64_t d;
+};
+
+// =====================================================================================================================
+// dq_h_kernel: bs <= 16, d / KC <= NW * NCH chunks.  grid.x = m / (16 * RT).
+// Wave w owns chunks w, w + NW, ... (NCH of them) of the workgroup's RT row tiles: it requests the RT weight tiles and
+// DMAs the 16 x KC slab of x for each chunk into its own LDS region, all at once, then consumes chunk i behind
+// vmcnt((NCH-1-i) * ops per chunk).  RT > 1 (fewer workgroups, each ingesting all of x once for RT tiles) lost at
+// every shape tried (profiles/r02b_k2lab.log): the per-wave instruction stream, not the x traffic through the L2s, grows.
+// x slab image (16-byte units, as in round 1): DMA instruction q = 2*cb + rh moves 128-B column block cb of rows
+// 8*rh .. 8*rh+7; lane L = 8*(row&7) + slot fetches logical 16-B column slot ^ (row&7); logical (row b, column c16) sits at
+// unit 64*(2*(c16>>3) + (b>>3)) + 8*(b&7) + ((c16&7) ^ (b&7)): every ds_read_b128 group hits 16 distinct slots.
+// The weight tiles are asm loads (form (ii) of cdna_hip_programming.md 5.7): straight-line code, consumed right
+// behind the wait that names them; tests/test_k2_isa.py audits the generated code for touches in between.
+// =====================================================================================================================
+template <int BITS, class ACT, int RT, int NW, int NCH, bool HALF, bool EXACT>   // HALF: bs <= 8; EXACT: d / KC == NW * NCH
+__global__ __launch_bounds__(64 * NW) void dq_h_kernel(K2Args A)
+{
+    typedef DeqT<BITS, ACT> Q;
+    constexpr int KC = Q::KC, NT = Q::NT;
+    constexpr int ROWB = KC * 2, NCB = ROWB / 128, NI = 2 * NCB, XB = 16 * ROWB;
+    // (negative result, profiles/r02d_k2lab.log: loading half of the B fragments straight into registers, to use a second
+    //  return path beside the ~28 B/clk/CU LDS-DMA path, made the launch 0.9 us SLOWER)
+    constexpr int NDMA = HALF ? NI / 2 : NI, OPC = RT + NDMA;         // vector-memory operations per chunk
+    static_assert((NCH - 1) * OPC < 64, "vmcnt range");
+    static_assert(RT * 1024 + 64 <= NCH * XB, "a wave parks its partials in its own slab region");
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [NW][NCH] slabs; a wave parks its partials in its own
+    const EpiArgs &e = A.e;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    K2_STAMP(0);
+    const int j = lane & 15, g = lane >> 4;
+    const uint32_t nkc = (uint32_t)(A.d / KC);
+    const uint32_t rt0 = blockIdx.x * RT;
+    const uint32_t rowbytes = (uint32_t)A.d * 2u;
+    char *myreg = smem + wave * (NCH * XB);
+
+    // reducer role u = 4*r2 + q (below); the epilogue parameters of this wave's first role are requested now
+    float e_sc = 0.f, e_zr = 0.f, e_bi = 0.f;
+    if (wave < 4 * RT) {
+        const int64_t row = (int64_t)(rt0 + (wave >> 2)) * 16 + (lane & 15);
+        e_sc = e.qfn == QUIPAMD_QFN_B ? e.scale[0] : e.scale[row];
+        if (e.qfn != QUIPAMD_QFN_B) e_zr = e.zero[row];
+        if (e.bias) e_bi = e.bias[row];
+    }
+
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.x, 0, (int)(e.bs * (int64_t)rowbytes), 0x00020000);
+    const uint32_t voff_lo = (lane >> 3) * rowbytes + ((uint32_t)((lane & 7) ^ (lane >> 3)) << 4);
+    const uint32_t voff_hi = voff_lo + 8u * rowbytes;
+    const uint32_t rd_base = lds_addr(myreg) + (j >> 3) * 1024 + (j & 7) * 128;
+    const uint32_t rd0 = rd_base + (((0 + g) ^ (j & 7)) << 4);        // even MFMA steps
+    const uint32_t rd1 = rd_base + (((4 + g) ^ (j & 7)) << 4);        // odd MFMA steps
+
+    auto chunk_of = [&](int i) -> uint32_t { return i * NW + wave; };
+    // ---- request everything --------------------------------------------------------------------------------------------
+    u32x4 w[NCH][RT];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const uint32_t kc = chunk_of(i);
+        if (EXACT || kc < nkc) {                                      // wave-uniform
+#pragma unroll
+            for (int r = 0; r < RT; ++r) load_w_nt(w[i][r], A.qw + ((uint64_t)(rt0 + r) * nkc + kc) * 64 + lane);
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                if ((q & 1) && HALF) continue;                        // rows 8..15 of a slab feed batch columns never stored
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void2_t *)(myreg + i * XB + q * 1024), 16, (q & 1) ? voff_hi : voff_lo,
+                                                         kc * ROWB + (q >> 1) * 128, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) w[i][r] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+
+    K2_STAMP(1);
+    // two accumulator chains each (even / odd MFMA steps): a dependent MFMA behind other instructions costs ~60 cycles
+    // (MI355X_MICROARCH.md "one EXTRA issue slot between two MFMAs on the SAME accumulator"), an independent one 16
+    f32x4_t acc[RT][2], accx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r][0] = acc[r][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const u32x4 ones = {opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES)};
+    static_for<NCH>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const uint32_t kc = chunk_of(i);
+        if (EXACT || kc < nkc) {
+            constexpr int NWAIT = EXACT ? (NCH - 1 - i) * OPC : 0;    // ragged K: everything, then compute
+            if constexpr (RT == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[i][0]) : "n"(NWAIT) : "memory");
+            else if constexpr (RT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[i][0]), "+v"(w[i][1]) : "n"(NWAIT) : "memory");
+            else {
+                static_assert(RT == 1 || RT == 2 || RT == 4, "row tiles per wave");
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[i][0]), "+v"(w[i][1]), "+v"(w[i][2]), "+v"(w[i][RT - 1]) : "n"(NWAIT) : "memory");
+            }
+            if constexpr (i == 0) K2_STAMP(2);
+            if constexpr (i == NCH - 1) K2_STAMP(3);
+            u32x4 xf[NT];
+            static_for<NT>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                lds_read16<i * XB + (t >> 1) * 2048>(xf[t], (t & 1) ? rd1 : rd0);
+            });
+            wait_lgkm(xf);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) acc[r][t & 1] = ACT::mfma(Q::frag(w[i][r], t), xf[t], acc[r][t & 1]);
+                accx[t & 1] = ACT::mfma(ones, xf[t], accx[t & 1]);   // row sums of x on the matrix pipe: D[.][b] = sum_k x[b,k]
+            }
+        }
+    });
+    K2_STAMP(4);
+
+    // ---- meet: the NW k-partials of every tile ---------------------------------------------------------------------------
+    {
+        float *p = reinterpret_cast<float *>(myreg);                  // [RT][4][64] accumulator components, then [16] row sums
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const f32x4_t a = acc[r][0] + acc[r][1];
+            p[r * 256 + lane] = a[0]; p[r * 256 + 64 + lane] = a[1];
+            p[r * 256 + 128 + lane] = a[2]; p[r * 256 + 192 + lane] = a[3];
+        }
+        if (lane < 16) p[RT * 256 + lane] = accx[0][0] + accx[1][0];
+    }
+    K2_STAMP(5);
+    __syncthreads();
+    K2_STAMP(6);
+    // 4*RT reducer roles; role u = 4*r2 + q finishes batch rows 4q .. 4q+3 x the 16 weight rows of tile r2: lane l -> batch
+    // row b = 4q + (l>>4), weight row l&15 (16 consecutive outputs of y per 16 lanes) = accumulator component (l&3) of MFMA
+    // lane b + 16*((l&15)>>2)
+    asm volatile("" : "+v"(e_sc), "+v"(e_zr), "+v"(e_bi));            // keep the epilogue arithmetic (and its vmcnt wait) down here
+#pragma unroll 1
+    for (int u = wave; u < 4 * RT; u += NW) {
+        const int r2 = u >> 2, q = u & 3;
+        const int b = 4 * q + (lane >> 4), wr = lane & 15;
+        const int src = r2 * 256 + (wr & 3) * 64 + b + 16 * (wr >> 2);
+        float a = 0.f, xsum = 0.f;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) {
+            const float *p = reinterpret_cast<const float *>(smem + v * (NCH * XB));
+            a += p[src];
+            xsum += p[RT * 256 + b];
+        }
+        const int64_t row = (int64_t)(rt0 + r2) * 16 + wr;
+        if (b < e.bs) {
+            if (u != wave) {                                          // fewer waves than reducer roles
+                e_sc = e.qfn == QUIPAMD_QFN_B ? e.scale[0] : e.scale[row];
+                e_zr = e.qfn == QUIPAMD_QFN_B ? 0.f : e.zero[row];
+                e_bi = e.bias ? e.bias[row] : 0.f;
+            }
+            const float alpha = e.qfn == QUIPAMD_QFN_B ? e_sc * e.two_over_maxq : e_sc;
+            const float c0 = e.qfn == QUIPAMD_QFN_B ? Q::OFF + 0.5f * (float)e.maxq : Q::OFF + e_zr;
+            const float val = alpha * (a - c0 * xsum) + e_bi;
+            const int64_t o = (int64_t)b * e.m + row;
+            if (e.y_f32) ((float *)e.y)[o] = e.accumulate ? ((float *)e.y)[o] + val : val;
+            else ((uint16_t *)e.y)[o] = e.y_f16 ? f32_to_f16_bits(val) : f32_to_bf16_bits(val);
+        }
+    }
+    K2_STAMP(7);
+    K2_STAMP_FLUSH();
+}
+
+template <int BITS, class ACT, int RT, int NW, int NCH, bool HALF, bool EXACT>
+int launch_h2(const K2Args &A, hipStream_t s)
+{
+    typedef DeqT<BITS, ACT> Q;
+    constexpr size_t lds = (size_t)NW * NCH * 16 * Q::KC * 2;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = dq_h_kernel<BITS, ACT, RT, NW, NCH, HALF, EXACT>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return qa_fail(QUIPAMD_ERR_LAUNCH, "dequant_gemm: cannot raise dynamic LDS to %zu", lds);
+    kern<<<dim3((unsigned)(A.e.m / 16 / RT)), 64 * NW, lds, s>>>(A);
+    QA_LAUNCH_CHECK("quipamd_dequant_gemm(h)");
+    return QUIPAMD_OK;
+}
+// requires (m / 16) % RT == 0, bs <= 16, d / KC <= NW * NCH
+template <int BITS, class ACT, int RT, int NW, int NCH>
+int launch_h(const K2Args &A, hipStream_t s)
+{
+    const bool exact = A.d / (512 / BITS) == NW * NCH;
+    if (A.e.bs <= 8)
+        return exact ? launch_h2<BITS, ACT, RT, NW, NCH, true, true>(A, s) : launch_h2<BITS, ACT, RT, NW, NCH, true, false>(A, s);
+    return exact ? launch_h2<BITS, ACT, RT, NW, NCH, false, true>(A, s) : launch_h2<BITS, ACT, RT, NW, NCH, false, false>(A, s);
+}
+
+// =====================================================================================================================
+// dq_s_kernel: bs <= 16, weight stream.  Workgroup = NW * KSP compute waves + TWO loader waves (weights; x).
+// Compute wave (h, w) <-> row tile blockIdx.x * NW + w, the stages s = h (mod KSP) of K: one wave per row tile is a
+// serial chain of ~100 instructions per KiB of weights at ~4.5 cycles each (measured, profiles/r02c_k2probe_timeline.log:
+// the loaders never wait for data, the compute waves are the bottleneck), so K is split over KSP waves per tile whose
+// partials meet in LDS once, at the end.  Everything a compute wave touches comes out of LDS:
+// the loader waves DMA, per stage of 256 k, the NW * TPS weight tiles (1 KiB each, lane-linear = the STREAM tile as it
+// is) and the 8 KiB slab of x into one slot of a D-deep ring, D-1 stages ahead, non-temporal for the weights.
+// The compute waves therefore have NO vector-memory queue at all (only ds_reads, which hipcc counts exactly), and the
+// loaders nothing but their DMA queue with one constant counted wait -- the engine of cdna_hip_programming.md 5.6.
+// Why not weights as register loads in the compute waves: hipcc drains vmcnt at the loop header for loop-carried loads
+// (observed: waits 0,3,2,1 over a 4-deep register ring -- a full HBM round trip every fourth stage), and asm loads get
+// their destination registers copied before the data has landed (observed: wrong results, memory faults;
+// profiles/r02a_k2lab.log).  Per-wave vmcnt + role split keeps every wait exact with no inline-asm loads.
+// One barrier per stage:  loaders: wait stage s landed -> barrier(s) -> DMA stage s+D-1 into the slot of stage s-1
+//                         compute: barrier(s) -> weight tile + fragments of stage s -> 8 x (dequant, MFMA).
+// Past the end the loaders repeat the last stage (clamped): every counted wait stays a constant.
+// x is ingested once per workgroup: 8 KiB of x per NW * TPS KiB of weights.
+// =====================================================================================================================
+template <int BITS, class ACT, int NW, int KSP, int D>
+__global__ __launch_bounds__(64 * (NW * KSP + 2)) void dq_s_kernel(K2Args A, uint32_t ntile)
+{
+    typedef DeqSel<BITS, ACT> Q;                                      // 2 bits: multi-exponent dequantisation (dq_common.h)
+    constexpr int KC = Q::KC, NT = Q::NT;
+    constexpr int KS = 256, TPS = KS / KC;                            // k per stage, weight tiles per stage and row tile
+    constexpr int XB = 16 * KS * 2, NI = 8;                            // slab bytes, DMA instructions per slab
+    constexpr int NWT = NW * TPS, SB1 = XB + NWT * 1024;               // weight tiles per stage, bytes per stage
+    constexpr int SB = KSP * SB1, NCW = NW * KSP;                      // ring slot = KSP stages; compute waves
+    static_assert(KSP * NI * (D - 2) < 64 && KSP * NWT * (D - 2) < 64 && D >= 3, "vmcnt range");
+    static_assert(NCW * 1024 + NCW * 128 <= D * SB, "exchange area");
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [D] slots of KSP stages {x slab, NWT weight tiles}
+    const EpiArgs &e = A.e;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t ns = (uint32_t)(A.d / KS), nss = (ns + KSP - 1) / KSP;   // stages, ring steps
+    const uint32_t rowbytes = (uint32_t)A.d * 2u;
+    const uint32_t tile0 = blockIdx.x * NW;                            // first row tile of the workgroup
+
+    if (wave == NCW) {
+        // ---- weight loader: tile (row tile r, chunk c) is 1 KiB at ((r * nkc + c) * 1024) -------------------------------------
+        const uint32_t nkc = ns * TPS;
+        __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.qw, 0, (int)((uint64_t)ntile * nkc * 1024u), 0x00020000);
+        const uint32_t vl = (uint32_t)lane * 16u;
+        auto issue_w = [&](uint32_t ss) {
+            const uint32_t slot = ss % D;
+#pragma unroll
+            for (int h = 0; h < KSP; ++h) {
+                const uint32_t st = ss * KSP + h, sc = st < ns ? st : ns - 1;
+#pragma unroll
+                for (int i = 0; i < NWT; ++i) {
+                    const uint32_t r = tile0 + i / TPS, rc = r < ntile ? r : ntile - 1;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void2_t *)(smem + slot * SB + h * SB1 + XB + i * 1024), 16, vl,
+                                                             (rc * nkc + sc * TPS + i % TPS) * 1024u, 0, 2 /* nt */);
+                }
+            }
+        };
+        K2_ACC_DECL;
+#pragma unroll
+        for (int c = 0; c < D - 1; ++c) issue_w(c);
+#pragma unroll 1
+        for (uint32_t ss = 0; ss < nss; ++ss) {
+            K2_ACC(0, wait_vm<KSP * NWT * (D - 2)>());                 // ring step ss has landed
+            K2_ACC(1, __builtin_amdgcn_s_barrier());
+            K2_ACC(2, issue_w(ss + D - 1));
+        }
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                                  // "LDS is free"
+        __builtin_amdgcn_s_barrier();                                  // the exchange below
+        K2_ACC_FLUSH();
+        return;
+    }
+    if (wave == NCW + 1) {
+        // ---- x loader --------------------------------------------------------------------------------------------------------
+        __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.x, 0, (int)(e.bs * (int64_t)rowbytes), 0x00020000);
+        const uint32_t voff_lo = (lane >> 3) * rowbytes + ((uint32_t)((lane & 7) ^ (lane >> 3)) << 4);
+        const uint32_t voff_hi = voff_lo + 8u * rowbytes;
+        auto issue_x = [&](uint32_t ss) {
+            const uint32_t slot = ss % D;
+#pragma unroll
+            for (int h = 0; h < KSP; ++h) {
+                const uint32_t st = ss * KSP + h, sc = st < ns ? st : ns - 1;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)                           // DMA instruction i = 2 * column block + row half
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void2_t *)(smem + slot * SB + h * SB1 + i * 1024), 16,
+                                                             (i & 1) ? voff_hi : voff_lo, sc * (KS * 2) + (i >> 1) * 128, 0, 0);
+            }
+        };
+        K2_ACC_DECL;
+#pragma unroll
+        for (int c = 0; c < D - 1; ++c) issue_x(c);
+#pragma unroll 1
+        for (uint32_t ss = 0; ss < nss; ++ss) {
+            K2_ACC(0, wait_vm<KSP * NI * (D - 2)>());
+            K2_ACC(1, __builtin_amdgcn_s_barrier());
+            K2_ACC(2, issue_x(ss + D - 1));
+        }
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        K2_ACC_FLUSH();
+        return;
+    }
+
+    // ---- compute waves: wave = h * NW + (row tile in the workgroup); k-half h takes stage ss*KSP + h of every ring step ----
+    K2_ACC_DECL;
+    const int j = lane & 15, g = lane >> 4;
+    const int hh = wave / NW, wt = wave - hh * NW;
+    const uint32_t rt = tile0 + wt;
+    const bool live = rt < ntile;                                      // wave-uniform; a dead wave still meets the barriers
+    const uint32_t rd_base = (j >> 3) * 1024 + (j & 7) * 128;
+    const uint32_t rd0 = rd_base + (((0 + g) ^ (j & 7)) << 4);
+    const uint32_t rd1 = rd_base + (((4 + g) ^ (j & 7)) << 4);
+    const uint32_t wof = XB + (uint32_t)wt * TPS * 1024 + (uint32_t)lane * 16;
+
+    // four accumulator chains: a dependent MFMA behind other instructions costs ~60 cycles, an independent one 16
+    f32x4_t acc[4], accx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acco[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const u32x4 ones = {opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES)};
+    const typename Q::Consts qc = Q::make_consts();
+    const u32x4 offs[2] = {Q::off_frag(0, qc), Q::off_frag(1, qc)};
+#pragma unroll 1
+    for (uint32_t ss = 0; ss < nss; ++ss) {
+        K2_ACC(1, __builtin_amdgcn_s_barrier());
+        if (KSP > 1 && ss * KSP + hh >= ns) continue;                  // ragged tail of the k-split (wave-uniform)
+        const char *sl = smem + (ss % D) * SB + hh * SB1;
+        u32x4 ws[TPS], xf[8];
+#pragma unroll
+        for (int t = 0; t < TPS; ++t) ws[t] = *reinterpret_cast<const u32x4 *>(sl + wof + t * 1024);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) xf[t] = *reinterpret_cast<const u32x4 *>(sl + (t >> 1) * 2048 + ((t & 1) ? rd1 : rd0));
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t & 3] = ACT::mfma(Q::frag(ws[(t * 32) / KC], t % NT, qc), xf[t], acc[t & 3]);
+        if ((ss % NW) == (uint32_t)wt) {                               // one wave per stage keeps S_1 = sum x and S_off = sum OFF_k x
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                accx[t & 1] = ACT::mfma(ones, xf[t], accx[t & 1]);
+                if constexpr (!Q::UNIFORM) acco[t & 1] = ACT::mfma(offs[t & 1], xf[t], acco[t & 1]);
+            }
+        }
+    }
+    K2_ACC_FLUSH();
+    __builtin_amdgcn_s_barrier();                                      // every ring read retired: LDS is free
+    const f32x4_t asum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    float *xch = reinterpret_cast<float *>(smem);                      // [NCW][4][64] k-half partials, then [NCW][16] S_1, [NCW][16] S_off
+    float *xsh = xch + NCW * 256, *xso = xsh + NCW * 16;
+    if (KSP > 1 && hh > 0) {
+        float *p = xch + wave * 256 + lane;
+        p[0] = asum[0]; p[64] = asum[1]; p[128] = asum[2]; p[192] = asum[3];
+    }
+    if (lane < 16) {
+        xsh[wave * 16 + lane] = accx[0][0] + accx[1][0];
+        if constexpr (!Q::UNIFORM) xso[wave * 16 + lane] = acco[0][0] + acco[1][0];
+    }
+    const uint32_t rtc = live ? rt : ntile - 1;
+    EpiRow epi = load_epi(e, (int64_t)rtc * 16 + 4 * g);
+    __syncthreads();
+    if (hh == 0) {
+        f32x4_t a = asum;
+#pragma unroll
+        for (int h = 1; h < KSP; ++h) {
+            const float *p = xch + (h * NW + wt) * 256 + lane;
+            a[0] += p[0]; a[1] += p[64]; a[2] += p[128]; a[3] += p[192];
+        }
+        float xsum = 0.f, xoff = 0.f;
+#pragma unroll
+        for (int v = 0; v < NCW; ++v) {
+            xsum += xsh[v * 16 + j];
+            if constexpr (!Q::UNIFORM) xoff += xso[v * 16 + j];
+        }
+        if constexpr (!Q::UNIFORM) { a[0] -= xoff; a[1] -= xoff; a[2] -= xoff; a[3] -= xoff; }
+        if (live) epilogue_store(e, epi, Q::OFF, a, xsum, (int64_t)j, (int64_t)rt * 16 + 4 * g);
+    }
+}
+
+template <int BITS, class ACT, int NW, int KSP, int D>
+int launch_s(const K2Args &A, hipStream_t s)
+{
+    constexpr int TPS = 256 / (512 / BITS);
+    constexpr size_t lds = (size_t)D * KSP * (16 * 256 * 2 + NW * TPS * 1024);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    QA_REQUIRE(A.e.m * A.d * BITS / 8 < ((int64_t)1 << 32), QUIPAMD_ERR_SHAPE, "dequant_gemm(s): packed weights >= 4 GiB");
+    auto kern = dq_s_kernel<BITS, ACT, NW, KSP, D>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return qa_fail(QUIPAMD_ERR_LAUNCH, "dequant_gemm: cannot raise dynamic LDS to %zu", lds);
+    const uint32_t ntile = (uint32_t)(A.e.m / 16);
+    kern<<<dim3((ntile + NW - 1) / NW), 64 * (NW * KSP + 2), lds, s>>>(A, ntile);
+    QA_LAUNCH_CHECK("quipamd_dequant_gemm(s)");
+    return QUIPAMD_OK;
+}
+
+// =====================================================================================================================
+// dq_mb_kernel: bs > 16.  Workgroup = WR x WB compute waves + NL loader waves; compute wave (wr, wb) owns RTw row
+// tiles x BTw batch tiles: workgroup tile = (ROWS = WR*RTw*16 rows) x (NB = WB*BTw*16 batch rows), all of K.
+// A stage = 256 k: the NB x 512 B panel of x (NB/8 * 4 DMA instructions of 8 rows x 128 B, XOR-swizzled through the
+// source address) plus the ROWS/16 * TPG weight tiles of the workgroup, DMA'd by the loader waves into one of TWO LDS
+// buffers while the compute waves work on the other: the loaders' wait is a plain vmcnt(0), the compute waves touch
+// nothing but LDS (same reasoning as dq_s_kernel), ONE barrier per 256 k.
+// Per 32-k MFMA step and compute wave: BTw fragment reads, RTw dequantised A fragments (8 VALU each), RTw*BTw MFMAs:
+// every A fragment feeds BTw MFMAs, every B fragment RTw.  The sums S_1, S_off of batch tile bt (dq_common.h) ride on the
+// matrix pipe of the wave with wr = bt % WR (profiles/r02e: VALU and MFMA issue are equally loaded here, ~45 % each).
+//     loaders: wait stage s landed -> barrier(s) -> DMA stage s+1 into the buffer of stage s-1
+//     compute: barrier(s) -> 8 steps on buffer s & 1
+// =====================================================================================================================
+template <int BITS, class ACT, int WR, int WB, int RTw, int BTw, int NL>
+__global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, uint32_t nrb, uint32_t nby)
+{
+    typedef DeqSel<BITS, ACT> Q;                                      // 2 bits: multi-exponent dequantisation (dq_common.h)
+    constexpr int KC = Q::KC, NTT = Q::NT;
+    constexpr int TPG = 256 / KC;                                      // weight tiles per stage and row tile
+    constexpr int NCW = WR * WB, NB = WB * BTw * 16, NRT = WR * RTw;   // compute waves, batch rows, row tiles per workgroup
+    constexpr int NXP = NB / 8 * 4, NWT = NRT * TPG, NOPS = NXP + NWT; // x pieces, weight tiles, DMA instructions per stage
+    constexpr int XBYTES = NB * 512, SB = XBYTES + NWT * 1024;         // stage bytes
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2] stages {x panel [4 column blocks][NB/8 row blocks][1 KiB], weight tiles}
+    const EpiArgs &e = A.e;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD-aware order: the nby batch blocks of one row block run on one XCD (block id % 8), back to back
+    const uint32_t id = blockIdx.x, xcd = id & 7, within = id >> 3;
+    const uint32_t by = within % nby, rbk = (within / nby) * 8 + xcd;
+    if (rbk >= nrb) return;                                            // whole workgroup
+    const uint32_t ns = (uint32_t)(A.d / 256), nkc = ns * TPG;
+    const uint32_t ntile = (uint32_t)(e.m / 16);
+    const int64_t brow0 = (int64_t)by * NB;
+    const uint32_t rowbytes = (uint32_t)A.d * 2u;
+
+    if (wave >= NCW) {
+        // ---- loader waves: DMA instruction o of a stage: o < NXP: x piece (column block o / (NB/8), row block o % (NB/8)); else weight tile o - NXP
+        const int lw = wave - NCW;
+        const int64_t rem = (e.bs - brow0) * (int64_t)rowbytes;
+        __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(A.x + brow0 * A.d), 0, (int)rem, 0x00020000);
+        __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.qw, 0, (int)((uint64_t)ntile * nkc * 1024u), 0x00020000);
+        const uint32_t vx = (lane >> 3) * rowbytes + ((uint32_t)((lane & 7) ^ (lane >> 3)) << 4), vw = (uint32_t)lane * 16u;
+        auto issue = [&](uint32_t st) {
+            char *dst = smem + (st & 1) * SB;
+#pragma unroll
+            for (int o = lw; o < NOPS; o += NL) {
+                if (o < NXP) {
+                    const int cb = o / (NB / 8), rb = o % (NB / 8);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void2_t *)(dst + o * 1024), 16, vx + (uint32_t)rb * 8u * rowbytes,
+                                                             st * 512u + cb * 128, 0, 0);
+                } else {
+                    const int i = o - NXP;
+                    const uint32_t r = rbk * NRT + i / TPG, rc = r < ntile ? r : ntile - 1;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void2_t *)(dst + XBYTES + i * 1024), 16, vw,
+                                                             (rc * nkc + st * TPG + i % TPG) * 1024u, 0, 0);
+                }
+            }
+        };
+        issue(0);
+#pragma unroll 1
+        for (uint32_t s = 0; s < ns; ++s) {
+            wait_vm<0>();                                              // stage s has landed
+            __builtin_amdgcn_s_barrier();
+            if (s + 1 < ns) issue(s + 1);
+        }
+        __builtin_amdgcn_s_barrier();                                  // "every fragment read retired"
+        __builtin_amdgcn_s_barrier();                                  // the row-sum exchange
+        return;
+    }
+
+    // ---- compute waves -----------------------------------------------------------------------------------------------------
+    const int wr = wave / WB, wb = wave - wr * WB;
+    const int j = lane & 15, g = lane >> 4;
+    const uint32_t rt0 = rbk * NRT + wr * RTw;                         // first row tile of this wave
+    // fragment of batch tile bt, column block cb, step half sh: row R = (wb*BTw + bt)*16 + j -> row block R>>3, in-block row j&7
+    const uint32_t rdA = (uint32_t)(wb * BTw) * 2048 + (j >> 3) * 1024 + (j & 7) * 128;
+    const uint32_t rd0 = rdA + (((0 + g) ^ (j & 7)) << 4);
+    const uint32_t rd1 = rdA + (((4 + g) ^ (j & 7)) << 4);
+    const uint32_t wof = XBYTES + (uint32_t)(wr * RTw) * TPG * 1024 + (uint32_t)lane * 16;
+
+    f32x4_t acc[RTw][BTw];
+#pragma unroll
+    for (int bt = 0; bt < BTw; ++bt)
+#pragma unroll
+        for (int r = 0; r < RTw; ++r) acc[r][bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // S_1 = sum_k x and S_off = sum_k OFF_k x of batch tile bt are kept, on the matrix pipe, by the wave with wr = bt % WR
+    constexpr int NSB = (BTw + WR - 1) / WR;
+    f32x4_t sum1[NSB], sumo[NSB];
+#pragma unroll
+    for (int q = 0; q < NSB; ++q) sum1[q] = sumo[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const typename Q::Consts qc = Q::make_consts();
+    const u32x4 ones = {opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES)};
+    const u32x4 offs[2] = {Q::off_frag(0, qc), Q::off_frag(1, qc)};
+#pragma unroll 1
+    for (uint32_t s = 0; s < ns; ++s) {
+        __builtin_amdgcn_s_barrier();
+        const char *sl = smem + (s & 1) * SB;
+        u32x4 wc[RTw][TPG];
+#pragma unroll
+        for (int r = 0; r < RTw; ++r)
+#pragma unroll
+            for (int t = 0; t < TPG; ++t) wc[r][t] = *reinterpret_cast<const u32x4 *>(sl + wof + (r * TPG + t) * 1024);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            u32x4 xf[BTw][2];
+#pragma unroll
+            for (int bt = 0; bt < BTw; ++bt) {
+                xf[bt][0] = *reinterpret_cast<const u32x4 *>(sl + cb * (NB * 128) + bt * 2048 + rd0);
+                xf[bt][1] = *reinterpret_cast<const u32x4 *>(sl + cb * (NB * 128) + bt * 2048 + rd1);
+            }
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                const int gstep = 2 * cb + sh, tile = gstep / NTT, tstep = gstep % NTT;   // MFMA step inside the stage
+#pragma unroll
+                for (int r = 0; r < RTw; ++r) {
+                    const u32x4 a = Q::frag(wc[r][tile], tstep, qc);
+#pragma unroll
+                    for (int bt = 0; bt < BTw; ++bt) acc[r][bt] = ACT::mfma(a, xf[bt][sh], acc[r][bt]);
+                }
+                static_for<WR>([&](auto KK) {                           // wave-uniform: only the k = wr block runs
+                    constexpr int kk = decltype(KK)::value;
+                    if (wr == kk) {
+#pragma unroll
+                        for (int q = 0; q < NSB; ++q)
+                            if (kk + q * WR < BTw) {
+                                sum1[q] = ACT::mfma(ones, xf[kk + q * WR][sh], sum1[q]);
+                                if constexpr (!Q::UNIFORM) sumo[q] = ACT::mfma(offs[sh], xf[kk + q * WR][sh], sumo[q]);
+                            }
+                    }
+                });
+            }
+        }
+    }
+    __builtin_amdgcn_s_barrier();                                      // every fragment read retired: LDS is free
+
+    // row sums of x: owner waves publish [wb][bt][16], everybody reads
+    float *xsh = reinterpret_cast<float *>(smem), *xso = xsh + NB;     // [NB] S_1, [NB] S_off
+#pragma unroll
+    for (int q = 0; q < NSB; ++q) {
+        const int bt = wr + q * WR;
+        if (bt < BTw && lane < 16) {
+            xsh[(wb * BTw + bt) * 16 + lane] = sum1[q][0];
+            if constexpr (!Q::UNIFORM) xso[(wb * BTw + bt) * 16 + lane] = sumo[q][0];
+        }
+    }
+    __syncthreads();
+    float xsum[BTw], xoff[BTw];
+#pragma unroll
+    for (int bt = 0; bt < BTw; ++bt) {
+        xsum[bt] = xsh[(wb * BTw + bt) * 16 + j];
+        xoff[bt] = Q::UNIFORM ? 0.f : xso[(wb * BTw + bt) * 16 + j];
+    }
+#pragma unroll
+    for (int r = 0; r < RTw; ++r) {
+        if (rt0 + r >= ntile) continue;
+        const int64_t r0 = (int64_t)(rt0 + r) * 16 + 4 * g;
+        const EpiRow epi = load_epi(e, r0);
+#pragma unroll
+        for (int bt = 0; bt < BTw; ++bt) {
+            f32x4_t a = acc[r][bt];
+            if constexpr (!Q::UNIFORM) { a[0] -= xoff[bt]; a[1] -= xoff[bt]; a[2] -= xoff[bt]; a[3] -= xoff[bt]; }
+            epilogue_store(e, epi, Q::OFF, a, xsum[bt], brow0 + (wb * BTw + bt) * 16 + j, r0);
+        }
+    }
+}
+
+template <int BITS, class ACT, int WR, int WB, int RTw, int BTw, int NL>
+int launch_mb2(const K2Args &A, hipStream_t s)
+{
+    constexpr int NB = WB * BTw * 16, ROWS = WR * RTw * 16, TPG = 256 / (512 / BITS);
+    constexpr size_t lds = (size_t)2 * (NB * 512 + ROWS / 16 * TPG * 1024);
+    static_assert(lds <= 160 * 1024 && lds >= (size_t)NB * 8, "LDS budget");
+    QA_REQUIRE(A.e.m * A.d * BITS / 8 < ((int64_t)1 << 32), QUIPAMD_ERR_SHAPE, "dequant_gemm(mb): packed weights >= 4 GiB");
+    auto kern = dq_mb_kernel<BITS, ACT, WR, WB, RTw, BTw, NL>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return qa_fail(QUIPAMD_ERR_LAUNCH, "dequant_gemm: cannot raise dynamic LDS to %zu", lds);
+    const uint32_t nrb = (uint32_t)((A.e.m + ROWS - 1) / ROWS), nby = (uint32_t)((A.e.bs + NB - 1) / NB);
+    const uint32_t nrb8 = (nrb + 7) / 8 * 8;                           // padded so that id -> (xcd, within) covers every row block
+    const uint64_t nblk = (uint64_t)nrb8 * nby;
+    QA_REQUIRE(nblk < (1ull << 31), QUIPAMD_ERR_SHAPE, "dequant_gemm: grid too large");
+    kern<<<dim3((unsigned)nblk), 64 * (WR * WB + NL), lds, s>>>(A, nrb, nby);
+    QA_LAUNCH_CHECK("quipamd_dequant_gemm(mb)");
+    return QUIPAMD_OK;
+}
+
+}   // namespace

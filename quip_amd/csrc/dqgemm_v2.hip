@@ -1,0 +1,87 @@
+// dqgemm_v2.hip -- instantiations and shape heuristic of the second-generation K2 kernels (dqgemm_v2.h).
+// k2v2_launch() is called by quipamd_dequant_gemm (dqgemm.hip) before the round-1 kernels: it returns
+// K2V2_NOT_TAKEN when the shape is better served by those (bf16 only), a status otherwise.  fp16 activations
+// (quant.py:226-229 widens x, it never narrows it: an fp16 model keeps all its activation bits on the fp16 MFMA pipe)
+// exist only here, so every fp16 shape is taken.
+#include "dqgemm_v2.h"
+#include "k2_dispatch.h"
+
+namespace {
+
+template <int BITS, class ACT>
+int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
+{
+    const int64_t m = c.m, d = c.d, bs = c.bs;
+    const int64_t ntile = m / 16, nkc = d / (512 / BITS);
+    const bool f16 = c.x_dtype == QUIPAMD_F16;
+    int fam = c.cfg[0], p1 = c.cfg[1], p2 = c.cfg[2];
+    const bool h_fits = bs <= 16 && nkc <= (BITS == 2 ? 16 : 32);
+    const bool mb_ok = d % 256 == 0;
+    if (fam == K2_FAM_AUTO) {
+        // measured on MI355X, profiles/r02*_k2lab.log (cold weights):
+        //   h: every shape whose K fits one pass of LDS (d <= 4096) and whose grid is not many rounds of 1-per-CU workgroups
+        //   s: tall layers (>= 1024 row tiles), where a weight stream pays; below that the round-1 kernels, which split K
+        //      over 16 waves, are faster
+        //   mb: bs > 16 when there are >= ~200 workgroup tiles of 256 x 128
+        if (bs <= 16) {
+            if (h_fits && ntile <= 768) fam = K2_FAM_H;
+            else if (ntile >= 1024 && d % 256 == 0) fam = K2_FAM_S;
+            else if (f16) fam = (d % 256 == 0) ? K2_FAM_S : K2_FAM_NONE;
+            else return K2V2_NOT_TAKEN;
+        } else {
+            const int64_t tiles = ((m + 255) / 256) * ((bs + 127) / 128);
+            if (mb_ok && ((tiles >= 200 && BITS == 2) || f16)) fam = K2_FAM_MB;   // 4 bit: the big tile does not fit LDS, round 1 wins
+            else if (f16) fam = K2_FAM_NONE;
+            else return K2V2_NOT_TAKEN;
+        }
+    }
+    if (fam == K2_FAM_H) {
+        QA_REQUIRE(h_fits, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: kernel family h needs bs <= 16 and d <= %d", BITS == 2 ? 4096 : 4096);
+        if constexpr (BITS == 2) {
+            if (p1 == 0) { p1 = nkc <= 8 ? 8 : 8; p2 = nkc <= 8 ? 1 : 2; }
+            if (p1 == 8 && p2 == 1 && nkc <= 8) return launch_h<2, ACT, 1, 8, 1>(A, s);
+            if (p1 == 8 && p2 == 2) return launch_h<2, ACT, 1, 8, 2>(A, s);
+            if (p1 == 4 && p2 == 4) return launch_h<2, ACT, 1, 4, 4>(A, s);
+        } else {
+            if (p1 == 0) { p1 = 8; p2 = nkc <= 16 ? 2 : 4; }
+            if (p1 == 8 && p2 == 2 && nkc <= 16) return launch_h<4, ACT, 1, 8, 2>(A, s);
+            if (p1 == 8 && p2 == 4) return launch_h<4, ACT, 1, 8, 4>(A, s);
+        }
+        return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: no h kernel for nw=%d nch=%d (d=%lld)", p1, p2, (long long)d);
+    }
+    if (fam == K2_FAM_S) {
+        QA_REQUIRE(bs <= 16 && d % 256 == 0, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: kernel family s needs bs <= 16 and d %% 256 == 0");
+        if (p1 == 0) { p1 = 7; p2 = 2; }
+        if (p1 == 7 && p2 == 2) return launch_s<BITS, ACT, 7, 2, 3>(A, s);
+        if (p1 == 4 && p2 == 2) return launch_s<BITS, ACT, 4, 2, 4>(A, s);
+        if (p1 == 8 && p2 == 1) return launch_s<BITS, ACT, 8, 1, 4>(A, s);
+        return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: no s kernel for nw=%d ksp=%d", p1, p2);
+    }
+    if (fam == K2_FAM_MB) {
+        QA_REQUIRE(mb_ok, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: kernel family mb needs d %% 256 == 0");
+        if (p1 == 0) p1 = (((m + 255) / 256) * ((bs + 127) / 128) >= 200) ? 44 : 22;
+        if (p1 == 44) {                                                   // 256 rows x 128 batch rows, 4 x 4 tiles per wave (4 bit: 128 rows)
+            if constexpr (BITS == 2) return launch_mb2<BITS, ACT, 4, 2, 4, 4, 2>(A, s);
+            else return launch_mb2<BITS, ACT, 4, 2, 2, 4, 2>(A, s);
+        }
+        if (p1 == 22) return launch_mb2<BITS, ACT, 4, 2, 2, 2, 2>(A, s);   // 128 rows x  64 batch rows
+        return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: no mb kernel %d", p1);
+    }
+    return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: fp16 activations need d %% 256 == 0 (d=%lld)", (long long)d);
+}
+
+}   // namespace
+
+int k2v2_launch(const K2Call &c, void *stream)
+{
+    if (c.cfg[0] == K2_FAM_OLD) return K2V2_NOT_TAKEN;
+    K2Args A;
+    A.x = (const uint16_t *)c.x; A.qw = (const u32x4 *)c.qweight; A.d = c.d;
+    EpiArgs &e = A.e;
+    e.scale = c.scale; e.zero = c.zero; e.bias = c.bias; e.y = c.y; e.qfn = c.qfn; e.maxq = c.maxq;
+    e.two_over_maxq = 2.0f / (float)c.maxq;
+    e.y_f32 = c.y_dtype == QUIPAMD_F32; e.y_f16 = c.y_dtype == QUIPAMD_F16; e.accumulate = c.accumulate; e.bs = c.bs; e.m = c.m;
+    hipStream_t s = (hipStream_t)stream;
+    if (c.x_dtype == QUIPAMD_F16) return c.bits == 2 ? run_family<2, ActF16>(c, A, s) : run_family<4, ActF16>(c, A, s);
+    return c.bits == 2 ? run_family<2, ActBF16>(c, A, s) : run_family<4, ActBF16>(c, A, s);
+}

@@ -84,12 +84,34 @@ def _f32vec(t, dev):
     return None if t is None else t.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
 
 
+def _grid(scale, zero, m, qfn, dev):
+    """Grid parameters as the kernels index them: float32, contiguous, scale[1] for qfn b (scalar grid, quant.py:13-14),
+    scale[m] / zero[m] per output row for qfn a / c (quant.py:124-126).  A scalar is expanded to m rows; anything else
+    (the per-column shapes Quantizer.find_params(weight=False) can produce) is refused instead of being read out of bounds."""
+    scale, zero = _f32vec(scale, dev), _f32vec(zero, dev)
+    if scale is None:
+        raise ValueError("grid scale is None (Quantizer.find_params not called?)")
+    if qfn == 'b':
+        if scale.numel() != 1:
+            raise ValueError(f"qfn b takes one scalar scale, got {scale.numel()} values")
+        return scale, zero
+    def rows(t, what):
+        if t is None:
+            raise ValueError(f"qfn {qfn} needs {what}")
+        if t.numel() == 1 and m != 1:
+            return t.expand(m).contiguous()
+        if t.numel() != m:
+            raise ValueError(f"{what} has {t.numel()} values for {m} rows: only per-row (or scalar) grids are supported")
+        return t
+    return rows(scale, "scale"), rows(zero, "zero")
+
+
 def gridmap(W, qfn, scale, zero, maxq):
     """grid coordinates float32 [m,d] (vector_balance.py:515, 522-524)."""
     _need_gpu(W)
     W = W.contiguous()
     m, d = W.shape
-    scale, zero = _f32vec(scale, W.device), _f32vec(zero, W.device)
+    scale, zero = _grid(scale, zero, m, qfn, W.device)
     out = torch.empty((m, d), dtype=torch.float32, device=W.device)
     _lib.call("quipamd_gridmap", _p(W), _dtype(W), QFN[qfn], _p(scale), _p(zero), int(maxq), _p(out), m, d, _stream())
     return out
@@ -100,7 +122,7 @@ def quantize(W, qfn, scale, zero, maxq, want_codes=False):
     _need_gpu(W)
     W2 = W.contiguous().reshape(W.shape[0], -1)
     m, d = W2.shape
-    scale, zero = _f32vec(scale, W.device), _f32vec(zero, W.device)
+    scale, zero = _grid(scale, zero, m, qfn, W.device)
     out = torch.empty_like(W2)
     codes = torch.empty((m, d), dtype=torch.uint8, device=W.device) if want_codes else None
     _lib.call("quipamd_quantize", _p(W2), _dtype(W2), QFN[qfn], _p(scale), _p(zero), int(maxq), _p(codes), _p(out),
@@ -113,7 +135,7 @@ def codes_to_weight(codes, qfn, scale, zero, maxq, out_dtype=torch.float16):
     _need_gpu(codes)
     codes = codes.contiguous()
     m, d = codes.shape
-    scale, zero = _f32vec(scale, codes.device), _f32vec(zero, codes.device)
+    scale, zero = _grid(scale, zero, m, qfn, codes.device)
     out = torch.empty((m, d), dtype=out_dtype, device=codes.device)
     _lib.call("quipamd_codes_to_weight", _p(codes), QFN[qfn], _p(scale), _p(zero), int(maxq), _p(out), _DT[out_dtype],
               m, d, _stream())
@@ -121,22 +143,33 @@ def codes_to_weight(codes, qfn, scale, zero, maxq, out_dtype=torch.float16):
 
 
 # ------------------------------------------------------------------------------------------------- K2
-def dequant_gemm(x, qweight, bits, qfn, scale, zero, bias, out=None, out_dtype=torch.bfloat16, accumulate=False,
-                 m=None):
-    """y[bs,m] = x[bs,d] @ dequant(qweight)^T + bias; qweight in STREAM layout."""
+def dequant_gemm(x, qweight, bits, qfn, scale, zero, bias, out=None, out_dtype=None, accumulate=False,
+                 m=None, cfg=None):
+    """y[bs,m] = x[bs,d] @ dequant(qweight)^T + bias; qweight in STREAM layout.  x: bf16 or fp16 (the MFMA runs in x's
+    dtype); y: x's dtype (default) or fp32.  cfg = (family, p1, p2): force a kernel (include/quip_amd.h), for benchmarks."""
     _need_gpu(x, qweight)
-    assert x.dim() == 2 and x.dtype == torch.bfloat16
+    assert x.dim() == 2 and x.dtype in (torch.bfloat16, torch.float16), "x must be bf16 or fp16"
     x = x.contiguous()
     bs, d = x.shape
     if m is None:
         m = qweight.numel() * 32 // container_bits(bits) // d
     dev = x.device
-    scale, zero, bias = _f32vec(scale, dev), _f32vec(zero, dev), _f32vec(bias, dev)
+    scale, zero = _grid(scale, zero, m, qfn, dev)
+    bias = _f32vec(bias, dev)
+    if bias is not None and bias.numel() != m:
+        raise ValueError(f"bias has {bias.numel()} values for {m} rows")
     if out is None:
         assert not accumulate
-        out = torch.empty((bs, m), dtype=out_dtype, device=dev)
-    _lib.call("quipamd_dequant_gemm", _p(x), _dtype(x), _p(qweight), bits, LAYOUT_STREAM, QFN[qfn], _p(scale),
-              _p(zero), _p(bias), _p(out), _dtype(out), int(bool(accumulate)), bs, m, d, _stream())
+        out = torch.empty((bs, m), dtype=out_dtype or x.dtype, device=dev)
+    assert out.is_contiguous() and out.shape == (bs, m)
+    if cfg is None:
+        _lib.call("quipamd_dequant_gemm", _p(x), _dtype(x), _p(qweight), bits, LAYOUT_STREAM, QFN[qfn], _p(scale),
+                  _p(zero), _p(bias), _p(out), _dtype(out), int(bool(accumulate)), bs, m, d, _stream())
+    else:
+        c = (ctypes.c_int32 * 4)(*(list(cfg) + [0, 0, 0, 0])[:4])
+        _lib.call("quipamd_dequant_gemm_cfg", _p(x), _dtype(x), _p(qweight), bits, LAYOUT_STREAM, QFN[qfn], _p(scale),
+                  _p(zero), _p(bias), _p(out), _dtype(out), int(bool(accumulate)), bs, m, d,
+                  ctypes.cast(c, ctypes.c_void_p), _stream())
     return out
 
 
@@ -145,6 +178,8 @@ def dequant_gemm_grouped(xs, qweights, bits, qfn, scales, zeros, outs, m):
     n = len(xs)
     bs, d = xs[0].shape
     vp = ctypes.c_void_p
+    for t in list(scales) + (list(zeros) if zeros is not None else []):
+        _f32ptr(t, "scale / zero")
     arr = lambda ts: (vp * n)(*[vp(0 if t is None else t.data_ptr()) for t in ts])
     zs = arr(zeros) if zeros is not None and zeros[0] is not None else None
     _lib.call("quipamd_dequant_gemm_grouped", n, arr(xs), _dtype(xs[0]), arr(qweights), bits, LAYOUT_STREAM, QFN[qfn], arr(scales),
@@ -169,6 +204,16 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _f32ptr(t, what):
+    """raw float* handed to a kernel: the tensor must BE float32 and contiguous (e.g. model.half() must not have touched
+    a packed layer's grid buffers -- QuantLinear._apply keeps them fp32)."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise TypeError(f"{what} must be a contiguous float32 tensor, got {t.dtype}, contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
 def ortho_small_ops(op_list, rows):
     """up to 4 fused small-batch operator applications in ONE launch (quipamd_ortho_apply_small_ops)."""
     arr = (SmallOp * len(op_list))(*op_list)
@@ -187,6 +232,8 @@ def dequant_gemm_vop(vops, qweights, scales, biases, ys, bs, m, bits=2):
     """V-side operator + grouped 2-bit dequant-GEMM in ONE launch (quipamd_dequant_gemm_vop; d = 2048, bs <= 8)."""
     n = len(vops)
     arr = (SmallOp * n)(*vops)
+    for t in list(scales) + (list(biases) if biases is not None else []):
+        _f32ptr(t, "scale / bias")
     vp = lambda ts: (ctypes.c_void_p * n)(*[0 if t is None else t.data_ptr() for t in ts])
     _lib.call("quipamd_dequant_gemm_vop", ctypes.cast(arr, ctypes.c_void_p), vp(qweights), vp(scales),
               vp(biases if biases is not None else [None] * n), vp(ys), n, bits, bs, m, _stream())
@@ -299,6 +346,7 @@ class OrthoOp:
         For ortho_small_chain: x may be None (a second op) and out may be None with out_dtype / ld given (a first op whose
         result is only handed over)."""
         assert self.small_ok and (x is None or x.stride(1) == 1) and (out is None or out.stride(1) == 1)
+        _f32ptr(colscale, "colscale"), _f32ptr(bias, "bias")          # read as float* by the kernel
         if x is None or out is None:
             n = self.p * self.q
             M0, M1 = self._M[bool(transpose)]

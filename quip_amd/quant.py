@@ -142,6 +142,19 @@ class QuantLinear(nn.Module):
         self.U = None     # ops.OrthoOp over out features
         self.V = None     # ops.OrthoOp over in features
 
+    _F32_BUFFERS = ('scales', 'zeros', 'bias', 'inv_scaleWH')
+
+    def _apply(self, fn, recurse=True):
+        """model.half() / .to(dtype) must not narrow the grid parameters: the kernels read them as float32 (and fp16 could
+        not hold them).  Device moves are followed, dtype changes of these buffers are undone without a round trip."""
+        keep = {n: getattr(self, n, None) for n in self._F32_BUFFERS}
+        super()._apply(fn, recurse)
+        for n, old in keep.items():
+            new = getattr(self, n, None)
+            if old is not None and new is not None and new.dtype != torch.float32:
+                self._buffers[n] = old.to(device=new.device, dtype=torch.float32)
+        return self
+
     @torch.no_grad()
     def pack(self, codes, scale, zero=None, bias=None, scaleWH=None, U=None, V=None):
         """codes uint8 [out,in] on the GPU; scale float[1] (qfn b) or [out] (qfn a); U/V reference-style
@@ -191,15 +204,24 @@ class QuantLinear(nn.Module):
         ql.V = None if st["V"] is None else ops.OrthoOp(st["V"], device)
         return ql
 
+    def act_dtype(self, x):
+        """dtype of the activations fed to K2: the reference operator widens x to fp32 (quant.py:226-229), so an fp16
+        model must not lose mantissa bits to a bf16 cast -- fp16 x runs on the fp16 MFMA pipe (needs in_features % 256 == 0,
+        or in_features <= 4096); bf16 / fp32 x run in bf16 (fp32: range over mantissa)."""
+        if x.dtype == torch.float16 and (self.infeatures % 256 == 0 or self.infeatures <= 4096):
+            return torch.float16
+        return torch.bfloat16
+
     def forward(self, x):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
+        adt = self.act_dtype(x)
         if self.V is not None:
-            xt = self.V.apply_rows(x2.contiguous(), colscale=self.inv_scaleWH, out_dtype=torch.bfloat16)
+            xt = self.V.apply_rows(x2.contiguous(), colscale=self.inv_scaleWH, out_dtype=adt)
         else:
-            xt = x2.to(torch.bfloat16)
+            xt = x2.to(adt)
             if self.inv_scaleWH is not None:
-                xt = (x2.float() * self.inv_scaleWH).to(torch.bfloat16)
+                xt = (x2.float() * self.inv_scaleWH).to(adt)
         if self.U is None:
             y = ops.dequant_gemm(xt, self.qweight, self.bits, self.qfn, self.scales, self.zeros, self.bias,
                                  out_dtype=torch.float32, m=self.outfeatures)
@@ -362,7 +384,8 @@ def save_packed(layers, path):
 
 def load_packed(path, device):
     """inverse of save_packed: {name: QuantLinear on `device`}, ready for make_quant(model, layers)."""
-    return {name: QuantLinear.from_packed_state(st, device) for name, st in torch.load(path, weights_only=False).items()}
+    # the record holds tensors, lists, tuples, ints, strings and None only: no need for (unsafe) full unpickling
+    return {name: QuantLinear.from_packed_state(st, device) for name, st in torch.load(path, map_location='cpu', weights_only=True).items()}
 
 
 def make_quant(module, layers, name=''):

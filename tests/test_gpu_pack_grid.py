@@ -151,8 +151,16 @@ def test_degenerate_and_rejected_calls(ops):
     assert y.shape == (0, 32)
     with pytest.raises(QuipAmdError):                                  # d not a multiple of the 2-bit chunk (256)
         ops.dequant_gemm(torch.zeros(4, 384, dtype=torch.bfloat16, device=DEV), qs, 2, 'b', sc, None, None, m=32)
-    with pytest.raises(AssertionError):                                # fp16 activations must be converted by the caller
-        ops.dequant_gemm(torch.zeros(4, 512, dtype=torch.float16, device=DEV), qs, 2, 'b', sc, None, None, m=32)
+    with pytest.raises(AssertionError):                                # fp32 activations must be narrowed by the caller
+        ops.dequant_gemm(torch.zeros(4, 512, dtype=torch.float32, device=DEV), qs, 2, 'b', sc, None, None, m=32)
+    with pytest.raises(ValueError):                                    # per-column grids are refused, not read out of bounds
+        ops.quantize(torch.zeros(32, 512, device=DEV), 'a', torch.ones(1, 512), torch.zeros(1, 512), 3)
+    with pytest.raises(ValueError):
+        ops.dequant_gemm(torch.zeros(4, 512, dtype=torch.bfloat16, device=DEV), qs, 2, 'a', torch.ones(7), torch.zeros(7), None, m=32)
+    # a scalar per-row grid is expanded
+    w = torch.randn(32, 512, device=DEV)
+    assert torch.equal(ops.quantize(w, 'a', torch.tensor(0.5), torch.tensor(2.0), 3),
+                       ops.quantize(w, 'a', torch.full((32,), 0.5), torch.full((32, 1), 2.0), 3))
     np.random.seed(0)
     torch.manual_seed(0)
     op = ops.OrthoOp(method.gen_rand_ortho_butterfly(40), DEV)
