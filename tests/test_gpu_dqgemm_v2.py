@@ -124,7 +124,8 @@ def test_one_hot_weights_detect_transposes(ops, O, cfg, dt):
     y_ref = 3.0 * x[:, cols]                                      # qfn a with scale 1, zero 0: What = q
     qs = ops.pack(torch.from_numpy(codes).to(DEV), bits, ops.LAYOUT_STREAM)
     y = ops.dequant_gemm(xt.to(DEV), qs, bits, "a", torch.ones(m), torch.zeros(m), None, out_dtype=torch.float32, cfg=cfg)
-    assert _rel(y.cpu().numpy().astype(np.float64), y_ref) <= 1e-5
+    # 1e-4: the multi-exponent dequantisation (offsets up to 128) costs ~1e-5 of cancellation; a transposed operand costs O(1)
+    assert _rel(y.cpu().numpy().astype(np.float64), y_ref) <= 1e-4
 
 
 def test_accumulate_contract_and_determinism(ops, O):

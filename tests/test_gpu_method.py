@@ -335,7 +335,9 @@ def test_device_rng_sampler_gives_special_orthogonal_factors():
 @pytest.mark.parametrize("rows,ngroups,with_ln,m", [(1, 3, True, 2048), (1, 1, False, 2048), (3, 1, True, 8192), (8, 2, False, 2048)])
 def test_operator_fused_dequant_gemm_is_bit_identical_to_two_launches(Q, rows, ngroups, with_ln, m):
     """quipamd_dequant_gemm_vop: V (LayerNorm(x) (/) s) in the prologue of the 2-bit dequant-GEMM (d = 2048) ==
-    packed_v_stage followed by packed_gemm_stage."""
+    packed_v_stage followed by packed_gemm_stage.  Bit-identical where the two-launch path runs the round-1 tile kernel
+    the fused kernel shares its summation order with (grouped launches); a single layer now takes the one-pass kernel
+    of dqgemm_v2.h, whose k-partials meet in a different order: equal to fp32 accumulation noise there."""
     from quip_amd import ops, method
     torch.manual_seed(5)
     np.random.seed(5)
@@ -358,7 +360,10 @@ def test_operator_fused_dequant_gemm_is_bit_identical_to_two_launches(Q, rows, n
     want = Q.packed_gemm_stage(qls, Q.packed_v_stage(qls, x, ln=ln))
     got = Q.packed_vgemm_stage(qls, x, ln=ln)
     for a, b in zip(got, want):
-        assert torch.equal(a, b)
+        if ngroups > 1:
+            assert torch.equal(a, b)
+        else:
+            assert float((a - b).norm() / b.norm()) <= 2e-6
 
 
 @pytest.mark.parametrize("argv", [["--quant", "ldlq", "--incoh", "--pack"], ["--quant", "gptq", "--wbits", "4"],
