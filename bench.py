@@ -144,10 +144,18 @@ def main():
                             launch(weights[i % nw], cst)
                 wgraph.replay()
             barrier()
+            # The K launches are one hipGraph; its ~10 us host-side launch latency is not step time.  A ~100 us spin kernel
+            # goes first, the start event and the graph are enqueued behind it while it spins, so the events bracket
+            # exactly the K kernels back to back (what rocprofv3's per-kernel durations add up to); the W warm-up launches are
+            # replayed once more right in front of the start event.
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            graph.replay()
-            e1.record()
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(250000)
+                if wgraph is not None:
+                    wgraph.replay()                          # pre-roll: the timed launches start from a busy, warm GPU
+                e0.record(side)
+                graph.replay()
+                e1.record(side)
             barrier()
             t = e0.elapsed_time(e1) * 1e-3
         if dist is not None:
@@ -224,6 +232,48 @@ def main():
             "hbm_GBs": round(BYTES_ACC / (t_acc_cold / args.steps) / 1e9, 1),
             "hbm_frac": round(BYTES_ACC / (t_acc_cold / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
+
+    # ---- the same kernel family on the shapes where it is a stream / a GEMM, and fp16 activations ----------
+    def k2_leg(m_, d_, bs_, dt, steps):
+        g = torch.Generator().manual_seed(1)
+        codes_ = torch.randint(0, 4, (m_, d_), generator=g, dtype=torch.uint8).to(dev)
+        q_ = ops.pack(codes_, BITS, ops.LAYOUT_STREAM)
+        del codes_
+        wb = m_ * d_ * BITS // 8
+        nr = max(2, min(96, (400 << 20) // wb + 1))
+        ring_ = [q_] + [q_.clone() for _ in range(nr - 1)]
+        x_ = torch.randn(bs_, d_, generator=g).to(dt).to(dev)
+        y_ = torch.empty(bs_, m_, dtype=dt, device=dev)
+        sc_ = torch.tensor([0.05], device=dev)
+
+        def l_(qw, stream):
+            rc = fn(vp(x_.data_ptr()), ops._DT[dt], vp(qw.data_ptr()), BITS, 1, 1, vp(sc_.data_ptr()), vp(0), vp(0),
+                    vp(y_.data_ptr()), ops._DT[dt], 0, bs_, m_, d_, stream)
+            if rc:
+                raise RuntimeError(lib.quipamd_last_error())
+        nonlocal launch
+        keep = launch
+        launch = l_
+        try:
+            tt = timed(ring_, steps, min(steps, 20)) / steps
+        finally:
+            launch = keep
+        by = wb + 2 * bs_ * d_ + 2 * bs_ * m_
+        return {"us_per_launch": round(tt * 1e6, 3), "GBs": round(by / tt / 1e9, 1), "hbm_frac": round(by / tt / 1e9 / HBM_PEAK_GBS, 4),
+                "TFLOPs": round(2.0 * bs_ * m_ * d_ / tt / 1e12, 1), "mfma_frac": round(2.0 * bs_ * m_ * d_ / tt / 1e12 / MFMA_PEAK_TF, 4)}
+    if rank == 0 and world == 1 and not args.no_ldlq:
+        try:
+            del ring
+            ring = [qs]
+            torch.cuda.empty_cache()
+            out["k2_shapes"] = {
+                "what": "quipamd_dequant_gemm, w2 qfn b, cold weights, default kernel choice; bytes/flops as SURVEY.md 8(d)",
+                "4096x4096 bs16 fp16": k2_leg(4096, 4096, 16, torch.float16, 200),
+                "28672x7168 bs16 bf16 (weight stream)": k2_leg(28672, 7168, 16, torch.bfloat16, 100),
+                "28672x7168 bs256 bf16 (MFMA)": k2_leg(28672, 7168, 256, torch.bfloat16, 50),
+                "4096x4096 bs2048 bf16 (prefill)": k2_leg(4096, 4096, 2048, torch.bfloat16, 50)}
+        except Exception as ex:
+            out["k2_shapes"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     # The side measurements below must never cost the headline line: exceptions are caught per leg, and a watchdog on
     # every rank covers a hang (a collective that never completes cannot be caught): when it fires, rank 0 prints the
@@ -313,7 +363,7 @@ def main():
     # ---- the other half of BASELINE.json's metric: OPT-1.3B w2 decode tok/s on one GPU (configs[2]) -----------------
     if rank == 0 and world == 1 and not args.no_decode:
         import importlib.util
-        del ring
+        ring = None
         torch.cuda.empty_cache()
         spec = importlib.util.spec_from_file_location(
             "decode_opt", os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "decode_opt.py"))
@@ -354,6 +404,24 @@ def main():
                 torch.nn.functional.linear(xc, Wd)
             n += 20
         dt = (time.perf_counter() - t0) / n
+        try:        # the other CPU figure: the oracle's OpenMP restatement of round_ldl (vector_balance.py:155-199) on the host cores
+            from oracle import quip_oracle as OR
+            import numpy as _np
+            rows_s, dl = 512, 4096
+            rs = _np.random.default_rng(0)
+            Xs = (rs.standard_normal((2 * dl, dl)) * _np.arange(1, dl + 1) ** -0.75).astype(_np.float32)
+            Hs = Xs.T @ Xs / (2 * dl)
+            Hs += 0.01 * _np.diag(Hs).mean() * _np.eye(dl, dtype=_np.float32)
+            Ls = OR.ldl_factor(Hs)
+            wg_s = _np.clip(rs.random((rows_s, dl), dtype=_np.float32) * 3.6 - 0.3, 0, 3)
+            t0 = time.perf_counter()
+            OR.round_ldl(wg_s, Hs, 2, L=Ls)
+            t_l = time.perf_counter() - t0
+            out["ldlq_cpu_port"] = {"what": f"oracle round_ldl (C, OpenMP) on {rows_s} of 4096 rows x 4096 columns, w2; full layer = x{4096 // rows_s}",
+                                    "sample_s": round(t_l, 3), "full_layer_s_extrapolated": round(t_l * 4096 / rows_s, 2),
+                                    "cores": os.cpu_count(), "kind": "port"}
+        except Exception as ex:
+            out["ldlq_cpu_port"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
         out["cpu_baseline"] = {"value": round(FLOPS / dt / 1e12, 4), "unit": "TFLOP/s", "cores": cores, "kind": "port",
                                "sample": f"{n} calls of torch CPU F.linear fp32 x[16,4096] @ What[4096,4096]^T "
                                          f"(dense fake-quant weights, what the reference runs at inference), "

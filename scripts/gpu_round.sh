@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 TAG=${1:-r1}
 echo "== pytest gpu" ; timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu_$TAG.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_$TAG.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke_$TAG.log
-echo "== bench"; timeout 900 python bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc=$?"; cat $O/bench_$TAG.json; tail -3 $O/bench_$TAG.err
+echo "== bench"; timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc=$?"; cat $O/bench_$TAG.json; tail -3 $O/bench_$TAG.err
 cd /tmp
 echo "== rocprof kernel-trace (cold regime, eager launches)"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --steps 1000 --warmup 100 --profile-cold-only --eager > $O/prof_bench_$TAG.log 2>&1; echo "rc=$?"

@@ -29,7 +29,7 @@ def main(paths):
         print()
 
 
-def k2_json(fetch_db, write_db, out_path, match="dqgemm"):
+def k2_json(fetch_db, write_db, out_path, match="dq"):
     """HBM bytes per launch of the K2 kernel from two PMC passes: FETCH_SIZE (KB, reads 1/2 of a wide coalesced
     stream on gfx950 -> x2, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (KB, 1:1)."""
     import json
