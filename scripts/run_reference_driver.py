@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Launcher that puts quip_amd under the reference driver's module names and runs the driver's
+`opt_sequential` on it:
+
+    from gptq import *; from bal import Balance; from near import Nearest; from modelutils import *; from quant import *   (opt.py:6-10)
+
+all resolve to quip_amd.{gptq,bal,near,modelutils,quant} (+ method, vector_balance behind them).  With the reference checkout
+at hand (QUIP_REFERENCE=/path/to/QuIP, a machine that has both it and a GPU) the reference's own, unmodified opt.py is
+imported and its opt_sequential (opt.py:29-190) is called; without it (the GPU test box has no reference tree) the same call
+sequence restated in scripts/quantize_opt.py runs.  Either way every quantisation call lands in libquip_amd.so."""
+import importlib
+import importlib.util
+import os
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ALIASES = ("quant", "method", "vector_balance", "bal", "gptq", "near", "modelutils")
+
+
+def alias_modules():
+    import quip_amd
+    for name in ALIASES:
+        sys.modules[name] = importlib.import_module(f"quip_amd.{name}")
+    return quip_amd
+
+
+def load_driver():
+    """(opt_sequential, is_reference): signature opt_sequential(model, dataloader, dev, args) -> (quantizers | report, errors)"""
+    alias_modules()
+    ref = os.environ.get("QUIP_REFERENCE")
+    if ref and os.path.exists(os.path.join(ref, "opt.py")):
+        spec = importlib.util.spec_from_file_location("opt", os.path.join(ref, "opt.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)              # `from quant import *` etc. bind to quip_amd here
+        return mod.opt_sequential, True
+    spec = importlib.util.spec_from_file_location("quantize_opt", os.path.join(ROOT, "scripts", "quantize_opt.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def opt_sequential(model, dataloader, dev, args):
+        a = types.SimpleNamespace(arch="opt", nsamples=args.nsamples, quant=args.quant, wbits=args.wbits, npasses=args.npasses,
+                                  qfn=args.qfn, percdamp=args.percdamp, incoh=bool(args.pre_proj), pack=bool(args.pre_proj_extra))
+        report, _ = mod.opt_sequential(model, [b[0] for b in dataloader], dev, a)
+        return report, [r["error"] for r in report]
+    return opt_sequential, False
+
+
+if __name__ == "__main__":
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import tiny_model as TM
+    name = sys.argv[1] if len(sys.argv) > 1 else "ldlq_w2_incoh"
+    drv, is_ref = load_driver()
+    dev = torch.device("cuda:0")
+    model = TM.build_tiny_opt().to(dev)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    _, errors = drv(model, TM.calibration_batches(), dev, types.SimpleNamespace(nsamples=TM.NSAMPLES, **TM.CONFIGS[name]))
+    print({"config": name, "reference_driver": is_ref, "errors": [float(e) for e in errors]})

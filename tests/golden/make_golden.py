@@ -361,9 +361,58 @@ def gen_rounders():
          "with torch.cuda.synchronize stubbed.  H = correlated fixture, d=192, m=40", **arrs)
 
 
+# ---------------------------------------------------------------- H. the reference DRIVER, end to end
+def gen_driver():
+    """/root/reference/opt.py:29-190 `opt_sequential`, unmodified, on the tiny random-init fp16 OPT of tiny_model.py, CPU,
+    for `nearest` (w4 qfn a), `ldlq` (w4 qfn a) and `ldlq --incoh_processing` (w2 qfn b; opt.py:594-600 turns that flag into
+    pre_gptqH + pre_rescale + pre_proj with the blocked butterfly, pre_proj_extra = 0).  Records, per quantised Linear in
+    driver order: error, Hmag (method.py:228-233), the first 8 rows of the final weights and a SHA-256 of all of them;
+    plus the quantised model's logits on two probe sequences.  numpy / torch RNGs are seeded right before each run
+    (the reference itself never seeds them, datautils.py:5-7)."""
+    import hashlib
+    import types
+    import tiny_model as TM
+    import opt as ref_opt                      # the reference driver module itself
+    arrs = {}
+    rec = []
+    orig_free = ref_method.QuantMethod.free
+
+    def recording_free(self):                   # error / Hmag live on the method object until free() (opt.py:165-168)
+        rec.append((float(self.error), float(self.Hmag)))
+        return orig_free(self)
+    ref_method.QuantMethod.free = recording_free
+    for cname, cfg in TM.CONFIGS.items():
+        model = TM.build_tiny_opt()
+        args = types.SimpleNamespace(nsamples=TM.NSAMPLES, **cfg)
+        del rec[:]
+        np.random.seed(0)
+        torch.manual_seed(0)
+        quantizers, errors = ref_opt.opt_sequential(model, TM.calibration_batches(), torch.device("cpu"), args)
+        assert len(rec) == len(errors) == 12
+        arrs[f"{cname}_error"] = np.asarray([r[0] for r in rec], np.float64)
+        arrs[f"{cname}_Hmag"] = np.asarray([r[1] for r in rec], np.float64)
+        names = sorted(quantizers.keys(), key=lambda k: list(quantizers.keys()).index(k))
+        arrs[f"{cname}_names"] = np.asarray(names)
+        for k in names:
+            w = dict(model.named_parameters())[k + ".weight"].detach()
+            assert w.dtype == torch.float16
+            arrs[f"{cname}_{k}_rows8"] = w[:8].view(torch.int16).numpy().copy()
+            arrs[f"{cname}_{k}_sha256"] = np.asarray(hashlib.sha256(w.contiguous().view(torch.int16).numpy().tobytes()).hexdigest())
+        with torch.no_grad():
+            arrs[f"{cname}_logits"] = model(TM.probe_tokens()).logits.float().numpy().astype(np.float16)
+    ref_method.QuantMethod.free = orig_free
+    with torch.no_grad():
+        arrs["fp16_logits"] = TM.build_tiny_opt()(TM.probe_tokens()).logits.float().numpy().astype(np.float16)
+    save("driver", "opt.py:29-190 opt_sequential (the reference driver, unmodified) on tests/golden/tiny_model.py: per-Linear "
+         "error / Hmag, final fp16 weights (first 8 rows + SHA-256), logits; configs nearest_w4, ldlq_w4, ldlq_w2_incoh", **arrs)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rounders":
         gen_rounders()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "driver":
+        gen_driver()
         sys.exit(0)
     gen_grids()
     gen_pack()
@@ -372,3 +421,4 @@ if __name__ == "__main__":
     gen_method()
     gen_counter()
     gen_rounders()
+    gen_driver()

@@ -1,0 +1,51 @@
+"""The tiny random-init OPT model and calibration tokens shared by tests/golden/make_golden.py (which runs the REFERENCE's
+own opt_sequential on it, on CPU, to produce driver.npz) and tests/test_gpu_driver.py (which runs the same call sequence
+on quip_amd, on the GPU, and compares).  Weights come from a seeded numpy RandomState in sorted parameter order, so the
+model does not depend on Hugging Face's initialisers or on torch's RNG."""
+import numpy as np
+import torch
+
+HIDDEN, FFN, LAYERS, HEADS, VOCAB, SEQLEN, NSAMPLES = 256, 1024, 2, 4, 512, 64, 8
+
+
+def build_tiny_opt(seed=1234):
+    from transformers import OPTConfig, OPTForCausalLM
+    cfg = OPTConfig(hidden_size=HIDDEN, ffn_dim=FFN, num_hidden_layers=LAYERS, num_attention_heads=HEADS,
+                    word_embed_proj_dim=HIDDEN, vocab_size=VOCAB, max_position_embeddings=SEQLEN, dropout=0.0,
+                    attention_dropout=0.0, activation_dropout=0.0, layerdrop=0.0)
+    model = OPTForCausalLM(cfg)
+    rs = np.random.RandomState(seed)
+    with torch.no_grad():
+        for name, p in sorted(model.named_parameters(), key=lambda kv: kv[0]):
+            if "layer_norm" in name or "layernorm" in name:
+                v = (1.0 + 0.1 * rs.randn(*p.shape)) if name.endswith("weight") else 0.05 * rs.randn(*p.shape)
+            elif name.endswith("bias"):
+                v = 0.02 * rs.randn(*p.shape)
+            else:
+                v = 0.05 * rs.randn(*p.shape)
+            p.copy_(torch.from_numpy(np.asarray(v, dtype=np.float32)))
+    model = model.half().eval()
+    model.seqlen = SEQLEN
+    return model
+
+
+def calibration_batches(seed=1):
+    rs = np.random.RandomState(seed)
+    toks = rs.randint(0, VOCAB, size=(NSAMPLES, SEQLEN))
+    return [(torch.from_numpy(toks[i:i + 1]).long(), None) for i in range(NSAMPLES)]   # (input_ids, _) like datautils loaders
+
+
+def probe_tokens(seed=2):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy(rs.randint(0, VOCAB, size=(2, SEQLEN))).long()
+
+
+CONFIGS = {
+    # name: the reference driver's argparse namespace for this run (opt.py:485-600)
+    "nearest_w4": dict(quant="nearest", wbits=4, qfn="a", npasses=0, unbiased=False, lazy_batch=False, percdamp=0.01,
+                       pre_gptqH=True, pre_rescale=False, pre_proj=False, pre_proj_extra=0, groupsize=-1),
+    "ldlq_w4": dict(quant="ldlq", wbits=4, qfn="a", npasses=0, unbiased=False, lazy_batch=False, percdamp=0.01,
+                    pre_gptqH=True, pre_rescale=False, pre_proj=False, pre_proj_extra=0, groupsize=-1),
+    "ldlq_w2_incoh": dict(quant="ldlq", wbits=2, qfn="b", npasses=0, unbiased=False, lazy_batch=False, percdamp=0.01,
+                          pre_gptqH=True, pre_rescale=True, pre_proj=True, pre_proj_extra=0, groupsize=-1),
+}
