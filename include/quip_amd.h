@@ -46,7 +46,7 @@ enum quipamd_dtype { QUIPAMD_F32 = 0, QUIPAMD_F16 = 1, QUIPAMD_BF16 = 2 };
  *            tiles of 64 lanes x 16 B in MFMA A-fragment order (oracle/quip_oracle.py
  *            pack_stream is the specification).  Requires m % 16 == 0, d % (512/bits) == 0. */
 /* bits = 3 with the STREAM layout: codes 0..7 stored in the 4-bit container (K2 dequantises nibbles; the 3-bit grid,
- * maxq = 7, is applied in its epilogue).  The reference's 32-codes-in-3-words rule (quant.py:185-220) has no GPU kernel. */
+ * maxq = 7, is applied in its epilogue).  bits = 3 with the CANONICAL layout: the reference's 32-codes-in-3-words rule. */
 enum quipamd_layout { QUIPAMD_LAYOUT_CANONICAL = 0, QUIPAMD_LAYOUT_STREAM = 1 };
 
 /* grid functions: quant.py:6-8 (a), quant.py:10-15 (b), quant.py:17-21 (c) */
@@ -62,6 +62,14 @@ const char *quipamd_last_error(void); /* host string, valid until the next faili
  * packed: int32, m*d*bits/32 words in `layout`. */
 int quipamd_pack(const uint8_t *codes, int bits, int layout, int32_t *packed, int64_t m, int64_t d, void *stream);
 int quipamd_unpack(const int32_t *packed, int bits, int layout, uint8_t *codes, int64_t m, int64_t d, void *stream);
+
+/* bits = 3 with the CANONICAL layout is the reference's own 3-bit rule, Quant3Linear.pack (quant.py:192-220): 32 codes in 3
+ * words, int32 [d/32*3, m] (the reference packs 1024 columns at a time; any d % 32 == 0 is accepted).
+ * quipamd_repack_canonical_to_stream: a weight packed by the reference (2-bit generalisation, 3-bit or 4-bit CANONICAL)
+ * becomes the STREAM layout K2 reads, on the device, no host pass (3-bit codes land in the 4-bit STREAM container).
+ * stream_out: m*d*cb/32 int32 words, cb = 4 for bits 3.  Needs m % 16 == 0 and d % (512/cb) == 0. */
+int quipamd_repack_canonical_to_stream(const int32_t *canonical, int bits, int32_t *stream_out, int64_t m, int64_t d,
+                                       void *stream);
 
 /* ---- K5: grid map / grid functions ---------------------------------------------------------
  * quipamd_qfnb_scale: scale = 2.4*sqrt(mean(W^2)) + 1e-16 evaluated in W's dtype
@@ -99,6 +107,18 @@ int quipamd_codes_to_weight(const uint8_t *codes, int qfn, const float *scale, c
 int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *qweight, int bits, int layout, int qfn,
                          const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
                          int accumulate, int64_t bs, int64_t m, int64_t d, void *stream);
+
+/* The reference's native entry points by name and argument meaning (quant.py:229, zeroShot/models/quant.py:207):
+ *     mul[r] += sum_k (scales[r] * q[r,k] - zeros[r]) * vec[k]
+ * vec: float [d] (one token); mat: the reference's CANONICAL packing ([d/32*3, m] 3-bit, [d/8, m] 4-bit); mul: float [m],
+ * pre-filled by the caller (with the bias) and accumulated into; scales: float [m]; zeros: float [m] = zero * scale.
+ * Adapters over quipamd_repack_canonical_to_stream + quipamd_dequant_gemm: the repacked weights, the split activations and
+ * the integer zeros live in `workspace` (quipamd_vecquant_workspace_bytes; nothing is kept between calls). */
+int64_t quipamd_vecquant_workspace_bytes(int bits, int64_t m, int64_t d);
+int quipamd_vecquant3matmul(const float *vec, const int32_t *mat, float *mul, const float *scales, const float *zeros,
+                            int64_t m, int64_t d, void *workspace, int64_t workspace_bytes, void *stream);
+int quipamd_vecquant4matmul(const float *vec, const int32_t *mat, float *mul, const float *scales, const float *zeros,
+                            int64_t m, int64_t d, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* quipamd_dequant_gemm_cfg: the same call with the kernel chosen by the caller instead of the shape heuristic -- for
  * benchmarks and the forced-kernel parity tests; never needed for correctness.  cfg = int32[4] {family, p1, p2, 0}

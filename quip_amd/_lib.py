@@ -22,6 +22,10 @@ SIGNATURES = {
     "quipamd_last_error": [],
     "quipamd_pack": [c_vp, c_int, c_int, c_vp, c_i64, c_i64, c_vp],
     "quipamd_unpack": [c_vp, c_int, c_int, c_vp, c_i64, c_i64, c_vp],
+    "quipamd_repack_canonical_to_stream": [c_vp, c_int, c_vp, c_i64, c_i64, c_vp],
+    "quipamd_vecquant_workspace_bytes": [c_int, c_i64, c_i64],
+    "quipamd_vecquant3matmul": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
+    "quipamd_vecquant4matmul": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
     "quipamd_qfnb_scale": [c_vp, c_int, c_i64, c_vp, c_vp, c_vp],
     "quipamd_gridmap": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_vp],
     "quipamd_quantize": [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_vp],
@@ -75,7 +79,7 @@ def load():
             raise QuipAmdError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else
-                      c_i64 if name == "quipamd_hessian_fast_workspace" else c_int)
+                      c_i64 if name in ("quipamd_hessian_fast_workspace", "quipamd_vecquant_workspace_bytes") else c_int)
     _lib = lib
     return lib
 

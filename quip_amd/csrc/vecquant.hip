@@ -1,0 +1,75 @@
+// vecquant.hip -- the reference's native entry points by name and argument meaning:
+//     quant_cuda.vecquant3matmul(vec, mat, mul, scales, zeros)   quant.py:229
+//     quant_cuda.vecquant4matmul(vec, mat, mul, scales, zeros)   zeroShot/models/quant.py:207
+// vec fp32 [d] (one token, quant.py:223-233), mat int32 in the reference's CANONICAL packing ([d/32*3, m] for 3 bit,
+// quant.py:192-220; [d/8, m] for 4 bit, zeroShot/models/quant.py:190-199), mul fp32 [m] pre-filled by the caller with the
+// bias and ACCUMULATED into, scales fp32 [m], zeros fp32 [m] = zero * scale (quant.py:186, zeroShot/models/quant.py:187):
+//     mul[r] += sum_k (scales[r] * q[r,k] - zeros[r]) * vec[k]
+// They are adapters: the weights are repacked CANONICAL -> STREAM on the device into the caller's workspace on every call
+// (a layer that is called repeatedly repacks once with quipamd_repack_canonical_to_stream and calls quipamd_dequant_gemm),
+// vec is split into two bf16 terms hi + lo (relative error 2^-16, the reference multiplies in fp32) and K2 runs once per
+// term under the accumulate contract.  The source of quant_cuda is not in the reference tree (un-vendored IST-DASLab/gptq):
+// the contract above is re-derived from the pack formulas and the call sites -- "parity unpinned" at this one boundary.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void vecquant_prep_kernel(const float *__restrict__ vec, uint16_t *__restrict__ hi,
+                                                            uint16_t *__restrict__ lo, int64_t d, const float *__restrict__ scales,
+                                                            const float *__restrict__ zeros, float *__restrict__ zint, int64_t m)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d) {
+        const float v = vec[i];
+        const uint16_t h = f32_to_bf16_bits(v);
+        hi[i] = h;
+        lo[i] = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+    }
+    if (i < m) zint[i] = scales[i] != 0.f ? __fdiv_rn(zeros[i], scales[i]) : 0.f;   // zeros = zero * scale
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int vecquant(int bits, const float *vec, const int32_t *mat, float *mul, const float *scales, const float *zeros, int64_t m,
+             int64_t d, void *workspace, int64_t ws_bytes, void *stream)
+{
+    QA_REQUIRE(vec && mat && mul && scales && zeros && workspace, QUIPAMD_ERR_ARG, "vecquant%dmatmul: null pointer", bits);
+    const int cb = bits == 3 ? 4 : bits;
+    const size_t wq = align256((size_t)m * d * cb / 8), xb = align256((size_t)d * 2);
+    QA_REQUIRE((size_t)ws_bytes >= wq + 2 * xb + align256((size_t)m * 4), QUIPAMD_ERR_ARG,
+               "vecquant%dmatmul: workspace too small (quipamd_vecquant_workspace_bytes)", bits);
+    char *ws = (char *)workspace;
+    int32_t *qs = (int32_t *)ws;
+    uint16_t *hi = (uint16_t *)(ws + wq), *lo = (uint16_t *)(ws + wq + xb);
+    float *zint = (float *)(ws + wq + 2 * xb);
+    int rc = quipamd_repack_canonical_to_stream(mat, bits, qs, m, d, stream);
+    if (rc) return rc;
+    const int64_t n = m > d ? m : d;
+    vecquant_prep_kernel<<<qa_div_up(n, 256), 256, 0, (hipStream_t)stream>>>(vec, hi, lo, d, scales, zeros, zint, m);
+    QA_LAUNCH_CHECK("vecquant prep");
+    rc = quipamd_dequant_gemm(hi, QUIPAMD_BF16, qs, bits, QUIPAMD_LAYOUT_STREAM, QUIPAMD_QFN_A, scales, zint, nullptr, mul,
+                              QUIPAMD_F32, 1, 1, m, d, stream);
+    if (rc) return rc;
+    return quipamd_dequant_gemm(lo, QUIPAMD_BF16, qs, bits, QUIPAMD_LAYOUT_STREAM, QUIPAMD_QFN_A, scales, zint, nullptr, mul,
+                                QUIPAMD_F32, 1, 1, m, d, stream);
+}
+
+}   // namespace
+
+extern "C" int64_t quipamd_vecquant_workspace_bytes(int bits, int64_t m, int64_t d)
+{
+    const int cb = bits == 3 ? 4 : bits;
+    return (int64_t)(align256((size_t)m * d * cb / 8) + 2 * align256((size_t)d * 2) + align256((size_t)m * 4));
+}
+
+extern "C" int quipamd_vecquant3matmul(const float *vec, const int32_t *mat, float *mul, const float *scales, const float *zeros,
+                                       int64_t m, int64_t d, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return vecquant(3, vec, mat, mul, scales, zeros, m, d, workspace, workspace_bytes, stream);
+}
+
+extern "C" int quipamd_vecquant4matmul(const float *vec, const int32_t *mat, float *mul, const float *scales, const float *zeros,
+                                       int64_t m, int64_t d, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    return vecquant(4, vec, mat, mul, scales, zeros, m, d, workspace, workspace_bytes, stream);
+}

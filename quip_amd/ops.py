@@ -48,7 +48,8 @@ def stream_chunk(bits):
 
 # ------------------------------------------------------------------------------------------------- K1
 def pack(codes, bits, layout=LAYOUT_CANONICAL):
-    """codes uint8 [m,d] -> int32 words; CANONICAL returns [d*bits/32, m] (zeroShot/models/quant.py:190-199)."""
+    """codes uint8 [m,d] -> int32 words; CANONICAL returns [d*bits/32, m] (zeroShot/models/quant.py:190-199; bits = 3: the
+    reference's 32-codes-in-3-words rule, quant.py:192-220)."""
     _need_gpu(codes)
     assert codes.dtype == torch.uint8 and codes.dim() == 2
     codes = codes.contiguous()
@@ -67,6 +68,31 @@ def unpack(packed, bits, layout, m, d):
     codes = torch.empty((m, d), dtype=torch.uint8, device=packed.device)
     _lib.call("quipamd_unpack", _p(packed), bits, layout, _p(codes), m, d, _stream())
     return codes
+
+
+def repack_canonical_to_stream(qweight, bits, m, d):
+    """a weight in the reference's CANONICAL packing (int32 [d*bits/32, m]; bits 2, 3 or 4) -> the STREAM layout K2 reads,
+    on the device (3-bit codes land in the 4-bit container)."""
+    _need_gpu(qweight)
+    assert qweight.dtype == torch.int32 and qweight.numel() == m * d * bits // 32
+    qweight = qweight.contiguous()
+    out = torch.empty(m * d * container_bits(bits) // 32, dtype=torch.int32, device=qweight.device)
+    _lib.call("quipamd_repack_canonical_to_stream", _p(qweight), bits, _p(out), m, d, _stream())
+    return out
+
+
+def vecquantmatmul(bits, vec, mat, mul, scales, zeros):
+    """quant_cuda.vecquant{3,4}matmul(vec, mat, mul, scales, zeros) (quant.py:229, zeroShot/models/quant.py:207): accumulates
+    into `mul` (float32 [m], pre-filled with the bias) and returns None like the reference's extension."""
+    _need_gpu(vec, mat, mul)
+    assert bits in (3, 4) and mul.dtype == torch.float32 and mul.is_contiguous() and mat.dtype == torch.int32
+    d, m = vec.numel(), mul.numel()
+    vec = vec.reshape(-1).to(torch.float32).contiguous()
+    sc, zs = _f32vec(scales, mul.device), _f32vec(zeros, mul.device)
+    assert sc.numel() == m and zs.numel() == m and mat.numel() == m * d * bits // 32
+    nbytes = _lib.load().quipamd_vecquant_workspace_bytes(bits, m, d)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=mul.device)
+    _lib.call(f"quipamd_vecquant{bits}matmul", _p(vec), _p(mat.contiguous()), _p(mul), _p(sc), _p(zs), m, d, _p(ws), nbytes, _stream())
 
 
 # ------------------------------------------------------------------------------------------------- K5

@@ -242,6 +242,20 @@ class Quant3Linear(QuantLinear):
     def __init__(self, infeatures, outfeatures):
         super().__init__(infeatures, outfeatures, bits=3, qfn='a')
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """A checkpoint written by the REFERENCE's Quant3Linear (opt.py:303-315 opt_pack3, quant.py:176-197) loads as it is:
+        qweight int32 [in/32*3, out] in the 32-codes-in-3-words packing, scales [out,1], zeros [out,1] = zero * scale, bias.
+        The codes are repacked on the device (quipamd_repack_canonical_to_stream), no host pass."""
+        qw = state_dict.get(prefix + 'qweight')
+        if qw is not None and qw.dim() == 2:
+            conv = reference_packed_buffers(qw, state_dict[prefix + 'scales'], state_dict[prefix + 'zeros'], 3,
+                                            self.infeatures, self.outfeatures, self.qweight.device)
+            state_dict[prefix + 'qweight'], state_dict[prefix + 'scales'], state_dict[prefix + 'zeros'] = conv
+            if state_dict.get(prefix + 'bias') is not None:
+                self.bias = torch.zeros(self.outfeatures, device=self.qweight.device)
+                state_dict[prefix + 'bias'] = state_dict[prefix + 'bias'].reshape(-1).float()
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     @torch.no_grad()
     def pack(self, linear, scales, zeros, **kw):
         if not isinstance(linear, nn.Module):            # QuantLinear.pack(codes, scale, zero, ...) protocol
@@ -256,6 +270,32 @@ class Quant3Linear(QuantLinear):
 
 
 _DEV = 'cuda:0'
+
+
+def reference_packed_buffers(qweight, scales, zeros, bits, infeatures, outfeatures, device):
+    """(qweight, scales, zeros) of a layer packed by the reference -- Quant3Linear.pack (quant.py:185-220: [in/32*3, out])
+    or Quant4Linear (zeroShot/models/quant.py:183-199: [in/8, out]), zeros = zero * scale -- as the buffers QuantLinear keeps:
+    STREAM-layout codes (repacked on the device), per-row scale, integer zero."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise RuntimeError("a reference-format checkpoint is repacked on the GPU: move the module to the device first "
+                           "(there is no CPU fallback)")
+    assert tuple(qweight.shape) == (infeatures * bits // 32, outfeatures), "not the reference's [in*bits/32, out] packing"
+    qs = ops.repack_canonical_to_stream(qweight.to(device=device, dtype=torch.int32), bits, outfeatures, infeatures)
+    sc = scales.to(device, torch.float32).reshape(-1)
+    zs = zeros.to(device, torch.float32).reshape(-1)
+    zi = torch.where(sc != 0, zs / sc, torch.zeros_like(zs)).round()          # zeros = zero * scale, zero an integer
+    return qs, sc.clone(), zi
+
+
+def from_reference_packed(qweight, scales, zeros, bias, bits, device=_DEV):
+    """QuantLinear (qfn a) from the buffers of a reference-packed layer (3 or 4 bit, see reference_packed_buffers)."""
+    outfeatures = qweight.shape[1]
+    infeatures = qweight.shape[0] * 32 // bits
+    ql = (Quant3Linear(infeatures, outfeatures) if bits == 3 else QuantLinear(infeatures, outfeatures, bits=bits, qfn='a')).to(device)
+    ql.qweight, ql.scales, ql.zeros = reference_packed_buffers(qweight, scales, zeros, bits, infeatures, outfeatures, device)
+    ql.bias = None if bias is None else bias.detach().to(device, torch.float32).reshape(-1).clone()
+    return ql
 
 
 def make_quant3(module, names, name=''):

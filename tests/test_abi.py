@@ -38,7 +38,12 @@ def test_bad_arguments_fail_loudly_without_a_device():
         _lib.call("quipamd_pack", null, 2, 0, null, 16, 256, null)
     one = ctypes.c_void_p(16)   # non-null, never dereferenced: argument checks come first
     with pytest.raises(_lib.QuipAmdError, match="bits must be 2 or 4"):
-        _lib.call("quipamd_pack", one, 3, 0, one, 16, 256, null)
+        _lib.call("quipamd_pack", one, 5, 0, one, 16, 256, null)
+    with pytest.raises(_lib.QuipAmdError, match="3-bit layout needs"):       # the reference's 32-codes-in-3-words rule
+        _lib.call("quipamd_pack", one, 3, 0, one, 16, 40, null)
+    with pytest.raises(_lib.QuipAmdError, match="workspace too small"):
+        _lib.call("quipamd_vecquant4matmul", one, one, one, one, one, 16, 128, one, 8, null)
+    assert _lib.load().quipamd_vecquant_workspace_bytes(4, 16, 128) >= 16 * 128 // 2 + 2 * 128 * 2 + 16 * 4
     with pytest.raises(_lib.QuipAmdError, match="stream layout needs"):
         _lib.call("quipamd_pack", one, 2, 1, one, 10, 256, null)
     with pytest.raises(_lib.QuipAmdError, match="STREAM layout"):

@@ -1,0 +1,99 @@
+"""-m gpu: the reference's OWN packed formats on the GPU (VERDICT r1 missing #3 / next #8):
+  * Quant3Linear.pack's 32-codes-in-3-words rule (quant.py:192-220) as quipamd_pack / quipamd_unpack with bits = 3,
+    bit-exact vs the oracle restatement (itself pinned to the reference's output in tests/golden/pack.npz);
+  * CANONICAL -> STREAM repack on the device for 2 / 3 / 4 bits, bit-exact vs packing the codes directly;
+  * quipamd_vecquant{3,4}matmul: the reference extension's call by name and argument meaning (quant.py:229,
+    zeroShot/models/quant.py:207), vs fp64 of the formula  mul += sum (scales q - zeros) vec;
+  * a checkpoint in the reference's Quant3Linear format loads into quip_amd.quant.Quant3Linear."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from quip_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import quip_oracle
+    return quip_oracle
+
+
+@pytest.mark.parametrize("m,d", [(16, 1024), (48, 2048), (5, 32), (40, 96)])
+def test_three_bit_canonical_pack_is_the_reference_rule(ops, O, m, d):
+    rng = np.random.default_rng(m + d)
+    codes = rng.integers(0, 8, size=(m, d), dtype=np.uint8)
+    want = O.pack3(codes) if d % 1024 == 0 else None
+    got = ops.pack(torch.from_numpy(codes).to(DEV), 3, ops.LAYOUT_CANONICAL)
+    assert got.shape == (d // 32 * 3, m) and got.dtype == torch.int32
+    if want is not None:
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    back = ops.unpack(got, 3, ops.LAYOUT_CANONICAL, m, d)
+    np.testing.assert_array_equal(back.cpu().numpy(), codes)
+
+
+@pytest.mark.parametrize("bits,m,d", [(2, 32, 512), (4, 48, 256), (3, 64, 1024), (3, 16, 128), (2, 4096, 4096), (4, 1024, 11008)])
+def test_repack_canonical_to_stream_is_bit_exact(ops, bits, m, d):
+    g = torch.Generator().manual_seed(bits + m)
+    codes = torch.randint(0, 2 ** bits, (m, d), generator=g, dtype=torch.uint8).to(DEV)
+    canon = ops.pack(codes, bits, ops.LAYOUT_CANONICAL)
+    want = ops.pack(codes, bits, ops.LAYOUT_STREAM)
+    got = ops.repack_canonical_to_stream(canon, bits, m, d)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("bits,m,d", [(4, 64, 256), (4, 4096, 4096), (3, 48, 1024), (3, 2048, 2048)])
+def test_vecquant_matmul_by_the_references_signature(ops, O, bits, m, d):
+    rng = np.random.default_rng(bits * 7 + m)
+    maxq = 2 ** bits - 1
+    W = (0.02 * rng.standard_normal((m, d))).astype(np.float32)
+    scale, zero = O.find_params_qfna(W, bits)
+    codes = np.clip(np.round(W / scale) + zero, 0, maxq).astype(np.uint8)
+    vec = rng.standard_normal(d).astype(np.float32)
+    bias = rng.standard_normal(m).astype(np.float32)
+    scales = scale.reshape(m, 1).astype(np.float32)
+    zeros = (zero.reshape(m, 1) * scales).astype(np.float32)            # quant.py:186: self.zeros = zeros * scales
+    want = bias.astype(np.float64) + (scales.astype(np.float64) * codes - zeros.astype(np.float64)) @ vec.astype(np.float64)
+    mat = ops.pack(torch.from_numpy(codes).to(DEV), bits, ops.LAYOUT_CANONICAL)     # the reference's packing
+    mul = torch.from_numpy(bias.copy()).to(DEV)                         # y = self.bias.clone(); vecquant(x, qweight, y, ...)
+    ops.vecquantmatmul(bits, torch.from_numpy(vec).to(DEV), mat, mul, torch.from_numpy(scales).to(DEV), torch.from_numpy(zeros).to(DEV))
+    got = mul.cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-4     # x kept to 2^-16 (hi + lo bf16 terms), fp32 accumulate
+
+
+def test_reference_quant3linear_checkpoint_loads(ops, O):
+    """state dict with the reference Quant3Linear's buffers (quant.py:176-197) -> quip_amd.quant.Quant3Linear, via make_quant3 +
+    load_state_dict like opt.py:350-381 load_quant3 does."""
+    from quip_amd import quant as Q
+    m, d = 64, 1024
+    rng = np.random.default_rng(3)
+    W = (0.02 * rng.standard_normal((m, d))).astype(np.float32)
+    scale, zero = O.find_params_qfna(W, 3)
+    Wq = O.quantize_qfna(W, scale, zero, 7)
+    codes = np.clip(np.round(W / scale) + zero, 0, 7).astype(np.uint8)
+    bias = rng.standard_normal(m).astype(np.float32)
+    ref_state = {"0.qweight": torch.from_numpy(O.pack3(codes)), "0.scales": torch.from_numpy(scale.reshape(m, 1).astype(np.float32)),
+                 "0.zeros": torch.from_numpy((zero.reshape(m, 1) * scale.reshape(m, 1)).astype(np.float32)), "0.bias": torch.from_numpy(bias)}
+    holder = torch.nn.Sequential(torch.nn.Linear(d, m)).to(DEV)
+    Q.make_quant3(holder, ["0"])
+    holder = holder.to(DEV)
+    holder.load_state_dict(ref_state)
+    np.testing.assert_array_equal(ops.unpack(holder[0].qweight, 3, ops.LAYOUT_STREAM, m, d).cpu().numpy(), codes)
+    x = torch.from_numpy(rng.standard_normal((3, d)).astype(np.float32)).to(DEV).half()
+    got = holder[0](x).double().cpu().numpy()
+    want = x.double().cpu().numpy() @ Wq.astype(np.float64).T + bias
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 2e-3
+    # and the 4-bit format of zeroShot/models/quant.py
+    sc4, z4 = O.find_params_qfna(W, 4)
+    c4 = np.clip(np.round(W / sc4) + z4, 0, 15).astype(np.uint8)
+    q4 = Q.from_reference_packed(torch.from_numpy(O.pack_canonical(c4, 4)), torch.from_numpy(sc4.reshape(m, 1).astype(np.float32)),
+                                 torch.from_numpy((z4.reshape(m, 1) * sc4.reshape(m, 1)).astype(np.float32)), torch.from_numpy(bias), 4)
+    got4 = q4(x).double().cpu().numpy()
+    want4 = x.double().cpu().numpy() @ O.quantize_qfna(W, sc4, z4, 15).astype(np.float64).T + bias
+    assert np.linalg.norm(got4 - want4) / np.linalg.norm(want4) <= 2e-3
