@@ -326,6 +326,15 @@ def main():
             out["sharded_ldlq"] = {"what": f"LDLQ codes of one {lm}x{ld} Linear (OPT-30B fc1 shape), w{BITS}, rows over {world} rank(s); "
                                            "wall time incl. LT broadcast, row scatter, code gather",
                                    "ms": round(tl * 1e3, 3), "far_field_TFLOPs": round(lm * ld * ld / tl / 1e12, 2), "scaling": "strong"}
+            if world > 1:                          # one more pass with per-phase synchronisation: where the time and the bytes go
+                shard.TIMING = True
+                barrier()
+                shard.ldlq_round_sharded(wg, LT, BITS)
+                barrier()
+                shard.TIMING = False
+                if rank == 0:
+                    st = dict(shard.last_stats)
+                    out["sharded_ldlq"]["exchange"] = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in st.items()}
         except Exception as ex:                       # a side measurement must never take the headline line down
             out["sharded_ldlq"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 

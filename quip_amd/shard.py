@@ -66,7 +66,21 @@ def _unpack_all(words, bits, m, d):
     return ops.unpack(words, bits, ops.LAYOUT_STREAM, m, d)
 
 
-def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=None, gather_packed=None):
+last_stats = {}      # owner side, filled by every ldlq_round_sharded call: bytes per phase (and seconds when timing is on)
+TIMING = False       # True: synchronise around every phase and record wall-clock seconds in last_stats (benchmarks only)
+
+
+def _tick(dev):
+    if TIMING:
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        import time
+        return time.perf_counter()
+    return 0.0
+
+
+def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=None, gather_packed=None, force_exchange=False,
+                       lt_ready=None, next_LT=None):
     """LDLQ codes of one Linear with its rows split over the ranks of `group`.
     gather_packed: return the codes to the owner as STREAM-packed words (bits/8 bytes per code instead of 1; the
     STREAM layout is row-tile-major, so the per-rank chunks concatenate into the whole matrix's packing).  Default:
@@ -75,20 +89,27 @@ def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=Non
     Collective: every rank calls it.  On `src`: wgrid float32 [m,d] grid coordinates, LT float32 [d,d]
     (ops.unit_lower_t of the Cholesky factor), eta float32 [m,d] or None; returns codes uint8 [m,d].
     On the other ranks the tensor arguments are ignored (pass None) and None is returned.
-    `compute(wgrid_chunk, LT, bits, eta_chunk) -> uint8 codes` defaults to the HIP kernel."""
+    `compute(wgrid_chunk, LT, bits, eta_chunk) -> uint8 codes` defaults to the HIP kernel.
+    force_exchange: run broadcast / scatter / gather (and the HIP pack / unpack around the gather) also with ONE rank -- how a
+    single-GPU box exercises the RCCL path.
+    lt_ready: (LT tensor on the comm device, work handle | None) prefetched by a previous call's `next_LT` on every rank: the
+    LT broadcast of this job is skipped.  next_LT (owner: float32 [d2, d2], others: anything non-None the header says): the
+    NEXT job's LT is broadcast between this job's scatter and its compute, i.e. it travels while every rank rounds
+    (SURVEY.md 8(e)); returned as the second element of the result tuple (codes | None, (LT_next, work))."""
     compute = compute or _default_compute
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = _comm_device(group)
-    hdr = torch.zeros(4, dtype=torch.int64, device=dev)
+    hdr = torch.zeros(6, dtype=torch.int64, device=dev)
     if rank == src:
         assert wgrid.dim() == 2 and LT.shape == (wgrid.shape[1], wgrid.shape[1])
-        hdr = torch.tensor([wgrid.shape[0], wgrid.shape[1], int(bits), int(eta is not None)], dtype=torch.int64,
-                           device=dev)
-    if world > 1:
+        hdr = torch.tensor([wgrid.shape[0], wgrid.shape[1], int(bits), int(eta is not None), int(lt_ready is not None),
+                            0 if next_LT is None else next_LT.shape[0]], dtype=torch.int64, device=dev)
+    if world > 1 or force_exchange:
         dist.broadcast(hdr, src=src, group=group)
-    m, d, bits, has_eta = (int(v) for v in hdr.tolist())
-    if world == 1:
-        return compute(wgrid, LT, bits, eta)
+    m, d, bits, has_eta, lt_pref, d_next = (int(v) for v in hdr.tolist())
+    if world == 1 and not force_exchange:
+        out = compute(wgrid, LT, bits, eta)
+        return (out, None) if next_LT is not None else out
     if gather_packed is None:
         gather_packed = dist.get_backend(group) == "nccl" and bits in (2, 4) and d % (512 // bits) == 0
 
@@ -101,11 +122,22 @@ def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=Non
             t = torch.cat([t, torch.zeros(pad, d, dtype=torch.float32, device=dev)], 0)
         return list(t.split(c, 0))
 
-    if rank == src:
-        LT = LT.to(dev, torch.float32).contiguous()
+    stats = {"world": world, "m": m, "d": d, "bytes_broadcast_LT": 0, "bytes_scatter": 0, "bytes_gather": 0}
+    t0 = _tick(dev)
+    if lt_pref:                                                       # prefetched under the previous job's rounding
+        assert lt_ready is not None, "the owner announced a prefetched LT this rank does not hold"
+        LT, work = lt_ready
+        if work is not None:
+            work.wait()
+        assert LT.shape == (d, d)
     else:
-        LT = torch.empty(d, d, dtype=torch.float32, device=dev)
-    dist.broadcast(LT, src=src, group=group)                          # the one tree/ring-shaped transfer
+        if rank == src:
+            LT = LT.to(dev, torch.float32).contiguous()
+        else:
+            LT = torch.empty(d, d, dtype=torch.float32, device=dev)
+        dist.broadcast(LT, src=src, group=group)                      # the one tree/ring-shaped transfer
+        stats["bytes_broadcast_LT"] = 4 * d * d
+    t1 = _tick(dev)
 
     mine = torch.empty(c, d, dtype=torch.float32, device=dev)
     dist.scatter(mine, padded_chunks(wgrid) if rank == src else None, src=src, group=group)
@@ -113,42 +145,83 @@ def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=Non
     if has_eta:
         eta_mine = torch.empty(c, d, dtype=torch.float32, device=dev)
         dist.scatter(eta_mine, padded_chunks(eta) if rank == src else None, src=src, group=group)
+    stats["bytes_scatter"] = 4 * c * d * (world - 1) * (2 if has_eta else 1)
+    t2 = _tick(dev)
+
+    nxt = None
+    if d_next:                                                        # the next job's LT rides under this job's rounding
+        if rank == src:
+            nl = next_LT.to(dev, torch.float32).contiguous()
+        else:
+            nl = torch.empty(d_next, d_next, dtype=torch.float32, device=dev)
+        nxt = (nl, dist.broadcast(nl, src=src, group=group, async_op=True))
+        stats["bytes_broadcast_next_LT"] = 4 * d_next * d_next
 
     lo, hi = row_partition(m, world)[rank]
     n_real = hi - lo
     codes = torch.zeros(c, d, dtype=torch.uint8, device=dev)
     if n_real > 0:                                                    # padded rows are never rounded
         codes[:n_real] = compute(mine[:n_real], LT, bits, None if eta_mine is None else eta_mine[:n_real])
+    t3 = _tick(dev)
+
+    def done(out):
+        if rank == src:
+            t4 = _tick(dev)
+            stats["bytes_gather"] = (c * d * bits // 8 if gather_packed else c * d) * (world - 1)
+            if TIMING:
+                stats.update({"s_broadcast_LT": t1 - t0, "s_scatter": t2 - t1, "s_round": t3 - t2, "s_gather": t4 - t3})
+            last_stats.clear()
+            last_stats.update(stats)
+        return (out, nxt) if d_next else out
 
     if gather_packed:
         words = _pack_chunk(codes, bits)                               # c*d*bits/32 int32 words, whole 16-row tiles
         parts = [torch.empty_like(words) for _ in range(world)] if rank == src else None
         dist.gather(words, parts, dst=src, group=group)
         if rank != src:
-            return None
-        return _unpack_all(torch.cat(parts, 0), bits, c * world, d)[:m].contiguous()
+            return done(None)
+        return done(_unpack_all(torch.cat(parts, 0), bits, c * world, d)[:m].contiguous())
     parts = [torch.empty(c, d, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == src else None
     dist.gather(codes, parts, dst=src, group=group)
     if rank != src:
-        return None
-    return torch.cat(parts, 0)[:m].contiguous()
+        return done(None)
+    return done(torch.cat(parts, 0)[:m].contiguous())
 
 
 class ShardedLDLQ:
     """Owner-side handle used by vector_balance.quantize_weight_vecbal when a process group with more than one
     rank is active: announces a job to the ranks parked in serve(), then joins the collective itself."""
 
-    def __init__(self, group=None, src=0, compute=None):
-        self.group, self.src, self.compute = group, src, compute
+    def __init__(self, group=None, src=0, compute=None, force_exchange=False):
+        self.group, self.src, self.compute, self.force_exchange = group, src, compute, force_exchange
+        self._lt_ready = None      # (LT, work): the coming job's LT, already broadcast under the previous job's rounding
+        self._queue = []           # LT factors of the coming round() calls, in call order (queue_LTs)
 
     def _announce(self, op):
         dev = _comm_device(self.group)
         dist.broadcast(torch.tensor([op], dtype=torch.int64, device=dev), src=self.src, group=self.group)
 
+    def queue_LTs(self, LTs):
+        """The driver knows the LT factors of the next Linears it will round (all Hessians of a transformer block exist
+        before its first Linear is rounded, opt.py:141-150): queue them in call order.  round() then takes its LT from the
+        queue and broadcasts the FOLLOWING one while every rank rounds the current one."""
+        self._queue = list(LTs)
+
+    def queued(self):
+        return bool(self._queue)
+
     def round(self, wgrid, LT, bits, eta=None):
         if dist.get_world_size(self.group) > 1:
             self._announce(_OP_LDLQ)
-        return ldlq_round_sharded(wgrid, LT, bits, eta=eta, src=self.src, group=self.group, compute=self.compute)
+        if self._queue:
+            LT = self._queue.pop(0)
+        nxt = self._queue[0] if self._queue else None
+        ready, self._lt_ready = self._lt_ready, None
+        out = ldlq_round_sharded(wgrid, LT, bits, eta=eta, src=self.src, group=self.group, compute=self.compute,
+                                 force_exchange=self.force_exchange, lt_ready=ready, next_LT=nxt)
+        if nxt is not None:
+            out, self._lt_ready = out
+        return out
 
     def shutdown(self):
         if dist.get_world_size(self.group) > 1:
@@ -159,13 +232,14 @@ def serve(group=None, src=0, compute=None):
     """Worker loop for every rank except the owner: wait for a job header, join the collective, repeat until the
     owner calls ShardedLDLQ.shutdown().  Returns the number of jobs served."""
     dev = _comm_device(group)
-    jobs = 0
+    jobs, ready = 0, None
     while True:
         op = torch.zeros(1, dtype=torch.int64, device=dev)
         dist.broadcast(op, src=src, group=group)
         if int(op.item()) == _OP_STOP:
             return jobs
-        ldlq_round_sharded(None, None, 0, src=src, group=group, compute=compute)
+        out = ldlq_round_sharded(None, None, 0, src=src, group=group, compute=compute, lt_ready=ready, next_LT=True)
+        ready = out[1] if isinstance(out, tuple) else None           # a prefetched LT for the next job, if the owner sent one
         jobs += 1
 
 
@@ -197,6 +271,9 @@ def all_reduce_hessians(methods, group=None):
     tri = torch.tensor([1.0 if getattr(m, "_tri", False) else 0.0 for m in methods], dtype=torch.float64, device=dev)
     dist.all_reduce(tri, op=dist.ReduceOp.MAX, group=group)
     for m, n, t in zip(methods, counts.tolist(), tri.tolist()):
+        if m.H is None:                     # a follower of QuantMethod.share_hessian_from (q/k/v share one accumulator): its
+            m.nsamples = int(round(n))      # leader's H is reduced once; only the sample count is per method
+            continue
         assert m.H.dtype == torch.float64, "all_reduce_hessians: call before post_batch"
         H = m.H if m.H.device == dev else m.H.to(dev)
         dist.all_reduce(H, group=group)

@@ -60,11 +60,11 @@ def _round_ldl_codes(w, H, nbits, n_greedy_passes, unbiased):
         codes = ops.ldlq_round(w, _ldl_transposed(H), nbits, eta=None)
         return _greedy_passes(w, codes, H.to(torch.float32), nbits, n_greedy_passes)
     eta = torch.rand(w.shape).to(w.device) if unbiased else None     # same CPU draw as vector_balance.py:174-175
-    LT = _ldl_transposed(H)
     sharded = shard.active()
     if sharded is not None:                                           # rows split over the ranks of the node (shard.py)
+        LT = None if sharded.queued() else _ldl_transposed(H)         # queued: the driver factored this block's H up front
         return sharded.round(w, LT, nbits, eta=eta)
-    return ops.ldlq_round(w, LT, nbits, eta=eta)
+    return ops.ldlq_round(w, _ldl_transposed(H), nbits, eta=eta)
 
 
 def round_ldl(w, H, nbits, n_greedy_passes=9, unbiased=False):
@@ -112,10 +112,13 @@ def quantize_weight_vecbal(w, H, nbits, npasses, scale, zero, maxq, unbiased=Fal
     """grid map -> LDLQ -> weights, returned as fp16 like the reference (vector_balance.py:500-532).
     return_codes=True additionally returns (codes uint8 [m,d], scale fp32, zero fp32|None): the integer state
     the reference throws away and a packed layer needs (SURVEY.md section 7 "hard parts")."""
-    if qmethod not in ('ldlq', 'ldlqRG'):
-        raise NotImplementedError(f"qmethod {qmethod!r} is outside the quip_amd hot path (only 'ldlq' / 'ldlqRG')")
+    if qmethod not in ('ldlq', 'ldlqRG', 'ldl_gptqequiv'):
+        raise NotImplementedError(f"qmethod {qmethod!r} is outside the quip_amd hot path (only 'ldlq' / 'ldlqRG' / 'ldl_gptqequiv')")
     mq = int(maxq.item()) if torch.is_tensor(maxq) else int(maxq)
-    if qmethod == 'ldlqRG':                       # sort the columns by diag(H), round, undo the sort (:139-153)
+    if qmethod == 'ldl_gptqequiv':                # optq_ldlq_equiv.py: LDLQ in OPTQ's column order (vector_balance.py:381-422, :508)
+        def rounder(wgrid):
+            return round_ldl_gptqequiv(wgrid, H, nbits, unbiased=unbiased).to(torch.uint8)
+    elif qmethod == 'ldlqRG':                       # sort the columns by diag(H), round, undo the sort (:139-153)
         perm = torch.argsort(torch.diag(H))
         inv = torch.empty_like(perm)
         inv[perm] = torch.arange(perm.numel(), device=perm.device)

@@ -1,0 +1,81 @@
+"""-m gpu (one GPU): the RCCL branch of quip_amd/shard.py for real -- a world-1 `nccl` process group with force_exchange:
+broadcast / scatter / gather run through RCCL on HIP memory, the codes travel STREAM-packed (HIP pack kernel before the
+gather, HIP unpack after it), K4 rounds the chunk.  Until now that branch had only been exercised with gloo and an injected
+CPU kernel.  Then the torchrun-able sharded driver (scripts/quantize_opt_sharded.py) end to end with one
+rank, against the unsharded driver sequence."""
+import importlib.util
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def nccl_group():
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    yield
+    dist.destroy_process_group()
+
+
+def _fixture(m, d, seed):
+    from quip_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(d, d, generator=g) / d ** 0.5
+    X = (torch.randn(2 * d, d, generator=g) * torch.arange(1, d + 1) ** -0.75) @ A
+    H = (X.T @ X / (2 * d)).to(DEV)
+    H = H + 0.01 * H.diag().mean() * torch.eye(d, device=DEV)
+    LT = ops.cholesky_lt(H)
+    W = (torch.rand(m, d, generator=g) * 3.6 - 0.3).clamp(0, 3).to(DEV)
+    return W, LT
+
+
+@pytest.mark.parametrize("m,d,bits", [(256, 512, 2), (1000, 1024, 2), (96, 256, 4)])
+def test_rccl_exchange_with_hip_pack_unpack(nccl_group, m, d, bits):
+    from quip_amd import ops, shard
+    W, LT = _fixture(m, d, seed=m)
+    want = ops.ldlq_round(W, LT, bits)
+    h = shard.ShardedLDLQ(force_exchange=True)
+    got = h.round(W, LT, bits)
+    assert torch.equal(got, want)
+    st = shard.last_stats
+    assert st["world"] == 1 and st["bytes_broadcast_LT"] == 4 * d * d and st["bytes_gather"] == 0 and st["bytes_scatter"] == 0
+    # the queued form: LT of job 2 is broadcast under the rounding of job 1
+    W2, LT2 = _fixture(m, d, seed=m + 1)
+    h.queue_LTs([LT, LT2])
+    a = h.round(W, None, bits)
+    assert shard.last_stats["bytes_broadcast_next_LT"] == 4 * d * d
+    b = h.round(W2, None, bits)
+    assert shard.last_stats["bytes_broadcast_LT"] == 0
+    assert torch.equal(a, want) and torch.equal(b, ops.ldlq_round(W2, LT2, bits))
+    # unpacked gather (the branch RCCL takes when the shape does not pack) gives the same codes
+    c = shard.ldlq_round_sharded(W, LT, bits, force_exchange=True, gather_packed=False)
+    assert torch.equal(c, want)
+
+
+def test_sharded_driver_script_one_rank(nccl_group):
+    """scripts/quantize_opt_sharded.py with --force-exchange == the same block sequence without the exchange."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("quantize_opt_sharded", os.path.join(root, "scripts", "quantize_opt_sharded.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = ["--hidden", "256", "--ffn", "1024", "--heads", "4", "--layers", "2", "--nsamples", "4", "--seqlen", "64", "--vocab", "512", "--incoh"]
+    a = mod.main(argv + ["--force-exchange"])
+    b = mod.main(argv)
+    assert a["linears"] == b["linears"] == 12
+    assert a["bytes_broadcast_LT"] > 0 and a["bytes_broadcast_next_LT"] > 0 and b["bytes_broadcast_LT"] == 0
+    assert abs(a["mean_proxy_error"] - b["mean_proxy_error"]) <= 1e-6 * abs(b["mean_proxy_error"])

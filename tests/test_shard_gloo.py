@@ -48,7 +48,25 @@ def _worker(rank, world, port, m, d, bits, use_eta, mode, out_path):
     try:
         W, LT, eta = _fixture(m, d, seed=5)
         eta = eta if use_eta else None
-        if mode == "collective":
+        if mode == "queue":                          # a block's LT factors queued: LT k+1 travels under the rounding of k
+            W2, LT2, _ = _fixture(m, d // 2, seed=6)
+            if rank == 0:
+                h = shard.ShardedLDLQ(compute=_oracle_compute)
+                h.queue_LTs([LT, LT2, LT])
+                got = h.round(W, None, bits, eta=eta)
+                assert shard.last_stats["bytes_broadcast_LT"] == 4 * d * d and shard.last_stats["bytes_broadcast_next_LT"] == d * d
+                got2 = h.round(W2, None, bits)
+                assert shard.last_stats["bytes_broadcast_LT"] == 0     # came with the previous job
+                got3 = h.round(W[: m // 2], None, bits)
+                assert not h.queued() and "bytes_broadcast_next_LT" not in shard.last_stats
+                got4 = h.round(W2, LT2, bits)                          # and a plain job after the queue has drained
+                h.shutdown()
+                assert torch.equal(got2, _oracle_compute(W2, LT2, bits, None)) and torch.equal(got4, got2)
+                assert torch.equal(got3, _oracle_compute(W[: m // 2], LT, bits, None))
+            else:
+                assert shard.serve(compute=_oracle_compute) == 4
+                got = None
+        elif mode == "collective":
             got = shard.ldlq_round_sharded(W if rank == 0 else None, LT if rank == 0 else None, bits,
                                            eta=eta if rank == 0 else None, compute=_oracle_compute)
             assert (got is None) == (rank != 0)
@@ -70,7 +88,8 @@ def _worker(rank, world, port, m, d, bits, use_eta, mode, out_path):
 
 
 @pytest.mark.parametrize("m,d,bits,use_eta,mode", [(96, 128, 2, False, "collective"), (40, 128, 4, True, "collective"),
-                                                    (16, 64, 2, False, "collective"), (70, 128, 2, True, "serve")])
+                                                    (16, 64, 2, False, "collective"), (70, 128, 2, True, "serve"),
+                                                    (48, 128, 2, False, "queue")])
 def test_sharded_ldlq_matches_unsharded(tmp_path, m, d, bits, use_eta, mode):
     out = str(tmp_path / "res.pt")
     mp.spawn(_worker, args=(2, _free_port(), m, d, bits, use_eta, mode, out), nprocs=2, join=True)
@@ -106,6 +125,10 @@ def test_world_size_one_is_a_plain_call():
         h = shard.ShardedLDLQ(compute=_oracle_compute)
         assert torch.equal(h.round(W, LT, 2), got)
         h.shutdown()
+        # force_exchange: the whole broadcast / scatter / gather path with one rank (what a single-GPU box uses to run RCCL)
+        hx = shard.ShardedLDLQ(compute=_oracle_compute, force_exchange=True)
+        assert torch.equal(hx.round(W, LT, 2), got)
+        assert shard.last_stats["world"] == 1 and shard.last_stats["bytes_broadcast_LT"] == 4 * 64 * 64
     finally:
         dist.destroy_process_group()
 
@@ -126,7 +149,10 @@ def _hessian_worker(rank, world, port, out_path):
         for qm, x in zip(qms, X):
             for j in range(a, b):
                 qm.add_batch(x[j].unsqueeze(0), None)
-        shard.all_reduce_hessians(qms)
+        follower = QuantMethod(torch.nn.Linear(d_in[0], 4))          # shares the first Linear's input (q/k/v): H is None
+        follower.share_hessian_from(qms[0])
+        shard.all_reduce_hessians(qms + [follower])
+        assert follower.H is None or follower.H is qms[0].H
         for qm in qms:
             qm.post_batch()
         if rank == 0:
