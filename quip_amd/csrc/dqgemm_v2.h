@@ -291,7 +291,7 @@ int launch_h(const K2Args &A, hipStream_t s)
 // Past the end the loaders repeat the last stage (clamped): every counted wait stays a constant.
 // x is ingested once per workgroup: 8 KiB of x per NW * TPS KiB of weights.
 // =====================================================================================================================
-template <int BITS, class ACT, int NW, int KSP, int D>
+template <int BITS, class ACT, int NW, int KSP, int SPW, int D>
 __global__ __launch_bounds__(64 * (NW * KSP + 2)) void dq_s_kernel(K2Args A, uint32_t ntile)
 {
     typedef DeqSel<BITS, ACT> Q;                                      // 2 bits: multi-exponent dequantisation (dq_common.h)
@@ -299,15 +299,16 @@ __global__ __launch_bounds__(64 * (NW * KSP + 2)) void dq_s_kernel(K2Args A, uin
     constexpr int KS = 256, TPS = KS / KC;                            // k per stage, weight tiles per stage and row tile
     constexpr int XB = 16 * KS * 2, NI = 8;                            // slab bytes, DMA instructions per slab
     constexpr int NWT = NW * TPS, SB1 = XB + NWT * 1024;               // weight tiles per stage, bytes per stage
-    constexpr int SB = KSP * SB1, NCW = NW * KSP;                      // ring slot = KSP stages; compute waves
-    static_assert(KSP * NI * (D - 2) < 64 && KSP * NWT * (D - 2) < 64 && D >= 3, "vmcnt range");
-    static_assert(NCW * 1024 + NCW * 128 <= D * SB, "exchange area");
+    constexpr int SPS = KSP * SPW;                                     // stages per ring step: SPW for each of the KSP k-parts
+    constexpr int SB = SPS * SB1, NCW = NW * KSP;                      // ring slot; compute waves
+    static_assert(SPS * NI * (D - 2) < 64 && SPS * NWT * (D - 2) < 64 && D >= 2, "vmcnt range");
+    static_assert(NCW * 1024 + NCW * 128 <= D * SB && NW <= 8, "exchange area");
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [D] slots of KSP stages {x slab, NWT weight tiles}
     const EpiArgs &e = A.e;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t ns = (uint32_t)(A.d / KS), nss = (ns + KSP - 1) / KSP;   // stages, ring steps
+    const uint32_t ns = (uint32_t)(A.d / KS), nss = (ns + SPS - 1) / SPS;   // stages, ring steps
     const uint32_t rowbytes = (uint32_t)A.d * 2u;
     const uint32_t tile0 = blockIdx.x * NW;                            // first row tile of the workgroup
 
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(64 * (NW * KSP + 2)) void dq_s_kernel(K2Args A, uin
         auto issue_w = [&](uint32_t ss) {
             const uint32_t slot = ss % D;
 #pragma unroll
-            for (int h = 0; h < KSP; ++h) {
-                const uint32_t st = ss * KSP + h, sc = st < ns ? st : ns - 1;
+            for (int h = 0; h < SPS; ++h) {
+                const uint32_t st = ss * SPS + h, sc = st < ns ? st : ns - 1;
 #pragma unroll
                 for (int i = 0; i < NWT; ++i) {
                     const uint32_t r = tile0 + i / TPS, rc = r < ntile ? r : ntile - 1;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(64 * (NW * KSP + 2)) void dq_s_kernel(K2Args A, uin
         for (int c = 0; c < D - 1; ++c) issue_w(c);
 #pragma unroll 1
         for (uint32_t ss = 0; ss < nss; ++ss) {
-            K2_ACC(0, wait_vm<KSP * NWT * (D - 2)>());                 // ring step ss has landed
+            K2_ACC(0, wait_vm<SPS * NWT * (D - 2)>());                 // ring step ss has landed
             K2_ACC(1, __builtin_amdgcn_s_barrier());
             K2_ACC(2, issue_w(ss + D - 1));
         }
@@ -352,8 +353,8 @@ __global__ __launch_bounds__(64 * (NW * KSP + 2)) void dq_s_kernel(K2Args A, uin
         auto issue_x = [&](uint32_t ss) {
             const uint32_t slot = ss % D;
 #pragma unroll
-            for (int h = 0; h < KSP; ++h) {
-                const uint32_t st = ss * KSP + h, sc = st < ns ? st : ns - 1;
+            for (int h = 0; h < SPS; ++h) {
+                const uint32_t st = ss * SPS + h, sc = st < ns ? st : ns - 1;
 #pragma unroll
                 for (int i = 0; i < NI; ++i)                           // DMA instruction i = 2 * column block + row half
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void2_t *)(smem + slot * SB + h * SB1 + i * 1024), 16,
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(64 * (NW * KSP + 2)) void dq_s_kernel(K2Args A, uin
         for (int c = 0; c < D - 1; ++c) issue_x(c);
 #pragma unroll 1
         for (uint32_t ss = 0; ss < nss; ++ss) {
-            K2_ACC(0, wait_vm<KSP * NI * (D - 2)>());
+            K2_ACC(0, wait_vm<SPS * NI * (D - 2)>());
             K2_ACC(1, __builtin_amdgcn_s_barrier());
             K2_ACC(2, issue_x(ss + D - 1));
         }
@@ -397,20 +398,25 @@ __global__ __launch_bounds__(64 * (NW * KSP + 2)) void dq_s_kernel(K2Args A, uin
 #pragma unroll 1
     for (uint32_t ss = 0; ss < nss; ++ss) {
         K2_ACC(1, __builtin_amdgcn_s_barrier());
-        if (KSP > 1 && ss * KSP + hh >= ns) continue;                  // ragged tail of the k-split (wave-uniform)
-        const char *sl = smem + (ss % D) * SB + hh * SB1;
-        u32x4 ws[TPS], xf[8];
 #pragma unroll
-        for (int t = 0; t < TPS; ++t) ws[t] = *reinterpret_cast<const u32x4 *>(sl + wof + t * 1024);
+        for (int u = 0; u < SPW; ++u) {
+            if (ss * SPS + hh * SPW + u >= ns) continue;              // ragged tail of the ring step (wave-uniform)
+            const char *sl = smem + (ss % D) * SB + (hh * SPW + u) * SB1;
+            u32x4 ws[TPS], xf[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) xf[t] = *reinterpret_cast<const u32x4 *>(sl + (t >> 1) * 2048 + ((t & 1) ? rd1 : rd0));
+            for (int t = 0; t < TPS; ++t) ws[t] = *reinterpret_cast<const u32x4 *>(sl + wof + t * 1024);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t & 3] = ACT::mfma(Q::frag(ws[(t * 32) / KC], t % NT, qc), xf[t], acc[t & 3]);
-        if ((ss % NW) == (uint32_t)wt) {                               // one wave per stage keeps S_1 = sum x and S_off = sum OFF_k x
+            for (int t = 0; t < 8; ++t) xf[t] = *reinterpret_cast<const u32x4 *>(sl + (t >> 1) * 2048 + ((t & 1) ? rd1 : rd0));
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                accx[t & 1] = ACT::mfma(ones, xf[t], accx[t & 1]);
-                if constexpr (!Q::UNIFORM) acco[t & 1] = ACT::mfma(offs[t & 1], xf[t], acco[t & 1]);
+            for (int t = 0; t < 8; ++t) acc[t & 3] = ACT::mfma(Q::frag(ws[(t * 32) / KC], t % NT, qc), xf[t], acc[t & 3]);
+            // one wave per stage keeps S_1 = sum x and S_off = sum OFF_k x (dealing the 8 steps round-robin to the NW waves
+            // through a switch was measured 20 % SLOWER per wave: profiles/r02h_k2lab.log)
+            if (((ss * SPW + u) % NW) == (uint32_t)wt) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    accx[t & 1] = ACT::mfma(ones, xf[t], accx[t & 1]);
+                    if constexpr (!Q::UNIFORM) acco[t & 1] = ACT::mfma(offs[t & 1], xf[t], acco[t & 1]);
+                }
             }
         }
     }
@@ -448,14 +454,14 @@ __global__ __launch_bounds__(64 * (NW * KSP + 2)) void dq_s_kernel(K2Args A, uin
     }
 }
 
-template <int BITS, class ACT, int NW, int KSP, int D>
+template <int BITS, class ACT, int NW, int KSP, int SPW, int D>
 int launch_s(const K2Args &A, hipStream_t s)
 {
     constexpr int TPS = 256 / (512 / BITS);
-    constexpr size_t lds = (size_t)D * KSP * (16 * 256 * 2 + NW * TPS * 1024);
+    constexpr size_t lds = (size_t)D * KSP * SPW * (16 * 256 * 2 + NW * TPS * 1024);
     static_assert(lds <= 160 * 1024, "LDS budget");
     QA_REQUIRE(A.e.m * A.d * BITS / 8 < ((int64_t)1 << 32), QUIPAMD_ERR_SHAPE, "dequant_gemm(s): packed weights >= 4 GiB");
-    auto kern = dq_s_kernel<BITS, ACT, NW, KSP, D>;
+    auto kern = dq_s_kernel<BITS, ACT, NW, KSP, SPW, D>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return qa_fail(QUIPAMD_ERR_LAUNCH, "dequant_gemm: cannot raise dynamic LDS to %zu", lds);
