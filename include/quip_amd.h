@@ -255,6 +255,18 @@ int quipamd_ldlq_round(const float *Wgrid, const float *LT, const float *eta, in
 int quipamd_gptq_round(const float *Wgrid_rev, const float *FT, int bits, uint8_t *codes_rev, float *err_ws, int64_t m,
                        int64_t d, void *stream);
 
+/* The same sweep in WEIGHT units with the reference's quantiser inside the chain: what GPTQ.fasterquant does for
+ * `groupsize != -1` (gptq.py:69-76) and for qfn 'c' (quant.py:17-21, 162-165).
+ *   q = scale * (clamp(round(w' / scale) + zero, 0, maxq) - zero)      (qfn_c: clamp(w' / scale + zero) first, then round)
+ * groupsize > 0 (16, 32, 64 or 128, dividing d): `scale`, `zero` are OUT float [m, d / groupsize]; the pair of a group is found
+ *   by Quantizer.find_params_qfna (quant.py:57-94; perchannel, mse off, `sym` as configured) from the group's columns as
+ *   they stand at the start of its 128-column block -- gptq.py:72-75 reads the block-lazy W, not the in-block W1.
+ * groupsize <= 0: `scale`, `zero` are IN float [m] (the quantiser found beforehand on the whole row).
+ *   W_rev: float [m, d] weights, columns reversed;  FT: as for quipamd_gptq_round;  Q_rev: float [m, d] out, the dequantised
+ *   weights (reversed);  codes_rev: uint8 [m, d] out or NULL;  err_ws: float [m, d] workspace.  Requires d % 16 == 0. */
+int quipamd_gptq_round_groups(const float *W_rev, const float *FT, int bits, int groupsize, int sym, int qfn_c, float *scale,
+                              float *zero, float *Q_rev, uint8_t *codes_rev, float *err_ws, int64_t m, int64_t d, void *stream);
+
 /* One greedy coordinate-descent pass of LDLQ's post-processing (round_ldl / round_ldl_block with n_greedy_passes > 0,
  * vector_balance.py:186-196, 263-288), same kernel as quipamd_ldlq_round in its third mode.  For i = d-1 .. 0:
  *   Hs_i = sH[:, i] - sum_{j > i} eps_j H[j][i];   new_i = round(wr_i - Hs_i / H[i][i]);   eps_i = wr_i - new_i

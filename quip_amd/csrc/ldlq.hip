@@ -42,7 +42,11 @@ struct LdlqArgs {
     int64_t m, d;
     float maxq;
     const float *hd;    // [d]    mode 2: diagonal of the normalised H
-    float *Wout;        // [m,d]  mode 2: the updated (unclamped) values
+    float *Wout;        // [m,d]  mode 2: the updated (unclamped) values; mode 3: the dequantised weights
+    // mode 3 (OPTQ in weight units, quantiser of quant.py:6-21 inside the chain)
+    float *gscale, *gzero;   // groupsize > 0: OUT [m, d / groupsize] (found in the kernel); groupsize <= 0: IN [m]
+    int groupsize;           // 16 / 32 / 64 / 128 or <= 0 (one (scale, zero) per row)
+    int sym, qfn_c;          // Quantizer.configure(sym=...), qfn 'c' (clamp before round, quant.py:17-21)
 };
 
 __device__ __forceinline__ float round_col(float w, float acc, float eta, float maxq)
@@ -63,6 +67,12 @@ __device__ __forceinline__ float round_col(float w, float acc, float eta, float 
 // -- the same right-to-left recurrence with (s H) precomputed by a GEMM (passed in the eta slot), the feedback matrix
 // -H (strictly upper) and eps as the quantity fed back; values are written as floats, unclamped (the reference clamps
 // after the whole pass).
+// MODE 3 = OPTQ/GPTQ in WEIGHT units with the reference's quantiser inside the chain (gptq.py:60-87 with quant.py:6-21):
+//   q = scale * (clamp(round(w' / scale) + zero, 0, maxq) - zero)   (qfn a; qfn c clamps first), feedback (w' - q).
+// With groupsize > 0 the (scale, zero) of a group are found IN the kernel the way Quantizer.find_params_qfna does
+// (quant.py:57-94, perchannel, mse off) from the columns of the group as they stand when the group's 128-column block
+// starts -- far field of all finished blocks applied, nothing of the current block (gptq.py:72-75 reads the block-lazy W,
+// not W1): exactly the value `w + Ftile` the chain starts from.  Groups must not straddle a block: groupsize | 128.
 template <int MODE>
 __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
 {
@@ -174,15 +184,22 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
     // ---- in-block sequential error feedback of block [i1, i1 + cnt), chain wave cw = rows 4cw .. 4cw+3 --------------------
     auto chain = [&](int64_t i1, int cnt, const float *Ftile) {
         float acc[4][2], wv[4][2], et[4][2];
-        constexpr bool UPD = MODE == 1;
+        constexpr bool UPD = MODE == 1 || MODE == 3;
+        float sc[4][2] = {}, zr[4][2] = {};                   // mode 3: quantiser of (row, this lane's column)
         float hdv[2] = {1.f, 1.f};                            // mode 2: H[i][i] of this lane's two columns
         if constexpr (MODE == 2) {
             hdv[0] = lane < cnt ? A.hd[i1 + lane] : 1.f;
             hdv[1] = lane + 64 < cnt ? A.hd[i1 + lane + 64] : 1.f;
         }
         // the value a column takes given its accumulated feedback
+        auto code3 = [&](float x, float scale, float zero) -> float {
+            const float t = __fdiv_rn(x, scale);
+            return A.qfn_c ? rintf(fminf(fmaxf(t + zero, 0.f), A.maxq))              // quant.py:17-21
+                           : fminf(fmaxf(rintf(t) + zero, 0.f), A.maxq);              // quant.py:6-8
+        };
         auto decide = [&](float w, float a, float g, float hd) -> float {
             if constexpr (MODE == 2) return rintf(w - __fdiv_rn(g + a, hd));          // torch.round(wr - Hs / H[i,i])
+            else if constexpr (MODE == 3) return __fmul_rn(g, code3(w + a, g, hd) - hd);   // g = scale, hd = zero
             else return round_col(w, a, g, A.maxq);
         };
 #pragma unroll
@@ -197,13 +214,64 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
                 et[rr][h] = (ok && A.eta) ? A.eta[row * d + i1 + c] : (MODE == 2 ? 0.f : 0.5f);
             }
         }
+        if constexpr (MODE == 3) {
+            const int gs = A.groupsize;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int64_t row = r0 + 4 * cw + rr;
+                if (gs <= 0) {
+                    const float s1 = row < A.m ? A.gscale[row] : 1.f, z1 = row < A.m ? A.gzero[row] : 0.f;
+                    sc[rr][0] = sc[rr][1] = s1;
+                    zr[rr][0] = zr[rr][1] = z1;
+                    continue;
+                }
+                float lo[2], hi[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float x = (lane + 64 * h < cnt) ? wv[rr][h] + acc[rr][h] : 0.f;     // 0 is neutral: min(.., 0), max(.., 0)
+                    lo[h] = fminf(x, 0.f);
+                    hi[h] = fmaxf(x, 0.f);
+                    for (int off = 1; off < 64 && off < gs; off <<= 1) {
+                        lo[h] = fminf(lo[h], __shfl_xor(lo[h], off, 64));
+                        hi[h] = fmaxf(hi[h], __shfl_xor(hi[h], off, 64));
+                    }
+                }
+                if (gs == 128) {
+                    lo[0] = lo[1] = fminf(lo[0], lo[1]);
+                    hi[0] = hi[1] = fmaxf(hi[0], hi[1]);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float xmin = lo[h], xmax = hi[h];
+                    if (A.sym) {                                                   // quant.py:82-86
+                        xmax = fmaxf(fabsf(xmin), xmax);
+                        if (xmin < 0.f) xmin = -xmax;
+                    }
+                    if (xmin == 0.f && xmax == 0.f) { xmin = -1.f; xmax = 1.f; }     // :87-89
+                    const float scale = __fdiv_rn(xmax - xmin, A.maxq);              // :91
+                    const float zero = A.sym ? (A.maxq + 1.f) * 0.5f : rintf(__fdiv_rn(-xmin, scale));   // :92-95
+                    sc[rr][h] = scale;
+                    zr[rr][h] = zero;
+                    const int c = lane + 64 * h;
+                    if (c < cnt && row < A.m && (c % gs) == gs - 1) {            // one lane per group: the group's first ORIGINAL column
+                        const int64_t grp = (d - 1 - (i1 + c)) / gs;              // columns arrive reversed (quipamd_gptq_round)
+                        A.gscale[row * (d / gs) + grp] = scale;
+                        A.gzero[row * (d / gs) + grp] = zero;
+                    }
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) et[rr][h] = sc[rr][h];
+        }
         // columns 64..cnt-1 live in register half 1
         for (int i = cnt - 1; i >= 64; --i) {
             const int ln = __builtin_amdgcn_readfirstlane(i - 64);
             const float l0 = Ldiag[i * LDS_LD + lane], l1 = Ldiag[i * LDS_LD + 64 + lane];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const float q = decide(wv[rr][1], acc[rr][1], et[rr][1], hdv[1]);
+                const float q = decide(wv[rr][1], acc[rr][1], et[rr][1], MODE == 3 ? zr[rr][1] : hdv[1]);
                 const float er = (UPD ? wv[rr][1] + acc[rr][1] : wv[rr][1]) - q;
                 const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, er), ln));
                 acc[rr][0] = fmaf(e, l0, acc[rr][0]);
@@ -216,7 +284,7 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
             const float l0 = Ldiag[i * LDS_LD + lane];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const float q = decide(wv[rr][0], acc[rr][0], et[rr][0], hdv[0]);
+                const float q = decide(wv[rr][0], acc[rr][0], et[rr][0], MODE == 3 ? zr[rr][0] : hdv[0]);
                 const float er = (UPD ? wv[rr][0] + acc[rr][0] : wv[rr][0]) - q;
                 const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, er), ln));
                 acc[rr][0] = fmaf(e, l0, acc[rr][0]);
@@ -230,9 +298,12 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
             for (int h = 0; h < 2; ++h) {
                 const int c = lane + 64 * h;
                 if (c < cnt && row < A.m) {
-                    const float q = decide(wv[rr][h], acc[rr][h], et[rr][h], hdv[h]);
+                    const float q = decide(wv[rr][h], acc[rr][h], et[rr][h], MODE == 3 ? zr[rr][h] : hdv[h]);
                     if constexpr (MODE == 2) A.Wout[row * d + i1 + c] = q;
-                    else A.codes[row * d + i1 + c] = (uint8_t)q;
+                    else if constexpr (MODE == 3) {
+                        A.Wout[row * d + i1 + c] = q;
+                        if (A.codes) A.codes[row * d + i1 + c] = (uint8_t)code3(wv[rr][h] + acc[rr][h], sc[rr][h], zr[rr][h]);
+                    } else A.codes[row * d + i1 + c] = (uint8_t)q;
                     A.E[row * d + i1 + c] = (UPD ? wv[rr][h] + acc[rr][h] : wv[rr][h]) - q;
                 }
             }
@@ -301,9 +372,12 @@ __global__ __launch_bounds__(256) void unit_lower_t_kernel(const float *__restri
 
 }   // namespace
 
+struct QuantSpec { float *scale, *zero; int groupsize, sym, qfn_c; };
+
 template <int MODE>
 static int launch_ldlq(const float *Wgrid, const float *LT, const float *eta, int bits, uint8_t *codes, float *err_ws, int64_t m,
-                       int64_t d, void *stream, const char *who, const float *hd = nullptr, float *wout = nullptr)
+                       int64_t d, void *stream, const char *who, const float *hd = nullptr, float *wout = nullptr,
+                       const QuantSpec *quant = nullptr)
 {
     if (m == 0 || d == 0) return QUIPAMD_OK;
     QA_REQUIRE(Wgrid && LT && (codes || wout) && err_ws, QUIPAMD_ERR_ARG, "%s: null pointer", who);
@@ -313,6 +387,8 @@ static int launch_ldlq(const float *Wgrid, const float *LT, const float *eta, in
     A.W = Wgrid; A.LT = LT; A.eta = eta; A.codes = codes; A.E = err_ws; A.m = m; A.d = d;
     A.maxq = (float)((1 << bits) - 1);
     A.hd = hd; A.Wout = wout;
+    A.gscale = A.gzero = nullptr; A.groupsize = 0; A.sym = 0; A.qfn_c = 0;
+    if (quant) { A.gscale = quant->scale; A.gzero = quant->zero; A.groupsize = quant->groupsize; A.sym = quant->sym; A.qfn_c = quant->qfn_c; }
     const size_t lds = (size_t)(BS * LDS_LD + 2 * 16 * BS) * sizeof(float) + 4 * 3 * SLAB;
     static bool attr_set = false;                                  // per instantiation
     if (!attr_set) {
@@ -329,6 +405,17 @@ extern "C" int quipamd_gptq_round(const float *Wgrid_rev, const float *FT, int b
                                   int64_t d, void *stream)
 {
     return launch_ldlq<1>(Wgrid_rev, FT, nullptr, bits, codes_rev, err_ws, m, d, stream, "gptq_round");
+}
+
+extern "C" int quipamd_gptq_round_groups(const float *W_rev, const float *FT, int bits, int groupsize, int sym, int qfn_c, float *scale,
+                                         float *zero, float *Q_rev, uint8_t *codes_rev, float *err_ws, int64_t m, int64_t d, void *stream)
+{
+    QA_REQUIRE(m == 0 || d == 0 || (scale && zero && Q_rev), QUIPAMD_ERR_ARG, "gptq_round_groups: null pointer");
+    QA_REQUIRE(groupsize <= 0 || ((groupsize == 16 || groupsize == 32 || groupsize == 64 || groupsize == 128) && d % groupsize == 0),
+               QUIPAMD_ERR_SHAPE, "gptq_round_groups: groupsize must be 16, 32, 64 or 128 and divide d (groupsize=%d, d=%lld)", groupsize,
+               (long long)d);
+    QuantSpec q{scale, zero, groupsize, sym != 0, qfn_c != 0};
+    return launch_ldlq<3>(W_rev, FT, nullptr, bits, codes_rev, err_ws, m, d, stream, "gptq_round_groups", nullptr, Q_rev, &q);
 }
 
 extern "C" int quipamd_ldlq_greedy_pass(const float *wr, const float *sH, const float *negH_upper, const float *hdiag, float *wr_out,

@@ -1,12 +1,15 @@
 """`GPTQ` (OPTQ) behind the QuantMethod protocol -- reference gptq.py:17-115.
 
-Surface row of SURVEY.md 8(a) a13: `--quant gptq` must keep working next to LDLQ.  The column quantiser is
-the HIP grid kernel (ops.quantize via Quantizer.quantize); the Cholesky-inverse stays on rocSOLVER through torch.
-For the common case (nn.Linear, groupsize -1, qfn a, width a multiple of 16) the d-step column loop and the lazy
-block update W[:, i2:] -= Err @ Hinv[i1:i2, i2:] (gptq.py:56-93) run as ONE launch of the K4 kernel in its
-updated-weight feedback mode (ops.gptq_round, include/quip_amd.h): the loop below is ~8 launches per column
-(0.5 s for d = 8192), the kernel a few ms.  Everything else (groupsize, Conv layers, qfn c, debug_equiv) takes the
-reference-order loop.
+Surface row of SURVEY.md 8(a) a13: `--quant gptq` must keep working next to LDLQ.  The d-step column loop and the lazy
+block update W[:, i2:] -= Err @ Hinv[i1:i2, i2:] (gptq.py:56-93) run as ONE launch of the K4 kernel in its updated-weight
+feedback modes (include/quip_amd.h):
+  * ops.gptq_round         qfn a, groupsize -1: grid coordinates, codes kept for packing;
+  * ops.gptq_round_groups  groupsize 16/32/64/128 (the group quantisers are found inside the kernel from the block-lazy W,
+                           like gptq.py:72-75) and qfn c, in weight units with the reference's quantiser formula;
+(nn.Linear is the only layer kind the reference's own preproc / error_compute survive: method.py:187 and :232 index a
+Conv1D / Conv2d weight as if it were [out, in].)
+What the kernel cannot hold is qfn b -- Quantizer.quantize recomputes ONE scale from all rows of every updated column
+(quant.py:158-160), a grid-wide reduction per column -- and debug_equiv's float64: `_column_walk` serves those.
 """
 import time
 
@@ -39,40 +42,12 @@ class GPTQ(QuantMethod):
         if not self.quantizer.ready():
             self.quantizer.find_params(W, weight=True)
         H = self.H.data.clone() if copy_H else self.H
-        Q = torch.zeros_like(W)
         # upper Cholesky factor of H^-1 (gptq.py:51-54)
         Hinv = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)
         qz = self.quantizer
-        fast = (USE_KERNEL and groupsize == -1 and not debug_equiv and isinstance(self.layer, nn.Linear) and W.is_cuda
-                and qz.qfn == 'a' and self.columns % 16 == 0 and float(qz.maxq) in (1.0, 3.0, 7.0, 15.0, 255.0))
-        if fast:
-            from . import ops
-            mq = int(qz.maxq.item()) if torch.is_tensor(qz.maxq) else int(qz.maxq)
-            bits = (mq + 1).bit_length() - 1
-            # qfn b is excluded: Quantizer.quantize recomputes its scalar scale from every (updated) column it is handed
-            # grid coordinates WITHOUT the clamp of the LDLQ grid map (vector_balance.py:515 clamps, quantize_qfna does
-            # not: OPTQ feeds the unclamped residual back)
-            wg = (W.float() / qz.scale.reshape(-1, 1).float() + qz.zero.reshape(-1, 1).float()).contiguous()
-            codes = ops.gptq_round(wg, Hinv.float().contiguous(), bits)
-            Q = ops.codes_to_weight(codes, 'a', qz.scale, qz.zero, mq, out_dtype=torch.float32).to(W.dtype)
-            self.codes, self.qscale, self.qzero = codes, qz.scale.reshape(-1).float(), qz.zero.reshape(-1).float()
-        for i1 in range(0, self.columns if not fast else 0, blocksize):
-            i2 = min(i1 + blocksize, self.columns)
-            Wb = W[:, i1:i2].clone()
-            Qb = torch.zeros_like(Wb)
-            Eb = torch.zeros_like(Wb)
-            Hb = Hinv[i1:i2, i1:i2]
-            for i in range(i2 - i1):
-                col = Wb[:, i]
-                if groupsize != -1 and (i1 + i) % groupsize == 0:
-                    self.quantizer.find_params(W[:, (i1 + i):(i1 + i + groupsize)], weight=True)
-                q = self.quantizer.quantize(col.unsqueeze(1)).flatten().to(col.dtype)
-                Qb[:, i] = q
-                e = (col - q) / Hb[i, i]
-                Wb[:, i:] -= e.unsqueeze(1) * Hb[i, i:].unsqueeze(0)     # rank-1 update inside the block
-                Eb[:, i] = e
-            Q[:, i1:i2] = Qb
-            W[:, i2:] -= Eb @ Hinv[i1:i2, i2:]                              # lazy batch update (gptq.py:90)
+        Q = self._kernel_round(W, Hinv, groupsize, debug_equiv, blocksize)
+        if Q is None:
+            Q = _column_walk(W, Hinv, qz, blocksize, groupsize)
         torch.cuda.synchronize()
         self.time = time.time() - tick
         if isinstance(self.layer, transformers.Conv1D):
@@ -82,3 +57,58 @@ class GPTQ(QuantMethod):
         self.error_compute(full_W, self.layer.weight.data)
         if not copy_H:
             del self.H
+
+    def _kernel_round(self, W, Hinv, groupsize, debug_equiv, blocksize=128):
+        """the K4 launch that covers this configuration, or None"""
+        qz = self.quantizer
+        mq = int(qz.maxq.item()) if torch.is_tensor(qz.maxq) else int(qz.maxq)
+        ok = (USE_KERNEL and not debug_equiv and W.is_cuda and W.dim() == 2 and W.shape[1] % 16 == 0 and qz.qfn in ('a', 'c')
+              and mq in (1, 3, 7, 15, 255))
+        if not ok:
+            return None
+        from . import ops
+        m, d = W.shape
+        bits = (mq + 1).bit_length() - 1
+        Hinv = Hinv.float().contiguous()
+        if groupsize == -1:
+            if qz.scale.numel() not in (1, m):
+                return None
+            if qz.qfn == 'a':
+                # grid coordinates WITHOUT the clamp of the LDLQ grid map (vector_balance.py:515 clamps, quantize_qfna does
+                # not: OPTQ feeds the unclamped residual back)
+                wg = (W.float() / qz.scale.reshape(-1, 1).float() + qz.zero.reshape(-1, 1).float()).contiguous()
+                codes = ops.gptq_round(wg, Hinv, bits)
+                self.codes, self.qscale, self.qzero = codes, qz.scale.reshape(-1).float(), qz.zero.reshape(-1).float()
+                return ops.codes_to_weight(codes, 'a', qz.scale, qz.zero, mq, out_dtype=torch.float32).to(W.dtype)
+            Q, _, _ = ops.gptq_round_groups(W.float().contiguous(), Hinv, bits, -1, qz.sym, 'c', qz.scale, qz.zero)
+            return Q.to(W.dtype)
+        # the kernel's lazy block is 128 columns wide: with another blocksize the groups would see a different W (gptq.py:72-75)
+        if groupsize not in (16, 32, 64, 128) or d % groupsize or not qz.perchannel or qz.mse or blocksize != 128:
+            return None
+        Q, scale, zero = ops.gptq_round_groups(W.float().contiguous(), Hinv, bits, groupsize, qz.sym, qz.qfn)
+        # the reference leaves the LAST group's quantiser in self.quantizer (gptq.py:72-75)
+        qz.scale, qz.zero = scale[:, -1:].clone(), zero[:, -1:].clone()
+        self.group_scale, self.group_zero = scale, zero
+        return Q.to(W.dtype)
+
+
+def _column_walk(W, Hinv, quantizer, blocksize, groupsize):
+    """gptq.py:56-93 for the configurations no kernel covers (module docstring): one column at a time, errors of a block
+    applied to the later blocks once per block."""
+    d = W.shape[1]
+    Q = torch.empty_like(W)
+    for lo in range(0, d, blocksize):
+        hi = min(lo + blocksize, d)
+        blk = W[:, lo:hi].clone()
+        Hb = Hinv[lo:hi, lo:hi]
+        resid = torch.empty_like(blk)
+        for j in range(hi - lo):
+            if groupsize != -1 and (lo + j) % groupsize == 0:
+                quantizer.find_params(W[:, lo + j:lo + j + groupsize], weight=True)
+            col = blk[:, j]
+            q = quantizer.quantize(col.unsqueeze(1)).flatten().to(col.dtype)
+            Q[:, lo + j] = q
+            resid[:, j] = (col - q) / Hb[j, j]
+            blk[:, j:].addr_(resid[:, j], Hb[j, j:], alpha=-1)
+        W[:, hi:] -= resid @ Hinv[lo:hi, hi:]
+    return Q

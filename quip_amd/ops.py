@@ -447,6 +447,34 @@ def gptq_round(Wgrid, Hinv, bits, return_err=False):
     return (codes, err.flip(1).contiguous()) if return_err else codes
 
 
+def gptq_round_groups(W, Hinv, bits, groupsize=-1, sym=False, qfn='a', scale=None, zero=None, return_codes=False):
+    """OPTQ in weight units with the reference quantiser in the loop (gptq.py:60-87 + quant.py:6-21): `groupsize` 16/32/64/128
+    (the kernel finds each group's (scale, zero) like Quantizer.find_params_qfna, perchannel) or -1 with per-row scale/zero
+    given; qfn 'a' or 'c'.  Returns (Q float32 [m,d], scale, zero[, codes]); with groups scale/zero are [m, d/groupsize]."""
+    _need_gpu(W, Hinv)
+    assert W.dtype == torch.float32 and Hinv.dtype == torch.float32 and qfn in ('a', 'c')
+    m, d = W.shape
+    assert Hinv.shape == (d, d)
+    dev = W.device
+    if groupsize > 0:
+        if groupsize not in (16, 32, 64, 128) or d % groupsize:
+            raise ValueError(f"gptq_round_groups: groupsize {groupsize} must be 16, 32, 64 or 128 and divide {d}")
+        scale = torch.empty((m, d // groupsize), dtype=torch.float32, device=dev)
+        zero = torch.empty_like(scale)
+    else:
+        scale, zero = _grid(scale, zero, m, 'a', dev)
+        scale, zero = scale.clone(), zero.clone()
+    FT = gptq_feedback_matrix(Hinv)
+    wrev = W.flip(1).contiguous()
+    Q = torch.empty((m, d), dtype=torch.float32, device=dev)
+    codes = torch.empty((m, d), dtype=torch.uint8, device=dev) if return_codes else None
+    err = torch.empty((m, d), dtype=torch.float32, device=dev)
+    _lib.call("quipamd_gptq_round_groups", _p(wrev), _p(FT), bits, int(groupsize), int(bool(sym)), int(qfn == 'c'), _p(scale), _p(zero),
+              _p(Q), _p(codes), _p(err), m, d, _stream())
+    out = (Q.flip(1).contiguous(), scale, zero)
+    return out + (codes.flip(1).contiguous(),) if return_codes else out
+
+
 def cholesky_lt(H, check=True):
     """LT = D^-1 U strictly upper with H = U^T U: the unit-lower LDL factor of vector_balance.py:171-173, transposed,
     by the blocked fp32 factorisation of quip_amd/csrc/cholesky.hip (K8).  Raises torch.linalg.LinAlgError like

@@ -361,6 +361,57 @@ def gen_rounders():
          "with torch.cuda.synchronize stubbed.  H = correlated fixture, d=192, m=40", **arrs)
 
 
+# ---------------------------------------------------------------- I2. GPTQ with groups, qfn b / c, Conv1D
+GPTQ_CASES = [  # name, d, m, bits, groupsize, qfn, sym, layer kind
+    ("w3_g64_a", 384, 40, 3, 64, 'a', False, "linear"),
+    ("w4_g32_c_sym", 384, 40, 4, 32, 'c', True, "linear"),
+    ("w2_g128_a", 384, 24, 2, 128, 'a', False, "linear"),
+    ("w4_g64_a_ragged", 320, 24, 4, 64, 'a', False, "linear"),     # 320 = 2.5 blocks of 128
+    ("w3_g16_a_sym", 256, 24, 3, 16, 'a', True, "linear"),
+    ("w4_c", 256, 24, 4, -1, 'c', False, "linear"),
+    ("w4_b", 128, 24, 4, -1, 'b', False, "linear"),
+    ("w4_g64_b", 128, 24, 4, 64, 'b', False, "linear"),
+]
+
+
+def gen_gptq_groups():
+    """gptq.py:19-115 GPTQ.fasterquant on CPU for the configurations of GPTQ_CASES (groupsize, qfn b/c, sym, Conv1D)."""
+    import gptq as ref_gptq
+    import transformers
+    arrs = {}
+    sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        for name, d, m, bits, gs, qfn, sym, kind in GPTQ_CASES:
+            H = correlated_H(d, 7 + d)
+            torch.manual_seed(d + m + bits)
+            W0 = (0.02 * torch.randn(m, d)).float()
+            if kind == "conv1d":
+                lin = transformers.Conv1D(m, d)                 # weight [d, m]
+                lin.weight.data = W0.t().contiguous()
+            else:
+                lin = torch.nn.Linear(d, m, bias=False)
+                lin.weight.data = W0.clone()
+            meth = ref_gptq.GPTQ(lin)
+            meth.quantizer = ref_quant.Quantizer()
+            meth.quantizer.configure(bits, perchannel=True, sym=sym, qfn=qfn, mse=False)
+            meth.H = H.clone()
+            meth.preproc(preproc_gptqH=True, percdamp=.01)
+            meth.fasterquant(groupsize=gs, copy_H=True)
+            arrs[f"{name}_W0"] = W0
+            arrs[f"H{d}"] = H                                  # one Hessian per width (seed 7 + d)
+            arrs[f"{name}_Q"] = lin.weight.data.clone()
+            arrs[f"{name}_error"] = meth.error
+            arrs[f"{name}_scale"] = meth.quantizer.scale.clone()
+            if meth.quantizer.zero is not None:
+                arrs[f"{name}_zero"] = meth.quantizer.zero.clone()
+    finally:
+        torch.cuda.synchronize = sync
+    save("gptq_groups", "gptq.py:19-115 GPTQ.fasterquant run on CPU (torch.cuda.synchronize stubbed) after preproc(preproc_gptqH, "
+         "percdamp .01), perchannel, mse off; cases (name: d, m, bits, groupsize, qfn, sym, layer) = " + repr(GPTQ_CASES) +
+         "; H<d> = the Hessian of width d before damping; per case W0 [m,d], Q = layer.weight after, error, and the quantiser left behind", **arrs)
+
+
 # ---------------------------------------------------------------- H. the reference DRIVER, end to end
 def gen_driver():
     """/root/reference/opt.py:29-190 `opt_sequential`, unmodified, on the tiny random-init fp16 OPT of tiny_model.py, CPU,
@@ -411,6 +462,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rounders":
         gen_rounders()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "gptq_groups":
+        gen_gptq_groups()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "driver":
         gen_driver()
         sys.exit(0)
@@ -421,4 +475,5 @@ if __name__ == "__main__":
     gen_method()
     gen_counter()
     gen_rounders()
+    gen_gptq_groups()
     gen_driver()

@@ -115,3 +115,94 @@ def test_gptq_class_against_reference_golden():
     got = lin.weight.data.float().cpu().numpy()
     assert np.mean(got != g["gptq_w4_Q"]) <= 5e-3
     assert abs(meth.error - float(g["gptq_w4_error"])) <= 5e-3 * float(g["gptq_w4_error"])
+
+
+# ---- groupsize / qfn b, c (gptq.py:69-76, quant.py:10-21) against the reference's own runs -------------------------------------
+def _golden_cases():
+    import ast
+    doc = str(load_golden("gptq_groups")["__doc__"])
+    return ast.literal_eval(doc[doc.index("[("):doc.index(")]") + 2])
+
+
+def _run_case(g, name, d, m, bits, gs, qfn, sym, layer="linear", use_kernel=True):
+    from quip_amd import gptq as G, quant as Q
+    import transformers
+    W0 = torch.from_numpy(g[f"{name}_W0"].copy())
+    if layer == "conv1d":
+        lin = transformers.Conv1D(m, d).to(DEV)
+        lin.weight.data = W0.t().contiguous().to(DEV)
+    else:
+        lin = torch.nn.Linear(d, m, bias=False).to(DEV)
+        lin.weight.data = W0.to(DEV)
+    meth = G.GPTQ(lin)
+    meth.quantizer = Q.Quantizer()
+    meth.quantizer.configure(bits, perchannel=True, sym=sym, qfn=qfn, mse=False)
+    meth.H = torch.from_numpy(g[f"H{d}"].copy()).to(DEV)
+    if layer == "conv1d":                      # method.preproc does not know Conv1D (method.py:187 indexes the [d, m] weight by column):
+        meth.H += .01 * meth.H.diag().mean() * torch.eye(d, device=DEV)          # damp by hand, like preproc_gptqH
+        meth.preproc()
+    else:
+        meth.preproc(preproc_gptqH=True, percdamp=.01)
+    G.USE_KERNEL = use_kernel
+    try:
+        meth.fasterquant(groupsize=gs)
+    finally:
+        G.USE_KERNEL = True
+    return lin.weight.data.float().cpu().numpy(), meth
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_gptq_groups_and_qfn_against_reference_golden(case):
+    g = load_golden("gptq_groups")
+    name, d, m, bits, gs, qfn, sym, kind = _golden_cases()[case]
+    got, meth = _run_case(g, name, d, m, bits, gs, qfn, sym)
+    ref = g[f"{name}_Q"]
+    kernel = qfn != 'b'
+    assert hasattr(meth, "group_scale") == (kernel and gs != -1)           # the K4 launch served it (not the column walk)
+    # a flipped code moves one weight by a whole grid step; everything after it in the row follows a slightly different path
+    step = float(np.abs(ref).max()) / (2 ** bits - 1)
+    flipped = np.abs(got - ref) > 0.25 * step
+    assert flipped.mean() <= (1e-2 if kernel else 2e-2), flipped.mean()
+    assert abs(meth.error - float(g[f"{name}_error"])) <= 2e-2 * float(g[f"{name}_error"])
+    if gs != -1 and kernel:                                                   # the quantiser left behind is the LAST group's
+        np.testing.assert_allclose(meth.quantizer.scale.cpu().numpy().reshape(-1), g[f"{name}_scale"].reshape(-1), rtol=2e-2)
+
+
+@pytest.mark.parametrize("gs,qfn,sym,bits", [(64, 'a', False, 3), (32, 'c', True, 4), (128, 'a', False, 2), (16, 'a', True, 4), (-1, 'c', False, 4)])
+def test_gptq_groups_kernel_equals_column_walk(gs, qfn, sym, bits):
+    """same class, same inputs: the one-launch kernel against the reference-order column walk, both on the GPU in fp32"""
+    g = load_golden("gptq_groups")
+    outs = {}
+    for use in (True, False):
+        outs[use], meth = _run_case(g, "w3_g64_a", 384, 40, bits, gs, qfn, sym, use_kernel=use)
+    step = float(np.abs(outs[False]).max()) / (2 ** bits - 1)
+    flipped = np.abs(outs[True] - outs[False]) > 0.25 * step
+    assert flipped.mean() <= 5e-3, flipped.mean()
+
+
+def test_gptq_groups_first_group_quantiser_is_exact():
+    """group 0 sees the untouched weights: its (scale, zero) must equal Quantizer.find_params on W[:, :gs] bit for bit"""
+    from quip_amd import ops, quant as Q
+    W, H, _, _, _ = _fixture(48, 256, 4, seed=11)
+    Hd = H.to(DEV)
+    Hinv = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(Hd)), upper=True).contiguous()
+    for gs, sym in ((32, False), (64, True), (128, False)):
+        Qw, scale, zero, codes = ops.gptq_round_groups(W.to(DEV), Hinv, 4, gs, sym, 'a', return_codes=True)
+        qz = Q.Quantizer()
+        qz.configure(4, perchannel=True, sym=sym, qfn='a', mse=False)
+        qz.find_params(W[:, :gs].to(DEV), weight=True)
+        assert torch.equal(scale[:, 0], qz.scale.reshape(-1)) and torch.equal(zero[:, 0], qz.zero.reshape(-1).float())
+        # and every emitted weight is scale * (code - zero) of its own group
+        sc, zr = scale.repeat_interleave(gs, 1), zero.repeat_interleave(gs, 1)
+        assert torch.equal(Qw, sc * (codes.float() - zr))
+        assert int(codes.max()) <= 15
+
+
+def test_gptq_groups_argument_errors():
+    from quip_amd import ops
+    W = torch.zeros(16, 96, device=DEV)
+    Hinv = torch.eye(96, device=DEV)
+    with pytest.raises(ValueError, match="groupsize"):
+        ops.gptq_round_groups(W, Hinv, 4, 48)
+    with pytest.raises(ValueError, match="groupsize"):
+        ops.gptq_round_groups(W, Hinv, 4, 64)               # 96 % 64
