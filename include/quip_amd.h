@@ -267,6 +267,17 @@ int quipamd_gptq_round(const float *Wgrid_rev, const float *FT, int bits, uint8_
 int quipamd_gptq_round_groups(const float *W_rev, const float *FT, int bits, int groupsize, int sym, int qfn_c, float *scale,
                               float *zero, float *Q_rev, uint8_t *codes_rev, float *err_ws, int64_t m, int64_t d, void *stream);
 
+/* FT for the two entry points above straight from the (damped) Hessian: replaces
+ *   Hinv = cholesky(cholesky_inverse(cholesky(H)), upper=True)     (gptq.py:51-54, three rocSOLVER calls behind torch)
+ * by  FT = I - (I + N)^-1,  N = quipamd_cholesky_lt of the column-reversed H  (csrc/trinv.hip has the algebra).
+ *   H: float [d, d] symmetric positive definite;  FT: float [d, d] out;  work: float [2 d d];  info: int [1] as for
+ *   quipamd_cholesky_lt (indices refer to the REVERSED matrix).  Requires d % 16 == 0. */
+int quipamd_gptq_feedback(const float *H, float *FT, float *work, int64_t d, int *info, void *stream);
+
+/* X = (I + N)^-1 for a strictly-upper-triangular N (only the strict upper part of N is read; X comes back upper
+ * triangular with a unit diagonal, its strict lower part is NOT written).  N, X, work: three distinct float [d, d]. */
+int quipamd_unit_upper_inverse(const float *N, float *X, float *work, int64_t d, void *stream);
+
 /* One greedy coordinate-descent pass of LDLQ's post-processing (round_ldl / round_ldl_block with n_greedy_passes > 0,
  * vector_balance.py:186-196, 263-288), same kernel as quipamd_ldlq_round in its third mode.  For i = d-1 .. 0:
  *   Hs_i = sH[:, i] - sum_{j > i} eps_j H[j][i];   new_i = round(wr_i - Hs_i / H[i][i]);   eps_i = wr_i - new_i

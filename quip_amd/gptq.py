@@ -2,7 +2,8 @@
 
 Surface row of SURVEY.md 8(a) a13: `--quant gptq` must keep working next to LDLQ.  The d-step column loop and the lazy
 block update W[:, i2:] -= Err @ Hinv[i1:i2, i2:] (gptq.py:56-93) run as ONE launch of the K4 kernel in its updated-weight
-feedback modes (include/quip_amd.h):
+feedback modes (include/quip_amd.h), fed by ops.gptq_feedback (flip + K8 Cholesky + one unit-triangular inverse on the fp32
+matrix pipe instead of gptq.py:51-54's three rocSOLVER factorisations):
   * ops.gptq_round         qfn a, groupsize -1: grid coordinates, codes kept for packing;
   * ops.gptq_round_groups  groupsize 16/32/64/128 (the group quantisers are found inside the kernel from the block-lazy W,
                            like gptq.py:72-75) and qfn c, in weight units with the reference's quantiser formula;
@@ -42,12 +43,11 @@ class GPTQ(QuantMethod):
         if not self.quantizer.ready():
             self.quantizer.find_params(W, weight=True)
         H = self.H.data.clone() if copy_H else self.H
-        # upper Cholesky factor of H^-1 (gptq.py:51-54)
-        Hinv = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)
-        qz = self.quantizer
-        Q = self._kernel_round(W, Hinv, groupsize, debug_equiv, blocksize)
+        Q = self._kernel_round(W, H, groupsize, debug_equiv, blocksize)
         if Q is None:
-            Q = _column_walk(W, Hinv, qz, blocksize, groupsize)
+            # upper Cholesky factor of H^-1 (gptq.py:51-54)
+            Hinv = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)
+            Q = _column_walk(W, Hinv, self.quantizer, blocksize, groupsize)
         torch.cuda.synchronize()
         self.time = time.time() - tick
         if isinstance(self.layer, transformers.Conv1D):
@@ -58,8 +58,9 @@ class GPTQ(QuantMethod):
         if not copy_H:
             del self.H
 
-    def _kernel_round(self, W, Hinv, groupsize, debug_equiv, blocksize=128):
-        """the K4 launch that covers this configuration, or None"""
+    def _kernel_round(self, W, H, groupsize, debug_equiv, blocksize=128):
+        """the K4 launch that covers this configuration, or None.  The feedback matrix comes from H through K8 and one
+        triangular inverse (ops.gptq_feedback) -- the Cholesky / inverse / Cholesky of gptq.py:51-54 is never formed."""
         qz = self.quantizer
         mq = int(qz.maxq.item()) if torch.is_tensor(qz.maxq) else int(qz.maxq)
         ok = (USE_KERNEL and not debug_equiv and W.is_cuda and W.dim() == 2 and W.shape[1] % 16 == 0 and qz.qfn in ('a', 'c')
@@ -69,23 +70,23 @@ class GPTQ(QuantMethod):
         from . import ops
         m, d = W.shape
         bits = (mq + 1).bit_length() - 1
-        Hinv = Hinv.float().contiguous()
         if groupsize == -1:
             if qz.scale.numel() not in (1, m):
                 return None
+            FT = ops.gptq_feedback(H.float())
             if qz.qfn == 'a':
                 # grid coordinates WITHOUT the clamp of the LDLQ grid map (vector_balance.py:515 clamps, quantize_qfna does
                 # not: OPTQ feeds the unclamped residual back)
                 wg = (W.float() / qz.scale.reshape(-1, 1).float() + qz.zero.reshape(-1, 1).float()).contiguous()
-                codes = ops.gptq_round(wg, Hinv, bits)
+                codes = ops.gptq_round(wg, None, bits, FT=FT)
                 self.codes, self.qscale, self.qzero = codes, qz.scale.reshape(-1).float(), qz.zero.reshape(-1).float()
                 return ops.codes_to_weight(codes, 'a', qz.scale, qz.zero, mq, out_dtype=torch.float32).to(W.dtype)
-            Q, _, _ = ops.gptq_round_groups(W.float().contiguous(), Hinv, bits, -1, qz.sym, 'c', qz.scale, qz.zero)
+            Q, _, _ = ops.gptq_round_groups(W.float().contiguous(), None, bits, -1, qz.sym, 'c', qz.scale, qz.zero, FT=FT)
             return Q.to(W.dtype)
         # the kernel's lazy block is 128 columns wide: with another blocksize the groups would see a different W (gptq.py:72-75)
         if groupsize not in (16, 32, 64, 128) or d % groupsize or not qz.perchannel or qz.mse or blocksize != 128:
             return None
-        Q, scale, zero = ops.gptq_round_groups(W.float().contiguous(), Hinv, bits, groupsize, qz.sym, qz.qfn)
+        Q, scale, zero = ops.gptq_round_groups(W.float().contiguous(), None, bits, groupsize, qz.sym, qz.qfn, FT=ops.gptq_feedback(H.float()))
         # the reference leaves the LAST group's quantiser in self.quantizer (gptq.py:72-75)
         qz.scale, qz.zero = scale[:, -1:].clone(), zero[:, -1:].clone()
         self.group_scale, self.group_zero = scale, zero

@@ -432,13 +432,44 @@ def gptq_feedback_matrix(Hinv):
     return torch.triu((-Hn.t()).flip(0, 1), diagonal=1).contiguous()
 
 
-def gptq_round(Wgrid, Hinv, bits, return_err=False):
-    """OPTQ codes uint8 [m,d] of grid coordinates Wgrid given Hinv = chol(H^-1, upper) (gptq.py:56-93, groupsize -1)."""
-    _need_gpu(Wgrid, Hinv)
-    assert Wgrid.dtype == torch.float32 and Hinv.dtype == torch.float32
+def gptq_feedback(H, check=True):
+    """FT of the OPTQ sweep from the (damped) Hessian itself, on our own kernels: flip, K8 Cholesky, one unit-triangular
+    inverse (csrc/trinv.hip) -- stands in for gptq.py:51-54's cholesky / cholesky_inverse / cholesky and
+    gptq_feedback_matrix.  Raises torch.linalg.LinAlgError like torch.linalg.cholesky when H is not positive definite."""
+    _need_gpu(H)
+    assert H.dtype == torch.float32 and H.dim() == 2 and H.shape[0] == H.shape[1]
+    d = H.shape[0]
+    H = H.contiguous()
+    FT = torch.empty_like(H)
+    work = torch.empty((2, d, d), dtype=torch.float32, device=H.device)
+    info = torch.zeros(1, dtype=torch.int32, device=H.device)
+    _lib.call("quipamd_gptq_feedback", _p(H), _p(FT), _p(work), d, _p(info), _stream())
+    if check and int(info.item()):
+        raise torch.linalg.LinAlgError("quip_amd.gptq_feedback: the Hessian is not positive-definite")
+    return FT
+
+
+def unit_upper_inverse(N):
+    """(I + triu(N, 1))^-1, upper triangular (csrc/trinv.hip)."""
+    _need_gpu(N)
+    assert N.dtype == torch.float32 and N.dim() == 2 and N.shape[0] == N.shape[1]
+    N = N.contiguous()
+    X = torch.zeros_like(N)
+    work = torch.empty_like(N)
+    _lib.call("quipamd_unit_upper_inverse", _p(N), _p(X), _p(work), N.shape[0], _stream())
+    return X
+
+
+def gptq_round(Wgrid, Hinv, bits, return_err=False, FT=None):
+    """OPTQ codes uint8 [m,d] of grid coordinates Wgrid given Hinv = chol(H^-1, upper) (gptq.py:56-93, groupsize -1) or the
+    prepared feedback matrix FT (gptq_feedback)."""
+    _need_gpu(Wgrid, Hinv, FT)
+    assert Wgrid.dtype == torch.float32
     m, d = Wgrid.shape
-    assert Hinv.shape == (d, d)
-    FT = gptq_feedback_matrix(Hinv)
+    if FT is None:
+        assert Hinv.dtype == torch.float32 and Hinv.shape == (d, d)
+        FT = gptq_feedback_matrix(Hinv)
+    assert FT.shape == (d, d) and FT.dtype == torch.float32 and FT.is_contiguous()
     wrev = Wgrid.flip(1).contiguous()
     codes = torch.empty((m, d), dtype=torch.uint8, device=Wgrid.device)
     err = torch.empty((m, d), dtype=torch.float32, device=Wgrid.device)
@@ -447,14 +478,13 @@ def gptq_round(Wgrid, Hinv, bits, return_err=False):
     return (codes, err.flip(1).contiguous()) if return_err else codes
 
 
-def gptq_round_groups(W, Hinv, bits, groupsize=-1, sym=False, qfn='a', scale=None, zero=None, return_codes=False):
+def gptq_round_groups(W, Hinv, bits, groupsize=-1, sym=False, qfn='a', scale=None, zero=None, return_codes=False, FT=None):
     """OPTQ in weight units with the reference quantiser in the loop (gptq.py:60-87 + quant.py:6-21): `groupsize` 16/32/64/128
     (the kernel finds each group's (scale, zero) like Quantizer.find_params_qfna, perchannel) or -1 with per-row scale/zero
     given; qfn 'a' or 'c'.  Returns (Q float32 [m,d], scale, zero[, codes]); with groups scale/zero are [m, d/groupsize]."""
-    _need_gpu(W, Hinv)
-    assert W.dtype == torch.float32 and Hinv.dtype == torch.float32 and qfn in ('a', 'c')
+    _need_gpu(W, Hinv, FT)
+    assert W.dtype == torch.float32 and qfn in ('a', 'c')
     m, d = W.shape
-    assert Hinv.shape == (d, d)
     dev = W.device
     if groupsize > 0:
         if groupsize not in (16, 32, 64, 128) or d % groupsize:
@@ -464,7 +494,10 @@ def gptq_round_groups(W, Hinv, bits, groupsize=-1, sym=False, qfn='a', scale=Non
     else:
         scale, zero = _grid(scale, zero, m, 'a', dev)
         scale, zero = scale.clone(), zero.clone()
-    FT = gptq_feedback_matrix(Hinv)
+    if FT is None:
+        assert Hinv.dtype == torch.float32 and Hinv.shape == (d, d)
+        FT = gptq_feedback_matrix(Hinv)
+    assert FT.shape == (d, d) and FT.dtype == torch.float32 and FT.is_contiguous()
     wrev = W.flip(1).contiguous()
     Q = torch.empty((m, d), dtype=torch.float32, device=dev)
     codes = torch.empty((m, d), dtype=torch.uint8, device=dev) if return_codes else None

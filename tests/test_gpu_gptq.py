@@ -206,3 +206,62 @@ def test_gptq_groups_argument_errors():
         ops.gptq_round_groups(W, Hinv, 4, 48)
     with pytest.raises(ValueError, match="groupsize"):
         ops.gptq_round_groups(W, Hinv, 4, 64)               # 96 % 64
+
+
+# ---- the feedback matrix without H^-1 (csrc/trinv.hip) -------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [16, 128, 144, 256, 400, 1024, 1424])
+def test_unit_upper_inverse(d):
+    from quip_amd import ops
+    g = torch.Generator().manual_seed(d)
+    N = torch.triu(torch.randn(d, d, generator=g) / d ** 0.5, 1)
+    junk = torch.tril(torch.full((d, d), 7.0))                                # the lower part and the diagonal must not be read
+    X = ops.unit_upper_inverse((N + junk).to(DEV)).cpu().double()
+    ref = torch.linalg.inv(torch.eye(d, dtype=torch.float64) + N.double())
+    assert float((torch.triu(X) - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert torch.equal(torch.diagonal(X), torch.ones(d, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("d", [64, 192, 384, 2048])
+def test_gptq_feedback_equals_the_inverse_cholesky_route(d):
+    """FT from (flip, K8, triangular inverse) against gptq.py:51-54's route in float64"""
+    from quip_amd import ops
+    _, H, _, _, _ = _fixture(16, d, 4, seed=d)
+    H = H + 0.01 * H.diag().mean() * torch.eye(d)
+    FT = ops.gptq_feedback(H.to(DEV)).cpu().double()
+    Hinv = torch.linalg.cholesky(torch.linalg.inv(H.double()), upper=True)
+    ref = ops.gptq_feedback_matrix(Hinv)
+    assert float((FT - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    assert float(torch.tril(FT).abs().max()) == 0.0
+
+
+def test_gptq_feedback_rejects_indefinite_matrix():
+    from quip_amd import ops
+    H = torch.eye(64, device=DEV)
+    H[5, 5] = -1.0
+    with pytest.raises(torch.linalg.LinAlgError):
+        ops.gptq_feedback(H)
+
+
+def test_gptq_feedback_full_width_timing():
+    """d = 8192 (OPT-1.3B fc2 / OPT-30B attention width class): a few tens of ms, against ~100 ms of the rocSOLVER triple"""
+    import time
+    from quip_amd import ops
+    d = 8192
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(d + 512, d, generator=g).to(DEV)
+    H = X.T @ X / (d + 512)
+    H += 0.01 * H.diag().mean() * torch.eye(d, device=DEV)
+    ops.gptq_feedback(H)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    FT = ops.gptq_feedback(H)
+    torch.cuda.synchronize()
+    t_ours = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    Hinv = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)
+    torch.cuda.synchronize()
+    t_ref = time.perf_counter() - t0
+    ref = ops.gptq_feedback_matrix(Hinv)
+    print(f"gptq_feedback d={d}: {t_ours * 1e3:.1f} ms; rocSOLVER cholesky/cholesky_inverse/cholesky: {t_ref * 1e3:.1f} ms")
+    assert float((FT - ref).abs().max()) <= 2e-3
+    assert t_ours < 0.25
