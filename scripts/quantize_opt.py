@@ -107,7 +107,7 @@ def opt_sequential(model, batches, dev, args):
             m.preproc(preproc_gptqH=True, percdamp=args.percdamp, preproc_rescale=args.incoh, preproc_proj=args.incoh,
                       preproc_proj_extra=1 if args.pack else 0)
             if args.quant == 'gptq':
-                m.fasterquant(groupsize=-1)
+                m.fasterquant(groupsize=getattr(args, 'groupsize', -1))
             elif args.quant == 'nearest':
                 m.fasterquant()
             else:
@@ -122,6 +122,16 @@ def opt_sequential(model, batches, dev, args):
             outs[j] = run_layer(layer, j)
         inps, outs = outs, inps
     return report, packed
+
+
+def llama_sequential(model, batches, dev, args):
+    """llama.py:36-171 on quip_amd: the same block-sequential loop over model.model.layers.  Carries the fixes the reference's
+    Llama driver needs before any method runs under transformers 5: `args` is a parameter, not a module
+    global; Balance.configure gets its four arguments and fasterquant its lazy_batch; and EVERY keyword the first decoder
+    layer was called with is captured and passed back -- in particular position_embeddings = (cos, sin), without which
+    LlamaDecoderLayer cannot run (the reference forwards only attention_mask and position_ids, llama.py:58-63,134,160)."""
+    args.arch = 'llama'
+    return opt_sequential(model, batches, dev, args)
 
 
 def main():
@@ -139,6 +149,7 @@ def main():
     ap.add_argument("--npasses", type=int, default=0)
     ap.add_argument("--qfn", default=None)
     ap.add_argument("--percdamp", type=float, default=0.01)
+    ap.add_argument("--groupsize", type=int, default=-1, help="GPTQ group size (gptq.py:69-76): 16 / 32 / 64 / 128 run in the kernel")
     ap.add_argument("--incoh", action="store_true", help="--incoh_processing: rescale + random orthogonal projection")
     ap.add_argument("--pack", action="store_true", help="swap the quantised Linears for packed QuantLinear layers afterwards")
     args = ap.parse_args()

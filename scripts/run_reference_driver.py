@@ -41,10 +41,57 @@ def load_driver():
 
     def opt_sequential(model, dataloader, dev, args):
         a = types.SimpleNamespace(arch="opt", nsamples=args.nsamples, quant=args.quant, wbits=args.wbits, npasses=args.npasses,
-                                  qfn=args.qfn, percdamp=args.percdamp, incoh=bool(args.pre_proj), pack=bool(args.pre_proj_extra))
+                                  qfn=args.qfn, percdamp=args.percdamp, incoh=bool(args.pre_proj), pack=bool(args.pre_proj_extra),
+                                  groupsize=getattr(args, "groupsize", -1))
         report, _ = mod.opt_sequential(model, [b[0] for b in dataloader], dev, a)
         return report, [r["error"] for r in report]
     return opt_sequential, False
+
+
+def load_llama_driver():
+    """llama_sequential(model, dataloader, dev, args) -> (report | quantizers, errors).  With QUIP_REFERENCE set the reference's
+    own llama.py:36-171 runs on quip_amd (its module global `args` injected, HF's LlamaDecoderLayer.forward wrapped to derive
+    the position_embeddings llama.py does not forward -- the same two adaptations tests/golden/make_golden.py needed to run it
+    on CPU); otherwise scripts/quantize_opt.py's llama_sequential, which carries the fixes itself."""
+    alias_modules()
+    ref = os.environ.get("QUIP_REFERENCE")
+    if ref and os.path.exists(os.path.join(ref, "llama.py")):
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden", "_shims"))     # texttable
+        sys.path.insert(0, ref)                                                  # datautils
+        spec = importlib.util.spec_from_file_location("llama", os.path.join(ref, "llama.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        from transformers.models.llama import modeling_llama as ML
+        import quip_amd.method as M
+
+        def llama_sequential(model, dataloader, dev, args):
+            orig_fwd, orig_free, errors = ML.LlamaDecoderLayer.forward, M.QuantMethod.free, []
+
+            def fwd(self, hidden_states, *a, position_embeddings=None, position_ids=None, **kw):
+                if position_embeddings is None:
+                    position_embeddings = model.model.rotary_emb(hidden_states, position_ids=position_ids)
+                return orig_fwd(self, hidden_states, *a, position_embeddings=position_embeddings, position_ids=position_ids, **kw)
+
+            def free(self):
+                errors.append(float(self.error))
+                return orig_free(self)
+            ML.LlamaDecoderLayer.forward, M.QuantMethod.free, mod.args = fwd, free, args
+            try:
+                return mod.llama_sequential(model, dataloader, dev), errors
+            finally:
+                ML.LlamaDecoderLayer.forward, M.QuantMethod.free = orig_fwd, orig_free
+        return llama_sequential, True
+    spec = importlib.util.spec_from_file_location("quantize_opt", os.path.join(ROOT, "scripts", "quantize_opt.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def llama_sequential(model, dataloader, dev, args):
+        a = types.SimpleNamespace(nsamples=args.nsamples, quant=args.quant, wbits=args.wbits, npasses=args.npasses, qfn=args.qfn,
+                                  percdamp=args.percdamp, incoh=bool(args.pre_proj), pack=bool(args.pre_proj_extra),
+                                  groupsize=args.groupsize)
+        report, _ = mod.llama_sequential(model, [b[0] for b in dataloader], dev, a)
+        return report, [r["error"] for r in report]
+    return llama_sequential, False
 
 
 if __name__ == "__main__":

@@ -458,12 +458,80 @@ def gen_driver():
          "error / Hmag, final fp16 weights (first 8 rows + SHA-256), logits; configs nearest_w4, ldlq_w4, ldlq_w2_incoh", **arrs)
 
 
+# ---------------------------------------------------------------- H2. the reference LLAMA driver
+def gen_llama_driver():
+    """/root/reference/llama.py:36-171 `llama_sequential`, unmodified, on the tiny random-init fp16 Llama of tiny_model.py, CPU,
+    for the branches that run as shipped: `nearest` and `gptq` (groupsize -1 and 64).  Two things outside the reference are
+    adapted so that its code runs at all under transformers 5: `llama.args` (the driver reads a module
+    global) is set from tiny_model.LLAMA_CONFIGS, and transformers' LlamaDecoderLayer.forward is wrapped so that a call
+    WITHOUT position_embeddings (the reference forwards only attention_mask / position_ids, llama.py:134,160) computes them
+    from position_ids with the model's own rotary module -- the values HF's LlamaModel.forward would have passed."""
+    import hashlib
+    import types
+    import tiny_model as TM
+    import llama as ref_llama
+    from transformers.models.llama import modeling_llama as ML
+    arrs = {}
+    rec = []
+    orig_free = ref_method.QuantMethod.free
+    orig_fwd = ML.LlamaDecoderLayer.forward
+    rot = {}
+
+    def recording_free(self):
+        rec.append((float(self.error), float(self.Hmag)))
+        return orig_free(self)
+
+    def fwd(self, hidden_states, *a, position_embeddings=None, position_ids=None, **kw):
+        if position_embeddings is None:
+            position_embeddings = rot["m"](hidden_states, position_ids=position_ids)
+        return orig_fwd(self, hidden_states, *a, position_embeddings=position_embeddings, position_ids=position_ids, **kw)
+    ref_method.QuantMethod.free = recording_free
+    ML.LlamaDecoderLayer.forward = fwd
+    sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        for cname, cfg in TM.LLAMA_CONFIGS.items():
+            model = TM.build_tiny_llama()
+            rot["m"] = model.model.rotary_emb
+            ref_llama.args = types.SimpleNamespace(nsamples=TM.NSAMPLES, **cfg)
+            del rec[:]
+            np.random.seed(0)
+            torch.manual_seed(0)
+            quantizers = ref_llama.llama_sequential(model, TM.calibration_batches(), torch.device("cpu"))
+            assert len(rec) == len(quantizers) == 14
+            arrs[f"{cname}_error"] = np.asarray([r[0] for r in rec], np.float64)
+            arrs[f"{cname}_Hmag"] = np.asarray([r[1] for r in rec], np.float64)
+            names = [k.replace("model.decoder.layers.", "model.layers.") for k in quantizers.keys()]   # llama.py:153 keeps OPT's prefix
+            arrs[f"{cname}_names"] = np.asarray(names)
+            params = dict(model.named_parameters())
+            for k in names:
+                w = params[k + ".weight"].detach()
+                assert w.dtype == torch.float16
+                arrs[f"{cname}_{k}_rows8"] = w[:8].view(torch.int16).numpy().copy()
+                arrs[f"{cname}_{k}_sha256"] = np.asarray(hashlib.sha256(w.contiguous().view(torch.int16).numpy().tobytes()).hexdigest())
+            with torch.no_grad():
+                arrs[f"{cname}_logits"] = model(TM.probe_tokens()).logits.float().numpy().astype(np.float16)
+        with torch.no_grad():
+            arrs["fp16_logits"] = TM.build_tiny_llama()(TM.probe_tokens()).logits.float().numpy().astype(np.float16)
+    finally:
+        ref_method.QuantMethod.free = orig_free
+        ML.LlamaDecoderLayer.forward = orig_fwd
+        torch.cuda.synchronize = sync
+    save("driver_llama", "llama.py:36-171 llama_sequential (the reference driver, unmodified; args injected as the module global it reads, "
+         "HF's LlamaDecoderLayer.forward wrapped to derive position_embeddings from position_ids) on tests/golden/tiny_model.py "
+         "build_tiny_llama: per-Linear error / Hmag in driver order, final fp16 weights (first 8 rows + SHA-256), logits; "
+         "configs nearest_w4, gptq_w4, gptq_w3_g64", **arrs)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rounders":
         gen_rounders()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gptq_groups":
         gen_gptq_groups()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "driver_llama":
+        gen_llama_driver()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "driver":
         gen_driver()
@@ -477,3 +545,4 @@ if __name__ == "__main__":
     gen_rounders()
     gen_gptq_groups()
     gen_driver()
+    gen_llama_driver()

@@ -49,3 +49,34 @@ CONFIGS = {
     "ldlq_w2_incoh": dict(quant="ldlq", wbits=2, qfn="b", npasses=0, unbiased=False, lazy_batch=False, percdamp=0.01,
                           pre_gptqH=True, pre_rescale=True, pre_proj=True, pre_proj_extra=0, groupsize=-1),
 }
+
+
+# ---- the Llama twin (llama.py:36-171) ------------------------------------------------------------------------------------------
+L_HIDDEN, L_FFN, L_LAYERS, L_HEADS, L_KV_HEADS = 256, 688, 2, 4, 4          # 688 = 16 * 43: Llama's 11008 = 256 * 43 in small
+
+
+def build_tiny_llama(seed=4321):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(hidden_size=L_HIDDEN, intermediate_size=L_FFN, num_hidden_layers=L_LAYERS, num_attention_heads=L_HEADS,
+                      num_key_value_heads=L_KV_HEADS, vocab_size=VOCAB, max_position_embeddings=SEQLEN, rms_norm_eps=1e-5,
+                      attention_dropout=0.0, tie_word_embeddings=False)
+    model = LlamaForCausalLM(cfg)
+    rs = np.random.RandomState(seed)
+    with torch.no_grad():
+        for name, p in sorted(model.named_parameters(), key=lambda kv: kv[0]):
+            v = (1.0 + 0.1 * rs.randn(*p.shape)) if "norm" in name else 0.05 * rs.randn(*p.shape)
+            p.copy_(torch.from_numpy(np.asarray(v, dtype=np.float32)))
+    model = model.half().eval()
+    model.seqlen = SEQLEN
+    return model
+
+
+LLAMA_CONFIGS = {
+    # the branches of llama.py:91-116 that run as shipped (the Balance branch reads an undefined args.qbits)
+    "nearest_w4": dict(quant="nearest", wbits=4, qfn="a", npasses=0, unbiased=False, percdamp=0.01,
+                       pre_gptqH=True, pre_rescale=False, pre_proj=False, pre_proj_extra=0, groupsize=-1),
+    "gptq_w4": dict(quant="gptq", wbits=4, qfn="a", npasses=0, unbiased=False, percdamp=0.01,
+                    pre_gptqH=True, pre_rescale=False, pre_proj=False, pre_proj_extra=0, groupsize=-1),
+    "gptq_w3_g64": dict(quant="gptq", wbits=3, qfn="a", npasses=0, unbiased=False, percdamp=0.01,
+                        pre_gptqH=True, pre_rescale=False, pre_proj=False, pre_proj_extra=0, groupsize=64),
+}
