@@ -213,6 +213,15 @@ typedef struct quipamd_small_op {
 /* nops (1..4) independent ops in ONE launch (the q / k / v projections of a block share their input): `ops` is a HOST
  * array; all ops must share p, q and the dtypes; every op is applied to `rows` rows. */
 int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int nops, int64_t rows, void *stream);
+/* The decode-step form of quipamd_ortho_apply_small_ops: every 16 x 16 tile of every op's p x q output image gets its own
+ * workgroup (8 to 32 per operator instead of 1), for the Kronecker shapes of a decode step: p x q = 64x32 (n = 2048),
+ * 64x64 (4096), 128x64 (8192) -- quipamd_ortho_apply_tiles_supported(p, q) -- with split-bf16 factors.  Same descriptor,
+ * same arithmetic (bit-identical to quipamd_ortho_apply_small_ops without LayerNorm; the LayerNorm statistics are summed in a
+ * different order).  store_inv[i]: int32 [n], the inverse of ops[i].store_idx (image position -> output index); NULL entries
+ * (or a NULL array) exactly where store_idx is NULL.  rows <= 65535. */
+int quipamd_ortho_apply_tiles(const quipamd_small_op *ops, const int32_t *const *store_inv, int nops, int64_t rows, void *stream);
+int quipamd_ortho_apply_tiles_supported(int p, int q);
+
 /* Chain of two operator applications in ONE launch (decode: U^T y + bias + residual -> [LayerNorm] -> V (x (/) s) of two
  * consecutive packed layers):  t = epilogue_first(Q_first x_first)  is stored to first->out (when not NULL) in
  * first->out_dtype and, rounded to that dtype, is the input of every second[i] (1..3 ops that share it, e.g. the q / k / v

@@ -37,6 +37,8 @@ SIGNATURES = {
     "quipamd_dequant_gemm_grouped": [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
                                      c_i64, c_i64, c_i64, c_vp],
     "quipamd_ortho_apply_small_ops": [c_vp, c_int, c_i64, c_vp],
+    "quipamd_ortho_apply_tiles": [c_vp, c_vp, c_int, c_i64, c_vp],
+    "quipamd_ortho_apply_tiles_supported": [c_int, c_int],
     "quipamd_tune_dequant_gemm": [c_int, c_int, c_int, c_int],
     "quipamd_ortho_apply_rows": [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_i64,
                                  c_vp, c_int, c_i64, c_i64, c_vp, c_vp],

@@ -246,6 +246,28 @@ def ortho_small_ops(op_list, rows):
     _lib.call("quipamd_ortho_apply_small_ops", ctypes.cast(arr, ctypes.c_void_p), len(op_list), rows, _stream())
 
 
+TILE_ROWS = 8          # up to this many rows a Kronecker operator is cut into 16 x 16 output tiles, one workgroup each
+USE_TILES = True
+
+
+def ortho_tile_ops(op_list, inv_list, rows):
+    """up to 4 operator applications, every 16 x 16 tile of every output image on its own workgroup (quipamd_ortho_apply_tiles):
+    the decode-step form of ortho_small_ops.  inv_list[i]: the inverse of op i's store permutation (int32) or None."""
+    n = len(op_list)
+    arr = (SmallOp * n)(*op_list)
+    inv = (ctypes.c_void_p * n)(*[ctypes.c_void_p(0 if t is None else t.data_ptr()) for t in inv_list])
+    _lib.call("quipamd_ortho_apply_tiles", ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(inv, ctypes.c_void_p), n, rows, _stream())
+
+
+def ortho_apply_ops(entries, rows):
+    """entries: [(OrthoOp, SmallOp descriptor, transpose)] sharing p, q and dtypes -> ONE launch: tiled over many workgroups for
+    a handful of rows (decode), one workgroup per row otherwise."""
+    if USE_TILES and rows <= TILE_ROWS and all(o.tile_ok and o.use_split for o, _, _ in entries):
+        ortho_tile_ops([d for _, d, _ in entries], [o.store_inv(t) for o, _, t in entries], rows)
+    else:
+        ortho_small_ops([d for _, d, _ in entries], rows)
+
+
 def ortho_small_chain(first, seconds, rows):
     """`first` then each of `seconds` (1..3 SmallOp sharing its result) in ONE launch (quipamd_ortho_apply_small_chain)."""
     one = (SmallOp * 1)(first)
@@ -317,6 +339,14 @@ class OrthoOp:
                     hi = M.to(torch.bfloat16)
                     return hi.contiguous(), (M - hi.float()).to(torch.bfloat16).contiguous()
                 self._Msplit = {k: hl(m0) + hl(m1) for k, (m0, m1) in self._M.items()}
+        # csrc/ortho_tile.hip covers 64x32 too, but a launch has ~3.4 us of fixed latency (ramp, first load, store) and at
+        # n = 2048 one workgroup finishes in 5.2 us against 6.0 us tiled (profiles/r02l_decode_kernel_trace.txt): tiles from n = 4096
+        self.tile_ok = self.split_ok and (self.p, self.q) in ((64, 64), (128, 64))
+        self.tile_supported = self.split_ok and (self.p, self.q) in ((64, 32), (64, 64), (128, 64))
+
+    def store_inv(self, transpose):
+        """image position -> output index: the inverse of the `store_idx` small_op() hands to the kernels"""
+        return self.pin if transpose else self.inv_pout
 
     def state(self):
         """the reference-style generator tuple ([B0, B1], p_in, p_out) on the CPU -- what a packed checkpoint stores."""
@@ -351,7 +381,7 @@ class OrthoOp:
             if rows > self.SMALL_ROWS and x.dtype == torch.float32:
                 self.use_split = False
             try:
-                ortho_small_ops([self.small_op(x, out, transpose=transpose, colscale=cs, bias=_f32vec(bias, x.device))], rows)
+                ortho_apply_ops([(self, self.small_op(x, out, transpose=transpose, colscale=cs, bias=_f32vec(bias, x.device)), bool(transpose))], rows)
             finally:
                 self.use_split = split
             return out

@@ -341,13 +341,13 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False):
     x = x.contiguous()
     xts = [torch.empty((rows, d), dtype=torch.bfloat16, device=dev) for _ in qls]
     lnp = _ln_params(ln)
-    ops.ortho_small_ops([q.V.small_op(x, xt, colscale=q.inv_scaleWH, ln=lnp) for q, xt in zip(qls, xts)], rows)
+    ops.ortho_apply_ops([(q.V, q.V.small_op(x, xt, colscale=q.inv_scaleWH, ln=lnp), False) for q, xt in zip(qls, xts)], rows)
     ys = [torch.empty((rows, m), dtype=torch.float32, device=dev) for _ in qls]
     ops.dequant_gemm_grouped(xts, [q.qweight for q in qls], qls[0].bits, 'b', [q.scales for q in qls], None, ys, m)
     outs = [torch.empty((rows, m), dtype=x.dtype, device=dev) for _ in qls]
     res = None if residual is None else residual.contiguous()
-    ops.ortho_small_ops([q.U.small_op(y, o, transpose=True, bias=q.bias, residual=res, relu=relu) for q, y, o in zip(qls, ys, outs)],
-                        rows)
+    ops.ortho_apply_ops([(q.U, q.U.small_op(y, o, transpose=True, bias=q.bias, residual=res, relu=relu), True)
+                         for q, y, o in zip(qls, ys, outs)], rows)
     return outs
 
 
@@ -361,7 +361,8 @@ def packed_v_stage(qls, x, ln=None):
     """launch 1 of packed_forward_fused on its own: xt_i = V_i (LayerNorm(x) (/) s_i), bf16."""
     rows, d = x.shape[0], qls[0].infeatures
     xts = [torch.empty((rows, d), dtype=torch.bfloat16, device=x.device) for _ in qls]
-    ops.ortho_small_ops([q.V.small_op(x.contiguous(), xt, colscale=q.inv_scaleWH, ln=_ln_params(ln)) for q, xt in zip(qls, xts)], rows)
+    x = x.contiguous()
+    ops.ortho_apply_ops([(q.V, q.V.small_op(x, xt, colscale=q.inv_scaleWH, ln=_ln_params(ln)), False) for q, xt in zip(qls, xts)], rows)
     return xts
 
 
@@ -398,7 +399,7 @@ def packed_u_stage(qls, ys, dtype, residual=None, relu=False):
     rows, m = ys[0].shape
     outs = [torch.empty((rows, m), dtype=dtype, device=ys[0].device) for _ in qls]
     res = None if residual is None else residual.contiguous()
-    ops.ortho_small_ops([q.U.small_op(y, o, transpose=True, bias=q.bias, residual=res, relu=relu) for q, y, o in zip(qls, ys, outs)], rows)
+    ops.ortho_apply_ops([(q.U, q.U.small_op(y, o, transpose=True, bias=q.bias, residual=res, relu=relu), True) for q, y, o in zip(qls, ys, outs)], rows)
     return outs
 
 

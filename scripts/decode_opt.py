@@ -119,9 +119,25 @@ class Decoder(nn.Module):
             x = packed_u_stage([blk.fc2], packed_gemm_stage([blk.fc2], xt2), dt, residual=x)[0]
         return x
 
+    tiled = False            # every operator application cut into 16 x 16 output tiles over 8-32 workgroups (csrc/ortho_tile.hip): 13 launches
+
+    def step_tiled(self, x, pos, caches):
+        """V-op, GEMM, U-op as three launches per packed layer group, each operator launch spread over many CUs."""
+        dt = x.dtype
+        for blk, (kc, vc) in zip(self.blocks, caches):
+            qkv = [blk.q_proj, blk.k_proj, blk.v_proj]
+            q, k, v = packed_u_stage(qkv, packed_gemm_stage(qkv, packed_v_stage(qkv, x, ln=blk.ln1)), dt)
+            o = ops.decode_attention(q, k, v, kc, vc, pos)
+            x = packed_u_stage([blk.out_proj], packed_gemm_stage([blk.out_proj], packed_v_stage([blk.out_proj], o)), dt, residual=x)[0]
+            h = packed_u_stage([blk.fc1], packed_gemm_stage([blk.fc1], packed_v_stage([blk.fc1], x, ln=blk.ln2)), dt, relu=True)[0]
+            x = packed_u_stage([blk.fc2], packed_gemm_stage([blk.fc2], packed_v_stage([blk.fc2], h)), dt, residual=x)[0]
+        return x
+
     def step(self, ids, pos, caches, arange):
         """one token for every batch row: ids int64 [bs], pos int64 [1]; returns logits [bs, vocab]."""
         x = self.tok(ids) + self.posemb(pos + 2)
+        if self.tiled:
+            return F.linear(self.lnf(self.step_tiled(x, pos, caches)), self.tok.weight)
         if self.vfused:
             return F.linear(self.lnf(self.step_vfused(x, pos, caches)), self.tok.weight)
         if self.chained:
@@ -242,6 +258,11 @@ def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense
             med, mean, lv = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
             out["packed_w%d_vfused" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
                                                "logits_bit_identical_to_chained": bool(torch.equal(lc, lv))}
+        model.tiled = True
+        torch.manual_seed(7)
+        med, mean, lt = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+        out["packed_w%d_tiled" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+                                          "logits_rel_diff_vs_chained": float((lt - lc).norm() / lc.norm())}
         return out
     med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
     out["packed_w%d" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med, "packed_weight_MB": nbytes / 1e6,
@@ -264,6 +285,10 @@ def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense
         med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
         out["packed_w%d_vfused" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
                                            "what": "V-side operator in the prologue of the dequant-GEMM for the d = 2048 inputs (9 launches per block)"}
+    model.tiled = True
+    med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+    out["packed_w%d_tiled" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+                                      "what": "every operator application tiled over 8-32 workgroups (13 launches per block)"}
     del model
     torch.cuda.empty_cache()
     return out

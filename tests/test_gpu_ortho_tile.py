@@ -1,0 +1,107 @@
+"""-m gpu: the tiled (many-workgroup) form of the small-batch Kronecker operator (csrc/ortho_tile.hip) against the one-workgroup
+kernel it stands in for at decode batch sizes, and against the dense orthogonal matrix in float64."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _op(n, seed):
+    from quip_amd import ops, method
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    return ops.OrthoOp(method.gen_rand_ortho_butterfly_noblock(n), DEV)
+
+
+def _dense(op):
+    """Q with Q x = apply_rows(x): from the identity through the one-workgroup fp32 kernel"""
+    from quip_amd import ops
+    eye = torch.eye(op.n, device=DEV)
+    old = ops.USE_TILES
+    ops.USE_TILES = False
+    try:
+        keep = ops.OrthoOp.use_split
+        ops.OrthoOp.use_split = False
+        Q = op.apply_rows(eye).t().contiguous()            # row r of apply_rows(I) = Q e_r = column r of Q
+        ops.OrthoOp.use_split = keep
+    finally:
+        ops.USE_TILES = old
+    return Q.double()
+
+
+@pytest.mark.parametrize("n,pq", [(2048, (64, 32)), (4096, (64, 64)), (8192, (128, 64))])
+@pytest.mark.parametrize("transpose", [False, True])
+@pytest.mark.parametrize("rows", [1, 3, 8])
+def test_tiles_equal_the_single_workgroup_kernel(n, pq, transpose, rows):
+    from quip_amd import ops
+    op = _op(n, seed=n + rows)
+    assert (op.p, op.q) == pq and op.tile_supported and op.tile_ok == (n >= 4096)
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, n, generator=g).to(DEV)
+    cs = (0.5 + torch.rand(n, generator=g)).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    res = torch.randn(rows, n, generator=g).to(DEV).half()
+    outs = {}
+    for tiles in (True, False):
+        ops.USE_TILES = tiles
+        try:
+            for xdt, odt in ((torch.float16, torch.bfloat16), (torch.float32, torch.float16), (torch.float32, torch.float32)):
+                xi = x.to(xdt)
+                out = torch.empty(rows, n, dtype=odt, device=DEV)
+                d = op.small_op(xi, out, transpose=transpose, colscale=cs, bias=bias, residual=res, relu=(odt == torch.float16))
+                if tiles:
+                    ops.ortho_tile_ops([d], [op.store_inv(transpose)], rows)
+                else:
+                    ops.ortho_small_ops([d], rows)
+                outs[(tiles, xdt, odt)] = out.clone()
+        finally:
+            ops.USE_TILES = True
+    for k in [k for k in outs if k[0]]:
+        assert torch.equal(outs[k], outs[(False,) + k[1:]]), k               # same products, same order: bit-identical
+    Q = _dense(op)
+    ref = (x.double() * cs.double()) @ (Q if transpose else Q.t()) + bias.double() + res.double()
+    got = outs[(True, torch.float32, torch.float32)].double()
+    assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("n", [2048, 8192])
+def test_tiles_with_layernorm_and_three_ops(n):
+    """q / k / v share the input: three operators, one launch, LayerNorm folded in"""
+    from quip_amd import ops
+    opsl = [_op(n, seed=s) for s in (1, 2, 3)]
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(2, n, generator=g).to(DEV).half()
+    ln = torch.nn.LayerNorm(n).to(DEV).half()
+    ln.weight.data = (1 + 0.1 * torch.randn(n, generator=g)).to(DEV).half()
+    ln.bias.data = (0.1 * torch.randn(n, generator=g)).to(DEV).half()
+    cs = [(0.5 + torch.rand(n, generator=g)).to(DEV) for _ in opsl]
+    res = {}
+    for tiles in (True, False):
+        ops.USE_TILES = tiles
+        try:
+            outs = [torch.empty(2, n, dtype=torch.bfloat16, device=DEV) for _ in opsl]
+            descs = [o.small_op(x, out, colscale=c, ln=(ln.weight, ln.bias, ln.eps)) for o, out, c in zip(opsl, outs, cs)]
+            if tiles:
+                ops.ortho_tile_ops(descs, [o.store_inv(False) for o in opsl], 2)
+            else:
+                ops.ortho_small_ops(descs, 2)
+            res[tiles] = [o.float() for o in outs]
+        finally:
+            ops.USE_TILES = True
+    for a, b in zip(res[True], res[False]):
+        assert float((a - b).abs().max()) <= 2 ** -7 * float(b.abs().max())      # one bf16 ulp: the statistics sum in another order
+        assert float((a != b).float().mean()) <= 2e-2
+
+
+def test_tiles_refuse_other_shapes():
+    from quip_amd import _lib
+    lib = _lib.load()
+    assert lib.quipamd_ortho_apply_tiles_supported(64, 32) == 1 and lib.quipamd_ortho_apply_tiles_supported(128, 64) == 1
+    assert lib.quipamd_ortho_apply_tiles_supported(96, 32) == 0
+    op = _op(1024, seed=0)                                  # 32 x 32
+    assert not op.tile_ok and not op.tile_supported
+    x = torch.randn(1, 1024, device=DEV)
+    y = op.apply_rows(x)                                    # falls back to the one-workgroup kernel
+    assert torch.isfinite(y).all()
