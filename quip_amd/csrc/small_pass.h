@@ -2,6 +2,7 @@
 // and dqgemm_vop.hip (operator fused into the dequant-GEMM prologue): helpers, LDS sizing, and the split-bf16 pass.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -65,16 +66,72 @@ __device__ __forceinline__ float4 round4_any(int dt, const float4 &v)
     return v;
 }
 
-// block-wide sum over 1024 threads (16 waves): wave shuffle + one LDS round
+// ---- loads that do not force a wait ---------------------------------------------------------------------------------------------
+// load4_any converts inside the dtype branch, so hipcc has to put an s_waitcnt vmcnt(0) into every branch: N operands of
+// run-time dtype became N SERIAL round trips (1.8 us of a 4.5 us operator launch, s_memtime stamps in scripts/tilelab.hip).
+// raw4_load only issues the load (8 B for the 16-bit types, 16 B for fp32) and hands back the bits; raw4_cvt converts
+// where the value is used, after everything else has been requested.
+__device__ __forceinline__ uint4 raw4_load(const void *p, int dt, int64_t i)
+{
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (dt == QUIPAMD_F32) r = *reinterpret_cast<const uint4 *>((const float *)p + i);
+    else {
+        const uint2 t = *reinterpret_cast<const uint2 *>((const uint16_t *)p + i);
+        r.x = t.x;
+        r.y = t.y;
+    }
+    return r;
+}
+__device__ __forceinline__ float4 raw4_cvt(const uint4 &r, int dt)
+{
+    if (dt == QUIPAMD_F32) return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+    if (dt == QUIPAMD_F16)
+        return make_float4(f16_bits_to_f32(r.x & 0xffff), f16_bits_to_f32(r.x >> 16), f16_bits_to_f32(r.y & 0xffff), f16_bits_to_f32(r.y >> 16));
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint32_t raw1_load(const void *p, int dt, int64_t i)
+{
+    return dt == QUIPAMD_F32 ? ((const uint32_t *)p)[i] : (uint32_t)((const uint16_t *)p)[i];
+}
+__device__ __forceinline__ float raw1_cvt(uint32_t r, int dt)
+{
+    return dt == QUIPAMD_F32 ? __uint_as_float(r) : dt == QUIPAMD_F16 ? f16_bits_to_f32((uint16_t)r) : __uint_as_float(r << 16);
+}
+
+// wave-wide sum on the DPP network (4 v_add with a DPP operand + 4 v_readlane) instead of six ds_bpermute round trips;
+// every lane gets the total
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror: lanes 0-7 <-> 7-0
+    v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror: every lane of a 16-lane row holds the row sum
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+// block-wide sum over NWAVES waves: one LDS round, ONE barrier (each call site owns its red[] slots)
+template <int NWAVES> __device__ __forceinline__ float block_sum_dpp(float v, float *red /* [NWAVES] */)
+{
+    const float w = wave_sum_dpp(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWAVES; i += 4) {
+        const float4 r = *reinterpret_cast<const float4 *>(red + i);
+        t += (r.x + r.y) + (r.z + r.w);
+    }
+    return t;
+}
+
+// block-wide sum over 1024 threads (16 waves): DPP wave sums + one LDS round; the trailing barrier frees red[] for the next call
 __device__ __forceinline__ float block_sum(float v, float *red /* [16] */)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = red[threadIdx.x & 15];
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    const float t = block_sum_dpp<16>(v, red);
     __syncthreads();
     return t;
 }
@@ -153,26 +210,33 @@ __device__ __forceinline__ void small_split_pass(const SmallArgs &A, int64_t row
     // mix stages: fetched where they are used they were 2-3 exposed L2 round trips per launch (a decode step is a chain
     // of these launches; rocprof: 6-9 us each).  PF = 2 covers n <= 8192; larger rows load the rest in place.
     constexpr int PF = 2;
-    float4 pgm[PF], pbt[PF], pcs[PF], pbias[PF], pres[PF];
+    // LayerNorm parameters and the residual come in the model's dtype: for f16 (the decode case) only the BITS are requested
+    // here and converted where they are used -- load4_any converts inside its dtype branch, which costs a full wait per
+    // operand (raw4_load above); other dtypes are loaded in place, later.
+    const bool ln16 = A.ln_gamma && A.ln_dtype == QUIPAMD_F16, res16 = A.residual && A.res_dtype == QUIPAMD_F16;
+    float4 pcs[PF], pbias[PF];
+    uint2 rgm[PF], rbt[PF], rres[PF];
     int4 pld[PF], pst[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int v4 = tid + 1024 * u;
-        pgm[u] = pbt[u] = pbias[u] = pres[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pbias[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         pcs[u] = make_float4(1.f, 1.f, 1.f, 1.f);
         pld[u] = pst[u] = make_int4(4 * v4, 4 * v4 + 1, 4 * v4 + 2, 4 * v4 + 3);
+        rgm[u] = rbt[u] = rres[u] = make_uint2(0u, 0u);
         if (v4 < n4) {
-            if (A.ln_gamma) {
-                pgm[u] = load4_any(A.ln_gamma, A.ln_dtype, 4 * v4);
-                pbt[u] = load4_any(A.ln_beta, A.ln_dtype, 4 * v4);
+            if (ln16) {
+                rgm[u] = *reinterpret_cast<const uint2 *>((const uint16_t *)A.ln_gamma + 4 * v4);
+                rbt[u] = *reinterpret_cast<const uint2 *>((const uint16_t *)A.ln_beta + 4 * v4);
             }
             if (A.colscale) pcs[u] = *reinterpret_cast<const float4 *>(A.colscale + 4 * v4);
             if (A.load_idx) pld[u] = *reinterpret_cast<const int4 *>(A.load_idx + 4 * v4);
             if (A.store_idx) pst[u] = *reinterpret_cast<const int4 *>(A.store_idx + 4 * v4);
             if (A.bias) pbias[u] = *reinterpret_cast<const float4 *>(A.bias + 4 * v4);
-            if (A.residual) pres[u] = load4_any(A.residual, A.res_dtype, row * A.ldo + 4 * v4);
+            if (res16) rres[u] = *reinterpret_cast<const uint2 *>((const uint16_t *)A.residual + row * A.ldo + 4 * v4);
         }
     }
+    auto f16x4 = [](const uint2 &r) { return raw4_cvt(make_uint4(r.x, r.y, 0u, 0u), QUIPAMD_F16); };
     if (A.ln_gamma) {
         float s1 = 0.f;
 #pragma unroll
@@ -191,8 +255,8 @@ __device__ __forceinline__ void small_split_pass(const SmallArgs &A, int64_t row
         for (int u = 0; u < MAXV; ++u) {
             const int v4 = tid + 1024 * u;
             if (v4 < n4) {
-                const float4 gm = u < PF ? pgm[u < PF ? u : 0] : load4_any(A.ln_gamma, A.ln_dtype, 4 * v4);
-                const float4 bt = u < PF ? pbt[u < PF ? u : 0] : load4_any(A.ln_beta, A.ln_dtype, 4 * v4);
+                const float4 gm = (u < PF && ln16) ? f16x4(rgm[u < PF ? u : 0]) : load4_any(A.ln_gamma, A.ln_dtype, 4 * v4);
+                const float4 bt = (u < PF && ln16) ? f16x4(rbt[u < PF ? u : 0]) : load4_any(A.ln_beta, A.ln_dtype, 4 * v4);
                 xv[u] = make_float4((xv[u].x - mean) * rstd * gm.x + bt.x, (xv[u].y - mean) * rstd * gm.y + bt.y,
                                     (xv[u].z - mean) * rstd * gm.z + bt.z, (xv[u].w - mean) * rstd * gm.w + bt.w);
             }
@@ -336,7 +400,7 @@ __device__ __forceinline__ void small_split_pass(const SmallArgs &A, int64_t row
                 v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
             }
             if (A.residual) {
-                const float4 c = u < PF ? pres[u < PF ? u : 0] : load4_any(A.residual, A.res_dtype, row * A.ldo + 4 * v4);
+                const float4 c = (u < PF && res16) ? f16x4(rres[u < PF ? u : 0]) : load4_any(A.residual, A.res_dtype, row * A.ldo + 4 * v4);
                 v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
             }
             if (A.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));

@@ -259,10 +259,24 @@ def ortho_tile_ops(op_list, inv_list, rows):
     _lib.call("quipamd_ortho_apply_tiles", ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(inv, ctypes.c_void_p), n, rows, _stream())
 
 
+def _tile_form(d):
+    """which compiled operand set of csrc/ortho_tile.hip a descriptor has: 'V' (activation side), 'U' (output side) or None"""
+    if not d.load_idx or not d.store_idx:
+        return None
+    if d.x_dtype == _DT[torch.float16] and d.colscale and not d.bias and not d.residual and not d.relu \
+            and (not d.ln_gamma or d.ln_dtype == _DT[torch.float16]):
+        return ('V', bool(d.ln_gamma))
+    if d.x_dtype == _DT[torch.float32] and not d.colscale and d.bias and not d.ln_gamma \
+            and (not d.residual or d.res_dtype == _DT[torch.float16]):
+        return ('U', bool(d.residual))
+    return None
+
+
 def ortho_apply_ops(entries, rows):
     """entries: [(OrthoOp, SmallOp descriptor, transpose)] sharing p, q and dtypes -> ONE launch: tiled over many workgroups for
     a handful of rows (decode), one workgroup per row otherwise."""
-    if USE_TILES and rows <= TILE_ROWS and all(o.tile_ok and o.use_split for o, _, _ in entries):
+    forms = {_tile_form(d) for _, d, _ in entries}
+    if USE_TILES and rows <= TILE_ROWS and all(o.tile_ok and o.use_split for o, _, _ in entries) and len(forms) == 1 and None not in forms:
         ortho_tile_ops([d for _, d, _ in entries], [o.store_inv(t) for o, _, t in entries], rows)
     else:
         ortho_small_ops([d for _, d, _ in entries], rows)
@@ -339,9 +353,8 @@ class OrthoOp:
                     hi = M.to(torch.bfloat16)
                     return hi.contiguous(), (M - hi.float()).to(torch.bfloat16).contiguous()
                 self._Msplit = {k: hl(m0) + hl(m1) for k, (m0, m1) in self._M.items()}
-        # csrc/ortho_tile.hip covers 64x32 too, but a launch has ~3.4 us of fixed latency (ramp, first load, store) and at
-        # n = 2048 one workgroup finishes in 5.2 us against 6.0 us tiled (profiles/r02l_decode_kernel_trace.txt): tiles from n = 4096
-        self.tile_ok = self.split_ok and (self.p, self.q) in ((64, 64), (128, 64))
+        # csrc/ortho_tile.hip: one workgroup per 16 x 16 output tile for a handful of rows (decode)
+        self.tile_ok = self.split_ok and (self.p, self.q) in ((64, 32), (64, 64), (128, 64))
         self.tile_supported = self.split_ok and (self.p, self.q) in ((64, 32), (64, 64), (128, 64))
 
     def store_inv(self, transpose):

@@ -115,9 +115,14 @@ class Decoder(nn.Module):
             o = ops.decode_attention(q, k, v, kc, vc, pos)
             x = packed_u_stage([blk.out_proj], packed_vgemm_stage([blk.out_proj], o), dt, residual=x)[0]
             y1 = packed_vgemm_stage([blk.fc1], x, ln=blk.ln2)[0]
-            _, xt2 = packed_u_then_v(blk.fc1, y1, dt, [blk.fc2], relu=True, store=False)
+            if self.split_handover:      # n = 8192: two tiled launches (32 workgroups each) beat the one-workgroup chain (17.4 us)
+                xt2 = packed_v_stage([blk.fc2], packed_u_stage([blk.fc1], [y1], dt, relu=True)[0])
+            else:
+                _, xt2 = packed_u_then_v(blk.fc1, y1, dt, [blk.fc2], relu=True, store=False)
             x = packed_u_stage([blk.fc2], packed_gemm_stage([blk.fc2], xt2), dt, residual=x)[0]
         return x
+
+    split_handover = False
 
     tiled = False            # every operator application cut into 16 x 16 output tiles over 8-32 workgroups (csrc/ortho_tile.hip): 13 launches
 
@@ -258,6 +263,11 @@ def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense
             med, mean, lv = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
             out["packed_w%d_vfused" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
                                                "logits_bit_identical_to_chained": bool(torch.equal(lc, lv))}
+            model.split_handover = True
+            torch.manual_seed(7)
+            med, mean, lh = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+            out["packed_w%d_vfused_split_handover" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+                                                              "logits_bit_identical_to_vfused": bool(torch.equal(lh, lv))}
         model.tiled = True
         torch.manual_seed(7)
         med, mean, lt = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
@@ -285,10 +295,16 @@ def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense
         med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
         out["packed_w%d_vfused" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
                                            "what": "V-side operator in the prologue of the dequant-GEMM for the d = 2048 inputs (9 launches per block)"}
+        model.split_handover = True
+        med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+        out["packed_w%d_vfused_split_handover" % bits] = {
+            "ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+            "what": "as vfused, the n = 8192 fc1 -> fc2 hand-over as two tiled operator launches (32 workgroups each) instead of "
+                    "one one-workgroup chain launch (10 launches per block)"}
     model.tiled = True
     med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
     out["packed_w%d_tiled" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
-                                      "what": "every operator application tiled over 8-32 workgroups (13 launches per block)"}
+                                      "what": "V-op, GEMM, U-op as separate launches, every operator tiled over 8-32 workgroups (13 launches per block)"}
     del model
     torch.cuda.empty_cache()
     return out

@@ -37,33 +37,44 @@ def _dense(op):
 def test_tiles_equal_the_single_workgroup_kernel(n, pq, transpose, rows):
     from quip_amd import ops
     op = _op(n, seed=n + rows)
-    assert (op.p, op.q) == pq and op.tile_supported and op.tile_ok == (n >= 4096)
+    assert (op.p, op.q) == pq and op.tile_supported and op.tile_ok
     g = torch.Generator().manual_seed(rows)
     x = torch.randn(rows, n, generator=g).to(DEV)
     cs = (0.5 + torch.rand(n, generator=g)).to(DEV)
     bias = torch.randn(n, generator=g).to(DEV)
     res = torch.randn(rows, n, generator=g).to(DEV).half()
+    # the two operand sets a decode step has (csrc/ortho_tile.hip): activation side and output side
+    cases = {"V": dict(xdt=torch.float16, odt=torch.bfloat16, kw=dict(colscale=cs)),
+             "V16": dict(xdt=torch.float16, odt=torch.float16, kw=dict(colscale=cs)),
+             "U": dict(xdt=torch.float32, odt=torch.float16, kw=dict(bias=bias, residual=res, relu=True)),
+             "U32": dict(xdt=torch.float32, odt=torch.float32, kw=dict(bias=bias))}
     outs = {}
     for tiles in (True, False):
-        ops.USE_TILES = tiles
-        try:
-            for xdt, odt in ((torch.float16, torch.bfloat16), (torch.float32, torch.float16), (torch.float32, torch.float32)):
-                xi = x.to(xdt)
-                out = torch.empty(rows, n, dtype=odt, device=DEV)
-                d = op.small_op(xi, out, transpose=transpose, colscale=cs, bias=bias, residual=res, relu=(odt == torch.float16))
-                if tiles:
-                    ops.ortho_tile_ops([d], [op.store_inv(transpose)], rows)
-                else:
-                    ops.ortho_small_ops([d], rows)
-                outs[(tiles, xdt, odt)] = out.clone()
-        finally:
-            ops.USE_TILES = True
-    for k in [k for k in outs if k[0]]:
-        assert torch.equal(outs[k], outs[(False,) + k[1:]]), k               # same products, same order: bit-identical
+        for name, c in cases.items():
+            xi = x.to(c["xdt"])
+            out = torch.empty(rows, n, dtype=c["odt"], device=DEV)
+            d = op.small_op(xi, out, transpose=transpose, **c["kw"])
+            if tiles:
+                ops.ortho_tile_ops([d], [op.store_inv(transpose)], rows)
+            else:
+                ops.ortho_small_ops([d], rows)
+            outs[(tiles, name)] = out.clone()
+    for name in cases:
+        assert torch.equal(outs[(True, name)], outs[(False, name)]), name           # same products, same order: bit-identical
     Q = _dense(op)
-    ref = (x.double() * cs.double()) @ (Q if transpose else Q.t()) + bias.double() + res.double()
-    got = outs[(True, torch.float32, torch.float32)].double()
+    ref = x.double() @ (Q if transpose else Q.t()) + bias.double()
+    got = outs[(True, "U32")].double()
     assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
+def test_tiles_refuse_an_operand_set_they_were_not_compiled_for():
+    from quip_amd import ops
+    op = _op(2048, seed=3)
+    x = torch.randn(1, 2048, device=DEV).half()
+    out = torch.empty(1, 2048, dtype=torch.bfloat16, device=DEV)
+    d = op.small_op(x, out, bias=torch.zeros(2048, device=DEV))                   # f16 input with a bias: neither side
+    with pytest.raises(RuntimeError, match="neither"):
+        ops.ortho_tile_ops([d], [op.store_inv(False)], 1)
 
 
 @pytest.mark.parametrize("n", [2048, 8192])
