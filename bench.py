@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ldlq", action="store_true", help="skip the sharded-LDLQ side measurement")
     ap.add_argument("--no-decode", action="store_true", help="skip the OPT-1.3B w2 decode tok/s side measurement")
+    ap.add_argument("--no-llama", action="store_true", help="skip the Llama-2-7B-architecture decode side measurement (about 40 s)")
     ap.add_argument("--profile-cold-only", action="store_true",
                     help="for rocprofv3 passes: run only the cold bf16 regime (so per-kernel averages are the headline kernel's)")
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of a hipGraph")
@@ -403,6 +404,28 @@ def main():
                          "packed_weight_MB": round(dres["packed_w2"]["packed_weight_MB"], 1),
                          "hbm_bound_tok_per_s": round(dres["packed_w2"]["hbm_bound_tok_per_s"]),
                          "data": "random-init OPT-1.3B architecture, nearest-rounded qfn-b codes (scripts/decode_opt.py)"}
+
+    # ---- the Llama half of the decode row (llama.py:418-471): Llama-2-7B architecture, w2, batch 1 (scripts/decode_llama.py) ----
+    if rank == 0 and world == 1 and not args.no_decode and not args.no_llama:
+        try:
+            import importlib.util
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts"))
+            spec = importlib.util.spec_from_file_location(
+                "decode_llama", os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "decode_llama.py"))
+            lmod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(lmod)
+            torch.cuda.empty_cache()
+            lres = lmod.run(layers=32, bits=BITS, bs=1, prompt=32, tokens=48)
+            out["decode_llama"] = {"metric": "Llama-2-7B-architecture w2 (incoherence-processed, packed) decode tok/s, batch 1, one hipGraph per token",
+                                   "value": round(lres["packed_w2_fused"]["tok_per_s"], 1), "unit": "tok/s",
+                                   "ms_per_token": round(lres["packed_w2_fused"]["ms_per_token_median"], 3),
+                                   "unfused_tok_per_s": round(lres["packed_w2"]["tok_per_s"], 1),
+                                   "dense_fp16_same_harness_tok_per_s": round(lres["dense_fp16"]["tok_per_s"], 1),
+                                   "packed_weight_MB": round(lres["packed_w2"]["packed_weight_MB"], 1),
+                                   "hbm_bound_tok_per_s": round(lres["packed_w2"]["hbm_bound_tok_per_s"]),
+                                   "data": "random-init Llama-2-7B architecture, nearest-rounded qfn-b codes (scripts/decode_llama.py)"}
+        except Exception as ex:
+            out["decode_llama"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         Wd = ops.codes_to_weight(codes, "b", scale, None, MAXQ, out_dtype=torch.float32).cpu()

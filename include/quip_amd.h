@@ -185,8 +185,8 @@ int quipamd_ortho_apply_small(const float *M0, const float *M1, const int32_t *l
 
 /* One small-batch operator application with the elementwise work of its neighbours in the decoder block fused in
  * (a decode step is launch-latency bound):  out = [relu]( Q . ( colscale * [LayerNorm](x) ) + bias + residual ).
- * Fields as in quipamd_ortho_apply_small; ln_gamma / ln_beta (dtype ln_dtype, NULL = no LayerNorm, statistics in
- * fp32 over the row with ln_eps); residual ([rows, n], leading dimension ldo, dtype res_dtype, NULL = none). */
+ * Fields as in quipamd_ortho_apply_small; ln_gamma / ln_beta (dtype ln_dtype, ln_gamma NULL = no normalisation, statistics in
+ * fp32 over the row with ln_eps; ln_gamma without ln_beta = RMSNorm, x * rsqrt(mean(x^2) + eps) * gamma, the Llama block's norm); residual ([rows, n], leading dimension ldo, dtype res_dtype, NULL = none). */
 typedef struct quipamd_small_op {
     const float *M0, *M1;
     const int32_t *load_idx, *store_idx;
@@ -221,6 +221,13 @@ int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int nops, int64_t
  * (or a NULL array) exactly where store_idx is NULL.  rows <= 65535. */
 int quipamd_ortho_apply_tiles(const quipamd_small_op *ops, const int32_t *const *store_inv, int nops, int64_t rows, void *stream);
 int quipamd_ortho_apply_tiles_supported(int p, int q);
+
+/* The same for a Kronecker operator p x 16 with a large p (Llama's 11008 = 688 x 16: neither factor fits a workgroup's LDS, the
+ * general quipamd_ortho_apply_rows pads one row to 16): one workgroup per 16 rows of the p x 16 image (p / 16 workgroups per
+ * operator and row), fp32 MFMA, factors M0 [p, p] / M1 [16, 16] as for quipamd_ortho_apply_small.  Operand sets: (x f16, colscale)
+ * or (x f32, bias, [f16 residual], relu); both permutations and their store_inv; no normalisation.  p % 16 == 0, 64 <= p <= 768. */
+int quipamd_ortho_apply_bigp(const quipamd_small_op *ops, const int32_t *const *store_inv, int nops, int64_t rows, void *stream);
+int quipamd_ortho_apply_bigp_supported(int p, int q);
 
 /* Chain of two operator applications in ONE launch (decode: U^T y + bias + residual -> [LayerNorm] -> V (x (/) s) of two
  * consecutive packed layers):  t = epilogue_first(Q_first x_first)  is stored to first->out (when not NULL) in
@@ -328,6 +335,13 @@ int quipamd_hessian_accum_fast(const void *x, int x_dtype, int64_t ldx, int64_t 
  *   info: DEVICE int, 0 on success, else 1 + the first column whose pivot was not positive (LAPACK potrf convention) --
  *   the factor is then meaningless. */
 int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *info, void *stream);
+
+/* Rotary position embedding of one decode step, in place on q [bs, heads * hd] and k [bs, kv_heads * hd] (row strides ldq, ldk)
+ * at position *pos (DEVICE memory: the launch can be replayed in a hipGraph while the position advances):
+ *   x[i] <- x[i] cos[pos][i] - x[i + hd/2] sin[pos][i];  x[i + hd/2] <- x[i + hd/2] cos[pos][i] + x[i] sin[pos][i]   (i < hd/2)
+ * = HF's apply_rotary_pos_emb (q * cos + rotate_half(q) * sin) behind llama.py:418-471.  cos / sin: float [maxpos, hd]. */
+int quipamd_rope_inplace(void *q, void *k, const float *cos_table, const float *sin_table, const int64_t *pos, int dtype,
+                         int64_t bs, int heads, int kv_heads, int hd, int64_t ldq, int64_t ldk, void *stream);
 
 /* ---- single-token decode attention (the decode loop of benchmark(), opt.py:431-482) -------------
  * Replaces the eager HF attention chain of one decode step (cache append, q K^T, scale + causal mask, softmax, p V --

@@ -39,6 +39,8 @@ SIGNATURES = {
     "quipamd_ortho_apply_small_ops": [c_vp, c_int, c_i64, c_vp],
     "quipamd_ortho_apply_tiles": [c_vp, c_vp, c_int, c_i64, c_vp],
     "quipamd_ortho_apply_tiles_supported": [c_int, c_int],
+    "quipamd_ortho_apply_bigp": [c_vp, c_vp, c_int, c_i64, c_vp],
+    "quipamd_ortho_apply_bigp_supported": [c_int, c_int],
     "quipamd_tune_dequant_gemm": [c_int, c_int, c_int, c_int],
     "quipamd_ortho_apply_rows": [c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_i64,
                                  c_vp, c_int, c_i64, c_i64, c_vp, c_vp],
@@ -54,6 +56,7 @@ SIGNATURES = {
     "quipamd_unit_upper_inverse": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "quipamd_gptq_round_groups": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp],
     "quipamd_decode_attention": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_i64, c_float, c_i64, c_vp],
+    "quipamd_rope_inplace": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_i64, c_i64, c_vp],
     "quipamd_cholesky_lt": [c_vp, c_vp, c_i64, c_vp, c_vp],
     "quipamd_hessian_accum": [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp],
     "quipamd_hessian_finish": [c_vp, c_double, c_vp, c_i64, c_vp],

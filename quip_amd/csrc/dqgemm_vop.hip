@@ -154,7 +154,6 @@ extern "C" int quipamd_dequant_gemm_vop(const quipamd_small_op *vops, const int3
                    "dequant_gemm_vop: x must be f16 or bf16");
         QA_REQUIRE(o.ldx >= 2048 && o.ldx % 4 == 0 && !o.residual && !o.bias && !o.relu, QUIPAMD_ERR_ARG,
                    "dequant_gemm_vop: V-side descriptor expected (no bias / residual / relu)");
-        QA_REQUIRE(!o.ln_gamma || o.ln_beta, QUIPAMD_ERR_ARG, "dequant_gemm_vop: LayerNorm needs gamma and beta");
         B.v[i] = o;
         B.qw[i] = (const uint4 *)qweight[i];
         B.scale[i] = scale[i];

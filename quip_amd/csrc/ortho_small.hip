@@ -60,10 +60,14 @@ __global__ __launch_bounds__(1024) void ortho_small_kernel(SmallBatch Bt)
         xv[u] = v4 < n4 ? load4<TI>(A.x, row * A.ldx + 4 * v4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (A.ln_gamma) {
-        float s1 = 0.f;
+        const bool rms = A.ln_beta == nullptr;                 // RMSNorm: no mean, no shift
+        float mean = 0.f;
+        if (!rms) {
+            float s1 = 0.f;
 #pragma unroll
-        for (int u = 0; u < MAXV; ++u) s1 += (xv[u].x + xv[u].y) + (xv[u].z + xv[u].w);
-        const float mean = block_sum(s1, red) / (float)n;
+            for (int u = 0; u < MAXV; ++u) s1 += (xv[u].x + xv[u].y) + (xv[u].z + xv[u].w);
+            mean = block_sum(s1, red) / (float)n;
+        }
         float s2 = 0.f;
 #pragma unroll
         for (int u = 0; u < MAXV; ++u) {
@@ -77,7 +81,8 @@ __global__ __launch_bounds__(1024) void ortho_small_kernel(SmallBatch Bt)
         for (int u = 0; u < MAXV; ++u) {
             const int v4 = tid + 1024 * u;
             if (v4 < n4) {
-                const float4 gm = load4_any(A.ln_gamma, A.ln_dtype, 4 * v4), bt = load4_any(A.ln_beta, A.ln_dtype, 4 * v4);
+                const float4 gm = load4_any(A.ln_gamma, A.ln_dtype, 4 * v4);
+                const float4 bt = rms ? make_float4(0.f, 0.f, 0.f, 0.f) : load4_any(A.ln_beta, A.ln_dtype, 4 * v4);
                 xv[u] = make_float4((xv[u].x - mean) * rstd * gm.x + bt.x, (xv[u].y - mean) * rstd * gm.y + bt.y,
                                     (xv[u].z - mean) * rstd * gm.z + bt.z, (xv[u].w - mean) * rstd * gm.w + bt.w);
             }
@@ -297,7 +302,6 @@ extern "C" int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int no
                    "ortho_apply_small: ops of one launch must share p, q and dtypes (op %d differs)", i);
         QA_REQUIRE(o.ldx >= (int64_t)p * q && o.ldo >= (int64_t)p * q && o.ldx % 4 == 0 && o.ldo % 4 == 0, QUIPAMD_ERR_SHAPE,
                    "ortho_apply_small: leading dimensions must be >= n and multiples of 4");
-        QA_REQUIRE(!o.ln_gamma || o.ln_beta, QUIPAMD_ERR_ARG, "ortho_apply_small: LayerNorm needs gamma and beta");
         B.op[i] = o;
     }
     for (int i = nops; i < QUIPAMD_SMALL_MAX_OPS; ++i) B.op[i] = ops[0];
@@ -340,7 +344,6 @@ extern "C" int quipamd_ortho_apply_small_chain(const quipamd_small_op *first, co
         QA_REQUIRE(o.p == p && o.q == q && o.out_dtype == out_dtype && o.out && o.M0_hi && o.M0_lo && o.M1_hi && o.M1_lo, QUIPAMD_ERR_ARG,
                    "ortho_apply_small_chain: second op %d must share p, q, the output dtype and carry split-bf16 factors", i);
         QA_REQUIRE(o.ldo >= (int64_t)p * q && o.ldo % 4 == 0, QUIPAMD_ERR_SHAPE, "ortho_apply_small_chain: leading dimensions");
-        QA_REQUIRE(!o.ln_gamma || o.ln_beta, QUIPAMD_ERR_ARG, "ortho_apply_small_chain: LayerNorm needs gamma and beta");
         QA_REQUIRE(!o.residual, QUIPAMD_ERR_UNSUPPORTED, "ortho_apply_small_chain: residual on a second op");
         B.op[1 + i] = o;
     }

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(TT) void ortho_tile_kernel(TileBatch Bt)
         }
         if constexpr (LN) {
             rgm[u] = *reinterpret_cast<const uint2 *>((const uint16_t *)A.ln_gamma + 4 * v4);
-            rbt[u] = *reinterpret_cast<const uint2 *>((const uint16_t *)A.ln_beta + 4 * v4);
+            rbt[u] = *reinterpret_cast<const uint2 *>((const uint16_t *)(A.ln_beta ? A.ln_beta : A.ln_gamma) + 4 * v4);   // RMSNorm: unused
         }
         pld[u] = *reinterpret_cast<const int4 *>(A.load_idx + 4 * v4);
     }
@@ -125,10 +125,14 @@ __global__ __launch_bounds__(TT) void ortho_tile_kernel(TileBatch Bt)
 #pragma unroll
     for (int u = 0; u < MAXV; ++u) xv[u] = raw4_cvt(rx[u], SIDE == 0 ? QUIPAMD_F16 : QUIPAMD_F32);
     if constexpr (LN) {
-        float s1 = 0.f;
+        const bool rms = A.ln_beta == nullptr;              // RMSNorm (Llama): x * rsqrt(mean(x^2) + eps) * gamma
+        float mean = 0.f;
+        if (!rms) {
+            float s1 = 0.f;
 #pragma unroll
-        for (int u = 0; u < MAXV; ++u) s1 += (xv[u].x + xv[u].y) + (xv[u].z + xv[u].w);
-        const float mean = block_sum_dpp<TT / 64>(s1, red) / (float)N;
+            for (int u = 0; u < MAXV; ++u) s1 += (xv[u].x + xv[u].y) + (xv[u].z + xv[u].w);
+            mean = block_sum_dpp<TT / 64>(s1, red) / (float)N;
+        }
         float s2 = 0.f;
 #pragma unroll
         for (int u = 0; u < MAXV; ++u) {
@@ -138,7 +142,8 @@ __global__ __launch_bounds__(TT) void ortho_tile_kernel(TileBatch Bt)
         const float rstd = rsqrtf(block_sum_dpp<TT / 64>(s2, red + 8) / (float)N + A.ln_eps);
 #pragma unroll
         for (int u = 0; u < MAXV; ++u) {
-            const float4 gm = raw4_cvt(make_uint4(rgm[u].x, rgm[u].y, 0u, 0u), QUIPAMD_F16), bt = raw4_cvt(make_uint4(rbt[u].x, rbt[u].y, 0u, 0u), QUIPAMD_F16);
+            const float4 gm = raw4_cvt(make_uint4(rgm[u].x, rgm[u].y, 0u, 0u), QUIPAMD_F16);
+            const float4 bt = rms ? make_float4(0.f, 0.f, 0.f, 0.f) : raw4_cvt(make_uint4(rbt[u].x, rbt[u].y, 0u, 0u), QUIPAMD_F16);
             xv[u] = make_float4((xv[u].x - mean) * rstd * gm.x + bt.x, (xv[u].y - mean) * rstd * gm.y + bt.y,
                                 (xv[u].z - mean) * rstd * gm.z + bt.z, (xv[u].w - mean) * rstd * gm.w + bt.w);
         }
@@ -316,7 +321,6 @@ extern "C" int quipamd_ortho_apply_tiles(const quipamd_small_op *ops, const int3
         QA_REQUIRE(o.M0_hi && o.M0_lo && o.M1_hi && o.M1_lo && o.x && o.out, QUIPAMD_ERR_ARG,
                    "ortho_apply_tiles: op %d needs x, out and the four split-bf16 factor arrays", i);
         QA_REQUIRE(o.ldx >= (int64_t)p * q && o.ldo >= (int64_t)p * q && o.ldx % 4 == 0, QUIPAMD_ERR_SHAPE, "ortho_apply_tiles: leading dimensions");
-        QA_REQUIRE(!o.ln_gamma || o.ln_beta, QUIPAMD_ERR_ARG, "ortho_apply_tiles: LayerNorm needs gamma and beta");
         bool f = false;
         const int sd = tile_side(o, store_inv ? store_inv[i] : nullptr, f);
         QA_REQUIRE(sd >= 0, QUIPAMD_ERR_UNSUPPORTED,

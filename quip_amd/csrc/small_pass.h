@@ -227,7 +227,7 @@ __device__ __forceinline__ void small_split_pass(const SmallArgs &A, int64_t row
         if (v4 < n4) {
             if (ln16) {
                 rgm[u] = *reinterpret_cast<const uint2 *>((const uint16_t *)A.ln_gamma + 4 * v4);
-                rbt[u] = *reinterpret_cast<const uint2 *>((const uint16_t *)A.ln_beta + 4 * v4);
+                if (A.ln_beta) rbt[u] = *reinterpret_cast<const uint2 *>((const uint16_t *)A.ln_beta + 4 * v4);
             }
             if (A.colscale) pcs[u] = *reinterpret_cast<const float4 *>(A.colscale + 4 * v4);
             if (A.load_idx) pld[u] = *reinterpret_cast<const int4 *>(A.load_idx + 4 * v4);
@@ -238,10 +238,15 @@ __device__ __forceinline__ void small_split_pass(const SmallArgs &A, int64_t row
     }
     auto f16x4 = [](const uint2 &r) { return raw4_cvt(make_uint4(r.x, r.y, 0u, 0u), QUIPAMD_F16); };
     if (A.ln_gamma) {
-        float s1 = 0.f;
+        // ln_beta == NULL: RMSNorm (Llama) -- no mean, no shift:  x * rsqrt(mean(x^2) + eps) * gamma
+        const bool rms = A.ln_beta == nullptr;
+        float mean = 0.f;
+        if (!rms) {
+            float s1 = 0.f;
 #pragma unroll
-        for (int u = 0; u < MAXV; ++u) s1 += (xv[u].x + xv[u].y) + (xv[u].z + xv[u].w);
-        const float mean = block_sum(s1, red) / (float)n;
+            for (int u = 0; u < MAXV; ++u) s1 += (xv[u].x + xv[u].y) + (xv[u].z + xv[u].w);
+            mean = block_sum(s1, red) / (float)n;
+        }
         float s2 = 0.f;
 #pragma unroll
         for (int u = 0; u < MAXV; ++u) {
@@ -256,7 +261,8 @@ __device__ __forceinline__ void small_split_pass(const SmallArgs &A, int64_t row
             const int v4 = tid + 1024 * u;
             if (v4 < n4) {
                 const float4 gm = (u < PF && ln16) ? f16x4(rgm[u < PF ? u : 0]) : load4_any(A.ln_gamma, A.ln_dtype, 4 * v4);
-                const float4 bt = (u < PF && ln16) ? f16x4(rbt[u < PF ? u : 0]) : load4_any(A.ln_beta, A.ln_dtype, 4 * v4);
+                const float4 bt = rms ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                      : (u < PF && ln16) ? f16x4(rbt[u < PF ? u : 0]) : load4_any(A.ln_beta, A.ln_dtype, 4 * v4);
                 xv[u] = make_float4((xv[u].x - mean) * rstd * gm.x + bt.x, (xv[u].y - mean) * rstd * gm.y + bt.y,
                                     (xv[u].z - mean) * rstd * gm.z + bt.z, (xv[u].w - mean) * rstd * gm.w + bt.w);
             }

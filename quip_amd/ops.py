@@ -272,10 +272,23 @@ def _tile_form(d):
     return None
 
 
+def ortho_bigp_ops(op_list, inv_list, rows):
+    """operators p x 16 with a large p (11008 = 688 x 16), one workgroup per 16 image rows (quipamd_ortho_apply_bigp)"""
+    n = len(op_list)
+    arr = (SmallOp * n)(*op_list)
+    inv = (ctypes.c_void_p * n)(*[ctypes.c_void_p(0 if t is None else t.data_ptr()) for t in inv_list])
+    _lib.call("quipamd_ortho_apply_bigp", ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(inv, ctypes.c_void_p), n, rows, _stream())
+
+
 def ortho_apply_ops(entries, rows):
     """entries: [(OrthoOp, SmallOp descriptor, transpose)] sharing p, q and dtypes -> ONE launch: tiled over many workgroups for
     a handful of rows (decode), one workgroup per row otherwise."""
     forms = {_tile_form(d) for _, d, _ in entries}
+    if all(o.bigp_ok and not o.small_ok for o, _, _ in entries):
+        assert rows <= TILE_ROWS and len(forms) == 1 and None not in forms and not any(d.ln_gamma for _, d, _ in entries), \
+            "p x 16 operators: a handful of rows, activation-side or output-side operand set, no normalisation"
+        ortho_bigp_ops([d for _, d, _ in entries], [o.store_inv(t) for o, _, t in entries], rows)
+        return
     if USE_TILES and rows <= TILE_ROWS and all(o.tile_ok and o.use_split for o, _, _ in entries) and len(forms) == 1 and None not in forms:
         ortho_tile_ops([d for _, d, _ in entries], [o.store_inv(t) for o, _, t in entries], rows)
     else:
@@ -342,9 +355,12 @@ class OrthoOp:
         lds = (self.p * (self.p + 4) + self.q * (self.q + 4) + 2 * self.p * (self.q + 4) + 16) * 4
         self.split_ok = False
         self.small_ok = (not self.blocked) and self.p % 16 == 0 and self.q % 16 == 0 and lds <= 160 * 1024 and self.n <= 16384 and (self.q & (self.q - 1)) == 0
-        if self.small_ok:
+        # p x 16 with a large p (Llama's 11008 = 688 x 16): csrc/ortho_bigp.hip for a handful of rows
+        self.bigp_ok = (not self.blocked) and self.q == 16 and self.p % 16 == 0 and 64 <= self.p and self.n <= 12288
+        if self.small_ok or self.bigp_ok:
             self._M = {False: (B0[0].contiguous(), B1[0].contiguous()),
                        True: (B0[0].t().contiguous(), B1[0].t().contiguous())}
+        if self.small_ok:
             # split-bf16 copies of the factors (hi + lo) for the bf16-pipe variant of the small-batch kernel
             split_lds = 2 * (2 * (self.p * (self.p + 8) + self.q * (self.q + 8)) + 2 * self.q * (self.p + 8) + 2 * self.p * (self.q + 8)) + 64
             self.split_ok = self.p % 32 == 0 and self.q % 32 == 0 and 2 * self.q >= self.p and split_lds <= 160 * 1024
@@ -356,6 +372,17 @@ class OrthoOp:
         # csrc/ortho_tile.hip: one workgroup per 16 x 16 output tile for a handful of rows (decode)
         self.tile_ok = self.split_ok and (self.p, self.q) in ((64, 32), (64, 64), (128, 64))
         self.tile_supported = self.split_ok and (self.p, self.q) in ((64, 32), (64, 64), (128, 64))
+
+    def zero_bias(self):
+        """n float32 zeros: what a bias-free layer (Llama) hands the output-side kernels as `bias`"""
+        if getattr(self, '_zero_bias', None) is None:
+            self._zero_bias = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+        return self._zero_bias
+
+    def one_scale(self):
+        if getattr(self, '_one_scale', None) is None:
+            self._one_scale = torch.ones(self.n, dtype=torch.float32, device=self.device)
+        return self._one_scale
 
     def store_inv(self, transpose):
         """image position -> output index: the inverse of the `store_idx` small_op() hands to the kernels"""
@@ -398,6 +425,18 @@ class OrthoOp:
             finally:
                 self.use_split = split
             return out
+        if self.bigp_ok and rows <= TILE_ROWS and x.stride(0) % 4 == 0 and x.dtype in (torch.float16, torch.float32) \
+                and self.pin is not None and self.pout is not None:
+            if x.dtype == torch.float16:            # activation-side operand set: (x f16, colscale); a bias is added afterwards
+                ones = cs if cs is not None else self.one_scale()
+                ortho_bigp_ops([self.small_op(x, out, transpose=transpose, colscale=ones)], [self.store_inv(transpose)], rows)
+                if bias is not None:
+                    out += _f32vec(bias, x.device).to(out.dtype)
+                return out
+            if cs is None:                           # output-side operand set: (x f32, bias)
+                b = _f32vec(bias, x.device) if bias is not None else self.zero_bias()
+                ortho_bigp_ops([self.small_op(x, out, transpose=transpose, bias=b)], [self.store_inv(transpose)], rows)
+                return out
         ws = torch.empty((16 * ((rows + 15) // 16), self.n), dtype=torch.float32, device=x.device)
         f1, f2 = self._stage_frags(bool(transpose))
         gather, scatter = (self.inv_pout, self.pin) if transpose else (self.pin, self.inv_pout)
@@ -414,7 +453,7 @@ class OrthoOp:
         ln = (gamma, beta, eps) tensors on the device; every tensor argument must outlive the launch call.
         For ortho_small_chain: x may be None (a second op) and out may be None with out_dtype / ld given (a first op whose
         result is only handed over)."""
-        assert self.small_ok and (x is None or x.stride(1) == 1) and (out is None or out.stride(1) == 1)
+        assert (self.small_ok or self.bigp_ok) and (x is None or x.stride(1) == 1) and (out is None or out.stride(1) == 1)
         _f32ptr(colscale, "colscale"), _f32ptr(bias, "bias")          # read as float* by the kernel
         if x is None or out is None:
             n = self.p * self.q
@@ -618,6 +657,20 @@ def hessian_finish(Hacc, nsamples):
 
 
 # ------------------------------------------------------------------------------------------------- decode attention
+def rope_inplace(q, k, cos_table, sin_table, pos, heads, kv_heads=None):
+    """rotary embedding of one decode step, in place on q [bs, heads*hd] and k [bs, kv_heads*hd] at position pos (int64 [1] on
+    the device); cos_table / sin_table float32 [maxpos, hd] in HF's duplicated-halves layout (quipamd_rope_inplace)."""
+    _need_gpu(q, k, cos_table, sin_table, pos)
+    kv_heads = kv_heads or heads
+    bs = q.shape[0]
+    hd = q.shape[1] // heads
+    assert q.dtype == k.dtype and q.stride(1) == 1 and k.stride(1) == 1 and k.shape[1] == kv_heads * hd
+    assert cos_table.dtype == torch.float32 and sin_table.dtype == torch.float32 and cos_table.shape[1] == hd and cos_table.is_contiguous()
+    assert pos.dtype == torch.int64 and pos.numel() == 1
+    _lib.call("quipamd_rope_inplace", _p(q), _p(k), _p(cos_table), _p(sin_table), _p(pos), _dtype(q), bs, heads, kv_heads, hd,
+              q.stride(0), k.stride(0), _stream())
+
+
 def decode_attention(q, k, v, kcache, vcache, pos, scale=None):
     """one decode step of causal attention with a static KV cache, one launch (quip_amd/csrc/decode_attn.hip).
     q, k, v: [bs, heads*hd] f16/bf16; kcache, vcache: [bs, heads, maxlen, hd] contiguous (updated in place at *pos);

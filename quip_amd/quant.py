@@ -312,7 +312,16 @@ def make_quant3(module, names, name=''):
 
 
 def _ln_params(ln):
-    return None if ln is None else (ln.weight, ln.bias, ln.eps)
+    """(gamma, beta, eps) of an nn.LayerNorm; an RMSNorm module (torch.nn.RMSNorm, HF LlamaRMSNorm: weight + eps /
+    variance_epsilon, no bias) gives beta = None, which the kernels read as RMSNorm."""
+    if ln is None:
+        return None
+    eps = getattr(ln, 'eps', None)
+    if eps is None:
+        eps = getattr(ln, 'variance_epsilon', None)
+    if eps is None:
+        eps = torch.finfo(ln.weight.dtype).eps              # torch.nn.RMSNorm(eps=None)
+    return (ln.weight, getattr(ln, 'bias', None), eps)
 
 
 def _fusable(ql, rows):
@@ -320,35 +329,62 @@ def _fusable(ql, rows):
             and ql.qfn == 'b')
 
 
+def _norm(ln, x):
+    if ln is None:
+        return x
+    if isinstance(ln, nn.Module):
+        return ln(x)
+    g, b, eps = ln                                          # a (gamma, beta, eps) tuple: LayerNorm, or RMSNorm when beta is None
+    xf = x.float()
+    if b is None:
+        return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * g.float()).to(x.dtype)
+    return torch.nn.functional.layer_norm(xf, (x.shape[-1],), g.float(), b.float(), eps).to(x.dtype)
+
+
 def packed_forward_fused(qls, x, ln=None, residual=None, relu=False):
-    """Forward of 1..4 packed layers that share the input x [rows, d] (q / k / v of a block, or a single layer) in THREE
-    launches total, with the neighbouring elementwise work of the decoder block folded in (a decode step is
-    launch-latency bound):
-        launch 1   xt_i = V_i ( LayerNorm(x) (/) s_i )                     ln: an nn.LayerNorm or None
+    """Forward of 1..4 packed layers that share the input x [rows, d] (q / k / v of a block, gate / up of a Llama MLP, or a
+    single layer) in THREE launches total, with the neighbouring elementwise work of the decoder block folded in (a decode
+    step is launch-latency bound):
+        launch 1   xt_i = V_i ( Norm(x) (/) s_i )                          ln: nn.LayerNorm / an RMSNorm module / None
         launch 2   y_i  = What_i xt_i                                      grouped fused dequant-GEMM
         launch 3   out_i = [relu]( U_i^T y_i + bias_i + residual )
-    Returns the list of outputs in x's dtype.  Falls back to the plain forward when a layer has no small-batch
-    operators (then ln / residual / relu are applied with torch ops)."""
+    Returns the list of outputs in x's dtype.  Each side is decided on its own: an operator that does not fit the small-batch
+    kernels (Llama's 11008 = 688 x 16) takes the general K3 launches for THAT side only, with the norm / residual / relu
+    it would have absorbed done by torch ops; layers without operators at all take the plain forward."""
     rows = x.shape[0]
     assert x.dim() == 2
-    if not all(_fusable(q, rows) for q in qls) or len({(q.infeatures, q.outfeatures, q.bits) for q in qls}) != 1:
-        h = x if ln is None else ln(x)
+    same = len({(q.infeatures, q.outfeatures, q.bits) for q in qls}) == 1
+    if not same or any(q.U is None or q.V is None or q.qfn != 'b' for q in qls) or rows > ops.OrthoOp.SMALL_ROWS:
+        h = _norm(ln, x)
         outs = [q(h) for q in qls]
         if residual is not None:
             outs = [o + residual for o in outs]
         return [torch.relu(o) for o in outs] if relu else outs
     dev, m, d = x.device, qls[0].outfeatures, qls[0].infeatures
     x = x.contiguous()
-    xts = [torch.empty((rows, d), dtype=torch.bfloat16, device=dev) for _ in qls]
-    lnp = _ln_params(ln)
-    ops.ortho_apply_ops([(q.V, q.V.small_op(x, xt, colscale=q.inv_scaleWH, ln=lnp), False) for q, xt in zip(qls, xts)], rows)
+    # launch 1
+    fast = lambda o, norm: o.small_ok or (o.bigp_ok and norm is None and rows <= ops.TILE_ROWS)
+    if all(fast(q.V, ln) for q in qls):
+        xts = [torch.empty((rows, d), dtype=torch.bfloat16, device=dev) for _ in qls]
+        lnp = _ln_params(ln)
+        ops.ortho_apply_ops([(q.V, q.V.small_op(x, xt, colscale=q.inv_scaleWH, ln=lnp), False) for q, xt in zip(qls, xts)], rows)
+    else:
+        h = _norm(ln, x)
+        xts = [q.V.apply_rows(h, colscale=q.inv_scaleWH, out_dtype=torch.bfloat16) for q in qls]
+    # launch 2
     ys = [torch.empty((rows, m), dtype=torch.float32, device=dev) for _ in qls]
     ops.dequant_gemm_grouped(xts, [q.qweight for q in qls], qls[0].bits, 'b', [q.scales for q in qls], None, ys, m)
-    outs = [torch.empty((rows, m), dtype=x.dtype, device=dev) for _ in qls]
+    # launch 3
     res = None if residual is None else residual.contiguous()
-    ops.ortho_apply_ops([(q.U, q.U.small_op(y, o, transpose=True, bias=q.bias, residual=res, relu=relu), True)
-                         for q, y, o in zip(qls, ys, outs)], rows)
-    return outs
+    if all(fast(q.U, None) for q in qls):
+        outs = [torch.empty((rows, m), dtype=x.dtype, device=dev) for _ in qls]
+        ops.ortho_apply_ops([(q.U, q.U.small_op(y, o, transpose=True, bias=q.bias if q.bias is not None else q.U.zero_bias(), residual=res, relu=relu), True)
+                             for q, y, o in zip(qls, ys, outs)], rows)
+        return outs
+    outs = [q.U.apply_rows(y, transpose=True, out_dtype=x.dtype, bias=q.bias) for q, y in zip(qls, ys)]
+    if res is not None:
+        outs = [o + res for o in outs]
+    return [torch.relu(o) for o in outs] if relu else outs
 
 
 def _chainable(qa, qbs, rows):
@@ -399,7 +435,7 @@ def packed_u_stage(qls, ys, dtype, residual=None, relu=False):
     rows, m = ys[0].shape
     outs = [torch.empty((rows, m), dtype=dtype, device=ys[0].device) for _ in qls]
     res = None if residual is None else residual.contiguous()
-    ops.ortho_apply_ops([(q.U, q.U.small_op(y, o, transpose=True, bias=q.bias, residual=res, relu=relu), True) for q, y, o in zip(qls, ys, outs)], rows)
+    ops.ortho_apply_ops([(q.U, q.U.small_op(y, o, transpose=True, bias=q.bias if q.bias is not None else q.U.zero_bias(), residual=res, relu=relu), True) for q, y, o in zip(qls, ys, outs)], rows)
     return outs
 
 

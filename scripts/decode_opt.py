@@ -185,7 +185,7 @@ def time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager):
     caches = [(torch.zeros(bs, heads, maxlen, hd, dtype=dtype, device=dev), torch.zeros(bs, heads, maxlen, hd, dtype=dtype, device=dev))
               for _ in range(model.layers_n)]
     arange = torch.arange(maxlen, device=dev)
-    ids = torch.randint(0, 50000, (bs,), device=dev)
+    ids = torch.randint(0, min(50000, model.tok.weight.shape[0]), (bs,), device=dev)
     pos = torch.zeros(1, dtype=torch.int64, device=dev)
     logits_out = torch.zeros(bs, model.tok.weight.shape[0], dtype=dtype, device=dev)
 

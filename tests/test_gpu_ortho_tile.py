@@ -116,3 +116,34 @@ def test_tiles_refuse_other_shapes():
     x = torch.randn(1, 1024, device=DEV)
     y = op.apply_rows(x)                                    # falls back to the one-workgroup kernel
     assert torch.isfinite(y).all()
+
+
+# ---- p x 16 operators with a large p (csrc/ortho_bigp.hip; Llama's 11008 = 688 x 16) ------------------------------------------------
+@pytest.mark.parametrize("n", [11008, 2048 * 3])                 # 688 x 16;  6144 = 2^11 * 3 -> 192 x 32?  (see the skip)
+@pytest.mark.parametrize("transpose", [False, True])
+@pytest.mark.parametrize("rows", [1, 4])
+def test_bigp_equals_the_general_two_launch_kernel(n, transpose, rows):
+    from quip_amd import ops
+    op = _op(n, seed=n % 97 + rows)
+    if not op.bigp_ok:
+        pytest.skip(f"{n} factors as {op.p} x {op.q}")
+    assert not op.small_ok
+    g = torch.Generator().manual_seed(n + rows)
+    x = torch.randn(rows, n, generator=g).to(DEV)
+    cs = (0.5 + torch.rand(n, generator=g)).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    res = torch.randn(rows, n, generator=g).to(DEV).half()
+    # reference: the general kernel (rows > TILE_ROWS is never sent to the p x 16 kernel: pad the batch)
+    pad = lambda t: torch.cat([t, torch.zeros(ops.TILE_ROWS + 1 - rows, n, dtype=t.dtype, device=DEV)], 0)
+    ref_v = op.apply_rows(pad(x.half()), transpose=transpose, colscale=cs, out_dtype=torch.float32)[:rows]
+    ref_u = op.apply_rows(pad(x), transpose=transpose, out_dtype=torch.float32, bias=bias)[:rows]
+    got_v = op.apply_rows(x.half(), transpose=transpose, colscale=cs, out_dtype=torch.float32)
+    got_u = op.apply_rows(x, transpose=transpose, out_dtype=torch.float32, bias=bias)
+    assert float((got_v - ref_v).abs().max()) <= 2e-5 * float(ref_v.abs().max())
+    assert float((got_u - ref_u).abs().max()) <= 2e-5 * float(ref_u.abs().max())
+    # the fused epilogue: bias + residual + relu, f16 out
+    out = torch.empty(rows, n, dtype=torch.float16, device=DEV)
+    d = op.small_op(x, out, transpose=transpose, bias=bias, residual=res, relu=True)
+    ops.ortho_apply_ops([(op, d, transpose)], rows)
+    want = torch.relu(ref_u + res.float())
+    assert float((out.float() - want).abs().max()) <= 2e-3 * float(want.abs().max())
