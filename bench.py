@@ -27,6 +27,7 @@ import argparse
 import ctypes
 import json
 import os
+import sys
 import time
 
 import numpy as np
