@@ -222,6 +222,26 @@ def test_ldlq_full_size_properties_4096(ops):
     assert proxy(codes.float() - W) < 0.2 * proxy(near - W)
 
 
+def test_ldlq_opt30b_fc1_shape_sampled_rows_bit_exact(ops, O):
+    """BASELINE configs[4] (OPT-30B fc1: 28672 x 7168, w2): the whole Linear in one K4 launch; 48 sampled rows -- first, last,
+    a ragged middle -- against the kernel-order oracle (C, fp32, same summation order), bit for bit.  Rows are independent, so
+    the sample pins every workgroup's arithmetic; the rest of the matrix is pinned by the grid invariant."""
+    m, d, bits, maxq = 28672, 7168, 2, 3
+    g = torch.Generator().manual_seed(30)
+    X = (torch.randn(d + 512, d, generator=g) * (torch.arange(1, d + 1) ** -0.5)).to(DEV)
+    H = X.T @ X / (d + 512)
+    del X
+    H += 0.01 * H.diag().mean() * torch.eye(d, device=DEV)
+    LT = ops.cholesky_lt(H)
+    del H
+    W = (torch.rand(m, d, generator=g) * (maxq + 0.6) - 0.3).clamp(0, maxq).to(DEV)
+    codes = ops.ldlq_round(W, LT, bits)
+    assert int(codes.max()) <= maxq
+    rows = torch.cat([torch.arange(0, 16), torch.arange(14331, 14347), torch.arange(m - 16, m)])
+    want = O.round_ldl_kernel_order(W[rows.to(DEV)].cpu().numpy(), LT.cpu().numpy(), bits)
+    np.testing.assert_array_equal(codes[rows.to(DEV)].cpu().numpy(), want)
+
+
 # --------------------------------------------------------------------------------------------- K8
 def _spd(d, seed, damp=0.01):
     g = torch.Generator().manual_seed(seed)
