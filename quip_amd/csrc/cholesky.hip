@@ -265,11 +265,12 @@ template <int WT> int launch_syrk(float *A, int64_t d, int64_t prow0, int nk, in
     const size_t lds = (size_t)2 * NB * LDW * sizeof(float);
     const int64_t rem = d - base, T = (rem + BN - 1) / BN;
     auto kern = chol_syrk_kernel<WT>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static QaPerDevice attr_done_dev;
+    const int attr_done_d = attr_done_dev.dev();
+    if ((attr_done_d < 0 || !attr_done_dev.done[attr_done_d])) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: cannot reserve %zu B of LDS", lds);
-        attr_done = true;
+        if (attr_done_d >= 0) attr_done_dev.done[attr_done_d] = true;
     }
     kern<<<(unsigned)(strip ? T : T * (T + 1) / 2), 256, lds, s>>>(A, d, prow0, nk, base, strip ? 1 : 0);
     return QUIPAMD_OK;

@@ -77,4 +77,16 @@ template <> struct DT<BF16> {
     default: return qa_fail(QUIPAMD_ERR_ARG, "bad dtype %d", (int)(dt));         \
     }
 
+// hipFuncSetAttribute is per DEVICE: one process driving several GPUs must raise the dynamic-LDS limit on each of them
+// (a per-process `static bool` made the second device's first launch fail).  One instance per kernel instantiation.
+struct QaPerDevice {
+    bool done[64] = {};
+    int dev() const
+    {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return (d >= 0 && d < 64) ? d : -1;
+    }
+};
+
 static inline int qa_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

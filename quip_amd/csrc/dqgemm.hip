@@ -442,11 +442,12 @@ int launch_tile(const TileGroup &G, int ngroups, const EpiArgs &e, int64_t d, in
     constexpr size_t lds = (size_t)CW * DEPTH * XB + (size_t)(CW * RT * 256 + CW * 64) * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = dqgemm_tile_kernel<BITS, RT, CW, DEPTH>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
+    static QaPerDevice attr_set_dev;
+    const int attr_set_d = attr_set_dev.dev();
+    if ((attr_set_d < 0 || !attr_set_dev.done[attr_set_d]) && lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "dequant_gemm: cannot raise dynamic LDS to %zu", lds);
-        attr_set = true;
+        if (attr_set_d >= 0) attr_set_dev.done[attr_set_d] = true;
     }
     const uint32_t nkc = (uint32_t)(d / Q::KC);
     const uint32_t cps = (nkc + S - 1) / S;
@@ -466,11 +467,12 @@ int launch_cfg(const uint16_t *x, const uint4 *qw, const EpiArgs &e, int64_t d, 
     constexpr size_t lds = (size_t)NW * REGION;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = dqgemm_kernel<BITS, RT, BT, NW>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
+    static QaPerDevice attr_set_dev;
+    const int attr_set_d = attr_set_dev.dev();
+    if ((attr_set_d < 0 || !attr_set_dev.done[attr_set_d]) && lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "dequant_gemm: cannot raise dynamic LDS to %zu", lds);
-        attr_set = true;
+        if (attr_set_d >= 0) attr_set_dev.done[attr_set_d] = true;
     }
     const int64_t nby = (e.bs + 16 * BT - 1) / (16 * BT);
     QA_REQUIRE(nby <= 65535, QUIPAMD_ERR_SHAPE, "dequant_gemm: bs too large for this kernel (%lld)", (long long)e.bs);

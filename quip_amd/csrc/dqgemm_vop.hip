@@ -122,11 +122,12 @@ int launch_vop(const VopBatch &B, int ngroups, int64_t m, int bs, int maxq, hipS
     constexpr int CP = 64, CQ = 32, CW = 8, RT = 2, XB = 16 * 256 * 2;
     const size_t lds = (size_t)CW * XB + (size_t)(CW * RT * 256 + CW * 64) * 4 + small_split_lds(CP, CQ);
     auto kern = dqgemm_vop_kernel<TI, CP, CQ>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static QaPerDevice attr_set_dev;
+    const int attr_set_d = attr_set_dev.dev();
+    if ((attr_set_d < 0 || !attr_set_dev.done[attr_set_d])) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "dequant_gemm_vop: cannot raise dynamic LDS to %zu", lds);
-        attr_set = true;
+        if (attr_set_d >= 0) attr_set_dev.done[attr_set_d] = true;
     }
     kern<<<dim3((unsigned)(m / 16 / RT), (unsigned)ngroups), 1024, lds, s>>>(B, m, bs, maxq, 2.0f / (float)maxq);
     QA_LAUNCH_CHECK("quipamd_dequant_gemm_vop");

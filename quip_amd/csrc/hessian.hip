@@ -245,11 +245,12 @@ int launch_syrk(const void *x, int64_t ldx, int64_t tokens, int64_t d, double *H
     int64_t nbig = N;
     if (WT > 1 && N > SLOTS && N % SLOTS) nbig = N / SLOTS * SLOTS;
     auto kern = hsyrk_kernel<TI, WT, VEC>;
-    static bool attr_done = false;                         // per instantiation
-    if (!attr_done) {
+    static QaPerDevice attr_done_dev;                         // per instantiation
+    const int attr_done_d = attr_done_dev.dev();
+    if ((attr_done_d < 0 || !attr_done_dev.done[attr_done_d])) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "hessian_accum: cannot reserve %zu B of LDS", lds);
-        attr_done = true;
+        if (attr_done_d >= 0) attr_done_dev.done[attr_done_d] = true;
     }
     kern<<<(unsigned)(nbig + 4 * (N - nbig)), 256, lds, s>>>((const typename DT<TI>::storage *)x, ldx, tokens, d, H, (int)nbig);
     QA_LAUNCH_CHECK("hessian_accum");

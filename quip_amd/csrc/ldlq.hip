@@ -390,11 +390,12 @@ static int launch_ldlq(const float *Wgrid, const float *LT, const float *eta, in
     A.gscale = A.gzero = nullptr; A.groupsize = 0; A.sym = 0; A.qfn_c = 0;
     if (quant) { A.gscale = quant->scale; A.gzero = quant->zero; A.groupsize = quant->groupsize; A.sym = quant->sym; A.qfn_c = quant->qfn_c; }
     const size_t lds = (size_t)(BS * LDS_LD + 2 * 16 * BS) * sizeof(float) + 4 * 3 * SLAB;
-    static bool attr_set = false;                                  // per instantiation
-    if (!attr_set) {
+    static QaPerDevice attr_set_dev;                                  // per instantiation
+    const int attr_set_d = attr_set_dev.dev();
+    if ((attr_set_d < 0 || !attr_set_dev.done[attr_set_d])) {
         if (hipFuncSetAttribute((const void *)ldlq_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "%s: cannot raise dynamic LDS to %zu", who, lds);
-        attr_set = true;
+        if (attr_set_d >= 0) attr_set_dev.done[attr_set_d] = true;
     }
     ldlq_kernel<MODE><<<(unsigned)((m + 15) / 16), 512, lds, (hipStream_t)stream>>>(A);
     QA_LAUNCH_CHECK(who);
