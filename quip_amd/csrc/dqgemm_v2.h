@@ -565,46 +565,48 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
     const typename Q::Consts qc = Q::make_consts();
     const u32x4 ones = {opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES)};
     const u32x4 offs[2] = {Q::off_frag(0, qc), Q::off_frag(1, qc)};
+    // The stage loop exists WR times, once per value of wr: which batch tile's sums a wave keeps is then a compile-time
+    // constant inside the loop.  Tested per MFMA step instead (`if (wr == kk)` in the body) it was four scalar test-and-branch
+    // blocks per step, 116 SALU instructions and 32 taken / not-taken branches per 256-k stage.
+    static_for<WR>([&](auto KK) {
+        constexpr int kk = decltype(KK)::value;
+        if (wr != kk) return;
 #pragma unroll 1
-    for (uint32_t s = 0; s < ns; ++s) {
-        __builtin_amdgcn_s_barrier();
-        const char *sl = smem + (s & 1) * SB;
-        u32x4 wc[RTw][TPG];
+        for (uint32_t s = 0; s < ns; ++s) {
+            __builtin_amdgcn_s_barrier();
+            const char *sl = smem + (s & 1) * SB;
+            u32x4 wc[RTw][TPG];
 #pragma unroll
-        for (int r = 0; r < RTw; ++r)
+            for (int r = 0; r < RTw; ++r)
 #pragma unroll
-            for (int t = 0; t < TPG; ++t) wc[r][t] = *reinterpret_cast<const u32x4 *>(sl + wof + (r * TPG + t) * 1024);
+                for (int t = 0; t < TPG; ++t) wc[r][t] = *reinterpret_cast<const u32x4 *>(sl + wof + (r * TPG + t) * 1024);
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            u32x4 xf[BTw][2];
+            for (int cb = 0; cb < 4; ++cb) {
+                u32x4 xf[BTw][2];
 #pragma unroll
-            for (int bt = 0; bt < BTw; ++bt) {
-                xf[bt][0] = *reinterpret_cast<const u32x4 *>(sl + cb * (NB * 128) + bt * 2048 + rd0);
-                xf[bt][1] = *reinterpret_cast<const u32x4 *>(sl + cb * (NB * 128) + bt * 2048 + rd1);
-            }
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh) {
-                const int gstep = 2 * cb + sh, tile = gstep / NTT, tstep = gstep % NTT;   // MFMA step inside the stage
-#pragma unroll
-                for (int r = 0; r < RTw; ++r) {
-                    const u32x4 a = Q::frag(wc[r][tile], tstep, qc);
-#pragma unroll
-                    for (int bt = 0; bt < BTw; ++bt) acc[r][bt] = ACT::mfma(a, xf[bt][sh], acc[r][bt]);
+                for (int bt = 0; bt < BTw; ++bt) {
+                    xf[bt][0] = *reinterpret_cast<const u32x4 *>(sl + cb * (NB * 128) + bt * 2048 + rd0);
+                    xf[bt][1] = *reinterpret_cast<const u32x4 *>(sl + cb * (NB * 128) + bt * 2048 + rd1);
                 }
-                static_for<WR>([&](auto KK) {                           // wave-uniform: only the k = wr block runs
-                    constexpr int kk = decltype(KK)::value;
-                    if (wr == kk) {
 #pragma unroll
-                        for (int q = 0; q < NSB; ++q)
-                            if (kk + q * WR < BTw) {
-                                sum1[q] = ACT::mfma(ones, xf[kk + q * WR][sh], sum1[q]);
-                                if constexpr (!Q::UNIFORM) sumo[q] = ACT::mfma(offs[sh], xf[kk + q * WR][sh], sumo[q]);
-                            }
+                for (int sh = 0; sh < 2; ++sh) {
+                    const int gstep = 2 * cb + sh, tile = gstep / NTT, tstep = gstep % NTT;   // MFMA step inside the stage
+#pragma unroll
+                    for (int r = 0; r < RTw; ++r) {
+                        const u32x4 a = Q::frag(wc[r][tile], tstep, qc);
+#pragma unroll
+                        for (int bt = 0; bt < BTw; ++bt) acc[r][bt] = ACT::mfma(a, xf[bt][sh], acc[r][bt]);
                     }
-                });
+#pragma unroll
+                    for (int q = 0; q < NSB; ++q)
+                        if (kk + q * WR < BTw) {
+                            sum1[q] = ACT::mfma(ones, xf[kk + q * WR][sh], sum1[q]);
+                            if constexpr (!Q::UNIFORM) sumo[q] = ACT::mfma(offs[sh], xf[kk + q * WR][sh], sumo[q]);
+                        }
+                }
             }
         }
-    }
+    });
     __builtin_amdgcn_s_barrier();                                      // every fragment read retired: LDS is free
 
     // row sums of x: owner waves publish [wb][bt][16], everybody reads
