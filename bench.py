@@ -116,8 +116,8 @@ def main():
             with torch.cuda.stream(side):
                 st = vp(side.cuda_stream)
                 for i in range(warmup):
-                    launch(weights[i % nw], st)
-                barrier()
+                    launch(weights[(nw - 1 - i) % nw], st)          # warm-up copies come from the END of the ring: the timed
+                barrier()                                             # launches (copies 0 .. K-1) never see a pre-touched copy
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(side)
                 for i in range(steps):
@@ -130,7 +130,7 @@ def main():
             with torch.cuda.stream(side):
                 st = vp(side.cuda_stream)
                 for i in range(min(warmup, 32)):
-                    launch(weights[i % nw], st)
+                    launch(weights[(nw - 1 - i) % nw], st)
                 side.synchronize()
                 with torch.cuda.graph(graph, stream=side):
                     cst = vp(torch.cuda.current_stream().cuda_stream)
@@ -143,7 +143,7 @@ def main():
                     with torch.cuda.graph(wgraph, stream=side):
                         cst = vp(torch.cuda.current_stream().cuda_stream)
                         for i in range(warmup):
-                            launch(weights[i % nw], cst)
+                            launch(weights[(nw - 1 - i) % nw], cst)   # distinct from the timed copies while K + W <= ring
                 wgraph.replay()
             barrier()
             # The K launches are one hipGraph; its ~10 us host-side launch latency is not step time.  A ~100 us spin kernel
@@ -215,7 +215,7 @@ def main():
         "dtype": "bf16",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: single 4096x4096 Linear, w2 qfn-b, fused dequant-GEMM, bs=16, "
-                               "cold weights (96-copy ring, 384 MiB)", "m": M, "d": D, "bs": BS, "bits": BITS,
+                               f"cold weights (ring of {len(ring)} packed copies, {len(ring) * qs.numel() * 4 // 2**20} MiB; the timed launches stream copies 0..{min(len(ring), args.steps) - 1}, the warm-up ones come from the other end of the ring)", "m": M, "d": D, "bs": BS, "bits": BITS,
                    "launch": "eager" if args.eager else "hipGraph", "parallelism": f"dp{world} (replicas)"},
         "parity_rel_err": rel,
         "roofline": {"bound": "hbm", "achieved": round(gbs_cold, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -45,9 +45,6 @@ namespace {
 // (the s_memtime phase probe and its ablation switches live in scripts/probe_k2.hip, not in the product kernel)
 #define QA_ABL(bit) 0
 #define QA_KEEP(v) do { } while (0)
-#define QA_STAMP_DECL do { } while (0)
-#define QA_STAMP(ph) do { } while (0)
-#define QA_STAMP_FLUSH(NWAVES, WAVE) do { } while (0)
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -88,9 +85,6 @@ __global__ __launch_bounds__(64 * NW) void dqgemm_kernel(const uint16_t *__restr
     constexpr int PART = RT * BT * 5 * 64 * 4;   // parked partials per wave
     constexpr int REGION = (BT * XB > PART) ? BT * XB : PART;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    QA_STAMP_DECL;
-    QA_STAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -144,11 +138,9 @@ __global__ __launch_bounds__(64 * NW) void dqgemm_kernel(const uint16_t *__restr
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t *)(myreg + bt * XB + (2 * cb + rh) * 1024), 16,
                                                              (rh ? voff_hi : voff_lo) + bt * 16u * rowbytes,
                                                              soff + cb * 128, 0, 0);
-        QA_STAMP(1);
         // hipcc forces vmcnt(0) before any ds_read while an LDS-DMA is pending, so per-column-block counted
         // waits would be drained anyway: one wait (wave-private data: no barrier needed)
         wait_vmcnt(0);
-        QA_STAMP(2);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
@@ -190,9 +182,7 @@ __global__ __launch_bounds__(64 * NW) void dqgemm_kernel(const uint16_t *__restr
                 p[0] = acc[r][bt][0]; p[64] = acc[r][bt][1]; p[128] = acc[r][bt][2]; p[192] = acc[r][bt][3];
                 p[256] = xs[bt];
             }
-        QA_STAMP(3);
         __syncthreads();
-        QA_STAMP(4);
         // wave u reduces the (r, bt) pairs u, u + NW, ...
         for (int pr = wave; pr < RT * BT; pr += NW) {
             f32x4_t a = {0.f, 0.f, 0.f, 0.f};
@@ -208,10 +198,7 @@ __global__ __launch_bounds__(64 * NW) void dqgemm_kernel(const uint16_t *__restr
             if (pr != wave) epi = load_epi(e, r0);
             epilogue_store(e, epi, Q::OFF, a, s, (int64_t)(bt0 + bt) * 16 + j, r0);
         }
-        QA_STAMP(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        QA_STAMP(6);
-        QA_STAMP_FLUSH(NW, wave);
     } else {
 #pragma unroll
         for (int r = 0; r < RT; ++r)
