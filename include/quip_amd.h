@@ -225,7 +225,9 @@ int quipamd_ortho_apply_tiles_supported(int p, int q);
 /* The same for a Kronecker operator p x 16 with a large p (Llama's 11008 = 688 x 16: neither factor fits a workgroup's LDS, the
  * general quipamd_ortho_apply_rows pads one row to 16): one workgroup per 16 rows of the p x 16 image (p / 16 workgroups per
  * operator and row), fp32 MFMA, factors M0 [p, p] / M1 [16, 16] as for quipamd_ortho_apply_small.  Operand sets: (x f16, colscale)
- * or (x f32, bias, [f16 residual], relu); both permutations and their store_inv; no normalisation.  p % 16 == 0, 64 <= p <= 768. */
+ * or (x f32, bias, [f16 residual], relu); both permutations and their store_inv; no normalisation.  p % 16 == 0, 64 <= p <= 768.
+ * Activation side with `residual` (f16, row stride ldx) and relu = 1: the input row is silu(x) * residual -- the Llama MLP's
+ * act_fn(gate) * up computed on load (llama's down_proj input), rounded to f16 after the silu and after the product like torch. */
 int quipamd_ortho_apply_bigp(const quipamd_small_op *ops, const int32_t *const *store_inv, int nops, int64_t rows, void *stream);
 int quipamd_ortho_apply_bigp_supported(int p, int q);
 

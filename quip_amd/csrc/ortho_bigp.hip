@@ -9,6 +9,8 @@
 // on v_mfma_f32_16x16x4_f32 (exact fp32 chains; the factor rows come straight from L2 as A fragments, 16 x p floats per
 // workgroup).  Every workgroup loads, scales and scatters the whole row itself (n floats into a 16 x (p+4) LDS image).
 // Operand sets as in ortho_tile.hip: SIDE 0 = x f16 + column scale, SIDE 1 = x f32 + bias (+ f16 residual); both permutations.
+// SIDE 0 with RES = the Llama MLP hand-over: the input row is silu(gate) * up, gate = x, up = `residual` (f16 [rows, n], row
+// stride ldx), computed on load -- llama's  down_proj(act_fn(gate_proj(x)) * up_proj(x))  without the two elementwise launches.
 #include "common.h"
 
 #include "small_pass.h"
@@ -42,7 +44,9 @@ __global__ __launch_bounds__(BT) void ortho_bigp_kernel(BigpBatch Bt)
     // ---- request the whole row and its scatter operands ----------------------------------------------------------------------------
     const uint16_t *xrow16 = (const uint16_t *)A.x + row * A.ldx;
     const float *xrow32 = (const float *)A.x + row * A.ldx;
+    const uint16_t *urow16 = (const uint16_t *)A.residual + row * A.ldx;       // SIDE 0 + RES: the `up` row
     uint4 rx[BMAXV];
+    uint2 ru[BMAXV];
     float4 pcs[BMAXV];
     int4 pld[BMAXV];
 #pragma unroll
@@ -53,6 +57,7 @@ __global__ __launch_bounds__(BT) void ortho_bigp_kernel(BigpBatch Bt)
                 const uint2 t = *reinterpret_cast<const uint2 *>(xrow16 + 4 * v4);
                 rx[u] = make_uint4(t.x, t.y, 0u, 0u);
                 pcs[u] = *reinterpret_cast<const float4 *>(A.colscale + 4 * v4);
+                if constexpr (RES) ru[u] = *reinterpret_cast<const uint2 *>(urow16 + 4 * v4);
             } else {
                 rx[u] = *reinterpret_cast<const uint4 *>(xrow32 + 4 * v4);
             }
@@ -74,6 +79,15 @@ __global__ __launch_bounds__(BT) void ortho_bigp_kernel(BigpBatch Bt)
         const int v4 = tid + BT * u;
         if (v4 < n4) {
             float4 v = raw4_cvt(rx[u], SIDE == 0 ? QUIPAMD_F16 : QUIPAMD_F32);
+            if constexpr (SIDE == 0 && RES) {
+                // silu(g) * up, rounded to f16 like the two torch launches it replaces (F.silu(g) rounds, then the product rounds)
+                const float4 up = raw4_cvt(make_uint4(ru[u].x, ru[u].y, 0u, 0u), QUIPAMD_F16);
+                auto gate = [](float g, float w) {
+                    const float sl = f16_bits_to_f32(f32_to_f16_bits(g / (1.f + __expf(-g))));
+                    return f16_bits_to_f32(f32_to_f16_bits(sl * w));
+                };
+                v = make_float4(gate(v.x, up.x), gate(v.y, up.y), gate(v.z, up.z), gate(v.w, up.w));
+            }
             if constexpr (SIDE == 0) v = make_float4(v.x * pcs[u].x, v.y * pcs[u].y, v.z * pcs[u].z, v.w * pcs[u].w);
             const float vv[4] = {v.x, v.y, v.z, v.w};
             const int pp[4] = {pld[u].x, pld[u].y, pld[u].z, pld[u].w};
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(BT) void ortho_bigp_kernel(BigpBatch Bt)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             if constexpr (SIDE == 1) obias[reg] = A.bias[(uint32_t)oidx[reg]];
-            if constexpr (RES) rres[reg] = ((const uint16_t *)A.residual + row * A.ldo)[(uint32_t)oidx[reg]];
+            if constexpr (SIDE == 1 && RES) rres[reg] = ((const uint16_t *)A.residual + row * A.ldo)[(uint32_t)oidx[reg]];
         }
     }
 
@@ -159,8 +173,8 @@ __global__ __launch_bounds__(BT) void ortho_bigp_kernel(BigpBatch Bt)
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-        float v = (ov[reg] + obias[reg]) + (RES ? f16_bits_to_f32((uint16_t)rres[reg]) : 0.f);
-        ov[reg] = A.relu ? fmaxf(v, 0.f) : v;
+        float v = (ov[reg] + obias[reg]) + ((SIDE == 1 && RES) ? f16_bits_to_f32((uint16_t)rres[reg]) : 0.f);
+        ov[reg] = (SIDE == 1 && A.relu) ? fmaxf(v, 0.f) : v;
     }
     if (A.out_dtype == QUIPAMD_F32) {
         float *o = (float *)A.out + row * A.ldo;
@@ -198,9 +212,10 @@ extern "C" int quipamd_ortho_apply_bigp(const quipamd_small_op *ops, const int32
         QA_REQUIRE(o.ldx >= (int64_t)p * q && o.ldo >= (int64_t)p * q && o.ldx % 4 == 0 && !o.ln_gamma, QUIPAMD_ERR_SHAPE,
                    "ortho_apply_bigp: leading dimensions / no normalisation on this path");
         int sd = -1;
-        if (o.x_dtype == QUIPAMD_F16 && o.colscale && !o.bias && !o.residual && !o.relu) sd = 0;
+        // activation side; `residual` (f16, same row stride as x) + relu = 1 there means "x is the gate, residual is up: feed silu(x) * up"
+        if (o.x_dtype == QUIPAMD_F16 && o.colscale && !o.bias && ((!o.residual && !o.relu) || (o.residual && o.relu && o.res_dtype == QUIPAMD_F16))) sd = 0;
         else if (o.x_dtype == QUIPAMD_F32 && !o.colscale && o.bias && (!o.residual || o.res_dtype == QUIPAMD_F16)) sd = 1;
-        QA_REQUIRE(sd >= 0, QUIPAMD_ERR_UNSUPPORTED, "ortho_apply_bigp: op %d is neither (x f16, colscale) nor (x f32, bias, [f16 residual])", i);
+        QA_REQUIRE(sd >= 0, QUIPAMD_ERR_UNSUPPORTED, "ortho_apply_bigp: op %d is neither (x f16, colscale, [silu-gate pair]) nor (x f32, bias, [f16 residual])", i);
         const bool r = o.residual != nullptr;
         QA_REQUIRE(side < 0 || (sd == side && r == res), QUIPAMD_ERR_ARG, "ortho_apply_bigp: ops of one launch must have the same operand set");
         side = sd;
@@ -221,7 +236,8 @@ extern "C" int quipamd_ortho_apply_bigp(const quipamd_small_op *ops, const int32
             return qa_fail(QUIPAMD_ERR_LAUNCH, "ortho_apply_bigp: cannot raise dynamic LDS to %zu", lds);                            \
         kern<<<grid, BT, lds, s>>>(B);                                                                                               \
     } while (0)
-    if (side == 0) QA_BIGP(0, false);
+    if (side == 0 && res) QA_BIGP(0, true);
+    else if (side == 0) QA_BIGP(0, false);
     else if (res) QA_BIGP(1, true);
     else QA_BIGP(1, false);
 #undef QA_BIGP

@@ -266,6 +266,9 @@ def _tile_form(d):
     if d.x_dtype == _DT[torch.float16] and d.colscale and not d.bias and not d.residual and not d.relu \
             and (not d.ln_gamma or d.ln_dtype == _DT[torch.float16]):
         return ('V', bool(d.ln_gamma))
+    if d.x_dtype == _DT[torch.float16] and d.colscale and not d.bias and d.residual and d.relu and not d.ln_gamma \
+            and d.res_dtype == _DT[torch.float16]:
+        return ('G', False)                  # silu(x) * residual on load: the p x 16 kernel only (Llama's down_proj input)
     if d.x_dtype == _DT[torch.float32] and not d.colscale and d.bias and not d.ln_gamma \
             and (not d.residual or d.res_dtype == _DT[torch.float16]):
         return ('U', bool(d.residual))
@@ -289,9 +292,11 @@ def ortho_apply_ops(entries, rows):
             "p x 16 operators: a handful of rows, activation-side or output-side operand set, no normalisation"
         ortho_bigp_ops([d for _, d, _ in entries], [o.store_inv(t) for o, _, t in entries], rows)
         return
-    if USE_TILES and rows <= TILE_ROWS and all(o.tile_ok and o.use_split for o, _, _ in entries) and len(forms) == 1 and None not in forms:
+    if USE_TILES and rows <= TILE_ROWS and all(o.tile_ok and o.use_split for o, _, _ in entries) and len(forms) == 1 \
+            and all(f is not None and f[0] in 'VU' for f in forms):
         ortho_tile_ops([d for _, d, _ in entries], [o.store_inv(t) for o, _, t in entries], rows)
     else:
+        assert all(f is None or f[0] != 'G' for f in forms), "the silu-gate input form exists on the p x 16 kernel only"
         ortho_small_ops([d for _, d, _ in entries], rows)
 
 

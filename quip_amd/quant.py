@@ -341,7 +341,7 @@ def _norm(ln, x):
     return torch.nn.functional.layer_norm(xf, (x.shape[-1],), g.float(), b.float(), eps).to(x.dtype)
 
 
-def packed_forward_fused(qls, x, ln=None, residual=None, relu=False):
+def packed_forward_fused(qls, x, ln=None, residual=None, relu=False, gate_up=None):
     """Forward of 1..4 packed layers that share the input x [rows, d] (q / k / v of a block, gate / up of a Llama MLP, or a
     single layer) in THREE launches total, with the neighbouring elementwise work of the decoder block folded in (a decode
     step is launch-latency bound):
@@ -350,9 +350,16 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False):
         launch 3   out_i = [relu]( U_i^T y_i + bias_i + residual )
     Returns the list of outputs in x's dtype.  Each side is decided on its own: an operator that does not fit the small-batch
     kernels (Llama's 11008 = 688 x 16) takes the general K3 launches for THAT side only, with the norm / residual / relu
-    it would have absorbed done by torch ops; layers without operators at all take the plain forward."""
+    it would have absorbed done by torch ops; layers without operators at all take the plain forward.
+    gate_up: x is the GATE of a Llama MLP and gate_up the `up` projection [rows, d]; the layer's input is silu(x) * gate_up
+    (llama's down_proj(act_fn(gate) * up)), formed on load inside launch 1 when the V-side operator is p x 16, else by torch."""
     rows = x.shape[0]
     assert x.dim() == 2
+    if gate_up is not None:
+        one = len(qls) == 1 and qls[0].V is not None and qls[0].U is not None and qls[0].qfn == 'b'
+        if not (one and ln is None and qls[0].V.bigp_ok and not qls[0].V.small_ok and rows <= ops.TILE_ROWS and x.dtype == torch.float16
+                and x.stride(0) == gate_up.stride(0) and gate_up.dtype == torch.float16):
+            x, gate_up = torch.nn.functional.silu(x) * gate_up, None
     same = len({(q.infeatures, q.outfeatures, q.bits) for q in qls}) == 1
     if not same or any(q.U is None or q.V is None or q.qfn != 'b' for q in qls) or rows > ops.OrthoOp.SMALL_ROWS:
         h = _norm(ln, x)
@@ -367,7 +374,12 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False):
     if all(fast(q.V, ln) for q in qls):
         xts = [torch.empty((rows, d), dtype=torch.bfloat16, device=dev) for _ in qls]
         lnp = _ln_params(ln)
-        ops.ortho_apply_ops([(q.V, q.V.small_op(x, xt, colscale=q.inv_scaleWH, ln=lnp), False) for q, xt in zip(qls, xts)], rows)
+        if gate_up is not None:                                 # silu(x) * up on load (csrc/ortho_bigp.hip)
+            gate_up = gate_up.contiguous()
+            ops.ortho_apply_ops([(q.V, q.V.small_op(x, xt, colscale=q.inv_scaleWH, residual=gate_up, relu=True), False)
+                                 for q, xt in zip(qls, xts)], rows)
+        else:
+            ops.ortho_apply_ops([(q.V, q.V.small_op(x, xt, colscale=q.inv_scaleWH, ln=lnp), False) for q, xt in zip(qls, xts)], rows)
     else:
         h = _norm(ln, x)
         xts = [q.V.apply_rows(h, colscale=q.inv_scaleWH, out_dtype=torch.bfloat16) for q in qls]

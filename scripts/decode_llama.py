@@ -66,7 +66,7 @@ class Block(nn.Module):
         if self.fused:
             x = packed_forward_fused([self.o_proj], o, residual=x)[0]
             g, u = packed_forward_fused([self.gate_proj, self.up_proj], x, ln=self.n2)
-            return packed_forward_fused([self.down_proj], F.silu(g) * u, residual=x)[0]
+            return packed_forward_fused([self.down_proj], g, residual=x, gate_up=u)[0]       # silu(g) * u formed inside the V launch
         x = x + self.o_proj(o)
         hn = self.n2(x)
         return x + self.down_proj(F.silu(self.gate_proj(hn)) * self.up_proj(hn))

@@ -147,3 +147,20 @@ def test_bigp_equals_the_general_two_launch_kernel(n, transpose, rows):
     ops.ortho_apply_ops([(op, d, transpose)], rows)
     want = torch.relu(ref_u + res.float())
     assert float((out.float() - want).abs().max()) <= 2e-3 * float(want.abs().max())
+
+
+def test_bigp_silu_gate_input_form():
+    """activation side of Llama's down_proj: the kernel forms silu(gate) * up on load (both f16, rounded like the two torch launches)"""
+    from quip_amd import ops
+    n, rows = 11008, 2
+    op = _op(n, seed=5)
+    assert op.bigp_ok and not op.small_ok
+    g = torch.Generator().manual_seed(3)
+    gate = (2 * torch.randn(rows, n, generator=g)).to(DEV).half()
+    up = torch.randn(rows, n, generator=g).to(DEV).half()
+    cs = (0.5 + torch.rand(n, generator=g)).to(DEV)
+    out = torch.empty(rows, n, dtype=torch.float32, device=DEV)
+    ops.ortho_apply_ops([(op, op.small_op(gate, out, colscale=cs, residual=up, relu=True), False)], rows)
+    h = torch.nn.functional.silu(gate) * up                                      # f16, as the Llama block computes it
+    want = op.apply_rows(h, colscale=cs, out_dtype=torch.float32)
+    assert float((out - want).abs().max()) <= 1e-3 * float(want.abs().max())    # an f16 ulp of h here and there (__expf vs expf)
