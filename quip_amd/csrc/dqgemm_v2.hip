@@ -51,10 +51,15 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
     }
     if (fam == K2_FAM_S) {
         QA_REQUIRE(bs <= 16 && d % 256 == 0, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: kernel family s needs bs <= 16 and d %% 256 == 0");
-        if (p1 == 0) { p1 = 7; p2 = 2; }
+        if (p1 == 0) {
+            // one workgroup per CU and whole rounds: 7 row tiles per workgroup fit 1792 tiles (28672 rows) exactly, 8 fit 2048
+            // (32768 rows: 18.0 us with 8 x 256 workgroups, 27 us with 293 workgroups of 7 -- profiles/r02l_k2lab_s.log)
+            const int64_t r7 = ((ntile + 6) / 7 + 255) / 256, r8 = ((ntile + 7) / 8 + 255) / 256;
+            if (r8 * 8 < r7 * 7) { p1 = 8; p2 = 1; } else { p1 = 7; p2 = 2; }
+        }
         if (p1 == 7 && p2 == 2) return launch_s<BITS, ACT, 7, 2, 1, 3>(A, s);
         if (p1 == 4 && p2 == 2) return launch_s<BITS, ACT, 4, 2, 1, 4>(A, s);
-        if (p1 == 8 && p2 == 1) return launch_s<BITS, ACT, 8, 1, 1, 4>(A, s);
+        if (p1 == 8 && p2 == 1) return launch_s<BITS, ACT, 8, 1, 2, 3>(A, s);
         return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: no s kernel for nw=%d ksp=%d", p1, p2);
     }
     if (fam == K2_FAM_MB) {
