@@ -112,6 +112,16 @@ def main():
         """returns seconds for exactly `steps` launches (max over ranks).  `launch` is looked up at call time."""
         side = torch.cuda.Stream()
         nw = len(weights)
+        if nw > 1:
+            # One untimed walk over the whole ring, in order: every copy's pages are mapped and translated before the timed
+            # region (a K = 20 run would otherwise pay first-touch page-table walks on every launch, which a model whose layers
+            # are read once per token does not), while the DATA of the copies the timed launches stream (0 .. K-1, the oldest)
+            # has been pushed out of the 256 MiB Infinity Cache by the 384 MiB that followed it.
+            with torch.cuda.stream(side):
+                st = vp(side.cuda_stream)
+                for i in range(nw):
+                    launch(weights[i], st)
+                side.synchronize()
         if args.eager:
             with torch.cuda.stream(side):
                 st = vp(side.cuda_stream)
