@@ -149,7 +149,7 @@ def run(layers=32, bits=2, bs=1, prompt=64, tokens=64, with_dense=True):
     model = build(layers, dev, dtype)
     out = {"config": {"arch": "Llama-2-7B (hidden 4096, intermediate 11008, heads 32 x 128, vocab 32000)", "layers": layers, "bits": bits,
                       "bs": bs, "prompt": prompt, "tokens": tokens, "launch": "hipGraph",
-                      "weights": "random init, nearest-rounded qfn-b codes, Kronecker U/V (64x64, 688x16), random scaleWH"}}
+                      "weights": "random init, nearest-rounded qfn-b codes, Kronecker U/V (64x64, 688x16; one sampled operator per width, side and layer parity -- the 688x688 Haar factor is slow to sample -- so the 1.3 MB of factors per block are shared by every other block), random scaleWH"}}
     if with_dense:
         med, _, _ = D.time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, False)
         out["dense_fp16"] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
