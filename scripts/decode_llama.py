@@ -109,7 +109,6 @@ def pack_model(model, bits, dev, seed=0, twin=True):
     torch.manual_seed(seed)
     maxq = 2 ** bits - 1
     dense, nbytes = {}, 0
-    gens = {}                                               # the Haar sampling of a 688 x 688 factor is slow: one operator per width and role
     for li, blk in enumerate(model.blocks):
         for name in Decoder.NAMES:
             lin = getattr(blk, name)
@@ -117,11 +116,8 @@ def pack_model(model, bits, dev, seed=0, twin=True):
             W = lin.weight.data
             s = ops.qfnb_scale(W)
             What, codes = ops.quantize(W, 'b', s, None, maxq, want_codes=True)
-            for key, n in (("U", m), ("V", d)):
-                if (key, n, li % 2) not in gens:
-                    gens[(key, n, li % 2)] = method.gen_rand_ortho_butterfly_noblock(n)
-            U = ops.OrthoOp(gens[("U", m, li % 2)], dev)
-            V = ops.OrthoOp(gens[("V", d, li % 2)], dev)
+            U = ops.OrthoOp(method.gen_rand_ortho_butterfly_noblock(m), dev)      # every layer its own operators, like the reference
+            V = ops.OrthoOp(method.gen_rand_ortho_butterfly_noblock(d), dev)
             sWH = (0.5 + torch.rand(d)).to(dev)
             ql = QuantLinear(d, m, bits=bits, qfn='b').to(dev)
             ql.pack(codes, s, None, bias=None, scaleWH=sWH, U=U, V=V)
@@ -149,7 +145,7 @@ def run(layers=32, bits=2, bs=1, prompt=64, tokens=64, with_dense=True):
     model = build(layers, dev, dtype)
     out = {"config": {"arch": "Llama-2-7B (hidden 4096, intermediate 11008, heads 32 x 128, vocab 32000)", "layers": layers, "bits": bits,
                       "bs": bs, "prompt": prompt, "tokens": tokens, "launch": "hipGraph",
-                      "weights": "random init, nearest-rounded qfn-b codes, Kronecker U/V (64x64, 688x16; one sampled operator per width, side and layer parity -- the 688x688 Haar factor is slow to sample -- so the 1.3 MB of factors per block are shared by every other block), random scaleWH"}}
+                      "weights": "random init, nearest-rounded qfn-b codes, Kronecker U/V (64x64, 688x16), random scaleWH"}}
     if with_dense:
         med, _, _ = D.time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, False)
         out["dense_fp16"] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
