@@ -202,6 +202,7 @@ extern "C" int quipamd_ortho_apply_bigp(const quipamd_small_op *ops, const int32
     QA_REQUIRE(quipamd_ortho_apply_bigp_supported(p, q), QUIPAMD_ERR_UNSUPPORTED,
                "ortho_apply_bigp: p x q = %d x %d (wants q = 16, p a multiple of 16, p * 16 <= %d)", p, q, 4 * BT * BMAXV);
     QA_REQUIRE(rows >= 0 && rows <= 65535, QUIPAMD_ERR_SHAPE, "ortho_apply_bigp: bad row count");
+    if (rows == 0) return QUIPAMD_OK;
     BigpBatch B;
     int side = -1;
     bool res = false;

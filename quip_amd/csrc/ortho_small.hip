@@ -286,6 +286,7 @@ extern "C" int quipamd_ortho_apply_small_ops(const quipamd_small_op *ops, int no
     QA_REQUIRE((int64_t)p * q <= 16 * 1024, QUIPAMD_ERR_SHAPE, "ortho_apply_small: n = %d > 16384", p * q);
     QA_REQUIRE((q & (q - 1)) == 0, QUIPAMD_ERR_SHAPE, "ortho_apply_small: q = %d must be a power of two; use quipamd_ortho_apply_rows", q);
     QA_REQUIRE(rows >= 0 && rows < ((int64_t)1 << 31), QUIPAMD_ERR_SHAPE, "ortho_apply_small: bad row count");
+    if (rows == 0) return QUIPAMD_OK;                           // an empty batch has null data pointers
     const bool split = ops[0].M0_hi != nullptr;
     if (split) {
         QA_REQUIRE(p % 32 == 0 && q % 32 == 0, QUIPAMD_ERR_SHAPE, "ortho_apply_small: split-bf16 factors need p, q multiples of 32");

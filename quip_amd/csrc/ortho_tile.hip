@@ -312,6 +312,7 @@ extern "C" int quipamd_ortho_apply_tiles(const quipamd_small_op *ops, const int3
     QA_REQUIRE(quipamd_ortho_apply_tiles_supported(p, q), QUIPAMD_ERR_UNSUPPORTED,
                "ortho_apply_tiles: p x q = %d x %d is not one of 64x32, 64x64, 128x64; use quipamd_ortho_apply_small_ops", p, q);
     QA_REQUIRE(rows >= 0 && rows <= 65535, QUIPAMD_ERR_SHAPE, "ortho_apply_tiles: bad row count");
+    if (rows == 0) return QUIPAMD_OK;                           // an empty batch has null data pointers: nothing to check, nothing to do
     TileBatch B;
     int side = -2;
     bool flag = false;

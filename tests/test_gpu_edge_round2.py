@@ -1,0 +1,78 @@
+"""-m gpu: empty and ragged inputs through the entry points added in round 2 (the reference's tests exercise empty / ragged
+shapes of its own operators; a C ABI must not fault on them either)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_empty_inputs_are_no_ops():
+    from quip_amd import ops, method
+    # GPTQ with groups on an empty weight
+    W = torch.zeros(0, 128, device=DEV)
+    Hinv = torch.eye(128, device=DEV)
+    Q, sc, zr = ops.gptq_round_groups(W, Hinv, 4, 64)
+    assert Q.shape == (0, 128) and sc.shape == (0, 2)
+    # feedback matrix / triangular inverse of a 0 x 0 problem
+    assert ops.gptq_feedback(torch.zeros(0, 0, device=DEV)).shape == (0, 0)
+    assert ops.unit_upper_inverse(torch.zeros(0, 0, device=DEV)).shape == (0, 0)
+    # operators on zero rows: tiled, p x 16 and one-workgroup forms
+    np.random.seed(0)
+    torch.manual_seed(0)
+    for n in (2048, 11008):
+        op = ops.OrthoOp(method.gen_rand_ortho_butterfly_noblock(n), DEV)
+        y = op.apply_rows(torch.zeros(0, n, device=DEV).half(), colscale=torch.ones(n, device=DEV), out_dtype=torch.bfloat16)
+        assert y.shape == (0, n)
+    # rotary on an empty batch
+    cos = torch.ones(8, 64, device=DEV)
+    q = torch.zeros(0, 4 * 64, device=DEV).half()
+    ops.rope_inplace(q, q.clone(), cos, cos, torch.zeros(1, dtype=torch.int64, device=DEV), 4)
+    # repack / 3-bit pack of zero rows
+    assert ops.pack(torch.zeros(0, 128, dtype=torch.uint8, device=DEV), 3).numel() == 0
+    assert ops.repack_canonical_to_stream(torch.zeros(0, dtype=torch.int32, device=DEV).reshape(12, 0), 3, 0, 128).numel() == 0
+
+
+@pytest.mark.parametrize("m", [1, 15, 17, 40])
+def test_gptq_groups_ragged_row_counts(m):
+    """row counts that are not multiples of the 16-row workgroup: the last workgroup is partly empty"""
+    from quip_amd import ops
+    d, bits, gs = 256, 3, 32
+    g = torch.Generator().manual_seed(m)
+    X = torch.randn(2 * d, d, generator=g)
+    H = (X.T @ X / (2 * d) + 0.01 * torch.eye(d)).to(DEV)
+    W = (0.02 * torch.randn(48, d, generator=g)).to(DEV)
+    FT = ops.gptq_feedback(H)
+    Qfull, sfull, zfull = ops.gptq_round_groups(W, None, bits, gs, FT=FT)
+    Qm, sm, zm = ops.gptq_round_groups(W[:m].contiguous(), None, bits, gs, FT=FT)
+    assert torch.equal(Qm, Qfull[:m]) and torch.equal(sm, sfull[:m]) and torch.equal(zm, zfull[:m])       # rows are independent
+
+
+@pytest.mark.parametrize("d", [16, 48, 130 * 16])
+def test_gptq_feedback_ragged_widths(d):
+    from quip_amd import ops
+    g = torch.Generator().manual_seed(d)
+    X = torch.randn(2 * d, d, generator=g)
+    H = X.T @ X / (2 * d) + 0.05 * torch.eye(d)
+    FT = ops.gptq_feedback(H.to(DEV)).cpu().double()
+    Hinv = torch.linalg.cholesky(torch.linalg.inv(H.double()), upper=True)
+    ref = ops.gptq_feedback_matrix(Hinv)
+    assert float((FT - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_vecquant_single_row_and_wide():
+    """the reference's operator is a GEMV (one activation vector): m = 16 rows (one tile) and a wide d"""
+    from quip_amd import ops
+    from oracle import quip_oracle as O
+    for bits, m, d in ((4, 16, 4096), (3, 32, 1024)):
+        rng = np.random.default_rng(bits)
+        codes = rng.integers(0, 2 ** bits, size=(m, d), dtype=np.uint8)
+        scales = rng.uniform(0.01, 0.03, m).astype(np.float32)
+        zp = rng.integers(0, 2 ** bits, m).astype(np.float32)
+        vec = rng.standard_normal(d).astype(np.float32)
+        qw = ops.pack(torch.from_numpy(codes).to(DEV), bits)
+        mul = torch.zeros(m, device=DEV)
+        ops.vecquantmatmul(bits, torch.from_numpy(vec).to(DEV), qw, mul, torch.from_numpy(scales).to(DEV), torch.from_numpy(zp * scales).to(DEV))
+        want = (scales[:, None] * (codes.astype(np.float64) - zp[:, None])) @ vec.astype(np.float64)
+        assert np.abs(mul.cpu().numpy() - want).max() <= 2e-4 * np.abs(want).max() + 1e-5
