@@ -205,10 +205,12 @@ class QuantLinear(nn.Module):
         return ql
 
     def act_dtype(self, x):
-        """dtype of the activations fed to K2: the reference operator widens x to fp32 (quant.py:226-229), so an fp16
-        model must not lose mantissa bits to a bf16 cast -- fp16 x runs on the fp16 MFMA pipe (needs in_features % 256 == 0,
-        or in_features <= 4096); bf16 / fp32 x run in bf16 (fp32: range over mantissa)."""
-        if x.dtype == torch.float16 and (self.infeatures % 256 == 0 or self.infeatures <= 4096):
+        """dtype of the activations fed to K2: the reference operator widens x to fp32 (quant.py:226-229), so an fp16 model
+        must not lose mantissa bits to a bf16 cast -- fp16 x runs on the fp16 MFMA pipe where a kernel for it exists
+        (in_features % 256 == 0 for any batch; up to 16 rows also any in_features <= 4096); bf16 / fp32 x run in bf16
+        (fp32: range over mantissa)."""
+        rows = x.numel() // max(x.shape[-1], 1)
+        if x.dtype == torch.float16 and (self.infeatures % 256 == 0 or (rows <= 16 and self.infeatures <= 4096)):
             return torch.float16
         return torch.bfloat16
 

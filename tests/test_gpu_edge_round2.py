@@ -76,3 +76,24 @@ def test_vecquant_single_row_and_wide():
         ops.vecquantmatmul(bits, torch.from_numpy(vec).to(DEV), qw, mul, torch.from_numpy(scales).to(DEV), torch.from_numpy(zp * scales).to(DEV))
         want = (scales[:, None] * (codes.astype(np.float64) - zp[:, None])) @ vec.astype(np.float64)
         assert np.abs(mul.cpu().numpy() - want).max() <= 2e-4 * np.abs(want).max() + 1e-5
+
+
+@pytest.mark.parametrize("rows", [1, 8, 16, 17, 32, 200])
+def test_fp16_layer_with_a_width_the_fp16_kernels_do_not_tile(rows):
+    """4-bit layer, in_features = 384 (a valid STREAM width for 4 bits, not a multiple of 256): up to 16 rows run on the fp16
+    pipe, larger batches must fall back to bf16 activations instead of failing"""
+    from quip_amd import ops, quant as Q
+    d, m, bits = 384, 64, 4
+    g = torch.Generator().manual_seed(rows)
+    codes = torch.randint(0, 16, (m, d), generator=g, dtype=torch.uint8).to(DEV)
+    scale = (0.01 + 0.02 * torch.rand(m, generator=g)).to(DEV)
+    zero = torch.randint(0, 16, (m,), generator=g).float().to(DEV)
+    ql = Q.QuantLinear(d, m, bits=bits, qfn='a').to(DEV)
+    ql.pack(codes, scale, zero, bias=None)
+    x = torch.randn(rows, d, generator=g).to(DEV).half()
+    y = ql(x)
+    Wd = scale[:, None] * (codes.float() - zero[:, None])
+    ref = x.float() @ Wd.t()
+    assert y.dtype == torch.float16 and y.shape == (rows, m)
+    tol = 2e-3 if rows <= 16 else 1e-2                        # fp16 activations / bf16 activations
+    assert float((y.float() - ref).norm() / ref.norm()) <= tol
