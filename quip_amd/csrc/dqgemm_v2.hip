@@ -26,7 +26,7 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
         if (bs <= 16) {
             if (h_fits && ntile <= 768) fam = K2_FAM_H;
             else if (ntile >= 1024 && d % 256 == 0) fam = K2_FAM_S;
-            else if (f16) fam = (d % 256 == 0) ? K2_FAM_S : K2_FAM_NONE;
+            else if (f16) fam = h_fits ? K2_FAM_H : (d % 256 == 0) ? K2_FAM_S : K2_FAM_NONE;   // fp16 exists only here: any shape a kernel can hold
             else return K2V2_NOT_TAKEN;
         } else {
             const int64_t tiles = ((m + 255) / 256) * ((bs + 127) / 128);

@@ -97,3 +97,18 @@ def test_fp16_layer_with_a_width_the_fp16_kernels_do_not_tile(rows):
     assert y.dtype == torch.float16 and y.shape == (rows, m)
     tol = 2e-3 if rows <= 16 else 1e-2                        # fp16 activations / bf16 activations
     assert float((y.float() - ref).norm() / ref.norm()) <= tol
+
+
+def test_fp16_tall_narrow_layer_small_batch():
+    """fp16 activations, many row tiles (> 768) and a width that is not a multiple of 256: the one-pass kernel takes it"""
+    from quip_amd import ops
+    m, d, bits, bs = 16384, 384, 4, 8
+    g = torch.Generator().manual_seed(1)
+    codes = torch.randint(0, 16, (m, d), generator=g, dtype=torch.uint8).to(DEV)
+    scale = (0.01 + 0.02 * torch.rand(m, generator=g)).to(DEV)
+    zero = torch.randint(0, 16, (m,), generator=g).float().to(DEV)
+    qw = ops.pack(codes, bits, ops.LAYOUT_STREAM)
+    x = torch.randn(bs, d, generator=g).to(DEV).half()
+    y = ops.dequant_gemm(x, qw, bits, 'a', scale, zero, None, out_dtype=torch.float32, m=m)
+    ref = x.float() @ (scale[:, None] * (codes.float() - zero[:, None])).t()
+    assert float((y - ref).norm() / ref.norm()) <= 1e-3
