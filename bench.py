@@ -55,7 +55,8 @@ def parse():
     ap.add_argument("--no-llama", action="store_true", help="skip the Llama-2-7B-architecture decode side measurement (about 40 s)")
     ap.add_argument("--profile-cold-only", action="store_true",
                     help="for rocprofv3 passes: run only the cold bf16 regime (so per-kernel averages are the headline kernel's)")
-    ap.add_argument("--eager", action="store_true", help="time eager launches instead of a hipGraph")
+    ap.add_argument("--eager", action="store_true", help="time eager launches queued behind a spin kernel (default for --steps <= 256)")
+    ap.add_argument("--graph", action="store_true", help="time one hipGraph of K launches (default for --steps > 256)")
     return ap.parse_args()
 
 
@@ -122,13 +123,23 @@ def main():
                 for i in range(nw):
                     launch(weights[i], st)
                 side.synchronize()
-        if args.eager:
+        # How the K launches reach the GPU.  Up to 256 steps: eager launches enqueued while a spin kernel holds the stream, so they run
+        # back to back from the queue.  More: one hipGraph (the host cannot enqueue thousands of launches ahead of the GPU).  A SHORT
+        # graph pays its own start-up inside the timed region (K = 20: 5.3-5.4 us per launch as a graph, 4.96-4.98 queued eagerly,
+        # 4.77 at K = 2000 either way; profiles/r02s_bench_ring_walk.txt, r02u_bench_launch_modes.txt) -- the kernel is the same.
+        use_eager = args.eager or (not args.graph and steps <= 256)
+        if use_eager:
             with torch.cuda.stream(side):
                 st = vp(side.cuda_stream)
                 for i in range(warmup):
                     launch(weights[(nw - 1 - i) % nw], st)          # warm-up copies come from the END of the ring: the timed
                 barrier()                                             # launches (copies 0 .. K-1) never see a pre-touched copy
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                # the launches are enqueued while a spin kernel holds the stream, so they run back to back from the queue (host launch
+                # latency is not step time): ~5 us of host time per launch, the spin covers the first ~400
+                torch.cuda._sleep(int(min(steps, 400) * 12000 + 100000))
+                for i in range(min(warmup, 8)):
+                    launch(weights[(nw - 1 - i) % nw], st)          # pre-roll right in front of the start event
                 e0.record(side)
                 for i in range(steps):
                     launch(weights[i % nw], st)
@@ -226,7 +237,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: single 4096x4096 Linear, w2 qfn-b, fused dequant-GEMM, bs=16, "
                                f"cold weights (ring of {len(ring)} packed copies, {len(ring) * qs.numel() * 4 // 2**20} MiB; the timed launches stream copies 0..{min(len(ring), args.steps) - 1}, the warm-up ones come from the other end of the ring)", "m": M, "d": D, "bs": BS, "bits": BITS,
-                   "launch": "eager" if args.eager else "hipGraph", "parallelism": f"dp{world} (replicas)"},
+                   "launch": ("eager launches queued behind a spin kernel" if (args.eager or (not args.graph and args.steps <= 256))
+                              else "one hipGraph of K launches"), "parallelism": f"dp{world} (replicas)"},
         "parity_rel_err": rel,
         "roofline": {"bound": "hbm", "achieved": round(gbs_cold, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(gbs_cold / HBM_PEAK_GBS, 4), "traffic": traffic,
