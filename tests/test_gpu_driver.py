@@ -52,6 +52,15 @@ def _relvec(a, b):
     return np.abs(a - b) / np.abs(b)
 
 
+def _ppl(logits, tokens):
+    """perplexity of next-token prediction on the probe sequences ("per-layer error and perplexity on synthetic
+    tokens vs the reference CPU run") -- logits [2, seq, vocab], tokens [2, seq]"""
+    lg = torch.from_numpy(np.asarray(logits, np.float32))[:, :-1]
+    tgt = torch.as_tensor(tokens)[:, 1:]
+    nll = torch.nn.functional.cross_entropy(lg.reshape(-1, lg.shape[-1]), tgt.reshape(-1).long())
+    return float(torch.exp(nll))
+
+
 def test_the_module_aliases_resolve_to_quip_amd():
     import run_reference_driver as R
     R.alias_modules()
@@ -75,6 +84,9 @@ def test_nearest_matches_the_reference_driver_bit_for_bit(golden):
         assert _relvec(np.asarray([r["Hmag"] for r in rep]), golden["nearest_w4_Hmag"]).max() <= 1e-3
     ref = golden["nearest_w4_logits"].astype(np.float32)
     assert np.linalg.norm(logits - ref) / np.linalg.norm(ref) <= 2e-3
+    import tiny_model as TM
+    toks = TM.probe_tokens().numpy()
+    assert abs(_ppl(logits, toks) / _ppl(ref, toks) - 1.0) <= 1e-3                 # same weights: same perplexity
 
 
 def _ldlq_gates(golden, name, errors, logits, rep, tol0, tol1, tol_sum, tol_dist):
@@ -89,6 +101,10 @@ def _ldlq_gates(golden, name, errors, logits, rep, tol0, tol1, tol_sum, tol_dist
     ref = golden[f"{name}_logits"].astype(np.float32)
     d_got, d_ref = np.linalg.norm(logits - fp), np.linalg.norm(ref - fp)
     assert abs(d_got / d_ref - 1.0) <= tol_dist, (d_got, d_ref)
+    import tiny_model as TM
+    toks = TM.probe_tokens().numpy()
+    # perplexity on the synthetic probe tokens: two valid LDLQ runs land within a couple of percent of each other
+    assert abs(_ppl(logits, toks) / _ppl(ref, toks) - 1.0) <= 3e-2, (_ppl(logits, toks), _ppl(ref, toks), _ppl(fp, toks))
 
 
 def test_ldlq_matches_the_reference_driver(golden):
@@ -142,6 +158,9 @@ def test_llama_nearest_matches_the_reference_driver_bit_for_bit(golden_llama):
     assert _relvec(errors, g["nearest_w4_error"]).max() <= 2e-3
     ref = g["nearest_w4_logits"].astype(np.float32)
     assert np.linalg.norm(logits - ref) / np.linalg.norm(ref) <= 3e-3
+    import tiny_model as TM
+    toks = TM.probe_tokens().numpy()
+    assert abs(_ppl(logits, toks) / _ppl(ref, toks) - 1.0) <= 1e-3
 
 
 @pytest.mark.parametrize("name,bits", [("gptq_w4", 4), ("gptq_w3_g64", 3)])
