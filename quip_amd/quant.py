@@ -15,19 +15,32 @@ def _as_maxq(maxq):
     return int(maxq.item()) if torch.is_tensor(maxq) else int(maxq)
 
 
+def _f64(x):
+    """float64 tensors (optq_ldlq_equiv.py builds its FakeLayer in float64 "for numerics", gptq.py:25-27) have no kernel: the
+    grid formulas are evaluated with torch ops on the tensor's own device, exactly as the reference writes them."""
+    return torch.is_tensor(x) and x.dtype == torch.float64
+
+
 def quantize_qfna(x, scale, zero, maxq):
     """quant.py:6-8  s*(clamp(round(x/s)+z, 0, maxq) - z), per-row scale/zero."""
+    if _f64(x):
+        return scale * (torch.clamp(torch.round(x / scale) + zero, 0, maxq) - zero)
     return ops.quantize(x, 'a', scale, zero, _as_maxq(maxq))
 
 
 def quantize_qfnb(x, scale, maxq):
     """quant.py:10-15  symmetric scalar-scale grid."""
+    if _f64(x):
+        q = torch.clamp(torch.round(((x / scale + 1) / 2) * maxq), 0, maxq)
+        return ((q / maxq) * 2 - 1) * scale
     s = scale if torch.is_tensor(scale) else torch.tensor([float(scale)])
     return ops.quantize(x, 'b', s, None, _as_maxq(maxq))
 
 
 def quantize_qfnc(x, scale, zero, maxq):
     """quant.py:17-21  clamp-then-round variant (OPTQ == LDLQ equivalence)."""
+    if _f64(x):
+        return scale * (torch.round(torch.clamp(x / scale + zero, 0, maxq)) - zero)
     return ops.quantize(x, 'c', scale, zero, _as_maxq(maxq))
 
 
@@ -106,6 +119,9 @@ class Quantizer(nn.Module):
             return quantize_qfna(x, self.scale, self.zero, self.maxq)
         if self.qfn == 'b':
             assert torch.all(self.maxq != 0)
+            if _f64(x):
+                self.scale = 2.4 * x.square().mean().sqrt() + 1e-16
+                return quantize_qfnb(x, self.scale, self.maxq)
             s = ops.qfnb_scale(x)                               # 2.4*rms(x)+1e-16 in x's dtype, quant.py:150
             self.scale = s.to(x.dtype).reshape(())
             return ops.quantize(x, 'b', s, None, _as_maxq(self.maxq))

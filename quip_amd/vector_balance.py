@@ -115,6 +115,10 @@ def quantize_weight_vecbal(w, H, nbits, npasses, scale, zero, maxq, unbiased=Fal
     if qmethod not in ('ldlq', 'ldlqRG', 'ldl_gptqequiv'):
         raise NotImplementedError(f"qmethod {qmethod!r} is outside the quip_amd hot path (only 'ldlq' / 'ldlqRG' / 'ldl_gptqequiv')")
     mq = int(maxq.item()) if torch.is_tensor(maxq) else int(maxq)
+    if w.dtype == torch.float64:                      # optq_ldlq_equiv.py hands over a float64 FakeLayer: the kernels round in fp32
+        w, H = w.float(), H.float()
+        scale = None if scale is None else scale.float()
+        zero = None if zero is None else zero.float()
     if qmethod == 'ldl_gptqequiv':                # optq_ldlq_equiv.py: LDLQ in OPTQ's column order (vector_balance.py:381-422, :508)
         def rounder(wgrid):
             return round_ldl_gptqequiv(wgrid, H, nbits, unbiased=unbiased).to(torch.uint8)

@@ -412,3 +412,42 @@ def test_reference_driver_sequence_end_to_end(argv, monkeypatch):
     assert out["linears"] == nlin and np.isfinite(out["mean_proxy_error"]) and np.isfinite(out["logits_rel_change_fake_quant"])
     if "--pack" in argv:
         assert out["packed_layers"] == nlin and out["logits_rel_diff_packed_vs_fake_quant"] < 2e-2
+
+
+def test_optq_ldlq_equiv_script_scenario(Q):
+    """/root/reference/optq_ldlq_equiv.py:10-73 on the package: a float64 FakeLayer (not an nn.Module), GPTQ with qfn c and
+    debug_equiv=True against Balance('ldl_gptqequiv'), same grid -- the script asserts equal quantisers and prints how many
+    weights agree.  The GPTQ side stays in float64 (torch ops on the GPU, the column walk), the LDLQ side runs the fp32 kernels
+    and returns fp16 like the reference: >= 98 % of the weights within 1e-3, proxy losses within 1 %."""
+    import copy
+    from quip_amd.gptq import GPTQ
+    from quip_amd.bal import Balance
+
+    class FakeLayer:                                           # optq_ldlq_equiv.py:10-14, tensors on the GPU
+        def __init__(self, m, d):
+            self.weight = torch.rand(m, d, dtype=torch.float64, device=DEV)
+            x = torch.rand(d, d, dtype=torch.float64, device=DEV)
+            self.H = x.T @ x + 0.01 * torch.eye(d, device=DEV)
+    torch.manual_seed(0)
+    wbits = 3
+    layer = FakeLayer(320, 512)
+    lg, ll = copy.deepcopy(layer), copy.deepcopy(layer)
+    g = GPTQ(lg)
+    g.H = lg.H
+    g.quantizer = Q.Quantizer()
+    g.quantizer.configure(wbits, perchannel=True, sym=False, qfn='c', mse=False)
+    g.preproc(preproc_gptqH=False, percdamp=0, preproc_rescale=False, preproc_proj=False, preproc_proj_extra=0)
+    l = Balance(ll)
+    l.H = ll.H
+    l.configure('ldl_gptqequiv', wbits, npasses=1, unbiased=False)
+    l.quantizer = Q.Quantizer()
+    l.quantizer.configure(wbits, perchannel=True, sym=False, qfn='a', mse=False)
+    l.preproc(preproc_gptqH=False, percdamp=0, preproc_rescale=False, preproc_proj=False, preproc_proj_extra=0)
+    g.fasterquant(groupsize=-1, debug_equiv=True)
+    l.fasterquant()
+    assert torch.all(g.quantizer.scale.float() == l.quantizer.scale.float())           # the script's own assertions (:71-73)
+    assert torch.all(g.quantizer.zero.float() == l.quantizer.zero.float())
+    assert g.quantizer.maxq == l.quantizer.maxq
+    diff = (lg.weight.double() - ll.weight.double()).abs()
+    assert float((diff < 1e-3).double().mean()) >= 0.98
+    assert abs(g.error - l.error) <= 1e-2 * g.error
