@@ -10,8 +10,9 @@
 //   diag   one wavefront factors the 64 x 64 diagonal block in registers: lane = column, 64 registers = rows; the pivot
 //          row reaches the other lanes with v_readlane (scalar broadcast), no LDS, no barrier: ~8 us per block instead
 //          of 64 x 3.5 us.
-//   panel  U_kk^T X = A_k,rest by forward substitution, one thread per column (64 registers), the entries of U_kk
-//          arrive as wave-uniform scalar loads; exact substitution, no explicit inverse.
+//   panel  U_kk^T X = A_k,rest blocked 4 x 16 rows on the fp32 matrix pipe: X_i = W_i (B_i - sum_{j<i} U_ji^T X_j) with the four
+//          16 x 16 inverses W_i = (U_ii^T)^-1 formed by 16-step substitutions in every workgroup (round 1: one thread per column,
+//          64 substitution steps, LDS-broadcast bound at 21 us per panel on the serial chain).
 //   syrk   (panels are factored in PAIRS: a 64-row strip update lets the second panel of a pair be factored, then one
 //          rank-128 update covers everything behind the pair -- the rank-64 form re-read and re-wrote the trailing
 //          matrix every 64 columns and was HBM-bound at d >= 4096)
@@ -117,45 +118,80 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(float *A, int64_t d, int6
     }
 }
 
-// ---- panel: X = U_kk^-T A[k0:k0+64, c] for the columns c >= k0+64, one thread per column ----------------------------------
-// (only launched when columns remain, so the 64 rows of the step are always inside the matrix).  U_kk sits in LDS and
-// is read as broadcast float4s: 2080 wave-uniform scalar loads made hipcc hoist them all and spill 700 SGPRs (and a
-// compiler-level fence per row to pin them turns them into vector loads).  A broadcast read still moves 16 B to each
-// of 64 lanes, so this kernel is LDS-bandwidth bound (21 us); two columns per thread to halve the reads per column
-// ran out of registers (hipcc moves every row's reads to the top) -- left as is.
-__global__ __launch_bounds__(256) void chol_panel_kernel(float *A, int64_t d, int64_t k0)
+// ---- panel: X = U_kk^-T A[k0:k0+64, c] for the columns c >= k0+64, on the matrix pipe ---------------------------------------------
+// (only launched when columns remain, so the 64 rows of the step are always inside the matrix)
+// Blocked 4 x 16 rows:  X_i = W_i ( B_i - sum_{j<i} U_ji^T X_j ),  W_i = (U_ii^T)^-1,  i = 0..3, as fp32 MFMAs
+// (v_mfma_f32_16x16x4_f32: exact fp32 fma chains).  The round-1 form -- one thread per column, 64 substitution steps, U_kk read as
+// broadcast float4s from LDS -- was LDS-bandwidth bound at 21 us and sat, with the 17 us diagonal block, on the serial chain of
+// the factorisation (2.4 of the 3.5 ms at d = 4096).  One wave = one
+// 16-column tile of the panel: 64 x 16 values in the MFMA D layout (lane = column, 4 rows per register group), which IS the
+// B-operand layout, so X_j feeds the next products without a shuffle; U_kk^T and the four 16 x 16 inverses are A operands read as
+// float4 from LDS.  The inverses (16-step substitutions, 16 lanes each) are recomputed by every workgroup: ~1 us.
+__global__ __launch_bounds__(256) void chol_panel_mfma_kernel(float *A, int64_t d, int64_t k0)
 {
-    __shared__ __attribute__((aligned(16))) float Us[NB][NB + 4];
+    __shared__ __attribute__((aligned(16))) float UT[NB][NB + 4];        // UT[c][r] = U[r][c] for r <= c, else 0
+    __shared__ __attribute__((aligned(16))) float Wi[4][16][20];         // Wi[i][r][k] = (U_ii^T)^-1 [r][k]
     {
         const float *U = A + k0 * d + k0;
 #pragma unroll
         for (int u = 0; u < NB * NB / 256; ++u) {
             const int idx = u * 256 + threadIdx.x, r = idx >> 6, cc = idx & 63;
-            Us[r][cc] = U[(int64_t)r * d + cc];
+            UT[cc][r] = cc >= r ? U[(int64_t)r * d + cc] : 0.f;
         }
     }
     __syncthreads();
-    const int64_t c = k0 + NB + (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float *Ac = A + k0 * d + (c < d ? c : k0 + NB);
-    float b[NB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 16) {
+        // column t of the inverse of L = U_ii^T (lower):  L[r][k] = UT[16i + r][16i + k]
+        const int i = wave, t = lane;
+        float x[16];
 #pragma unroll
-    for (int r = 0; r < NB; ++r) b[r] = Ac[(int64_t)r * d];
+        for (int r = 0; r < 16; ++r) {
+            float sacc = 0.f;
 #pragma unroll
-    for (int s = 0; s < NB; ++s) {
-        const float x = b[s] / Us[s][s];
-        b[s] = x;
-#pragma unroll
-        for (int r4 = ((s + 1) & ~3); r4 < NB; r4 += 4) {
-            const float4 u = *reinterpret_cast<const float4 *>(&Us[s][r4]);
-            if (r4 + 0 > s) b[r4 + 0] = fmaf(-u.x, x, b[r4 + 0]);
-            if (r4 + 1 > s) b[r4 + 1] = fmaf(-u.y, x, b[r4 + 1]);
-            if (r4 + 2 > s) b[r4 + 2] = fmaf(-u.z, x, b[r4 + 2]);
-            if (r4 + 3 > s) b[r4 + 3] = fmaf(-u.w, x, b[r4 + 3]);
+            for (int k = 0; k < r; ++k) sacc = fmaf(UT[16 * i + r][16 * i + k], x[k], sacc);      // x[k] = 0 for k < t
+            const float diag = UT[16 * i + r][16 * i + r];
+            x[r] = r < t ? 0.f : (r == t ? 1.f / diag : -sacc / diag);
         }
-    }
-    if (c < d) {
 #pragma unroll
-        for (int r = 0; r < NB; ++r) Ac[(int64_t)r * d] = b[r];
+        for (int r = 0; r < 16; ++r) Wi[i][r][t] = x[r];
+    }
+    __syncthreads();
+    const int64_t c0 = k0 + NB + ((int64_t)blockIdx.x * 4 + wave) * 16;
+    if (c0 >= d) return;
+    const int jc = lane & 15, g = lane >> 4;
+    const int64_t col = c0 + jc;
+    const bool in = col < d;
+    float *Ac = A + k0 * d + (in ? col : k0 + NB);
+    f32x4_t X[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) X[i][reg] = in ? Ac[(int64_t)(16 * i + 4 * g + reg) * d] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4_t t = X[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(&UT[16 * i + jc][16 * j + 4 * g]);   // A[r][k] = U[16j + k][16i + r]
+            t = __builtin_amdgcn_mfma_f32_16x16x4f32(-a4.x, X[j][0], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_16x16x4f32(-a4.y, X[j][1], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_16x16x4f32(-a4.z, X[j][2], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_16x16x4f32(-a4.w, X[j][3], t, 0, 0, 0);
+        }
+        const float4 w4 = *reinterpret_cast<const float4 *>(&Wi[i][jc][4 * g]);
+        f32x4_t xi = {0.f, 0.f, 0.f, 0.f};
+        xi = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, t[0], xi, 0, 0, 0);
+        xi = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, t[1], xi, 0, 0, 0);
+        xi = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, t[2], xi, 0, 0, 0);
+        xi = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, t[3], xi, 0, 0, 0);
+        X[i] = xi;
+    }
+    if (in) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Ac[(int64_t)(16 * i + 4 * g + reg) * d] = X[i][reg];
     }
 }
 
@@ -317,12 +353,12 @@ extern "C" int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *in
     for (int64_t k0 = 0; k0 < d; k0 += 2 * NB) {
         diag(k0);
         if (d - k0 - NB <= 0) break;
-        chol_panel_kernel<<<(unsigned)((d - k0 - NB + 255) / 256), 256, 0, s>>>(LT, d, k0);
+        chol_panel_mfma_kernel<<<(unsigned)((d - k0 - NB + 63) / 64), 256, 0, s>>>(LT, d, k0);
         int rc = launch_syrk<2>(LT, d, k0, 1, k0 + NB, true, s);                  // rows k0+64 .. k0+127, all columns behind
         if (rc != QUIPAMD_OK) return rc;
         diag(k0 + NB);
         if (d - k0 - 2 * NB <= 0) break;
-        chol_panel_kernel<<<(unsigned)((d - k0 - 2 * NB + 255) / 256), 256, 0, s>>>(LT, d, k0 + NB);
+        chol_panel_mfma_kernel<<<(unsigned)((d - k0 - 2 * NB + 63) / 64), 256, 0, s>>>(LT, d, k0 + NB);
         rc = trailing_update(LT, d, k0, 2, k0 + 2 * NB, s);
         if (rc != QUIPAMD_OK) return rc;
     }
