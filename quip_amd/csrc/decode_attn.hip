@@ -123,11 +123,14 @@ int launch_attn(const void *q, const void *k, const void *v, void *kc, void *vc,
     typedef typename DT<TI>::storage S;
     const size_t lds = (size_t)(maxlen + 8 + 4 * HD) * sizeof(float);
     auto kern = decode_attn_kernel<TI, HD>;
-    static size_t reserved = 0;
-    if (lds > reserved && lds > 48 * 1024) {
+    static size_t reserved[64] = {};                                // per device and instantiation: the attribute is per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const bool known = dev >= 0 && dev < 64;
+    if (lds > 48 * 1024 && (!known || lds > reserved[dev])) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_attention: cannot reserve %zu B of LDS", lds);
-        reserved = lds;
+        if (known) reserved[dev] = lds;
     }
     kern<<<(unsigned)(bs * heads), 256, lds, s>>>((const S *)q, (const S *)k, (const S *)v, (S *)kc, (S *)vc, pos, (S *)out, heads,
                                                   maxlen, scale, ldq);
