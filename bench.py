@@ -136,8 +136,8 @@ def main():
                 barrier()                                             # launches (copies 0 .. K-1) never see a pre-touched copy
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 # the launches are enqueued while a spin kernel holds the stream, so they run back to back from the queue (host launch
-                # latency is not step time): ~5 us of host time per launch, the spin covers the first ~400
-                torch.cuda._sleep(int(min(steps, 400) * 12000 + 100000))
+                # latency is not step time): ~5 us of host time per launch, the spin (~14 us per launch) covers the first ~400
+                torch.cuda._sleep(int(min(steps, 400) * 30000 + 300000))    # generous: a loaded host still stays ahead of the GPU
                 for i in range(min(warmup, 8)):
                     launch(weights[(nw - 1 - i) % nw], st)          # pre-roll right in front of the start event
                 e0.record(side)
