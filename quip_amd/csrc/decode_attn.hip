@@ -17,6 +17,24 @@
 
 namespace {
 
+// wave-wide reductions on the DPP network (4 DPP operands + 4 v_readlane instead of six ds_bpermute round trips each)
+template <int CTRL> __device__ __forceinline__ float dpp_f(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <bool MAX> __device__ __forceinline__ float wave_reduce(float v)
+{
+    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+    v = op(v, dpp_f<0xB1>(v));       // quad_perm [1,0,3,2]
+    v = op(v, dpp_f<0x4E>(v));       // quad_perm [2,3,0,1]
+    v = op(v, dpp_f<0x141>(v));      // row_half_mirror
+    v = op(v, dpp_f<0x140>(v));      // row_mirror: every lane of a 16-lane row holds the row's result
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return op(op(r0, r1), op(r2, r3));
+}
+
 template <class TI, int HD>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>::storage *q, const typename DT<TI>::storage *k,
                                                          const typename DT<TI>::storage *v, typename DT<TI>::storage *kc,
@@ -41,7 +59,21 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
 
     float qr[HD];
 #pragma unroll
-    for (int e = 0; e < HD; ++e) qr[e] = DT<TI>::load(qh, e) * scale;
+    for (int e8 = 0; e8 < HD; e8 += 8) {                            // 16-byte loads (HD scalar 2-byte loads per thread before)
+        S raw[8];
+        *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(qh + e8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qr[e8 + e] = DT<TI>::load(raw, e) * scale;
+    }
+    // the first batch of V rows does not depend on the scores: request it now, one round trip earlier
+    constexpr int CH = HD / 8, RS = 64 / CH;                         // chunks per row, rows per instruction (hd 64: 8, 8)
+    const int ch = lane % CH, rsub = lane / CH;
+    uint4 vraw0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int64_t t = (int64_t)wave * RS + (int64_t)u * 4 * RS + rsub;
+        vraw0[u] = t < T ? *reinterpret_cast<const uint4 *>(vcb + t * HD + 8 * ch) : make_uint4(0, 0, 0, 0);
+    }
 
     // ---- phase 1: scores --------------------------------------------------------------------------------------------
     float mx = -INFINITY;
@@ -58,8 +90,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
         scores[t] = acc;
         mx = fmaxf(mx, acc);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_reduce<true>(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -69,8 +100,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
         scores[t] = p;
         sum += p;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_reduce<false>(sum);
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
@@ -78,11 +108,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
     // ---- phase 2: o = p V ---------------------------------------------------------------------------------------------
     // lane = (row slot, 8-dim chunk): one 16-byte load per lane covers 64 / CH rows per instruction, up to 8 such loads
     // in flight, so a ~130-position context is ONE round trip per wave (one 128-byte row per instruction was five).
-    constexpr int CH = HD / 8, RS = 64 / CH;                         // chunks per row, rows per instruction (hd 64: 8, 8)
-    const int ch = lane % CH, rsub = lane / CH;
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    bool first = true;
     for (int64_t tb = (int64_t)wave * RS; tb < T; tb += 4 * RS * 8) {
         uint4 raw[8];
         float pw[8];
@@ -90,9 +119,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
         for (int u = 0; u < 8; ++u) {
             const int64_t t = tb + (int64_t)u * 4 * RS + rsub;
             const bool ok = t < T;
-            raw[u] = ok ? *reinterpret_cast<const uint4 *>(vcb + t * HD + 8 * ch) : make_uint4(0, 0, 0, 0);
+            if (first) raw[u] = vraw0[u];
+            else raw[u] = ok ? *reinterpret_cast<const uint4 *>(vcb + t * HD + 8 * ch) : make_uint4(0, 0, 0, 0);
             pw[u] = ok ? scores[t] : 0.f;
         }
+        first = false;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const S *rv = reinterpret_cast<const S *>(&raw[u]);
