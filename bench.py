@@ -57,6 +57,9 @@ def parse():
                     help="for rocprofv3 passes: run only the cold bf16 regime (so per-kernel averages are the headline kernel's)")
     ap.add_argument("--eager", action="store_true", help="time eager launches queued behind a spin kernel (default for --steps <= 256)")
     ap.add_argument("--graph", action="store_true", help="time one hipGraph of K launches (default for --steps > 256)")
+    ap.add_argument("--no-spin", action="store_true",
+                    help="with --eager: launch without the spin kernel in front (each kernel then starts on an idle GPU: the form the "
+                         "rocprofv3 passes use, whose per-kernel durations are the kernel alone)")
     return ap.parse_args()
 
 
@@ -137,7 +140,8 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 # the launches are enqueued while a spin kernel holds the stream, so they run back to back from the queue (host launch
                 # latency is not step time): ~5 us of host time per launch, the spin (~14 us per launch) covers the first ~400
-                torch.cuda._sleep(int(min(steps, 400) * 30000 + 300000))    # generous: a loaded host still stays ahead of the GPU
+                if not args.no_spin:
+                    torch.cuda._sleep(int(min(steps, 400) * 30000 + 300000))    # generous: a loaded host still stays ahead of the GPU
                 for i in range(min(warmup, 8)):
                     launch(weights[(nw - 1 - i) % nw], st)          # pre-roll right in front of the start event
                 e0.record(side)

@@ -12,10 +12,10 @@ echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== bench"; timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc=$?"; cat $O/bench_$TAG.json; tail -3 $O/bench_$TAG.err
 cd /tmp
 echo "== rocprof kernel-trace (cold regime, eager launches)"
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --steps 1000 --warmup 100 --profile-cold-only --eager > $O/prof_bench_$TAG.log 2>&1; echo "rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --steps 1000 --warmup 100 --profile-cold-only --eager --no-spin > $O/prof_bench_$TAG.log 2>&1; echo "rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "== rocprof pmc $c"
-  timeout 600 rocprofv3 --pmc $c --kernel-trace -d $O/pmc_${c}_$TAG -o pmc -- python $R/bench.py --steps 300 --warmup 30 --profile-cold-only --eager > $O/pmc_${c}_$TAG.log 2>&1; echo "rc=$?"
+  timeout 600 rocprofv3 --pmc $c --kernel-trace -d $O/pmc_${c}_$TAG -o pmc -- python $R/bench.py --steps 300 --warmup 30 --profile-cold-only --eager --no-spin > $O/pmc_${c}_$TAG.log 2>&1; echo "rc=$?"
 done
 cd $R
 python scripts/rocpd_summary.py $O/prof_$TAG/trace_results.db $O/pmc_FETCH_SIZE_$TAG/pmc_results.db $O/pmc_WRITE_SIZE_$TAG/pmc_results.db > $O/rocprof_summary_$TAG.txt 2>&1
