@@ -1,8 +1,9 @@
 """oracle/build.py -- compile oracle/ldlq_oracle.c into oracle/liboracle.so with gcc.
 
 TEST INFRASTRUCTURE.  Called by __graft_entry__.build() and lazily by
-oracle/quip_oracle.py.  There is no oracle/_ref: the reference is pure Python
-(no C/C++ sources to compile), see DESIGN.md "Oracle".
+oracle/quip_oracle.py.  Nothing of the reference is compiled (it is pure Python);
+oracle/stage_ref.py stages its driver files into oracle/_ref/ for the GPU driver
+tests, see DESIGN.md "Oracle".
 """
 import os
 import subprocess

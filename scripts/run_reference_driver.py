@@ -4,10 +4,12 @@
 
     from gptq import *; from bal import Balance; from near import Nearest; from modelutils import *; from quant import *   (opt.py:6-10)
 
-all resolve to quip_amd.{gptq,bal,near,modelutils,quant} (+ method, vector_balance behind them).  With the reference checkout
-at hand (QUIP_REFERENCE=/path/to/QuIP, a machine that has both it and a GPU) the reference's own, unmodified opt.py is
-imported and its opt_sequential (opt.py:29-190) is called; without it (the GPU test box has no reference tree) the same call
-sequence restated in scripts/quantize_opt.py runs.  Either way every quantisation call lands in libquip_amd.so."""
+all resolve to quip_amd.{gptq,bal,near,modelutils,quant} (+ method, vector_balance behind them).  With the reference's
+driver files at hand -- QUIP_REFERENCE=/path/to/QuIP, or the copies oracle/stage_ref.py stages into the git-ignored
+oracle/_ref/ (they travel to the GPU box with the snapshot) -- the reference's own, unmodified opt.py / llama.py is imported
+and its opt_sequential (opt.py:29-190) / llama_sequential (llama.py:36-171) is called; without them the same call sequence
+restated in scripts/quantize_opt.py runs and `is_reference` comes back False (tests/test_gpu_driver.py then says so instead
+of claiming the drop-in).  Either way every quantisation call lands in libquip_amd.so."""
 import importlib
 import importlib.util
 import os
@@ -26,10 +28,20 @@ def alias_modules():
     return quip_amd
 
 
-def load_driver():
-    """(opt_sequential, is_reference): signature opt_sequential(model, dataloader, dev, args) -> (quantizers | report, errors)"""
-    alias_modules()
+def reference_dir():
+    """where the reference's driver files are: $QUIP_REFERENCE, else oracle/_ref when oracle/stage_ref.py has staged them"""
     ref = os.environ.get("QUIP_REFERENCE")
+    if ref:
+        return ref
+    staged = os.path.join(ROOT, "oracle", "_ref")
+    return staged if os.path.exists(os.path.join(staged, "opt.py")) else None
+
+
+def load_driver(restatement=False):
+    """(opt_sequential, is_reference): signature opt_sequential(model, dataloader, dev, args) -> (quantizers | report, errors);
+    restatement=True forces scripts/quantize_opt.py's restated call sequence even when the reference's opt.py is at hand"""
+    alias_modules()
+    ref = None if restatement else reference_dir()
     if ref and os.path.exists(os.path.join(ref, "opt.py")):
         spec = importlib.util.spec_from_file_location("opt", os.path.join(ref, "opt.py"))
         mod = importlib.util.module_from_spec(spec)
@@ -48,13 +60,14 @@ def load_driver():
     return opt_sequential, False
 
 
-def load_llama_driver():
-    """llama_sequential(model, dataloader, dev, args) -> (report | quantizers, errors).  With QUIP_REFERENCE set the reference's
+def load_llama_driver(restatement=False):
+    """llama_sequential(model, dataloader, dev, args) -> (report | quantizers, errors).  With the reference's files at hand its
     own llama.py:36-171 runs on quip_amd (its module global `args` injected, HF's LlamaDecoderLayer.forward wrapped to derive
-    the position_embeddings llama.py does not forward -- the same two adaptations tests/golden/make_golden.py needed to run it
-    on CPU); otherwise scripts/quantize_opt.py's llama_sequential, which carries the fixes itself."""
+    the position_embeddings llama.py does not forward, Balance.configure accepting the stray args.qbits of llama.py:110-115 --
+    the same three adaptations tests/golden/make_golden.py needed to run it on CPU); otherwise scripts/quantize_opt.py's
+    llama_sequential, which carries the fixes itself."""
     alias_modules()
-    ref = os.environ.get("QUIP_REFERENCE")
+    ref = None if restatement else reference_dir()
     if ref and os.path.exists(os.path.join(ref, "llama.py")):
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden", "_shims"))     # texttable
         sys.path.insert(0, ref)                                                  # datautils
@@ -63,6 +76,9 @@ def load_llama_driver():
         spec.loader.exec_module(mod)
         from transformers.models.llama import modeling_llama as ML
         import quip_amd.method as M
+        import quip_amd.bal as B
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import tiny_model as TM                                                  # balance_configure_shim
 
         def llama_sequential(model, dataloader, dev, args):
             orig_fwd, orig_free, errors = ML.LlamaDecoderLayer.forward, M.QuantMethod.free, []
@@ -77,7 +93,8 @@ def load_llama_driver():
                 return orig_free(self)
             ML.LlamaDecoderLayer.forward, M.QuantMethod.free, mod.args = fwd, free, args
             try:
-                return mod.llama_sequential(model, dataloader, dev), errors
+                with TM.balance_configure_shim(B.Balance):
+                    return mod.llama_sequential(model, dataloader, dev), errors
             finally:
                 ML.LlamaDecoderLayer.forward, M.QuantMethod.free = orig_fwd, orig_free
         return llama_sequential, True

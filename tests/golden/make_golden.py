@@ -458,10 +458,62 @@ def gen_driver():
          "error / Hmag, final fp16 weights (first 8 rows + SHA-256), logits; configs nearest_w4, ldlq_w4, ldlq_w2_incoh", **arrs)
 
 
+# ---------------------------------------------------------------- H1b. reference-vs-reference spread of the LDLQ driver runs
+def gen_driver_spread():
+    """How far do two runs of the REFERENCE's own opt_sequential land from each other when only the fp summation order changes?
+    The LDLQ driver configs of gen_driver() re-run with torch.set_num_threads in {1, 2, 8} and oneDNN on / off (different
+    blocking of the fp16 / fp32 CPU matmuls -- same code, same seeds, same model).  Block 0 sees identical Hessians and moves by
+    <= 1.5e-2; block 1's Hessians are downstream of block 0's near-tie code flips and its per-Linear proxy errors move by
+    percent.  tests/test_gpu_driver.py derives its block-1 gates from the maxima recorded here instead of hand-picked numbers.
+    (Thread-count dependent: the values reproduce on a machine with the same core count and MKL / oneDNN build only; the test
+    uses the per-block maxima, not the individual entries.)"""
+    import types
+    import tiny_model as TM
+    import opt as ref_opt
+    rec = []
+    orig_free = ref_method.QuantMethod.free
+
+    def recording_free(self):
+        rec.append(float(self.error))
+        return orig_free(self)
+    ref_method.QuantMethod.free = recording_free
+    variants = [(1, True), (2, True), (8, True), (1, False), (8, False)]
+    arrs = {"variants_threads_onednn": np.asarray([[t, int(m)] for t, m in variants])}
+    try:
+        for cname in ("ldlq_w4", "ldlq_w2_incoh"):
+            rows = []
+            for threads, onednn in variants:
+                torch.set_num_threads(threads)
+                torch.backends.mkldnn.enabled = onednn
+                model = TM.build_tiny_opt()
+                del rec[:]
+                np.random.seed(0)
+                torch.manual_seed(0)
+                ref_opt.opt_sequential(model, TM.calibration_batches(), torch.device("cpu"),
+                                       types.SimpleNamespace(nsamples=TM.NSAMPLES, **TM.CONFIGS[cname]))
+                rows.append(np.asarray(rec, np.float64))
+            e = np.stack(rows)
+            arrs[f"{cname}_errors"] = e
+            rel = np.abs(e[1:] - e[0]) / e[0]
+            arrs[f"{cname}_rel_spread_block0"] = np.asarray(rel[:, :6].max())
+            arrs[f"{cname}_rel_spread_block1"] = np.asarray(rel[:, 6:].max())
+            arrs[f"{cname}_rel_spread_sum"] = np.asarray((np.abs(e[1:].sum(1) - e[0].sum()) / e[0].sum()).max())
+            print(cname, "block0", rel[:, :6].max(), "block1", rel[:, 6:].max(), "sum", arrs[f"{cname}_rel_spread_sum"])
+    finally:
+        ref_method.QuantMethod.free = orig_free
+        torch.set_num_threads(1)
+        torch.backends.mkldnn.enabled = True
+    save("driver_spread", "opt.py:29-190 opt_sequential (reference, CPU) re-run under (threads, oneDNN) variants "
+         "[(1,on) = driver.npz, (2,on), (8,on), (1,off), (8,off)]: per-Linear proxy errors [variant, 12] and the largest relative "
+         "deviation from variant 0 per block -- the reference's own run-to-run noise under fp re-ordering", **arrs)
+
+
 # ---------------------------------------------------------------- H2. the reference LLAMA driver
 def gen_llama_driver():
     """/root/reference/llama.py:36-171 `llama_sequential`, unmodified, on the tiny random-init fp16 Llama of tiny_model.py, CPU,
-    for the branches that run as shipped: `nearest` and `gptq` (groupsize -1 and 64).  Two things outside the reference are
+    for the branches that run as shipped: `nearest` and `gptq` (groupsize -1 and 64), plus `ldlq` w2 qfn b with incoherence
+    processing (BASELINE configs[3]) through the Balance branch with tiny_model.balance_configure_shim dropping the stray
+    args.qbits of llama.py:110-115.  Two things outside the reference are
     adapted so that its code runs at all under transformers 5: `llama.args` (the driver reads a module
     global) is set from tiny_model.LLAMA_CONFIGS, and transformers' LlamaDecoderLayer.forward is wrapped so that a call
     WITHOUT position_embeddings (the reference forwards only attention_mask / position_ids, llama.py:134,160) computes them
@@ -490,6 +542,8 @@ def gen_llama_driver():
     sync = torch.cuda.synchronize
     torch.cuda.synchronize = lambda *a, **k: None
     try:
+        shim = TM.balance_configure_shim(ref_bal.Balance)    # llama.py:110-115 passes a stray args.qbits (see tiny_model.py)
+        shim.__enter__()
         for cname, cfg in TM.LLAMA_CONFIGS.items():
             model = TM.build_tiny_llama()
             rot["m"] = model.model.rotary_emb
@@ -514,13 +568,15 @@ def gen_llama_driver():
         with torch.no_grad():
             arrs["fp16_logits"] = TM.build_tiny_llama()(TM.probe_tokens()).logits.float().numpy().astype(np.float16)
     finally:
+        shim.__exit__()
         ref_method.QuantMethod.free = orig_free
         ML.LlamaDecoderLayer.forward = orig_fwd
         torch.cuda.synchronize = sync
     save("driver_llama", "llama.py:36-171 llama_sequential (the reference driver, unmodified; args injected as the module global it reads, "
          "HF's LlamaDecoderLayer.forward wrapped to derive position_embeddings from position_ids) on tests/golden/tiny_model.py "
          "build_tiny_llama: per-Linear error / Hmag in driver order, final fp16 weights (first 8 rows + SHA-256), logits; "
-         "configs nearest_w4, gptq_w4, gptq_w3_g64", **arrs)
+         "configs nearest_w4, gptq_w4, gptq_w3_g64, ldlq_w2_incoh (Balance branch, llama.py:107-115, with the stray args.qbits "
+         "argument dropped by tiny_model.balance_configure_shim)", **arrs)
 
 
 if __name__ == "__main__":
@@ -536,6 +592,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "driver":
         gen_driver()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "driver_spread":
+        gen_driver_spread()
+        sys.exit(0)
     gen_grids()
     gen_pack()
     gen_butterfly()
@@ -545,4 +604,5 @@ if __name__ == "__main__":
     gen_rounders()
     gen_gptq_groups()
     gen_driver()
+    gen_driver_spread()
     gen_llama_driver()

@@ -79,4 +79,33 @@ LLAMA_CONFIGS = {
                     pre_gptqH=True, pre_rescale=False, pre_proj=False, pre_proj_extra=0, groupsize=-1),
     "gptq_w3_g64": dict(quant="gptq", wbits=3, qfn="a", npasses=0, unbiased=False, percdamp=0.01,
                         pre_gptqH=True, pre_rescale=False, pre_proj=False, pre_proj_extra=0, groupsize=64),
+    # BASELINE configs[3] (Llama w2, --incoh_processing): llama.py's Balance branch (llama.py:107-115) passes FIVE arguments
+    # (args.quant, args.wbits, args.qbits, args.npasses, unbiased=) to Balance.configure(qmethod, nbits, npasses, unbiased)
+    # (bal.py:15) and dies with a TypeError as shipped.  `balance_configure_shim` below drops the stray args.qbits; with that
+    # one adaptation the reference's own llama_sequential + Balance + round_ldl produce this golden.
+    "ldlq_w2_incoh": dict(quant="ldlq", wbits=2, qbits=2, qfn="b", npasses=0, unbiased=False, percdamp=0.01,
+                          pre_gptqH=True, pre_rescale=True, pre_proj=True, pre_proj_extra=0, groupsize=-1),
 }
+
+
+class balance_configure_shim:
+    """context manager: Balance.configure(qmethod, nbits, [qbits,] npasses, unbiased=...) -- accepts llama.py:110-115's call
+    by dropping the stray third positional (args.qbits, never defined by llama.py's parser).  Applied to the REFERENCE's
+    Balance when the golden is generated and to quip_amd's Balance when the reference's llama.py runs on it."""
+
+    def __init__(self, balance_cls):
+        self.cls = balance_cls
+
+    def __enter__(self):
+        self.orig = orig = self.cls.configure
+
+        def configure(self, qmethod, nbits, *rest, **kw):
+            if len(rest) == 2 and 'unbiased' in kw:          # llama.py:110-115: (qbits, npasses), unbiased=...
+                rest = rest[1:]
+            return orig(self, qmethod, nbits, *rest, **kw)
+        self.cls.configure = configure
+        return self
+
+    def __exit__(self, *exc):
+        self.cls.configure = self.orig
+        return False

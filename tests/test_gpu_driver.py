@@ -35,14 +35,24 @@ def golden():
     return np.load(os.path.join(HERE, "golden", "driver.npz"))
 
 
-def _run(name):
+STAGED = os.path.exists(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "opt.py"))   # oracle/stage_ref.py ran (build())
+DRIVERS = ["reference", "restatement"] if STAGED else ["restatement"]
+RAN = {}                                                     # which driver really executed, per test (printed by the last test)
+
+
+def _run(name, driver=None):
+    """driver: "reference" = the reference's OWN opt.py:29-190 (staged copy) on quip_amd; "restatement" = scripts/quantize_opt.py;
+    None = the reference's when staged"""
     import tiny_model as TM
     import run_reference_driver as R
-    drv, is_ref = R.load_driver()
+    drv, is_ref = R.load_driver(restatement=(driver == "restatement"))
+    assert is_ref == (driver == "reference" or (driver is None and STAGED)), "the staged reference driver did not load"
+    RAN[f"opt:{name}:{driver}"] = "reference opt.py" if is_ref else "scripts/quantize_opt.py"
     model = TM.build_tiny_opt().to(DEV)
     np.random.seed(0)
     torch.manual_seed(0)
     rep, errors = drv(model, TM.calibration_batches(), torch.device(DEV), types.SimpleNamespace(nsamples=TM.NSAMPLES, **TM.CONFIGS[name]))
+    model.to(DEV)                                            # opt.py:184 parks every finished block on the CPU
     with torch.no_grad():
         logits = model(TM.probe_tokens().to(DEV)).logits.float().cpu().numpy()
     return model, rep, np.asarray([float(e) for e in errors]), logits
@@ -71,8 +81,9 @@ def test_the_module_aliases_resolve_to_quip_amd():
     assert callable(modelutils.find_layers)
 
 
-def test_nearest_matches_the_reference_driver_bit_for_bit(golden):
-    model, rep, errors, logits = _run("nearest_w4")
+@pytest.mark.parametrize("driver", DRIVERS)
+def test_nearest_matches_the_reference_driver_bit_for_bit(golden, driver):
+    model, rep, errors, logits = _run("nearest_w4", driver)
     names = [str(n) for n in golden["nearest_w4_names"]]
     params = dict(model.named_parameters())
     for k in names:
@@ -108,9 +119,25 @@ def _ldlq_gates(golden, name, errors, logits, rep, tol0, tol1, tol_sum, tol_dist
     assert abs(_ppl(logits, toks) / _ppl(ref, toks) - 1.0) <= 0.5 * tol_dist, (_ppl(logits, toks), _ppl(ref, toks), _ppl(fp, toks))
 
 
-def test_ldlq_matches_the_reference_driver(golden):
-    model, rep, errors, logits = _run("ldlq_w4")
-    _ldlq_gates(golden, "ldlq_w4", errors, logits, rep, 5e-3, 6e-2, 1e-2, 0.10)
+@pytest.fixture(scope="module")
+def spread():
+    """the reference's OWN run-to-run noise under fp re-ordering (CPU thread count / oneDNN blocking), tests/golden/make_golden.py
+    gen_driver_spread: the block-1 gates below are 1.5 x what two reference runs differ by, not hand-picked numbers"""
+    return np.load(os.path.join(HERE, "golden", "driver_spread.npz"))
+
+
+def _tols(spread, name):
+    t0 = max(5e-3, float(spread[f"{name}_rel_spread_block0"]))
+    t1 = 1.5 * float(spread[f"{name}_rel_spread_block1"])
+    ts = max(1e-2, 2.5 * float(spread[f"{name}_rel_spread_sum"]))
+    return t0, t1, ts
+
+
+@pytest.mark.parametrize("driver", DRIVERS)
+def test_ldlq_matches_the_reference_driver(golden, spread, driver):
+    model, rep, errors, logits = _run("ldlq_w4", driver)
+    t0, t1, ts = _tols(spread, "ldlq_w4")                    # 5e-3, 6.0e-2, 1e-2
+    _ldlq_gates(golden, "ldlq_w4", errors, logits, rep, t0, t1, ts, 0.10)
     params = dict(model.named_parameters())
     for k in [str(n) for n in golden["ldlq_w4_names"]][:6]:
         got = params[k + ".weight"].detach()[:8].cpu().view(torch.int16).numpy()
@@ -120,9 +147,11 @@ def test_ldlq_matches_the_reference_driver(golden):
     assert np.linalg.norm(logits - fp) < np.linalg.norm(near - fp)
 
 
-def test_ldlq_with_incoherence_processing_matches_the_reference_driver(golden):
-    model, rep, errors, logits = _run("ldlq_w2_incoh")
-    _ldlq_gates(golden, "ldlq_w2_incoh", errors, logits, rep, 5e-3, 15e-2, 3e-2, 0.15)
+@pytest.mark.parametrize("driver", DRIVERS)
+def test_ldlq_with_incoherence_processing_matches_the_reference_driver(golden, spread, driver):
+    model, rep, errors, logits = _run("ldlq_w2_incoh", driver)
+    t0, t1, ts = _tols(spread, "ldlq_w2_incoh")              # 1.5e-2, 16.6e-2, 2.9e-2
+    _ldlq_gates(golden, "ldlq_w2_incoh", errors, logits, rep, t0, t1, ts, 0.15)
 
 
 # ---- the Llama driver (llama.py:36-171): tests/golden/driver_llama.npz is the reference's own llama_sequential on CPU -----------
@@ -131,23 +160,27 @@ def golden_llama():
     return np.load(os.path.join(HERE, "golden", "driver_llama.npz"))
 
 
-def _run_llama(name):
+def _run_llama(name, driver=None):
     import tiny_model as TM
     import run_reference_driver as R
-    drv, is_ref = R.load_llama_driver()
+    drv, is_ref = R.load_llama_driver(restatement=(driver == "restatement"))
+    assert is_ref == (driver == "reference" or (driver is None and STAGED)), "the staged reference driver did not load"
+    RAN[f"llama:{name}:{driver}"] = "reference llama.py" if is_ref else "scripts/quantize_opt.py"
     model = TM.build_tiny_llama().to(DEV)
     np.random.seed(0)
     torch.manual_seed(0)
     rep, errors = drv(model, TM.calibration_batches(), torch.device(DEV), types.SimpleNamespace(nsamples=TM.NSAMPLES, **TM.LLAMA_CONFIGS[name]))
+    model.to(DEV)                                            # llama.py:163 parks every finished block on the CPU
     with torch.no_grad():
         logits = model(TM.probe_tokens().to(DEV)).logits.float().cpu().numpy()
     return model, rep, np.asarray([float(e) for e in errors]), logits
 
 
-def test_llama_nearest_matches_the_reference_driver_bit_for_bit(golden_llama):
+@pytest.mark.parametrize("driver", DRIVERS)
+def test_llama_nearest_matches_the_reference_driver_bit_for_bit(golden_llama, driver):
     """14 Linears (q/k/v/o, gate/up/down x 2 blocks, down_proj 688 wide) through the position_embeddings pass-through"""
     g = golden_llama
-    model, rep, errors, logits = _run_llama("nearest_w4")
+    model, rep, errors, logits = _run_llama("nearest_w4", driver)
     names = [str(n) for n in g["nearest_w4_names"]]
     assert len(names) == 14 and len(errors) == 14
     if isinstance(rep, list):
@@ -186,3 +219,35 @@ def test_llama_gptq_matches_the_reference_driver(golden_llama, name, bits):
     fp = g["fp16_logits"].astype(np.float32)
     ref = g[f"{name}_logits"].astype(np.float32)
     assert abs(np.linalg.norm(logits - fp) / np.linalg.norm(ref - fp) - 1.0) <= 0.10
+
+
+@pytest.mark.parametrize("driver", DRIVERS)
+def test_llama_ldlq_w2_with_incoherence_processing_matches_the_reference_driver(golden_llama, spread, driver):
+    """BASELINE configs[3] at driver level: llama.py's Balance branch (llama.py:107-115,147-148; run on the reference side with
+    the stray args.qbits dropped, tiny_model.balance_configure_shim) -> Balance.fasterquant -> round_ldl, w2, qfn b, rescale +
+    blocked-butterfly projection from the seeded numpy / torch streams, on all 14 Linears incl. the 688-wide down_proj.  Same
+    structure of gates as the OPT twin: block 0 sees the reference's H (same operators, same rescale, same LDLQ) -> per-Linear
+    proxy error within the reference's own block-0 noise; block 1 is downstream of block 0's near-tie flips -> 1.5 x the
+    reference-vs-reference spread; the distance of the logits to the fp16 model's within 15 % of the reference's."""
+    g = golden_llama
+    model, rep, errors, logits = _run_llama("ldlq_w2_incoh", driver)
+    assert len(errors) == 14
+    ge = g["ldlq_w2_incoh_error"]
+    rel = _relvec(errors, ge)
+    t0, t1, ts = _tols(spread, "ldlq_w2_incoh")
+    assert rel[:7].max() <= t0, rel
+    assert rel[7:].max() <= t1, rel
+    assert abs(errors.sum() - ge.sum()) / ge.sum() <= ts
+    fp = g["fp16_logits"].astype(np.float32)
+    ref = g["ldlq_w2_incoh_logits"].astype(np.float32)
+    assert abs(np.linalg.norm(logits - fp) / np.linalg.norm(ref - fp) - 1.0) <= 0.15
+    # LDLQ at 2 bits beats nearest rounding at 2 bits on the same projected problem by construction; against the w4 nearest
+    # golden it must at least stay finite and ordered: every proxy error positive, down_proj (688 wide) the largest of block 1
+    assert (errors > 0).all() and int(np.argmax(errors[7:])) == 6
+
+
+def test_zz_report_which_driver_ran():
+    """not a gate: prints which driver file executed for every run above (visible with -rA / in the gpurun log)"""
+    print("drivers executed:", RAN)
+    if STAGED:
+        assert any(v.startswith("reference") for v in RAN.values())
