@@ -215,11 +215,14 @@ def main():
     launch = launch_bf16
     BYTES_ACC = M * D * BITS // 8 + 2 * BS * D + 2 * 4 * BS * M      # y read + written as fp32
 
-    traffic = None
+    traffic, traffic_source = None, None
     pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "k2_pmc_latest.json")
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
+            pmc = json.load(f)
+        traffic = pmc.get("hbm_bytes_per_launch")
+        traffic_source = ("profiles/k2_pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command "
+                          f"(scripts/gpu_round.sh), kernel {str(pmc.get('kernel', '?'))[:60]} -- counters cannot be collected inside the timed run")
 
     us_cold = t_cold / args.steps * 1e6
     us_warm = t_warm / args.steps * 1e6
@@ -245,7 +248,7 @@ def main():
                               else "one hipGraph of K launches"), "parallelism": f"dp{world} (replicas)"},
         "parity_rel_err": rel,
         "roofline": {"bound": "hbm", "achieved": round(gbs_cold, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(gbs_cold / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "frac": round(gbs_cold / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": BYTES, "us_per_launch": round(us_cold, 3),
                      "pct_mfma_peak": round(100 * tf_cold / world / MFMA_PEAK_TF, 2)},
         "warm": {"value": round(tf_warm, 3), "unit": "TFLOP/s", "us_per_launch": round(us_warm, 3)},
@@ -469,7 +472,12 @@ def main():
         try:        # the other CPU figure: the oracle's OpenMP restatement of round_ldl (vector_balance.py:155-199) on the host cores
             from oracle import quip_oracle as OR
             import numpy as _np
-            rows_s, dl = 512, 4096
+            rows_s, dl = 4096, 4096                                  # the whole layer, once (~13 s on the GPU box's host)
+            try:
+                import ctypes as _ct
+                omp_threads = int(_ct.CDLL("libgomp.so.1").omp_get_max_threads())
+            except Exception:
+                omp_threads = os.cpu_count()
             rs = _np.random.default_rng(0)
             Xs = (rs.standard_normal((2 * dl, dl)) * _np.arange(1, dl + 1) ** -0.75).astype(_np.float32)
             Hs = Xs.T @ Xs / (2 * dl)
@@ -479,12 +487,15 @@ def main():
             t0 = time.perf_counter()
             OR.round_ldl(wg_s, Hs, 2, L=Ls)
             t_l = time.perf_counter() - t0
-            out["ldlq_cpu_port"] = {"what": f"oracle round_ldl (C, OpenMP) on {rows_s} of 4096 rows x 4096 columns, w2; full layer = x{4096 // rows_s}",
-                                    "sample_s": round(t_l, 3), "full_layer_s_extrapolated": round(t_l * 4096 / rows_s, 2),
-                                    "cores": os.cpu_count(), "kind": "port"}
+            out["ldlq_cpu_port"] = {"what": f"oracle round_ldl (C, OpenMP over rows) on the full 4096 x 4096 layer, w2, timed once",
+                                    "full_layer_s": round(t_l, 2), "cores": omp_threads,
+                                    "cores_note": f"OpenMP threads of the oracle's row loop; torch's CPU pool (cpu_baseline) uses {cores} threads; the box has {os.cpu_count()} logical CPUs",
+                                    "kind": "port"}
         except Exception as ex:
             out["ldlq_cpu_port"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
-        out["cpu_baseline"] = {"value": round(FLOPS / dt / 1e12, 4), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+        out["cpu_baseline"] = {"value": round(FLOPS / dt / 1e12, 4), "unit": "TFLOP/s", "cores": cores,
+                               "cores_note": f"torch.get_num_threads() = the threads F.linear used; {os.cpu_count()} logical CPUs on the box",
+                               "kind": "port",
                                "sample": f"{n} calls of torch CPU F.linear fp32 x[16,4096] @ What[4096,4096]^T "
                                          f"(dense fake-quant weights, what the reference runs at inference), "
                                          f"{dt * 1e3:.3f} ms/call"}

@@ -113,8 +113,12 @@ int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *qweight, int
  * vec: float [d] (one token); mat: the reference's CANONICAL packing ([d/32*3, m] 3-bit, [d/8, m] 4-bit); mul: float [m],
  * pre-filled by the caller (with the bias) and accumulated into; scales: float [m]; zeros: float [m] = zero * scale.
  * Adapters over quipamd_repack_canonical_to_stream + quipamd_dequant_gemm: the repacked weights, the split activations and
- * the integer zeros live in `workspace` (quipamd_vecquant_workspace_bytes; nothing is kept between calls). */
+ * the integer zeros live in `workspace` (quipamd_vecquant_workspace_bytes).  The O(m d) repack runs once per
+ * (workspace, mat, bits, m, d, stream): the library remembers (host side) what a workspace's STREAM words were repacked from, so
+ * a decode loop calling with the same layer and workspace pays it on the first token only.  After rewriting `mat` IN PLACE, or
+ * using the workspace for anything else, call quipamd_vecquant_invalidate(workspace) (NULL: forget every workspace). */
 int64_t quipamd_vecquant_workspace_bytes(int bits, int64_t m, int64_t d);
+void quipamd_vecquant_invalidate(const void *workspace);
 int quipamd_vecquant3matmul(const float *vec, const int32_t *mat, float *mul, const float *scales, const float *zeros,
                             int64_t m, int64_t d, void *workspace, int64_t workspace_bytes, void *stream);
 int quipamd_vecquant4matmul(const float *vec, const int32_t *mat, float *mul, const float *scales, const float *zeros,
@@ -341,9 +345,10 @@ int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *info, void *s
 /* Rotary position embedding of one decode step, in place on q [bs, heads * hd] and k [bs, kv_heads * hd] (row strides ldq, ldk)
  * at position *pos (DEVICE memory: the launch can be replayed in a hipGraph while the position advances):
  *   x[i] <- x[i] cos[pos][i] - x[i + hd/2] sin[pos][i];  x[i + hd/2] <- x[i + hd/2] cos[pos][i] + x[i] sin[pos][i]   (i < hd/2)
- * = HF's apply_rotary_pos_emb (q * cos + rotate_half(q) * sin) behind llama.py:418-471.  cos / sin: float [maxpos, hd]. */
-int quipamd_rope_inplace(void *q, void *k, const float *cos_table, const float *sin_table, const int64_t *pos, int dtype,
-                         int64_t bs, int heads, int kv_heads, int hd, int64_t ldq, int64_t ldk, void *stream);
+ * = HF's apply_rotary_pos_emb (q * cos + rotate_half(q) * sin) behind llama.py:418-471.  cos / sin: float [table_rows, hd];
+ * a position outside [0, table_rows) leaves q and k untouched (never reads past the tables). */
+int quipamd_rope_inplace(void *q, void *k, const float *cos_table, const float *sin_table, int64_t table_rows, const int64_t *pos,
+                         int dtype, int64_t bs, int heads, int kv_heads, int hd, int64_t ldq, int64_t ldk, void *stream);
 
 /* ---- single-token decode attention (the decode loop of benchmark(), opt.py:431-482) -------------
  * Replaces the eager HF attention chain of one decode step (cache append, q K^T, scale + causal mask, softmax, p V --

@@ -24,6 +24,7 @@ SIGNATURES = {
     "quipamd_unpack": [c_vp, c_int, c_int, c_vp, c_i64, c_i64, c_vp],
     "quipamd_repack_canonical_to_stream": [c_vp, c_int, c_vp, c_i64, c_i64, c_vp],
     "quipamd_vecquant_workspace_bytes": [c_int, c_i64, c_i64],
+    "quipamd_vecquant_invalidate": [c_vp],
     "quipamd_vecquant3matmul": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
     "quipamd_vecquant4matmul": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
     "quipamd_qfnb_scale": [c_vp, c_int, c_i64, c_vp, c_vp, c_vp],
@@ -56,7 +57,7 @@ SIGNATURES = {
     "quipamd_unit_upper_inverse": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "quipamd_gptq_round_groups": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp],
     "quipamd_decode_attention": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_i64, c_float, c_i64, c_vp],
-    "quipamd_rope_inplace": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_i64, c_i64, c_vp],
+    "quipamd_rope_inplace": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_int, c_i64, c_i64, c_vp],
     "quipamd_cholesky_lt": [c_vp, c_vp, c_i64, c_vp, c_vp],
     "quipamd_hessian_accum": [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp],
     "quipamd_hessian_finish": [c_vp, c_double, c_vp, c_i64, c_vp],
@@ -86,7 +87,7 @@ def load():
         except AttributeError as e:
             raise QuipAmdError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else
+        fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else None if name == "quipamd_vecquant_invalidate" else
                       c_i64 if name in ("quipamd_hessian_fast_workspace", "quipamd_vecquant_workspace_bytes") else c_int)
     _lib = lib
     return lib

@@ -178,8 +178,8 @@ int launch_attn(const void *q, const void *k, const void *v, void *kc, void *vc,
 // (the tables hold HF's duplicated-halves layout [maxpos, hd]; fp32 arithmetic, one rounding to the activation dtype).
 template <class TI>
 __global__ __launch_bounds__(256) void rope_kernel(typename DT<TI>::storage *q, typename DT<TI>::storage *k, const float *cos_t,
-                                                   const float *sin_t, const int64_t *pos_p, int64_t total, int heads, int kv_heads, int hd,
-                                                   int64_t ldq, int64_t ldk)
+                                                   const float *sin_t, const int64_t *pos_p, int64_t table_rows, int64_t total, int heads,
+                                                   int kv_heads, int hd, int64_t ldq, int64_t ldk)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (b, head of q then of k, i < hd/2)
     if (idx >= total) return;
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256) void rope_kernel(typename DT<TI>::storage *q, 
     const int hh = (int)(t % (heads + kv_heads));
     const int64_t b = t / (heads + kv_heads);
     const int64_t pos = *pos_p;
+    if (pos < 0 || pos >= table_rows) return;                             // past the tables: q / k stay as they are (like decode_attention past maxlen)
     const float c = cos_t[pos * hd + i], s = sin_t[pos * hd + i];
     typename DT<TI>::storage *x = hh < heads ? q + b * ldq + (int64_t)hh * hd : k + b * ldk + (int64_t)(hh - heads) * hd;
     const float a = DT<TI>::load(x, i), bb = DT<TI>::load(x, i + half);
@@ -195,10 +196,10 @@ __global__ __launch_bounds__(256) void rope_kernel(typename DT<TI>::storage *q, 
     DT<TI>::store(x, i + half, bb * c + a * s);
 }
 
-extern "C" int quipamd_rope_inplace(void *q, void *k, const float *cos_table, const float *sin_table, const int64_t *pos, int dtype,
-                                    int64_t bs, int heads, int kv_heads, int hd, int64_t ldq, int64_t ldk, void *stream)
+extern "C" int quipamd_rope_inplace(void *q, void *k, const float *cos_table, const float *sin_table, int64_t table_rows, const int64_t *pos,
+                                    int dtype, int64_t bs, int heads, int kv_heads, int hd, int64_t ldq, int64_t ldk, void *stream)
 {
-    QA_REQUIRE(bs >= 0 && heads > 0 && kv_heads > 0 && hd > 0 && hd % 2 == 0, QUIPAMD_ERR_SHAPE, "rope_inplace: bad shape");
+    QA_REQUIRE(bs >= 0 && heads > 0 && kv_heads > 0 && hd > 0 && hd % 2 == 0 && table_rows > 0, QUIPAMD_ERR_SHAPE, "rope_inplace: bad shape");
     if (bs == 0) return QUIPAMD_OK;
     QA_REQUIRE(q && k && cos_table && sin_table && pos, QUIPAMD_ERR_ARG, "rope_inplace: null pointer");
     QA_REQUIRE(dtype == QUIPAMD_F16 || dtype == QUIPAMD_BF16, QUIPAMD_ERR_UNSUPPORTED, "rope_inplace: f16 / bf16 only");
@@ -206,9 +207,9 @@ extern "C" int quipamd_rope_inplace(void *q, void *k, const float *cos_table, co
     const unsigned grid = (unsigned)((total + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == QUIPAMD_F16)
-        rope_kernel<F16><<<grid, 256, 0, s>>>((uint16_t *)q, (uint16_t *)k, cos_table, sin_table, pos, total, heads, kv_heads, hd, ldq, ldk);
+        rope_kernel<F16><<<grid, 256, 0, s>>>((uint16_t *)q, (uint16_t *)k, cos_table, sin_table, pos, table_rows, total, heads, kv_heads, hd, ldq, ldk);
     else
-        rope_kernel<BF16><<<grid, 256, 0, s>>>((uint16_t *)q, (uint16_t *)k, cos_table, sin_table, pos, total, heads, kv_heads, hd, ldq, ldk);
+        rope_kernel<BF16><<<grid, 256, 0, s>>>((uint16_t *)q, (uint16_t *)k, cos_table, sin_table, pos, table_rows, total, heads, kv_heads, hd, ldq, ldk);
     QA_LAUNCH_CHECK("quipamd_rope_inplace");
     return QUIPAMD_OK;
 }

@@ -81,18 +81,42 @@ def repack_canonical_to_stream(qweight, bits, m, d):
     return out
 
 
+_VQ_WORKSPACES = {}      # mat.data_ptr() -> (weakref to mat, mat._version, bits, workspace): the library repacks once per workspace
+
+
 def vecquantmatmul(bits, vec, mat, mul, scales, zeros):
     """quant_cuda.vecquant{3,4}matmul(vec, mat, mul, scales, zeros) (quant.py:229, zeroShot/models/quant.py:207): accumulates
-    into `mul` (float32 [m], pre-filled with the bias) and returns None like the reference's extension."""
+    into `mul` (float32 [m], pre-filled with the bias) and returns None like the reference's extension.  Every `mat` keeps its
+    own workspace alive for as long as the tensor lives, so the CANONICAL -> STREAM repack inside the library runs on the first
+    call only (a decode loop calls this once per token per layer); an in-place change of `mat` (torch's version counter) or a
+    new tensor at the same address invalidates it."""
+    import weakref
     _need_gpu(vec, mat, mul)
     assert bits in (3, 4) and mul.dtype == torch.float32 and mul.is_contiguous() and mat.dtype == torch.int32
     d, m = vec.numel(), mul.numel()
     vec = vec.reshape(-1).to(torch.float32).contiguous()
     sc, zs = _f32vec(scales, mul.device), _f32vec(zeros, mul.device)
     assert sc.numel() == m and zs.numel() == m and mat.numel() == m * d * bits // 32
-    nbytes = _lib.load().quipamd_vecquant_workspace_bytes(bits, m, d)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=mul.device)
-    _lib.call(f"quipamd_vecquant{bits}matmul", _p(vec), _p(mat.contiguous()), _p(mul), _p(sc), _p(zs), m, d, _p(ws), nbytes, _stream())
+    lib = _lib.load()
+    nbytes = lib.quipamd_vecquant_workspace_bytes(bits, m, d)
+    matc = mat if mat.is_contiguous() else mat.contiguous()
+    ws = None
+    if matc is mat:
+        ent = _VQ_WORKSPACES.get(mat.data_ptr())
+        if ent is not None and ent[0]() is mat and ent[1] == mat._version and ent[2] == bits and ent[3].numel() == nbytes:
+            ws = ent[3]
+        else:
+            if ent is not None:
+                lib.quipamd_vecquant_invalidate(_p(ent[3]))
+            for k in [k for k, e in _VQ_WORKSPACES.items() if e[0]() is None]:        # layers that are gone
+                lib.quipamd_vecquant_invalidate(_p(_VQ_WORKSPACES.pop(k)[3]))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=mul.device)
+            lib.quipamd_vecquant_invalidate(_p(ws))                # the allocator may hand back an address the library remembers
+            _VQ_WORKSPACES[mat.data_ptr()] = (weakref.ref(mat), mat._version, bits, ws)
+    else:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=mul.device)
+        lib.quipamd_vecquant_invalidate(_p(ws))
+    _lib.call(f"quipamd_vecquant{bits}matmul", _p(vec), _p(matc), _p(mul), _p(sc), _p(zs), m, d, _p(ws), nbytes, _stream())
 
 
 # ------------------------------------------------------------------------------------------------- K5
@@ -671,8 +695,8 @@ def rope_inplace(q, k, cos_table, sin_table, pos, heads, kv_heads=None):
     hd = q.shape[1] // heads
     assert q.dtype == k.dtype and q.stride(1) == 1 and k.stride(1) == 1 and k.shape[1] == kv_heads * hd
     assert cos_table.dtype == torch.float32 and sin_table.dtype == torch.float32 and cos_table.shape[1] == hd and cos_table.is_contiguous()
-    assert pos.dtype == torch.int64 and pos.numel() == 1
-    _lib.call("quipamd_rope_inplace", _p(q), _p(k), _p(cos_table), _p(sin_table), _p(pos), _dtype(q), bs, heads, kv_heads, hd,
+    assert pos.dtype == torch.int64 and pos.numel() == 1 and sin_table.shape == cos_table.shape and sin_table.is_contiguous()
+    _lib.call("quipamd_rope_inplace", _p(q), _p(k), _p(cos_table), _p(sin_table), cos_table.shape[0], _p(pos), _dtype(q), bs, heads, kv_heads, hd,
               q.stride(0), k.stride(0), _stream())
 
 

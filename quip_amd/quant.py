@@ -266,13 +266,47 @@ class Quant3Linear(QuantLinear):
         The codes are repacked on the device (quipamd_repack_canonical_to_stream), no host pass."""
         qw = state_dict.get(prefix + 'qweight')
         if qw is not None and qw.dim() == 2:
-            conv = reference_packed_buffers(qw, state_dict[prefix + 'scales'], state_dict[prefix + 'zeros'], 3,
-                                            self.infeatures, self.outfeatures, self.qweight.device)
+            sc, zr, b = state_dict[prefix + 'scales'], state_dict[prefix + 'zeros'], state_dict.get(prefix + 'bias')
+            if tuple(qw.shape) != (self.infeatures * 3 // 32, self.outfeatures) or sc.numel() != self.outfeatures \
+                    or zr.numel() != self.outfeatures or (b is not None and b.numel() != self.outfeatures):
+                raise RuntimeError(f"{prefix}: not a reference Quant3Linear record for a {self.infeatures} -> {self.outfeatures} layer")
+            if self.qweight.device.type != 'cuda':
+                # the reference's flow (opt.py load_quant3): make_quant3 on the CPU, load_state_dict, THEN .to(dev).  The device
+                # repack has no CPU twin, so the canonical words wait on the module and are repacked by the first _apply that
+                # lands on a GPU; the state dict handed on to nn.Module holds nothing for this layer's buffers.
+                self._reference_pending = tuple(None if t is None else t.detach().clone() for t in (qw, sc, zr, b))
+                for k in ('qweight', 'scales', 'zeros', 'bias'):
+                    state_dict.pop(prefix + k, None)
+                missing = args[2] if len(args) > 2 else kwargs.get('missing_keys')
+                super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+                if missing is not None:                      # they are not missing, they are pending
+                    for k in ('qweight', 'scales', 'zeros', 'bias'):
+                        if prefix + k in missing:
+                            missing.remove(prefix + k)
+                return
+            conv = reference_packed_buffers(qw, sc, zr, 3, self.infeatures, self.outfeatures, self.qweight.device)
             state_dict[prefix + 'qweight'], state_dict[prefix + 'scales'], state_dict[prefix + 'zeros'] = conv
-            if state_dict.get(prefix + 'bias') is not None:
+            if b is not None:                                # only after every shape check above has passed
                 self.bias = torch.zeros(self.outfeatures, device=self.qweight.device)
-                state_dict[prefix + 'bias'] = state_dict[prefix + 'bias'].reshape(-1).float()
+                state_dict[prefix + 'bias'] = b.reshape(-1).float()
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        pend = getattr(self, '_reference_pending', None)
+        if pend is not None and self.qweight.device.type == 'cuda':
+            qw, sc, zr, b = pend
+            dev = self.qweight.device
+            self.qweight, self.scales, self.zeros = reference_packed_buffers(qw, sc, zr, 3, self.infeatures, self.outfeatures, dev)
+            self.bias = None if b is None else b.to(dev, torch.float32).reshape(-1).clone()
+            self._reference_pending = None
+        return self
+
+    def forward(self, x):
+        if getattr(self, '_reference_pending', None) is not None:
+            raise RuntimeError("Quant3Linear holds a reference-format checkpoint that is repacked on the GPU: move the module "
+                               "to the device first (there is no CPU fallback)")
+        return super().forward(x)
 
     @torch.no_grad()
     def pack(self, linear, scales, zeros, **kw):
@@ -339,7 +373,13 @@ def _ln_params(ln):
         eps = getattr(ln, 'variance_epsilon', None)
     if eps is None:
         eps = torch.finfo(ln.weight.dtype).eps              # torch.nn.RMSNorm(eps=None)
-    return (ln.weight, getattr(ln, 'bias', None), eps)
+    beta = getattr(ln, 'bias', None)
+    if beta is None and isinstance(ln, nn.LayerNorm):       # LayerNorm(bias=False) still subtracts the mean: a zero beta, not RMSNorm
+        beta = getattr(ln, '_quip_zero_beta', None)
+        if beta is None or beta.device != ln.weight.device or beta.dtype != ln.weight.dtype:
+            beta = torch.zeros_like(ln.weight)
+            ln._quip_zero_beta = beta
+    return (ln.weight, beta, eps)
 
 
 def _fusable(ql, rows):
@@ -389,16 +429,29 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False, gate_up=Non
     x = x.contiguous()
     # launch 1
     fast = lambda o, norm: o.small_ok or (o.bigp_ok and norm is None and rows <= ops.TILE_ROWS)
+
+    def launchable(entries):
+        """a p x 16-only operator exists for the compiled operand sets of csrc/ortho_bigp.hip alone (ops._tile_form): any other
+        combination of dtypes / operands (a bf16 model, an fp32 residual ...) takes the general K3 launches for that side"""
+        return all(o.small_ok or ops._tile_form(d_) is not None for o, d_, _ in entries)
+    v_entries = None
     if all(fast(q.V, ln) for q in qls):
         xts = [torch.empty((rows, d), dtype=torch.bfloat16, device=dev) for _ in qls]
         lnp = _ln_params(ln)
+        # a layer packed with preproc_proj but no rescale has no column scale: the kernels read ones
+        cs = [q.inv_scaleWH if q.inv_scaleWH is not None else q.V.one_scale() for q in qls]
         if gate_up is not None:                                 # silu(x) * up on load (csrc/ortho_bigp.hip)
             gate_up = gate_up.contiguous()
-            ops.ortho_apply_ops([(q.V, q.V.small_op(x, xt, colscale=q.inv_scaleWH, residual=gate_up, relu=True), False)
-                                 for q, xt in zip(qls, xts)], rows)
+            v_entries = [(q.V, q.V.small_op(x, xt, colscale=c, residual=gate_up, relu=True), False) for q, xt, c in zip(qls, xts, cs)]
         else:
-            ops.ortho_apply_ops([(q.V, q.V.small_op(x, xt, colscale=q.inv_scaleWH, ln=lnp), False) for q, xt in zip(qls, xts)], rows)
+            v_entries = [(q.V, q.V.small_op(x, xt, colscale=c, ln=lnp), False) for q, xt, c in zip(qls, xts, cs)]
+        if not launchable(v_entries):
+            v_entries = None
+    if v_entries is not None:
+        ops.ortho_apply_ops(v_entries, rows)
     else:
+        if gate_up is not None:
+            x, gate_up = torch.nn.functional.silu(x) * gate_up, None
         h = _norm(ln, x)
         xts = [q.V.apply_rows(h, colscale=q.inv_scaleWH, out_dtype=torch.bfloat16) for q in qls]
     # launch 2
@@ -408,9 +461,11 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False, gate_up=Non
     res = None if residual is None else residual.contiguous()
     if all(fast(q.U, None) for q in qls):
         outs = [torch.empty((rows, m), dtype=x.dtype, device=dev) for _ in qls]
-        ops.ortho_apply_ops([(q.U, q.U.small_op(y, o, transpose=True, bias=q.bias if q.bias is not None else q.U.zero_bias(), residual=res, relu=relu), True)
-                             for q, y, o in zip(qls, ys, outs)], rows)
-        return outs
+        u_entries = [(q.U, q.U.small_op(y, o, transpose=True, bias=q.bias if q.bias is not None else q.U.zero_bias(), residual=res, relu=relu), True)
+                     for q, y, o in zip(qls, ys, outs)]
+        if launchable(u_entries):
+            ops.ortho_apply_ops(u_entries, rows)
+            return outs
     outs = [q.U.apply_rows(y, transpose=True, out_dtype=x.dtype, bias=q.bias) for q, y in zip(qls, ys)]
     if res is not None:
         outs = [o + res for o in outs]

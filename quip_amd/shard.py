@@ -131,6 +131,8 @@ def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=Non
             work.wait()
         assert LT.shape == (d, d)
     else:
+        if lt_ready is not None and lt_ready[1] is not None:          # the owner dropped its queue (desync): drain, forget
+            lt_ready[1].wait()
         if rank == src:
             LT = LT.to(dev, torch.float32).contiguous()
         else:
@@ -194,33 +196,50 @@ class ShardedLDLQ:
 
     def __init__(self, group=None, src=0, compute=None, force_exchange=False):
         self.group, self.src, self.compute, self.force_exchange = group, src, compute, force_exchange
-        self._lt_ready = None      # (LT, work): the coming job's LT, already broadcast under the previous job's rounding
-        self._queue = []           # LT factors of the coming round() calls, in call order (queue_LTs)
+        self._lt_ready = None      # (key, (LT, work)): the coming job's LT, already broadcast under the previous job's rounding
+        self._queue = []           # [(key, LT)] of the coming round() calls, in call order (queue_LTs)
+        self.desyncs = 0           # how often a round() call did not match the head of the queue (the queue is dropped then)
 
     def _announce(self, op):
         dev = _comm_device(self.group)
         dist.broadcast(torch.tensor([op], dtype=torch.int64, device=dev), src=self.src, group=self.group)
 
-    def queue_LTs(self, LTs):
+    def queue_LTs(self, items):
         """The driver knows the LT factors of the next Linears it will round (all Hessians of a transformer block exist
-        before its first Linear is rounded, opt.py:141-150): queue them in call order.  round() then takes its LT from the
-        queue and broadcasts the FOLLOWING one while every rank rounds the current one."""
-        self._queue = list(LTs)
+        before its first Linear is rounded, opt.py:141-150): queue them in call order as (H, LT) pairs -- H the very tensor
+        the rounding will be called with (QuantMethod.H after preproc), LT = its transposed unit LDL factor.  round() takes
+        its LT from the queue only when the H it is asked to round IS the queued one (h_key) and broadcasts the FOLLOWING
+        entry's LT while every rank rounds the current one.  A call that does not match the head of the queue
+        (ldlqRG's permuted copy of H, a Linear that took the greedy-pass path, a skipped layer) drops the queue and the
+        prefetched LT and factors / broadcasts its own H: slower, never wrong."""
+        assert not self._queue and self._lt_ready is None, "queue_LTs: the previous block's queue was not consumed"
+        self._queue = [(h_key(H), LT) for H, LT in items]
 
-    def queued(self):
-        return bool(self._queue)
+    def queued(self, key=None):
+        """is the next round() call served from the queue?  key = h_key(H) of the H about to be rounded"""
+        return bool(self._queue) and (key is None or self._queue[0][0] == key)
 
-    def round(self, wgrid, LT, bits, eta=None):
+    def round(self, wgrid, LT, bits, eta=None, key=None):
         if dist.get_world_size(self.group) > 1:
             self._announce(_OP_LDLQ)
-        if self._queue:
-            LT = self._queue.pop(0)
-        nxt = self._queue[0] if self._queue else None
-        ready, self._lt_ready = self._lt_ready, None
+        ready = None
+        if self._queue and self._queue[0][0] == key and key is not None:
+            _, LT = self._queue.pop(0)
+            if self._lt_ready is not None and self._lt_ready[0] == key:
+                ready = self._lt_ready[1]
+        elif self._queue or self._lt_ready is not None:              # not what the queue describes: never round with its factor
+            self.desyncs += 1
+            self._queue = []
+        stale, self._lt_ready = (self._lt_ready if ready is None else None), None
+        if stale is not None and stale[1][1] is not None:
+            stale[1][1].wait()                                        # a prefetch nobody will use: let it land, then forget it
+        assert LT is not None, "round(): no LT given and none queued for this H"
+        nxt_key, nxt = self._queue[0] if self._queue else (None, None)
         out = ldlq_round_sharded(wgrid, LT, bits, eta=eta, src=self.src, group=self.group, compute=self.compute,
                                  force_exchange=self.force_exchange, lt_ready=ready, next_LT=nxt)
         if nxt is not None:
-            out, self._lt_ready = out
+            out, pre = out
+            self._lt_ready = (nxt_key, pre) if pre is not None else None
         return out
 
     def shutdown(self):
@@ -282,6 +301,11 @@ def all_reduce_hessians(methods, group=None):
         m.nsamples = int(round(n))
         if t:                         # a rank that saw no sample still has to mirror the triangle in post_batch
             m._tri = True
+
+
+def h_key(H):
+    """identity of the Hessian a queued LT was factored from: the tensor's storage address and shape"""
+    return (int(H.data_ptr()), tuple(H.shape))
 
 
 _active = None

@@ -62,8 +62,9 @@ def _round_ldl_codes(w, H, nbits, n_greedy_passes, unbiased):
     eta = torch.rand(w.shape).to(w.device) if unbiased else None     # same CPU draw as vector_balance.py:174-175
     sharded = shard.active()
     if sharded is not None:                                           # rows split over the ranks of the node (shard.py)
-        LT = None if sharded.queued() else _ldl_transposed(H)         # queued: the driver factored this block's H up front
-        return sharded.round(w, LT, nbits, eta=eta)
+        key = shard.h_key(H)                                          # a queued LT is used only for the H it was factored from
+        LT = None if sharded.queued(key) else _ldl_transposed(H)
+        return sharded.round(w, LT, nbits, eta=eta, key=key)
     return ops.ldlq_round(w, _ldl_transposed(H), nbits, eta=eta)
 
 

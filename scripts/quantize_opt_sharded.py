@@ -117,7 +117,7 @@ def main(argv=None):
                 for m in methods.values():                         # everything that couples rows: owner only
                     m.post_batch()
                     m.preproc(preproc_gptqH=True, percdamp=0.01, preproc_rescale=args.incoh, preproc_proj=args.incoh, preproc_proj_extra=0)
-                handle.queue_LTs([vector_balance._ldl_transposed(m.H) for m in methods.values()])
+                handle.queue_LTs([(m.H, vector_balance._ldl_transposed(m.H)) for m in methods.values()])
                 for name, m in methods.items():
                     m.fasterquant(lazy_batch=False)
                     for k in totals:

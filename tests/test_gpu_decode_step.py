@@ -56,6 +56,11 @@ def test_rope_inplace_matches_hf_formula():
     rq, rk = ref(q, heads), ref(k, kvh)
     ops.rope_inplace(q, k, cos, sin, pos, heads, kvh)
     assert float((q.float() - rq).abs().max()) <= 2e-3 and float((k.float() - rk).abs().max()) <= 2e-3
+    # a position past the tables never reads them: q / k come back untouched
+    q0, k0 = q.clone(), k.clone()
+    for bad in (maxpos, maxpos + 1000, -1):
+        ops.rope_inplace(q, k, cos, sin, torch.tensor([bad], device="cuda"), heads, kvh)
+        assert torch.equal(q, q0) and torch.equal(k, k0)
 
 
 @pytest.mark.parametrize("n", [2048, 4096])

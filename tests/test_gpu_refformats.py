@@ -65,6 +65,17 @@ def test_vecquant_matmul_by_the_references_signature(ops, O, bits, m, d):
     ops.vecquantmatmul(bits, torch.from_numpy(vec).to(DEV), mat, mul, torch.from_numpy(scales).to(DEV), torch.from_numpy(zeros).to(DEV))
     got = mul.cpu().numpy().astype(np.float64)
     assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-4     # x kept to 2^-16 (hi + lo bf16 terms), fp32 accumulate
+    # second token, same layer: the repack inside the library is skipped (workspace remembered per `mat`), same answer bit for bit
+    mul2 = torch.from_numpy(bias.copy()).to(DEV)
+    ops.vecquantmatmul(bits, torch.from_numpy(vec).to(DEV), mat, mul2, torch.from_numpy(scales).to(DEV), torch.from_numpy(zeros).to(DEV))
+    assert torch.equal(mul2, mul)
+    # the layer is re-quantised IN PLACE: the remembered repack must not be used
+    codes2 = (maxq - codes).astype(np.uint8)
+    mat.copy_(ops.pack(torch.from_numpy(codes2).to(DEV), bits, ops.LAYOUT_CANONICAL))
+    mul3 = torch.from_numpy(bias.copy()).to(DEV)
+    ops.vecquantmatmul(bits, torch.from_numpy(vec).to(DEV), mat, mul3, torch.from_numpy(scales).to(DEV), torch.from_numpy(zeros).to(DEV))
+    want3 = bias.astype(np.float64) + (scales.astype(np.float64) * codes2 - zeros.astype(np.float64)) @ vec.astype(np.float64)
+    assert np.linalg.norm(mul3.cpu().numpy() - want3) / np.linalg.norm(want3) <= 1e-4
 
 
 def test_reference_quant3linear_checkpoint_loads(ops, O):
@@ -89,6 +100,26 @@ def test_reference_quant3linear_checkpoint_loads(ops, O):
     got = holder[0](x).double().cpu().numpy()
     want = x.double().cpu().numpy() @ Wq.astype(np.float64).T + bias
     assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 2e-3
+    # the reference's own order (opt.py:350-381 load_quant3): make_quant3 and load_state_dict on the CPU, THEN .to(dev) -- the
+    # canonical words wait on the module and are repacked by the move; forward before the move raises (no CPU fallback)
+    cpu_holder = torch.nn.Sequential(torch.nn.Linear(d, m))
+    Q.make_quant3(cpu_holder, ["0"])
+    res = cpu_holder.load_state_dict({k: v.clone() for k, v in ref_state.items()})
+    assert not res.missing_keys and not res.unexpected_keys
+    with pytest.raises(RuntimeError):
+        cpu_holder[0](x.cpu())
+    cpu_holder = cpu_holder.to(DEV)
+    assert torch.equal(cpu_holder[0].qweight, holder[0].qweight) and torch.equal(cpu_holder[0].zeros, holder[0].zeros)
+    assert torch.equal(cpu_holder[0](x), holder[0](x))
+    # a record of the wrong shape is refused BEFORE the module is touched
+    bad = {k: v.clone() for k, v in ref_state.items()}
+    bad["0.scales"] = bad["0.scales"][:-1]
+    fresh = torch.nn.Sequential(torch.nn.Linear(d, m)).to(DEV)
+    Q.make_quant3(fresh, ["0"])
+    fresh = fresh.to(DEV)
+    with pytest.raises(RuntimeError):
+        fresh.load_state_dict(bad)
+    assert fresh[0].bias is None
     # and the 4-bit format of zeroShot/models/quant.py
     sc4, z4 = O.find_params_qfna(W, 4)
     c4 = np.clip(np.round(W / sc4) + z4, 0, 15).astype(np.uint8)

@@ -56,10 +56,11 @@ def test_rccl_exchange_with_hip_pack_unpack(nccl_group, m, d, bits):
     assert st["world"] == 1 and st["bytes_broadcast_LT"] == 4 * d * d and st["bytes_gather"] == 0 and st["bytes_scatter"] == 0
     # the queued form: LT of job 2 is broadcast under the rounding of job 1
     W2, LT2 = _fixture(m, d, seed=m + 1)
-    h.queue_LTs([LT, LT2])
-    a = h.round(W, None, bits)
+    Ha, Hb = torch.zeros(2, 2), torch.zeros(2, 2)                       # the queue is keyed by the identity of the H tensor
+    h.queue_LTs([(Ha, LT), (Hb, LT2)])
+    a = h.round(W, None, bits, key=shard.h_key(Ha))
     assert shard.last_stats["bytes_broadcast_next_LT"] == 4 * d * d
-    b = h.round(W2, None, bits)
+    b = h.round(W2, None, bits, key=shard.h_key(Hb))
     assert shard.last_stats["bytes_broadcast_LT"] == 0
     assert torch.equal(a, want) and torch.equal(b, ops.ldlq_round(W2, LT2, bits))
     # unpacked gather (the branch RCCL takes when the shape does not pack) gives the same codes

@@ -52,19 +52,33 @@ def _worker(rank, world, port, m, d, bits, use_eta, mode, out_path):
             W2, LT2, _ = _fixture(m, d // 2, seed=6)
             if rank == 0:
                 h = shard.ShardedLDLQ(compute=_oracle_compute)
-                h.queue_LTs([LT, LT2, LT])
-                got = h.round(W, None, bits, eta=eta)
+                H1, H2, H3, Hx = (torch.zeros(2, 2) for _ in range(4))       # stand-ins: the queue is keyed by the H tensor's identity
+                k1, k2, k3, kx = (shard.h_key(t) for t in (H1, H2, H3, Hx))
+                h.queue_LTs([(H1, LT), (H2, LT2), (H3, LT)])
+                assert h.queued(k1) and not h.queued(k2)
+                got = h.round(W, None, bits, eta=eta, key=k1)
                 assert shard.last_stats["bytes_broadcast_LT"] == 4 * d * d and shard.last_stats["bytes_broadcast_next_LT"] == d * d
-                got2 = h.round(W2, None, bits)
+                got2 = h.round(W2, None, bits, key=k2)
                 assert shard.last_stats["bytes_broadcast_LT"] == 0     # came with the previous job
-                got3 = h.round(W[: m // 2], None, bits)
+                got3 = h.round(W[: m // 2], None, bits, key=k3)
                 assert not h.queued() and "bytes_broadcast_next_LT" not in shard.last_stats
                 got4 = h.round(W2, LT2, bits)                          # and a plain job after the queue has drained
-                h.shutdown()
                 assert torch.equal(got2, _oracle_compute(W2, LT2, bits, None)) and torch.equal(got4, got2)
                 assert torch.equal(got3, _oracle_compute(W[: m // 2], LT, bits, None))
+                # desync: the queue says H1 -> LT, H2 -> LT2, but the caller rounds a Hessian the queue does not know
+                # (ldlqRG's permuted copy, a skipped Linear).  The queued factor and the LT2 already prefetched under job 5 must
+                # NOT be used: job 6 runs with the LT it was handed, the queue is dropped, job 7 is a plain job again.
+                h.queue_LTs([(H1, LT), (H2, LT2)])
+                got5 = h.round(W, None, bits, key=k1)
+                assert shard.last_stats["bytes_broadcast_next_LT"] == d * d
+                got6 = h.round(W, LT, bits, key=kx)                    # same shape as the queued job's, a different H
+                assert h.desyncs == 1 and not h.queued() and shard.last_stats["bytes_broadcast_LT"] == 4 * d * d
+                got7 = h.round(W2, LT2, bits, key=k2)
+                assert shard.last_stats["bytes_broadcast_LT"] == d * d
+                assert torch.equal(got5, _oracle_compute(W, LT, bits, None)) and torch.equal(got6, got5) and torch.equal(got7, got2)
+                h.shutdown()
             else:
-                assert shard.serve(compute=_oracle_compute) == 4
+                assert shard.serve(compute=_oracle_compute) == 7
                 got = None
         elif mode == "collective":
             got = shard.ldlq_round_sharded(W if rank == 0 else None, LT if rank == 0 else None, bits,
