@@ -499,13 +499,48 @@ def gen_driver_spread():
             arrs[f"{cname}_rel_spread_block1"] = np.asarray(rel[:, 6:].max())
             arrs[f"{cname}_rel_spread_sum"] = np.asarray((np.abs(e[1:].sum(1) - e[0].sum()) / e[0].sum()).max())
             print(cname, "block0", rel[:, :6].max(), "block1", rel[:, 6:].max(), "sum", arrs[f"{cname}_rel_spread_sum"])
+        # the Llama twin (llama.py:36-171, Balance branch with the qbits shim): 14 Linears, block 0 = the first 7
+        import llama as ref_llama
+        from transformers.models.llama import modeling_llama as ML
+        orig_fwd, rot, sync = ML.LlamaDecoderLayer.forward, {}, torch.cuda.synchronize
+
+        def fwd(self, hidden_states, *a, position_embeddings=None, position_ids=None, **kw):
+            if position_embeddings is None:
+                position_embeddings = rot["m"](hidden_states, position_ids=position_ids)
+            return orig_fwd(self, hidden_states, *a, position_embeddings=position_embeddings, position_ids=position_ids, **kw)
+        ML.LlamaDecoderLayer.forward = fwd
+        torch.cuda.synchronize = lambda *a, **k: None
+        try:
+            with TM.balance_configure_shim(ref_bal.Balance):
+                rows = []
+                for threads, onednn in variants:
+                    torch.set_num_threads(threads)
+                    torch.backends.mkldnn.enabled = onednn
+                    model = TM.build_tiny_llama()
+                    rot["m"] = model.model.rotary_emb
+                    ref_llama.args = types.SimpleNamespace(nsamples=TM.NSAMPLES, **TM.LLAMA_CONFIGS["ldlq_w2_incoh"])
+                    del rec[:]
+                    np.random.seed(0)
+                    torch.manual_seed(0)
+                    ref_llama.llama_sequential(model, TM.calibration_batches(), torch.device("cpu"))
+                    rows.append(np.asarray(rec, np.float64))
+            e = np.stack(rows)
+            rel = np.abs(e[1:] - e[0]) / e[0]
+            arrs["llama_ldlq_w2_incoh_errors"] = e
+            arrs["llama_ldlq_w2_incoh_rel_spread_block0"] = np.asarray(rel[:, :7].max())
+            arrs["llama_ldlq_w2_incoh_rel_spread_block1"] = np.asarray(rel[:, 7:].max())
+            arrs["llama_ldlq_w2_incoh_rel_spread_sum"] = np.asarray((np.abs(e[1:].sum(1) - e[0].sum()) / e[0].sum()).max())
+            print("llama ldlq_w2_incoh block0", rel[:, :7].max(), "block1", rel[:, 7:].max(), "sum", arrs["llama_ldlq_w2_incoh_rel_spread_sum"])
+        finally:
+            ML.LlamaDecoderLayer.forward = orig_fwd
+            torch.cuda.synchronize = sync
     finally:
         ref_method.QuantMethod.free = orig_free
         torch.set_num_threads(1)
         torch.backends.mkldnn.enabled = True
-    save("driver_spread", "opt.py:29-190 opt_sequential (reference, CPU) re-run under (threads, oneDNN) variants "
-         "[(1,on) = driver.npz, (2,on), (8,on), (1,off), (8,off)]: per-Linear proxy errors [variant, 12] and the largest relative "
-         "deviation from variant 0 per block -- the reference's own run-to-run noise under fp re-ordering", **arrs)
+    save("driver_spread", "opt.py:29-190 opt_sequential and llama.py:36-171 llama_sequential (reference, CPU) re-run under (threads, oneDNN) "
+         "variants [(1,on) = driver.npz / driver_llama.npz, (2,on), (8,on), (1,off), (8,off)]: per-Linear proxy errors [variant, 12 | 14] and "
+         "the largest relative deviation from variant 0 per block -- the reference's own run-to-run noise under fp re-ordering", **arrs)
 
 
 # ---------------------------------------------------------------- H2. the reference LLAMA driver
