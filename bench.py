@@ -415,15 +415,15 @@ def main():
             dres = None
             out["decode"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if rank == 0 and world == 1 and not args.no_decode and dres is not None:
-        cands = [k for k in ("packed_w2_vfused_split_handover", "packed_w2_vfused", "packed_w2_tiled", "packed_w2_chained") if k in dres]
+        cands = [k for k in ("packed_w2_v3", "packed_w2_vfused_split_handover", "packed_w2_vfused", "packed_w2_tiled", "packed_w2_chained") if k in dres]
         best = max(cands, key=lambda k: dres[k]["tok_per_s"])
         out["decode"] = {"metric": "OPT-1.3B w2 (incoherence-processed, packed) decode tok/s, batch 1, one hipGraph per token",
                          "value": round(dres[best]["tok_per_s"], 1), "unit": "tok/s",
                          "ms_per_token": round(dres[best]["ms_per_token_median"], 3),
                          "variant": best,
-                         "what": "packed K2/K3 launches with LayerNorm / bias / residual / ReLU folded in, the V-side operator in the "
-                                 "dequant-GEMM prologue for d = 2048, output-side operators tiled over 8-32 workgroups, single-launch "
-                                 "decode attention: 9-10 launches per block; all variants timed: " +
+                         "what": "v3 = csrc/decode_fused.hip: U^T(prev) + residual -> LayerNorm -> V -> 2-bit GEMM in ONE launch per packed "
+                                 "layer group (fp16 operator pass in the GEMM prologue), + tiled U^T of q/k/v + single-launch decode "
+                                 "attention: 6 launches per block; the round-2 variants (9-13 launches) timed beside it: " +
                                  ", ".join(f"{k[10:]} {dres[k]['tok_per_s']:.0f}" for k in cands),
                          "chained_10_launch_tok_per_s": round(dres["packed_w2_chained"]["tok_per_s"], 1),
                          "unchained_tok_per_s": round(dres["packed_w2_fused_attn"]["tok_per_s"], 1),

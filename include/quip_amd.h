@@ -252,6 +252,50 @@ int quipamd_ortho_apply_small_chain(const quipamd_small_op *first, const quipamd
 int quipamd_dequant_gemm_vop(const quipamd_small_op *vops, const int32_t *const *qweight, const float *const *scale,
                              const float *const *bias, float *const *y, int ngroups, int bits, int64_t bs, int64_t m, void *stream);
 
+/* ---- decode: one launch per packed Linear group, everything between two GEMMs in the consumer's prologue ------------------------
+ * (csrc/decode_fused.hip; the decode loop of benchmark(), opt.py:431-482 / llama.py:418-471, batch <= 4)
+ *     t    = [relu]( U_prev^T u_y + u_bias + u_residual )      optional (has_u): the output side of the PREVIOUS packed layer;
+ *                                                              t is stored to t_out (fp16, the new residual stream) when not NULL
+ *     h    = norm(t)  (norm 0: none, 1: LayerNorm gamma / beta, 2: RMSNorm gamma; fp32 statistics, eps)      [t = x without has_u]
+ *     x~_i = V_i ( h (/) s_i ),   y_i = What_i x~_i            i < ngroups <= 3 (q / k / v; gate / up), fp32 y [bs, m]
+ * quipamd_fop = a Kronecker operator prepared for this kernel: F0 / F1 are the two factor matrices of the wanted orientation
+ * (M0 [p][p], M1 [q][q], out = (M0 (x) M1) applied to the p x q image) as FP16 in MFMA B-fragment order
+ *     F0[((at * p/32 + S) * 64 + lane) * 8 + e] = M0[16 at + lane % 16][32 S + 8 (lane / 16) + e]        (F1 likewise with q),
+ * load_idx / store_idx with the meaning they have in quipamd_small_op, as uint16 [n], both required.  One fp16 product per factor entry: ~3e-4 relative per
+ * stage, below the 16-bit rounding of the pass's output (x~ feeds the fp16 MFMA, t is the fp16 residual stream).
+ * Shapes: U and V must both be p x q in {64 x 32, 64 x 64, 128 x 64}, d = p q; 2-bit qfn-b STREAM codes; scale[i] float [1];
+ * colscale[i] float [d] (ones when the layer has no rescale); m % 32 == 0 (64 x 32) or m % 16 == 0; all 16-bit tensors fp16;
+ * t_out must not alias u_residual (other workgroups still read it).  `args` is a HOST struct. */
+typedef struct quipamd_fop {
+    const void *F0, *F1;
+    const uint16_t *load_idx, *store_idx;      /* uint16 [n] (n <= 8192): half the registers and bytes of the int32 vectors */
+    int p, q;
+} quipamd_fop;
+typedef struct quipamd_fused_gemm_args {
+    int act_dtype, bits;
+    int has_u;
+    quipamd_fop U;
+    const float *u_y, *u_bias;
+    const void *u_residual;
+    int64_t ld_residual;
+    int u_relu;
+    void *t_out;
+    int64_t ld_t;
+    const void *x;
+    int64_t ldx;
+    int norm;
+    const void *ln_gamma, *ln_beta;
+    float ln_eps;
+    int ngroups;
+    quipamd_fop V[3];
+    const float *colscale[3];
+    const int32_t *qweight[3];
+    const float *scale[3];
+    float *y[3];
+    int64_t bs, m;
+} quipamd_fused_gemm_args;
+int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *args, void *stream);
+
 /* ---- K4: LDLQ rounding -------------------------------------------------------------------------
  * Replaces round_ldl / round_ldl_block (vector_balance.py:155-199, 218-257; n_greedy_passes = 0):
  *   for i = d-1 .. 0:  q_i = clamp(floor(w_i + sum_{j>i} (w_j - q_j) L[j,i] + eta_i), 0, 2^bits - 1)

@@ -1,0 +1,501 @@
+// decode_fused.hip -- one launch per packed Linear group of a batch-1 decode step (opt.py:431-482,
+// llama.py:418-471 benchmark()): everything that sits BETWEEN two dequant-GEMMs of a decoder block rides in the prologue of the
+// consuming GEMM, so the only launch boundaries left are the block's true all-to-all edges (the output of a GEMM is needed whole
+// by every workgroup of the next one):
+//
+//     t    = [relu]( U_prev^T y_prev + bias_prev + residual )          output-side operator of the PREVIOUS packed layer (optional)
+//     h    = LayerNorm | RMSNorm | identity (t)                        (t is also stored once: it is the new residual stream)
+//     x~_i = V_i ( h (/) s_i )                                         activation-side operator of layer i (1..3 layers sharing h)
+//     y_i  = What_i x~_i                                               2-bit fused dequant-GEMM, fp32 out
+//
+// Round 2 ran this as 2-3 launches (operator launch(es) 3.4-6 us each + GEMM 4.9 us; the operator in the GEMM prologue,
+// dqgemm_vop.hip, cost 7.8 us because the split-bf16 operator pass of small_pass.h is ~4 us of serial phases).  Here the operator
+// pass is rebuilt for the decode case:
+//   * ONE f16 product per factor entry (v_mfma_f32_16x16x32_f16) instead of three bf16 ones: the pass's output is rounded to 16
+//     bits anyway (x~ feeds the 16-bit MFMA of the GEMM, t is the fp16 residual stream), so hi + lo operands bought nothing
+//     there; f16 factors carry 2^-12 relative error per entry (orthogonal factors, |entry| <= 1), ~3e-4 per stage on the result;
+//   * factor matrices never touch LDS: the host stores them in MFMA B-fragment order and every wave pulls exactly the
+//     fragments of its own tiles with one 16-byte load per lane per k-step, requested at kernel start;
+//   * stage 1 is computed transposed (D = z^T M0^T) so that a lane ends up with 4 consecutive b of one a: one ds_write_b64 per
+//     tile puts the result into exactly the layout stage 2 reads its A fragments from (no 2-byte scatter between the stages);
+//   * compile-time (p, q), operands of the NEXT phase requested before the current one runs.
+// The weights of the workgroup (16 KiB - 32 KiB of packed codes) are requested first of all, so their HBM round trip hides
+// under the prologue; x~ is handed to the MFMAs through LDS as [batch row][k] (only lanes of real batch rows read it: bs <= 4).
+// Same STREAM weight layout, same epilogue algebra as dqgemm_vop.hip / dqgemm.hip (value = OFF + code, y = alpha (acc - c0 sum x)).
+#include "common.h"
+#include "dq_common.h"
+
+#include <type_traits>
+
+namespace {
+
+constexpr int FG_MAXG = 3, FG_MAXBS = 4, FG_NW = 16;
+
+typedef quipamd_fop Fop;
+
+struct FusedArgs {
+    Fop U;
+    const float *u_y, *u_bias;            // [bs, n] fp32; [n] fp32 or null
+    const uint16_t *u_res;                // [bs, ld_res] f16 or null
+    uint16_t *t_out;                      // [bs, ld_t] f16 or null
+    int64_t ld_res, ld_t;
+    int u_relu;
+    const uint16_t *x;                    // !HAS_U: [bs, ldx] f16
+    int64_t ldx;
+    int norm;                             // 0 none, 1 LayerNorm, 2 RMSNorm
+    const uint16_t *gamma, *beta;
+    float eps;
+    Fop V[FG_MAXG];
+    const float *colscale[FG_MAXG];
+    const uint4 *qw[FG_MAXG];
+    const float *scale[FG_MAXG];
+    float *y[FG_MAXG];
+    int bs;
+    int64_t m;
+};
+
+__device__ __forceinline__ uint32_t pack_f16x2(float a, float b)
+{
+    return (uint32_t)f32_to_f16_bits(a) | ((uint32_t)f32_to_f16_bits(b) << 16);
+}
+__device__ __forceinline__ float4 f16x4_to_f32(const uint2 &r)
+{
+    return make_float4(f16_bits_to_f32(r.x & 0xffff), f16_bits_to_f32(r.x >> 16), f16_bits_to_f32(r.y & 0xffff), f16_bits_to_f32(r.y >> 16));
+}
+
+// wave-wide sum on the DPP network; every lane gets the total
+__device__ __forceinline__ float fg_wave_sum(float v)
+{
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});
+    v += dpp(v, std::integral_constant<int, 0x4E>{});
+    v += dpp(v, std::integral_constant<int, 0x141>{});
+    v += dpp(v, std::integral_constant<int, 0x140>{});
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+// block-wide sum over the 16 waves: one LDS round, ONE barrier; each call site owns its own red[16]
+__device__ __forceinline__ float fg_block_sum(float v, float *red)
+{
+    const float w = fg_wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < FG_NW; i += 4) {
+        const float4 r = *reinterpret_cast<const float4 *>(red + i);
+        t += (r.x + r.y) + (r.z + r.w);
+    }
+    return t;
+}
+
+// ---- the operator pass --------------------------------------------------------------------------------------------------------
+// LDS images of one pass (P x Q operator, n = P Q):
+//   ZT  f16 [Q][P + 8]   z^T: element at image position (a, b) sits at ZT[b][a]          input of stage 1 (A fragments: 8 consecutive a')
+//   Z1  f16 [P][Q + 8]   result of stage 1 ("mix a"), row a                                 input of stage 2 (A fragments: 8 consecutive b')
+//   ZF  f32 [P][Q + 4]   result of stage 2 = the operator's image, gathered by store_idx
+template <int P, int Q> struct PassDims {
+    static constexpr int N = P * Q, PS = P + 8, QS = Q + 8, QF = Q + 4;
+    static constexpr int NT = (P / 16) * (Q / 16);                 // 16 x 16 output tiles per stage
+    static constexpr int TPW = (NT + FG_NW - 1) / FG_NW;          // tiles per wave
+    static constexpr int S0 = P / 32, S1 = Q / 32;                 // k-steps of stage 1 / stage 2
+    static constexpr int NV = (N / 4 + 1023) / 1024;               // float4 slots per thread (natural order: slot v4 = tid + 1024 u)
+    static constexpr size_t ZT_B = (size_t)Q * PS * 2, Z1_B = (size_t)P * QS * 2, ZF_B = (size_t)P * QF * 4;
+    static constexpr size_t BYTES = ZT_B + Z1_B + ZF_B;
+    static_assert(P % 32 == 0 && Q % 32 == 0 && (Q & (Q - 1)) == 0, "operator shape");
+};
+
+// this wave's factor fragments (host layout: F0 [P/16][P/32][64 lanes] uint4, F1 [Q/16][Q/32][64] uint4).  The stage-1 set is
+// requested a phase ahead by the caller, the stage-2 set at the top of mix_stages (it lands under stage 1 and its barrier):
+// holding both from kernel start spilled registers at 128 x 64 (1024 threads = 128 VGPRs per lane)
+template <int P, int Q> struct PassFrags {
+    uint4 f0[PassDims<P, Q>::TPW][PassDims<P, Q>::S0];
+};
+
+template <int P, int Q> __device__ __forceinline__ void load_frags(const Fop &op, int wave, int lane, PassFrags<P, Q> &fr)
+{
+    typedef PassDims<P, Q> D;
+    const uint4 *F0 = reinterpret_cast<const uint4 *>(op.F0);
+#pragma unroll
+    for (int i = 0; i < D::TPW; ++i) {
+        const int tile = wave + FG_NW * i;
+        if (tile < D::NT) {
+            const int at = tile % (P / 16);              // stage 1 tile = (bt, at): its B fragment depends on at only
+#pragma unroll
+            for (int S = 0; S < D::S0; ++S) fr.f0[i][S] = F0[(at * D::S0 + S) * 64 + lane];
+        }
+    }
+}
+
+// scatter 4 consecutive natural-order values into the stage-1 input image: value e goes to image position pos[e] = (a, b) -> ZT[b][a]
+template <int P, int Q> __device__ __forceinline__ void scatter4(uint16_t *ZT, const float4 &v, const uint2 &pos)
+{
+    typedef PassDims<P, Q> D;
+    constexpr int qsh = __builtin_ctz(Q);
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    const int pp[4] = {(int)(pos.x & 0xffff), (int)(pos.x >> 16), (int)(pos.y & 0xffff), (int)(pos.y >> 16)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ZT[(pp[e] & (Q - 1)) * D::PS + (pp[e] >> qsh)] = f32_to_f16_bits(vv[e]);
+}
+
+// the two mix stages: ZT -> Z1 -> ZF.  Caller: a barrier after the scatter; this function ends WITHOUT a barrier after writing ZF.
+template <int P, int Q>
+__device__ __forceinline__ void mix_stages(const Fop &op, const uint16_t *ZT, uint16_t *Z1, float *ZF, const PassFrags<P, Q> &fr, int wave, int lane)
+{
+    typedef PassDims<P, Q> D;
+    const int j = lane & 15, g = lane >> 4;
+    uint4 f1[D::TPW][D::S1];
+    {
+        const uint4 *F1 = reinterpret_cast<const uint4 *>(op.F1);
+#pragma unroll
+        for (int i = 0; i < D::TPW; ++i) {
+            const int tile = wave + FG_NW * i;
+            if (tile < D::NT) {
+                const int bt2 = tile % (Q / 16);         // stage 2 tile = (at, bt): its B fragment depends on bt only
+#pragma unroll
+                for (int S = 0; S < D::S1; ++S) f1[i][S] = F1[(bt2 * D::S1 + S) * 64 + lane];
+            }
+        }
+    }
+    // stage 1, transposed: D1[m = b][n = a] = sum_a' ZT[b][a'] M0[a][a'];  A = ZT rows (LDS), B = M0 rows (registers)
+#pragma unroll
+    for (int i = 0; i < D::TPW; ++i) {
+        const int tile = wave + FG_NW * i;
+        if (tile < D::NT) {
+            const int at = tile % (P / 16), bt = tile / (P / 16);
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            const uint16_t *arow = ZT + (16 * bt + j) * D::PS + 8 * g;
+#pragma unroll
+            for (int S = 0; S < D::S0; ++S) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(arow + 32 * S);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, fr.f0[i][S]), acc, 0, 0, 0);
+            }
+            // lane: a = 16 at + j, b = 16 bt + 4 g + {0..3}: four consecutive b of row a -> one 8-byte store
+            uint2 pk;
+            pk.x = pack_f16x2(acc[0], acc[1]);
+            pk.y = pack_f16x2(acc[2], acc[3]);
+            *reinterpret_cast<uint2 *>(Z1 + (16 * at + j) * D::QS + 16 * bt + 4 * g) = pk;
+        }
+    }
+    __syncthreads();
+    // stage 2: D2[m = a][n = b] = sum_b' Z1[a][b'] M1[b][b'];  A = Z1 rows (LDS), B = M1 rows (registers)
+#pragma unroll
+    for (int i = 0; i < D::TPW; ++i) {
+        const int tile = wave + FG_NW * i;
+        if (tile < D::NT) {
+            const int bt = tile % (Q / 16), at = tile / (Q / 16);
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            const uint16_t *arow = Z1 + (16 * at + j) * D::QS + 8 * g;
+#pragma unroll
+            for (int S = 0; S < D::S1; ++S) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(arow + 32 * S);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, f1[i][S]), acc, 0, 0, 0);
+            }
+            // lane: b = 16 bt + j, a = 16 at + 4 g + reg
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) ZF[(16 * at + 4 * g + reg) * D::QF + 16 * bt + j] = acc[reg];
+        }
+    }
+}
+
+template <int P, int Q> __device__ __forceinline__ float4 gather4(const float *ZF, const uint2 &pos)
+{
+    typedef PassDims<P, Q> D;
+    constexpr int qsh = __builtin_ctz(Q);
+    const int p0 = (int)(pos.x & 0xffff), p1 = (int)(pos.x >> 16), p2 = (int)(pos.y & 0xffff), p3 = (int)(pos.y >> 16);
+    return make_float4(ZF[(p0 >> qsh) * D::QF + (p0 & (Q - 1))], ZF[(p1 >> qsh) * D::QF + (p1 & (Q - 1))],
+                       ZF[(p2 >> qsh) * D::QF + (p2 & (Q - 1))], ZF[(p3 >> qsh) * D::QF + (p3 & (Q - 1))]);
+}
+
+// ---- the fused launch ------------------------------------------------------------------------------------------------------------
+// grid = (m / (16 RT), ngroups); 1024 threads = 16 waves = (16 / RT chunk slots) x RT row tiles; d = P Q = 256 (16 / RT) CPW
+template <int P, int Q, bool HAS_U, int RT, int CPW>
+__global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two_over_maxq, float c0)
+{
+    typedef PassDims<P, Q> D;
+    typedef DeqT<2, ActF16> DQ;
+    constexpr int N = D::N, NV = D::NV, NS = FG_NW / RT, NCH = N / 256, XTS = N + 8;      // x~ row stride (halves)
+    static_assert(NS * CPW == NCH, "chunks = slots x chunks per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t *XT = reinterpret_cast<uint16_t *>(smem);                         // [bs][N + 8] f16
+    char *pass = smem + (size_t)FG_MAXBS * XTS * 2;
+    uint16_t *ZT = reinterpret_cast<uint16_t *>(pass);
+    uint16_t *Z1 = reinterpret_cast<uint16_t *>(pass + D::ZT_B);
+    float *ZF = reinterpret_cast<float *>(pass + D::ZT_B + D::Z1_B);
+    float *park = reinterpret_cast<float *>(pass);                              // [NS][RT][4][64] + xsum [NS][64]: after the last pass
+    constexpr size_t PARK_B = (size_t)(FG_NW * 256 + FG_NW * 64) * 4;
+    float *red = reinterpret_cast<float *>(pass + (D::BYTES > PARK_B ? D::BYTES : PARK_B));            // [2][16]
+
+    const int gi = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = wave / RT, r = wave - slot * RT;
+    const int j = lane & 15, g = lane >> 4;
+    const uint32_t rt = blockIdx.x * RT + r;
+    const int bs = G.bs;
+
+    // ---- requested first: this wave's packed weights (HBM), then the factor fragments of the first pass ----------------------------
+    uint4 w[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) w[i] = (G.qw[gi] + ((uint64_t)rt * NCH + (slot * CPW + i)) * 64)[lane];
+    const float e_sc = G.scale[gi][0];
+    PassFrags<P, Q> fr;
+    const Fop &V = G.V[gi];
+    load_frags<P, Q>(HAS_U ? G.U : V, wave, lane, fr);
+
+    for (int b = 0; b < bs; ++b) {
+        float4 tv[NV];
+        if (HAS_U) {
+            // ---- t = [relu](U^T y + bias + residual) --------------------------------------------------------------------------------
+            float4 yv[NV];
+            uint2 ld[NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int v4 = tid + 1024 * u;
+                if (v4 < N / 4) {
+                    yv[u] = *reinterpret_cast<const float4 *>(G.u_y + (int64_t)b * N + 4 * v4);
+                    ld[u] = *reinterpret_cast<const uint2 *>(G.U.load_idx + 4 * v4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NV; ++u)
+                if (tid + 1024 * u < N / 4) scatter4<P, Q>(ZT, yv[u], ld[u]);
+            // operands of the gather, requested one phase ahead (after the scatter: its temporaries need the registers at 128 x 64)
+            uint2 st[NV];
+            float4 bi[NV];
+            uint2 rs[NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int v4 = tid + 1024 * u;
+                bi[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rs[u] = make_uint2(0u, 0u);
+                if (v4 < N / 4) {
+                    st[u] = *reinterpret_cast<const uint2 *>(G.U.store_idx + 4 * v4);
+                    if (G.u_bias) bi[u] = *reinterpret_cast<const float4 *>(G.u_bias + 4 * v4);
+                    if (G.u_res) rs[u] = *reinterpret_cast<const uint2 *>(G.u_res + (int64_t)b * G.ld_res + 4 * v4);
+                }
+            }
+            __syncthreads();
+            mix_stages<P, Q>(G.U, ZT, Z1, ZF, fr, wave, lane);
+            load_frags<P, Q>(V, wave, lane, fr);                                // the V-side fragments travel under the gather + norm
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int v4 = tid + 1024 * u;
+                tv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (v4 < N / 4) {
+                    float4 t = gather4<P, Q>(ZF, st[u]);
+                    const float4 rr = f16x4_to_f32(rs[u]);
+                    t = make_float4(t.x + bi[u].x + rr.x, t.y + bi[u].y + rr.y, t.z + bi[u].z + rr.z, t.w + bi[u].w + rr.w);
+                    if (G.u_relu) t = make_float4(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f));
+                    uint2 pk;                                                    // the residual stream is fp16: everything downstream sees the rounded value
+                    pk.x = pack_f16x2(t.x, t.y);
+                    pk.y = pack_f16x2(t.z, t.w);
+                    if (G.t_out && blockIdx.x == 0 && gi == 0) *reinterpret_cast<uint2 *>(G.t_out + (int64_t)b * G.ld_t + 4 * v4) = pk;
+                    tv[u] = f16x4_to_f32(pk);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int v4 = tid + 1024 * u;
+                tv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (v4 < N / 4) tv[u] = f16x4_to_f32(*reinterpret_cast<const uint2 *>(G.x + (int64_t)b * G.ldx + 4 * v4));
+            }
+        }
+        // operands of the V-side scatter / gather: requested before the reductions
+        uint2 gm[NV], bt_[NV];
+        float4 cs[NV];
+        uint2 vld[NV], vst[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int v4 = tid + 1024 * u;
+            gm[u] = bt_[u] = make_uint2(0u, 0u);
+            cs[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (v4 < N / 4) {
+                if (G.norm) gm[u] = *reinterpret_cast<const uint2 *>(G.gamma + 4 * v4);
+                if (G.norm == 1) bt_[u] = *reinterpret_cast<const uint2 *>(G.beta + 4 * v4);
+                cs[u] = *reinterpret_cast<const float4 *>(G.colscale[gi] + 4 * v4);
+                vld[u] = *reinterpret_cast<const uint2 *>(V.load_idx + 4 * v4);
+                vst[u] = *reinterpret_cast<const uint2 *>(V.store_idx + 4 * v4);
+            }
+        }
+        if (G.norm) {
+            float mean = 0.f;
+            if (G.norm == 1) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) s1 += (tv[u].x + tv[u].y) + (tv[u].z + tv[u].w);
+                mean = fg_block_sum(s1, red) / (float)N;
+            }
+            float s2 = 0.f;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                if (tid + 1024 * u < N / 4) {
+                    const float d0 = tv[u].x - mean, d1 = tv[u].y - mean, d2 = tv[u].z - mean, d3 = tv[u].w - mean;
+                    s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+            }
+            const float rstd = rsqrtf(fg_block_sum(s2, red + FG_NW) / (float)N + G.eps);
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const float4 gmf = f16x4_to_f32(gm[u]), btf = f16x4_to_f32(bt_[u]);
+                tv[u] = make_float4((tv[u].x - mean) * rstd * gmf.x + btf.x, (tv[u].y - mean) * rstd * gmf.y + btf.y,
+                                    (tv[u].z - mean) * rstd * gmf.z + btf.z, (tv[u].w - mean) * rstd * gmf.w + btf.w);
+            }
+        }
+        // ---- x~ = V (h (/) s) ------------------------------------------------------------------------------------------------------
+        // (ZT is free: with a U pass its last readers finished before the barrier in front of the gather; ZF's readers -- the gather
+        //  above -- finish before the barrier after this scatter, and ZF is written only after the barrier inside mix_stages)
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            if (tid + 1024 * u < N / 4) {
+                const float4 v = make_float4(tv[u].x * cs[u].x, tv[u].y * cs[u].y, tv[u].z * cs[u].z, tv[u].w * cs[u].w);
+                scatter4<P, Q>(ZT, v, vld[u]);
+            }
+        }
+        __syncthreads();
+        mix_stages<P, Q>(V, ZT, Z1, ZF, fr, wave, lane);
+        if (HAS_U && b + 1 < bs) load_frags<P, Q>(G.U, wave, lane, fr);        // next batch row starts with the U pass again
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int v4 = tid + 1024 * u;
+            if (v4 < N / 4) {
+                const float4 t = gather4<P, Q>(ZF, vst[u]);
+                uint2 pk;
+                pk.x = pack_f16x2(t.x, t.y);
+                pk.y = pack_f16x2(t.z, t.w);
+                *reinterpret_cast<uint2 *>(XT + (size_t)b * XTS + 4 * v4) = pk;
+            }
+        }
+        __syncthreads();                                                        // x~ row complete; ZF / ZT free for the next row (or park)
+    }
+
+    // ---- dequant + MFMA: this wave's CPW chunks of 256 columns x 16 rows -------------------------------------------------------------
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    float xs = 0.f;
+    const bool live = j < bs;                                                   // MFMA column j = batch row j
+    const uint16_t *xrow = XT + (size_t)(live ? j : 0) * XTS + 8 * g;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int c = slot * CPW + i;
+#pragma unroll
+        for (int t = 0; t < DQ::NT; ++t) {
+            uint4 xf = *reinterpret_cast<const uint4 *>(xrow + c * 256 + 32 * t);
+            if (!live) xf = make_uint4(0u, 0u, 0u, 0u);
+            const u32x4 a = DQ::frag(u32x4{w[i].x, w[i].y, w[i].z, w[i].w}, t);
+            acc = ActF16::mfma(a, u32x4{xf.x, xf.y, xf.z, xf.w}, acc);
+            if (r == 0) {
+                xs = ActF16::dot2(xf.x, ActF16::ONES, xs);
+                xs = ActF16::dot2(xf.y, ActF16::ONES, xs);
+                xs = ActF16::dot2(xf.z, ActF16::ONES, xs);
+                xs = ActF16::dot2(xf.w, ActF16::ONES, xs);
+            }
+        }
+    }
+    float *xpark = park + FG_NW * 256;
+    {
+        float *p = park + (slot * RT + r) * 256 + lane;
+        p[0] = acc[0]; p[64] = acc[1]; p[128] = acc[2]; p[192] = acc[3];
+        if (r == 0) {
+            xs += __shfl_xor(xs, 16);
+            xs += __shfl_xor(xs, 32);
+            xpark[slot * 64 + lane] = xs;                                        // lanes j of every g hold sum_k x~[j][k] over the slot's chunks
+        }
+    }
+    __syncthreads();
+    if (wave < RT) {                                                            // one reducer wave per row tile: lane = (batch row, row in tile)
+        const int r2 = wave, bb = lane >> 4, wr = lane & 15;
+        const int src = (wr & 3) * 64 + bb + 16 * (wr >> 2);                   // [acc component][mfma lane (j = bb, g = wr / 4)]
+        float a = 0.f, xsum = 0.f;
+#pragma unroll
+        for (int v = 0; v < NS; ++v) {
+            a += park[(v * RT + r2) * 256 + src];
+            xsum += xpark[v * 64 + bb];
+        }
+        const int64_t row = (int64_t)(blockIdx.x * RT + r2) * 16 + wr;
+        if (bb < bs) G.y[gi][(int64_t)bb * G.m + row] = e_sc * two_over_maxq * (a - c0 * xsum);
+    }
+}
+
+template <int P, int Q> constexpr size_t fused_lds()
+{
+    typedef PassDims<P, Q> D;
+    const size_t parkb = (size_t)(FG_NW * 256 + FG_NW * 64) * 4;
+    return (size_t)FG_MAXBS * (D::N + 8) * 2 + (D::BYTES > parkb ? D::BYTES : parkb) + 2 * FG_NW * 4 + 64;
+}
+
+template <int P, int Q, bool HAS_U, int RT, int CPW> int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
+{
+    const size_t lds = fused_lds<P, Q>();
+    auto kern = fused_gemm_kernel<P, Q, HAS_U, RT, CPW>;
+    static QaPerDevice attr;
+    const int d = attr.dev();
+    if (d < 0 || !attr.done[d]) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_fused_gemm: cannot raise dynamic LDS to %zu", lds);
+        if (d >= 0) attr.done[d] = true;
+    }
+    const float maxq = 3.f;
+    kern<<<dim3((unsigned)(A.m / 16 / RT), (unsigned)ngroups), 1024, lds, s>>>(A, 2.0f / maxq, DeqT<2, ActF16>::OFF + 0.5f * maxq);
+    QA_LAUNCH_CHECK("quipamd_decode_fused_gemm");
+    return QUIPAMD_OK;
+}
+
+bool fop_ok(const quipamd_fop &o, int p, int q) { return o.F0 && o.F1 && o.load_idx && o.store_idx && o.p == p && o.q == q; }
+
+}   // namespace
+
+extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void *stream)
+{
+    QA_REQUIRE(a, QUIPAMD_ERR_ARG, "decode_fused_gemm: null args");
+    QA_REQUIRE(a->act_dtype == QUIPAMD_F16, QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: fp16 activations only");
+    QA_REQUIRE(a->bits == 2, QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: 2-bit qfn-b codes only");
+    QA_REQUIRE(a->ngroups >= 1 && a->ngroups <= FG_MAXG, QUIPAMD_ERR_ARG, "decode_fused_gemm: 1..%d groups", FG_MAXG);
+    QA_REQUIRE(a->bs >= 0 && a->bs <= FG_MAXBS, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: bs %lld > %d", (long long)a->bs, FG_MAXBS);
+    if (a->bs == 0) return QUIPAMD_OK;
+    const int p = a->V[0].p, q = a->V[0].q;
+    const int64_t n = (int64_t)p * q;
+    FusedArgs A;
+    A.U = a->U;
+    A.u_y = a->u_y; A.u_bias = a->u_bias; A.u_res = (const uint16_t *)a->u_residual; A.t_out = (uint16_t *)a->t_out;
+    A.ld_res = a->ld_residual; A.ld_t = a->ld_t; A.u_relu = a->u_relu;
+    A.x = (const uint16_t *)a->x; A.ldx = a->ldx;
+    A.norm = a->norm; A.gamma = (const uint16_t *)a->ln_gamma; A.beta = (const uint16_t *)a->ln_beta; A.eps = a->ln_eps;
+    A.bs = (int)a->bs; A.m = a->m;
+    QA_REQUIRE(a->norm >= 0 && a->norm <= 2 && (a->norm == 0 || a->ln_gamma) && (a->norm != 1 || a->ln_beta), QUIPAMD_ERR_ARG,
+               "decode_fused_gemm: norm %d needs gamma (and beta for LayerNorm)", a->norm);
+    if (a->has_u) {
+        QA_REQUIRE(!a->t_out || a->t_out != a->u_residual, QUIPAMD_ERR_ARG, "decode_fused_gemm: t_out must not alias u_residual");
+        QA_REQUIRE(fop_ok(a->U, p, q) && a->u_y, QUIPAMD_ERR_ARG, "decode_fused_gemm: the output-side operator must be %d x %d like the activation-side one", p, q);
+        QA_REQUIRE((!a->u_residual || (a->ld_residual >= n && a->ld_residual % 4 == 0)) && (!a->t_out || (a->ld_t >= n && a->ld_t % 4 == 0)),
+                   QUIPAMD_ERR_SHAPE, "decode_fused_gemm: residual / t_out row strides");
+    } else {
+        QA_REQUIRE(a->x && a->ldx >= n && a->ldx % 4 == 0, QUIPAMD_ERR_ARG, "decode_fused_gemm: x [bs, ldx] needed without an output-side operator");
+    }
+    for (int i = 0; i < FG_MAXG; ++i) {
+        const int k = i < a->ngroups ? i : 0;
+        QA_REQUIRE(fop_ok(a->V[k], p, q) && a->colscale[k] && a->qweight[k] && a->scale[k] && a->y[k], QUIPAMD_ERR_ARG,
+                   "decode_fused_gemm: null pointer / operator shape in group %d", k);
+        A.V[i] = a->V[k]; A.colscale[i] = a->colscale[k]; A.qw[i] = (const uint4 *)a->qweight[k]; A.scale[i] = a->scale[k]; A.y[i] = a->y[k];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const bool u = a->has_u != 0;
+    if (p == 64 && q == 32) {
+        QA_REQUIRE(a->m > 0 && a->m % 32 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 32 (m = %lld)", (long long)a->m);
+        return u ? launch_fused<64, 32, true, 2, 1>(A, a->ngroups, s) : launch_fused<64, 32, false, 2, 1>(A, a->ngroups, s);
+    }
+    if (p == 64 && q == 64) {
+        QA_REQUIRE(a->m > 0 && a->m % 16 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 16 (m = %lld)", (long long)a->m);
+        return u ? launch_fused<64, 64, true, 1, 1>(A, a->ngroups, s) : launch_fused<64, 64, false, 1, 1>(A, a->ngroups, s);
+    }
+    if (p == 128 && q == 64) {
+        QA_REQUIRE(a->m > 0 && a->m % 16 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 16 (m = %lld)", (long long)a->m);
+        return u ? launch_fused<128, 64, true, 1, 2>(A, a->ngroups, s) : launch_fused<128, 64, false, 1, 2>(A, a->ngroups, s);
+    }
+    return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: operator %d x %d (64 x 32, 64 x 64, 128 x 64)", p, q);
+}

@@ -343,6 +343,72 @@ def dequant_gemm_vop(vops, qweights, scales, biases, ys, bs, m, bits=2):
               vp(biases if biases is not None else [None] * n), vp(ys), n, bits, bs, m, _stream())
 
 
+# ---- decode: fused launches (csrc/decode_fused.hip) ---------------------------------------------------------------------------
+class Fop(ctypes.Structure):
+    """mirror of `quipamd_fop` (include/quip_amd.h)"""
+    _fields_ = [("F0", ctypes.c_void_p), ("F1", ctypes.c_void_p), ("load_idx", ctypes.c_void_p), ("store_idx", ctypes.c_void_p),
+                ("p", ctypes.c_int), ("q", ctypes.c_int)]
+
+
+class FusedGemmArgs(ctypes.Structure):
+    """mirror of `quipamd_fused_gemm_args`"""
+    _fields_ = [("act_dtype", ctypes.c_int), ("bits", ctypes.c_int), ("has_u", ctypes.c_int), ("U", Fop),
+                ("u_y", ctypes.c_void_p), ("u_bias", ctypes.c_void_p), ("u_residual", ctypes.c_void_p), ("ld_residual", ctypes.c_int64),
+                ("u_relu", ctypes.c_int), ("t_out", ctypes.c_void_p), ("ld_t", ctypes.c_int64),
+                ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64),
+                ("norm", ctypes.c_int), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p), ("ln_eps", ctypes.c_float),
+                ("ngroups", ctypes.c_int), ("V", Fop * 3), ("colscale", ctypes.c_void_p * 3), ("qweight", ctypes.c_void_p * 3),
+                ("scale", ctypes.c_void_p * 3), ("y", ctypes.c_void_p * 3), ("bs", ctypes.c_int64), ("m", ctypes.c_int64)]
+
+
+FUSED_SHAPES = ((64, 32), (64, 64), (128, 64))
+FUSED_MAX_ROWS = 4
+
+
+def _f16_b_frags(M):
+    """M [P, P] fp32 (out index i, in index k) -> fp16 [P/16, P/32, 64, 8] in v_mfma_f32_16x16x32_f16 B-fragment order
+    (include/quip_amd.h quipamd_fop): element [t][S][lane][e] = M[16 t + lane % 16][32 S + 8 (lane // 16) + e]"""
+    P = M.shape[0]
+    F = M.to(torch.float16).view(P // 16, 16, P // 32, 4, 8)          # [t, j, S, g, e]
+    return F.permute(0, 2, 3, 1, 4).contiguous().reshape(-1)          # [t, S, g, j, e]: lane = 16 g + j
+
+
+def decode_fused_gemm(*, V, colscale, qweight, scale, y, m, bs, x=None, U=None, u_y=None, u_bias=None, u_residual=None, u_relu=False,
+                      t_out=None, norm=0, ln_gamma=None, ln_beta=None, ln_eps=0.0):
+    """one launch of quipamd_decode_fused_gemm.  V / colscale / qweight / scale / y: lists (1..3 groups); V, U: Fop records
+    (OrthoOp.fop); 16-bit tensors fp16.  See include/quip_amd.h for the contract."""
+    a = FusedGemmArgs()
+    a.act_dtype, a.bits = _DT[torch.float16], 2
+    a.has_u = int(U is not None)
+    if U is not None:
+        a.U = U
+        a.u_y, a.u_bias = _ptr(u_y), _f32ptr(u_bias, "u_bias")
+        a.u_residual, a.ld_residual = _ptr(u_residual), 0 if u_residual is None else u_residual.stride(0)
+        a.u_relu = int(bool(u_relu))
+        a.t_out, a.ld_t = _ptr(t_out), 0 if t_out is None else t_out.stride(0)
+        assert u_y.dtype == torch.float32 and u_y.is_contiguous()
+        assert u_residual is None or (u_residual.dtype == torch.float16 and u_residual.stride(1) == 1)
+        assert t_out is None or (t_out.dtype == torch.float16 and t_out.stride(1) == 1)
+    else:
+        assert x.dtype == torch.float16 and x.stride(1) == 1
+        a.x, a.ldx = _ptr(x), x.stride(0)
+    a.norm, a.ln_eps = int(norm), float(ln_eps)
+    if norm:
+        assert ln_gamma.dtype == torch.float16 and (norm != 1 or ln_beta.dtype == torch.float16)
+        a.ln_gamma, a.ln_beta = _ptr(ln_gamma), _ptr(ln_beta)
+    n = len(V)
+    a.ngroups = n
+    for i in range(n):
+        a.V[i] = V[i]
+        a.colscale[i] = _f32ptr(colscale[i], "colscale")
+        a.qweight[i] = qweight[i].data_ptr()
+        a.scale[i] = _f32ptr(scale[i], "scale")
+        assert y[i].dtype == torch.float32 and y[i].is_contiguous()
+        a.y[i] = y[i].data_ptr()
+    a.bs, a.m = int(bs), int(m)
+    _lib.call("quipamd_decode_fused_gemm", ctypes.byref(a), _stream())
+
+
 def _mfma_b_frags(M):
     """M [C, P, P] (out index i, in index k) -> float [C, NT, NT, 64, 4] in v_mfma_f32_16x16x4_f32 B-fragment order
     (include/quip_amd.h): element [c][nt][S][lane][s] = M[c][16 nt + (lane & 15)][16 S + 4 (lane >> 4) + s]."""
@@ -412,6 +478,25 @@ class OrthoOp:
         if getattr(self, '_one_scale', None) is None:
             self._one_scale = torch.ones(self.n, dtype=torch.float32, device=self.device)
         return self._one_scale
+
+    def fop(self, transpose):
+        """the operator prepared for csrc/decode_fused.hip (quipamd_fop): fp16 factors in MFMA B-fragment order + uint16 index
+        vectors; built once per orientation and kept on the device"""
+        cache = self.__dict__.setdefault('_fops', {})
+        key = bool(transpose)
+        if key not in cache:
+            assert self.fused_ok
+            M0, M1 = self._M[key]
+            ident = torch.arange(self.n, device=self.device, dtype=torch.int32)
+            ld, st = (self.pout, self.inv_pin) if key else (self.inv_pin, self.pout)
+            i16 = lambda t: (ident if t is None else t).to(torch.int16).contiguous()       # n <= 8192: the bits of a uint16
+            keep = (_f16_b_frags(M0), _f16_b_frags(M1), i16(ld), i16(st))
+            cache[key] = (Fop(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), self.p, self.q), keep)
+        return cache[key][0]
+
+    @property
+    def fused_ok(self):
+        return (not self.blocked) and (self.p, self.q) in FUSED_SHAPES and (self.small_ok or self.bigp_ok)
 
     def store_inv(self, transpose):
         """image position -> output index: the inverse of the `store_idx` small_op() hands to the kernels"""

@@ -538,6 +538,49 @@ def packed_u_then_v(qa, y, dtype, qbs, residual=None, relu=False, ln=None, store
     return t, xts
 
 
+def fused_ok(qls, rows, x_dtype=torch.float16, prev=None):
+    """can `fused_stage` run these layers?  (csrc/decode_fused.hip: 2-bit qfn-b layers of one shape sharing their input, Kronecker
+    operators of a decode shape on both sides, fp16 activations, a handful of rows; `prev`: the packed layer whose output-side
+    operator rides in the prologue -- its U must have the consumers' V shape)"""
+    q0 = qls[0]
+    ok = (1 <= len(qls) <= 3 and rows <= ops.FUSED_MAX_ROWS and x_dtype == torch.float16
+          and all(q.bits == 2 and q.qfn == 'b' and q.V is not None and q.V.fused_ok and q.scales.numel() == 1 for q in qls)
+          and len({(q.infeatures, q.outfeatures, q.V.p, q.V.q) for q in qls}) == 1
+          and q0.outfeatures % (32 if (q0.V.p, q0.V.q) == (64, 32) else 16) == 0)
+    if ok and prev is not None:
+        ok = prev.U is not None and prev.U.fused_ok and (prev.U.p, prev.U.q) == (q0.V.p, q0.V.q)
+    return ok
+
+
+def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, ln=None, store=False):
+    """ONE launch (quipamd_decode_fused_gemm) for everything between two dequant-GEMMs of a decode step:
+        t    = [relu]( U_prev^T y_prev + bias_prev + residual )     when `prev` (the packed layer that produced y_prev) is given,
+                                                                    else t = x
+        y_i  = What_i V_i ( Norm(t) (/) s_i )                       for the 1..3 layers `qls` sharing t; fp32 [rows, m]
+    Returns (ys, t): t is the fp16 tensor written by the launch when store=True (the new residual stream), else None.
+    ln: nn.LayerNorm / an RMSNorm module / None."""
+    q0 = qls[0]
+    rows = (x if prev is None else y_prev).shape[0]
+    dev = q0.qweight.device
+    m, d = q0.outfeatures, q0.infeatures
+    ys = [torch.empty((rows, m), dtype=torch.float32, device=dev) for _ in qls]
+    kw = dict(V=[q.V.fop(False) for q in qls], colscale=[q.inv_scaleWH if q.inv_scaleWH is not None else q.V.one_scale() for q in qls],
+              qweight=[q.qweight for q in qls], scale=[q.scales for q in qls], y=ys, m=m, bs=rows)
+    lnp = _ln_params(ln)
+    if lnp is not None:
+        g, b, eps = lnp
+        kw.update(norm=1 if b is not None else 2, ln_gamma=g, ln_beta=b, ln_eps=eps)
+    t = None
+    if prev is None:
+        kw.update(x=x.contiguous())
+    else:
+        t = torch.empty((rows, d), dtype=torch.float16, device=dev) if store else None
+        kw.update(U=prev.U.fop(True), u_y=y_prev, u_bias=prev.bias, u_residual=None if residual is None else residual.contiguous(),
+                  u_relu=relu, t_out=t)
+    ops.decode_fused_gemm(**kw)
+    return ys, t
+
+
 def save_packed(layers, path):
     """Packed checkpoint: {dotted module name: QuantLinear} -> one torch file of CPU tensors (replaces the dense fp16
     `torch.save(model.state_dict())` of opt.py:644-646 for the quantised Linears; 2 bits/weight + factors)."""

@@ -30,7 +30,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quip_amd import ops, method  # noqa: E402
 from quip_amd.quant import (QuantLinear, packed_forward_fused, packed_v_stage, packed_gemm_stage, packed_u_stage,  # noqa: E402
-                            packed_u_then_v, packed_vgemm_stage, vgemm_fusable)
+                            packed_u_then_v, packed_vgemm_stage, vgemm_fusable, fused_stage, fused_ok)
 
 
 class Block(nn.Module):
@@ -124,6 +124,33 @@ class Decoder(nn.Module):
 
     split_handover = False
 
+    v3 = False               # csrc/decode_fused.hip: everything between two GEMMs in the consuming GEMM's prologue -- 6 launches per block
+
+    def v3_ok(self, bs):
+        b = self.blocks[0]
+        return (fused_ok([b.q_proj, b.k_proj, b.v_proj], bs, prev=b.fc2) and fused_ok([b.out_proj], bs)
+                and fused_ok([b.fc1], bs, prev=b.out_proj) and fused_ok([b.fc2], bs, prev=b.fc1))
+
+    def step_v3(self, x, pos, caches):
+        """per block: [U_fc2^T(prev) + residual -> LN1 -> V_qkv -> GEMM qkv] [U_qkv^T (tiled)] [attention] [V_o -> GEMM o]
+        [U_o^T + residual -> LN2 -> V_fc1 -> GEMM fc1] [U_fc1^T + relu -> V_fc2 -> GEMM fc2]; the last block's U_fc2^T + residual is
+        one tiled operator launch."""
+        dt = x.dtype
+        prev, y2 = None, None
+        for blk, (kc, vc) in zip(self.blocks, caches):
+            qkv = [blk.q_proj, blk.k_proj, blk.v_proj]
+            if prev is None:
+                ys, _ = fused_stage(qkv, x=x, ln=blk.ln1)
+            else:
+                ys, x = fused_stage(qkv, prev=prev, y_prev=y2, residual=x, ln=blk.ln1, store=True)
+            q, k, v = packed_u_stage(qkv, ys, dt)
+            o = ops.decode_attention(q, k, v, kc, vc, pos)
+            yo = fused_stage([blk.out_proj], x=o)[0][0]
+            (y1,), x = fused_stage([blk.fc1], prev=blk.out_proj, y_prev=yo, residual=x, ln=blk.ln2, store=True)
+            y2 = fused_stage([blk.fc2], prev=blk.fc1, y_prev=y1, relu=True)[0][0]
+            prev = blk.fc2
+        return packed_u_stage([prev], [y2], dt, residual=x)[0]
+
     tiled = False            # every operator application cut into 16 x 16 output tiles over 8-32 workgroups (csrc/ortho_tile.hip): 13 launches
 
     def step_tiled(self, x, pos, caches):
@@ -141,6 +168,8 @@ class Decoder(nn.Module):
     def step(self, ids, pos, caches, arange):
         """one token for every batch row: ids int64 [bs], pos int64 [1]; returns logits [bs, vocab]."""
         x = self.tok(ids) + self.posemb(pos + 2)
+        if self.v3:
+            return F.linear(self.lnf(self.step_v3(x, pos, caches)), self.tok.weight)
         if self.tiled:
             return F.linear(self.lnf(self.step_tiled(x, pos, caches)), self.tok.weight)
         if self.vfused:
@@ -225,7 +254,7 @@ def time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager):
     return float(np.median(lat)), float(np.mean(lat)), logits_out.float().clone()
 
 
-def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense=True, only_chained=False):
+def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense=True, only_chained=False, v3_only=False):
     """build the model, time dense fp16 (optional), packed, and fused-packed decode; returns a dict."""
     dev, dtype = torch.device("cuda:0"), torch.float16
     maxlen = prompt + tokens + 8
@@ -268,6 +297,15 @@ def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense
             med, mean, lh = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
             out["packed_w%d_vfused_split_handover" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
                                                               "logits_bit_identical_to_vfused": bool(torch.equal(lh, lv))}
+        if model.v3_ok(bs):
+            model.v3 = True
+            torch.manual_seed(7)
+            med, mean, l3 = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+            out["packed_w%d_v3" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+                                           "logits_rel_diff_vs_chained": float((l3 - lc).norm() / lc.norm())}
+            model.v3 = False
+        if v3_only:
+            return out
         model.tiled = True
         torch.manual_seed(7)
         med, mean, lt = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
@@ -301,6 +339,13 @@ def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense
             "ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
             "what": "as vfused, the n = 8192 fc1 -> fc2 hand-over as two tiled operator launches (32 workgroups each) instead of "
                     "one one-workgroup chain launch (10 launches per block)"}
+    if model.v3_ok(bs):
+        model.v3 = True
+        med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+        out["packed_w%d_v3" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+                                       "what": "csrc/decode_fused.hip: U^T(prev) + residual -> norm -> V -> GEMM in ONE launch per packed layer group "
+                                               "(fp16 operator pass in the GEMM prologue); 6 launches per block"}
+        model.v3 = False
     model.tiled = True
     med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
     out["packed_w%d_tiled" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
@@ -319,9 +364,10 @@ def main():
     ap.add_argument("--tokens", type=int, default=128)
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--only-chained", action="store_true", help="time only the chained packed variant (for kernel traces)")
+    ap.add_argument("--v3-only", action="store_true", help="with --only-chained: stop after the v3 variant")
     args = ap.parse_args()
     print(json.dumps(run(args.layers, args.bits, args.bs, args.prompt, args.tokens, args.eager,
-                         with_dense=not args.only_chained, only_chained=args.only_chained)))
+                         with_dense=not args.only_chained, only_chained=args.only_chained, v3_only=args.v3_only)))
 
 
 def decode_check(layers=2, bits=2):
@@ -350,6 +396,12 @@ def decode_check(layers=2, bits=2):
     torch.manual_seed(1)
     _, _, la3 = time_decode(model, 2, 0, 3, 32, dev, dtype, True)
     chain_equal = bool(torch.equal(lc, la3))
+    l3 = None
+    if model.v3_ok(2):
+        model.v3 = True
+        torch.manual_seed(1)
+        _, _, l3 = time_decode(model, 2, 0, 0, 32, dev, dtype, True)
+        model.v3 = False
     for blk in model.blocks:
         blk.fused = False
         blk.fused_attn = False
@@ -360,14 +412,14 @@ def decode_check(layers=2, bits=2):
     torch.manual_seed(1)
     _, _, ld = time_decode(model, 2, 0, 0, 32, dev, dtype, True)
     return (float((lq - ld).norm() / ld.norm()), float((lf - ld).norm() / ld.norm()), float((la - ld).norm() / ld.norm()),
-            chain_equal)
+            chain_equal, None if l3 is None else float((l3 - ld).norm() / ld.norm()))
 
 
 if __name__ == "__main__":
     if "--check" in sys.argv:
-        e1, e2, e3, ceq = decode_check()
+        e1, e2, e3, ceq, e4 = decode_check()
         print(json.dumps({"decode_logits_rel_err_packed_vs_dense_twin": e1, "fused_packed_vs_dense_twin": e2,
-                          "fused_packed_fused_attn_vs_dense_twin": e3,
+                          "fused_packed_fused_attn_vs_dense_twin": e3, "v3_vs_dense_twin": e4,
                           "chained_logits_bit_identical_to_fused_attn_after_4_tokens": ceq}))
     else:
         main()

@@ -1,0 +1,148 @@
+"""-m gpu: quipamd_decode_fused_gemm (csrc/decode_fused.hip) -- the whole chain between two dequant-GEMMs of a decode step in
+the consuming GEMM's prologue -- against the same chain evaluated step by step in fp64 from the packed layers' own tensors:
+
+    t    = [relu](U_prev^T y_prev + bias_prev + residual)   rounded to fp16 (the residual stream), stored
+    h    = LayerNorm / RMSNorm / identity (t)
+    y_i  = What_i V_i (h (/) s_i)
+
+Gates: t within 1e-3 (relative l2) and 2 fp16 ulps of the largest entry; y within 2e-3 -- the pass runs on fp16 factors and
+images (3e-4 per stage) and x~ is rounded to fp16 in front of the MFMA; the 1e-3 contract of the projection itself stays with
+the K3 kernels (split-bf16 / fp32), this path is the decode step's (logits gated against HF in tests/test_gpu_decode_hf.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _layer(d, m, seed, bias=True):
+    from quip_amd import ops, method
+    from quip_amd.quant import QuantLinear
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    W = (0.02 * torch.randn(m, d, device=DEV)).half()
+    s = ops.qfnb_scale(W)
+    What, codes = ops.quantize(W, 'b', s, None, 3, want_codes=True)
+    U = ops.OrthoOp(method.gen_rand_ortho_butterfly_noblock(m), DEV)
+    V = ops.OrthoOp(method.gen_rand_ortho_butterfly_noblock(d), DEV)
+    sWH = (0.5 + torch.rand(d)).to(DEV)
+    ql = QuantLinear(d, m, bits=2, qfn='b').to(DEV)
+    ql.pack(codes, s, None, bias=(0.1 * torch.randn(m, device=DEV)) if bias else None, scaleWH=sWH, U=U, V=V)
+    return ql, What.double()
+
+
+def _dense(op, transpose=False):
+    """the operator as a dense fp64 matrix (rows of apply_rows on the identity)"""
+    n = op.n
+    eye = torch.eye(n, device=DEV, dtype=torch.float32)
+    M = op.apply_rows(eye, transpose=transpose).double()     # row r = Q e_r  -> M[r, :] = column r of Q
+    return M.t().contiguous()
+
+
+def _norm64(t, ln):
+    if ln is None:
+        return t
+    g, b, eps = ln
+    if b is None:
+        return t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + eps) * g.double()
+    mu = t.mean(-1, keepdim=True)
+    var = (t - mu).pow(2).mean(-1, keepdim=True)
+    return (t - mu) * torch.rsqrt(var + eps) * g.double() + b.double()
+
+
+class _LN(torch.nn.Module):
+    def __init__(self, g, b, eps):
+        super().__init__()
+        self.weight, self.bias, self.eps = g, b, eps
+
+
+class _RMS(torch.nn.Module):
+    def __init__(self, g, eps):
+        super().__init__()
+        self.weight, self.variance_epsilon = g, eps
+
+
+CASES = [
+    # d, m, groups, has_u, norm, relu, residual, bs
+    (2048, 2048, 3, False, "ln", False, False, 1),
+    (2048, 2048, 3, True, "ln", False, True, 1),
+    (2048, 2048, 1, False, None, False, False, 2),
+    (2048, 8192, 1, True, "ln", False, True, 4),
+    (8192, 2048, 1, True, None, True, False, 1),
+    (8192, 2048, 1, True, None, True, False, 3),
+    (4096, 4096, 3, True, "rms", False, True, 1),
+    (4096, 11008 // 16 * 16, 2, False, "rms", False, False, 2),
+]
+
+
+@pytest.mark.parametrize("d,m,groups,has_u,norm,relu,residual,bs", CASES)
+def test_fused_stage_matches_the_chain_in_fp64(d, m, groups, has_u, norm, relu, residual, bs):
+    from quip_amd.quant import fused_stage, fused_ok
+    qls, Whats = zip(*[_layer(d, m, 100 + 7 * i + d % 97) for i in range(groups)])
+    prev = _layer(d if not has_u else 2048 if d == 8192 else d, d, 55)[0] if has_u else None     # prev: * -> d (its U is d wide)
+    torch.manual_seed(d + m + bs)
+    g = (1 + 0.1 * torch.randn(d, device=DEV)).half()
+    b = (0.05 * torch.randn(d, device=DEV)).half()
+    ln_mod = _LN(g, b, 1e-5) if norm == "ln" else _RMS(g, 1e-5) if norm == "rms" else None
+    ln64 = (g, b, 1e-5) if norm == "ln" else (g, None, 1e-5) if norm == "rms" else None
+    assert fused_ok(list(qls), bs, prev=prev)
+    if has_u:
+        y_prev = torch.randn(bs, d, device=DEV) * 0.5
+        res = (torch.randn(bs, d, device=DEV)).half() if residual else None
+        ys, t = fused_stage(list(qls), prev=prev, y_prev=y_prev, residual=res, relu=relu, ln=ln_mod, store=True)
+        Ut = _dense(prev.U, transpose=True)
+        t64 = y_prev.double() @ Ut.t() + prev.bias.double()
+        if res is not None:
+            t64 = t64 + res.double()
+        if relu:
+            t64 = torch.relu(t64)
+        tg = t.double()
+        rel_t = float((tg - t64).norm() / t64.norm())
+        assert rel_t <= 1e-3, rel_t
+        assert float((tg - t64).abs().max()) <= 2 * 2.0 ** -11 * float(t64.abs().max()) + 1e-3 * float(t64.abs().max())
+        h_in = tg                                            # downstream of the fp16 value the launch stored
+    else:
+        x = torch.randn(bs, d, device=DEV).half()
+        ys, t = fused_stage(list(qls), x=x, ln=ln_mod)
+        assert t is None
+        h_in = x.double()
+    h = _norm64(h_in, ln64)
+    for q, What, y in zip(qls, Whats, ys):
+        Vd = _dense(q.V)
+        xt = (h * q.inv_scaleWH.double()) @ Vd.t()
+        want = xt @ What.t()
+        rel = float((y.double() - want).norm() / want.norm())
+        assert rel <= 2e-3, rel
+    torch.cuda.synchronize()
+
+
+def test_fused_stage_agrees_with_the_round2_launches():
+    """the same OPT hand-over as three round-2 launches (tiled U^T + residual, V with LayerNorm, grouped GEMM) and as ONE fused launch"""
+    from quip_amd.quant import fused_stage, packed_u_stage, packed_v_stage, packed_gemm_stage
+    d, m, bs = 2048, 2048, 1
+    qls = [_layer(d, m, 300 + i)[0] for i in range(3)]
+    prev = _layer(8192, d, 400)[0]
+    torch.manual_seed(5)
+    ln = torch.nn.LayerNorm(d, device=DEV, dtype=torch.float16)
+    ln.weight.data.add_(0.1 * torch.randn(d, device=DEV).half())
+    ln.bias.data.add_(0.05 * torch.randn(d, device=DEV).half())
+    y_prev = torch.randn(bs, d, device=DEV)
+    res = torch.randn(bs, d, device=DEV).half()
+    t_old = packed_u_stage([prev], [y_prev], torch.float16, residual=res)[0]
+    ys_old = packed_gemm_stage(qls, packed_v_stage(qls, t_old, ln=ln))
+    ys, t = fused_stage(qls, prev=prev, y_prev=y_prev, residual=res, ln=ln, store=True)
+    assert float((t.float() - t_old.float()).abs().max()) <= 4 * 2.0 ** -11 * float(t_old.float().abs().max())
+    for a, b_ in zip(ys, ys_old):
+        assert float((a - b_).norm() / b_.norm()) <= 4e-3       # the round-2 path rounds x~ to bf16 (2^-9), this one to fp16
+
+
+def test_fused_stage_rejects_what_it_cannot_run():
+    from quip_amd import ops, _lib
+    from quip_amd.quant import fused_ok
+    ql = _layer(2048, 2048, 1)[0]
+    assert not fused_ok([ql], 5) and not fused_ok([ql], 1, x_dtype=torch.bfloat16)
+    a = ops.FusedGemmArgs()
+    a.act_dtype, a.bits, a.ngroups, a.bs = 2, 2, 1, 1
+    with pytest.raises(_lib.QuipAmdError):
+        _lib.call("quipamd_decode_fused_gemm", __import__("ctypes").byref(a), None)

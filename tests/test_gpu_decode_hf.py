@@ -177,13 +177,12 @@ def test_opt_decode_harness_matches_hf_with_past_key_values():
     if D.vgemm_fusable([dec.blocks[0].q_proj, dec.blocks[0].k_proj, dec.blocks[0].v_proj], 1):
         dec.vfused, dec.split_handover = True, True
         report["vfused_split_handover"] = _gate("vfused", harness_logits(dec, toks, maxpos, dtype), ref, toks)
-    if hasattr(dec, "best_variant"):
-        dec.best_variant()
-        report["best"] = _gate("best", harness_logits(dec, toks, maxpos, dtype), ref, toks)
+    assert dec.v3_ok(1)
+    dec.v3 = True                                            # csrc/decode_fused.hip: 6 launches per block
+    report["v3"] = _gate("v3", harness_logits(dec, toks, maxpos, dtype), ref, toks)
+    dec.v3 = False
     # and the dense harness (fp16 Linears with the twin weights): the architecture alone, no packed kernels
     dec.chained = dec.vfused = dec.split_handover = dec.tiled = False
-    for k in [a for a in vars(dec) if a.startswith("v3")]:
-        setattr(dec, k, False)
     for li, blk in enumerate(dec.blocks):
         blk.fused = blk.fused_attn = False
         for name in ["q_proj", "k_proj", "v_proj", "out_proj", "fc1", "fc2"]:
