@@ -31,6 +31,20 @@ namespace {
 
 constexpr int FG_MAXG = 3, FG_MAXBS = 4, FG_NW = 16;
 
+// lab builds (scripts/fusedlab.hip, -DFG_PROBE): s_memtime stamps of wave 0 of workgroup (FG_PROBE_WG, 0) at the phase boundaries
+#ifdef FG_PROBE
+__device__ unsigned long long fg_probe_buf[32];
+#ifndef FG_PROBE_WG
+#define FG_PROBE_WG 0
+#endif
+#define FG_STAMP(i)                                                                                                   \
+    do {                                                                                                              \
+        if (blockIdx.x == FG_PROBE_WG && blockIdx.y == 0 && threadIdx.x == 0) fg_probe_buf[i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define FG_STAMP(i)
+#endif
+
 typedef quipamd_fop Fop;
 
 struct FusedArgs {
@@ -236,6 +250,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     const int j = lane & 15, g = lane >> 4;
     const uint32_t rt = blockIdx.x * RT + r;
     const int bs = G.bs;
+    FG_STAMP(0);
 
     // ---- requested first: this wave's packed weights (HBM), then the factor fragments of the first pass ----------------------------
     uint4 w[CPW];
@@ -278,10 +293,14 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                     if (G.u_res) rs[u] = *reinterpret_cast<const uint2 *>(G.u_res + (int64_t)b * G.ld_res + 4 * v4);
                 }
             }
+            FG_STAMP(1);                                                         // first loads landed, scatter done
             __syncthreads();
+            FG_STAMP(2);
             mix_stages<P, Q>(G.U, ZT, Z1, ZF, fr, wave, lane);
             load_frags<P, Q>(V, wave, lane, fr);                                // the V-side fragments travel under the gather + norm
+            FG_STAMP(3);
             __syncthreads();
+            FG_STAMP(4);
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const int v4 = tid + 1024 * u;
@@ -306,6 +325,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                 if (v4 < N / 4) tv[u] = f16x4_to_f32(*reinterpret_cast<const uint2 *>(G.x + (int64_t)b * G.ldx + 4 * v4));
             }
         }
+        FG_STAMP(5);                                                             // t in registers (gather / x load done)
         // operands of the V-side scatter / gather: requested before the reductions
         uint2 gm[NV], bt_[NV];
         float4 cs[NV];
@@ -347,6 +367,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                                     (tv[u].z - mean) * rstd * gmf.z + btf.z, (tv[u].w - mean) * rstd * gmf.w + btf.w);
             }
         }
+        FG_STAMP(6);                                                             // norm done
         // ---- x~ = V (h (/) s) ------------------------------------------------------------------------------------------------------
         // (ZT is free: with a U pass its last readers finished before the barrier in front of the gather; ZF's readers -- the gather
         //  above -- finish before the barrier after this scatter, and ZF is written only after the barrier inside mix_stages)
@@ -357,10 +378,14 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                 scatter4<P, Q>(ZT, v, vld[u]);
             }
         }
+        FG_STAMP(7);
         __syncthreads();
+        FG_STAMP(8);
         mix_stages<P, Q>(V, ZT, Z1, ZF, fr, wave, lane);
         if (HAS_U && b + 1 < bs) load_frags<P, Q>(G.U, wave, lane, fr);        // next batch row starts with the U pass again
+        FG_STAMP(9);
         __syncthreads();
+        FG_STAMP(10);
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int v4 = tid + 1024 * u;
@@ -372,7 +397,9 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                 *reinterpret_cast<uint2 *>(XT + (size_t)b * XTS + 4 * v4) = pk;
             }
         }
+        FG_STAMP(11);
         __syncthreads();                                                        // x~ row complete; ZF / ZT free for the next row (or park)
+        FG_STAMP(12);
     }
 
     // ---- dequant + MFMA: this wave's CPW chunks of 256 columns x 16 rows -------------------------------------------------------------
@@ -397,6 +424,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
             }
         }
     }
+    FG_STAMP(13);                                                               // MFMAs issued (weights landed)
     float *xpark = park + FG_NW * 256;
     {
         float *p = park + (slot * RT + r) * 256 + lane;
@@ -408,6 +436,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         }
     }
     __syncthreads();
+    FG_STAMP(14);
     if (wave < RT) {                                                            // one reducer wave per row tile: lane = (batch row, row in tile)
         const int r2 = wave, bb = lane >> 4, wr = lane & 15;
         const int src = (wr & 3) * 64 + bb + 16 * (wr >> 2);                   // [acc component][mfma lane (j = bb, g = wr / 4)]
@@ -420,6 +449,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         const int64_t row = (int64_t)(blockIdx.x * RT + r2) * 16 + wr;
         if (bb < bs) G.y[gi][(int64_t)bb * G.m + row] = e_sc * two_over_maxq * (a - c0 * xsum);
     }
+    FG_STAMP(15);
 }
 
 template <int P, int Q> constexpr size_t fused_lds()

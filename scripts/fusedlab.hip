@@ -1,0 +1,125 @@
+// fusedlab.hip -- lab harness for csrc/decode_fused.hip: times quipamd_decode_fused_gemm on the decode shapes of OPT-1.3B and prints
+// the s_memtime phase stamps of wave 0 of one workgroup (built with -DFG_PROBE; scripts/fusedlab.sh).  Synthetic operands (random
+// permutations, random codes): the timings do not depend on the values.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+#include <numeric>
+#include <algorithm>
+#include <random>
+#include "../quip_amd/csrc/decode_fused.hip"
+
+int qa_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "\n");
+    return code;
+}
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <class T> T *dev_alloc(size_t n, bool randomize = true)
+{
+    std::vector<unsigned char> h(n * sizeof(T));
+    static std::mt19937 rng(1);
+    for (auto &b : h) b = randomize ? (unsigned char)(rng() & 0x3f) : 0;          // small patterns: finite as f16 / f32
+    T *d;
+    CK(hipMalloc(&d, n * sizeof(T)));
+    CK(hipMemcpy(d, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+uint16_t *dev_perm(int n)
+{
+    std::vector<uint16_t> p(n);
+    std::iota(p.begin(), p.end(), 0);
+    static std::mt19937 rng(7);
+    std::shuffle(p.begin(), p.end(), rng);
+    uint16_t *d;
+    CK(hipMalloc(&d, n * 2));
+    CK(hipMemcpy(d, p.data(), n * 2, hipMemcpyHostToDevice));
+    return d;
+}
+quipamd_fop make_fop(int p, int q)
+{
+    quipamd_fop o;
+    o.F0 = dev_alloc<uint16_t>((size_t)p * p);
+    o.F1 = dev_alloc<uint16_t>((size_t)q * q);
+    o.load_idx = dev_perm(p * q);
+    o.store_idx = dev_perm(p * q);
+    o.p = p;
+    o.q = q;
+    return o;
+}
+
+void run(const char *name, int p, int q, int64_t m, int groups, bool has_u, int norm, int bs, int ncopies)
+{
+    const int n = p * q;
+    std::vector<quipamd_fused_gemm_args> args(ncopies);
+    for (int c = 0; c < ncopies; ++c) {                      // distinct weights per copy: every launch streams cold codes
+        quipamd_fused_gemm_args &a = args[c];
+        memset(&a, 0, sizeof(a));
+        a.act_dtype = QUIPAMD_F16; a.bits = 2; a.has_u = has_u; a.norm = norm; a.ln_eps = 1e-5f; a.ngroups = groups; a.bs = bs; a.m = m;
+        if (c == 0) {
+            a.U = make_fop(p, q);
+            a.u_y = dev_alloc<float>((size_t)bs * n); a.u_bias = dev_alloc<float>(n); a.u_residual = dev_alloc<uint16_t>((size_t)bs * n);
+            a.ld_residual = n; a.t_out = dev_alloc<uint16_t>((size_t)bs * n); a.ld_t = n; a.x = dev_alloc<uint16_t>((size_t)bs * n); a.ldx = n;
+            a.ln_gamma = dev_alloc<uint16_t>(n); a.ln_beta = dev_alloc<uint16_t>(n);
+            for (int g = 0; g < groups; ++g) {
+                a.V[g] = make_fop(p, q);
+                a.colscale[g] = dev_alloc<float>(n); a.scale[g] = dev_alloc<float>(1); a.y[g] = dev_alloc<float>((size_t)bs * m, false);
+            }
+        } else a = args[0];
+        for (int g = 0; g < groups; ++g) a.qweight[g] = dev_alloc<int32_t>((size_t)m * n / 16);
+    }
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    for (int i = 0; i < 5; ++i) if (quipamd_decode_fused_gemm(&args[i % ncopies], s)) exit(2);
+    CK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int K = 400;
+    hipGraph_t graph; hipGraphExec_t exec;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < K; ++i) quipamd_decode_fused_gemm(&args[i % ncopies], s);
+    CK(hipStreamEndCapture(s, &graph));
+    CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(exec, s)); CK(hipStreamSynchronize(s));
+    CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(exec, s)); CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-28s p=%d q=%d m=%lld groups=%d u=%d norm=%d bs=%d : %.3f us per launch (graph of %d, cold weights x%d)\n", name, p, q,
+           (long long)m, groups, (int)has_u, norm, bs, ms * 1e3 / K, K, ncopies);
+#ifdef FG_PROBE
+    CK(hipStreamSynchronize(s));
+    quipamd_decode_fused_gemm(&args[1 % ncopies], s);
+    CK(hipStreamSynchronize(s));
+    unsigned long long st[32];
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(fg_probe_buf), sizeof(st)));
+    static const char *nm[16] = {"start", "U loads+scatter", "barrier", "U mix", "barrier", "gather / x load", "norm", "V scatter", "barrier",
+                                 "V mix", "barrier", "x~ write", "barrier", "weights + MFMA", "park barrier", "reduce + store"};
+    printf("    phase stamps of wave 0 (cycles since start; delta):\n");
+    unsigned long long prev = st[0];
+    for (int i = 1; i < 16; ++i) {
+        if (!has_u && i >= 1 && i <= 4) continue;
+        printf("      %-18s %7llu  (+%llu)\n", nm[i], st[i] - st[0], st[i] - prev);
+        prev = st[i];
+    }
+#endif
+}
+
+int main()
+{
+    run("L3 out_proj (V only)", 64, 32, 2048, 1, false, 0, 1, 48);
+    run("L1 qkv block 0 (LN, V)", 64, 32, 2048, 3, false, 1, 1, 16);
+    run("L1 qkv (U, LN, V)", 64, 32, 2048, 3, true, 1, 1, 16);
+    run("L4 fc1 (U, LN, V)", 64, 32, 8192, 1, true, 1, 1, 16);
+    run("L6 fc2 (U relu, V)", 128, 64, 2048, 1, true, 0, 1, 16);
+    run("llama qkv (U, RMS, V)", 64, 64, 4096, 3, true, 2, 1, 8);
+    return 0;
+}
