@@ -255,6 +255,9 @@ int quipamd_dequant_gemm_vop(const quipamd_small_op *vops, const int32_t *const 
 /* ---- decode: one launch per packed Linear group, everything between two GEMMs in the consumer's prologue ------------------------
  * (csrc/decode_fused.hip; the decode loop of benchmark(), opt.py:431-482 / llama.py:418-471, batch <= 4)
  *     t    = [relu]( U_prev^T u_y + u_bias + u_residual )      optional (has_u): the output side of the PREVIOUS packed layer;
+ *                                                              u_bias float [d] and u_residual fp16 [bs, ld_residual] are both
+ *                                                              required (zeros where the layer has none: every operand load of the
+ *                                                              prologue is unconditional and issued in the kernel's first instructions);
  *                                                              t is stored to t_out (fp16, the new residual stream) when not NULL
  *     h    = norm(t)  (norm 0: none, 1: LayerNorm gamma / beta, 2: RMSNorm gamma; fp32 statistics, eps)      [t = x without has_u]
  *     x~_i = V_i ( h (/) s_i ),   y_i = What_i x~_i            i < ngroups <= 3 (q / k / v; gate / up), fp32 y [bs, m]

@@ -47,26 +47,32 @@ __device__ unsigned long long fg_probe_buf[32];
 
 typedef quipamd_fop Fop;
 
+struct FGroup {                           // one packed layer of the launch (blockIdx.y): 72 bytes of kernarg, fetched together
+    Fop V;
+    const float *colscale;
+    const uint4 *qw;
+    const float *scale;
+    float *y;
+};
+
 struct FusedArgs {
     Fop U;
-    const float *u_y, *u_bias;            // [bs, n] fp32; [n] fp32 or null
-    const uint16_t *u_res;                // [bs, ld_res] f16 or null
+    const float *u_y, *u_bias;            // [bs, n] fp32; [n] fp32 (zeros when the layer has no bias)
+    const uint16_t *u_res;                // [bs, ld_res] f16 (zeros when there is no residual)
     uint16_t *t_out;                      // [bs, ld_t] f16 or null
     int64_t ld_res, ld_t;
-    int u_relu;
     const uint16_t *x;                    // !HAS_U: [bs, ldx] f16
     int64_t ldx;
-    int norm;                             // 0 none, 1 LayerNorm, 2 RMSNorm
     const uint16_t *gamma, *beta;
-    float eps;
-    Fop V[FG_MAXG];
-    const float *colscale[FG_MAXG];
-    const uint4 *qw[FG_MAXG];
-    const float *scale[FG_MAXG];
-    float *y[FG_MAXG];
+    float eps, floor;                     // floor: 0 (relu) or -inf
     int bs;
     int64_t m;
+    FGroup g[FG_MAXG];
 };
+
+// keep a kernarg pointer's scalar load where it is written: hipcc fetches kernarg fields lazily, one s_load + s_waitcnt per first
+// use, and the prologue of this kernel was SEVEN serial kernarg round trips (~2000 cycles) before its first global load
+template <class T> __device__ __forceinline__ void touch_s(T *p) { asm volatile("" ::"s"(p)); }
 
 __device__ __forceinline__ uint32_t pack_f16x2(float a, float b)
 {
@@ -122,26 +128,30 @@ template <int P, int Q> struct PassDims {
     static_assert(P % 32 == 0 && Q % 32 == 0 && (Q & (Q - 1)) == 0, "operator shape");
 };
 
-// this wave's factor fragments (host layout: F0 [P/16][P/32][64 lanes] uint4, F1 [Q/16][Q/32][64] uint4).  The stage-1 set is
-// requested a phase ahead by the caller, the stage-2 set at the top of mix_stages (it lands under stage 1 and its barrier):
-// holding both from kernel start spilled registers at 128 x 64 (1024 threads = 128 VGPRs per lane)
+// this wave's factor fragments (host layout: F0 [P/16][P/32][64 lanes] uint4, F1 [Q/16][Q/32][64] uint4).  A wave's tiles are
+// wave, wave + 16, ...: because 16 is a multiple of P/16 and of Q/16 they all share the stage-1 fragment (it depends on at = tile %
+// (P/16) only) and the stage-2 fragment (bt = tile % (Q/16)): ONE set per wave, loaded straight from global memory in fragment order.
 template <int P, int Q> struct PassFrags {
-    uint4 f0[PassDims<P, Q>::TPW][PassDims<P, Q>::S0];
+    uint4 f0[PassDims<P, Q>::S0];
+    uint4 f1[PassDims<P, Q>::S1];
 };
 
-template <int P, int Q> __device__ __forceinline__ void load_frags(const Fop &op, int wave, int lane, PassFrags<P, Q> &fr)
+template <int P, int Q> __device__ __forceinline__ void load_f0(const Fop &op, int wave, int lane, PassFrags<P, Q> &fr)
 {
     typedef PassDims<P, Q> D;
+    static_assert(FG_NW % (P / 16) == 0 && FG_NW % (Q / 16) == 0, "a wave's tiles share their fragments");
     const uint4 *F0 = reinterpret_cast<const uint4 *>(op.F0);
+    const int at = wave % (P / 16);
 #pragma unroll
-    for (int i = 0; i < D::TPW; ++i) {
-        const int tile = wave + FG_NW * i;
-        if (tile < D::NT) {
-            const int at = tile % (P / 16);              // stage 1 tile = (bt, at): its B fragment depends on at only
+    for (int S = 0; S < D::S0; ++S) fr.f0[S] = F0[(at * D::S0 + S) * 64 + lane];
+}
+template <int P, int Q> __device__ __forceinline__ void load_f1(const Fop &op, int wave, int lane, PassFrags<P, Q> &fr)
+{
+    typedef PassDims<P, Q> D;
+    const uint4 *F1 = reinterpret_cast<const uint4 *>(op.F1);
+    const int bt = wave % (Q / 16);
 #pragma unroll
-            for (int S = 0; S < D::S0; ++S) fr.f0[i][S] = F0[(at * D::S0 + S) * 64 + lane];
-        }
-    }
+    for (int S = 0; S < D::S1; ++S) fr.f1[S] = F1[(bt * D::S1 + S) * 64 + lane];
 }
 
 // scatter 4 consecutive natural-order values into the stage-1 input image: value e goes to image position pos[e] = (a, b) -> ZT[b][a]
@@ -157,23 +167,10 @@ template <int P, int Q> __device__ __forceinline__ void scatter4(uint16_t *ZT, c
 
 // the two mix stages: ZT -> Z1 -> ZF.  Caller: a barrier after the scatter; this function ends WITHOUT a barrier after writing ZF.
 template <int P, int Q>
-__device__ __forceinline__ void mix_stages(const Fop &op, const uint16_t *ZT, uint16_t *Z1, float *ZF, const PassFrags<P, Q> &fr, int wave, int lane)
+__device__ __forceinline__ void mix_stages(const uint16_t *ZT, uint16_t *Z1, float *ZF, const PassFrags<P, Q> &fr, int wave, int lane)
 {
     typedef PassDims<P, Q> D;
     const int j = lane & 15, g = lane >> 4;
-    uint4 f1[D::TPW][D::S1];
-    {
-        const uint4 *F1 = reinterpret_cast<const uint4 *>(op.F1);
-#pragma unroll
-        for (int i = 0; i < D::TPW; ++i) {
-            const int tile = wave + FG_NW * i;
-            if (tile < D::NT) {
-                const int bt2 = tile % (Q / 16);         // stage 2 tile = (at, bt): its B fragment depends on bt only
-#pragma unroll
-                for (int S = 0; S < D::S1; ++S) f1[i][S] = F1[(bt2 * D::S1 + S) * 64 + lane];
-            }
-        }
-    }
     // stage 1, transposed: D1[m = b][n = a] = sum_a' ZT[b][a'] M0[a][a'];  A = ZT rows (LDS), B = M0 rows (registers)
 #pragma unroll
     for (int i = 0; i < D::TPW; ++i) {
@@ -185,7 +182,7 @@ __device__ __forceinline__ void mix_stages(const Fop &op, const uint16_t *ZT, ui
 #pragma unroll
             for (int S = 0; S < D::S0; ++S) {
                 const uint4 a = *reinterpret_cast<const uint4 *>(arow + 32 * S);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, fr.f0[i][S]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, fr.f0[S]), acc, 0, 0, 0);
             }
             // lane: a = 16 at + j, b = 16 bt + 4 g + {0..3}: four consecutive b of row a -> one 8-byte store
             uint2 pk;
@@ -206,7 +203,7 @@ __device__ __forceinline__ void mix_stages(const Fop &op, const uint16_t *ZT, ui
 #pragma unroll
             for (int S = 0; S < D::S1; ++S) {
                 const uint4 a = *reinterpret_cast<const uint4 *>(arow + 32 * S);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, f1[i][S]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, fr.f1[S]), acc, 0, 0, 0);
             }
             // lane: b = 16 bt + j, a = 16 at + 4 g + reg
 #pragma unroll
@@ -225,13 +222,17 @@ template <int P, int Q> __device__ __forceinline__ float4 gather4(const float *Z
 }
 
 // ---- the fused launch ------------------------------------------------------------------------------------------------------------
-// grid = (m / (16 RT), ngroups); 1024 threads = 16 waves = (16 / RT chunk slots) x RT row tiles; d = P Q = 256 (16 / RT) CPW
-template <int P, int Q, bool HAS_U, int RT, int CPW>
+// grid = (m / (16 RT), ngroups); 1024 threads = 16 waves = (16 / RT chunk slots) x RT row tiles; d = P Q = 256 (16 / RT) CPW.
+// NORM: 0 none, 1 LayerNorm, 2 RMSNorm.  Every global operand of the prologue is requested in the first instructions of the kernel
+// (EARLY: all of them when a thread owns one 4-element slot, n <= 4096; at n = 8192 the V-side set follows the U-side scatter, the
+// register file does not hold both): the phases between the barriers then run on registers and LDS only.
+template <int P, int Q, bool HAS_U, int NORM, int RT, int CPW>
 __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two_over_maxq, float c0)
 {
     typedef PassDims<P, Q> D;
     typedef DeqT<2, ActF16> DQ;
     constexpr int N = D::N, NV = D::NV, NS = FG_NW / RT, NCH = N / 256, XTS = N + 8;      // x~ row stride (halves)
+    constexpr bool EARLY = NV == 1;
     static_assert(NS * CPW == NCH, "chunks = slots x chunks per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint16_t *XT = reinterpret_cast<uint16_t *>(smem);                         // [bs][N + 8] f16
@@ -244,6 +245,15 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     float *red = reinterpret_cast<float *>(pass + (D::BYTES > PARK_B ? D::BYTES : PARK_B));            // [2][16]
 
     const int gi = blockIdx.y;
+    const FGroup &Gg = G.g[gi];
+    const Fop &V = Gg.V;
+    // all kernarg pointers of the prologue in ONE round trip
+    touch_s(Gg.qw); touch_s(V.F0); touch_s(V.F1); touch_s(V.load_idx); touch_s(V.store_idx); touch_s(Gg.colscale); touch_s(Gg.scale);
+    if (HAS_U) { touch_s(G.U.F0); touch_s(G.U.F1); touch_s(G.U.load_idx); touch_s(G.U.store_idx); touch_s(G.u_y); touch_s(G.u_bias); touch_s(G.u_res); }
+    else touch_s(G.x);
+    if (NORM) touch_s(G.gamma);
+    if (NORM == 1) touch_s(G.beta);
+
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = wave / RT, r = wave - slot * RT;
@@ -252,52 +262,91 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     const int bs = G.bs;
     FG_STAMP(0);
 
-    // ---- requested first: this wave's packed weights (HBM), then the factor fragments of the first pass ----------------------------
+    // ---- requested first: this wave's packed weights (HBM; streamed once: nt), then every operand of the prologue ------------------
     uint4 w[CPW];
 #pragma unroll
-    for (int i = 0; i < CPW; ++i) w[i] = (G.qw[gi] + ((uint64_t)rt * NCH + (slot * CPW + i)) * 64)[lane];
-    const float e_sc = G.scale[gi][0];
-    PassFrags<P, Q> fr;
-    const Fop &V = G.V[gi];
-    load_frags<P, Q>(HAS_U ? G.U : V, wave, lane, fr);
+    for (int i = 0; i < CPW; ++i) {
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Gg.qw + ((uint64_t)rt * NCH + (slot * CPW + i)) * 64 + lane));
+        w[i] = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+    PassFrags<P, Q> frU, frV;
+    float4 yv[NV], bi[NV], cs[NV];
+    uint2 ld[NV], st[NV], rs[NV], gm[NV], bt_[NV], vld[NV], vst[NV], xr[NV];
+    auto load_u_row = [&](int b) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int v4 = tid + 1024 * u;
+            if (v4 < N / 4) {
+                yv[u] = *reinterpret_cast<const float4 *>(G.u_y + (int64_t)b * N + 4 * v4);
+                rs[u] = *reinterpret_cast<const uint2 *>(G.u_res + (int64_t)b * G.ld_res + 4 * v4);
+            }
+        }
+    };
+    auto load_u_side = [&]() {
+        load_f0<P, Q>(G.U, wave, lane, frU);
+        load_f1<P, Q>(G.U, wave, lane, frU);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int v4 = tid + 1024 * u;
+            if (v4 < N / 4) {
+                ld[u] = *reinterpret_cast<const uint2 *>(G.U.load_idx + 4 * v4);
+                st[u] = *reinterpret_cast<const uint2 *>(G.U.store_idx + 4 * v4);
+                bi[u] = *reinterpret_cast<const float4 *>(G.u_bias + 4 * v4);
+            }
+        }
+    };
+    auto load_v_frags = [&]() {
+        load_f0<P, Q>(V, wave, lane, frV);
+        load_f1<P, Q>(V, wave, lane, frV);
+    };
+    auto load_v_side = [&]() {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int v4 = tid + 1024 * u;
+            gm[u] = bt_[u] = make_uint2(0u, 0u);
+            if (v4 < N / 4) {
+                if (NORM) gm[u] = *reinterpret_cast<const uint2 *>(G.gamma + 4 * v4);
+                if (NORM == 1) bt_[u] = *reinterpret_cast<const uint2 *>(G.beta + 4 * v4);
+                cs[u] = *reinterpret_cast<const float4 *>(Gg.colscale + 4 * v4);
+                vld[u] = *reinterpret_cast<const uint2 *>(V.load_idx + 4 * v4);
+                vst[u] = *reinterpret_cast<const uint2 *>(V.store_idx + 4 * v4);
+            }
+        }
+    };
+    auto load_x_row = [&](int b) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int v4 = tid + 1024 * u;
+            xr[u] = make_uint2(0u, 0u);
+            if (v4 < N / 4) xr[u] = *reinterpret_cast<const uint2 *>(G.x + (int64_t)b * G.ldx + 4 * v4);
+        }
+    };
+    if (HAS_U) {
+        load_u_row(0);
+        load_u_side();
+    } else load_x_row(0);
+    if (EARLY || !HAS_U) {
+        load_v_frags();
+        load_v_side();
+    }
 
     for (int b = 0; b < bs; ++b) {
         float4 tv[NV];
         if (HAS_U) {
             // ---- t = [relu](U^T y + bias + residual) --------------------------------------------------------------------------------
-            float4 yv[NV];
-            uint2 ld[NV];
-#pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                const int v4 = tid + 1024 * u;
-                if (v4 < N / 4) {
-                    yv[u] = *reinterpret_cast<const float4 *>(G.u_y + (int64_t)b * N + 4 * v4);
-                    ld[u] = *reinterpret_cast<const uint2 *>(G.U.load_idx + 4 * v4);
-                }
+            if (b > 0) {
+                load_u_row(b);
+                if (!EARLY) load_u_side();                                       // n = 8192: nothing row-independent stays in registers across a row
             }
 #pragma unroll
             for (int u = 0; u < NV; ++u)
                 if (tid + 1024 * u < N / 4) scatter4<P, Q>(ZT, yv[u], ld[u]);
-            // operands of the gather, requested one phase ahead (after the scatter: its temporaries need the registers at 128 x 64)
-            uint2 st[NV];
-            float4 bi[NV];
-            uint2 rs[NV];
-#pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                const int v4 = tid + 1024 * u;
-                bi[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                rs[u] = make_uint2(0u, 0u);
-                if (v4 < N / 4) {
-                    st[u] = *reinterpret_cast<const uint2 *>(G.U.store_idx + 4 * v4);
-                    if (G.u_bias) bi[u] = *reinterpret_cast<const float4 *>(G.u_bias + 4 * v4);
-                    if (G.u_res) rs[u] = *reinterpret_cast<const uint2 *>(G.u_res + (int64_t)b * G.ld_res + 4 * v4);
-                }
-            }
+            if (!EARLY) load_v_side();                                          // n = 8192: the V-side set travels under the U pass
             FG_STAMP(1);                                                         // first loads landed, scatter done
             __syncthreads();
             FG_STAMP(2);
-            mix_stages<P, Q>(G.U, ZT, Z1, ZF, fr, wave, lane);
-            load_frags<P, Q>(V, wave, lane, fr);                                // the V-side fragments travel under the gather + norm
+            mix_stages<P, Q>(ZT, Z1, ZF, frU, wave, lane);
+            if (!EARLY) load_v_frags();                                         // ... and its fragments under the gather (registers)
             FG_STAMP(3);
             __syncthreads();
             FG_STAMP(4);
@@ -308,8 +357,8 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                 if (v4 < N / 4) {
                     float4 t = gather4<P, Q>(ZF, st[u]);
                     const float4 rr = f16x4_to_f32(rs[u]);
-                    t = make_float4(t.x + bi[u].x + rr.x, t.y + bi[u].y + rr.y, t.z + bi[u].z + rr.z, t.w + bi[u].w + rr.w);
-                    if (G.u_relu) t = make_float4(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f));
+                    t = make_float4(fmaxf(t.x + bi[u].x + rr.x, G.floor), fmaxf(t.y + bi[u].y + rr.y, G.floor),
+                                    fmaxf(t.z + bi[u].z + rr.z, G.floor), fmaxf(t.w + bi[u].w + rr.w, G.floor));
                     uint2 pk;                                                    // the residual stream is fp16: everything downstream sees the rounded value
                     pk.x = pack_f16x2(t.x, t.y);
                     pk.y = pack_f16x2(t.z, t.w);
@@ -318,34 +367,14 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                 }
             }
         } else {
+            if (b > 0) load_x_row(b);
 #pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                const int v4 = tid + 1024 * u;
-                tv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (v4 < N / 4) tv[u] = f16x4_to_f32(*reinterpret_cast<const uint2 *>(G.x + (int64_t)b * G.ldx + 4 * v4));
-            }
+            for (int u = 0; u < NV; ++u) tv[u] = f16x4_to_f32(xr[u]);
         }
         FG_STAMP(5);                                                             // t in registers (gather / x load done)
-        // operands of the V-side scatter / gather: requested before the reductions
-        uint2 gm[NV], bt_[NV];
-        float4 cs[NV];
-        uint2 vld[NV], vst[NV];
-#pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const int v4 = tid + 1024 * u;
-            gm[u] = bt_[u] = make_uint2(0u, 0u);
-            cs[u] = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (v4 < N / 4) {
-                if (G.norm) gm[u] = *reinterpret_cast<const uint2 *>(G.gamma + 4 * v4);
-                if (G.norm == 1) bt_[u] = *reinterpret_cast<const uint2 *>(G.beta + 4 * v4);
-                cs[u] = *reinterpret_cast<const float4 *>(G.colscale[gi] + 4 * v4);
-                vld[u] = *reinterpret_cast<const uint2 *>(V.load_idx + 4 * v4);
-                vst[u] = *reinterpret_cast<const uint2 *>(V.store_idx + 4 * v4);
-            }
-        }
-        if (G.norm) {
+        if (NORM) {
             float mean = 0.f;
-            if (G.norm == 1) {
+            if (NORM == 1) {
                 float s1 = 0.f;
 #pragma unroll
                 for (int u = 0; u < NV; ++u) s1 += (tv[u].x + tv[u].y) + (tv[u].z + tv[u].w);
@@ -381,8 +410,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         FG_STAMP(7);
         __syncthreads();
         FG_STAMP(8);
-        mix_stages<P, Q>(V, ZT, Z1, ZF, fr, wave, lane);
-        if (HAS_U && b + 1 < bs) load_frags<P, Q>(G.U, wave, lane, fr);        // next batch row starts with the U pass again
+        mix_stages<P, Q>(ZT, Z1, ZF, frV, wave, lane);
         FG_STAMP(9);
         __syncthreads();
         FG_STAMP(10);
@@ -403,6 +431,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     }
 
     // ---- dequant + MFMA: this wave's CPW chunks of 256 columns x 16 rows -------------------------------------------------------------
+    const float e_sc = Gg.scale[0];                                             // needed by the reducer only: its latency hides under the MFMAs
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     float xs = 0.f;
     const bool live = j < bs;                                                   // MFMA column j = batch row j
@@ -447,7 +476,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
             xsum += xpark[v * 64 + bb];
         }
         const int64_t row = (int64_t)(blockIdx.x * RT + r2) * 16 + wr;
-        if (bb < bs) G.y[gi][(int64_t)bb * G.m + row] = e_sc * two_over_maxq * (a - c0 * xsum);
+        if (bb < bs) Gg.y[(int64_t)bb * G.m + row] = e_sc * two_over_maxq * (a - c0 * xsum);
     }
     FG_STAMP(15);
 }
@@ -459,10 +488,10 @@ template <int P, int Q> constexpr size_t fused_lds()
     return (size_t)FG_MAXBS * (D::N + 8) * 2 + (D::BYTES > parkb ? D::BYTES : parkb) + 2 * FG_NW * 4 + 64;
 }
 
-template <int P, int Q, bool HAS_U, int RT, int CPW> int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
+template <int P, int Q, bool HAS_U, int NORM, int RT, int CPW> int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
 {
     const size_t lds = fused_lds<P, Q>();
-    auto kern = fused_gemm_kernel<P, Q, HAS_U, RT, CPW>;
+    auto kern = fused_gemm_kernel<P, Q, HAS_U, NORM, RT, CPW>;
     static QaPerDevice attr;
     const int d = attr.dev();
     if (d < 0 || !attr.done[d]) {
@@ -474,6 +503,14 @@ template <int P, int Q, bool HAS_U, int RT, int CPW> int launch_fused(const Fuse
     kern<<<dim3((unsigned)(A.m / 16 / RT), (unsigned)ngroups), 1024, lds, s>>>(A, 2.0f / maxq, DeqT<2, ActF16>::OFF + 0.5f * maxq);
     QA_LAUNCH_CHECK("quipamd_decode_fused_gemm");
     return QUIPAMD_OK;
+}
+
+template <int P, int Q, int RT, int CPW> int dispatch_fused(const FusedArgs &A, bool u, int norm, int ngroups, hipStream_t s)
+{
+    if (u) return norm == 0 ? launch_fused<P, Q, true, 0, RT, CPW>(A, ngroups, s)
+                 : norm == 1 ? launch_fused<P, Q, true, 1, RT, CPW>(A, ngroups, s) : launch_fused<P, Q, true, 2, RT, CPW>(A, ngroups, s);
+    return norm == 0 ? launch_fused<P, Q, false, 0, RT, CPW>(A, ngroups, s)
+         : norm == 1 ? launch_fused<P, Q, false, 1, RT, CPW>(A, ngroups, s) : launch_fused<P, Q, false, 2, RT, CPW>(A, ngroups, s);
 }
 
 bool fop_ok(const quipamd_fop &o, int p, int q) { return o.F0 && o.F1 && o.load_idx && o.store_idx && o.p == p && o.q == q; }
@@ -493,16 +530,18 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
     FusedArgs A;
     A.U = a->U;
     A.u_y = a->u_y; A.u_bias = a->u_bias; A.u_res = (const uint16_t *)a->u_residual; A.t_out = (uint16_t *)a->t_out;
-    A.ld_res = a->ld_residual; A.ld_t = a->ld_t; A.u_relu = a->u_relu;
+    A.ld_res = a->ld_residual; A.ld_t = a->ld_t; A.floor = a->u_relu ? 0.f : -INFINITY;
     A.x = (const uint16_t *)a->x; A.ldx = a->ldx;
-    A.norm = a->norm; A.gamma = (const uint16_t *)a->ln_gamma; A.beta = (const uint16_t *)a->ln_beta; A.eps = a->ln_eps;
+    A.gamma = (const uint16_t *)a->ln_gamma; A.beta = (const uint16_t *)a->ln_beta; A.eps = a->ln_eps;
     A.bs = (int)a->bs; A.m = a->m;
     QA_REQUIRE(a->norm >= 0 && a->norm <= 2 && (a->norm == 0 || a->ln_gamma) && (a->norm != 1 || a->ln_beta), QUIPAMD_ERR_ARG,
                "decode_fused_gemm: norm %d needs gamma (and beta for LayerNorm)", a->norm);
     if (a->has_u) {
         QA_REQUIRE(!a->t_out || a->t_out != a->u_residual, QUIPAMD_ERR_ARG, "decode_fused_gemm: t_out must not alias u_residual");
-        QA_REQUIRE(fop_ok(a->U, p, q) && a->u_y, QUIPAMD_ERR_ARG, "decode_fused_gemm: the output-side operator must be %d x %d like the activation-side one", p, q);
-        QA_REQUIRE((!a->u_residual || (a->ld_residual >= n && a->ld_residual % 4 == 0)) && (!a->t_out || (a->ld_t >= n && a->ld_t % 4 == 0)),
+        QA_REQUIRE(fop_ok(a->U, p, q) && a->u_y && a->u_bias && a->u_residual, QUIPAMD_ERR_ARG,
+                   "decode_fused_gemm: the output-side operator must be %d x %d like the activation-side one, with u_y, u_bias and "
+                   "u_residual (zeros where a layer has none)", p, q);
+        QA_REQUIRE(a->ld_residual >= n && a->ld_residual % 4 == 0 && (!a->t_out || (a->ld_t >= n && a->ld_t % 4 == 0)),
                    QUIPAMD_ERR_SHAPE, "decode_fused_gemm: residual / t_out row strides");
     } else {
         QA_REQUIRE(a->x && a->ldx >= n && a->ldx % 4 == 0, QUIPAMD_ERR_ARG, "decode_fused_gemm: x [bs, ldx] needed without an output-side operator");
@@ -511,21 +550,21 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
         const int k = i < a->ngroups ? i : 0;
         QA_REQUIRE(fop_ok(a->V[k], p, q) && a->colscale[k] && a->qweight[k] && a->scale[k] && a->y[k], QUIPAMD_ERR_ARG,
                    "decode_fused_gemm: null pointer / operator shape in group %d", k);
-        A.V[i] = a->V[k]; A.colscale[i] = a->colscale[k]; A.qw[i] = (const uint4 *)a->qweight[k]; A.scale[i] = a->scale[k]; A.y[i] = a->y[k];
+        A.g[i].V = a->V[k]; A.g[i].colscale = a->colscale[k]; A.g[i].qw = (const uint4 *)a->qweight[k]; A.g[i].scale = a->scale[k]; A.g[i].y = a->y[k];
     }
     hipStream_t s = (hipStream_t)stream;
     const bool u = a->has_u != 0;
     if (p == 64 && q == 32) {
         QA_REQUIRE(a->m > 0 && a->m % 32 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 32 (m = %lld)", (long long)a->m);
-        return u ? launch_fused<64, 32, true, 2, 1>(A, a->ngroups, s) : launch_fused<64, 32, false, 2, 1>(A, a->ngroups, s);
+        return dispatch_fused<64, 32, 2, 1>(A, u, a->norm, a->ngroups, s);
     }
     if (p == 64 && q == 64) {
         QA_REQUIRE(a->m > 0 && a->m % 16 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 16 (m = %lld)", (long long)a->m);
-        return u ? launch_fused<64, 64, true, 1, 1>(A, a->ngroups, s) : launch_fused<64, 64, false, 1, 1>(A, a->ngroups, s);
+        return dispatch_fused<64, 64, 1, 1>(A, u, a->norm, a->ngroups, s);
     }
     if (p == 128 && q == 64) {
         QA_REQUIRE(a->m > 0 && a->m % 16 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 16 (m = %lld)", (long long)a->m);
-        return u ? launch_fused<128, 64, true, 1, 2>(A, a->ngroups, s) : launch_fused<128, 64, false, 1, 2>(A, a->ngroups, s);
+        return dispatch_fused<128, 64, 1, 2>(A, u, a->norm, a->ngroups, s);
     }
     return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: operator %d x %d (64 x 32, 64 x 64, 128 x 64)", p, q);
 }

@@ -575,8 +575,13 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
         kw.update(x=x.contiguous())
     else:
         t = torch.empty((rows, d), dtype=torch.float16, device=dev) if store else None
-        kw.update(U=prev.U.fop(True), u_y=y_prev, u_bias=prev.bias, u_residual=None if residual is None else residual.contiguous(),
-                  u_relu=relu, t_out=t)
+        if residual is None:                                 # the kernel always adds a residual row: zeros, kept per (operator, rows)
+            zr = prev.U.__dict__.setdefault('_zero_res', {})
+            if rows not in zr:
+                zr[rows] = torch.zeros((rows, d), dtype=torch.float16, device=dev)
+            residual = zr[rows]
+        kw.update(U=prev.U.fop(True), u_y=y_prev, u_bias=prev.bias if prev.bias is not None else prev.U.zero_bias(),
+                  u_residual=residual.contiguous(), u_relu=relu, t_out=t)
     ops.decode_fused_gemm(**kw)
     return ys, t
 
