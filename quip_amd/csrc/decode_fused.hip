@@ -247,12 +247,12 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     const int gi = blockIdx.y;
     const FGroup &Gg = G.g[gi];
     const Fop &V = Gg.V;
-    // all kernarg pointers of the prologue in ONE round trip
-    touch_s(Gg.qw); touch_s(V.F0); touch_s(V.F1); touch_s(V.load_idx); touch_s(V.store_idx); touch_s(Gg.colscale); touch_s(Gg.scale);
-    if (HAS_U) { touch_s(G.U.F0); touch_s(G.U.F1); touch_s(G.U.load_idx); touch_s(G.U.store_idx); touch_s(G.u_y); touch_s(G.u_bias); touch_s(G.u_res); }
-    else touch_s(G.x);
-    if (NORM) touch_s(G.gamma);
-    if (NORM == 1) touch_s(G.beta);
+    // every kernarg field the kernel will ever read, in ONE scalar round trip: hipcc fetches kernarg fields lazily -- one s_load +
+    // s_waitcnt lgkmcnt(0) per first use -- and round one of this kernel opened with SEVEN serial kernarg round trips (~2000
+    // cycles) and closed with three more in front of the final store.  One asm statement naming them all pins the loads here.
+    asm volatile("" ::"s"(Gg.qw), "s"(V.F0), "s"(V.F1), "s"(V.load_idx), "s"(V.store_idx), "s"(Gg.colscale), "s"(Gg.scale), "s"(Gg.y),
+                 "s"(G.U.F0), "s"(G.U.F1), "s"(G.U.load_idx), "s"(G.U.store_idx), "s"(G.u_y), "s"(G.u_bias), "s"(G.u_res), "s"(G.t_out),
+                 "s"(G.ld_res), "s"(G.ld_t), "s"(G.x), "s"(G.ldx), "s"(G.gamma), "s"(G.beta), "s"(G.eps), "s"(G.floor), "s"(G.bs), "s"(G.m));
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -262,13 +262,10 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     const int bs = G.bs;
     FG_STAMP(0);
 
-    // ---- requested first: this wave's packed weights (HBM; streamed once: nt), then every operand of the prologue ------------------
+    // ---- every operand of the prologue is requested NOW, in the order the phases consume them; the packed weights go LAST: vector
+    // memory returns in order (s_waitcnt vmcnt counts from the oldest), so a wait for the first activations behind a cold HBM
+    // weight load would be a wait for HBM (measured: +2000 cycles in front of the first scatter) ------------------------------------
     uint4 w[CPW];
-#pragma unroll
-    for (int i = 0; i < CPW; ++i) {
-        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Gg.qw + ((uint64_t)rt * NCH + (slot * CPW + i)) * 64 + lane));
-        w[i] = make_uint4(t[0], t[1], t[2], t[3]);
-    }
     PassFrags<P, Q> frU, frV;
     float4 yv[NV], bi[NV], cs[NV];
     uint2 ld[NV], st[NV], rs[NV], gm[NV], bt_[NV], vld[NV], vst[NV], xr[NV];
@@ -283,13 +280,17 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         }
     };
     auto load_u_side = [&]() {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int v4 = tid + 1024 * u;
+            if (v4 < N / 4) ld[u] = *reinterpret_cast<const uint2 *>(G.U.load_idx + 4 * v4);
+        }
         load_f0<P, Q>(G.U, wave, lane, frU);
         load_f1<P, Q>(G.U, wave, lane, frU);
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int v4 = tid + 1024 * u;
             if (v4 < N / 4) {
-                ld[u] = *reinterpret_cast<const uint2 *>(G.U.load_idx + 4 * v4);
                 st[u] = *reinterpret_cast<const uint2 *>(G.U.store_idx + 4 * v4);
                 bi[u] = *reinterpret_cast<const float4 *>(G.u_bias + 4 * v4);
             }
@@ -326,9 +327,15 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         load_u_side();
     } else load_x_row(0);
     if (EARLY || !HAS_U) {
-        load_v_frags();
         load_v_side();
+        load_v_frags();
     }
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {                                             // HBM, streamed once: nt
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Gg.qw + ((uint64_t)rt * NCH + (slot * CPW + i)) * 64 + lane));
+        w[i] = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+    const float e_sc = Gg.scale[0];                                             // needed by the reducer only
 
     for (int b = 0; b < bs; ++b) {
         float4 tv[NV];
@@ -373,22 +380,50 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         }
         FG_STAMP(5);                                                             // t in registers (gather / x load done)
         if (NORM) {
-            float mean = 0.f;
+            // statistics with ONE barrier: every wave reduces its own elements to (mean_w, M2_w) on the DPP network -- two-pass inside the
+            // wave, like torch's LayerNorm -- and the NWD waves that hold data are merged with Chan's formula (equal counts):
+            //   mean = avg mean_w,   M2 = sum M2_w + cnt sum (mean_w - mean)^2.     RMSNorm: one wave sum of squares.
+            constexpr int NWD = (N / 4 < 1024 ? N / 4 : 1024) / 64, CNT = N / NWD;      // waves with data, elements per such wave
+            float mean = 0.f, rstd;
             if (NORM == 1) {
                 float s1 = 0.f;
 #pragma unroll
                 for (int u = 0; u < NV; ++u) s1 += (tv[u].x + tv[u].y) + (tv[u].z + tv[u].w);
-                mean = fg_block_sum(s1, red) / (float)N;
-            }
-            float s2 = 0.f;
+                const float mw = fg_wave_sum(s1) * (1.0f / (float)CNT);
+                float s2 = 0.f;
 #pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                if (tid + 1024 * u < N / 4) {
-                    const float d0 = tv[u].x - mean, d1 = tv[u].y - mean, d2 = tv[u].z - mean, d3 = tv[u].w - mean;
+                for (int u = 0; u < NV; ++u) {
+                    const float d0 = tv[u].x - mw, d1 = tv[u].y - mw, d2 = tv[u].z - mw, d3 = tv[u].w - mw;
                     s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
                 }
+                const float m2w = fg_wave_sum(s2);
+                if (lane == 0) {
+                    red[wave] = mw;
+                    red[FG_NW + wave] = m2w;
+                }
+                __syncthreads();
+                float ms = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NWD; ++i) ms += red[i];
+                mean = ms * (1.0f / (float)NWD);
+#pragma unroll
+                for (int i = 0; i < NWD; ++i) {
+                    const float dm = red[i] - mean;
+                    m2 += red[FG_NW + i] + (float)CNT * dm * dm;
+                }
+                rstd = rsqrtf(m2 * (1.0f / (float)N) + G.eps);
+            } else {
+                float s2 = 0.f;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) s2 += (tv[u].x * tv[u].x + tv[u].y * tv[u].y) + (tv[u].z * tv[u].z + tv[u].w * tv[u].w);
+                const float w2 = fg_wave_sum(s2);
+                if (lane == 0) red[wave] = w2;
+                __syncthreads();
+                float t2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NWD; ++i) t2 += red[i];
+                rstd = rsqrtf(t2 * (1.0f / (float)N) + G.eps);
             }
-            const float rstd = rsqrtf(fg_block_sum(s2, red + FG_NW) / (float)N + G.eps);
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
                 const float4 gmf = f16x4_to_f32(gm[u]), btf = f16x4_to_f32(bt_[u]);
@@ -431,7 +466,6 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     }
 
     // ---- dequant + MFMA: this wave's CPW chunks of 256 columns x 16 rows -------------------------------------------------------------
-    const float e_sc = Gg.scale[0];                                             // needed by the reducer only: its latency hides under the MFMAs
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     float xs = 0.f;
     const bool live = j < bs;                                                   // MFMA column j = batch row j
@@ -439,18 +473,20 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
         const int c = slot * CPW + i;
+        uint4 xf[DQ::NT];                                                       // all eight fragment reads in flight, then the MFMAs: a
+#pragma unroll                                                                  // scalar branch per step (the r == 0 sums) had made it
+        for (int t = 0; t < DQ::NT; ++t) {                                      // read -> wait -> MFMA -> branch, eight times
+            xf[t] = *reinterpret_cast<const uint4 *>(xrow + c * 256 + 32 * t);
+            if (!live) xf[t] = make_uint4(0u, 0u, 0u, 0u);
+        }
 #pragma unroll
         for (int t = 0; t < DQ::NT; ++t) {
-            uint4 xf = *reinterpret_cast<const uint4 *>(xrow + c * 256 + 32 * t);
-            if (!live) xf = make_uint4(0u, 0u, 0u, 0u);
             const u32x4 a = DQ::frag(u32x4{w[i].x, w[i].y, w[i].z, w[i].w}, t);
-            acc = ActF16::mfma(a, u32x4{xf.x, xf.y, xf.z, xf.w}, acc);
-            if (r == 0) {
-                xs = ActF16::dot2(xf.x, ActF16::ONES, xs);
-                xs = ActF16::dot2(xf.y, ActF16::ONES, xs);
-                xs = ActF16::dot2(xf.z, ActF16::ONES, xs);
-                xs = ActF16::dot2(xf.w, ActF16::ONES, xs);
-            }
+            acc = ActF16::mfma(a, u32x4{xf[t].x, xf[t].y, xf[t].z, xf[t].w}, acc);
+            xs = ActF16::dot2(xf[t].x, ActF16::ONES, xs);                       // every wave (uniform code); only r == 0 publishes it
+            xs = ActF16::dot2(xf[t].y, ActF16::ONES, xs);
+            xs = ActF16::dot2(xf[t].z, ActF16::ONES, xs);
+            xs = ActF16::dot2(xf[t].w, ActF16::ONES, xs);
         }
     }
     FG_STAMP(13);                                                               // MFMAs issued (weights landed)
@@ -458,11 +494,9 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     {
         float *p = park + (slot * RT + r) * 256 + lane;
         p[0] = acc[0]; p[64] = acc[1]; p[128] = acc[2]; p[192] = acc[3];
-        if (r == 0) {
-            xs += __shfl_xor(xs, 16);
-            xs += __shfl_xor(xs, 32);
-            xpark[slot * 64 + lane] = xs;                                        // lanes j of every g hold sum_k x~[j][k] over the slot's chunks
-        }
+        xs += __shfl_xor(xs, 16);
+        xs += __shfl_xor(xs, 32);
+        if (r == 0) xpark[slot * 64 + lane] = xs;                               // lanes j of every g hold sum_k x~[j][k] over the slot's chunks
     }
     __syncthreads();
     FG_STAMP(14);
