@@ -255,9 +255,10 @@ int quipamd_dequant_gemm_vop(const quipamd_small_op *vops, const int32_t *const 
 /* ---- decode: one launch per packed Linear group, everything between two GEMMs in the consumer's prologue ------------------------
  * (csrc/decode_fused.hip; the decode loop of benchmark(), opt.py:431-482 / llama.py:418-471, batch <= 4)
  *     t    = [relu]( U_prev^T u_y + u_bias + u_residual )      optional (has_u): the output side of the PREVIOUS packed layer;
- *                                                              u_bias float [d] and u_residual fp16 [bs, ld_residual] are both
- *                                                              required (zeros where the layer has none: every operand load of the
- *                                                              prologue is unconditional and issued in the kernel's first instructions);
+ *                                                              u_y fp16 [bs, d] (a fused launch writes it with y_dtype F16),
+ *                                                              u_bias fp16 [d] (zeros where the layer has none), u_residual fp16
+ *                                                              [bs, ld_residual] or NULL; kernels exist for the combinations a decoder
+ *                                                              block needs (see dispatch_fused in csrc/decode_fused.hip);
  *                                                              t is stored to t_out (fp16, the new residual stream) when not NULL
  *     h    = norm(t)  (norm 0: none, 1: LayerNorm gamma / beta, 2: RMSNorm gamma; fp32 statistics, eps)      [t = x without has_u]
  *     x~_i = V_i ( h (/) s_i ),   y_i = What_i x~_i            i < ngroups <= 3 (q / k / v; gate / up), fp32 y [bs, m]
@@ -278,7 +279,7 @@ typedef struct quipamd_fused_gemm_args {
     int act_dtype, bits;
     int has_u;
     quipamd_fop U;
-    const float *u_y, *u_bias;
+    const void *u_y, *u_bias;        /* fp16 [bs, d], fp16 [d] */
     const void *u_residual;
     int64_t ld_residual;
     int u_relu;
@@ -294,7 +295,8 @@ typedef struct quipamd_fused_gemm_args {
     const float *colscale[3];
     const int32_t *qweight[3];
     const float *scale[3];
-    float *y[3];
+    void *y[3];
+    int y_dtype;                     /* QUIPAMD_F32, or QUIPAMD_F16 when the consumer is another fused launch (its scatter rounds to fp16 anyway) */
     int64_t bs, m;
 } quipamd_fused_gemm_args;
 int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *args, void *stream);

@@ -52,20 +52,20 @@ struct FGroup {                           // one packed layer of the launch (blo
     const float *colscale;
     const uint4 *qw;
     const float *scale;
-    float *y;
+    void *y;                              // [bs, m] fp32, or f16 when y_f16 (the consumer's scatter rounds it to f16 anyway)
 };
 
 struct FusedArgs {
     Fop U;
-    const float *u_y, *u_bias;            // [bs, n] fp32; [n] fp32 (zeros when the layer has no bias)
-    const uint16_t *u_res;                // [bs, ld_res] f16 (zeros when there is no residual)
+    const uint16_t *u_y, *u_bias;         // [bs, n] f16; [n] f16 (zeros when the layer has no bias)
+    const uint16_t *u_res;                // [bs, ld_res] f16 (HAS_RES)
     uint16_t *t_out;                      // [bs, ld_t] f16 or null
     int64_t ld_res, ld_t;
     const uint16_t *x;                    // !HAS_U: [bs, ldx] f16
     int64_t ldx;
     const uint16_t *gamma, *beta;
     float eps, floor;                     // floor: 0 (relu) or -inf
-    int bs;
+    int bs, y_f16;
     int64_t m;
     FGroup g[FG_MAXG];
 };
@@ -142,16 +142,20 @@ template <int P, int Q> __device__ __forceinline__ void load_f0(const Fop &op, i
     static_assert(FG_NW % (P / 16) == 0 && FG_NW % (Q / 16) == 0, "a wave's tiles share their fragments");
     const uint4 *F0 = reinterpret_cast<const uint4 *>(op.F0);
     const int at = wave % (P / 16);
-#pragma unroll
-    for (int S = 0; S < D::S0; ++S) fr.f0[S] = F0[(at * D::S0 + S) * 64 + lane];
+    if (wave < D::NT) {                                     // 64 x 32: eight tiles -- waves 8..15 own none and must not pull fragments
+#pragma unroll                                              // through the CU's one vector-memory path (64 B per clock, the prologue's bound)
+        for (int S = 0; S < D::S0; ++S) fr.f0[S] = F0[(at * D::S0 + S) * 64 + lane];
+    }
 }
 template <int P, int Q> __device__ __forceinline__ void load_f1(const Fop &op, int wave, int lane, PassFrags<P, Q> &fr)
 {
     typedef PassDims<P, Q> D;
     const uint4 *F1 = reinterpret_cast<const uint4 *>(op.F1);
     const int bt = wave % (Q / 16);
+    if (wave < D::NT) {
 #pragma unroll
-    for (int S = 0; S < D::S1; ++S) fr.f1[S] = F1[(bt * D::S1 + S) * 64 + lane];
+        for (int S = 0; S < D::S1; ++S) fr.f1[S] = F1[(bt * D::S1 + S) * 64 + lane];
+    }
 }
 
 // scatter 4 consecutive natural-order values into the stage-1 input image: value e goes to image position pos[e] = (a, b) -> ZT[b][a]
@@ -163,6 +167,17 @@ template <int P, int Q> __device__ __forceinline__ void scatter4(uint16_t *ZT, c
     const int pp[4] = {(int)(pos.x & 0xffff), (int)(pos.x >> 16), (int)(pos.y & 0xffff), (int)(pos.y >> 16)};
 #pragma unroll
     for (int e = 0; e < 4; ++e) ZT[(pp[e] & (Q - 1)) * D::PS + (pp[e] >> qsh)] = f32_to_f16_bits(vv[e]);
+}
+
+// the same for 4 values that already ARE f16 bits (the previous GEMM's output)
+template <int P, int Q> __device__ __forceinline__ void scatter4h(uint16_t *ZT, const uint2 &v, const uint2 &pos)
+{
+    typedef PassDims<P, Q> D;
+    constexpr int qsh = __builtin_ctz(Q);
+    const uint16_t vv[4] = {(uint16_t)(v.x & 0xffff), (uint16_t)(v.x >> 16), (uint16_t)(v.y & 0xffff), (uint16_t)(v.y >> 16)};
+    const int pp[4] = {(int)(pos.x & 0xffff), (int)(pos.x >> 16), (int)(pos.y & 0xffff), (int)(pos.y >> 16)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ZT[(pp[e] & (Q - 1)) * D::PS + (pp[e] >> qsh)] = vv[e];
 }
 
 // the two mix stages: ZT -> Z1 -> ZF.  Caller: a barrier after the scatter; this function ends WITHOUT a barrier after writing ZF.
@@ -226,7 +241,7 @@ template <int P, int Q> __device__ __forceinline__ float4 gather4(const float *Z
 // NORM: 0 none, 1 LayerNorm, 2 RMSNorm.  Every global operand of the prologue is requested in the first instructions of the kernel
 // (EARLY: all of them when a thread owns one 4-element slot, n <= 4096; at n = 8192 the V-side set follows the U-side scatter, the
 // register file does not hold both): the phases between the barriers then run on registers and LDS only.
-template <int P, int Q, bool HAS_U, int NORM, int RT, int CPW>
+template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW>
 __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two_over_maxq, float c0)
 {
     typedef PassDims<P, Q> D;
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     float *ZF = reinterpret_cast<float *>(pass + D::ZT_B + D::Z1_B);
     float *park = reinterpret_cast<float *>(pass);                              // [NS][RT][4][64] + xsum [NS][64]: after the last pass
     constexpr size_t PARK_B = (size_t)(FG_NW * 256 + FG_NW * 64) * 4;
-    float *red = reinterpret_cast<float *>(pass + (D::BYTES > PARK_B ? D::BYTES : PARK_B));            // [2][16]
+    float *red = reinterpret_cast<float *>(pass + (D::BYTES > PARK_B ? D::BYTES : PARK_B));            // [2][16] norm, [bs][16] sum x~
 
     const int gi = blockIdx.y;
     const FGroup &Gg = G.g[gi];
@@ -252,7 +267,8 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     // cycles) and closed with three more in front of the final store.  One asm statement naming them all pins the loads here.
     asm volatile("" ::"s"(Gg.qw), "s"(V.F0), "s"(V.F1), "s"(V.load_idx), "s"(V.store_idx), "s"(Gg.colscale), "s"(Gg.scale), "s"(Gg.y),
                  "s"(G.U.F0), "s"(G.U.F1), "s"(G.U.load_idx), "s"(G.U.store_idx), "s"(G.u_y), "s"(G.u_bias), "s"(G.u_res), "s"(G.t_out),
-                 "s"(G.ld_res), "s"(G.ld_t), "s"(G.x), "s"(G.ldx), "s"(G.gamma), "s"(G.beta), "s"(G.eps), "s"(G.floor), "s"(G.bs), "s"(G.m));
+                 "s"(G.ld_res), "s"(G.ld_t), "s"(G.x), "s"(G.ldx), "s"(G.gamma), "s"(G.beta), "s"(G.eps), "s"(G.floor), "s"(G.bs), "s"(G.m),
+                 "s"(G.y_f16));
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -267,32 +283,31 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     // weight load would be a wait for HBM (measured: +2000 cycles in front of the first scatter) ------------------------------------
     uint4 w[CPW];
     PassFrags<P, Q> frU, frV;
-    float4 yv[NV], bi[NV], cs[NV];
-    uint2 ld[NV], st[NV], rs[NV], gm[NV], bt_[NV], vld[NV], vst[NV], xr[NV];
-    auto load_u_row = [&](int b) {
+    float4 cs[NV];
+    uint2 yv[NV], bi[NV], ld[NV], st[NV], rs[NV], gm[NV], bt_[NV], vld[NV], vst[NV], xr[NV];
+    auto load_u_row = [&](int b) {                                              // what the first scatter needs
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int v4 = tid + 1024 * u;
             if (v4 < N / 4) {
-                yv[u] = *reinterpret_cast<const float4 *>(G.u_y + (int64_t)b * N + 4 * v4);
-                rs[u] = *reinterpret_cast<const uint2 *>(G.u_res + (int64_t)b * G.ld_res + 4 * v4);
+                yv[u] = *reinterpret_cast<const uint2 *>((G.u_y + (int64_t)b * N) + (uint32_t)(4 * v4));
+                ld[u] = *reinterpret_cast<const uint2 *>(G.U.load_idx + 4 * v4);
             }
         }
     };
-    auto load_u_side = [&]() {
-#pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const int v4 = tid + 1024 * u;
-            if (v4 < N / 4) ld[u] = *reinterpret_cast<const uint2 *>(G.U.load_idx + 4 * v4);
-        }
+    auto load_u_frags = [&]() {
         load_f0<P, Q>(G.U, wave, lane, frU);
         load_f1<P, Q>(G.U, wave, lane, frU);
+    };
+    auto load_u_side = [&](int b) {
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int v4 = tid + 1024 * u;
+            rs[u] = make_uint2(0u, 0u);
             if (v4 < N / 4) {
                 st[u] = *reinterpret_cast<const uint2 *>(G.U.store_idx + 4 * v4);
-                bi[u] = *reinterpret_cast<const float4 *>(G.u_bias + 4 * v4);
+                bi[u] = *reinterpret_cast<const uint2 *>(G.u_bias + 4 * v4);
+                if (HAS_RES) rs[u] = *reinterpret_cast<const uint2 *>((G.u_res + (int64_t)b * G.ld_res) + (uint32_t)(4 * v4));
             }
         }
     };
@@ -319,13 +334,19 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         for (int u = 0; u < NV; ++u) {
             const int v4 = tid + 1024 * u;
             xr[u] = make_uint2(0u, 0u);
-            if (v4 < N / 4) xr[u] = *reinterpret_cast<const uint2 *>(G.x + (int64_t)b * G.ldx + 4 * v4);
+            if (v4 < N / 4) xr[u] = *reinterpret_cast<const uint2 *>((G.x + (int64_t)b * G.ldx) + (uint32_t)(4 * v4));
         }
     };
-    if (HAS_U) {
-        load_u_row(0);
-        load_u_side();
-    } else load_x_row(0);
+    if (HAS_U) load_u_row(0);
+    else load_x_row(0);
+    // everything the FIRST phase needs is in the memory pipeline of every wave before anything else is requested: the CU has one
+    // vector-memory path (~64 B per clock) and the prologue pulls 100 - 350 KiB through it; without this barrier (no memory wait in
+    // it, the waves arrive within a few cycles) wave 15's activations queued behind the other waves' factor fragments
+    __syncthreads();
+    if (HAS_U && EARLY) {
+        load_u_frags();
+        load_u_side(0);
+    }
     if (EARLY || !HAS_U) {
         load_v_side();
         load_v_frags();
@@ -343,12 +364,20 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
             // ---- t = [relu](U^T y + bias + residual) --------------------------------------------------------------------------------
             if (b > 0) {
                 load_u_row(b);
-                if (!EARLY) load_u_side();                                       // n = 8192: nothing row-independent stays in registers across a row
+                if (EARLY && HAS_RES) {
+#pragma unroll
+                    for (int u = 0; u < NV; ++u)
+                        if (tid + 1024 * u < N / 4) rs[u] = *reinterpret_cast<const uint2 *>((G.u_res + (int64_t)b * G.ld_res) + (uint32_t)(4 * (tid + 1024 * u)));
+                }
             }
 #pragma unroll
             for (int u = 0; u < NV; ++u)
-                if (tid + 1024 * u < N / 4) scatter4<P, Q>(ZT, yv[u], ld[u]);
-            if (!EARLY) load_v_side();                                          // n = 8192: the V-side set travels under the U pass
+                if (tid + 1024 * u < N / 4) scatter4h<P, Q>(ZT, yv[u], ld[u]);
+            if (!EARLY) {                                                       // n = 8192: fragments, the gather's operands and the V-side set follow
+                load_u_frags();                                                 // the scatter (nothing row-independent stays in registers across a row)
+                load_u_side(b);
+                load_v_side();
+            }
             FG_STAMP(1);                                                         // first loads landed, scatter done
             __syncthreads();
             FG_STAMP(2);
@@ -363,13 +392,13 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                 tv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (v4 < N / 4) {
                     float4 t = gather4<P, Q>(ZF, st[u]);
-                    const float4 rr = f16x4_to_f32(rs[u]);
-                    t = make_float4(fmaxf(t.x + bi[u].x + rr.x, G.floor), fmaxf(t.y + bi[u].y + rr.y, G.floor),
-                                    fmaxf(t.z + bi[u].z + rr.z, G.floor), fmaxf(t.w + bi[u].w + rr.w, G.floor));
+                    const float4 rr = f16x4_to_f32(rs[u]), bb4 = f16x4_to_f32(bi[u]);
+                    t = make_float4(fmaxf(t.x + bb4.x + rr.x, G.floor), fmaxf(t.y + bb4.y + rr.y, G.floor),
+                                    fmaxf(t.z + bb4.z + rr.z, G.floor), fmaxf(t.w + bb4.w + rr.w, G.floor));
                     uint2 pk;                                                    // the residual stream is fp16: everything downstream sees the rounded value
                     pk.x = pack_f16x2(t.x, t.y);
                     pk.y = pack_f16x2(t.z, t.w);
-                    if (G.t_out && blockIdx.x == 0 && gi == 0) *reinterpret_cast<uint2 *>(G.t_out + (int64_t)b * G.ld_t + 4 * v4) = pk;
+                    if (G.t_out && blockIdx.x == 0 && gi == 0) *reinterpret_cast<uint2 *>((G.t_out + (int64_t)b * G.ld_t) + (uint32_t)(4 * v4)) = pk;
                     tv[u] = f16x4_to_f32(pk);
                 }
             }
@@ -449,6 +478,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         FG_STAMP(9);
         __syncthreads();
         FG_STAMP(10);
+        float xpart = 0.f;
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int v4 = tid + 1024 * u;
@@ -458,59 +488,56 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                 pk.x = pack_f16x2(t.x, t.y);
                 pk.y = pack_f16x2(t.z, t.w);
                 *reinterpret_cast<uint2 *>(XT + (size_t)b * XTS + 4 * v4) = pk;
+                const float4 tr = f16x4_to_f32(pk);                              // sum_k x~[k] of the ROUNDED values: the epilogue's offset term
+                xpart += (tr.x + tr.y) + (tr.z + tr.w);
             }
         }
+        xpart = fg_wave_sum(xpart);
+        if (lane == 0) red[2 * FG_NW + b * FG_NW + wave] = xpart;
         FG_STAMP(11);
         __syncthreads();                                                        // x~ row complete; ZF / ZT free for the next row (or park)
         FG_STAMP(12);
     }
 
     // ---- dequant + MFMA: this wave's CPW chunks of 256 columns x 16 rows -------------------------------------------------------------
+    // MFMA column j = batch row j.  Columns are independent (D[m][n] depends on B[:, n] only), so lanes of columns >= bs may read
+    // anything: they read row j % 4 of x~ (allocated, possibly never written) and their results are not stored -- no masking.
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    float xs = 0.f;
-    const bool live = j < bs;                                                   // MFMA column j = batch row j
-    const uint16_t *xrow = XT + (size_t)(live ? j : 0) * XTS + 8 * g;
+    const uint16_t *xrow = XT + (size_t)(j & (FG_MAXBS - 1)) * XTS + 8 * g;
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
         const int c = slot * CPW + i;
-        uint4 xf[DQ::NT];                                                       // all eight fragment reads in flight, then the MFMAs: a
-#pragma unroll                                                                  // scalar branch per step (the r == 0 sums) had made it
-        for (int t = 0; t < DQ::NT; ++t) {                                      // read -> wait -> MFMA -> branch, eight times
-            xf[t] = *reinterpret_cast<const uint4 *>(xrow + c * 256 + 32 * t);
-            if (!live) xf[t] = make_uint4(0u, 0u, 0u, 0u);
-        }
+        uint4 xf[DQ::NT];
+#pragma unroll
+        for (int t = 0; t < DQ::NT; ++t) xf[t] = *reinterpret_cast<const uint4 *>(xrow + c * 256 + 32 * t);
 #pragma unroll
         for (int t = 0; t < DQ::NT; ++t) {
             const u32x4 a = DQ::frag(u32x4{w[i].x, w[i].y, w[i].z, w[i].w}, t);
             acc = ActF16::mfma(a, u32x4{xf[t].x, xf[t].y, xf[t].z, xf[t].w}, acc);
-            xs = ActF16::dot2(xf[t].x, ActF16::ONES, xs);                       // every wave (uniform code); only r == 0 publishes it
-            xs = ActF16::dot2(xf[t].y, ActF16::ONES, xs);
-            xs = ActF16::dot2(xf[t].z, ActF16::ONES, xs);
-            xs = ActF16::dot2(xf[t].w, ActF16::ONES, xs);
         }
     }
-    FG_STAMP(13);                                                               // MFMAs issued (weights landed)
-    float *xpark = park + FG_NW * 256;
+    FG_STAMP(13);
     {
         float *p = park + (slot * RT + r) * 256 + lane;
         p[0] = acc[0]; p[64] = acc[1]; p[128] = acc[2]; p[192] = acc[3];
-        xs += __shfl_xor(xs, 16);
-        xs += __shfl_xor(xs, 32);
-        if (r == 0) xpark[slot * 64 + lane] = xs;                               // lanes j of every g hold sum_k x~[j][k] over the slot's chunks
     }
     __syncthreads();
     FG_STAMP(14);
     if (wave < RT) {                                                            // one reducer wave per row tile: lane = (batch row, row in tile)
+        constexpr int NWD = (N / 4 < 1024 ? N / 4 : 1024) / 64;                 // waves that wrote x~ (and its partial sums)
         const int r2 = wave, bb = lane >> 4, wr = lane & 15;
         const int src = (wr & 3) * 64 + bb + 16 * (wr >> 2);                   // [acc component][mfma lane (j = bb, g = wr / 4)]
         float a = 0.f, xsum = 0.f;
 #pragma unroll
-        for (int v = 0; v < NS; ++v) {
-            a += park[(v * RT + r2) * 256 + src];
-            xsum += xpark[v * 64 + bb];
-        }
+        for (int v = 0; v < NS; ++v) a += park[(v * RT + r2) * 256 + src];
+#pragma unroll
+        for (int v = 0; v < NWD; ++v) xsum += red[2 * FG_NW + bb * FG_NW + v];
         const int64_t row = (int64_t)(blockIdx.x * RT + r2) * 16 + wr;
-        if (bb < bs) Gg.y[(int64_t)bb * G.m + row] = e_sc * two_over_maxq * (a - c0 * xsum);
+        const float val = e_sc * two_over_maxq * (a - c0 * xsum);
+        if (bb < bs) {
+            if (G.y_f16) reinterpret_cast<uint16_t *>(Gg.y)[(int64_t)bb * G.m + row] = f32_to_f16_bits(val);
+            else reinterpret_cast<float *>(Gg.y)[(int64_t)bb * G.m + row] = val;
+        }
     }
     FG_STAMP(15);
 }
@@ -519,13 +546,13 @@ template <int P, int Q> constexpr size_t fused_lds()
 {
     typedef PassDims<P, Q> D;
     const size_t parkb = (size_t)(FG_NW * 256 + FG_NW * 64) * 4;
-    return (size_t)FG_MAXBS * (D::N + 8) * 2 + (D::BYTES > parkb ? D::BYTES : parkb) + 2 * FG_NW * 4 + 64;
+    return (size_t)FG_MAXBS * (D::N + 8) * 2 + (D::BYTES > parkb ? D::BYTES : parkb) + (2 + FG_MAXBS) * FG_NW * 4 + 64;
 }
 
-template <int P, int Q, bool HAS_U, int NORM, int RT, int CPW> int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
+template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW> int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
 {
     const size_t lds = fused_lds<P, Q>();
-    auto kern = fused_gemm_kernel<P, Q, HAS_U, NORM, RT, CPW>;
+    auto kern = fused_gemm_kernel<P, Q, HAS_U, HAS_RES, NORM, RT, CPW>;
     static QaPerDevice attr;
     const int d = attr.dev();
     if (d < 0 || !attr.done[d]) {
@@ -539,12 +566,17 @@ template <int P, int Q, bool HAS_U, int NORM, int RT, int CPW> int launch_fused(
     return QUIPAMD_OK;
 }
 
-template <int P, int Q, int RT, int CPW> int dispatch_fused(const FusedArgs &A, bool u, int norm, int ngroups, hipStream_t s)
+// the combinations a decoder block needs (each is a 1300-line kernel: the full cross product would be 36 of them):
+//   64 x 32 (OPT d = 2048) and 64 x 64 (Llama d = 4096):  [U + residual, norm]  [no U, norm]  [no U, no norm]  [U + residual, no norm]
+//   128 x 64 (OPT d = 8192):                               [U, no residual, no norm]  [no U, no norm]
+template <int P, int Q, int NORM_MODEL, int RT, int CPW>
+int dispatch_fused(const FusedArgs &A, bool u, bool res, int norm, int ngroups, hipStream_t s)
 {
-    if (u) return norm == 0 ? launch_fused<P, Q, true, 0, RT, CPW>(A, ngroups, s)
-                 : norm == 1 ? launch_fused<P, Q, true, 1, RT, CPW>(A, ngroups, s) : launch_fused<P, Q, true, 2, RT, CPW>(A, ngroups, s);
-    return norm == 0 ? launch_fused<P, Q, false, 0, RT, CPW>(A, ngroups, s)
-         : norm == 1 ? launch_fused<P, Q, false, 1, RT, CPW>(A, ngroups, s) : launch_fused<P, Q, false, 2, RT, CPW>(A, ngroups, s);
+    if (u && res && norm == NORM_MODEL) return launch_fused<P, Q, true, true, NORM_MODEL, RT, CPW>(A, ngroups, s);
+    if (u && res && norm == 0) return launch_fused<P, Q, true, true, 0, RT, CPW>(A, ngroups, s);
+    if (!u && norm == NORM_MODEL) return launch_fused<P, Q, false, false, NORM_MODEL, RT, CPW>(A, ngroups, s);
+    if (!u && norm == 0) return launch_fused<P, Q, false, false, 0, RT, CPW>(A, ngroups, s);
+    return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: %d x %d has no kernel for (U %d, residual %d, norm %d)", P, Q, (int)u, (int)res, norm);
 }
 
 bool fop_ok(const quipamd_fop &o, int p, int q) { return o.F0 && o.F1 && o.load_idx && o.store_idx && o.p == p && o.q == q; }
@@ -563,19 +595,20 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
     const int64_t n = (int64_t)p * q;
     FusedArgs A;
     A.U = a->U;
-    A.u_y = a->u_y; A.u_bias = a->u_bias; A.u_res = (const uint16_t *)a->u_residual; A.t_out = (uint16_t *)a->t_out;
+    A.u_y = (const uint16_t *)a->u_y; A.u_bias = (const uint16_t *)a->u_bias; A.u_res = (const uint16_t *)a->u_residual; A.t_out = (uint16_t *)a->t_out;
     A.ld_res = a->ld_residual; A.ld_t = a->ld_t; A.floor = a->u_relu ? 0.f : -INFINITY;
     A.x = (const uint16_t *)a->x; A.ldx = a->ldx;
     A.gamma = (const uint16_t *)a->ln_gamma; A.beta = (const uint16_t *)a->ln_beta; A.eps = a->ln_eps;
-    A.bs = (int)a->bs; A.m = a->m;
+    A.bs = (int)a->bs; A.m = a->m; A.y_f16 = a->y_dtype == QUIPAMD_F16;
+    QA_REQUIRE(a->y_dtype == QUIPAMD_F16 || a->y_dtype == QUIPAMD_F32, QUIPAMD_ERR_ARG, "decode_fused_gemm: y_dtype f32 or f16");
     QA_REQUIRE(a->norm >= 0 && a->norm <= 2 && (a->norm == 0 || a->ln_gamma) && (a->norm != 1 || a->ln_beta), QUIPAMD_ERR_ARG,
                "decode_fused_gemm: norm %d needs gamma (and beta for LayerNorm)", a->norm);
     if (a->has_u) {
         QA_REQUIRE(!a->t_out || a->t_out != a->u_residual, QUIPAMD_ERR_ARG, "decode_fused_gemm: t_out must not alias u_residual");
-        QA_REQUIRE(fop_ok(a->U, p, q) && a->u_y && a->u_bias && a->u_residual, QUIPAMD_ERR_ARG,
-                   "decode_fused_gemm: the output-side operator must be %d x %d like the activation-side one, with u_y, u_bias and "
-                   "u_residual (zeros where a layer has none)", p, q);
-        QA_REQUIRE(a->ld_residual >= n && a->ld_residual % 4 == 0 && (!a->t_out || (a->ld_t >= n && a->ld_t % 4 == 0)),
+        QA_REQUIRE(fop_ok(a->U, p, q) && a->u_y && a->u_bias, QUIPAMD_ERR_ARG,
+                   "decode_fused_gemm: the output-side operator must be %d x %d like the activation-side one, with u_y and u_bias "
+                   "(zeros where the layer has none)", p, q);
+        QA_REQUIRE((!a->u_residual || (a->ld_residual >= n && a->ld_residual % 4 == 0)) && (!a->t_out || (a->ld_t >= n && a->ld_t % 4 == 0)),
                    QUIPAMD_ERR_SHAPE, "decode_fused_gemm: residual / t_out row strides");
     } else {
         QA_REQUIRE(a->x && a->ldx >= n && a->ldx % 4 == 0, QUIPAMD_ERR_ARG, "decode_fused_gemm: x [bs, ldx] needed without an output-side operator");
@@ -587,18 +620,20 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
         A.g[i].V = a->V[k]; A.g[i].colscale = a->colscale[k]; A.g[i].qw = (const uint4 *)a->qweight[k]; A.g[i].scale = a->scale[k]; A.g[i].y = a->y[k];
     }
     hipStream_t s = (hipStream_t)stream;
-    const bool u = a->has_u != 0;
+    const bool u = a->has_u != 0, res = u && a->u_residual != nullptr;
     if (p == 64 && q == 32) {
         QA_REQUIRE(a->m > 0 && a->m % 32 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 32 (m = %lld)", (long long)a->m);
-        return dispatch_fused<64, 32, 2, 1>(A, u, a->norm, a->ngroups, s);
+        return dispatch_fused<64, 32, 1, 2, 1>(A, u, res, a->norm, a->ngroups, s);
     }
     if (p == 64 && q == 64) {
         QA_REQUIRE(a->m > 0 && a->m % 16 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 16 (m = %lld)", (long long)a->m);
-        return dispatch_fused<64, 64, 1, 1>(A, u, a->norm, a->ngroups, s);
+        return dispatch_fused<64, 64, 2, 1, 1>(A, u, res, a->norm, a->ngroups, s);
     }
     if (p == 128 && q == 64) {
         QA_REQUIRE(a->m > 0 && a->m % 16 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 16 (m = %lld)", (long long)a->m);
-        return dispatch_fused<128, 64, 1, 2>(A, u, a->norm, a->ngroups, s);
+        if (u && !res && a->norm == 0) return launch_fused<128, 64, true, false, 0, 1, 2>(A, a->ngroups, s);
+        if (!u && a->norm == 0) return launch_fused<128, 64, false, false, 0, 1, 2>(A, a->ngroups, s);
+        return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: 128 x 64 runs (U, no residual, no norm) and (no U, no norm) only");
     }
     return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: operator %d x %d (64 x 32, 64 x 64, 128 x 64)", p, q);
 }

@@ -358,7 +358,8 @@ class FusedGemmArgs(ctypes.Structure):
                 ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64),
                 ("norm", ctypes.c_int), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p), ("ln_eps", ctypes.c_float),
                 ("ngroups", ctypes.c_int), ("V", Fop * 3), ("colscale", ctypes.c_void_p * 3), ("qweight", ctypes.c_void_p * 3),
-                ("scale", ctypes.c_void_p * 3), ("y", ctypes.c_void_p * 3), ("bs", ctypes.c_int64), ("m", ctypes.c_int64)]
+                ("scale", ctypes.c_void_p * 3), ("y", ctypes.c_void_p * 3), ("y_dtype", ctypes.c_int), ("bs", ctypes.c_int64),
+                ("m", ctypes.c_int64)]
 
 
 FUSED_SHAPES = ((64, 32), (64, 64), (128, 64))
@@ -382,11 +383,11 @@ def decode_fused_gemm(*, V, colscale, qweight, scale, y, m, bs, x=None, U=None, 
     a.has_u = int(U is not None)
     if U is not None:
         a.U = U
-        a.u_y, a.u_bias = _ptr(u_y), _f32ptr(u_bias, "u_bias")
+        a.u_y, a.u_bias = _ptr(u_y), _ptr(u_bias)
         a.u_residual, a.ld_residual = _ptr(u_residual), 0 if u_residual is None else u_residual.stride(0)
         a.u_relu = int(bool(u_relu))
         a.t_out, a.ld_t = _ptr(t_out), 0 if t_out is None else t_out.stride(0)
-        assert u_y.dtype == torch.float32 and u_y.is_contiguous()
+        assert u_y.dtype == torch.float16 and u_y.is_contiguous() and u_bias.dtype == torch.float16 and u_bias.is_contiguous()
         assert u_residual is None or (u_residual.dtype == torch.float16 and u_residual.stride(1) == 1)
         assert t_out is None or (t_out.dtype == torch.float16 and t_out.stride(1) == 1)
     else:
@@ -403,8 +404,9 @@ def decode_fused_gemm(*, V, colscale, qweight, scale, y, m, bs, x=None, U=None, 
         a.colscale[i] = _f32ptr(colscale[i], "colscale")
         a.qweight[i] = qweight[i].data_ptr()
         a.scale[i] = _f32ptr(scale[i], "scale")
-        assert y[i].dtype == torch.float32 and y[i].is_contiguous()
+        assert y[i].dtype == y[0].dtype and y[i].dtype in (torch.float32, torch.float16) and y[i].is_contiguous()
         a.y[i] = y[i].data_ptr()
+    a.y_dtype = _DT[y[0].dtype]
     a.bs, a.m = int(bs), int(m)
     _lib.call("quipamd_decode_fused_gemm", ctypes.byref(a), _stream())
 

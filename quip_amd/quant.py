@@ -538,10 +538,12 @@ def packed_u_then_v(qa, y, dtype, qbs, residual=None, relu=False, ln=None, store
     return t, xts
 
 
-def fused_ok(qls, rows, x_dtype=torch.float16, prev=None):
+def fused_ok(qls, rows, x_dtype=torch.float16, prev=None, norm=True, residual=True):
     """can `fused_stage` run these layers?  (csrc/decode_fused.hip: 2-bit qfn-b layers of one shape sharing their input, Kronecker
     operators of a decode shape on both sides, fp16 activations, a handful of rows; `prev`: the packed layer whose output-side
-    operator rides in the prologue -- its U must have the consumers' V shape)"""
+    operator rides in the prologue -- its U must have the consumers' V shape.  Kernels exist for the combinations a decoder block
+    needs: d = 2048 / 4096: (prev + residual, norm or not), (no prev, norm or not); d = 8192: (prev, no residual, no norm),
+    (no prev, no norm).)"""
     q0 = qls[0]
     ok = (1 <= len(qls) <= 3 and rows <= ops.FUSED_MAX_ROWS and x_dtype == torch.float16
           and all(q.bits == 2 and q.qfn == 'b' and q.V is not None and q.V.fused_ok and q.scales.numel() == 1 for q in qls)
@@ -549,21 +551,26 @@ def fused_ok(qls, rows, x_dtype=torch.float16, prev=None):
           and q0.outfeatures % (32 if (q0.V.p, q0.V.q) == (64, 32) else 16) == 0)
     if ok and prev is not None:
         ok = prev.U is not None and prev.U.fused_ok and (prev.U.p, prev.U.q) == (q0.V.p, q0.V.q)
+    if ok:
+        big = (q0.V.p, q0.V.q) == (128, 64)
+        ok = (not norm and (prev is None or not residual)) if big else (prev is None or residual)
     return ok
 
 
-def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, ln=None, store=False):
+def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, ln=None, store=False, y_dtype=torch.float32):
     """ONE launch (quipamd_decode_fused_gemm) for everything between two dequant-GEMMs of a decode step:
         t    = [relu]( U_prev^T y_prev + bias_prev + residual )     when `prev` (the packed layer that produced y_prev) is given,
                                                                     else t = x
-        y_i  = What_i V_i ( Norm(t) (/) s_i )                       for the 1..3 layers `qls` sharing t; fp32 [rows, m]
+        y_i  = What_i V_i ( Norm(t) (/) s_i )                       for the 1..3 layers `qls` sharing t; [rows, m] in y_dtype
     Returns (ys, t): t is the fp16 tensor written by the launch when store=True (the new residual stream), else None.
-    ln: nn.LayerNorm / an RMSNorm module / None."""
+    ln: nn.LayerNorm / an RMSNorm module / None.  y_prev: fp16 (what a fused launch writes with y_dtype=torch.float16; an fp32
+    y_prev is rounded here -- the kernel's first step is that rounding anyway).  y_dtype fp16 when the consumer is another fused
+    launch, fp32 for the K3 operator kernels."""
     q0 = qls[0]
     rows = (x if prev is None else y_prev).shape[0]
     dev = q0.qweight.device
     m, d = q0.outfeatures, q0.infeatures
-    ys = [torch.empty((rows, m), dtype=torch.float32, device=dev) for _ in qls]
+    ys = [torch.empty((rows, m), dtype=y_dtype, device=dev) for _ in qls]
     kw = dict(V=[q.V.fop(False) for q in qls], colscale=[q.inv_scaleWH if q.inv_scaleWH is not None else q.V.one_scale() for q in qls],
               qweight=[q.qweight for q in qls], scale=[q.scales for q in qls], y=ys, m=m, bs=rows)
     lnp = _ln_params(ln)
@@ -575,13 +582,12 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
         kw.update(x=x.contiguous())
     else:
         t = torch.empty((rows, d), dtype=torch.float16, device=dev) if store else None
-        if residual is None:                                 # the kernel always adds a residual row: zeros, kept per (operator, rows)
-            zr = prev.U.__dict__.setdefault('_zero_res', {})
-            if rows not in zr:
-                zr[rows] = torch.zeros((rows, d), dtype=torch.float16, device=dev)
-            residual = zr[rows]
-        kw.update(U=prev.U.fop(True), u_y=y_prev, u_bias=prev.bias if prev.bias is not None else prev.U.zero_bias(),
-                  u_residual=residual.contiguous(), u_relu=relu, t_out=t)
+        b16 = prev.__dict__.get('_bias16')
+        if b16 is None or b16.device != dev:                # OPT's biases ARE fp16 values (kept as fp32 for the K3 kernels): exact
+            b16 = (prev.bias.to(torch.float16) if prev.bias is not None else torch.zeros(d, dtype=torch.float16, device=dev)).contiguous()
+            prev.__dict__['_bias16'] = b16
+        kw.update(U=prev.U.fop(True), u_y=y_prev.to(torch.float16).contiguous(), u_bias=b16,
+                  u_residual=None if residual is None else residual.contiguous(), u_relu=relu, t_out=t)
     ops.decode_fused_gemm(**kw)
     return ys, t
 

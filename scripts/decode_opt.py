@@ -128,8 +128,8 @@ class Decoder(nn.Module):
 
     def v3_ok(self, bs):
         b = self.blocks[0]
-        return (fused_ok([b.q_proj, b.k_proj, b.v_proj], bs, prev=b.fc2) and fused_ok([b.out_proj], bs)
-                and fused_ok([b.fc1], bs, prev=b.out_proj) and fused_ok([b.fc2], bs, prev=b.fc1))
+        return (fused_ok([b.q_proj, b.k_proj, b.v_proj], bs, prev=b.fc2) and fused_ok([b.out_proj], bs, norm=False)
+                and fused_ok([b.fc1], bs, prev=b.out_proj) and fused_ok([b.fc2], bs, prev=b.fc1, norm=False, residual=False))
 
     def step_v3(self, x, pos, caches):
         """per block: [U_fc2^T(prev) + residual -> LN1 -> V_qkv -> GEMM qkv] [U_qkv^T (tiled)] [attention] [V_o -> GEMM o]
@@ -145,9 +145,11 @@ class Decoder(nn.Module):
                 ys, x = fused_stage(qkv, prev=prev, y_prev=y2, residual=x, ln=blk.ln1, store=True)
             q, k, v = packed_u_stage(qkv, ys, dt)
             o = ops.decode_attention(q, k, v, kc, vc, pos)
-            yo = fused_stage([blk.out_proj], x=o)[0][0]
-            (y1,), x = fused_stage([blk.fc1], prev=blk.out_proj, y_prev=yo, residual=x, ln=blk.ln2, store=True)
-            y2 = fused_stage([blk.fc2], prev=blk.fc1, y_prev=y1, relu=True)[0][0]
+            h16 = torch.float16                                 # y consumed by another fused launch: fp16 (its scatter rounds to fp16 anyway)
+            yo = fused_stage([blk.out_proj], x=o, y_dtype=h16)[0][0]
+            (y1,), x = fused_stage([blk.fc1], prev=blk.out_proj, y_prev=yo, residual=x, ln=blk.ln2, store=True, y_dtype=h16)
+            last = blk is self.blocks[-1]
+            y2 = fused_stage([blk.fc2], prev=blk.fc1, y_prev=y1, relu=True, y_dtype=torch.float32 if last else h16)[0][0]
             prev = blk.fc2
         return packed_u_stage([prev], [y2], dt, residual=x)[0]
 

@@ -57,22 +57,22 @@ quipamd_fop make_fop(int p, int q)
     return o;
 }
 
-void run(const char *name, int p, int q, int64_t m, int groups, bool has_u, int norm, int bs, int ncopies)
+void run(const char *name, int p, int q, int64_t m, int groups, bool has_u, int norm, int bs, int ncopies, bool res = true)
 {
     const int n = p * q;
     std::vector<quipamd_fused_gemm_args> args(ncopies);
     for (int c = 0; c < ncopies; ++c) {                      // distinct weights per copy: every launch streams cold codes
         quipamd_fused_gemm_args &a = args[c];
         memset(&a, 0, sizeof(a));
-        a.act_dtype = QUIPAMD_F16; a.bits = 2; a.has_u = has_u; a.norm = norm; a.ln_eps = 1e-5f; a.ngroups = groups; a.bs = bs; a.m = m;
+        a.act_dtype = QUIPAMD_F16; a.bits = 2; a.has_u = has_u; a.norm = norm; a.ln_eps = 1e-5f; a.ngroups = groups; a.bs = bs; a.m = m; a.y_dtype = QUIPAMD_F16;
         if (c == 0) {
             a.U = make_fop(p, q);
-            a.u_y = dev_alloc<float>((size_t)bs * n); a.u_bias = dev_alloc<float>(n); a.u_residual = dev_alloc<uint16_t>((size_t)bs * n);
+            a.u_y = dev_alloc<uint16_t>((size_t)bs * n); a.u_bias = dev_alloc<uint16_t>(n); a.u_residual = res ? dev_alloc<uint16_t>((size_t)bs * n) : nullptr;
             a.ld_residual = n; a.t_out = dev_alloc<uint16_t>((size_t)bs * n); a.ld_t = n; a.x = dev_alloc<uint16_t>((size_t)bs * n); a.ldx = n;
             a.ln_gamma = dev_alloc<uint16_t>(n); a.ln_beta = dev_alloc<uint16_t>(n);
             for (int g = 0; g < groups; ++g) {
                 a.V[g] = make_fop(p, q);
-                a.colscale[g] = dev_alloc<float>(n); a.scale[g] = dev_alloc<float>(1); a.y[g] = dev_alloc<float>((size_t)bs * m, false);
+                a.colscale[g] = dev_alloc<float>(n); a.scale[g] = dev_alloc<float>(1); a.y[g] = dev_alloc<uint16_t>((size_t)bs * m, false);
             }
         } else a = args[0];
         for (int g = 0; g < groups; ++g) a.qweight[g] = dev_alloc<int32_t>((size_t)m * n / 16);
@@ -119,7 +119,7 @@ int main()
     run("L1 qkv block 0 (LN, V)", 64, 32, 2048, 3, false, 1, 1, 16);
     run("L1 qkv (U, LN, V)", 64, 32, 2048, 3, true, 1, 1, 16);
     run("L4 fc1 (U, LN, V)", 64, 32, 8192, 1, true, 1, 1, 16);
-    run("L6 fc2 (U relu, V)", 128, 64, 2048, 1, true, 0, 1, 16);
+    run("L6 fc2 (U relu, V)", 128, 64, 2048, 1, true, 0, 1, 16, false);
     run("llama qkv (U, RMS, V)", 64, 64, 4096, 3, true, 2, 1, 8);
     return 0;
 }

@@ -72,6 +72,7 @@ CASES = [
     (8192, 2048, 1, True, None, True, False, 1),
     (8192, 2048, 1, True, None, True, False, 3),
     (4096, 4096, 3, True, "rms", False, True, 1),
+    (2048, 2048, 1, True, None, False, True, 2),
     (4096, 11008 // 16 * 16, 2, False, "rms", False, False, 2),
 ]
 
@@ -86,13 +87,13 @@ def test_fused_stage_matches_the_chain_in_fp64(d, m, groups, has_u, norm, relu, 
     b = (0.05 * torch.randn(d, device=DEV)).half()
     ln_mod = _LN(g, b, 1e-5) if norm == "ln" else _RMS(g, 1e-5) if norm == "rms" else None
     ln64 = (g, b, 1e-5) if norm == "ln" else (g, None, 1e-5) if norm == "rms" else None
-    assert fused_ok(list(qls), bs, prev=prev)
+    assert fused_ok(list(qls), bs, prev=prev, norm=norm is not None, residual=residual)
     if has_u:
-        y_prev = torch.randn(bs, d, device=DEV) * 0.5
+        y_prev = (torch.randn(bs, d, device=DEV) * 0.5).half().float()     # the producing launch hands it over as fp16
         res = (torch.randn(bs, d, device=DEV)).half() if residual else None
         ys, t = fused_stage(list(qls), prev=prev, y_prev=y_prev, residual=res, relu=relu, ln=ln_mod, store=True)
         Ut = _dense(prev.U, transpose=True)
-        t64 = y_prev.double() @ Ut.t() + prev.bias.double()
+        t64 = y_prev.double() @ Ut.t() + prev.bias.half().double()
         if res is not None:
             t64 = t64 + res.double()
         if relu:
@@ -108,6 +109,11 @@ def test_fused_stage_matches_the_chain_in_fp64(d, m, groups, has_u, norm, relu, 
         assert t is None
         h_in = x.double()
     h = _norm64(h_in, ln64)
+    if d == 2048 and groups == 3:                            # the fp16 hand-over form: same numbers, rounded once more
+        ys16, _ = fused_stage(list(qls), x=None if has_u else x, prev=prev, y_prev=y_prev if has_u else None, residual=res if has_u else None,
+                              relu=relu, ln=ln_mod, store=has_u, y_dtype=torch.float16)
+        for a16, a32 in zip(ys16, ys):
+            assert torch.equal(a16, a32.half())
     for q, What, y in zip(qls, Whats, ys):
         Vd = _dense(q.V)
         xt = (h * q.inv_scaleWH.double()) @ Vd.t()
@@ -127,7 +133,7 @@ def test_fused_stage_agrees_with_the_round2_launches():
     ln = torch.nn.LayerNorm(d, device=DEV, dtype=torch.float16)
     ln.weight.data.add_(0.1 * torch.randn(d, device=DEV).half())
     ln.bias.data.add_(0.05 * torch.randn(d, device=DEV).half())
-    y_prev = torch.randn(bs, d, device=DEV)
+    y_prev = torch.randn(bs, d, device=DEV).half().float()       # a fused producer hands its output over as fp16
     res = torch.randn(bs, d, device=DEV).half()
     t_old = packed_u_stage([prev], [y_prev], torch.float16, residual=res)[0]
     ys_old = packed_gemm_stage(qls, packed_v_stage(qls, t_old, ln=ln))
