@@ -301,6 +301,16 @@ typedef struct quipamd_fused_gemm_args {
 } quipamd_fused_gemm_args;
 int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *args, void *stream);
 
+/* The same attention launch with the OUTPUT-SIDE operators of the q / k / v projections in its prologue (csrc/decode_attn.hip):
+ *     q = U_q^T y_q + b_q,  k = U_k^T y_k + b_k,  v = U_v^T y_v + b_v   (rounded to fp16),  [rotary on q, k],  then as above.
+ * U[3]: quipamd_fop records of the TRANSPOSED operators (all p x q with p q = heads hd); y[3]: fp16 [bs, heads hd] in the
+ * projected basis (a fused GEMM launch with y_dtype F16); bias[3]: fp16 [heads hd] (zeros where a layer has none);
+ * cos_table / sin_table: float [table_rows, hd] (HF's duplicated-halves layout) or both NULL (OPT: learned positions);
+ * out: fp16 [bs, ldo].  head_dim 64 with 64 x 32 operators (OPT-1.3B), 128 with 64 x 64 (Llama-2-7B) or 64 x 32. */
+int quipamd_decode_attention_fused(const quipamd_fop *U, const void *const *y, const void *const *bias, void *kcache, void *vcache,
+                                   const int64_t *pos, void *out, const float *cos_table, const float *sin_table, int64_t table_rows,
+                                   int64_t bs, int heads, int hd, int64_t maxlen, float scale, int64_t ldo, void *stream);
+
 /* ---- K4: LDLQ rounding -------------------------------------------------------------------------
  * Replaces round_ldl / round_ldl_block (vector_balance.py:155-199, 218-257; n_greedy_passes = 0):
  *   for i = d-1 .. 0:  q_i = clamp(floor(w_i + sum_{j>i} (w_j - q_j) L[j,i] + eta_i), 0, 2^bits - 1)

@@ -14,6 +14,7 @@
 //            activation dtype.
 // fp32 throughout (the eager chain rounds scores and probabilities to fp16); the result differs from it by that rounding.
 #include "common.h"
+#include "fpass.h"
 
 namespace {
 
@@ -212,6 +213,255 @@ extern "C" int quipamd_rope_inplace(void *q, void *k, const float *cos_table, co
         rope_kernel<BF16><<<grid, 256, 0, s>>>((uint16_t *)q, (uint16_t *)k, cos_table, sin_table, pos, table_rows, total, heads, kv_heads, hd, ldq, ldk);
     QA_LAUNCH_CHECK("quipamd_rope_inplace");
     return QUIPAMD_OK;
+}
+
+namespace {
+
+// ---- attention with the output-side operators of q / k / v in its prologue (decode step, fp16) -------------------------------------
+// The three dequant-GEMMs of a block hand over y_q, y_k, y_v in the projected basis; q = U_q^T y_q + b_q (likewise k, v) was a
+// launch of its own (4.7 us).  A head needs 64 (128) entries of each -- but behind the permutation they depend on the whole
+// image, so every (batch row, head) workgroup runs the three small operator passes itself (3 x 0.4 MFLOP on the fp16 matrix pipe,
+// images in LDS, fpass.h) and gathers only its head's slice; rotary (Llama) is applied to that slice in LDS.  Then the same
+// phases as decode_attn_kernel, with q read from LDS and this step's k, v appended to the cache from LDS.
+struct AttnUArgs {
+    Fop U[3];
+    const uint16_t *y[3];                 // f16 [bs, n]
+    const uint16_t *bias[3];              // f16 [n]
+    uint16_t *kc, *vc, *out;
+    const int64_t *pos;
+    const float *cos_t, *sin_t;           // rotary tables [table_rows, HD] or null
+    int64_t table_rows, maxlen, ldo;
+    int heads;
+    float scale;
+};
+
+template <int HD, int P, int Q>
+__global__ __launch_bounds__(256) void decode_attn_u_kernel(AttnUArgs G)
+{
+    typedef uint16_t S;
+    typedef F16 TI;
+    constexpr int NW = 4, N = P * Q;
+    typedef PassDims<P, Q, NW> D;
+    constexpr int NV = D::NV;
+    extern __shared__ __attribute__((aligned(16))) char smem_u[];
+    // [3 image sets][q k v slices f16 3 x HD][scores maxlen][red 8][part 4 x HD]
+    char *img = smem_u;
+    uint16_t *qkv = reinterpret_cast<uint16_t *>(smem_u + 3 * D::BYTES);
+    float *scores = reinterpret_cast<float *>(smem_u + 3 * D::BYTES + 3 * HD * 2 + 32);
+    float *red = scores + G.maxlen, *part = red + 8;
+    asm volatile("" ::"s"(G.U[0].F0), "s"(G.U[0].F1), "s"(G.U[0].load_idx), "s"(G.U[0].store_idx), "s"(G.U[1].F0), "s"(G.U[1].F1),
+                 "s"(G.U[1].load_idx), "s"(G.U[1].store_idx), "s"(G.U[2].F0), "s"(G.U[2].F1), "s"(G.U[2].load_idx), "s"(G.U[2].store_idx),
+                 "s"(G.y[0]), "s"(G.y[1]), "s"(G.y[2]), "s"(G.bias[0]), "s"(G.bias[1]), "s"(G.bias[2]), "s"(G.kc), "s"(G.vc), "s"(G.out),
+                 "s"(G.pos), "s"(G.cos_t), "s"(G.sin_t), "s"(G.table_rows), "s"(G.maxlen), "s"(G.ldo), "s"(G.heads), "s"(G.scale));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / G.heads, head = blockIdx.x % G.heads;
+    const int64_t pos = *G.pos, T = pos + 1;
+    if (pos < 0 || pos >= G.maxlen) return;                         // uniform; a full cache is the caller's error
+    S *kcb = G.kc + ((int64_t)b * G.heads + head) * G.maxlen * HD, *vcb = G.vc + ((int64_t)b * G.heads + head) * G.maxlen * HD;
+
+    // ---- prologue: q, k, v slices of this head ---------------------------------------------------------------------------------------
+    uint2 yv[3][NV], ld[3][NV];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const uint32_t v4 = tid + 256 * u;
+            yv[o][u] = *reinterpret_cast<const uint2 *>((G.y[o] + (int64_t)b * N) + 4 * v4);
+            ld[o][u] = *reinterpret_cast<const uint2 *>(G.U[o].load_idx + 4 * v4);
+        }
+    PassFrags<P, Q> fr[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        load_f0<P, Q, NW>(G.U[o], wave, lane, fr[o]);
+        load_f1<P, Q, NW>(G.U[o], wave, lane, fr[o]);
+    }
+    // the gather of the head's slice: thread t < 3 HD owns element (op = t / HD, e = t % HD)
+    const int gop = tid / HD, ge = tid - gop * HD;
+    uint32_t gst = 0;
+    uint16_t gbi = 0;
+    if (tid < 3 * HD) {
+        const int i = head * HD + ge;
+        gst = G.U[gop < 3 ? gop : 0].store_idx[i];
+        gbi = G.bias[gop < 3 ? gop : 0][i];
+    }
+    float rc = 1.f, rs_ = 0.f;
+    if (G.cos_t && tid < 2 * HD && pos < G.table_rows) {            // rotary on q and k: x[e] c - x[e + HD/2] s ; x[e + HD/2] c + x[e] s
+        rc = G.cos_t[pos * HD + (ge % (HD / 2))];
+        rs_ = G.sin_t[pos * HD + (ge % (HD / 2))];
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        uint16_t *ZT = reinterpret_cast<uint16_t *>(img + o * D::BYTES);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) scatter4h<P, Q>(ZT, yv[o][u], ld[o][u]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        uint16_t *ZT = reinterpret_cast<uint16_t *>(img + o * D::BYTES), *Z1 = reinterpret_cast<uint16_t *>(img + o * D::BYTES + D::ZT_B);
+        mix_stage1<P, Q, NW>(ZT, Z1, fr[o], wave, lane);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        uint16_t *Z1 = reinterpret_cast<uint16_t *>(img + o * D::BYTES + D::ZT_B);
+        float *ZF = reinterpret_cast<float *>(img + o * D::BYTES + D::ZT_B + D::Z1_B);
+        mix_stage2<P, Q, NW>(Z1, ZF, fr[o], wave, lane);
+    }
+    __syncthreads();
+    if (tid < 3 * HD) {
+        constexpr int qsh = __builtin_ctz(Q);
+        const float *ZF = reinterpret_cast<const float *>(img + gop * D::BYTES + D::ZT_B + D::Z1_B);
+        const float v = ZF[(gst >> qsh) * D::QF + (gst & (Q - 1))] + f16_bits_to_f32(gbi);
+        qkv[tid] = f32_to_f16_bits(v);                               // q, k, v exist as fp16 values, like the separate launch wrote them
+    }
+    __syncthreads();
+    if (G.cos_t) {                                                    // rotate_half form of HF's apply_rotary_pos_emb (llama.py:418-471), fp32 math
+        float r = 0.f;
+        if (tid < 2 * HD) {
+            const float a = f16_bits_to_f32(qkv[tid]);
+            const float o2 = f16_bits_to_f32(qkv[ge < HD / 2 ? tid + HD / 2 : tid - HD / 2]);
+            r = ge < HD / 2 ? a * rc - o2 * rs_ : a * rc + o2 * rs_;
+        }
+        __syncthreads();
+        if (tid < 2 * HD) qkv[tid] = f32_to_f16_bits(r);
+        __syncthreads();
+    }
+    // append this token's k, v; the barrier makes them visible to the cache reads below
+    if (tid >= HD && tid < 2 * HD) kcb[pos * HD + tid - HD] = qkv[tid];
+    else if (tid >= 2 * HD && tid < 3 * HD) vcb[pos * HD + tid - 2 * HD] = qkv[tid];
+    __syncthreads();
+
+    float qr[HD];
+#pragma unroll
+    for (int e8 = 0; e8 < HD; e8 += 8) {
+        S raw[8];
+        *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(qkv + e8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qr[e8 + e] = DT<TI>::load(raw, e) * G.scale;
+    }
+    constexpr int CH = HD / 8, RS = 64 / CH;
+    const int ch = lane % CH, rsub = lane / CH;
+    uint4 vraw0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int64_t t = (int64_t)wave * RS + (int64_t)u * 4 * RS + rsub;
+        vraw0[u] = t < T ? *reinterpret_cast<const uint4 *>(vcb + t * HD + 8 * ch) : make_uint4(0, 0, 0, 0);
+    }
+    float mx = -INFINITY;
+    for (int64_t t = tid; t < T; t += 256) {
+        const S *row = kcb + t * HD;
+        float acc = 0.f;
+#pragma unroll
+        for (int e8 = 0; e8 < HD; e8 += 8) {
+            S raw[8];
+            *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(row + e8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(qr[e8 + e], DT<TI>::load(raw, e), acc);
+        }
+        scores[t] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_reduce<true>(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int64_t t = tid; t < T; t += 256) {
+        const float p_ = __expf(scores[t] - mx);
+        scores[t] = p_;
+        sum += p_;
+    }
+    sum = wave_reduce<false>(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    bool first = true;
+    for (int64_t tb = (int64_t)wave * RS; tb < T; tb += 4 * RS * 8) {
+        uint4 raw[8];
+        float pw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t t = tb + (int64_t)u * 4 * RS + rsub;
+            const bool ok = t < T;
+            if (first) raw[u] = vraw0[u];
+            else raw[u] = ok ? *reinterpret_cast<const uint4 *>(vcb + t * HD + 8 * ch) : make_uint4(0, 0, 0, 0);
+            pw[u] = ok ? scores[t] : 0.f;
+        }
+        first = false;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const S *rv = reinterpret_cast<const S *>(&raw[u]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(pw[u], DT<TI>::load(rv, e), o[e]);
+        }
+    }
+#pragma unroll
+    for (int off = CH; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += __shfl_xor(o[e], off);
+    if (rsub == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[wave * HD + 8 * ch + e] = o[e];
+    }
+    __syncthreads();
+    if (tid < HD) {
+        const float r = (part[tid] + part[HD + tid]) + (part[2 * HD + tid] + part[3 * HD + tid]);
+        DT<TI>::store(G.out + (int64_t)b * G.ldo + head * HD, tid, r * inv);
+    }
+}
+
+template <int HD, int P, int Q> int launch_attn_u(const AttnUArgs &A, int64_t bs, hipStream_t s)
+{
+    typedef PassDims<P, Q, 4> D;
+    const size_t lds = 3 * D::BYTES + 3 * HD * 2 + 32 + (size_t)(A.maxlen + 8 + 4 * HD) * sizeof(float);
+    auto kern = decode_attn_u_kernel<HD, P, Q>;
+    static size_t reserved[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const bool known = dev >= 0 && dev < 64;
+    if (lds > 160 * 1024) return qa_fail(QUIPAMD_ERR_SHAPE, "decode_attention_fused: %zu B of LDS (maxlen too large for this operator shape)", lds);
+    if (lds > 48 * 1024 && (!known || lds > reserved[dev])) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_attention_fused: cannot reserve %zu B of LDS", lds);
+        if (known) reserved[dev] = lds;
+    }
+    kern<<<(unsigned)(bs * A.heads), 256, lds, s>>>(A);
+    QA_LAUNCH_CHECK("decode_attention_fused");
+    return QUIPAMD_OK;
+}
+
+}   // namespace
+
+extern "C" int quipamd_decode_attention_fused(const quipamd_fop *U, const void *const *y, const void *const *bias, void *kcache, void *vcache,
+                                              const int64_t *pos, void *out, const float *cos_table, const float *sin_table,
+                                              int64_t table_rows, int64_t bs, int heads, int hd, int64_t maxlen, float scale, int64_t ldo,
+                                              void *stream)
+{
+    QA_REQUIRE(bs >= 0 && heads > 0 && maxlen > 0 && maxlen <= 32768, QUIPAMD_ERR_SHAPE, "decode_attention_fused: bad shape");
+    if (bs == 0) return QUIPAMD_OK;
+    QA_REQUIRE(U && y && bias && kcache && vcache && pos && out, QUIPAMD_ERR_ARG, "decode_attention_fused: null pointer");
+    QA_REQUIRE((cos_table == nullptr) == (sin_table == nullptr) && (!cos_table || table_rows > 0), QUIPAMD_ERR_ARG, "decode_attention_fused: rotary tables");
+    const int p = U[0].p, q = U[0].q;
+    QA_REQUIRE((int64_t)p * q == (int64_t)heads * hd, QUIPAMD_ERR_SHAPE, "decode_attention_fused: operator %d x %d vs heads %d x %d", p, q, heads, hd);
+    QA_REQUIRE(ldo >= (int64_t)heads * hd, QUIPAMD_ERR_SHAPE, "decode_attention_fused: out row stride");
+    AttnUArgs A;
+    for (int o = 0; o < 3; ++o) {
+        QA_REQUIRE(U[o].F0 && U[o].F1 && U[o].load_idx && U[o].store_idx && U[o].p == p && U[o].q == q && y[o] && bias[o], QUIPAMD_ERR_ARG,
+                   "decode_attention_fused: operator / y / bias %d", o);
+        A.U[o] = U[o]; A.y[o] = (const uint16_t *)y[o]; A.bias[o] = (const uint16_t *)bias[o];
+    }
+    A.kc = (uint16_t *)kcache; A.vc = (uint16_t *)vcache; A.out = (uint16_t *)out; A.pos = pos; A.cos_t = cos_table; A.sin_t = sin_table;
+    A.table_rows = table_rows; A.maxlen = maxlen; A.ldo = ldo; A.heads = heads; A.scale = scale;
+    hipStream_t s = (hipStream_t)stream;
+    if (hd == 64 && p == 64 && q == 32) return launch_attn_u<64, 64, 32>(A, bs, s);
+    if (hd == 128 && p == 64 && q == 64) return launch_attn_u<128, 64, 64>(A, bs, s);
+    if (hd == 128 && p == 64 && q == 32) return launch_attn_u<128, 64, 32>(A, bs, s);
+    return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_attention_fused: head_dim %d with a %d x %d operator (64 with 64 x 32; 128 with 64 x 64 or 64 x 32)", hd, p, q);
 }
 
 extern "C" int quipamd_decode_attention(const void *q, const void *k, const void *v, void *kcache, void *vcache, const int64_t *pos,

@@ -24,8 +24,7 @@
 // Same STREAM weight layout, same epilogue algebra as dqgemm_vop.hip / dqgemm.hip (value = OFF + code, y = alpha (acc - c0 sum x)).
 #include "common.h"
 #include "dq_common.h"
-
-#include <type_traits>
+#include "fpass.h"
 
 namespace {
 
@@ -44,8 +43,6 @@ __device__ unsigned long long fg_probe_buf[32];
 #else
 #define FG_STAMP(i)
 #endif
-
-typedef quipamd_fop Fop;
 
 struct FGroup {                           // one packed layer of the launch (blockIdx.y): 72 bytes of kernarg, fetched together
     Fop V;
@@ -74,29 +71,6 @@ struct FusedArgs {
 // use, and the prologue of this kernel was SEVEN serial kernarg round trips (~2000 cycles) before its first global load
 template <class T> __device__ __forceinline__ void touch_s(T *p) { asm volatile("" ::"s"(p)); }
 
-__device__ __forceinline__ uint32_t pack_f16x2(float a, float b)
-{
-    return (uint32_t)f32_to_f16_bits(a) | ((uint32_t)f32_to_f16_bits(b) << 16);
-}
-__device__ __forceinline__ float4 f16x4_to_f32(const uint2 &r)
-{
-    return make_float4(f16_bits_to_f32(r.x & 0xffff), f16_bits_to_f32(r.x >> 16), f16_bits_to_f32(r.y & 0xffff), f16_bits_to_f32(r.y >> 16));
-}
-
-// wave-wide sum on the DPP network; every lane gets the total
-__device__ __forceinline__ float fg_wave_sum(float v)
-{
-    auto dpp = [](float x, auto ctrl) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
-    };
-    v += dpp(v, std::integral_constant<int, 0xB1>{});
-    v += dpp(v, std::integral_constant<int, 0x4E>{});
-    v += dpp(v, std::integral_constant<int, 0x141>{});
-    v += dpp(v, std::integral_constant<int, 0x140>{});
-    const int b = __builtin_bit_cast(int, v);
-    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
-           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
-}
 // block-wide sum over the 16 waves: one LDS round, ONE barrier; each call site owns its own red[16]
 __device__ __forceinline__ float fg_block_sum(float v, float *red)
 {
@@ -110,130 +84,6 @@ __device__ __forceinline__ float fg_block_sum(float v, float *red)
         t += (r.x + r.y) + (r.z + r.w);
     }
     return t;
-}
-
-// ---- the operator pass --------------------------------------------------------------------------------------------------------
-// LDS images of one pass (P x Q operator, n = P Q):
-//   ZT  f16 [Q][P + 8]   z^T: element at image position (a, b) sits at ZT[b][a]          input of stage 1 (A fragments: 8 consecutive a')
-//   Z1  f16 [P][Q + 8]   result of stage 1 ("mix a"), row a                                 input of stage 2 (A fragments: 8 consecutive b')
-//   ZF  f32 [P][Q + 4]   result of stage 2 = the operator's image, gathered by store_idx
-template <int P, int Q> struct PassDims {
-    static constexpr int N = P * Q, PS = P + 8, QS = Q + 8, QF = Q + 4;
-    static constexpr int NT = (P / 16) * (Q / 16);                 // 16 x 16 output tiles per stage
-    static constexpr int TPW = (NT + FG_NW - 1) / FG_NW;          // tiles per wave
-    static constexpr int S0 = P / 32, S1 = Q / 32;                 // k-steps of stage 1 / stage 2
-    static constexpr int NV = (N / 4 + 1023) / 1024;               // float4 slots per thread (natural order: slot v4 = tid + 1024 u)
-    static constexpr size_t ZT_B = (size_t)Q * PS * 2, Z1_B = (size_t)P * QS * 2, ZF_B = (size_t)P * QF * 4;
-    static constexpr size_t BYTES = ZT_B + Z1_B + ZF_B;
-    static_assert(P % 32 == 0 && Q % 32 == 0 && (Q & (Q - 1)) == 0, "operator shape");
-};
-
-// this wave's factor fragments (host layout: F0 [P/16][P/32][64 lanes] uint4, F1 [Q/16][Q/32][64] uint4).  A wave's tiles are
-// wave, wave + 16, ...: because 16 is a multiple of P/16 and of Q/16 they all share the stage-1 fragment (it depends on at = tile %
-// (P/16) only) and the stage-2 fragment (bt = tile % (Q/16)): ONE set per wave, loaded straight from global memory in fragment order.
-template <int P, int Q> struct PassFrags {
-    uint4 f0[PassDims<P, Q>::S0];
-    uint4 f1[PassDims<P, Q>::S1];
-};
-
-template <int P, int Q> __device__ __forceinline__ void load_f0(const Fop &op, int wave, int lane, PassFrags<P, Q> &fr)
-{
-    typedef PassDims<P, Q> D;
-    static_assert(FG_NW % (P / 16) == 0 && FG_NW % (Q / 16) == 0, "a wave's tiles share their fragments");
-    const uint4 *F0 = reinterpret_cast<const uint4 *>(op.F0);
-    const int at = wave % (P / 16);
-    if (wave < D::NT) {                                     // 64 x 32: eight tiles -- waves 8..15 own none and must not pull fragments
-#pragma unroll                                              // through the CU's one vector-memory path (64 B per clock, the prologue's bound)
-        for (int S = 0; S < D::S0; ++S) fr.f0[S] = F0[(at * D::S0 + S) * 64 + lane];
-    }
-}
-template <int P, int Q> __device__ __forceinline__ void load_f1(const Fop &op, int wave, int lane, PassFrags<P, Q> &fr)
-{
-    typedef PassDims<P, Q> D;
-    const uint4 *F1 = reinterpret_cast<const uint4 *>(op.F1);
-    const int bt = wave % (Q / 16);
-    if (wave < D::NT) {
-#pragma unroll
-        for (int S = 0; S < D::S1; ++S) fr.f1[S] = F1[(bt * D::S1 + S) * 64 + lane];
-    }
-}
-
-// scatter 4 consecutive natural-order values into the stage-1 input image: value e goes to image position pos[e] = (a, b) -> ZT[b][a]
-template <int P, int Q> __device__ __forceinline__ void scatter4(uint16_t *ZT, const float4 &v, const uint2 &pos)
-{
-    typedef PassDims<P, Q> D;
-    constexpr int qsh = __builtin_ctz(Q);
-    const float vv[4] = {v.x, v.y, v.z, v.w};
-    const int pp[4] = {(int)(pos.x & 0xffff), (int)(pos.x >> 16), (int)(pos.y & 0xffff), (int)(pos.y >> 16)};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) ZT[(pp[e] & (Q - 1)) * D::PS + (pp[e] >> qsh)] = f32_to_f16_bits(vv[e]);
-}
-
-// the same for 4 values that already ARE f16 bits (the previous GEMM's output)
-template <int P, int Q> __device__ __forceinline__ void scatter4h(uint16_t *ZT, const uint2 &v, const uint2 &pos)
-{
-    typedef PassDims<P, Q> D;
-    constexpr int qsh = __builtin_ctz(Q);
-    const uint16_t vv[4] = {(uint16_t)(v.x & 0xffff), (uint16_t)(v.x >> 16), (uint16_t)(v.y & 0xffff), (uint16_t)(v.y >> 16)};
-    const int pp[4] = {(int)(pos.x & 0xffff), (int)(pos.x >> 16), (int)(pos.y & 0xffff), (int)(pos.y >> 16)};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) ZT[(pp[e] & (Q - 1)) * D::PS + (pp[e] >> qsh)] = vv[e];
-}
-
-// the two mix stages: ZT -> Z1 -> ZF.  Caller: a barrier after the scatter; this function ends WITHOUT a barrier after writing ZF.
-template <int P, int Q>
-__device__ __forceinline__ void mix_stages(const uint16_t *ZT, uint16_t *Z1, float *ZF, const PassFrags<P, Q> &fr, int wave, int lane)
-{
-    typedef PassDims<P, Q> D;
-    const int j = lane & 15, g = lane >> 4;
-    // stage 1, transposed: D1[m = b][n = a] = sum_a' ZT[b][a'] M0[a][a'];  A = ZT rows (LDS), B = M0 rows (registers)
-#pragma unroll
-    for (int i = 0; i < D::TPW; ++i) {
-        const int tile = wave + FG_NW * i;
-        if (tile < D::NT) {
-            const int at = tile % (P / 16), bt = tile / (P / 16);
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-            const uint16_t *arow = ZT + (16 * bt + j) * D::PS + 8 * g;
-#pragma unroll
-            for (int S = 0; S < D::S0; ++S) {
-                const uint4 a = *reinterpret_cast<const uint4 *>(arow + 32 * S);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, fr.f0[S]), acc, 0, 0, 0);
-            }
-            // lane: a = 16 at + j, b = 16 bt + 4 g + {0..3}: four consecutive b of row a -> one 8-byte store
-            uint2 pk;
-            pk.x = pack_f16x2(acc[0], acc[1]);
-            pk.y = pack_f16x2(acc[2], acc[3]);
-            *reinterpret_cast<uint2 *>(Z1 + (16 * at + j) * D::QS + 16 * bt + 4 * g) = pk;
-        }
-    }
-    __syncthreads();
-    // stage 2: D2[m = a][n = b] = sum_b' Z1[a][b'] M1[b][b'];  A = Z1 rows (LDS), B = M1 rows (registers)
-#pragma unroll
-    for (int i = 0; i < D::TPW; ++i) {
-        const int tile = wave + FG_NW * i;
-        if (tile < D::NT) {
-            const int bt = tile % (Q / 16), at = tile / (Q / 16);
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-            const uint16_t *arow = Z1 + (16 * at + j) * D::QS + 8 * g;
-#pragma unroll
-            for (int S = 0; S < D::S1; ++S) {
-                const uint4 a = *reinterpret_cast<const uint4 *>(arow + 32 * S);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, fr.f1[S]), acc, 0, 0, 0);
-            }
-            // lane: b = 16 bt + j, a = 16 at + 4 g + reg
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) ZF[(16 * at + 4 * g + reg) * D::QF + 16 * bt + j] = acc[reg];
-        }
-    }
-}
-
-template <int P, int Q> __device__ __forceinline__ float4 gather4(const float *ZF, const uint2 &pos)
-{
-    typedef PassDims<P, Q> D;
-    constexpr int qsh = __builtin_ctz(Q);
-    const int p0 = (int)(pos.x & 0xffff), p1 = (int)(pos.x >> 16), p2 = (int)(pos.y & 0xffff), p3 = (int)(pos.y >> 16);
-    return make_float4(ZF[(p0 >> qsh) * D::QF + (p0 & (Q - 1))], ZF[(p1 >> qsh) * D::QF + (p1 & (Q - 1))],
-                       ZF[(p2 >> qsh) * D::QF + (p2 & (Q - 1))], ZF[(p3 >> qsh) * D::QF + (p3 & (Q - 1))]);
 }
 
 // ---- the fused launch ------------------------------------------------------------------------------------------------------------

@@ -806,3 +806,29 @@ def decode_attention(q, k, v, kcache, vcache, pos, scale=None):
     _lib.call("quipamd_decode_attention", _p(q), _p(k), _p(v), _p(kcache), _p(vcache), _p(pos), _p(out), _dtype(q), bs,
               heads, hd, maxlen, ctypes.c_float(sc), ld, _stream())
     return out
+
+
+def decode_attention_fused(Uops, ys, biases, kcache, vcache, pos, cos_table=None, sin_table=None, scale=None):
+    """decode attention with the output-side operators of q / k / v in its prologue (quipamd_decode_attention_fused):
+    Uops: the three OrthoOp of the projections (applied transposed); ys: their GEMM outputs in the projected basis, fp16 [bs, heads*hd];
+    biases: fp16 [heads*hd] each; rotary tables float32 [rows, hd] (Llama) or None.  Returns out fp16 [bs, heads*hd]."""
+    _need_gpu(kcache, vcache, pos, *ys)
+    bs, heads, maxlen, hd = kcache.shape
+    n = heads * hd
+    assert len(Uops) == len(ys) == len(biases) == 3 and kcache.dtype == vcache.dtype == torch.float16
+    assert kcache.is_contiguous() and vcache.is_contiguous() and pos.dtype == torch.int64 and pos.numel() == 1
+    for y, bv in zip(ys, biases):
+        assert y.dtype == torch.float16 and y.shape == (bs, n) and y.is_contiguous() and bv.dtype == torch.float16 and bv.numel() == n
+    fops = (Fop * 3)(*[o.fop(True) for o in Uops])
+    vp = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    out = torch.empty((bs, n), dtype=torch.float16, device=kcache.device)
+    rows = 0
+    if cos_table is not None:
+        assert cos_table.dtype == sin_table.dtype == torch.float32 and cos_table.shape == sin_table.shape and cos_table.shape[1] == hd
+        assert cos_table.is_contiguous() and sin_table.is_contiguous()
+        rows = cos_table.shape[0]
+    sc = float(scale) if scale is not None else 1.0 / (hd ** 0.5)
+    _lib.call("quipamd_decode_attention_fused", ctypes.cast(fops, ctypes.c_void_p), ctypes.cast(vp(ys), ctypes.c_void_p),
+              ctypes.cast(vp(biases), ctypes.c_void_p), _p(kcache), _p(vcache), _p(pos), _p(out), _p(cos_table), _p(sin_table), rows, bs,
+              heads, hd, maxlen, ctypes.c_float(sc), n, _stream())
+    return out

@@ -557,6 +557,31 @@ def fused_ok(qls, rows, x_dtype=torch.float16, prev=None, norm=True, residual=Tr
     return ok
 
 
+def bias16(ql):
+    """the layer's bias as fp16 [out] on its device (zeros when it has none), kept on the module: what the fused decode launches read
+    (OPT's biases ARE fp16 values, held as fp32 for the K3 kernels: exact)"""
+    b = ql.__dict__.get('_bias16')
+    dev = ql.qweight.device
+    if b is None or b.device != dev:
+        b = (ql.bias.to(torch.float16) if ql.bias is not None else torch.zeros(ql.outfeatures, dtype=torch.float16, device=dev)).contiguous()
+        ql.__dict__['_bias16'] = b
+    return b
+
+
+def fused_attention(qkv, ys, kcache, vcache, pos, cos_table=None, sin_table=None):
+    """decode attention with U_q^T, U_k^T, U_v^T (+ bias) of the three packed projections `qkv` in its prologue; ys: their fp16 GEMM
+    outputs from fused_stage(..., y_dtype=torch.float16)"""
+    return ops.decode_attention_fused([q.U for q in qkv], ys, [bias16(q) for q in qkv], kcache, vcache, pos, cos_table, sin_table)
+
+
+def fused_attention_ok(qkv, kcache):
+    bs, heads, maxlen, hd = kcache.shape
+    shapes = {(q.U.p, q.U.q) for q in qkv if q.U is not None}
+    return (len(qkv) == 3 and all(q.U is not None and q.U.fused_ok for q in qkv) and len(shapes) == 1 and kcache.dtype == torch.float16
+            and next(iter(shapes)) in (((64, 32),) if hd == 64 else ((64, 64), (64, 32)) if hd == 128 else ())
+            and all(q.outfeatures == heads * hd for q in qkv))
+
+
 def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, ln=None, store=False, y_dtype=torch.float32):
     """ONE launch (quipamd_decode_fused_gemm) for everything between two dequant-GEMMs of a decode step:
         t    = [relu]( U_prev^T y_prev + bias_prev + residual )     when `prev` (the packed layer that produced y_prev) is given,
@@ -582,11 +607,7 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
         kw.update(x=x.contiguous())
     else:
         t = torch.empty((rows, d), dtype=torch.float16, device=dev) if store else None
-        b16 = prev.__dict__.get('_bias16')
-        if b16 is None or b16.device != dev:                # OPT's biases ARE fp16 values (kept as fp32 for the K3 kernels): exact
-            b16 = (prev.bias.to(torch.float16) if prev.bias is not None else torch.zeros(d, dtype=torch.float16, device=dev)).contiguous()
-            prev.__dict__['_bias16'] = b16
-        kw.update(U=prev.U.fop(True), u_y=y_prev.to(torch.float16).contiguous(), u_bias=b16,
+        kw.update(U=prev.U.fop(True), u_y=y_prev.to(torch.float16).contiguous(), u_bias=bias16(prev),
                   u_residual=None if residual is None else residual.contiguous(), u_relu=relu, t_out=t)
     ops.decode_fused_gemm(**kw)
     return ys, t

@@ -30,7 +30,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quip_amd import ops, method  # noqa: E402
 from quip_amd.quant import (QuantLinear, packed_forward_fused, packed_v_stage, packed_gemm_stage, packed_u_stage,  # noqa: E402
-                            packed_u_then_v, packed_vgemm_stage, vgemm_fusable, fused_stage, fused_ok)
+                            packed_u_then_v, packed_vgemm_stage, vgemm_fusable, fused_stage, fused_ok, fused_attention, fused_attention_ok)
 
 
 class Block(nn.Module):
@@ -124,6 +124,7 @@ class Decoder(nn.Module):
 
     split_handover = False
 
+    v3_attn = True           # with v3: the output-side operators of q / k / v in the attention launch (csrc/decode_attn.hip) -- 5 launches
     v3 = False               # csrc/decode_fused.hip: everything between two GEMMs in the consuming GEMM's prologue -- 6 launches per block
 
     def v3_ok(self, bs):
@@ -137,15 +138,20 @@ class Decoder(nn.Module):
         one tiled operator launch."""
         dt = x.dtype
         prev, y2 = None, None
+        h16 = torch.float16                                     # y consumed by another fused launch: fp16 (its scatter rounds to fp16 anyway)
         for blk, (kc, vc) in zip(self.blocks, caches):
             qkv = [blk.q_proj, blk.k_proj, blk.v_proj]
+            attn_u = self.v3_attn and fused_attention_ok(qkv, kc)
+            ydt = h16 if attn_u else torch.float32
             if prev is None:
-                ys, _ = fused_stage(qkv, x=x, ln=blk.ln1)
+                ys, _ = fused_stage(qkv, x=x, ln=blk.ln1, y_dtype=ydt)
             else:
-                ys, x = fused_stage(qkv, prev=prev, y_prev=y2, residual=x, ln=blk.ln1, store=True)
-            q, k, v = packed_u_stage(qkv, ys, dt)
-            o = ops.decode_attention(q, k, v, kc, vc, pos)
-            h16 = torch.float16                                 # y consumed by another fused launch: fp16 (its scatter rounds to fp16 anyway)
+                ys, x = fused_stage(qkv, prev=prev, y_prev=y2, residual=x, ln=blk.ln1, store=True, y_dtype=ydt)
+            if attn_u:                                          # U_q^T, U_k^T, U_v^T + bias in the attention launch's prologue: 5 launches per block
+                o = fused_attention(qkv, ys, kc, vc, pos)
+            else:
+                q, k, v = packed_u_stage(qkv, ys, dt)
+                o = ops.decode_attention(q, k, v, kc, vc, pos)
             yo = fused_stage([blk.out_proj], x=o, y_dtype=h16)[0][0]
             (y1,), x = fused_stage([blk.fc1], prev=blk.out_proj, y_prev=yo, residual=x, ln=blk.ln2, store=True, y_dtype=h16)
             last = blk is self.blocks[-1]
@@ -301,10 +307,12 @@ def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense
                                                               "logits_bit_identical_to_vfused": bool(torch.equal(lh, lv))}
         if model.v3_ok(bs):
             model.v3 = True
-            torch.manual_seed(7)
-            med, mean, l3 = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
-            out["packed_w%d_v3" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
-                                           "logits_rel_diff_vs_chained": float((l3 - lc).norm() / lc.norm())}
+            for flag, key in ((False, "packed_w%d_v3_6launch" % bits), (True, "packed_w%d_v3" % bits)):
+                type(model).v3_attn = flag
+                torch.manual_seed(7)
+                med, mean, l3 = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+                out[key] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+                            "logits_rel_diff_vs_chained": float((l3 - lc).norm() / lc.norm())}
             model.v3 = False
         if v3_only:
             return out

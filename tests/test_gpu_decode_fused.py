@@ -152,3 +152,38 @@ def test_fused_stage_rejects_what_it_cannot_run():
     a.act_dtype, a.bits, a.ngroups, a.bs = 2, 2, 1, 1
     with pytest.raises(_lib.QuipAmdError):
         _lib.call("quipamd_decode_fused_gemm", __import__("ctypes").byref(a), None)
+
+
+@pytest.mark.parametrize("n,heads,hd,rope,bs,pos", [(2048, 32, 64, False, 1, 37), (2048, 32, 64, False, 2, 0), (4096, 32, 128, True, 1, 21),
+                                                     (4096, 32, 128, False, 2, 5), (2048, 16, 128, True, 1, 63)])
+def test_attention_with_the_output_side_operators_in_its_prologue(n, heads, hd, rope, bs, pos):
+    """quipamd_decode_attention_fused against the three launches it replaces (tiled U^T + bias of q / k / v [+ rotary] + decode
+    attention): out and the appended cache rows"""
+    from quip_amd import ops
+    from quip_amd.quant import packed_u_stage, fused_attention, fused_attention_ok
+    qkv = [_layer(n, n, 700 + i + n % 13)[0] for i in range(3)]
+    maxlen = 64
+    torch.manual_seed(n + pos)
+    kc = (0.5 * torch.randn(bs, heads, maxlen, hd, device=DEV)).half()
+    vc = (0.5 * torch.randn(bs, heads, maxlen, hd, device=DEV)).half()
+    ys = [(0.5 * torch.randn(bs, n, device=DEV)).half() for _ in range(3)]
+    p_t = torch.tensor([pos], device=DEV)
+    cos = sin = None
+    if rope:
+        inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+        emb = torch.cat([torch.outer(torch.arange(maxlen, dtype=torch.float32), inv)] * 2, -1)
+        cos, sin = emb.cos().to(DEV).contiguous(), emb.sin().to(DEV).contiguous()
+    assert fused_attention_ok(qkv, kc)
+    kc0, vc0 = kc.clone(), vc.clone()
+    q, k, v = packed_u_stage(qkv, [y.float() for y in ys], torch.float16)
+    if rope:
+        ops.rope_inplace(q, k, cos, sin, p_t, heads)
+    want = ops.decode_attention(q, k, v, kc0, vc0, p_t)
+    got = fused_attention(qkv, ys, kc, vc, p_t, cos, sin)
+    torch.cuda.synchronize()
+    for a, b_ in ((kc[:, :, pos], kc0[:, :, pos]), (vc[:, :, pos], vc0[:, :, pos])):
+        assert float((a.float() - b_.float()).norm() / b_.float().norm()) <= 2e-3
+    mask = torch.ones(maxlen, dtype=torch.bool, device=DEV)
+    mask[pos] = False
+    assert torch.equal(kc[:, :, mask], kc0[:, :, mask]) and torch.equal(vc[:, :, mask], vc0[:, :, mask])    # nothing else touched
+    assert float((got.float() - want.float()).norm() / want.float().norm()) <= 3e-3
