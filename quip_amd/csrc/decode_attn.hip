@@ -276,19 +276,24 @@ __global__ __launch_bounds__(256) void decode_attn_u_kernel(AttnUArgs G)
         load_f0<P, Q, NW>(G.U[o], wave, lane, fr[o]);
         load_f1<P, Q, NW>(G.U[o], wave, lane, fr[o]);
     }
-    // the gather of the head's slice: thread t < 3 HD owns element (op = t / HD, e = t % HD)
-    const int gop = tid / HD, ge = tid - gop * HD;
-    uint32_t gst = 0;
-    uint16_t gbi = 0;
-    if (tid < 3 * HD) {
-        const int i = head * HD + ge;
-        gst = G.U[gop < 3 ? gop : 0].store_idx[i];
-        gbi = G.bias[gop < 3 ? gop : 0][i];
-    }
-    float rc = 1.f, rs_ = 0.f;
-    if (G.cos_t && tid < 2 * HD && pos < G.table_rows) {            // rotary on q and k: x[e] c - x[e + HD/2] s ; x[e + HD/2] c + x[e] s
-        rc = G.cos_t[pos * HD + (ge % (HD / 2))];
-        rs_ = G.sin_t[pos * HD + (ge % (HD / 2))];
+    // the gather of the head's slice: element t < 3 HD = (op = t / HD, e = t % HD), owned by thread t % 256 (HD = 128: two rounds)
+    constexpr int GR = (3 * HD + 255) / 256;
+    uint32_t gst[GR];
+    uint16_t gbi[GR];
+    float rc[GR], rs_[GR];
+#pragma unroll
+    for (int it = 0; it < GR; ++it) {
+        const int t = tid + 256 * it;
+        gst[it] = 0; gbi[it] = 0; rc[it] = 1.f; rs_[it] = 0.f;
+        if (t < 3 * HD) {
+            const int gop = t / HD, ge = t - gop * HD, i = head * HD + ge;
+            gst[it] = gop == 0 ? G.U[0].store_idx[i] : gop == 1 ? G.U[1].store_idx[i] : G.U[2].store_idx[i];
+            gbi[it] = gop == 0 ? G.bias[0][i] : gop == 1 ? G.bias[1][i] : G.bias[2][i];
+            if (G.cos_t && gop < 2 && pos < G.table_rows) {         // rotary on q and k: x[e] c - x[e + HD/2] s ; x[e + HD/2] c + x[e] s
+                rc[it] = G.cos_t[pos * HD + (ge % (HD / 2))];
+                rs_[it] = G.sin_t[pos * HD + (ge % (HD / 2))];
+            }
+        }
     }
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
@@ -310,27 +315,46 @@ __global__ __launch_bounds__(256) void decode_attn_u_kernel(AttnUArgs G)
         mix_stage2<P, Q, NW>(Z1, ZF, fr[o], wave, lane);
     }
     __syncthreads();
-    if (tid < 3 * HD) {
-        constexpr int qsh = __builtin_ctz(Q);
-        const float *ZF = reinterpret_cast<const float *>(img + gop * D::BYTES + D::ZT_B + D::Z1_B);
-        const float v = ZF[(gst >> qsh) * D::QF + (gst & (Q - 1))] + f16_bits_to_f32(gbi);
-        qkv[tid] = f32_to_f16_bits(v);                               // q, k, v exist as fp16 values, like the separate launch wrote them
+#pragma unroll
+    for (int it = 0; it < GR; ++it) {
+        const int t = tid + 256 * it;
+        if (t < 3 * HD) {
+            constexpr int qsh = __builtin_ctz(Q);
+            const int gop = t / HD;
+            const float *ZF = reinterpret_cast<const float *>(img + gop * D::BYTES + D::ZT_B + D::Z1_B);
+            const float v = ZF[(gst[it] >> qsh) * D::QF + (gst[it] & (Q - 1))] + f16_bits_to_f32(gbi[it]);
+            qkv[t] = f32_to_f16_bits(v);                             // q, k, v exist as fp16 values, like the separate launch wrote them
+        }
     }
     __syncthreads();
     if (G.cos_t) {                                                    // rotate_half form of HF's apply_rotary_pos_emb (llama.py:418-471), fp32 math
-        float r = 0.f;
-        if (tid < 2 * HD) {
-            const float a = f16_bits_to_f32(qkv[tid]);
-            const float o2 = f16_bits_to_f32(qkv[ge < HD / 2 ? tid + HD / 2 : tid - HD / 2]);
-            r = ge < HD / 2 ? a * rc - o2 * rs_ : a * rc + o2 * rs_;
+        float r[GR];
+#pragma unroll
+        for (int it = 0; it < GR; ++it) {
+            const int t = tid + 256 * it;
+            r[it] = 0.f;
+            if (t < 2 * HD) {
+                const int ge = t % HD;
+                const float a = f16_bits_to_f32(qkv[t]);
+                const float o2 = f16_bits_to_f32(qkv[ge < HD / 2 ? t + HD / 2 : t - HD / 2]);
+                r[it] = ge < HD / 2 ? a * rc[it] - o2 * rs_[it] : a * rc[it] + o2 * rs_[it];
+            }
         }
         __syncthreads();
-        if (tid < 2 * HD) qkv[tid] = f32_to_f16_bits(r);
+#pragma unroll
+        for (int it = 0; it < GR; ++it) {
+            const int t = tid + 256 * it;
+            if (t < 2 * HD) qkv[t] = f32_to_f16_bits(r[it]);
+        }
         __syncthreads();
     }
     // append this token's k, v; the barrier makes them visible to the cache reads below
-    if (tid >= HD && tid < 2 * HD) kcb[pos * HD + tid - HD] = qkv[tid];
-    else if (tid >= 2 * HD && tid < 3 * HD) vcb[pos * HD + tid - 2 * HD] = qkv[tid];
+#pragma unroll
+    for (int it = 0; it < GR; ++it) {
+        const int t = tid + 256 * it;
+        if (t >= HD && t < 2 * HD) kcb[pos * HD + t - HD] = qkv[t];
+        else if (t >= 2 * HD && t < 3 * HD) vcb[pos * HD + t - 2 * HD] = qkv[t];
+    }
     __syncthreads();
 
     float qr[HD];
