@@ -311,6 +311,10 @@ int quipamd_decode_attention_fused(const quipamd_fop *U, const void *const *y, c
                                    const int64_t *pos, void *out, const float *cos_table, const float *sin_table, int64_t table_rows,
                                    int64_t bs, int heads, int hd, int64_t maxlen, float scale, int64_t ldo, void *stream);
 
+/* Greedy token of a decode step: out[r] = argmax_i x[r, i] (int64, DEVICE), the smallest index among equal maxima like torch.argmax;
+ * x: [rows, n] f32 / f16 / bf16 with row stride ld.  One workgroup per row (benchmark(), opt.py:463-480 picks the next token this way). */
+int quipamd_argmax_rows(const void *x, int dtype, int64_t rows, int64_t n, int64_t ld, int64_t *out, void *stream);
+
 /* ---- K4: LDLQ rounding -------------------------------------------------------------------------
  * Replaces round_ldl / round_ldl_block (vector_balance.py:155-199, 218-257; n_greedy_passes = 0):
  *   for i = d-1 .. 0:  q_i = clamp(floor(w_i + sum_{j>i} (w_j - q_j) L[j,i] + eta_i), 0, 2^bits - 1)

@@ -832,3 +832,14 @@ def decode_attention_fused(Uops, ys, biases, kcache, vcache, pos, cos_table=None
               ctypes.cast(vp(biases), ctypes.c_void_p), _p(kcache), _p(vcache), _p(pos), _p(out), _p(cos_table), _p(sin_table), rows, bs,
               heads, hd, maxlen, ctypes.c_float(sc), n, _stream())
     return out
+
+
+def argmax_rows(x, out=None):
+    """out[r] = argmax x[r, :] as int64 on the device (first index among equal maxima), one launch (quipamd_argmax_rows)"""
+    _need_gpu(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
+    assert out.dtype == torch.int64 and out.numel() == x.shape[0] and out.is_contiguous()
+    _lib.call("quipamd_argmax_rows", _p(x), _dtype(x), x.shape[0], x.shape[1], x.stride(0), _p(out), _stream())
+    return out

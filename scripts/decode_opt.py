@@ -217,6 +217,9 @@ def pack_model(model, bits, dev, seed=0):
     return dense_twin, nbytes
 
 
+FAST_ARGMAX = True
+
+
 def time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager):
     heads, hd = model.heads, model.h // model.heads
     caches = [(torch.zeros(bs, heads, maxlen, hd, dtype=dtype, device=dev), torch.zeros(bs, heads, maxlen, hd, dtype=dtype, device=dev))
@@ -229,7 +232,10 @@ def time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager):
     def one():
         lg = model.step(ids, pos, caches, arange)
         logits_out.copy_(lg)
-        ids.copy_(lg.argmax(-1))
+        if FAST_ARGMAX and lg.is_cuda:
+            ops.argmax_rows(lg, out=ids)                     # one 3 us launch; torch's generic reduction: 18 us for 50272 logits
+        else:
+            ids.copy_(lg.argmax(-1))
         pos.add_(1)
 
     with torch.no_grad():

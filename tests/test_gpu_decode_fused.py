@@ -187,3 +187,15 @@ def test_attention_with_the_output_side_operators_in_its_prologue(n, heads, hd, 
     mask[pos] = False
     assert torch.equal(kc[:, :, mask], kc0[:, :, mask]) and torch.equal(vc[:, :, mask], vc0[:, :, mask])    # nothing else touched
     assert float((got.float() - want.float()).norm() / want.float().norm()) <= 3e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.bfloat16])
+def test_argmax_rows_is_torch_argmax(dtype):
+    from quip_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(3, 50272, device=DEV).to(dtype)
+    x[1, 777] = x[1, 40000] = 50.0                          # a tie: the first index wins, like torch.argmax
+    x[2] = 0.25                                              # all equal
+    got = ops.argmax_rows(x)
+    assert torch.equal(got, x.float().argmax(-1)) and int(got[1]) == 777 and int(got[2]) == 0
+    assert ops.argmax_rows(x[:0]).numel() == 0
