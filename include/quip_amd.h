@@ -262,10 +262,18 @@ int quipamd_dequant_gemm_vop(const quipamd_small_op *vops, const int32_t *const 
  *                                                              t is stored to t_out (fp16, the new residual stream) when not NULL
  *     h    = norm(t)  (norm 0: none, 1: LayerNorm gamma / beta, 2: RMSNorm gamma; fp32 statistics, eps)      [t = x without has_u]
  *     x~_i = V_i ( h (/) s_i ),   y_i = What_i x~_i            i < ngroups <= 3 (q / k / v; gate / up), fp32 y [bs, m]
+ * PERMUTATIONS FOLDED INTO THE PACKING (free at pack time): the decode launches take the packed codes of a layer with
+ *   - its ROWS in "ZT order" of its own output-side operator U: row b * p + a of the packed matrix is the row i of the layer with
+ *     load position pout_U[i] = a * q + b, so that the GEMM's output vector IS the transposed image U^T starts from (the consumer's
+ *     scatter is a straight 16-byte copy; u_y and the y of quipamd_decode_attention_fused / quipamd_decode_u_only are in this order);
+ *   - its COLUMNS in image order of its own activation-side operator V: column a * q + b is the column k with pout_V[k] = a * q + b,
+ *     so that the image V produces IS x~ (written straight into the GEMM's operand row; no gather).
+ *   quip_amd.quant.QuantLinear.decode_qweight() builds that copy of the codes once (unpack, index, pack).
  * quipamd_fop = a Kronecker operator prepared for this kernel: F0 / F1 are the two factor matrices of the wanted orientation
  * (M0 [p][p], M1 [q][q], out = (M0 (x) M1) applied to the p x q image) as FP16 in MFMA B-fragment order
  *     F0[((at * p/32 + S) * 64 + lane) * 8 + e] = M0[16 at + lane % 16][32 S + 8 (lane / 16) + e]        (F1 likewise with q),
- * load_idx / store_idx with the meaning they have in quipamd_small_op, as uint16 [n], both required.  One fp16 product per factor entry: ~3e-4 relative per
+ * load_idx / store_idx with the meaning they have in quipamd_small_op, as uint16 [n] (an output-side operator needs store_idx only,
+ * an activation-side one load_idx only: the other permutation lives in the packing).  One fp16 product per factor entry: ~3e-4 relative per
  * stage, below the 16-bit rounding of the pass's output (x~ feeds the fp16 MFMA, t is the fp16 residual stream).
  * Shapes: U and V must both be p x q in {64 x 32, 64 x 64, 128 x 64}, d = p q; 2-bit qfn-b STREAM codes; scale[i] float [1];
  * colscale[i] float [d] (ones when the layer has no rescale); m % 32 == 0 (64 x 32) or m % 16 == 0; all 16-bit tensors fp16;
@@ -310,6 +318,12 @@ int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *args, void *stream)
 int quipamd_decode_attention_fused(const quipamd_fop *U, const void *const *y, const void *const *bias, void *kcache, void *vcache,
                                    const int64_t *pos, void *out, const float *cos_table, const float *sin_table, int64_t table_rows,
                                    int64_t bs, int heads, int hd, int64_t maxlen, float scale, int64_t ldo, void *stream);
+
+/* The output side of a packed layer on its own (the end of the last decoder block): out = [relu](U^T y + bias + residual), fp16.
+ * U: the TRANSPOSED operator (quipamd_fop; 64 x 32, 64 x 64 or 128 x 64); y: fp16 [bs, n] in ZT order (see below); bias fp16 [n];
+ * residual fp16 [bs, ld_residual] or NULL; out fp16 [bs, ld_out], not aliasing the residual. */
+int quipamd_decode_u_only(const quipamd_fop *U, const void *y, const void *bias, const void *residual, int64_t ld_residual, int relu,
+                          void *out, int64_t ld_out, int64_t bs, void *stream);
 
 /* Greedy token of a decode step: out[r] = argmax_i x[r, i] (int64, DEVICE), the smallest index among equal maxima like torch.argmax;
  * x: [rows, n] f32 / f16 / bf16 with row stride ld.  One workgroup per row (benchmark(), opt.py:463-480 picks the next token this way). */

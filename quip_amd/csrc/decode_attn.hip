@@ -242,15 +242,14 @@ __global__ __launch_bounds__(256) void decode_attn_u_kernel(AttnUArgs G)
     typedef F16 TI;
     constexpr int NW = 4, N = P * Q;
     typedef PassDims<P, Q, NW> D;
-    constexpr int NV = D::NV;
     extern __shared__ __attribute__((aligned(16))) char smem_u[];
     // [3 image sets][q k v slices f16 3 x HD][scores maxlen][red 8][part 4 x HD]
     char *img = smem_u;
     uint16_t *qkv = reinterpret_cast<uint16_t *>(smem_u + 3 * D::BYTES);
     float *scores = reinterpret_cast<float *>(smem_u + 3 * D::BYTES + 3 * HD * 2 + 32);
     float *red = scores + G.maxlen, *part = red + 8;
-    asm volatile("" ::"s"(G.U[0].F0), "s"(G.U[0].F1), "s"(G.U[0].load_idx), "s"(G.U[0].store_idx), "s"(G.U[1].F0), "s"(G.U[1].F1),
-                 "s"(G.U[1].load_idx), "s"(G.U[1].store_idx), "s"(G.U[2].F0), "s"(G.U[2].F1), "s"(G.U[2].load_idx), "s"(G.U[2].store_idx),
+    asm volatile("" ::"s"(G.U[0].F0), "s"(G.U[0].F1), "s"(G.U[0].store_idx), "s"(G.U[1].F0), "s"(G.U[1].F1),
+                 "s"(G.U[1].store_idx), "s"(G.U[2].F0), "s"(G.U[2].F1), "s"(G.U[2].store_idx),
                  "s"(G.y[0]), "s"(G.y[1]), "s"(G.y[2]), "s"(G.bias[0]), "s"(G.bias[1]), "s"(G.bias[2]), "s"(G.kc), "s"(G.vc), "s"(G.out),
                  "s"(G.pos), "s"(G.cos_t), "s"(G.sin_t), "s"(G.table_rows), "s"(G.maxlen), "s"(G.ldo), "s"(G.heads), "s"(G.scale));
     const int tid = threadIdx.x, lane = tid & 63;
@@ -261,15 +260,13 @@ __global__ __launch_bounds__(256) void decode_attn_u_kernel(AttnUArgs G)
     S *kcb = G.kc + ((int64_t)b * G.heads + head) * G.maxlen * HD, *vcb = G.vc + ((int64_t)b * G.heads + head) * G.maxlen * HD;
 
     // ---- prologue: q, k, v slices of this head ---------------------------------------------------------------------------------------
-    uint2 yv[3][NV], ld[3][NV];
+    constexpr int NCV = N / 8 / 256;                                  // 16-byte chunks of one projection's output row per thread
+    static_assert(NCV * 256 * 8 == N, "n = 2048 or 4096");
+    uint4 yc[3][NCV];                                                 // y_q, y_k, y_v arrive in ZT order (fpass.h copy_chunk_zt): no index vectors
 #pragma unroll
     for (int o = 0; o < 3; ++o)
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const uint32_t v4 = tid + 256 * u;
-            yv[o][u] = *reinterpret_cast<const uint2 *>((G.y[o] + (int64_t)b * N) + 4 * v4);
-            ld[o][u] = *reinterpret_cast<const uint2 *>(G.U[o].load_idx + 4 * v4);
-        }
+        for (int u = 0; u < NCV; ++u) yc[o][u] = *reinterpret_cast<const uint4 *>((G.y[o] + (int64_t)b * N) + 8 * (uint32_t)(tid + 256 * u));
     PassFrags<P, Q> fr[3];
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
@@ -299,7 +296,7 @@ __global__ __launch_bounds__(256) void decode_attn_u_kernel(AttnUArgs G)
     for (int o = 0; o < 3; ++o) {
         uint16_t *ZT = reinterpret_cast<uint16_t *>(img + o * D::BYTES);
 #pragma unroll
-        for (int u = 0; u < NV; ++u) scatter4h<P, Q>(ZT, yv[o][u], ld[o][u]);
+        for (int u = 0; u < NCV; ++u) copy_chunk_zt<P, Q>(ZT, yc[o][u], tid + 256 * u);
     }
     __syncthreads();
 #pragma unroll
@@ -463,6 +460,81 @@ template <int HD, int P, int Q> int launch_attn_u(const AttnUArgs &A, int64_t bs
 
 namespace {
 
+// ---- the output side of a packed layer on its own: out = [relu](U^T y + bias + residual), y in ZT order (the end of the last block) ----
+struct UOnlyArgs {
+    Fop U;
+    const uint16_t *y, *bias, *res;       // f16 [bs, n] (ZT order), f16 [n], f16 [bs, ld_res] or null
+    uint16_t *out;                        // f16 [bs, ld_out]
+    int64_t ld_res, ld_out;
+    float floor;
+};
+
+template <int P, int Q> __global__ __launch_bounds__(1024) void u_only_kernel(UOnlyArgs G)
+{
+    typedef PassDims<P, Q> D;
+    constexpr int N = D::N, NV = D::NV, NCV = (N / 8 + 1023) / 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem_o[];
+    uint16_t *ZT = reinterpret_cast<uint16_t *>(smem_o), *Z1 = reinterpret_cast<uint16_t *>(smem_o + D::ZT_B);
+    float *ZF = reinterpret_cast<float *>(smem_o + D::ZT_B + D::Z1_B);
+    asm volatile("" ::"s"(G.U.F0), "s"(G.U.F1), "s"(G.U.store_idx), "s"(G.y), "s"(G.bias), "s"(G.res), "s"(G.out), "s"(G.ld_res), "s"(G.ld_out), "s"(G.floor));
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint4 yc[NCV];
+#pragma unroll
+    for (int u = 0; u < NCV; ++u)
+        if (tid + 1024 * u < N / 8) yc[u] = *reinterpret_cast<const uint4 *>((G.y + (int64_t)b * N) + 8 * (uint32_t)(tid + 1024 * u));
+    PassFrags<P, Q> fr;
+    load_f0<P, Q>(G.U, wave, lane, fr);
+    load_f1<P, Q>(G.U, wave, lane, fr);
+    uint2 st[NV], bi[NV], rs[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int v4 = tid + 1024 * u;
+        rs[u] = make_uint2(0u, 0u);
+        if (v4 < N / 4) {
+            st[u] = *reinterpret_cast<const uint2 *>(G.U.store_idx + 4 * v4);
+            bi[u] = *reinterpret_cast<const uint2 *>(G.bias + 4 * v4);
+            if (G.res) rs[u] = *reinterpret_cast<const uint2 *>((G.res + (int64_t)b * G.ld_res) + (uint32_t)(4 * v4));
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NCV; ++u)
+        if (tid + 1024 * u < N / 8) copy_chunk_zt<P, Q>(ZT, yc[u], tid + 1024 * u);
+    __syncthreads();
+    mix_stages<P, Q>(ZT, Z1, ZF, fr, wave, lane);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int v4 = tid + 1024 * u;
+        if (v4 < N / 4) {
+            float4 t = gather4<P, Q>(ZF, st[u]);
+            const float4 rr = f16x4_to_f32(rs[u]), bb = f16x4_to_f32(bi[u]);
+            t = make_float4(fmaxf(t.x + bb.x + rr.x, G.floor), fmaxf(t.y + bb.y + rr.y, G.floor), fmaxf(t.z + bb.z + rr.z, G.floor),
+                            fmaxf(t.w + bb.w + rr.w, G.floor));
+            uint2 pk;
+            pk.x = pack_f16x2(t.x, t.y);
+            pk.y = pack_f16x2(t.z, t.w);
+            *reinterpret_cast<uint2 *>((G.out + (int64_t)b * G.ld_out) + (uint32_t)(4 * v4)) = pk;
+        }
+    }
+}
+
+template <int P, int Q> int launch_u_only(const UOnlyArgs &A, int64_t bs, hipStream_t s)
+{
+    const size_t lds = PassDims<P, Q>::BYTES;
+    auto kern = u_only_kernel<P, Q>;
+    static QaPerDevice attr;
+    const int d = attr.dev();
+    if (lds > 48 * 1024 && (d < 0 || !attr.done[d])) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_u_only: cannot reserve %zu B of LDS", lds);
+        if (d >= 0) attr.done[d] = true;
+    }
+    kern<<<(unsigned)bs, 1024, lds, s>>>(A);
+    QA_LAUNCH_CHECK("quipamd_decode_u_only");
+    return QUIPAMD_OK;
+}
+
 // ---- greedy token of one decode step: argmax over the vocabulary, one workgroup per batch row ---------------------------------------
 // (benchmark(), opt.py:463-480: `torch.argmax(out.logits[0, -1])` -- torch's generic reduction takes 18 us for 50272 logits;
 // ties go to the smallest index like torch.argmax)
@@ -494,6 +566,25 @@ template <class TI> __global__ __launch_bounds__(1024) void argmax_rows_kernel(c
 
 }   // namespace
 
+extern "C" int quipamd_decode_u_only(const quipamd_fop *U, const void *y, const void *bias, const void *residual, int64_t ld_residual,
+                                     int relu, void *out, int64_t ld_out, int64_t bs, void *stream)
+{
+    QA_REQUIRE(U && bs >= 0, QUIPAMD_ERR_ARG, "decode_u_only: bad arguments");
+    if (bs == 0) return QUIPAMD_OK;
+    const int64_t n = (int64_t)U->p * U->q;
+    QA_REQUIRE(U->F0 && U->F1 && U->store_idx && y && bias && out && ld_out >= n && ld_out % 4 == 0 && (!residual || (ld_residual >= n && ld_residual % 4 == 0)),
+               QUIPAMD_ERR_ARG, "decode_u_only: null pointer / row strides");
+    QA_REQUIRE(!residual || residual != out, QUIPAMD_ERR_ARG, "decode_u_only: out must not alias the residual");
+    UOnlyArgs A;
+    A.U = *U; A.y = (const uint16_t *)y; A.bias = (const uint16_t *)bias; A.res = (const uint16_t *)residual; A.out = (uint16_t *)out;
+    A.ld_res = ld_residual; A.ld_out = ld_out; A.floor = relu ? 0.f : -INFINITY;
+    hipStream_t s = (hipStream_t)stream;
+    if (U->p == 64 && U->q == 32) return launch_u_only<64, 32>(A, bs, s);
+    if (U->p == 64 && U->q == 64) return launch_u_only<64, 64>(A, bs, s);
+    if (U->p == 128 && U->q == 64) return launch_u_only<128, 64>(A, bs, s);
+    return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_u_only: operator %d x %d", U->p, U->q);
+}
+
 extern "C" int quipamd_argmax_rows(const void *x, int dtype, int64_t rows, int64_t n, int64_t ld, int64_t *out, void *stream)
 {
     QA_REQUIRE(rows >= 0 && n > 0 && n < 0x7fffffff && ld >= n, QUIPAMD_ERR_SHAPE, "argmax_rows: bad shape");
@@ -519,7 +610,7 @@ extern "C" int quipamd_decode_attention_fused(const quipamd_fop *U, const void *
     QA_REQUIRE(ldo >= (int64_t)heads * hd, QUIPAMD_ERR_SHAPE, "decode_attention_fused: out row stride");
     AttnUArgs A;
     for (int o = 0; o < 3; ++o) {
-        QA_REQUIRE(U[o].F0 && U[o].F1 && U[o].load_idx && U[o].store_idx && U[o].p == p && U[o].q == q && y[o] && bias[o], QUIPAMD_ERR_ARG,
+        QA_REQUIRE(U[o].F0 && U[o].F1 && U[o].store_idx && U[o].p == p && U[o].q == q && y[o] && bias[o], QUIPAMD_ERR_ARG,
                    "decode_attention_fused: operator / y / bias %d", o);
         A.U[o] = U[o]; A.y[o] = (const uint16_t *)y[o]; A.bias[o] = (const uint16_t *)bias[o];
     }

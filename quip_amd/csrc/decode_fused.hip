@@ -115,8 +115,8 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     // every kernarg field the kernel will ever read, in ONE scalar round trip: hipcc fetches kernarg fields lazily -- one s_load +
     // s_waitcnt lgkmcnt(0) per first use -- and round one of this kernel opened with SEVEN serial kernarg round trips (~2000
     // cycles) and closed with three more in front of the final store.  One asm statement naming them all pins the loads here.
-    asm volatile("" ::"s"(Gg.qw), "s"(V.F0), "s"(V.F1), "s"(V.load_idx), "s"(V.store_idx), "s"(Gg.colscale), "s"(Gg.scale), "s"(Gg.y),
-                 "s"(G.U.F0), "s"(G.U.F1), "s"(G.U.load_idx), "s"(G.U.store_idx), "s"(G.u_y), "s"(G.u_bias), "s"(G.u_res), "s"(G.t_out),
+    asm volatile("" ::"s"(Gg.qw), "s"(V.F0), "s"(V.F1), "s"(V.load_idx), "s"(Gg.colscale), "s"(Gg.scale), "s"(Gg.y),
+                 "s"(G.U.F0), "s"(G.U.F1), "s"(G.U.store_idx), "s"(G.u_y), "s"(G.u_bias), "s"(G.u_res), "s"(G.t_out),
                  "s"(G.ld_res), "s"(G.ld_t), "s"(G.x), "s"(G.ldx), "s"(G.gamma), "s"(G.beta), "s"(G.eps), "s"(G.floor), "s"(G.bs), "s"(G.m),
                  "s"(G.y_f16));
 
@@ -134,15 +134,14 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     uint4 w[CPW];
     PassFrags<P, Q> frU, frV;
     float4 cs[NV];
-    uint2 yv[NV], bi[NV], ld[NV], st[NV], rs[NV], gm[NV], bt_[NV], vld[NV], vst[NV], xr[NV];
-    auto load_u_row = [&](int b) {                                              // what the first scatter needs
+    uint2 bi[NV], st[NV], rs[NV], gm[NV], bt_[NV], vld[NV], xr[NV];
+    constexpr int NCV = (N / 8 + 1023) / 1024;                                  // 16-byte chunks of the U pass's input row per thread
+    uint4 yc[NCV];
+    auto load_u_row = [&](int b) {                                              // what the first scatter needs: the row itself, in ZT order
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const int v4 = tid + 1024 * u;
-            if (v4 < N / 4) {
-                yv[u] = *reinterpret_cast<const uint2 *>((G.u_y + (int64_t)b * N) + (uint32_t)(4 * v4));
-                ld[u] = *reinterpret_cast<const uint2 *>(G.U.load_idx + 4 * v4);
-            }
+        for (int u = 0; u < NCV; ++u) {
+            const int c = tid + 1024 * u;
+            if (c < N / 8) yc[u] = *reinterpret_cast<const uint4 *>((G.u_y + (int64_t)b * N) + (uint32_t)(8 * c));
         }
     };
     auto load_u_frags = [&]() {
@@ -175,7 +174,6 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                 if (NORM == 1) bt_[u] = *reinterpret_cast<const uint2 *>(G.beta + 4 * v4);
                 cs[u] = *reinterpret_cast<const float4 *>(Gg.colscale + 4 * v4);
                 vld[u] = *reinterpret_cast<const uint2 *>(V.load_idx + 4 * v4);
-                vst[u] = *reinterpret_cast<const uint2 *>(V.store_idx + 4 * v4);
             }
         }
     };
@@ -221,8 +219,8 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                 }
             }
 #pragma unroll
-            for (int u = 0; u < NV; ++u)
-                if (tid + 1024 * u < N / 4) scatter4h<P, Q>(ZT, yv[u], ld[u]);
+            for (int u = 0; u < NCV; ++u)
+                if (tid + 1024 * u < N / 8) copy_chunk_zt<P, Q>(ZT, yc[u], tid + 1024 * u);
             if (!EARLY) {                                                       // n = 8192: fragments, the gather's operands and the V-side set follow
                 load_u_frags();                                                 // the scatter (nothing row-independent stays in registers across a row)
                 load_u_side(b);
@@ -324,28 +322,15 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         FG_STAMP(7);
         __syncthreads();
         FG_STAMP(8);
-        mix_stages<P, Q>(ZT, Z1, ZF, frV, wave, lane);
+        mix_stage1<P, Q>(ZT, Z1, frV, wave, lane);
         FG_STAMP(9);
         __syncthreads();
         FG_STAMP(10);
-        float xpart = 0.f;
-#pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const int v4 = tid + 1024 * u;
-            if (v4 < N / 4) {
-                const float4 t = gather4<P, Q>(ZF, vst[u]);
-                uint2 pk;
-                pk.x = pack_f16x2(t.x, t.y);
-                pk.y = pack_f16x2(t.z, t.w);
-                *reinterpret_cast<uint2 *>(XT + (size_t)b * XTS + 4 * v4) = pk;
-                const float4 tr = f16x4_to_f32(pk);                              // sum_k x~[k] of the ROUNDED values: the epilogue's offset term
-                xpart += (tr.x + tr.y) + (tr.z + tr.w);
-            }
-        }
+        float xpart = mix_stage2_xt<P, Q>(Z1, XT + (size_t)b * XTS, frV, wave, lane);   // x~ in image order = the order of the weights' columns
         xpart = fg_wave_sum(xpart);
-        if (lane == 0) red[2 * FG_NW + b * FG_NW + wave] = xpart;
+        if (lane == 0) red[2 * FG_NW + b * FG_NW + wave] = xpart;              // waves without tiles publish 0
         FG_STAMP(11);
-        __syncthreads();                                                        // x~ row complete; ZF / ZT free for the next row (or park)
+        __syncthreads();                                                        // x~ row complete; ZT / Z1 free for the next row (or park)
         FG_STAMP(12);
     }
 
@@ -374,7 +359,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     __syncthreads();
     FG_STAMP(14);
     if (wave < RT) {                                                            // one reducer wave per row tile: lane = (batch row, row in tile)
-        constexpr int NWD = (N / 4 < 1024 ? N / 4 : 1024) / 64;                 // waves that wrote x~ (and its partial sums)
+        constexpr int NWD = FG_NW;                                               // every wave published its part of sum x~
         const int r2 = wave, bb = lane >> 4, wr = lane & 15;
         const int src = (wr & 3) * 64 + bb + 16 * (wr >> 2);                   // [acc component][mfma lane (j = bb, g = wr / 4)]
         float a = 0.f, xsum = 0.f;

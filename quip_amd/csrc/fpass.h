@@ -153,6 +153,49 @@ __device__ __forceinline__ void mix_stage2(const uint16_t *Z1, float *ZF, const 
         }
     }
 }
+// stage 2 of an ACTIVATION-side pass whose consumer is the dequant-GEMM: the weights' COLUMNS are stored in image order (the output
+// permutation of V is folded into the packing, free at pack time), so the image IS x~: every lane rounds its four results to f16 and
+// writes them straight into the GEMM's operand row XT[a * Q + b] -- no fp32 image, no gather, no barrier in between.  Returns the
+// lane's sum of the rounded values (the epilogue's sum_k x~[k]).
+template <int P, int Q, int NW = 16>
+__device__ __forceinline__ float mix_stage2_xt(const uint16_t *Z1, uint16_t *XT, const PassFrags<P, Q> &fr, int wave, int lane)
+{
+    typedef PassDims<P, Q, NW> D;
+    const int j = lane & 15, g = lane >> 4;
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < D::TPW; ++i) {
+        const int tile = wave + NW * i;
+        if (tile < D::NT) {
+            const int bt = tile % (Q / 16), at = tile / (Q / 16);
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            const uint16_t *arow = Z1 + (16 * at + j) * D::QS + 8 * g;
+#pragma unroll
+            for (int S = 0; S < D::S1; ++S) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(arow + 32 * S);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, fr.f1[S]), acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const uint16_t h = f32_to_f16_bits(acc[reg]);
+                XT[(16 * at + 4 * g + reg) * Q + 16 * bt + j] = h;
+                part += f16_bits_to_f32(h);
+            }
+        }
+    }
+    return part;
+}
+
+// the input of an OUTPUT-side pass arrives in "ZT order": the producing GEMM's ROWS are stored so that its output vector is the
+// transposed image row-major, yT[b * P + a] (the load permutation of U^T folded into the packing) -- the scatter is a straight copy
+// of 16-byte chunks into the padded rows of ZT.  chunk c = (b = c / (P / 8), a8 = c % (P / 8)).
+template <int P, int Q> __device__ __forceinline__ void copy_chunk_zt(uint16_t *ZT, const uint4 &v, int c)
+{
+    typedef PassDims<P, Q> D;
+    const int b = c / (P / 8), a8 = c - b * (P / 8);
+    *reinterpret_cast<uint4 *>(ZT + b * D::PS + 8 * a8) = v;
+}
+
 // the two mix stages: ZT -> Z1 -> ZF.  Caller: a barrier after the scatter; this function ends WITHOUT a barrier after writing ZF.
 template <int P, int Q, int NW = 16>
 __device__ __forceinline__ void mix_stages(const uint16_t *ZT, uint16_t *Z1, float *ZF, const PassFrags<P, Q> &fr, int wave, int lane)

@@ -496,6 +496,20 @@ class OrthoOp:
             cache[key] = (Fop(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), self.p, self.q), keep)
         return cache[key][0]
 
+    def zt_rows(self):
+        """int64 [n] on the device: zt[i] = position of element i of a vector that U^T (this operator, transposed) is applied to in
+        "ZT order" -- the transposed image row-major, b * p + a for load position pout[i] = a * q + b (include/quip_amd.h)"""
+        if getattr(self, '_zt_rows', None) is None:
+            pos = self._p_out.to(self.device)
+            self._zt_rows = (pos % self.q) * self.p + pos // self.q
+        return self._zt_rows
+
+    def image_cols(self):
+        """int64 [n] on the device: img[k] = image position the (forward) operator's output element k is read from, pout[k]"""
+        if getattr(self, '_img_cols', None) is None:
+            self._img_cols = self._p_out.to(self.device).clone()
+        return self._img_cols
+
     @property
     def fused_ok(self):
         return (not self.blocked) and (self.p, self.q) in FUSED_SHAPES and (self.small_ok or self.bigp_ok)
@@ -842,4 +856,17 @@ def argmax_rows(x, out=None):
         out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
     assert out.dtype == torch.int64 and out.numel() == x.shape[0] and out.is_contiguous()
     _lib.call("quipamd_argmax_rows", _p(x), _dtype(x), x.shape[0], x.shape[1], x.stride(0), _p(out), _stream())
+    return out
+
+
+def decode_u_only(U, y, bias16, residual=None, relu=False):
+    """out = [relu](U^T y + bias + residual) as one small launch (quipamd_decode_u_only): y fp16 [bs, n] in ZT order of U"""
+    _need_gpu(y)
+    n = U.n
+    assert y.dtype == torch.float16 and y.shape[1] == n and y.is_contiguous() and bias16.dtype == torch.float16 and bias16.numel() == n
+    assert residual is None or (residual.dtype == torch.float16 and residual.stride(1) == 1)
+    out = torch.empty((y.shape[0], n), dtype=torch.float16, device=y.device)
+    fop = U.fop(True)
+    _lib.call("quipamd_decode_u_only", ctypes.byref(fop), _p(y), _p(bias16), _p(residual), 0 if residual is None else residual.stride(0),
+              int(bool(relu)), _p(out), n, y.shape[0], _stream())
     return out

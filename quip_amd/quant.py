@@ -201,6 +201,35 @@ class QuantLinear(nn.Module):
         bias = None if getattr(layer, 'bias', None) is None else layer.bias.data
         return ql.pack(codes, method.qscale, method.qzero, bias=bias, scaleWH=sWH, U=U, V=V)
 
+    @torch.no_grad()
+    def decode_qweight(self):
+        """the codes as the fused decode launches read them (include/quip_amd.h "permutations folded into the packing"): rows in ZT order
+        of U, columns in image order of V -- built once (unpack, index, pack on the device) and kept beside `qweight`"""
+        qd = self.__dict__.get('_qweight_d')
+        if qd is None or qd.device != self.qweight.device:
+            m, d = self.outfeatures, self.infeatures
+            codes = ops.unpack(self.qweight, self.bits, ops.LAYOUT_STREAM, m, d)
+            if self.U is not None:
+                perm = torch.empty(m, dtype=torch.int64, device=codes.device)
+                perm[self.U.zt_rows()] = torch.arange(m, device=codes.device)          # new row r holds old row perm[r]
+                codes = codes[perm]
+            if self.V is not None:
+                perm = torch.empty(d, dtype=torch.int64, device=codes.device)
+                perm[self.V.image_cols()] = torch.arange(d, device=codes.device)
+                codes = codes[:, perm]
+            qd = ops.pack(codes.contiguous(), self.bits, ops.LAYOUT_STREAM)
+            self.__dict__['_qweight_d'] = qd
+        return qd
+
+    def to_zt(self, y):
+        """a vector in this layer's natural output order -> ZT order (what its decode launch produces)"""
+        out = torch.empty_like(y)
+        out[..., self.U.zt_rows()] = y
+        return out
+
+    def from_zt(self, y):
+        return y[..., self.U.zt_rows()]
+
     def packed_state(self):
         """everything needed to rebuild the layer, as CPU tensors / plain Python (the packed checkpoint record):
         STREAM-layout codes, grid parameters, bias, 1/scaleWH and the generator tuples of U and V."""
@@ -574,6 +603,11 @@ def fused_attention(qkv, ys, kcache, vcache, pos, cos_table=None, sin_table=None
     return ops.decode_attention_fused([q.U for q in qkv], ys, [bias16(q) for q in qkv], kcache, vcache, pos, cos_table, sin_table)
 
 
+def fused_u_only(ql, y, residual=None, relu=False):
+    """out = [relu](U^T y + bias + residual), fp16: the output side of packed layer `ql` on its own; y fp16 in ZT order"""
+    return ops.decode_u_only(ql.U, y, bias16(ql), residual=None if residual is None else residual.contiguous(), relu=relu)
+
+
 def fused_attention_ok(qkv, kcache):
     bs, heads, maxlen, hd = kcache.shape
     shapes = {(q.U.p, q.U.q) for q in qkv if q.U is not None}
@@ -588,6 +622,8 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
                                                                     else t = x
         y_i  = What_i V_i ( Norm(t) (/) s_i )                       for the 1..3 layers `qls` sharing t; [rows, m] in y_dtype
     Returns (ys, t): t is the fp16 tensor written by the launch when store=True (the new residual stream), else None.
+    ys[i] and y_prev are in ZT ORDER of the producing layer's U (QuantLinear.to_zt / from_zt; the launches read decode_qweight(), the
+    codes with both permutations folded in) -- only fused_stage / fused_attention / fused_u_only consume them.
     ln: nn.LayerNorm / an RMSNorm module / None.  y_prev: fp16 (what a fused launch writes with y_dtype=torch.float16; an fp32
     y_prev is rounded here -- the kernel's first step is that rounding anyway).  y_dtype fp16 when the consumer is another fused
     launch, fp32 for the K3 operator kernels."""
@@ -597,7 +633,7 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
     m, d = q0.outfeatures, q0.infeatures
     ys = [torch.empty((rows, m), dtype=y_dtype, device=dev) for _ in qls]
     kw = dict(V=[q.V.fop(False) for q in qls], colscale=[q.inv_scaleWH if q.inv_scaleWH is not None else q.V.one_scale() for q in qls],
-              qweight=[q.qweight for q in qls], scale=[q.scales for q in qls], y=ys, m=m, bs=rows)
+              qweight=[q.decode_qweight() for q in qls], scale=[q.scales for q in qls], y=ys, m=m, bs=rows)
     lnp = _ln_params(ln)
     if lnp is not None:
         g, b, eps = lnp

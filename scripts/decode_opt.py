@@ -30,7 +30,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quip_amd import ops, method  # noqa: E402
 from quip_amd.quant import (QuantLinear, packed_forward_fused, packed_v_stage, packed_gemm_stage, packed_u_stage,  # noqa: E402
-                            packed_u_then_v, packed_vgemm_stage, vgemm_fusable, fused_stage, fused_ok, fused_attention, fused_attention_ok)
+                            packed_u_then_v, packed_vgemm_stage, vgemm_fusable, fused_stage, fused_ok, fused_attention, fused_attention_ok, fused_u_only)
 
 
 class Block(nn.Module):
@@ -149,15 +149,14 @@ class Decoder(nn.Module):
                 ys, x = fused_stage(qkv, prev=prev, y_prev=y2, residual=x, ln=blk.ln1, store=True, y_dtype=ydt)
             if attn_u:                                          # U_q^T, U_k^T, U_v^T + bias in the attention launch's prologue: 5 launches per block
                 o = fused_attention(qkv, ys, kc, vc, pos)
-            else:
-                q, k, v = packed_u_stage(qkv, ys, dt)
+            else:                                               # (the fused launches hand y over in ZT order: K3 wants the natural one)
+                q, k, v = packed_u_stage(qkv, [l.from_zt(y) for l, y in zip(qkv, ys)], dt)
                 o = ops.decode_attention(q, k, v, kc, vc, pos)
             yo = fused_stage([blk.out_proj], x=o, y_dtype=h16)[0][0]
             (y1,), x = fused_stage([blk.fc1], prev=blk.out_proj, y_prev=yo, residual=x, ln=blk.ln2, store=True, y_dtype=h16)
-            last = blk is self.blocks[-1]
-            y2 = fused_stage([blk.fc2], prev=blk.fc1, y_prev=y1, relu=True, y_dtype=torch.float32 if last else h16)[0][0]
+            y2 = fused_stage([blk.fc2], prev=blk.fc1, y_prev=y1, relu=True, y_dtype=h16)[0][0]
             prev = blk.fc2
-        return packed_u_stage([prev], [y2], dt, residual=x)[0]
+        return fused_u_only(prev, y2, residual=x)
 
     tiled = False            # every operator application cut into 16 x 16 output tiles over 8-32 workgroups (csrc/ortho_tile.hip): 13 launches
 

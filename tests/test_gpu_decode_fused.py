@@ -91,7 +91,9 @@ def test_fused_stage_matches_the_chain_in_fp64(d, m, groups, has_u, norm, relu, 
     if has_u:
         y_prev = (torch.randn(bs, d, device=DEV) * 0.5).half().float()     # the producing launch hands it over as fp16
         res = (torch.randn(bs, d, device=DEV)).half() if residual else None
-        ys, t = fused_stage(list(qls), prev=prev, y_prev=y_prev, residual=res, relu=relu, ln=ln_mod, store=True)
+        # the launches exchange vectors in "ZT order" of the producing layer's U (include/quip_amd.h): the reference chain below is
+        # written in natural order, QuantLinear.to_zt / from_zt translate
+        ys, t = fused_stage(list(qls), prev=prev, y_prev=prev.to_zt(y_prev), residual=res, relu=relu, ln=ln_mod, store=True)
         Ut = _dense(prev.U, transpose=True)
         t64 = y_prev.double() @ Ut.t() + prev.bias.half().double()
         if res is not None:
@@ -110,7 +112,7 @@ def test_fused_stage_matches_the_chain_in_fp64(d, m, groups, has_u, norm, relu, 
         h_in = x.double()
     h = _norm64(h_in, ln64)
     if d == 2048 and groups == 3:                            # the fp16 hand-over form: same numbers, rounded once more
-        ys16, _ = fused_stage(list(qls), x=None if has_u else x, prev=prev, y_prev=y_prev if has_u else None, residual=res if has_u else None,
+        ys16, _ = fused_stage(list(qls), x=None if has_u else x, prev=prev, y_prev=prev.to_zt(y_prev) if has_u else None, residual=res if has_u else None,
                               relu=relu, ln=ln_mod, store=has_u, y_dtype=torch.float16)
         for a16, a32 in zip(ys16, ys):
             assert torch.equal(a16, a32.half())
@@ -118,6 +120,7 @@ def test_fused_stage_matches_the_chain_in_fp64(d, m, groups, has_u, norm, relu, 
         Vd = _dense(q.V)
         xt = (h * q.inv_scaleWH.double()) @ Vd.t()
         want = xt @ What.t()
+        y = q.from_zt(y)
         rel = float((y.double() - want).norm() / want.norm())
         assert rel <= 2e-3, rel
     torch.cuda.synchronize()
@@ -137,7 +140,8 @@ def test_fused_stage_agrees_with_the_round2_launches():
     res = torch.randn(bs, d, device=DEV).half()
     t_old = packed_u_stage([prev], [y_prev], torch.float16, residual=res)[0]
     ys_old = packed_gemm_stage(qls, packed_v_stage(qls, t_old, ln=ln))
-    ys, t = fused_stage(qls, prev=prev, y_prev=y_prev, residual=res, ln=ln, store=True)
+    ys, t = fused_stage(qls, prev=prev, y_prev=prev.to_zt(y_prev), residual=res, ln=ln, store=True)
+    ys = [q.from_zt(y) for q, y in zip(qls, ys)]
     assert float((t.float() - t_old.float()).abs().max()) <= 4 * 2.0 ** -11 * float(t_old.float().abs().max())
     for a, b_ in zip(ys, ys_old):
         assert float((a - b_).norm() / b_.norm()) <= 4e-3       # the round-2 path rounds x~ to bf16 (2^-9), this one to fp16
@@ -179,7 +183,7 @@ def test_attention_with_the_output_side_operators_in_its_prologue(n, heads, hd, 
     if rope:
         ops.rope_inplace(q, k, cos, sin, p_t, heads)
     want = ops.decode_attention(q, k, v, kc0, vc0, p_t)
-    got = fused_attention(qkv, ys, kc, vc, p_t, cos, sin)
+    got = fused_attention(qkv, [l.to_zt(y) for l, y in zip(qkv, ys)], kc, vc, p_t, cos, sin)
     torch.cuda.synchronize()
     for a, b_ in ((kc[:, :, pos], kc0[:, :, pos]), (vc[:, :, pos], vc0[:, :, pos])):
         assert float((a.float() - b_.float()).norm() / b_.float().norm()) <= 2e-3
@@ -199,3 +203,30 @@ def test_argmax_rows_is_torch_argmax(dtype):
     got = ops.argmax_rows(x)
     assert torch.equal(got, x.float().argmax(-1)) and int(got[1]) == 777 and int(got[2]) == 0
     assert ops.argmax_rows(x[:0]).numel() == 0
+
+
+@pytest.mark.parametrize("n,m_in,relu,residual,bs", [(2048, 8192, False, True, 1), (8192, 2048, True, False, 2), (4096, 4096, False, True, 3)])
+def test_output_side_operator_on_its_own(n, m_in, relu, residual, bs):
+    """quipamd_decode_u_only (the end of the last block) against U^T y + bias + residual in fp64"""
+    from quip_amd.quant import fused_u_only
+    ql = _layer(m_in, n, 900 + n % 11)[0]
+    torch.manual_seed(n)
+    y = (0.5 * torch.randn(bs, n, device=DEV)).half()
+    res = torch.randn(bs, n, device=DEV).half() if residual else None
+    got = fused_u_only(ql, ql.to_zt(y), residual=res, relu=relu).double()
+    want = y.double() @ _dense(ql.U, transpose=True).t() + ql.bias.half().double()
+    if res is not None:
+        want = want + res.double()
+    if relu:
+        want = torch.relu(want)
+    assert float((got - want).norm() / want.norm()) <= 1e-3
+
+
+def test_decode_qweight_is_the_layer_with_both_permutations_folded_in():
+    from quip_amd import ops
+    ql = _layer(2048, 2048, 11)[0]
+    c0 = ops.unpack(ql.qweight, 2, ops.LAYOUT_STREAM, 2048, 2048)
+    c1 = ops.unpack(ql.decode_qweight(), 2, ops.LAYOUT_STREAM, 2048, 2048)
+    zt, img = ql.U.zt_rows(), ql.V.image_cols()
+    assert torch.equal(c1[zt][:, img], c0)                  # row zt[i], column img[k] of the decode copy = (i, k) of the layer
+    assert sorted(zt.tolist()) == list(range(2048)) and sorted(img.tolist()) == list(range(2048))
