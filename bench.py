@@ -446,9 +446,12 @@ def main():
             spec.loader.exec_module(lmod)
             torch.cuda.empty_cache()
             lres = lmod.run(layers=32, bits=BITS, bs=1, prompt=32, tokens=48)
+            lbest = max([k for k in ("packed_w2_v3", "packed_w2_fused") if k in lres], key=lambda k: lres[k]["tok_per_s"])
             out["decode_llama"] = {"metric": "Llama-2-7B-architecture w2 (incoherence-processed, packed) decode tok/s, batch 1, one hipGraph per token",
-                                   "value": round(lres["packed_w2_fused"]["tok_per_s"], 1), "unit": "tok/s",
-                                   "ms_per_token": round(lres["packed_w2_fused"]["ms_per_token_median"], 3),
+                                   "value": round(lres[lbest]["tok_per_s"], 1), "unit": "tok/s",
+                                   "ms_per_token": round(lres[lbest]["ms_per_token_median"], 3),
+                                   "variant": lbest,
+                                   "round2_fused_13_launch_tok_per_s": round(lres["packed_w2_fused"]["tok_per_s"], 1),
                                    "unfused_tok_per_s": round(lres["packed_w2"]["tok_per_s"], 1),
                                    "dense_fp16_same_harness_tok_per_s": round(lres["dense_fp16"]["tok_per_s"], 1),
                                    "packed_weight_MB": round(lres["packed_w2"]["packed_weight_MB"], 1),

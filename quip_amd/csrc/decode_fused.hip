@@ -91,12 +91,15 @@ __device__ __forceinline__ float fg_block_sum(float v, float *red)
 // NORM: 0 none, 1 LayerNorm, 2 RMSNorm.  Every global operand of the prologue is requested in the first instructions of the kernel
 // (EARLY: all of them when a thread owns one 4-element slot, n <= 4096; at n = 8192 the V-side set follows the U-side scatter, the
 // register file does not hold both): the phases between the barriers then run on registers and LDS only.
-template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW>
+// NRT: row tiles a wave handles one after the other against the same x~ fragments (Llama's m = 4096 x 3 and 11008 x 2 would otherwise
+// be 768 / 1376 workgroups on 256 CUs, each repeating the prologue): a workgroup owns 16 RT NRT rows.
+template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT>
 __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two_over_maxq, float c0)
 {
     typedef PassDims<P, Q> D;
     typedef DeqT<2, ActF16> DQ;
     constexpr int N = D::N, NV = D::NV, NS = FG_NW / RT, NCH = N / 256, XTS = N + 8;      // x~ row stride (halves)
+    constexpr int PB = NRT < 4 ? NRT : 4;                                       // row tiles (per parallel row slot) parked per batch
     constexpr bool EARLY = NV == 1;
     static_assert(NS * CPW == NCH, "chunks = slots x chunks per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -105,8 +108,8 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     uint16_t *ZT = reinterpret_cast<uint16_t *>(pass);
     uint16_t *Z1 = reinterpret_cast<uint16_t *>(pass + D::ZT_B);
     float *ZF = reinterpret_cast<float *>(pass + D::ZT_B + D::Z1_B);
-    float *park = reinterpret_cast<float *>(pass);                              // [NS][RT][4][64] + xsum [NS][64]: after the last pass
-    constexpr size_t PARK_B = (size_t)(FG_NW * 256 + FG_NW * 64) * 4;
+    float *park = reinterpret_cast<float *>(pass);                              // [NS][RT PB][4][64]: after the last pass
+    constexpr size_t PARK_B = (size_t)(FG_NW * PB * 256) * 4;
     float *red = reinterpret_cast<float *>(pass + (D::BYTES > PARK_B ? D::BYTES : PARK_B));            // [2][16] norm, [bs][16] sum x~
 
     const int gi = blockIdx.y;
@@ -124,14 +127,14 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = wave / RT, r = wave - slot * RT;
     const int j = lane & 15, g = lane >> 4;
-    const uint32_t rt = blockIdx.x * RT + r;
+    const uint32_t rt0 = blockIdx.x * (RT * NRT) + r;                          // row tile of iteration k: rt0 + k RT
     const int bs = G.bs;
     FG_STAMP(0);
 
     // ---- every operand of the prologue is requested NOW, in the order the phases consume them; the packed weights go LAST: vector
     // memory returns in order (s_waitcnt vmcnt counts from the oldest), so a wait for the first activations behind a cold HBM
     // weight load would be a wait for HBM (measured: +2000 cycles in front of the first scatter) ------------------------------------
-    uint4 w[CPW];
+    uint4 w[NRT][CPW];
     PassFrags<P, Q> frU, frV;
     float4 cs[NV];
     uint2 bi[NV], st[NV], rs[NV], gm[NV], bt_[NV], vld[NV], xr[NV];
@@ -200,10 +203,12 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         load_v_frags();
     }
 #pragma unroll
-    for (int i = 0; i < CPW; ++i) {                                             // HBM, streamed once: nt
-        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Gg.qw + ((uint64_t)rt * NCH + (slot * CPW + i)) * 64 + lane));
-        w[i] = make_uint4(t[0], t[1], t[2], t[3]);
-    }
+    for (int k = 0; k < NRT; ++k)
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {                                         // HBM, streamed once: nt
+            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Gg.qw + ((uint64_t)(rt0 + k * RT) * NCH + (slot * CPW + i)) * 64 + lane));
+            w[k][i] = make_uint4(t[0], t[1], t[2], t[3]);
+        }
     const float e_sc = Gg.scale[0];                                             // needed by the reducer only
 
     for (int b = 0; b < bs; ++b) {
@@ -337,7 +342,9 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     // ---- dequant + MFMA: this wave's CPW chunks of 256 columns x 16 rows -------------------------------------------------------------
     // MFMA column j = batch row j.  Columns are independent (D[m][n] depends on B[:, n] only), so lanes of columns >= bs may read
     // anything: they read row j % 4 of x~ (allocated, possibly never written) and their results are not stored -- no masking.
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[NRT];
+#pragma unroll
+    for (int k = 0; k < NRT; ++k) acc[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const uint16_t *xrow = XT + (size_t)(j & (FG_MAXBS - 1)) * XTS + 8 * g;
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
@@ -346,48 +353,57 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
 #pragma unroll
         for (int t = 0; t < DQ::NT; ++t) xf[t] = *reinterpret_cast<const uint4 *>(xrow + c * 256 + 32 * t);
 #pragma unroll
-        for (int t = 0; t < DQ::NT; ++t) {
-            const u32x4 a = DQ::frag(u32x4{w[i].x, w[i].y, w[i].z, w[i].w}, t);
-            acc = ActF16::mfma(a, u32x4{xf[t].x, xf[t].y, xf[t].z, xf[t].w}, acc);
-        }
+        for (int k = 0; k < NRT; ++k)
+#pragma unroll
+            for (int t = 0; t < DQ::NT; ++t) {
+                const u32x4 a = DQ::frag(u32x4{w[k][i].x, w[k][i].y, w[k][i].z, w[k][i].w}, t);
+                acc[k] = ActF16::mfma(a, u32x4{xf[t].x, xf[t].y, xf[t].z, xf[t].w}, acc[k]);
+            }
     }
     FG_STAMP(13);
-    {
-        float *p = park + (slot * RT + r) * 256 + lane;
-        p[0] = acc[0]; p[64] = acc[1]; p[128] = acc[2]; p[192] = acc[3];
-    }
-    __syncthreads();
-    FG_STAMP(14);
-    if (wave < RT) {                                                            // one reducer wave per row tile: lane = (batch row, row in tile)
-        constexpr int NWD = FG_NW;                                               // every wave published its part of sum x~
-        const int r2 = wave, bb = lane >> 4, wr = lane & 15;
-        const int src = (wr & 3) * 64 + bb + 16 * (wr >> 2);                   // [acc component][mfma lane (j = bb, g = wr / 4)]
-        float a = 0.f, xsum = 0.f;
+    // the 16 / RT chunk slots meet in LDS, PB row tiles (per parallel row slot) at a time
 #pragma unroll
-        for (int v = 0; v < NS; ++v) a += park[(v * RT + r2) * 256 + src];
+    for (int h = 0; h < NRT / PB; ++h) {
+        if (h > 0) __syncthreads();                                             // the previous batch's reducers are done with park
 #pragma unroll
-        for (int v = 0; v < NWD; ++v) xsum += red[2 * FG_NW + bb * FG_NW + v];
-        const int64_t row = (int64_t)(blockIdx.x * RT + r2) * 16 + wr;
-        const float val = e_sc * two_over_maxq * (a - c0 * xsum);
-        if (bb < bs) {
-            if (G.y_f16) reinterpret_cast<uint16_t *>(Gg.y)[(int64_t)bb * G.m + row] = f32_to_f16_bits(val);
-            else reinterpret_cast<float *>(Gg.y)[(int64_t)bb * G.m + row] = val;
+        for (int kk = 0; kk < PB; ++kk) {
+            const int k = h * PB + kk;
+            float *p = park + ((slot * PB + kk) * RT + r) * 256 + lane;
+            p[0] = acc[k][0]; p[64] = acc[k][1]; p[128] = acc[k][2]; p[192] = acc[k][3];
+        }
+        __syncthreads();
+        FG_STAMP(14);
+        if (wave < RT * PB) {                                                   // one reducer wave per parked row tile: lane = (batch row, row in tile)
+            const int pr = wave, bb = lane >> 4, wr = lane & 15;                // pr = kk RT + r
+            const int src = (wr & 3) * 64 + bb + 16 * (wr >> 2);               // [acc component][mfma lane (j = bb, g = wr / 4)]
+            float a = 0.f, xsum = 0.f;
+#pragma unroll
+            for (int v = 0; v < NS; ++v) a += park[(v * PB * RT + pr) * 256 + src];
+#pragma unroll
+            for (int v = 0; v < FG_NW; ++v) xsum += red[2 * FG_NW + bb * FG_NW + v];         // every wave published its part of sum x~
+            const int64_t row = ((int64_t)blockIdx.x * (RT * NRT) + h * PB * RT + pr) * 16 + wr;
+            const float val = e_sc * two_over_maxq * (a - c0 * xsum);
+            if (bb < bs) {
+                if (G.y_f16) reinterpret_cast<uint16_t *>(Gg.y)[(int64_t)bb * G.m + row] = f32_to_f16_bits(val);
+                else reinterpret_cast<float *>(Gg.y)[(int64_t)bb * G.m + row] = val;
+            }
         }
     }
     FG_STAMP(15);
 }
 
-template <int P, int Q> constexpr size_t fused_lds()
+template <int P, int Q, int NRT> constexpr size_t fused_lds()
 {
     typedef PassDims<P, Q> D;
-    const size_t parkb = (size_t)(FG_NW * 256 + FG_NW * 64) * 4;
+    const size_t parkb = (size_t)(FG_NW * (NRT < 4 ? NRT : 4) * 256) * 4;
     return (size_t)FG_MAXBS * (D::N + 8) * 2 + (D::BYTES > parkb ? D::BYTES : parkb) + (2 + FG_MAXBS) * FG_NW * 4 + 64;
 }
 
-template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW> int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
+template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT>
+int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
 {
-    const size_t lds = fused_lds<P, Q>();
-    auto kern = fused_gemm_kernel<P, Q, HAS_U, HAS_RES, NORM, RT, CPW>;
+    const size_t lds = fused_lds<P, Q, NRT>();
+    auto kern = fused_gemm_kernel<P, Q, HAS_U, HAS_RES, NORM, RT, CPW, NRT>;
     static QaPerDevice attr;
     const int d = attr.dev();
     if (d < 0 || !attr.done[d]) {
@@ -396,7 +412,7 @@ template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW> int
         if (d >= 0) attr.done[d] = true;
     }
     const float maxq = 3.f;
-    kern<<<dim3((unsigned)(A.m / 16 / RT), (unsigned)ngroups), 1024, lds, s>>>(A, 2.0f / maxq, DeqT<2, ActF16>::OFF + 0.5f * maxq);
+    kern<<<dim3((unsigned)(A.m / 16 / (RT * NRT)), (unsigned)ngroups), 1024, lds, s>>>(A, 2.0f / maxq, DeqT<2, ActF16>::OFF + 0.5f * maxq);
     QA_LAUNCH_CHECK("quipamd_decode_fused_gemm");
     return QUIPAMD_OK;
 }
@@ -404,13 +420,13 @@ template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW> int
 // the combinations a decoder block needs (each is a 1300-line kernel: the full cross product would be 36 of them):
 //   64 x 32 (OPT d = 2048) and 64 x 64 (Llama d = 4096):  [U + residual, norm]  [no U, norm]  [no U, no norm]  [U + residual, no norm]
 //   128 x 64 (OPT d = 8192):                               [U, no residual, no norm]  [no U, no norm]
-template <int P, int Q, int NORM_MODEL, int RT, int CPW>
+template <int P, int Q, int NORM_MODEL, int RT, int CPW, int NRT>
 int dispatch_fused(const FusedArgs &A, bool u, bool res, int norm, int ngroups, hipStream_t s)
 {
-    if (u && res && norm == NORM_MODEL) return launch_fused<P, Q, true, true, NORM_MODEL, RT, CPW>(A, ngroups, s);
-    if (u && res && norm == 0) return launch_fused<P, Q, true, true, 0, RT, CPW>(A, ngroups, s);
-    if (!u && norm == NORM_MODEL) return launch_fused<P, Q, false, false, NORM_MODEL, RT, CPW>(A, ngroups, s);
-    if (!u && norm == 0) return launch_fused<P, Q, false, false, 0, RT, CPW>(A, ngroups, s);
+    if (u && res && norm == NORM_MODEL) return launch_fused<P, Q, true, true, NORM_MODEL, RT, CPW, NRT>(A, ngroups, s);
+    if (u && res && norm == 0) return launch_fused<P, Q, true, true, 0, RT, CPW, NRT>(A, ngroups, s);
+    if (!u && norm == NORM_MODEL) return launch_fused<P, Q, false, false, NORM_MODEL, RT, CPW, NRT>(A, ngroups, s);
+    if (!u && norm == 0) return launch_fused<P, Q, false, false, 0, RT, CPW, NRT>(A, ngroups, s);
     return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: %d x %d has no kernel for (U %d, residual %d, norm %d)", P, Q, (int)u, (int)res, norm);
 }
 
@@ -458,16 +474,21 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
     const bool u = a->has_u != 0, res = u && a->u_residual != nullptr;
     if (p == 64 && q == 32) {
         QA_REQUIRE(a->m > 0 && a->m % 32 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 32 (m = %lld)", (long long)a->m);
-        return dispatch_fused<64, 32, 1, 2, 1>(A, u, res, a->norm, a->ngroups, s);
+        return dispatch_fused<64, 32, 1, 2, 1, 1>(A, u, res, a->norm, a->ngroups, s);
     }
     if (p == 64 && q == 64) {
         QA_REQUIRE(a->m > 0 && a->m % 16 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 16 (m = %lld)", (long long)a->m);
-        return dispatch_fused<64, 64, 2, 1, 1>(A, u, res, a->norm, a->ngroups, s);
+        // row tiles per wave: as many as keep the grid within one round of 256 workgroups (each repeats the prologue)
+        const int64_t tiles = a->m / 16 * a->ngroups;
+        const int nrt = (tiles > 4 * 256 && a->m % 128 == 0) ? 8 : (tiles > 256 && a->m % 64 == 0) ? 4 : 1;
+        return nrt == 8 ? dispatch_fused<64, 64, 2, 1, 1, 8>(A, u, res, a->norm, a->ngroups, s)
+             : nrt == 4 ? dispatch_fused<64, 64, 2, 1, 1, 4>(A, u, res, a->norm, a->ngroups, s)
+                        : dispatch_fused<64, 64, 2, 1, 1, 1>(A, u, res, a->norm, a->ngroups, s);
     }
     if (p == 128 && q == 64) {
         QA_REQUIRE(a->m > 0 && a->m % 16 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 16 (m = %lld)", (long long)a->m);
-        if (u && !res && a->norm == 0) return launch_fused<128, 64, true, false, 0, 1, 2>(A, a->ngroups, s);
-        if (!u && a->norm == 0) return launch_fused<128, 64, false, false, 0, 1, 2>(A, a->ngroups, s);
+        if (u && !res && a->norm == 0) return launch_fused<128, 64, true, false, 0, 1, 2, 1>(A, a->ngroups, s);
+        if (!u && a->norm == 0) return launch_fused<128, 64, false, false, 0, 1, 2, 1>(A, a->ngroups, s);
         return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: 128 x 64 runs (U, no residual, no norm) and (no U, no norm) only");
     }
     return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: operator %d x %d (64 x 32, 64 x 64, 128 x 64)", p, q);

@@ -209,11 +209,11 @@ class QuantLinear(nn.Module):
         if qd is None or qd.device != self.qweight.device:
             m, d = self.outfeatures, self.infeatures
             codes = ops.unpack(self.qweight, self.bits, ops.LAYOUT_STREAM, m, d)
-            if self.U is not None:
-                perm = torch.empty(m, dtype=torch.int64, device=codes.device)
+            if self.U is not None and self.U.fused_ok:        # (an operator the fused launches cannot run -- Llama's 688 x 16 -- keeps the
+                perm = torch.empty(m, dtype=torch.int64, device=codes.device)   #  natural order: its side is served by the K3 kernels)
                 perm[self.U.zt_rows()] = torch.arange(m, device=codes.device)          # new row r holds old row perm[r]
                 codes = codes[perm]
-            if self.V is not None:
+            if self.V is not None and self.V.fused_ok:
                 perm = torch.empty(d, dtype=torch.int64, device=codes.device)
                 perm[self.V.image_cols()] = torch.arange(d, device=codes.device)
                 codes = codes[:, perm]
@@ -223,12 +223,14 @@ class QuantLinear(nn.Module):
 
     def to_zt(self, y):
         """a vector in this layer's natural output order -> ZT order (what its decode launch produces)"""
+        if self.U is None or not self.U.fused_ok:
+            return y
         out = torch.empty_like(y)
         out[..., self.U.zt_rows()] = y
         return out
 
     def from_zt(self, y):
-        return y[..., self.U.zt_rows()]
+        return y if (self.U is None or not self.U.fused_ok) else y[..., self.U.zt_rows()]
 
     def packed_state(self):
         """everything needed to rebuild the layer, as CPU tensors / plain Python (the packed checkpoint record):
@@ -601,6 +603,22 @@ def fused_attention(qkv, ys, kcache, vcache, pos, cos_table=None, sin_table=None
     """decode attention with U_q^T, U_k^T, U_v^T (+ bias) of the three packed projections `qkv` in its prologue; ys: their fp16 GEMM
     outputs from fused_stage(..., y_dtype=torch.float16)"""
     return ops.decode_attention_fused([q.U for q in qkv], ys, [bias16(q) for q in qkv], kcache, vcache, pos, cos_table, sin_table)
+
+
+def packed_v_stage_gate(ql, gate, up):
+    """x~ = V (silu(gate) * up (/) s), bf16: the activation side of Llama's down_proj with the MLP's elementwise product formed on load
+    (csrc/ortho_bigp.hip for the 688 x 16 operator; torch ops + the general K3 launch otherwise)"""
+    rows = gate.shape[0]
+    V = ql.V
+    if (V.bigp_ok and not V.small_ok and rows <= ops.TILE_ROWS and gate.dtype == torch.float16 and up.dtype == torch.float16
+            and gate.stride(0) == up.stride(0)):
+        xt = torch.empty((rows, ql.infeatures), dtype=torch.bfloat16, device=gate.device)
+        cs = ql.inv_scaleWH if ql.inv_scaleWH is not None else V.one_scale()
+        ent = [(V, V.small_op(gate.contiguous(), xt, colscale=cs, residual=up.contiguous(), relu=True), False)]
+        if all(ops._tile_form(d_) is not None for _, d_, _ in ent):
+            ops.ortho_apply_ops(ent, rows)
+            return xt
+    return V.apply_rows(torch.nn.functional.silu(gate) * up, colscale=ql.inv_scaleWH, out_dtype=torch.bfloat16)
 
 
 def fused_u_only(ql, y, residual=None, relu=False):

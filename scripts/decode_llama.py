@@ -29,7 +29,8 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quip_amd import ops, method  # noqa: E402
-from quip_amd.quant import QuantLinear, packed_forward_fused  # noqa: E402
+from quip_amd.quant import (QuantLinear, packed_forward_fused, fused_stage, fused_ok, fused_attention, fused_attention_ok,  # noqa: E402
+                            fused_u_only, packed_u_stage, packed_v_stage_gate)
 import decode_opt as D  # noqa: E402  (time_decode: hipGraph capture + per-token timing)
 
 
@@ -95,8 +96,42 @@ class Decoder(nn.Module):
         self.cos, self.sin = cos.to(self.tok.weight.device), sin.to(self.tok.weight.device)
         return self
 
+    v3 = False               # csrc/decode_fused.hip + decode_attn.hip: 8 launches per block (13+ in the round-2 fused variant)
+
+    def v3_ok(self, bs):
+        b = self.blocks[0]
+        qkv = [b.q_proj, b.k_proj, b.v_proj]
+        return (isinstance(b.q_proj, QuantLinear) and fused_ok(qkv, bs, prev=b.down_proj) and fused_ok([b.o_proj], bs, norm=False)
+                and fused_ok([b.gate_proj, b.up_proj], bs, prev=b.o_proj) and b.down_proj.U is not None and b.down_proj.U.fused_ok)
+
+    def step_v3(self, x, pos, caches):
+        """per block: [U_down^T(prev) + residual -> RMSNorm -> V_qkv -> GEMM q,k,v] [U_qkv^T + rotary + attention] [V_o -> GEMM o]
+        [U_o^T + residual -> RMSNorm -> V_gate/up -> GEMM gate, up] [U_gate^T, U_up^T: 688 x 16, K3] [V_down (silu * up on load), K3]
+        [GEMM down] [fp16 cast]; 11008 = 688 x 16 has no fused operator kernel (a 688 x 688 factor is 0.9 MB: not a workgroup's pass)"""
+        h16 = torch.float16
+        prev, yd = None, None
+        for blk, (kc, vc) in zip(self.blocks, caches):
+            qkv = [blk.q_proj, blk.k_proj, blk.v_proj]
+            if prev is None:
+                ys, _ = fused_stage(qkv, x=x, ln=blk.n1, y_dtype=h16)
+            else:
+                ys, x = fused_stage(qkv, prev=prev, y_prev=yd, residual=x, ln=blk.n1, store=True, y_dtype=h16)
+            o = fused_attention(qkv, ys, kc, vc, pos, self.cos, self.sin)
+            yo = fused_stage([blk.o_proj], x=o, y_dtype=h16)[0][0]
+            gu = [blk.gate_proj, blk.up_proj]
+            ygu, x = fused_stage(gu, prev=blk.o_proj, y_prev=yo, residual=x, ln=blk.n2, store=True, y_dtype=torch.float32)
+            g, u = packed_u_stage(gu, ygu, h16)
+            xt = packed_v_stage_gate(blk.down_proj, g, u)
+            yd32 = torch.empty((x.shape[0], blk.down_proj.outfeatures), dtype=torch.float32, device=x.device)
+            ops.dequant_gemm_grouped([xt], [blk.down_proj.decode_qweight()], 2, 'b', [blk.down_proj.scales], None, [yd32], blk.down_proj.outfeatures)
+            yd = yd32.to(h16)
+            prev = blk.down_proj
+        return fused_u_only(prev, yd, residual=x)
+
     def step(self, ids, pos, caches, arange):
         x = self.tok(ids)
+        if self.v3:
+            return self.lm_head(self.norm(self.step_v3(x, pos, caches)))
         for blk, (kc, vc) in zip(self.blocks, caches):
             x = blk(x, kc, vc, pos, self.cos, self.sin)
         return self.lm_head(self.norm(x))
@@ -161,6 +196,13 @@ def run(layers=32, bits=2, bs=1, prompt=64, tokens=64, with_dense=True):
     out["packed_w%d_fused" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
                                       "what": "q/k/v and gate/up grouped; RMSNorm folded into the V-side launch; residual folded into U^T; "
                                               "4096-wide operators tiled over 16 workgroups"}
+    if model.v3_ok(bs):
+        model.v3 = True
+        med, _, _ = D.time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, False)
+        out["packed_w%d_v3" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+                                       "what": "csrc/decode_fused.hip / decode_attn.hip: operator chains in the prologues of the 4096-wide GEMMs and of the "
+                                               "attention launch (rotary included); the 11008-wide operators on the K3 kernels: 8 launches per block"}
+        model.v3 = False
     del model
     torch.cuda.empty_cache()
     return out
@@ -177,6 +219,12 @@ def decode_check(layers=2, bits=2, small=True):
         blk.fused = True
     torch.manual_seed(1)
     _, _, lf = D.time_decode(model, 2, 0, 3, 32, dev, dtype, True)
+    l3 = None
+    if model.v3_ok(2):
+        model.v3 = True
+        torch.manual_seed(1)
+        _, _, l3 = D.time_decode(model, 2, 0, 3, 32, dev, dtype, True)
+        model.v3 = False
     for blk in model.blocks:
         blk.fused = False
     for (li, name), Wd in twin.items():
@@ -185,13 +233,13 @@ def decode_check(layers=2, bits=2, small=True):
         setattr(model.blocks[li], name, lin)
     torch.manual_seed(1)
     _, _, ld = D.time_decode(model, 2, 0, 3, 32, dev, dtype, True)
-    return float((lq - ld).norm() / ld.norm()), float((lf - ld).norm() / ld.norm())
+    return float((lq - ld).norm() / ld.norm()), float((lf - ld).norm() / ld.norm()), None if l3 is None else float((l3 - ld).norm() / ld.norm())
 
 
 if __name__ == "__main__":
     if "--check" in sys.argv:
-        e1, e2 = decode_check()
-        print(json.dumps({"llama_decode_logits_rel_err_packed_vs_dense_twin": e1, "fused_vs_dense_twin": e2}))
+        e1, e2, e3 = decode_check()
+        print(json.dumps({"llama_decode_logits_rel_err_packed_vs_dense_twin": e1, "fused_vs_dense_twin": e2, "v3_vs_dense_twin": e3}))
     else:
         ap = argparse.ArgumentParser()
         ap.add_argument("--layers", type=int, default=32)

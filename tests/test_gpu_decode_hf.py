@@ -212,6 +212,10 @@ def test_llama_decode_harness_matches_hf_with_past_key_values():
     for blk in dec.blocks:
         blk.fused = True
     report["fused"] = _gate("fused", harness_logits(dec, toks, maxpos, dtype), ref, toks)
+    assert dec.v3_ok(1)
+    dec.v3 = True                                            # fused launches (64 x 32 operators at hidden 2048) + rotary in the attention prologue
+    report["v3"] = _gate("v3", harness_logits(dec, toks, maxpos, dtype), ref, toks)
+    dec.v3 = False
     for li, blk in enumerate(dec.blocks):
         blk.fused = False
         for name in L.Decoder.NAMES:

@@ -34,8 +34,10 @@ def test_llama_decode_step_matches_its_dense_twin():
     spec = importlib.util.spec_from_file_location("decode_llama", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    e_plain, e_fused = mod.decode_check(layers=2, bits=2)
+    e_plain, e_fused, e_v3 = mod.decode_check(layers=2, bits=2)
     assert e_plain <= 1e-2 and e_fused <= 1e-2, (e_plain, e_fused)
+    # small = hidden 2048 (64 x 32 operators, head_dim 128): the fused launches incl. rotary in the attention prologue
+    assert e_v3 is not None and e_v3 <= 1e-2, e_v3
 
 
 def test_rope_inplace_matches_hf_formula():
