@@ -417,16 +417,18 @@ int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
     return QUIPAMD_OK;
 }
 
-// the combinations a decoder block needs (each is a 1300-line kernel: the full cross product would be 36 of them):
-//   64 x 32 (OPT d = 2048) and 64 x 64 (Llama d = 4096):  [U + residual, norm]  [no U, norm]  [no U, no norm]  [U + residual, no norm]
-//   128 x 64 (OPT d = 8192):                               [U, no residual, no norm]  [no U, no norm]
-template <int P, int Q, int NORM_MODEL, int RT, int CPW, int NRT>
+// the combinations a decoder block needs (each is a 1300-line kernel):
+//   64 x 32 (d = 2048) and 64 x 64 (d = 4096):  [U + residual | no U] x [no norm | LayerNorm | RMSNorm]
+//   128 x 64 (OPT d = 8192):                    [U, no residual, no norm]  [no U, no norm]
+template <int P, int Q, int RT, int CPW, int NRT>
 int dispatch_fused(const FusedArgs &A, bool u, bool res, int norm, int ngroups, hipStream_t s)
 {
-    if (u && res && norm == NORM_MODEL) return launch_fused<P, Q, true, true, NORM_MODEL, RT, CPW, NRT>(A, ngroups, s);
-    if (u && res && norm == 0) return launch_fused<P, Q, true, true, 0, RT, CPW, NRT>(A, ngroups, s);
-    if (!u && norm == NORM_MODEL) return launch_fused<P, Q, false, false, NORM_MODEL, RT, CPW, NRT>(A, ngroups, s);
-    if (!u && norm == 0) return launch_fused<P, Q, false, false, 0, RT, CPW, NRT>(A, ngroups, s);
+    if (u && res) return norm == 0 ? launch_fused<P, Q, true, true, 0, RT, CPW, NRT>(A, ngroups, s)
+                       : norm == 1 ? launch_fused<P, Q, true, true, 1, RT, CPW, NRT>(A, ngroups, s)
+                                   : launch_fused<P, Q, true, true, 2, RT, CPW, NRT>(A, ngroups, s);
+    if (!u) return norm == 0 ? launch_fused<P, Q, false, false, 0, RT, CPW, NRT>(A, ngroups, s)
+                 : norm == 1 ? launch_fused<P, Q, false, false, 1, RT, CPW, NRT>(A, ngroups, s)
+                             : launch_fused<P, Q, false, false, 2, RT, CPW, NRT>(A, ngroups, s);
     return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: %d x %d has no kernel for (U %d, residual %d, norm %d)", P, Q, (int)u, (int)res, norm);
 }
 
@@ -474,16 +476,16 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
     const bool u = a->has_u != 0, res = u && a->u_residual != nullptr;
     if (p == 64 && q == 32) {
         QA_REQUIRE(a->m > 0 && a->m % 32 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 32 (m = %lld)", (long long)a->m);
-        return dispatch_fused<64, 32, 1, 2, 1, 1>(A, u, res, a->norm, a->ngroups, s);
+        return dispatch_fused<64, 32, 2, 1, 1>(A, u, res, a->norm, a->ngroups, s);
     }
     if (p == 64 && q == 64) {
         QA_REQUIRE(a->m > 0 && a->m % 16 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 16 (m = %lld)", (long long)a->m);
         // row tiles per wave: as many as keep the grid within one round of 256 workgroups (each repeats the prologue)
         const int64_t tiles = a->m / 16 * a->ngroups;
         const int nrt = (tiles > 4 * 256 && a->m % 128 == 0) ? 8 : (tiles > 256 && a->m % 64 == 0) ? 4 : 1;
-        return nrt == 8 ? dispatch_fused<64, 64, 2, 1, 1, 8>(A, u, res, a->norm, a->ngroups, s)
-             : nrt == 4 ? dispatch_fused<64, 64, 2, 1, 1, 4>(A, u, res, a->norm, a->ngroups, s)
-                        : dispatch_fused<64, 64, 2, 1, 1, 1>(A, u, res, a->norm, a->ngroups, s);
+        return nrt == 8 ? dispatch_fused<64, 64, 1, 1, 8>(A, u, res, a->norm, a->ngroups, s)
+             : nrt == 4 ? dispatch_fused<64, 64, 1, 1, 4>(A, u, res, a->norm, a->ngroups, s)
+                        : dispatch_fused<64, 64, 1, 1, 1>(A, u, res, a->norm, a->ngroups, s);
     }
     if (p == 128 && q == 64) {
         QA_REQUIRE(a->m > 0 && a->m % 16 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 16 (m = %lld)", (long long)a->m);
