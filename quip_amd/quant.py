@@ -605,20 +605,20 @@ def fused_attention(qkv, ys, kcache, vcache, pos, cos_table=None, sin_table=None
     return ops.decode_attention_fused([q.U for q in qkv], ys, [bias16(q) for q in qkv], kcache, vcache, pos, cos_table, sin_table)
 
 
-def packed_v_stage_gate(ql, gate, up):
-    """x~ = V (silu(gate) * up (/) s), bf16: the activation side of Llama's down_proj with the MLP's elementwise product formed on load
+def packed_v_stage_gate(ql, gate, up, out_dtype=torch.bfloat16):
+    """x~ = V (silu(gate) * up (/) s) in out_dtype: the activation side of Llama's down_proj with the MLP's elementwise product formed on load
     (csrc/ortho_bigp.hip for the 688 x 16 operator; torch ops + the general K3 launch otherwise)"""
     rows = gate.shape[0]
     V = ql.V
     if (V.bigp_ok and not V.small_ok and rows <= ops.TILE_ROWS and gate.dtype == torch.float16 and up.dtype == torch.float16
             and gate.stride(0) == up.stride(0)):
-        xt = torch.empty((rows, ql.infeatures), dtype=torch.bfloat16, device=gate.device)
+        xt = torch.empty((rows, ql.infeatures), dtype=out_dtype, device=gate.device)
         cs = ql.inv_scaleWH if ql.inv_scaleWH is not None else V.one_scale()
         ent = [(V, V.small_op(gate.contiguous(), xt, colscale=cs, residual=up.contiguous(), relu=True), False)]
         if all(ops._tile_form(d_) is not None for _, d_, _ in ent):
             ops.ortho_apply_ops(ent, rows)
             return xt
-    return V.apply_rows(torch.nn.functional.silu(gate) * up, colscale=ql.inv_scaleWH, out_dtype=torch.bfloat16)
+    return V.apply_rows(torch.nn.functional.silu(gate) * up, colscale=ql.inv_scaleWH, out_dtype=out_dtype)
 
 
 def fused_u_only(ql, y, residual=None, relu=False):
