@@ -96,7 +96,7 @@ class Decoder(nn.Module):
         self.cos, self.sin = cos.to(self.tok.weight.device), sin.to(self.tok.weight.device)
         return self
 
-    v3 = False               # csrc/decode_fused.hip + decode_attn.hip: 7 launches per block (13+ in the round-2 fused variant)
+    v3 = False               # csrc/decode_fused.hip + decode_attn.hip: 8 launches per block (13+ in the round-2 fused variant)
 
     def v3_ok(self, bs):
         b = self.blocks[0]
@@ -107,7 +107,7 @@ class Decoder(nn.Module):
     def step_v3(self, x, pos, caches):
         """per block: [U_down^T(prev) + residual -> RMSNorm -> V_qkv -> GEMM q,k,v] [U_qkv^T + rotary + attention] [V_o -> GEMM o]
         [U_o^T + residual -> RMSNorm -> V_gate/up -> GEMM gate, up] [U_gate^T, U_up^T: 688 x 16, K3] [V_down (silu * up on load), K3]
-        [GEMM down]; 11008 = 688 x 16 has no fused operator kernel (a 688 x 688 factor is 0.9 MB: not a workgroup's pass)"""
+        [GEMM down] [fp16 cast]; 11008 = 688 x 16 has no fused operator kernel (a 688 x 688 factor is 0.9 MB: not a workgroup's pass)"""
         h16 = torch.float16
         prev, yd = None, None
         for blk, (kc, vc) in zip(self.blocks, caches):
@@ -121,9 +121,12 @@ class Decoder(nn.Module):
             gu = [blk.gate_proj, blk.up_proj]
             ygu, x = fused_stage(gu, prev=blk.o_proj, y_prev=yo, residual=x, ln=blk.n2, store=True, y_dtype=torch.float32)
             g, u = packed_u_stage(gu, ygu, h16)
-            xt = packed_v_stage_gate(blk.down_proj, g, u, out_dtype=h16)          # fp16 x~ -> the fp16 MFMA, y written as fp16: no cast launch
-            yd = torch.empty((x.shape[0], blk.down_proj.outfeatures), dtype=h16, device=x.device)
-            ops.dequant_gemm_grouped([xt], [blk.down_proj.decode_qweight()], 2, 'b', [blk.down_proj.scales], None, [yd], blk.down_proj.outfeatures)
+            # (fp16 x~ / y through this GEMM would save the cast launch, but K2's fp16 kernel for d = 11008 is 6 us slower than the bf16
+            #  tile kernel at batch 1: measured 378 vs 414 tok/s)
+            xt = packed_v_stage_gate(blk.down_proj, g, u)
+            yd32 = torch.empty((x.shape[0], blk.down_proj.outfeatures), dtype=torch.float32, device=x.device)
+            ops.dequant_gemm_grouped([xt], [blk.down_proj.decode_qweight()], 2, 'b', [blk.down_proj.scales], None, [yd32], blk.down_proj.outfeatures)
+            yd = yd32.to(h16)
             prev = blk.down_proj
         return fused_u_only(prev, yd, residual=x)
 
