@@ -306,6 +306,13 @@ typedef struct quipamd_fused_gemm_args {
     void *y[3];
     int y_dtype;                     /* QUIPAMD_F32, or QUIPAMD_F16 when the consumer is another fused launch (its scatter rounds to fp16 anyway) */
     int64_t bs, m;
+    /* optional, 128 x 64 with has_u, no residual, no norm, one group, bs <= 2 (OPT's fc1 -> fc2 hand-over): per-lane tables of the LAYER
+     * PAIR in the lane order of the MFMA result of U's second stage -- entry [(w * 64 + lane) * 8 + 4 i + reg] belongs to image element
+     * (a, b) = (16 at + 4 (lane / 16) + reg, 16 bt + lane % 16) of tile (at, bt) = ((w + 16 i) / 4, (w + 16 i) % 4), i.e. to the natural
+     * element k with U.store_idx[k] = a q + b:  pair_sig uint16 = LDS position (pv % q) (p + 8) + pv / q of pv = V.load_idx[k];
+     * pair_bias fp16 = u_bias[k];  pair_cs fp16 = colscale[0][k].  With them the gather / scale / scatter between the two operators is
+     * one scatter in the epilogue of U's stage 2 (U.store_idx, V[0].load_idx, u_bias and colscale[0] are then not read). */
+    const void *pair_sig, *pair_bias, *pair_cs;
 } quipamd_fused_gemm_args;
 int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *args, void *stream);
 

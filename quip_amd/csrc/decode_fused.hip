@@ -65,6 +65,7 @@ struct FusedArgs {
     int bs, y_f16;
     int64_t m;
     FGroup g[FG_MAXG];
+    const uint4 *pair_sig, *pair_bias, *pair_cs;   // fused_pair_kernel: per-lane tables in D-fragment order (include/quip_amd.h)
 };
 
 // keep a kernarg pointer's scalar load where it is written: hipcc fetches kernarg fields lazily, one s_load + s_waitcnt per first
@@ -392,6 +393,197 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     FG_STAMP(15);
 }
 
+// ---- n = 8192 (OPT's fc1 -> fc2 hand-over): t = relu(U^T y + bias) feeds x~ = V (t (/) s) with no norm and no residual in between ------
+// The generic kernel above spends 60 % of its 10 us at this size on (a) pulling 2 x 96 KiB of factor fragments per workgroup through
+// the CU's vector-memory path (every wave its own copy) and (b) four passes of random 2- and 4-byte LDS traffic over 8192 elements
+// (fp32 image, gather, scale, scatter).  Here
+//   * the fragments of BOTH operators go global -> registers -> LDS once per workgroup (2 x 40 KiB, three 16-byte loads per thread each)
+//     and every wave reads the ones of its tiles from LDS;
+//   * the gather / scatter pair between the operators is ONE scatter: the lane that holds element (a, b) of U's image after stage 2
+//     adds its bias, clamps, scales and writes the fp16 value straight to its place in V's input image.  Where that is, and the bias
+//     and 1 / s that go with it, are per-lane tables the host prepares once per layer pair in the lane order of the MFMA result
+//     (pair_sig: LDS offset in ZT_V, pair_bias, pair_cs: fp16; entry [(wave * 64 + lane) * 8 + 4 i + reg] for tile wave + 16 i).
+// bs <= 2 (x~ rows, 2 images and 80 KiB of fragments share the LDS).
+template <int P, int Q>
+__global__ __launch_bounds__(1024) void fused_pair_kernel(FusedArgs G, float two_over_maxq, float c0)
+{
+    typedef PassDims<P, Q> D;
+    typedef DeqT<2, ActF16> DQ;
+    constexpr int N = D::N, NS = FG_NW, NCH = N / 256, CPW = NCH / NS, XTS = N + 8, MAXBS = 2;
+    constexpr int NF0 = (P / 16) * D::S0, NF1 = (Q / 16) * D::S1, NFR = NF0 + NF1;        // 1 KiB fragment pieces per operator (32 + 8)
+    constexpr int FPT = (NFR * 64 + 1023) / 1024;                                          // uint4 per thread per operator
+    static_assert(D::TPW == 2 && N / 8 == 1024, "128 x 64");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t *XT = reinterpret_cast<uint16_t *>(smem);                                     // [MAXBS][N + 8]
+    char *pass = smem + (size_t)MAXBS * XTS * 2;
+    uint16_t *ZT = reinterpret_cast<uint16_t *>(pass);
+    uint16_t *Z1 = reinterpret_cast<uint16_t *>(pass + D::ZT_B);
+    float *park = reinterpret_cast<float *>(pass);                                          // [NS][4][64] after the last pass (16 KiB)
+    uint4 *FRU = reinterpret_cast<uint4 *>(pass + D::ZT_B + D::Z1_B);                       // [NFR][64] uint4
+    uint4 *FRV = FRU + NFR * 64;
+    float *red = reinterpret_cast<float *>(FRV + NFR * 64);                                 // [MAXBS][16] sum x~
+
+    const FGroup &Gg = G.g[0];
+    const Fop &V = Gg.V;
+    asm volatile("" ::"s"(Gg.qw), "s"(V.F0), "s"(V.F1), "s"(Gg.scale), "s"(Gg.y), "s"(G.U.F0), "s"(G.U.F1), "s"(G.u_y), "s"(G.floor), "s"(G.bs),
+                 "s"(G.m), "s"(G.y_f16), "s"(G.pair_sig), "s"(G.pair_bias), "s"(G.pair_cs));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int bs = G.bs;
+    FG_STAMP(0);
+
+    // ---- requests, in the order of use: the row, U's fragments | (barrier) | the pair tables, V's fragments, the weights ---------------
+    uint4 yc = *reinterpret_cast<const uint4 *>(G.u_y + 8 * (uint32_t)tid);
+    // an operator's fragments, piece-major [NF0 | NF1][64 lanes]: thread t copies entries t, t + 1024 (M0's 32 pieces) and, t < 512,
+    // entry t of M1's 8 pieces.  (Scalars, not an array: a conditionally written array went to scratch, with a wait behind every load.)
+    static_assert(NF0 * 64 == 2048 && NF1 * 64 == 512 && FPT == 3, "128 x 64");
+    const uint4 *U0 = reinterpret_cast<const uint4 *>(G.U.F0), *U1 = reinterpret_cast<const uint4 *>(G.U.F1);
+    const uint4 *V0 = reinterpret_cast<const uint4 *>(V.F0), *V1 = reinterpret_cast<const uint4 *>(V.F1);
+    const uint32_t t1 = tid & 511;
+    const uint4 fu0 = U0[tid], fu1 = U0[tid + 1024], fu2 = U1[t1];               // (waves 8..15 load M1's entry again; they do not store it)
+    __syncthreads();                                                            // first-phase requests of every wave are queued before the rest
+    const uint4 sg = G.pair_sig[tid], pb = G.pair_bias[tid], pc = G.pair_cs[tid];
+    const uint4 fv0 = V0[tid], fv1 = V0[tid + 1024], fv2 = V1[t1];
+    uint4 w[CPW];
+    const uint32_t rt = blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Gg.qw + ((uint64_t)rt * NCH + (wave * CPW + i)) * 64 + lane));
+        w[i] = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+    const float e_sc = Gg.scale[0];
+    const int at1 = wave % (P / 16), bt2 = wave % (Q / 16);                     // the factor tile of this wave's stage-1 / stage-2 tiles
+
+    for (int b = 0; b < bs; ++b) {
+        if (b > 0) yc = *reinterpret_cast<const uint4 *>((G.u_y + (int64_t)b * N) + 8 * (uint32_t)tid);
+        copy_chunk_zt<P, Q>(ZT, yc, tid);
+        if (b == 0) {
+            FRU[tid] = fu0;
+            FRU[tid + 1024] = fu1;
+            if (tid < 512) FRU[2048 + tid] = fu2;
+        }
+        FG_STAMP(1);
+        __syncthreads();
+        FG_STAMP(2);
+        PassFrags<P, Q> fr;
+#pragma unroll
+        for (int S = 0; S < D::S0; ++S) fr.f0[S] = FRU[(at1 * D::S0 + S) * 64 + lane];
+#pragma unroll
+        for (int S = 0; S < D::S1; ++S) fr.f1[S] = FRU[(NF0 + bt2 * D::S1 + S) * 64 + lane];
+        mix_stage1<P, Q>(ZT, Z1, fr, wave, lane);
+        FG_STAMP(3);
+        __syncthreads();                                                        // Z1 complete; ZT (U's input) dead: V's input image goes there
+        FG_STAMP(4);
+        // stage 2 of U^T with the hand-over in its epilogue: relu(. + bias) (/) s, fp16, into V's input image
+        {
+            auto half_of = [](const uint4 &v, int e) -> uint32_t {               // 16-bit entry e (0..7) of a 16-byte table row
+                const uint32_t d = (e >> 1) == 0 ? v.x : (e >> 1) == 1 ? v.y : (e >> 1) == 2 ? v.z : v.w;
+                return (e & 1) ? d >> 16 : d & 0xffffu;
+            };
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int tile = wave + FG_NW * i;
+                const int bt = tile % (Q / 16), at = tile / (Q / 16);
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                const uint16_t *arow = Z1 + (16 * at + j) * D::QS + 8 * g;
+#pragma unroll
+                for (int S = 0; S < D::S1; ++S) {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(arow + 32 * S);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, fr.f1[S]), acc, 0, 0, 0);
+                }
+                (void)bt;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int e = 4 * i + reg;
+                    const float bia = f16_bits_to_f32((uint16_t)half_of(pb, e)), csc = f16_bits_to_f32((uint16_t)half_of(pc, e));
+                    const float t = f16_bits_to_f32(f32_to_f16_bits(fmaxf(acc[reg] + bia, G.floor)));    // t exists as an fp16 value (the round-2 launches stored it)
+                    ZT[half_of(sg, e)] = f32_to_f16_bits(t * csc);
+                }
+            }
+        }
+        if (b == 0) {
+            FRV[tid] = fv0;
+            FRV[tid + 1024] = fv1;
+            if (tid < 512) FRV[2048 + tid] = fv2;
+        }
+        FG_STAMP(7);
+        __syncthreads();
+        FG_STAMP(8);
+#pragma unroll
+        for (int S = 0; S < D::S0; ++S) fr.f0[S] = FRV[(at1 * D::S0 + S) * 64 + lane];
+#pragma unroll
+        for (int S = 0; S < D::S1; ++S) fr.f1[S] = FRV[(NF0 + bt2 * D::S1 + S) * 64 + lane];
+        mix_stage1<P, Q>(ZT, Z1, fr, wave, lane);
+        FG_STAMP(9);
+        __syncthreads();
+        FG_STAMP(10);
+        float xpart = mix_stage2_xt<P, Q>(Z1, XT + (size_t)b * XTS, fr, wave, lane);
+        xpart = fg_wave_sum(xpart);
+        if (lane == 0) red[b * FG_NW + wave] = xpart;
+        FG_STAMP(11);
+        __syncthreads();
+        FG_STAMP(12);
+    }
+
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const uint16_t *xrow = XT + (size_t)(j & (MAXBS - 1)) * XTS + 8 * g;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int c = wave * CPW + i;
+        uint4 xf[DQ::NT];
+#pragma unroll
+        for (int t = 0; t < DQ::NT; ++t) xf[t] = *reinterpret_cast<const uint4 *>(xrow + c * 256 + 32 * t);
+#pragma unroll
+        for (int t = 0; t < DQ::NT; ++t) {
+            const u32x4 a = DQ::frag(u32x4{w[i].x, w[i].y, w[i].z, w[i].w}, t);
+            acc = ActF16::mfma(a, u32x4{xf[t].x, xf[t].y, xf[t].z, xf[t].w}, acc);
+        }
+    }
+    FG_STAMP(13);
+    {
+        float *p_ = park + wave * 256 + lane;
+        p_[0] = acc[0]; p_[64] = acc[1]; p_[128] = acc[2]; p_[192] = acc[3];
+    }
+    __syncthreads();
+    FG_STAMP(14);
+    if (wave == 0) {
+        const int bb = lane >> 4, wr = lane & 15;
+        const int src = (wr & 3) * 64 + bb + 16 * (wr >> 2);
+        float a = 0.f, xsum = 0.f;
+#pragma unroll
+        for (int v = 0; v < NS; ++v) a += park[v * 256 + src];
+#pragma unroll
+        for (int v = 0; v < FG_NW; ++v) xsum += red[(bb & (MAXBS - 1)) * FG_NW + v];
+        const int64_t row = (int64_t)blockIdx.x * 16 + wr;
+        const float val = e_sc * two_over_maxq * (a - c0 * xsum);
+        if (bb < bs) {
+            if (G.y_f16) reinterpret_cast<uint16_t *>(Gg.y)[(int64_t)bb * G.m + row] = f32_to_f16_bits(val);
+            else reinterpret_cast<float *>(Gg.y)[(int64_t)bb * G.m + row] = val;
+        }
+    }
+    FG_STAMP(15);
+}
+
+template <int P, int Q> int launch_pair(const FusedArgs &A, hipStream_t s)
+{
+    typedef PassDims<P, Q> D;
+    constexpr int NFR = (P / 16) * D::S0 + (Q / 16) * D::S1;
+    const size_t lds = (size_t)2 * (D::N + 8) * 2 + D::ZT_B + D::Z1_B + (size_t)2 * NFR * 1024 + 2 * FG_NW * 4 + 64;
+    auto kern = fused_pair_kernel<P, Q>;
+    static QaPerDevice attr;
+    const int d = attr.dev();
+    if (d < 0 || !attr.done[d]) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_fused_gemm (pair): cannot raise dynamic LDS to %zu", lds);
+        if (d >= 0) attr.done[d] = true;
+    }
+    const float maxq = 3.f;
+    kern<<<dim3((unsigned)(A.m / 16), 1), 1024, lds, s>>>(A, 2.0f / maxq, DeqT<2, ActF16>::OFF + 0.5f * maxq);
+    QA_LAUNCH_CHECK("quipamd_decode_fused_gemm (pair)");
+    return QUIPAMD_OK;
+}
+
 template <int P, int Q, int NRT> constexpr size_t fused_lds()
 {
     typedef PassDims<P, Q> D;
@@ -452,6 +644,7 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
     A.ld_res = a->ld_residual; A.ld_t = a->ld_t; A.floor = a->u_relu ? 0.f : -INFINITY;
     A.x = (const uint16_t *)a->x; A.ldx = a->ldx;
     A.gamma = (const uint16_t *)a->ln_gamma; A.beta = (const uint16_t *)a->ln_beta; A.eps = a->ln_eps;
+    A.pair_sig = A.pair_bias = A.pair_cs = nullptr;
     A.bs = (int)a->bs; A.m = a->m; A.y_f16 = a->y_dtype == QUIPAMD_F16;
     QA_REQUIRE(a->y_dtype == QUIPAMD_F16 || a->y_dtype == QUIPAMD_F32, QUIPAMD_ERR_ARG, "decode_fused_gemm: y_dtype f32 or f16");
     QA_REQUIRE(a->norm >= 0 && a->norm <= 2 && (a->norm == 0 || a->ln_gamma) && (a->norm != 1 || a->ln_beta), QUIPAMD_ERR_ARG,
@@ -489,6 +682,10 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
     }
     if (p == 128 && q == 64) {
         QA_REQUIRE(a->m > 0 && a->m % 16 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 16 (m = %lld)", (long long)a->m);
+        if (u && !res && a->norm == 0 && a->pair_sig && a->pair_bias && a->pair_cs && a->bs <= 2 && a->ngroups == 1 && !a->t_out) {
+            A.pair_sig = (const uint4 *)a->pair_sig; A.pair_bias = (const uint4 *)a->pair_bias; A.pair_cs = (const uint4 *)a->pair_cs;
+            return launch_pair<128, 64>(A, s);
+        }
         if (u && !res && a->norm == 0) return launch_fused<128, 64, true, false, 0, 1, 2, 1>(A, a->ngroups, s);
         if (!u && a->norm == 0) return launch_fused<128, 64, false, false, 0, 1, 2, 1>(A, a->ngroups, s);
         return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: 128 x 64 runs (U, no residual, no norm) and (no U, no norm) only");

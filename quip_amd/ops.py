@@ -359,7 +359,7 @@ class FusedGemmArgs(ctypes.Structure):
                 ("norm", ctypes.c_int), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p), ("ln_eps", ctypes.c_float),
                 ("ngroups", ctypes.c_int), ("V", Fop * 3), ("colscale", ctypes.c_void_p * 3), ("qweight", ctypes.c_void_p * 3),
                 ("scale", ctypes.c_void_p * 3), ("y", ctypes.c_void_p * 3), ("y_dtype", ctypes.c_int), ("bs", ctypes.c_int64),
-                ("m", ctypes.c_int64)]
+                ("m", ctypes.c_int64), ("pair_sig", ctypes.c_void_p), ("pair_bias", ctypes.c_void_p), ("pair_cs", ctypes.c_void_p)]
 
 
 FUSED_SHAPES = ((64, 32), (64, 64), (128, 64))
@@ -374,8 +374,33 @@ def _f16_b_frags(M):
     return F.permute(0, 2, 3, 1, 4).contiguous().reshape(-1)          # [t, S, g, j, e]: lane = 16 g + j
 
 
+def pair_tables(Uop, Vop, bias16, colscale):
+    """per-lane tables of a layer PAIR for the n = 8192 fused launch (include/quip_amd.h pair_sig / pair_bias / pair_cs): for the element
+    (a, b) of U^T's image that lane (w, lane) holds in register 4 i + reg after stage 2 -- where it goes in V's input image, and the bias
+    and 1 / s that go with it.  Uop: the previous layer's OrthoOp (applied transposed), Vop: the consumer's (forward)."""
+    p, q, dev = Uop.p, Uop.q, Uop.device
+    assert (Vop.p, Vop.q) == (p, q) and bias16.dtype == torch.float16
+    w = torch.arange(16, device=dev).view(16, 1, 1, 1)
+    lane = torch.arange(64, device=dev).view(1, 64, 1, 1)
+    i = torch.arange(2, device=dev).view(1, 1, 2, 1)
+    reg = torch.arange(4, device=dev).view(1, 1, 1, 4)
+    tile = w + 16 * i
+    bt, at = tile % (q // 16), tile // (q // 16)
+    a = 16 * at + 4 * (lane // 16) + reg
+    b = 16 * bt + lane % 16
+    posU = (a * q + b).reshape(-1)                                           # [16 * 64 * 8] in table order
+    n = p * q
+    ident = torch.arange(n, device=dev)
+    pinU = Uop._p_in.to(dev) if Uop.pin is not None else ident               # U^T's store_idx is inv_pin: element k sits at inv_pin[k] -> k = pin[pos]
+    k = pinU[posU]
+    inv_pin_V = torch.argsort(Vop._p_in.to(dev)) if Vop.pin is not None else ident
+    pv = inv_pin_V[k]                                                        # V's load_idx
+    sig = ((pv % q) * (p + 8) + pv // q).to(torch.int16).contiguous()
+    return sig, bias16.reshape(-1)[k].contiguous(), colscale.reshape(-1)[k].to(torch.float16).contiguous()
+
+
 def decode_fused_gemm(*, V, colscale, qweight, scale, y, m, bs, x=None, U=None, u_y=None, u_bias=None, u_residual=None, u_relu=False,
-                      t_out=None, norm=0, ln_gamma=None, ln_beta=None, ln_eps=0.0):
+                      t_out=None, norm=0, ln_gamma=None, ln_beta=None, ln_eps=0.0, pair=None):
     """one launch of quipamd_decode_fused_gemm.  V / colscale / qweight / scale / y: lists (1..3 groups); V, U: Fop records
     (OrthoOp.fop); 16-bit tensors fp16.  See include/quip_amd.h for the contract."""
     a = FusedGemmArgs()
@@ -408,6 +433,8 @@ def decode_fused_gemm(*, V, colscale, qweight, scale, y, m, bs, x=None, U=None, 
         a.y[i] = y[i].data_ptr()
     a.y_dtype = _DT[y[0].dtype]
     a.bs, a.m = int(bs), int(m)
+    if pair is not None:
+        a.pair_sig, a.pair_bias, a.pair_cs = (t.data_ptr() for t in pair)
     _lib.call("quipamd_decode_fused_gemm", ctypes.byref(a), _stream())
 
 

@@ -661,6 +661,13 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
         kw.update(x=x.contiguous())
     else:
         t = torch.empty((rows, d), dtype=torch.float16, device=dev) if store else None
+        if (q0.V.p, q0.V.q) == (128, 64) and len(qls) == 1 and residual is None and lnp is None and rows <= 2 and not store:
+            # n = 8192 (OPT fc1 -> fc2): the layer pair's per-lane tables turn gather + scale + scatter into one scatter (decode_fused.hip)
+            cache = q0.__dict__.setdefault('_pair_tables', {})
+            key = id(prev)
+            if key not in cache:
+                cache[key] = ops.pair_tables(prev.U, q0.V, bias16(prev), kw['colscale'][0])
+            kw.update(pair=cache[key])
         kw.update(U=prev.U.fop(True), u_y=y_prev.to(torch.float16).contiguous(), u_bias=bias16(prev),
                   u_residual=None if residual is None else residual.contiguous(), u_relu=relu, t_out=t)
     ops.decode_fused_gemm(**kw)

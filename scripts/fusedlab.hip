@@ -57,7 +57,7 @@ quipamd_fop make_fop(int p, int q)
     return o;
 }
 
-void run(const char *name, int p, int q, int64_t m, int groups, bool has_u, int norm, int bs, int ncopies, bool res = true)
+void run(const char *name, int p, int q, int64_t m, int groups, bool has_u, int norm, int bs, int ncopies, bool res = true, bool pair = false)
 {
     const int n = p * q;
     std::vector<quipamd_fused_gemm_args> args(ncopies);
@@ -70,6 +70,16 @@ void run(const char *name, int p, int q, int64_t m, int groups, bool has_u, int 
             a.u_y = dev_alloc<uint16_t>((size_t)bs * n); a.u_bias = dev_alloc<uint16_t>(n); a.u_residual = res ? dev_alloc<uint16_t>((size_t)bs * n) : nullptr;
             a.ld_residual = n; a.t_out = dev_alloc<uint16_t>((size_t)bs * n); a.ld_t = n; a.x = dev_alloc<uint16_t>((size_t)bs * n); a.ldx = n;
             a.ln_gamma = dev_alloc<uint16_t>(n); a.ln_beta = dev_alloc<uint16_t>(n);
+            if (pair) {                                      // valid LDS offsets: a permutation of the image positions
+                std::vector<uint16_t> sg(n);
+                std::vector<int> perm(n);
+                std::iota(perm.begin(), perm.end(), 0);
+                std::shuffle(perm.begin(), perm.end(), std::mt19937(3));
+                for (int i = 0; i < n; ++i) sg[i] = (uint16_t)((perm[i] % q) * (p + 8) + perm[i] / q);
+                uint16_t *d;
+                CK(hipMalloc(&d, n * 2)); CK(hipMemcpy(d, sg.data(), n * 2, hipMemcpyHostToDevice));
+                a.pair_sig = d; a.pair_bias = dev_alloc<uint16_t>(n); a.pair_cs = dev_alloc<uint16_t>(n);
+            }
             for (int g = 0; g < groups; ++g) {
                 a.V[g] = make_fop(p, q);
                 a.colscale[g] = dev_alloc<float>(n); a.scale[g] = dev_alloc<float>(1); a.y[g] = dev_alloc<uint16_t>((size_t)bs * m, false);
@@ -120,6 +130,7 @@ int main()
     run("L1 qkv (U, LN, V)", 64, 32, 2048, 3, true, 1, 1, 16);
     run("L4 fc1 (U, LN, V)", 64, 32, 8192, 1, true, 1, 1, 16);
     run("L6 fc2 (U relu, V)", 128, 64, 2048, 1, true, 0, 1, 16, false);
+    run("L6 fc2 pair kernel", 128, 64, 2048, 1, true, 0, 1, 16, false, true);
     run("llama qkv (U, RMS, V)", 64, 64, 4096, 3, true, 2, 1, 8);
     return 0;
 }

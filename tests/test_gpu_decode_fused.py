@@ -70,6 +70,7 @@ CASES = [
     (2048, 2048, 1, False, None, False, False, 2),
     (2048, 8192, 1, True, "ln", False, True, 4),
     (8192, 2048, 1, True, None, True, False, 1),
+    (8192, 2048, 1, True, None, True, False, 2),
     (8192, 2048, 1, True, None, True, False, 3),
     (4096, 4096, 3, True, "rms", False, True, 1),
     (2048, 2048, 1, True, None, False, True, 2),
@@ -116,13 +117,19 @@ def test_fused_stage_matches_the_chain_in_fp64(d, m, groups, has_u, norm, relu, 
                               relu=relu, ln=ln_mod, store=has_u, y_dtype=torch.float16)
         for a16, a32 in zip(ys16, ys):
             assert torch.equal(a16, a32.half())
-    for q, What, y in zip(qls, Whats, ys):
-        Vd = _dense(q.V)
-        xt = (h * q.inv_scaleWH.double()) @ Vd.t()
-        want = xt @ What.t()
-        y = q.from_zt(y)
-        rel = float((y.double() - want).norm() / want.norm())
-        assert rel <= 2e-3, rel
+    ys_all = [ys]
+    if d == 8192 and bs <= 2:                                # without `store` the layer-PAIR kernel runs (gather + scale + scatter folded into one scatter)
+        ys_pair, t_none = fused_stage(list(qls), prev=prev, y_prev=prev.to_zt(y_prev), residual=res, relu=relu, ln=ln_mod, store=False)
+        assert t_none is None and qls[0].__dict__.get('_pair_tables')
+        ys_all.append(ys_pair)
+    for ys_ in ys_all:
+        for q, What, y in zip(qls, Whats, ys_):
+            Vd = _dense(q.V)
+            xt = (h * q.inv_scaleWH.double()) @ Vd.t()
+            want = xt @ What.t()
+            y = q.from_zt(y)
+            rel = float((y.double() - want).norm() / want.norm())
+            assert rel <= 2e-3, rel
     torch.cuda.synchronize()
 
 
