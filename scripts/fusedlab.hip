@@ -68,7 +68,7 @@ void run(const char *name, int p, int q, int64_t m, int groups, bool has_u, int 
         if (c == 0) {
             a.U = make_fop(p, q);
             a.u_y = dev_alloc<uint16_t>((size_t)bs * n); a.u_bias = dev_alloc<uint16_t>(n); a.u_residual = res ? dev_alloc<uint16_t>((size_t)bs * n) : nullptr;
-            a.ld_residual = n; a.t_out = dev_alloc<uint16_t>((size_t)bs * n); a.ld_t = n; a.x = dev_alloc<uint16_t>((size_t)bs * n); a.ldx = n;
+            a.ld_residual = n; a.t_out = pair ? nullptr : dev_alloc<uint16_t>((size_t)bs * n); a.ld_t = n; a.x = dev_alloc<uint16_t>((size_t)bs * n); a.ldx = n;
             a.ln_gamma = dev_alloc<uint16_t>(n); a.ln_beta = dev_alloc<uint16_t>(n);
             if (pair) {                                      // valid LDS offsets: a permutation of the image positions
                 std::vector<uint16_t> sg(n);
