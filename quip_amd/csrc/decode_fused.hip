@@ -40,8 +40,16 @@ __device__ unsigned long long fg_probe_buf[32];
     do {                                                                                                              \
         if (blockIdx.x == FG_PROBE_WG && blockIdx.y == 0 && threadIdx.x == 0) fg_probe_buf[i] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+// per-wave stamps (lane 0 of every wave of the probed workgroup): slot i of wave w
+__device__ unsigned long long fg_wprobe_buf[16 * 8];
+#define FG_WSTAMP(i)                                                                                                  \
+    do {                                                                                                              \
+        if (blockIdx.x == FG_PROBE_WG && blockIdx.y == 0 && (threadIdx.x & 63) == 0)                                  \
+            fg_wprobe_buf[(threadIdx.x >> 6) * 8 + (i)] = __builtin_amdgcn_s_memtime();                               \
+    } while (0)
 #else
 #define FG_STAMP(i)
+#define FG_WSTAMP(i)
 #endif
 
 struct FGroup {                           // one packed layer of the launch (blockIdx.y): 72 bytes of kernarg, fetched together
@@ -432,6 +440,7 @@ __global__ __launch_bounds__(1024) void fused_pair_kernel(FusedArgs G, float two
     const int j = lane & 15, g = lane >> 4;
     const int bs = G.bs;
     FG_STAMP(0);
+    FG_WSTAMP(0);
 
     // ---- requests, in the order of use: the row, U's fragments | (barrier) | the pair tables, V's fragments, the weights ---------------
     uint4 yc = *reinterpret_cast<const uint4 *>(G.u_y + 8 * (uint32_t)tid);
@@ -442,7 +451,9 @@ __global__ __launch_bounds__(1024) void fused_pair_kernel(FusedArgs G, float two
     const uint4 *V0 = reinterpret_cast<const uint4 *>(V.F0), *V1 = reinterpret_cast<const uint4 *>(V.F1);
     const uint32_t t1 = tid & 511;
     const uint4 fu0 = U0[tid], fu1 = U0[tid + 1024], fu2 = U1[t1];               // (waves 8..15 load M1's entry again; they do not store it)
+    FG_WSTAMP(1);
     __syncthreads();                                                            // first-phase requests of every wave are queued before the rest
+    FG_WSTAMP(2);
     const uint4 sg = G.pair_sig[tid], pb = G.pair_bias[tid], pc = G.pair_cs[tid];
     const uint4 fv0 = V0[tid], fv1 = V0[tid + 1024], fv2 = V1[t1];
     uint4 w[CPW];
@@ -457,15 +468,19 @@ __global__ __launch_bounds__(1024) void fused_pair_kernel(FusedArgs G, float two
 
     for (int b = 0; b < bs; ++b) {
         if (b > 0) yc = *reinterpret_cast<const uint4 *>((G.u_y + (int64_t)b * N) + 8 * (uint32_t)tid);
+        FG_WSTAMP(3);
         copy_chunk_zt<P, Q>(ZT, yc, tid);
+        FG_WSTAMP(4);
         if (b == 0) {
             FRU[tid] = fu0;
             FRU[tid + 1024] = fu1;
             if (tid < 512) FRU[2048 + tid] = fu2;
         }
         FG_STAMP(1);
+        FG_WSTAMP(5);
         __syncthreads();
         FG_STAMP(2);
+        FG_WSTAMP(6);
         PassFrags<P, Q> fr;
 #pragma unroll
         for (int S = 0; S < D::S0; ++S) fr.f0[S] = FRU[(at1 * D::S0 + S) * 64 + lane];

@@ -120,6 +120,16 @@ void run(const char *name, int p, int q, int64_t m, int groups, bool has_u, int 
         printf("      %-18s %7llu  (+%llu)\n", nm[i], st[i] - st[0], st[i] - prev);
         prev = st[i];
     }
+    if (pair) {
+        unsigned long long ws[16 * 8];
+        CK(hipMemcpyFromSymbol(ws, HIP_SYMBOL(fg_wprobe_buf), sizeof(ws)));
+        printf("    per-wave stamps (cycles since wave 0's start): start | requests issued | priority barrier passed | before copy | y landed + copied | U frags landed + stored | barrier passed\n");
+        for (int w = 0; w < 16; ++w) {
+            printf("      wave %2d:", w);
+            for (int i = 0; i < 7; ++i) printf(" %7lld", (long long)(ws[w * 8 + i] - ws[0]));
+            printf("\n");
+        }
+    }
 #endif
 }
 
