@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libquip_amd.so")
+LIB_PATH = os.environ.get("QUIP_AMD_LIB") or os.path.join(_HERE, "csrc", "libquip_amd.so")     # QUIP_AMD_LIB: A / B builds in the labs
 
 c_i64, c_int, c_vp, c_double, c_float = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_float
 

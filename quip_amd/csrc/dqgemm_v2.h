@@ -118,8 +118,10 @@ __global__ __launch_bounds__(64 * NW) void dq_h_kernel(K2Args A)
     const EpiArgs &e = A.e;
     // every kernarg field in ONE scalar round trip (round 3, csrc/decode_fused.hip: hipcc fetches kernarg fields lazily, one
     // s_load + s_waitcnt per first use; this kernel opened with three serial kernarg round trips in front of its first vector load)
+#ifndef K2_NO_TOUCH
     asm volatile("" ::"s"(A.x), "s"(A.qw), "s"(A.d), "s"(e.scale), "s"(e.zero), "s"(e.bias), "s"(e.y), "s"(e.qfn), "s"(e.maxq), "s"(e.y_f32),
                  "s"(e.y_f16), "s"(e.accumulate), "s"(e.two_over_maxq), "s"(e.bs), "s"(e.m));
+#endif
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
