@@ -369,6 +369,33 @@ def main():
         except Exception as ex:                       # a side measurement must never take the headline line down
             out["sharded_ldlq"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
+    # ---- one whole transformer block of the sharded driver: calibration + Hessians + factors + rounding + re-forward (configs[4] path) ----
+    # OPT-1.3B block geometry, 64 calibration samples of 2048 tokens split over the N ranks (strong scaling: the work is fixed);
+    # every rank runs the SPMD loop of scripts/quantize_opt_sharded.py; rank 0 reports the phase split
+    if not args.no_ldlq:
+        try:
+            import importlib.util as _ilu
+            spec = _ilu.spec_from_file_location("quantize_opt_sharded", os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "quantize_opt_sharded.py"))
+            smod = _ilu.module_from_spec(spec)
+            spec.loader.exec_module(smod)
+            sargv = ["--hidden", "2048", "--ffn", "8192", "--heads", "32", "--layers", "1", "--nsamples", "64", "--seqlen", "2048", "--vocab", "4096", "--incoh",
+                     "--quiet"]
+            smod.main(sargv)                                    # warm-up (kernels, allocator, RCCL channels)
+            barrier()
+            sres = smod.main(sargv)
+            barrier()
+            if rank == 0:
+                ph = sres["phase_seconds_rank0"]
+                serial = ph["owner_preproc_factor_s"]
+                par = ph["forward_hessian_s"] + ph["round_s"] + ph["reforward_s"]
+                out["sharded_block"] = {"what": f"one OPT-1.3B-geometry block, LDLQ w{BITS} + incoherence processing, 64 x 2048 calibration tokens over {world} rank(s): "
+                                                "own samples -> K7 partial Hessians -> all-reduce -> owner preproc + LDL factors -> row-sharded K4 -> "
+                                                "weight broadcast -> re-forward (scripts/quantize_opt_sharded.py --calibration sharded)",
+                                        "wall_s": sres["wall_s"], "phase_seconds_rank0": ph, "scaling": "strong",
+                                        "amdahl_note": f"owner-only phases {serial:.3f} s of {serial + par:.3f} s measured here on rank 0's share"}
+        except Exception as ex:
+            out["sharded_block"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
     # ---- K7 Hessian accumulation: one add_batch call at the OPT-1.3B fc2 input shape -----------------
     if rank == 0 and world == 1 and not args.no_ldlq:
         try:

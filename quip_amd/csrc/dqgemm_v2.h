@@ -116,13 +116,10 @@ __global__ __launch_bounds__(64 * NW) void dq_h_kernel(K2Args A)
     static_assert(RT * 1024 + 64 <= NCH * XB, "a wave parks its partials in its own slab region");
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [NW][NCH] slabs; a wave parks its partials in its own
     const EpiArgs &e = A.e;
-    // every kernarg field in ONE scalar round trip (round 3, csrc/decode_fused.hip: hipcc fetches kernarg fields lazily, one
-    // s_load + s_waitcnt per first use; this kernel opened with three serial kernarg round trips in front of its first vector load)
-#ifndef K2_NO_TOUCH
-    asm volatile("" ::"s"(A.x), "s"(A.qw), "s"(A.d), "s"(e.scale), "s"(e.zero), "s"(e.bias), "s"(e.y), "s"(e.qfn), "s"(e.maxq), "s"(e.y_f32),
-                 "s"(e.y_f16), "s"(e.accumulate), "s"(e.two_over_maxq), "s"(e.bs), "s"(e.m));
-#endif
-
+    // (round 3, negative result, scripts/k2_ab.sh on one box, alternating runs: fetching every kernarg field in ONE scalar round trip
+    //  up front -- the fix that took 2000 cycles off the prologue of csrc/decode_fused.hip -- makes THIS kernel 0.13 us slower, 5.13 vs
+    //  4.98 us at K = 20 and 4.92 vs 4.79 at K = 2000: its lazily fetched fields already let the weight loads go out after the first
+    //  two s_loads, and waiting for all fifteen delays them)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     K2_STAMP(0);

@@ -194,8 +194,9 @@ class ShardedLDLQ:
     """Owner-side handle used by vector_balance.quantize_weight_vecbal when a process group with more than one
     rank is active: announces a job to the ranks parked in serve(), then joins the collective itself."""
 
-    def __init__(self, group=None, src=0, compute=None, force_exchange=False):
-        self.group, self.src, self.compute, self.force_exchange = group, src, compute, force_exchange
+    def __init__(self, group=None, src=0, compute=None, force_exchange=False, spmd=False):
+        """spmd=True: every rank runs the same driver loop and joins each collective by itself (worker_round): no job announcements"""
+        self.group, self.src, self.compute, self.force_exchange, self.spmd = group, src, compute, force_exchange, spmd
         self._lt_ready = None      # (key, (LT, work)): the coming job's LT, already broadcast under the previous job's rounding
         self._queue = []           # [(key, LT)] of the coming round() calls, in call order (queue_LTs)
         self.desyncs = 0           # how often a round() call did not match the head of the queue (the queue is dropped then)
@@ -220,7 +221,7 @@ class ShardedLDLQ:
         return bool(self._queue) and (key is None or self._queue[0][0] == key)
 
     def round(self, wgrid, LT, bits, eta=None, key=None):
-        if dist.get_world_size(self.group) > 1:
+        if dist.get_world_size(self.group) > 1 and not self.spmd:
             self._announce(_OP_LDLQ)
         ready = None
         if self._queue and self._queue[0][0] == key and key is not None:
@@ -243,7 +244,7 @@ class ShardedLDLQ:
         return out
 
     def shutdown(self):
-        if dist.get_world_size(self.group) > 1:
+        if dist.get_world_size(self.group) > 1 and not self.spmd:
             self._announce(_OP_STOP)
 
 
@@ -260,6 +261,33 @@ def serve(group=None, src=0, compute=None):
         out = ldlq_round_sharded(None, None, 0, src=src, group=group, compute=compute, lt_ready=ready, next_LT=True)
         ready = out[1] if isinstance(out, tuple) else None           # a prefetched LT for the next job, if the owner sent one
         jobs += 1
+
+
+def worker_round(ready=None, group=None, src=0, compute=None):
+    """SPMD counterpart of ShardedLDLQ.round on every rank but the owner: join ONE rounding job (the header broadcast by the owner says
+    what it is).  `ready`: what the previous call returned -- the LT the owner prefetched for this job, or None.  Returns the `ready`
+    for the next call."""
+    out = ldlq_round_sharded(None, None, 0, src=src, group=group, compute=compute, lt_ready=ready, next_LT=True)
+    return out[1] if isinstance(out, tuple) else None
+
+
+def broadcast_weights(layers, group=None, src=0):
+    """the quantised weights of a block's Linears from the owner to every rank (each rank re-forwards its own calibration samples
+    through the quantised block: opt.py:172-174 on N GPUs).  `layers`: nn.Linear modules in the same order on every rank; on the
+    owner `weight.data` is what fasterquant left there (a NEW fp16 tensor on the Balance path), elsewhere the stale copy it replaces.
+    Returns the bytes sent per receiving rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    dev = _comm_device(group)
+    nbytes = 0
+    for lin in layers:
+        w = lin.weight.data
+        buf = w if (w.device == dev and w.is_contiguous()) else w.to(dev).contiguous()
+        dist.broadcast(buf, src=src, group=group)
+        if buf is not w:
+            lin.weight.data.copy_(buf)
+        nbytes += buf.numel() * buf.element_size()
+    return nbytes
 
 
 # ------------------------------------------------------------------------------------- calibration-sample sharding

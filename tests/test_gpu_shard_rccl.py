@@ -80,3 +80,11 @@ def test_sharded_driver_script_one_rank(nccl_group):
     assert a["linears"] == b["linears"] == 12
     assert a["bytes_broadcast_LT"] > 0 and a["bytes_broadcast_next_LT"] > 0 and b["bytes_broadcast_LT"] == 0
     assert abs(a["mean_proxy_error"] - b["mean_proxy_error"]) <= 1e-6 * abs(b["mean_proxy_error"])
+    # sample-sharded calibration (SPMD loop: own samples -> partial Hessians -> all-reduce -> owner factors -> row-sharded rounding ->
+    # weight broadcast -> re-forward) against the round-2 owner-only loop: with one rank the summation orders coincide, so every
+    # per-Linear proxy error is the SAME number; the phase split is reported
+    c = mod.main(argv + ["--force-exchange", "--calibration", "owner"])
+    assert a["calibration"] == "sharded" and c["calibration"] == "owner" and a["errors"] == c["errors"]
+    ph = a["phase_seconds_rank0"]
+    assert set(ph) == {"forward_hessian_s", "allreduce_s", "owner_preproc_factor_s", "round_s", "broadcast_weights_s", "reforward_s"}
+    assert ph["forward_hessian_s"] > 0 and ph["round_s"] > 0

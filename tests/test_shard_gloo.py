@@ -80,6 +80,33 @@ def _worker(rank, world, port, m, d, bits, use_eta, mode, out_path):
             else:
                 assert shard.serve(compute=_oracle_compute) == 7
                 got = None
+        elif mode == "spmd":
+            # every rank runs the same driver loop (scripts/quantize_opt_sharded.py --calibration sharded): no job announcements; the
+            # owner rounds through ShardedLDLQ(spmd=True) with its queued LTs, the other rank joins each job with worker_round; then the
+            # owner's quantised weights are broadcast so that every rank can re-forward its own calibration samples
+            W2, LT2, _ = _fixture(m, d // 2, seed=6)
+            lins = [torch.nn.Linear(d, m, bias=False).half(), torch.nn.Linear(d // 2, m, bias=False).half()]
+            if rank == 0:
+                h = shard.ShardedLDLQ(compute=_oracle_compute, spmd=True)
+                H1, H2 = torch.zeros(2, 2), torch.zeros(2, 2)
+                h.queue_LTs([(H1, LT), (H2, LT2)])
+                got = h.round(W, None, bits, eta=eta, key=shard.h_key(H1))
+                got2 = h.round(W2, None, bits, key=shard.h_key(H2))
+                assert shard.last_stats["bytes_broadcast_LT"] == 0     # LT2 travelled under job 1
+                assert torch.equal(got2, _oracle_compute(W2, LT2, bits, None))
+                lins[0].weight.data = got.to(torch.float16)             # what fasterquant leaves behind: a NEW tensor on the owner
+                lins[1].weight.data = got2.to(torch.float16)
+                h.shutdown()                                            # spmd: nothing is announced
+            else:
+                ready = shard.worker_round(None, compute=_oracle_compute)
+                assert ready is not None                                # the owner prefetched LT2
+                assert shard.worker_round(ready, compute=_oracle_compute) is None
+                got = None
+            nbytes = shard.broadcast_weights(lins)
+            assert nbytes == 2 * (m * d + m * (d // 2))
+            want_w = _oracle_compute(W, LT, bits, eta).to(torch.float16)
+            assert torch.equal(lins[0].weight.data, want_w)            # every rank now holds the owner's quantised weights
+            assert torch.equal(lins[1].weight.data, _oracle_compute(W2, LT2, bits, None).to(torch.float16))
         elif mode == "collective":
             got = shard.ldlq_round_sharded(W if rank == 0 else None, LT if rank == 0 else None, bits,
                                            eta=eta if rank == 0 else None, compute=_oracle_compute)
@@ -103,7 +130,7 @@ def _worker(rank, world, port, m, d, bits, use_eta, mode, out_path):
 
 @pytest.mark.parametrize("m,d,bits,use_eta,mode", [(96, 128, 2, False, "collective"), (40, 128, 4, True, "collective"),
                                                     (16, 64, 2, False, "collective"), (70, 128, 2, True, "serve"),
-                                                    (48, 128, 2, False, "queue")])
+                                                    (48, 128, 2, False, "queue"), (64, 128, 2, True, "spmd")])
 def test_sharded_ldlq_matches_unsharded(tmp_path, m, d, bits, use_eta, mode):
     out = str(tmp_path / "res.pt")
     mp.spawn(_worker, args=(2, _free_port(), m, d, bits, use_eta, mode, out), nprocs=2, join=True)
