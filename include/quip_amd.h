@@ -128,7 +128,9 @@ int quipamd_vecquant4matmul(const float *vec, const int32_t *mat, float *mul, co
  * benchmarks and the forced-kernel parity tests; never needed for correctness.  cfg = int32[4] {family, p1, p2, 0}
  * (NULL or all 0 = heuristic): family 1 = round-1 kernels; 2 = "h" (bs <= 16, d <= 4096: p1 = waves, p2 = chunks per
  * wave); 3 = "s" (bs <= 16 weight stream: p1 = row tiles per workgroup, p2 = k-split); 4 = "mb" (bs > 16: p1 = 44 | 22,
- * the tile shape).  An unsupported combination fails with QUIPAMD_ERR_UNSUPPORTED.  Per call, thread safe. */
+ * the tile shape); 5 = "pf" (prefill: every 2-bit tile dequantised ONCE per workgroup into LDS, 32x32x16 MFMA mainloop; 2-bit qfn b,
+ * m % 256 == 0, d % 256 == 0: p1 = 21 (256 x 128 tile) | 22 (256 x 256)) -- the heuristic's choice from 256 batch rows on.
+ * An unsupported combination fails with QUIPAMD_ERR_UNSUPPORTED.  Per call, thread safe. */
 int quipamd_dequant_gemm_cfg(const void *x, int x_dtype, const int32_t *qweight, int bits, int layout, int qfn,
                              const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
                              int accumulate, int64_t bs, int64_t m, int64_t d, const int32_t *cfg, void *stream);

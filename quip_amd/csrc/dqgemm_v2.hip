@@ -80,6 +80,10 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
 int k2v2_launch(const K2Call &c, void *stream)
 {
     if (c.cfg[0] == K2_FAM_OLD) return K2V2_NOT_TAKEN;
+    // prefill-sized batches: every 2-bit tile dequantised once per workgroup (dqgemm_pf.hip).  From 256 batch rows on, when the grid
+    // of 256 x 128 tiles is at least half a round of the 256 CUs.
+    if (c.cfg[0] == K2_FAM_PF) return k2pf_launch(c, stream);
+    if (c.cfg[0] == K2_FAM_AUTO && c.bs >= 256 && k2pf_supported(c) && (c.m / 256) * ((c.bs + 127) / 128) >= 128) return k2pf_launch(c, stream);
     K2Args A;
     A.x = (const uint16_t *)c.x; A.qw = (const u32x4 *)c.qweight; A.d = c.d;
     EpiArgs &e = A.e;

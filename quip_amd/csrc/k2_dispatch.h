@@ -2,7 +2,7 @@
 #pragma once
 #include <stdint.h>
 
-enum { K2_FAM_AUTO = 0, K2_FAM_OLD = 1, K2_FAM_H = 2, K2_FAM_S = 3, K2_FAM_MB = 4, K2_FAM_NONE = 99 };
+enum { K2_FAM_AUTO = 0, K2_FAM_OLD = 1, K2_FAM_H = 2, K2_FAM_S = 3, K2_FAM_MB = 4, K2_FAM_PF = 5, K2_FAM_NONE = 99 };
 enum { K2V2_NOT_TAKEN = -1 };
 
 struct K2Call {
@@ -17,3 +17,7 @@ struct K2Call {
 
 // returns K2V2_NOT_TAKEN (use the round-1 kernels), QUIPAMD_OK, or an error status
 int k2v2_launch(const K2Call &c, void *stream);
+
+// dqgemm_pf.hip: the prefill kernel (weights dequantised once per workgroup into LDS, 32x32x16 MFMA mainloop); 2-bit qfn b only
+bool k2pf_supported(const K2Call &c);
+int k2pf_launch(const K2Call &c, void *stream);
