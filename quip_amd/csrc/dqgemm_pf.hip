@@ -13,6 +13,17 @@
 //   * sum_k x[b,k] for the offset term falls out of the B fragments the row-half-0 waves read anyway (v_dot2 against ones);
 //   * D[m][n = batch]: a lane holds 4 consecutive output features of one batch row per register quad -> 8-byte stores.
 // qfn b, 2-bit, m % TM == 0, d % 256 == 0; any bs (rows past bs read as zeros and are not stored).
+//
+// STATUS (round 3, profiles/r03t_k2_prefill.jsonl): correct (tests/test_gpu_dqgemm_v2.py) and SLOWER than the mb kernel it was meant to
+// replace -- 686 / 697 / 802 TFLOP/s at 4096^2 x 2048, 28672 x 7168 x 256, 8192^2 x 1024 against 924 / 938 / 1114 (dense bf16 rocBLAS on
+// the same box: 1058 / 825 / 1252, i.e. 0.33 - 0.50 of the 2.5 PF peak itself at these shapes) -- so the heuristic never picks it
+// (family 5 by cfg only).  Why: a 256 x 128 tile needs 128 + 146 registers per lane, i.e. ONE wave per SIMD (and LDS bandwidth rules
+// out smaller per-wave tiles: 64 x 64 per wave would read 256 B/clk/CU of fragments); with one wave per SIMD nothing overlaps the
+// MFMAs but the wave's own instruction stream, and hipcc schedules the step as  [fragment reads -> wait -> 8 MFMAs] x 4, then
+// [global wait -> 12 ds_write_b128 + 64 dequant VALU], then the barrier: ~3700 cycles per 64-column step for 1024 cycles of matrix
+// pipe.  The mb kernel hides the same work behind two loader waves and eight compute waves of 4 x 4 16x16x32 tiles.  What would
+// be needed here is the interleave Tensile's assembly kernels have (staging instructions placed between the MFMAs of the previous
+// step) -- ~4.5 fillers per MFMA at this tile, at the edge of what one wave per SIMD can hide (MI355X_MICROARCH.md: <= 5 per gap).
 #include "common.h"
 #include "dq_common.h"
 #include "k2_dispatch.h"

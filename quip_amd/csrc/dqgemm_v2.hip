@@ -80,10 +80,10 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
 int k2v2_launch(const K2Call &c, void *stream)
 {
     if (c.cfg[0] == K2_FAM_OLD) return K2V2_NOT_TAKEN;
-    // prefill-sized batches: every 2-bit tile dequantised once per workgroup (dqgemm_pf.hip).  From 256 batch rows on, when the grid
-    // of 256 x 128 tiles is at least half a round of the 256 CUs.
+    // dqgemm_pf.hip (every 2-bit tile dequantised once per workgroup into LDS, 32x32x16 mainloop) runs only when forced: measured
+    // SLOWER than the mb kernel at every prefill shape (profiles/r03t_k2_prefill.jsonl: 686 vs 924 TFLOP/s at 4096^2 x 2048, 697 vs 938 at
+    // 28672 x 7168 x 256; dense bf16 rocBLAS 1058 / 825) -- see the header of that file for why.
     if (c.cfg[0] == K2_FAM_PF) return k2pf_launch(c, stream);
-    if (c.cfg[0] == K2_FAM_AUTO && c.bs >= 256 && k2pf_supported(c) && (c.m / 256) * ((c.bs + 127) / 128) >= 128) return k2pf_launch(c, stream);
     K2Args A;
     A.x = (const uint16_t *)c.x; A.qw = (const u32x4 *)c.qweight; A.d = c.d;
     EpiArgs &e = A.e;
