@@ -449,8 +449,8 @@ def main():
                          "ms_per_token": round(dres[best]["ms_per_token_median"], 3),
                          "variant": best,
                          "what": "v3 = csrc/decode_fused.hip: U^T(prev) + residual -> LayerNorm -> V -> 2-bit GEMM in ONE launch per packed "
-                                 "layer group (fp16 operator pass in the GEMM prologue), + tiled U^T of q/k/v + single-launch decode "
-                                 "attention: 6 launches per block; the round-2 variants (9-13 launches) timed beside it: " +
+                                 "layer group (fp16 operator pass in the GEMM prologue), + decode attention with the U^T of q/k/v in "
+                                 "its prologue: 5 launches per block; the round-2 variants (9-13 launches) timed beside it: " +
                                  ", ".join(f"{k[10:]} {dres[k]['tok_per_s']:.0f}" for k in cands),
                          "chained_10_launch_tok_per_s": round(dres["packed_w2_chained"]["tok_per_s"], 1),
                          "unchained_tok_per_s": round(dres["packed_w2_fused_attn"]["tok_per_s"], 1),
