@@ -315,6 +315,9 @@ typedef struct quipamd_fused_gemm_args {
      * pair_bias fp16 = u_bias[k];  pair_cs fp16 = colscale[0][k].  With them the gather / scale / scatter between the two operators is
      * one scatter in the epilogue of U's stage 2 (U.store_idx, V[0].load_idx, u_bias and colscale[0] are then not read). */
     const void *pair_sig, *pair_bias, *pair_cs;
+    /* dtype of u_y: QUIPAMD_F16, or QUIPAMD_F32 -- the fp32 accumulator of quipamd_decode_bigp_v_gemm, rounded to fp16 on load (what a
+     * cast launch in between would do); fp32 has a kernel for 64 x 64 with residual and RMSNorm (Llama's down_proj -> q / k / v) only. */
+    int u_y_dtype;
 } quipamd_fused_gemm_args;
 int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *args, void *stream);
 
@@ -333,6 +336,53 @@ int quipamd_decode_attention_fused(const quipamd_fop *U, const void *const *y, c
  * residual fp16 [bs, ld_residual] or NULL; out fp16 [bs, ld_out], not aliasing the residual. */
 int quipamd_decode_u_only(const quipamd_fop *U, const void *y, const void *bias, const void *residual, int64_t ld_residual, int relu,
                           void *out, int64_t ld_out, int64_t bs, void *stream);
+
+/* ---- decode around a packed layer whose operator is p x 16 with a LARGE p (csrc/decode_bigp.hip; Llama's 11008 = 688 x 16,
+ * method.py:16-18 butterfly_factors): the MLP tail of llama.py:418-471's loop,  down_proj(silu(gate_proj(x)) * up_proj(x)), as two launches.
+ * Both take their input vector as the TRANSPOSED image, row-major: index b * p + a holds image position (a, b) -- for an output-side
+ * operator that is the "ZT order" the producing GEMM's rows are packed in (see quipamd_fused_gemm_args), for the activation-side
+ * operator it is what quipamd_decode_bigp_u writes through `dest`.  Factors: F0 = M0 [p][p] as fp16 MFMA B fragments with the k index
+ * zero padded to ks = ceil(p / 32) steps:  F0[((at * ks + S) * 64 + lane) * 8 + e] = M0[16 at + lane % 16][32 S + 8 (lane / 16) + e]
+ * (0 where the column index >= p);  M1 = float [16][16];  result image = M0 z M1^T.  Rows (batch) 1..4; p % 16 == 0, 64 <= p <= 1024.
+ *
+ * quipamd_decode_bigp_u: for every operator i (<= 3; gate and up in one launch)
+ *       out_i[r][dest_i[pos]] = fp16( ((M0 z M1^T)[pos] + bias_img_i[pos]) * post_img_i[pos] )        pos = a * 16 + b
+ *   y: fp16 [rows, n] transposed image; bias_img (fp16 [n]) / post_img (float [n]) in IMAGE order or NULL; dest: uint16 [n], any map
+ *   (the host composes the operator's own store permutation with the consumer's layout).  `clear` (NULL or a 16-byte aligned float
+ *   buffer of clear_n floats, clear_n % 4 == 0) is zeroed by the launch: the accumulator of the quipamd_decode_bigp_v_gemm that follows.
+ * quipamd_decode_bigp_v_gemm:  t = silu(gate) * up  (up NULL: t = gate), rounded to fp16 like the two torch launches it replaces;
+ *       x~ = M0 t M1^T (fp16, image order);   y[r][:] += scale * (2 / 3) * (codes - 1.5) x~        2-bit qfn-b STREAM codes [m, n]
+ *   with the COLUMNS of the codes in image order of the operator (column a * 16 + b multiplies x~ at image position (a, b)).
+ *   One workgroup per (16 image rows = 256 columns, 256 * row_tiles_per_wave rows); the K-slices are ADDED into y (float [rows, m])
+ *   with fp32 atomics: y must be zero (or hold what is to be accumulated onto) on entry, and the summation order is not fixed
+ *   (results differ in the last bits from run to run).  m % 256 == 0; row_tiles_per_wave 0 (choose) / 1 / 2 / 4. */
+typedef struct quipamd_bigp_u_op {
+    const void *F0;
+    const float *M1;
+    const void *y;
+    const void *bias_img;
+    const float *post_img;
+    const uint16_t *dest;
+    void *out;
+    int64_t ld_out;
+} quipamd_bigp_u_op;
+typedef struct quipamd_bigp_v_gemm_args {
+    const void *F0;
+    const float *M1;
+    const void *gate, *up;           /* fp16 [rows, ldx] */
+    int64_t ldx;
+    const void *qweight;
+    const float *scale;              /* float [1] */
+    int bits;                        /* 2 */
+    float *y;
+    int64_t m;
+    int p;
+    int64_t rows;
+    int row_tiles_per_wave;
+} quipamd_bigp_v_gemm_args;
+int quipamd_decode_bigp_supported(int p, int q);
+int quipamd_decode_bigp_u(const quipamd_bigp_u_op *ops, int nops, int p, int64_t rows, float *clear, int64_t clear_n, void *stream);
+int quipamd_decode_bigp_v_gemm(const quipamd_bigp_v_gemm_args *args, void *stream);
 
 /* Greedy token of a decode step: out[r] = argmax_i x[r, i] (int64, DEVICE), the smallest index among equal maxima like torch.argmax;
  * x: [rows, n] f32 / f16 / bf16 with row stride ld.  One workgroup per row (benchmark(), opt.py:463-480 picks the next token this way). */

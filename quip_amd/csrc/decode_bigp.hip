@@ -1,0 +1,384 @@
+// decode_bigp.hip -- the decode step around a packed layer whose Kronecker operator is p x 16 with a LARGE p: Llama's intermediate size
+// 11008 = 688 x 16 (method.py:16-18 butterfly_factors), i.e. the MLP tail of llama.py:418-471's benchmark() loop
+//     g = U_gate^T y_gate,  u = U_up^T y_up,   t = silu(g) * u (/) s_down,   x~ = V_down t,   y_down = What_down x~.
+// A 688 x 688 factor is 0.95 MB in fp16: not a workgroup's pass, so the two operators are cut where they are all-to-all (the mix over
+// the p index) and nowhere else.  Round 2 ran this tail as four launches (ortho_bigp.hip twice at ~10 us -- fp32 factors, int32 index
+// vectors and a 2-/4-byte LDS scatter of the whole row in EVERY workgroup --, the bf16 tile GEMM at 8.6 us, a cast); here it is two:
+//
+//   bigp_u_kernel       grid (p / 16, layers):  out[dest[pos]] = ((M0 z M1^T)[pos] + bias[pos]) * post[pos]     for pos in 16 image rows
+//   bigp_v_gemm_kernel  grid (p / 16, row groups):  x~[16 image rows] = M0 silu(g) * u M1^T  ->  y += What[rows, those 256 columns] x~
+//
+// What makes them short:
+//   * the vector a pass starts from arrives as the TRANSPOSED image, row-major (index b * p + a): the producing GEMM has its rows
+//     packed in that order (include/quip_amd.h "permutations folded into the packing"), bigp_u writes its output through a uint16
+//     table the host composes from U's store permutation and V_down's load permutation.  A lane's A fragment of the mix over a is then
+//     ONE 16-byte global load (8 consecutive a of one b) -- no index vector, no LDS image, no scatter;
+//   * the factor rows of the workgroup's 16 outputs come as fp16 MFMA B fragments (host order, zero padded to 32-deep steps):
+//     22 KiB per workgroup at p = 688, one 16-byte load per lane per step; v_mfma_f32_16x16x32_f16, K = p split over the waves (two
+//     steps each), the partial tiles meet in LDS as float4 per lane;
+//   * q = 16 is one tile: the reduced tile IS the B operand of the second mix (four v_mfma_f32_16x16x4_f32 against M1, fp32);
+//   * everything is requested in the first instructions of the kernel, weights last (in-order vmcnt, see decode_fused.hip);
+//   * bigp_v_gemm: a workgroup's 16 image rows are 256 consecutive columns of the packed matrix (columns in image order) = one STREAM
+//     chunk of every row tile, so the operator output goes straight into the 2-bit GEMM of that K-slice; the K-slices meet in y
+//     through fp32 atomics (64 consecutive floats per instruction).  y must be ZERO on entry: bigp_u clears it (`clear`) -- it runs
+//     between y's previous reader and this launch.
+// Rows (batch) <= 4, compile-time.
+#include "common.h"
+#include "dq_common.h"
+#include "fpass.h"
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+constexpr int BG_MAXG = 3, BG_MAXBS = 4, BG_MAXKS = 32;
+
+struct BUOp {
+    const uint4 *F0;              // [p/16][ks][64] B fragments of M0 (fp16, zero for a >= p)
+    const float *M1;              // [16][16]: z2 = M0 z M1^T
+    const uint16_t *y;            // f16 [bs][n] transposed image (b p + a)
+    const uint16_t *bias;         // f16 [n] image order, or null
+    const float *post;            // f32 [n] image order, or null
+    const uint16_t *dest;         // [n] image position -> output index
+    uint16_t *out;                // f16 [bs][ldo]
+    int64_t ldo;
+};
+struct BUArgs {
+    BUOp op[BG_MAXG];
+    float *clear;
+    int64_t clear_n4;             // float4 count
+    int p, ks;
+};
+
+// reduced partial tiles -> T (in the lane's D registers: b = 4g + s, a' = j) -> z2[a' = j][b' = 4g + reg] = sum_b T[a'][b] M1[b'][b]:
+// D[row = b'][col = a'], A = M1 rows (lane j = b', k = b), B = T (lane j = a', k = b) -- k = 4g + s over the four instructions
+__device__ __forceinline__ f32x4_t bg_mix_b(const f32x4_t &T, const float4 &m1)
+{
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(m1.x, T[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(m1.y, T[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(m1.z, T[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(m1.w, T[3], acc, 0, 0, 0);
+    return acc;
+}
+
+template <int BS>
+__global__ __launch_bounds__(1024) void bigp_u_kernel(BUArgs G)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *part = reinterpret_cast<float4 *>(smem);                            // [BS][nw][64]
+    const BUOp &O = G.op[blockIdx.y];
+    asm volatile("" ::"s"(O.F0), "s"(O.M1), "s"(O.y), "s"(O.bias), "s"(O.post), "s"(O.dest), "s"(O.out), "s"(O.ldo), "s"(G.p), "s"(G.ks),
+                 "s"(G.clear), "s"(G.clear_n4));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int at = blockIdx.x, p = G.p, ks = G.ks;
+    const int nw = (ks + 1) >> 1;                                               // waves that run the mix over a (the block has max(nw, BS) waves)
+    const bool mixer = wave < nw;
+    const int64_t n = (int64_t)p * 16;
+
+    // ---- requests: the row's A fragments, the factor fragments, then what the finishing waves need ------------------------------------
+    const int S0 = 2 * wave, S1 = 2 * wave + 1;
+    const bool two = S1 < ks;
+    int ka0 = 32 * S0 + 8 * g, ka1 = 32 * S1 + 8 * g;
+    ka0 = ka0 < p ? ka0 : 0;                                                    // (the factor fragment is zero there; any finite value of the row serves)
+    ka1 = ka1 < p ? ka1 : 0;
+    uint4 ya[BS][2], fb[2];
+    fb[0] = fb[1] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int r = 0; r < BS; ++r) ya[r][0] = ya[r][1] = make_uint4(0u, 0u, 0u, 0u);
+    if (mixer) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+            const uint16_t *row = O.y + r * n + (uint32_t)(j * p);
+            ya[r][0] = *reinterpret_cast<const uint4 *>(row + ka0);
+            ya[r][1] = *reinterpret_cast<const uint4 *>(row + ka1);
+        }
+        fb[0] = O.F0[(uint32_t)((at * ks + S0) * 64 + lane)];
+        fb[1] = O.F0[(uint32_t)((at * ks + (two ? S1 : S0)) * 64 + lane)];
+    }
+    const uint32_t pos0 = (uint32_t)((16 * at + j) * 16 + 4 * g);              // this lane's 4 results: image positions pos0 .. pos0 + 3
+    float4 m1 = make_float4(0.f, 0.f, 0.f, 0.f), po = make_float4(1.f, 1.f, 1.f, 1.f);
+    uint2 bi = make_uint2(0u, 0u), de = make_uint2(0u, 0u);
+    if (wave < BS) {
+        m1 = *reinterpret_cast<const float4 *>(O.M1 + j * 16 + 4 * g);
+        de = *reinterpret_cast<const uint2 *>(O.dest + pos0);
+        if (O.bias) bi = *reinterpret_cast<const uint2 *>(O.bias + pos0);
+        if (O.post) po = *reinterpret_cast<const float4 *>(O.post + pos0);
+    }
+    if (G.clear && blockIdx.x == 0 && blockIdx.y == 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t i = tid; i < G.clear_n4; i += blockDim.x) reinterpret_cast<float4 *>(G.clear)[i] = z;
+    }
+    if (!two) fb[1] = make_uint4(0u, 0u, 0u, 0u);
+
+    // ---- mix over a: D[row = b][col = a'] = sum_a zT[b][a] M0[a'][a], this wave's two 32-deep steps --------------------------------------
+    if (mixer) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            acc = ActF16::mfma(u32x4{ya[r][0].x, ya[r][0].y, ya[r][0].z, ya[r][0].w}, u32x4{fb[0].x, fb[0].y, fb[0].z, fb[0].w}, acc);
+            acc = ActF16::mfma(u32x4{ya[r][1].x, ya[r][1].y, ya[r][1].z, ya[r][1].w}, u32x4{fb[1].x, fb[1].y, fb[1].z, fb[1].w}, acc);
+            part[(r * nw + wave) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+    __syncthreads();
+    if (wave >= BS) return;
+    const int r = wave;
+    f32x4_t T = {0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < nw; ++w) {
+        const float4 v = part[(r * nw + w) * 64 + lane];
+        T[0] += v.x; T[1] += v.y; T[2] += v.z; T[3] += v.w;
+    }
+    const f32x4_t z2 = bg_mix_b(T, m1);
+    const float4 bb = f16x4_to_f32(bi);
+    uint16_t *o = O.out + r * O.ldo;
+    o[de.x & 0xffff] = f32_to_f16_bits((z2[0] + bb.x) * po.x);
+    o[de.x >> 16] = f32_to_f16_bits((z2[1] + bb.y) * po.y);
+    o[de.y & 0xffff] = f32_to_f16_bits((z2[2] + bb.z) * po.z);
+    o[de.y >> 16] = f32_to_f16_bits((z2[3] + bb.w) * po.w);
+}
+
+struct BVArgs {
+    const uint4 *F0;              // V's M0 as B fragments
+    const float *M1;
+    const uint16_t *gate, *up;    // f16 [bs][ldx] transposed image of V's input (GATE: t = silu(gate) * up, else t = gate)
+    int64_t ldx;
+    const uint4 *qw;              // 2-bit STREAM codes, columns in image order of V
+    const float *scale;
+    float *y;                     // fp32 [bs][m], accumulated
+    int64_t m;
+    int p, ks;
+};
+
+__device__ __forceinline__ uint32_t bg_gate2(uint32_t g2, uint32_t u2)
+{
+    // silu(g) * up, rounded to f16 like the two torch launches it replaces (F.silu rounds, then the product rounds)
+    auto one = [](float gv, float uv) {
+        const float sl = f16_bits_to_f32(f32_to_f16_bits(gv / (1.f + __expf(-gv))));
+        return sl * uv;
+    };
+    return pack_f16x2(one(f16_bits_to_f32(g2 & 0xffff), f16_bits_to_f32(u2 & 0xffff)), one(f16_bits_to_f32(g2 >> 16), f16_bits_to_f32(u2 >> 16)));
+}
+
+// grid = (p / 16 K-slices, m / (256 NRT) row groups); 1024 threads: wave w owns row tiles (16 blockIdx.y + w) NRT + k of the K-slice
+template <int BS, int NRT, bool GATE>
+__global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_over_maxq, float c0)
+{
+    typedef DeqT<2, ActF16> DQ;
+    constexpr int XTS = 256 + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t *XT = reinterpret_cast<uint16_t *>(smem);                          // [4][256 + 8] f16: x~ of the slice, k = 16 a_local + b
+    float *red = reinterpret_cast<float *>(smem + BG_MAXBS * XTS * 2);           // [4] sum x~
+    float *park = red + 4;                                                      // [16 waves][NRT][4][16]
+    float4 *part = reinterpret_cast<float4 *>(park + 16 * NRT * 64);            // [BS][nwp][64]
+    asm volatile("" ::"s"(G.F0), "s"(G.M1), "s"(G.gate), "s"(G.up), "s"(G.ldx), "s"(G.qw), "s"(G.scale), "s"(G.y), "s"(G.m), "s"(G.p), "s"(G.ks));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int at = blockIdx.x, p = G.p, ks = G.ks, nch = p >> 4;
+    const int nwp = (ks + 1) >> 1;                                              // waves that run the mix over a
+    const uint32_t rt0 = (blockIdx.y * 16 + wave) * NRT;
+
+    const int S0 = 2 * wave, S1 = 2 * wave + 1;
+    const bool mixer = wave < nwp, two = S1 < ks;
+    int ka0 = 32 * S0 + 8 * g, ka1 = 32 * S1 + 8 * g;
+    ka0 = ka0 < p ? ka0 : 0;
+    ka1 = ka1 < p ? ka1 : 0;
+    uint4 ga[BS][2], ua[BS][2], fb[2];
+    fb[0] = fb[1] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int r = 0; r < BS; ++r) ga[r][0] = ga[r][1] = ua[r][0] = ua[r][1] = make_uint4(0u, 0u, 0u, 0u);
+    if (mixer) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+            const uint16_t *grow = G.gate + r * G.ldx + (uint32_t)(j * p);
+            ga[r][0] = *reinterpret_cast<const uint4 *>(grow + ka0);
+            ga[r][1] = *reinterpret_cast<const uint4 *>(grow + ka1);
+            if (GATE) {
+                const uint16_t *urow = G.up + r * G.ldx + (uint32_t)(j * p);
+                ua[r][0] = *reinterpret_cast<const uint4 *>(urow + ka0);
+                ua[r][1] = *reinterpret_cast<const uint4 *>(urow + ka1);
+            }
+        }
+        fb[0] = G.F0[(uint32_t)((at * ks + S0) * 64 + lane)];
+        fb[1] = G.F0[(uint32_t)((at * ks + (two ? S1 : S0)) * 64 + lane)];
+    }
+    float4 m1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wave < BS) m1 = *reinterpret_cast<const float4 *>(G.M1 + j * 16 + 4 * g);
+    uint4 w[NRT];
+#pragma unroll
+    for (int k = 0; k < NRT; ++k) {                                              // HBM, streamed once: nt; requested LAST (in-order vmcnt)
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(G.qw + ((uint64_t)(rt0 + k) * nch + at) * 64 + lane));
+        w[k] = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+    const float e_sc = G.scale[0];
+    if (!two) fb[1] = make_uint4(0u, 0u, 0u, 0u);
+
+    if (mixer) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+            u32x4 a0 = {ga[r][0].x, ga[r][0].y, ga[r][0].z, ga[r][0].w}, a1 = {ga[r][1].x, ga[r][1].y, ga[r][1].z, ga[r][1].w};
+            if (GATE) {
+                a0 = u32x4{bg_gate2(ga[r][0].x, ua[r][0].x), bg_gate2(ga[r][0].y, ua[r][0].y), bg_gate2(ga[r][0].z, ua[r][0].z), bg_gate2(ga[r][0].w, ua[r][0].w)};
+                a1 = u32x4{bg_gate2(ga[r][1].x, ua[r][1].x), bg_gate2(ga[r][1].y, ua[r][1].y), bg_gate2(ga[r][1].z, ua[r][1].z), bg_gate2(ga[r][1].w, ua[r][1].w)};
+            }
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            acc = ActF16::mfma(a0, u32x4{fb[0].x, fb[0].y, fb[0].z, fb[0].w}, acc);
+            acc = ActF16::mfma(a1, u32x4{fb[1].x, fb[1].y, fb[1].z, fb[1].w}, acc);
+            part[(r * nwp + wave) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+    __syncthreads();
+    if (wave < BS) {
+        const int r = wave;
+        f32x4_t T = {0.f, 0.f, 0.f, 0.f};
+        for (int w2 = 0; w2 < nwp; ++w2) {
+            const float4 v = part[(r * nwp + w2) * 64 + lane];
+            T[0] += v.x; T[1] += v.y; T[2] += v.z; T[3] += v.w;
+        }
+        const f32x4_t z2 = bg_mix_b(T, m1);                                      // x~[a' = j][b' = 4g + reg]: k = 16 j + 4 g + reg of the slice
+        uint2 pk;
+        pk.x = pack_f16x2(z2[0], z2[1]);
+        pk.y = pack_f16x2(z2[2], z2[3]);
+        *reinterpret_cast<uint2 *>(XT + r * XTS + 16 * j + 4 * g) = pk;
+        const float4 rv = f16x4_to_f32(pk);                                      // the sum the epilogue subtracts is the sum of what the MFMAs see
+        const float s = fg_wave_sum((rv.x + rv.y) + (rv.z + rv.w));
+        if (lane == 0) red[r] = s;
+    }
+    __syncthreads();
+
+    // ---- 2-bit GEMM of this K-slice: MFMA column j = batch row j (columns >= BS read allocated garbage and are not stored) ----------------
+    f32x4_t acc[NRT];
+#pragma unroll
+    for (int k = 0; k < NRT; ++k) acc[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const uint16_t *xrow = XT + (j & (BG_MAXBS - 1)) * XTS + 8 * g;
+    uint4 xf[DQ::NT];
+#pragma unroll
+    for (int t = 0; t < DQ::NT; ++t) xf[t] = *reinterpret_cast<const uint4 *>(xrow + 32 * t);
+#pragma unroll
+    for (int k = 0; k < NRT; ++k)
+#pragma unroll
+        for (int t = 0; t < DQ::NT; ++t) {
+            const u32x4 a = DQ::frag(u32x4{w[k].x, w[k].y, w[k].z, w[k].w}, t);
+            acc[k] = ActF16::mfma(a, u32x4{xf[t].x, xf[t].y, xf[t].z, xf[t].w}, acc[k]);
+        }
+    // D[row = 4g + reg][col = j]: lanes j < BS park their 4 rows; the wave re-reads them as 16 NRT consecutive rows per batch row
+    float *mine = park + wave * (NRT * 64);
+    if (j < BS) {
+#pragma unroll
+        for (int k = 0; k < NRT; ++k) *reinterpret_cast<float4 *>(mine + (k * 4 + j) * 16 + 4 * g) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+    }
+    __syncthreads();
+    const float alpha = e_sc * two_over_maxq;
+#pragma unroll
+    for (int o = 0; o < (16 * NRT + 63) / 64; ++o) {
+        const int l = lane + 64 * o;
+        if (l < 16 * NRT) {
+            const int k = l >> 4, wr = l & 15;
+#pragma unroll
+            for (int r = 0; r < BS; ++r) {
+                const float val = alpha * (mine[(k * 4 + r) * 16 + wr] - c0 * red[r]);
+                unsafeAtomicAdd(G.y + (int64_t)r * G.m + (int64_t)rt0 * 16 + l, val);
+            }
+        }
+    }
+}
+
+}   // namespace
+
+extern "C" int quipamd_decode_bigp_supported(int p, int q)
+{
+    return q == 16 && p % 16 == 0 && p >= 64 && (p + 31) / 32 <= BG_MAXKS;
+}
+
+extern "C" int quipamd_decode_bigp_u(const quipamd_bigp_u_op *ops, int nops, int p, int64_t rows, float *clear, int64_t clear_n, void *stream)
+{
+    QA_REQUIRE(ops && nops >= 1 && nops <= BG_MAXG, QUIPAMD_ERR_ARG, "decode_bigp_u: 1..%d operators", BG_MAXG);
+    QA_REQUIRE(quipamd_decode_bigp_supported(p, 16), QUIPAMD_ERR_UNSUPPORTED, "decode_bigp_u: p = %d (wants p %% 16 == 0, 64 <= p <= %d)", p, 32 * BG_MAXKS);
+    QA_REQUIRE(rows >= 1 && rows <= BG_MAXBS, QUIPAMD_ERR_SHAPE, "decode_bigp_u: 1..%d rows", BG_MAXBS);
+    QA_REQUIRE((!clear && clear_n == 0) || (clear && clear_n > 0 && clear_n % 4 == 0 && ((uintptr_t)clear & 15) == 0), QUIPAMD_ERR_ARG,
+               "decode_bigp_u: clear wants a 16-byte aligned buffer of a multiple of 4 floats");
+    BUArgs A;
+    const int64_t n = (int64_t)p * 16;
+    for (int i = 0; i < BG_MAXG; ++i) {
+        const quipamd_bigp_u_op &o = ops[i < nops ? i : 0];
+        QA_REQUIRE(o.F0 && o.M1 && o.y && o.dest && o.out && o.ld_out >= n, QUIPAMD_ERR_ARG, "decode_bigp_u: operator %d: fragments, M1, y, dest, out wanted", i);
+        A.op[i] = BUOp{(const uint4 *)o.F0, o.M1, (const uint16_t *)o.y, (const uint16_t *)o.bias_img, o.post_img, o.dest, (uint16_t *)o.out, o.ld_out};
+    }
+    A.clear = clear;
+    A.clear_n4 = clear_n / 4;
+    A.p = p;
+    A.ks = (p + 31) / 32;
+    const int nw = (A.ks + 1) / 2;
+    const size_t lds = (size_t)rows * nw * 64 * sizeof(float4);
+    const dim3 grid((unsigned)(p / 16), (unsigned)nops);
+    hipStream_t s = (hipStream_t)stream;
+#define QA_BU(BS)                                                                                                                    \
+    do {                                                                                                                             \
+        auto kern = bigp_u_kernel<BS>;                                                                                               \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_bigp_u: cannot raise dynamic LDS to %zu", lds);                               \
+        kern<<<grid, 64 * (nw > BS ? nw : BS), lds, s>>>(A);                                                                                          \
+    } while (0)
+    switch ((int)rows) {
+    case 1: QA_BU(1); break;
+    case 2: QA_BU(2); break;
+    case 3: QA_BU(3); break;
+    default: QA_BU(4); break;
+    }
+#undef QA_BU
+    QA_LAUNCH_CHECK("quipamd_decode_bigp_u");
+    return QUIPAMD_OK;
+}
+
+extern "C" int quipamd_decode_bigp_v_gemm(const quipamd_bigp_v_gemm_args *a, void *stream)
+{
+    QA_REQUIRE(a, QUIPAMD_ERR_ARG, "decode_bigp_v_gemm: null args");
+    const int p = a->p;
+    QA_REQUIRE(quipamd_decode_bigp_supported(p, 16), QUIPAMD_ERR_UNSUPPORTED, "decode_bigp_v_gemm: p = %d (wants p %% 16 == 0, 64 <= p <= %d)", p, 32 * BG_MAXKS);
+    QA_REQUIRE(a->bits == 2, QUIPAMD_ERR_UNSUPPORTED, "decode_bigp_v_gemm: 2-bit qfn-b codes");
+    QA_REQUIRE(a->rows >= 1 && a->rows <= BG_MAXBS, QUIPAMD_ERR_SHAPE, "decode_bigp_v_gemm: 1..%d rows", BG_MAXBS);
+    QA_REQUIRE(a->F0 && a->M1 && a->gate && a->qweight && a->scale && a->y && a->ldx >= (int64_t)p * 16 && a->ldx % 8 == 0, QUIPAMD_ERR_ARG,
+               "decode_bigp_v_gemm: fragments, M1, input, codes, scale, y wanted; ldx >= n, ldx %% 8 == 0");
+    QA_REQUIRE(a->m > 0 && a->m % 256 == 0, QUIPAMD_ERR_SHAPE, "decode_bigp_v_gemm: m %% 256 == 0");
+    int nrt = a->row_tiles_per_wave;
+    if (nrt == 0) nrt = a->m % 1024 == 0 ? 4 : a->m % 512 == 0 ? 2 : 1;
+    QA_REQUIRE((nrt == 1 || nrt == 2 || nrt == 4) && a->m % (256 * nrt) == 0, QUIPAMD_ERR_ARG, "decode_bigp_v_gemm: row_tiles_per_wave 0 / 1 / 2 / 4 with m %% (256 x it) == 0");
+    BVArgs A{(const uint4 *)a->F0, a->M1, (const uint16_t *)a->gate, (const uint16_t *)a->up, a->ldx, (const uint4 *)a->qweight, a->scale, a->y, a->m, p, (p + 31) / 32};
+    const int nwp = (A.ks + 1) / 2, bs = (int)a->rows;
+    const float two_over_maxq = 2.0f / 3.0f, c0 = DeqT<2, ActF16>::OFF + 1.5f;
+    const dim3 grid((unsigned)(p / 16), (unsigned)(a->m / (256 * nrt)));
+    hipStream_t s = (hipStream_t)stream;
+#define QA_BV(BS, NRT, GT)                                                                                                           \
+    do {                                                                                                                             \
+        auto kern = bigp_v_gemm_kernel<BS, NRT, GT>;                                                                                 \
+        const size_t lds = (size_t)BG_MAXBS * 264 * 2 + 16 + (size_t)16 * NRT * 64 * 4 + (size_t)BS * nwp * 64 * sizeof(float4);     \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_bigp_v_gemm: cannot raise dynamic LDS to %zu", lds);                          \
+        kern<<<grid, 1024, lds, s>>>(A, two_over_maxq, c0);                                                                          \
+    } while (0)
+#define QA_BV_N(BS, GT)                                                                                                              \
+    do {                                                                                                                             \
+        if (nrt == 4) QA_BV(BS, 4, GT);                                                                                              \
+        else if (nrt == 2) QA_BV(BS, 2, GT);                                                                                         \
+        else QA_BV(BS, 1, GT);                                                                                                       \
+    } while (0)
+#define QA_BV_B(GT)                                                                                                                  \
+    do {                                                                                                                             \
+        switch (bs) {                                                                                                                \
+        case 1: QA_BV_N(1, GT); break;                                                                                               \
+        case 2: QA_BV_N(2, GT); break;                                                                                               \
+        case 3: QA_BV_N(3, GT); break;                                                                                               \
+        default: QA_BV_N(4, GT); break;                                                                                              \
+        }                                                                                                                            \
+    } while (0)
+    if (a->up) QA_BV_B(true);
+    else QA_BV_B(false);
+#undef QA_BV_B
+#undef QA_BV_N
+#undef QA_BV
+    QA_LAUNCH_CHECK("quipamd_decode_bigp_v_gemm");
+    return QUIPAMD_OK;
+}

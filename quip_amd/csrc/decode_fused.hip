@@ -102,7 +102,8 @@ __device__ __forceinline__ float fg_block_sum(float v, float *red)
 // register file does not hold both): the phases between the barriers then run on registers and LDS only.
 // NRT: row tiles a wave handles one after the other against the same x~ fragments (Llama's m = 4096 x 3 and 11008 x 2 would otherwise
 // be 768 / 1376 workgroups on 256 CUs, each repeating the prologue): a workgroup owns 16 RT NRT rows.
-template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT>
+// YF32: u_y is fp32 (the accumulator of quipamd_decode_bigp_v_gemm) and is rounded to fp16 on load -- what a cast launch in between would do.
+template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT, bool YF32 = false>
 __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two_over_maxq, float c0)
 {
     typedef PassDims<P, Q> D;
@@ -148,12 +149,29 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     float4 cs[NV];
     uint2 bi[NV], st[NV], rs[NV], gm[NV], bt_[NV], vld[NV], xr[NV];
     constexpr int NCV = (N / 8 + 1023) / 1024;                                  // 16-byte chunks of the U pass's input row per thread
-    uint4 yc[NCV];
+    uint4 yc[NCV], yc2[NCV];
     auto load_u_row = [&](int b) {                                              // what the first scatter needs: the row itself, in ZT order
 #pragma unroll
         for (int u = 0; u < NCV; ++u) {
             const int c = tid + 1024 * u;
-            if (c < N / 8) yc[u] = *reinterpret_cast<const uint4 *>((G.u_y + (int64_t)b * N) + (uint32_t)(8 * c));
+            if (c < N / 8) {
+                if constexpr (YF32) {
+                    const float *src = reinterpret_cast<const float *>(G.u_y) + (int64_t)b * N + (uint32_t)(8 * c);
+                    yc[u] = *reinterpret_cast<const uint4 *>(src);
+                    yc2[u] = *reinterpret_cast<const uint4 *>(src + 4);
+                } else {
+                    yc[u] = *reinterpret_cast<const uint4 *>((G.u_y + (int64_t)b * N) + (uint32_t)(8 * c));
+                }
+            }
+        }
+    };
+    auto u_row_f16 = [&](int u) {                                               // the chunk as 8 halves
+        if constexpr (YF32) {
+            auto f = [](uint32_t a) { return __builtin_bit_cast(float, a); };
+            return make_uint4(pack_f16x2(f(yc[u].x), f(yc[u].y)), pack_f16x2(f(yc[u].z), f(yc[u].w)),
+                              pack_f16x2(f(yc2[u].x), f(yc2[u].y)), pack_f16x2(f(yc2[u].z), f(yc2[u].w)));
+        } else {
+            return yc[u];
         }
     };
     auto load_u_frags = [&]() {
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
             }
 #pragma unroll
             for (int u = 0; u < NCV; ++u)
-                if (tid + 1024 * u < N / 8) copy_chunk_zt<P, Q>(ZT, yc[u], tid + 1024 * u);
+                if (tid + 1024 * u < N / 8) copy_chunk_zt<P, Q>(ZT, u_row_f16(u), tid + 1024 * u);
             if (!EARLY) {                                                       // n = 8192: fragments, the gather's operands and the V-side set follow
                 load_u_frags();                                                 // the scatter (nothing row-independent stays in registers across a row)
                 load_u_side(b);
@@ -606,11 +624,11 @@ template <int P, int Q, int NRT> constexpr size_t fused_lds()
     return (size_t)FG_MAXBS * (D::N + 8) * 2 + (D::BYTES > parkb ? D::BYTES : parkb) + (2 + FG_MAXBS) * FG_NW * 4 + 64;
 }
 
-template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT>
+template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT, bool YF32 = false>
 int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
 {
     const size_t lds = fused_lds<P, Q, NRT>();
-    auto kern = fused_gemm_kernel<P, Q, HAS_U, HAS_RES, NORM, RT, CPW, NRT>;
+    auto kern = fused_gemm_kernel<P, Q, HAS_U, HAS_RES, NORM, RT, CPW, NRT, YF32>;
     static QaPerDevice attr;
     const int d = attr.dev();
     if (d < 0 || !attr.done[d]) {
@@ -682,6 +700,11 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
     }
     hipStream_t s = (hipStream_t)stream;
     const bool u = a->has_u != 0, res = u && a->u_residual != nullptr;
+    const bool yf32 = u && a->u_y_dtype == QUIPAMD_F32;
+    QA_REQUIRE(!u || yf32 || a->u_y_dtype == QUIPAMD_F16, QUIPAMD_ERR_ARG, "decode_fused_gemm: u_y_dtype f16 or f32");
+    // fp32 u_y = the accumulator of quipamd_decode_bigp_v_gemm: Llama's down_proj -> next block's q / k / v
+    QA_REQUIRE(!yf32 || (p == 64 && q == 64 && res && a->norm == 2), QUIPAMD_ERR_UNSUPPORTED,
+               "decode_fused_gemm: fp32 u_y has a kernel for 64 x 64 with residual and RMSNorm only");
     if (p == 64 && q == 32) {
         QA_REQUIRE(a->m > 0 && a->m % 32 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 32 (m = %lld)", (long long)a->m);
         return dispatch_fused<64, 32, 2, 1, 1>(A, u, res, a->norm, a->ngroups, s);
@@ -691,6 +714,9 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
         // row tiles per wave: as many as keep the grid within one round of 256 workgroups (each repeats the prologue)
         const int64_t tiles = a->m / 16 * a->ngroups;
         const int nrt = (tiles > 4 * 256 && a->m % 128 == 0) ? 8 : (tiles > 256 && a->m % 64 == 0) ? 4 : 1;
+        if (yf32) return nrt == 8 ? launch_fused<64, 64, true, true, 2, 1, 1, 8, true>(A, a->ngroups, s)
+                       : nrt == 4 ? launch_fused<64, 64, true, true, 2, 1, 1, 4, true>(A, a->ngroups, s)
+                                  : launch_fused<64, 64, true, true, 2, 1, 1, 1, true>(A, a->ngroups, s);
         return nrt == 8 ? dispatch_fused<64, 64, 1, 1, 8>(A, u, res, a->norm, a->ngroups, s)
              : nrt == 4 ? dispatch_fused<64, 64, 1, 1, 4>(A, u, res, a->norm, a->ngroups, s)
                         : dispatch_fused<64, 64, 1, 1, 1>(A, u, res, a->norm, a->ngroups, s);

@@ -359,7 +359,8 @@ class FusedGemmArgs(ctypes.Structure):
                 ("norm", ctypes.c_int), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p), ("ln_eps", ctypes.c_float),
                 ("ngroups", ctypes.c_int), ("V", Fop * 3), ("colscale", ctypes.c_void_p * 3), ("qweight", ctypes.c_void_p * 3),
                 ("scale", ctypes.c_void_p * 3), ("y", ctypes.c_void_p * 3), ("y_dtype", ctypes.c_int), ("bs", ctypes.c_int64),
-                ("m", ctypes.c_int64), ("pair_sig", ctypes.c_void_p), ("pair_bias", ctypes.c_void_p), ("pair_cs", ctypes.c_void_p)]
+                ("m", ctypes.c_int64), ("pair_sig", ctypes.c_void_p), ("pair_bias", ctypes.c_void_p), ("pair_cs", ctypes.c_void_p),
+                ("u_y_dtype", ctypes.c_int)]
 
 
 FUSED_SHAPES = ((64, 32), (64, 64), (128, 64))
@@ -372,6 +373,69 @@ def _f16_b_frags(M):
     P = M.shape[0]
     F = M.to(torch.float16).view(P // 16, 16, P // 32, 4, 8)          # [t, j, S, g, e]
     return F.permute(0, 2, 3, 1, 4).contiguous().reshape(-1)          # [t, S, g, j, e]: lane = 16 g + j
+
+
+def _f16_b_frags_padded(M):
+    """_f16_b_frags for a p that is a multiple of 16 only: the k index zero padded to ks = ceil(p / 32) steps
+    (include/quip_amd.h quipamd_decode_bigp_u): fp16 [p/16, ks, 64, 8]"""
+    P = M.shape[0]
+    ks = (P + 31) // 32
+    Mp = torch.zeros((P, 32 * ks), dtype=torch.float16, device=M.device)
+    Mp[:, :P] = M.to(torch.float16)
+    F = Mp.view(P // 16, 16, ks, 4, 8)                                 # [t, j, S, g, e]
+    return F.permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+
+
+class BigpUOp(ctypes.Structure):
+    """quipamd_bigp_u_op"""
+    _fields_ = [("F0", ctypes.c_void_p), ("M1", ctypes.c_void_p), ("y", ctypes.c_void_p), ("bias_img", ctypes.c_void_p),
+                ("post_img", ctypes.c_void_p), ("dest", ctypes.c_void_p), ("out", ctypes.c_void_p), ("ld_out", ctypes.c_int64)]
+
+
+class BigpVGemmArgs(ctypes.Structure):
+    """quipamd_bigp_v_gemm_args"""
+    _fields_ = [("F0", ctypes.c_void_p), ("M1", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("up", ctypes.c_void_p), ("ldx", ctypes.c_int64),
+                ("qweight", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("bits", ctypes.c_int), ("y", ctypes.c_void_p), ("m", ctypes.c_int64),
+                ("p", ctypes.c_int), ("rows", ctypes.c_int64), ("row_tiles_per_wave", ctypes.c_int)]
+
+
+BIGP_MAX_ROWS = 4
+
+
+def decode_bigp_u(entries, rows, clear=None):
+    """ONE launch for the output-side p x 16 operators of up to three layers (quipamd_decode_bigp_u):
+    entries = [(U, y, bias_img | None, post_img | None, dest, out)]: U an OrthoOp with fold_ok (applied TRANSPOSED), y fp16 [rows, n] in ZT
+    order of U, bias_img fp16 [n] / post_img fp32 [n] in image order, dest int16-as-uint16 [n] (image position -> index of `out`), out fp16
+    [rows, >= n].  clear: an fp32 tensor the launch zeroes (the accumulator of the decode_bigp_v_gemm that follows)."""
+    U0 = entries[0][0]
+    _need_gpu(entries[0][1])
+    arr = (BigpUOp * len(entries))()
+    keep = []
+    for i, (U, y, bias_img, post_img, dest, out) in enumerate(entries):
+        assert U.bigp_fold_ok and U.p == U0.p and y.dtype == torch.float16 and y.shape == (rows, U.n) and y.is_contiguous()
+        assert out.dtype == torch.float16 and out.stride(1) == 1 and out.shape[0] == rows and dest.dtype == torch.int16 and dest.numel() == U.n
+        assert bias_img is None or (bias_img.dtype == torch.float16 and bias_img.numel() == U.n)
+        assert post_img is None or (post_img.dtype == torch.float32 and post_img.numel() == U.n)
+        F0, M1 = U.bigp_frags(True)
+        keep.append((F0, M1))
+        arr[i] = BigpUOp(_p(F0), _p(M1), _p(y), _p(bias_img), _p(post_img), _p(dest), _p(out), out.stride(0))
+    if clear is not None:
+        assert clear.dtype == torch.float32 and clear.is_contiguous() and clear.numel() % 4 == 0
+    _lib.call("quipamd_decode_bigp_u", arr, len(entries), U0.p, rows, _p(clear), 0 if clear is None else clear.numel(), _stream())
+
+
+def decode_bigp_v_gemm(V, gate, up, qweight_d, scale, y, row_tiles_per_wave=0):
+    """y += What V(silu(gate) * up) for a 2-bit qfn-b layer whose activation-side operator V is p x 16 (quipamd_decode_bigp_v_gemm):
+    gate / up fp16 [rows, n] as the transposed image of V's input (up None: the input is `gate` itself), qweight_d the codes with their
+    columns in image order of V (QuantLinear.decode_qweight()), y fp32 [rows, m] ACCUMULATED with atomics (zero it first)."""
+    _need_gpu(gate)
+    rows, m = y.shape
+    assert V.bigp_fold_ok and gate.dtype == torch.float16 and gate.shape == (rows, V.n) and gate.stride(1) == 1
+    assert up is None or (up.dtype == torch.float16 and up.shape == gate.shape and up.stride() == gate.stride())
+    assert y.dtype == torch.float32 and y.is_contiguous() and scale.dtype == torch.float32 and scale.numel() == 1
+    F0, M1 = V.bigp_frags(False)
+    a = BigpVGemmArgs(_p(F0), _p(M1), _p(gate), _p(up), gate.stride(0), _p(qweight_d), _p(scale), 2, _p(y), m, V.p, rows, int(row_tiles_per_wave))
+    _lib.call("quipamd_decode_bigp_v_gemm", ctypes.byref(a), _stream())
 
 
 def pair_tables(Uop, Vop, bias16, colscale):
@@ -412,7 +476,8 @@ def decode_fused_gemm(*, V, colscale, qweight, scale, y, m, bs, x=None, U=None, 
         a.u_residual, a.ld_residual = _ptr(u_residual), 0 if u_residual is None else u_residual.stride(0)
         a.u_relu = int(bool(u_relu))
         a.t_out, a.ld_t = _ptr(t_out), 0 if t_out is None else t_out.stride(0)
-        assert u_y.dtype == torch.float16 and u_y.is_contiguous() and u_bias.dtype == torch.float16 and u_bias.is_contiguous()
+        assert u_y.dtype in (torch.float16, torch.float32) and u_y.is_contiguous() and u_bias.dtype == torch.float16 and u_bias.is_contiguous()
+        a.u_y_dtype = _DT[u_y.dtype]
         assert u_residual is None or (u_residual.dtype == torch.float16 and u_residual.stride(1) == 1)
         assert t_out is None or (t_out.dtype == torch.float16 and t_out.stride(1) == 1)
     else:
@@ -540,6 +605,25 @@ class OrthoOp:
     @property
     def fused_ok(self):
         return (not self.blocked) and (self.p, self.q) in FUSED_SHAPES and (self.small_ok or self.bigp_ok)
+
+    @property
+    def bigp_fold_ok(self):
+        """p x 16 with a large p (Llama's 688 x 16): served by csrc/decode_bigp.hip"""
+        return bool(self.bigp_ok and (self.p, self.q) not in FUSED_SHAPES and self.p <= 1024)      # = quipamd_decode_bigp_supported
+
+    @property
+    def fold_ok(self):
+        """does a decode launch exist that takes this operator's permutations folded into the packing (QuantLinear.decode_qweight)?"""
+        return self.fused_ok or self.bigp_fold_ok
+
+    def bigp_frags(self, transpose):
+        """(F0, M1) for csrc/decode_bigp.hip: M0 of the wanted orientation as zero-padded fp16 B fragments, M1 fp32 [16, 16]"""
+        cache = self.__dict__.setdefault('_bigp_frags', {})
+        key = bool(transpose)
+        if key not in cache:
+            M0, M1 = self._M[key]
+            cache[key] = (_f16_b_frags_padded(M0), M1.to(torch.float32).contiguous())
+        return cache[key]
 
     def store_inv(self, transpose):
         """image position -> output index: the inverse of the `store_idx` small_op() hands to the kernels"""

@@ -209,11 +209,11 @@ class QuantLinear(nn.Module):
         if qd is None or qd.device != self.qweight.device:
             m, d = self.outfeatures, self.infeatures
             codes = ops.unpack(self.qweight, self.bits, ops.LAYOUT_STREAM, m, d)
-            if self.U is not None and self.U.fused_ok:        # (an operator the fused launches cannot run -- Llama's 688 x 16 -- keeps the
-                perm = torch.empty(m, dtype=torch.int64, device=codes.device)   #  natural order: its side is served by the K3 kernels)
+            if self.U is not None and self.U.fold_ok:         # (an operator no decode launch can run keeps the natural order: its side
+                perm = torch.empty(m, dtype=torch.int64, device=codes.device)   #  is served by the K3 kernels)
                 perm[self.U.zt_rows()] = torch.arange(m, device=codes.device)          # new row r holds old row perm[r]
                 codes = codes[perm]
-            if self.V is not None and self.V.fused_ok:
+            if self.V is not None and self.V.fold_ok:
                 perm = torch.empty(d, dtype=torch.int64, device=codes.device)
                 perm[self.V.image_cols()] = torch.arange(d, device=codes.device)
                 codes = codes[:, perm]
@@ -223,14 +223,14 @@ class QuantLinear(nn.Module):
 
     def to_zt(self, y):
         """a vector in this layer's natural output order -> ZT order (what its decode launch produces)"""
-        if self.U is None or not self.U.fused_ok:
+        if self.U is None or not self.U.fold_ok:
             return y
         out = torch.empty_like(y)
         out[..., self.U.zt_rows()] = y
         return out
 
     def from_zt(self, y):
-        return y if (self.U is None or not self.U.fused_ok) else y[..., self.U.zt_rows()]
+        return y if (self.U is None or not self.U.fold_ok) else y[..., self.U.zt_rows()]
 
     def packed_state(self):
         """everything needed to rebuild the layer, as CPU tensors / plain Python (the packed checkpoint record):
@@ -621,6 +621,57 @@ def packed_v_stage_gate(ql, gate, up, out_dtype=torch.bfloat16):
     return V.apply_rows(torch.nn.functional.silu(gate) * up, colscale=ql.inv_scaleWH, out_dtype=out_dtype)
 
 
+def bigp_tail_ok(ups, down, rows):
+    """can `fused_bigp_tail` run this MLP tail?  (csrc/decode_bigp.hip: 1..2 producers whose output-side operators are p x 16 with the
+    shape of the consumer's activation-side operator, 2-bit qfn-b consumer with one scale, a handful of rows)"""
+    V = down.V
+    return (1 <= len(ups) <= 2 and rows <= ops.BIGP_MAX_ROWS and V is not None and V.bigp_fold_ok and down.bits == 2 and down.qfn == 'b'
+            and down.scales.numel() == 1 and down.outfeatures % 256 == 0
+            and all(q.U is not None and q.U.bigp_fold_ok and (q.U.p, q.U.q) == (V.p, V.q) for q in ups))
+
+
+def _bigp_tail_tables(ups, down):
+    """per (producers, consumer): for every producer the uint16 map image position of U^T's result -> index in the TRANSPOSED input image
+    of the consumer's V (b * p + a of the position inv_pin_V[i] natural index i lands on), its bias in image order, and -- on the last
+    producer -- 1 / scaleWH of the consumer in image order (the column rescale rides on `up`: silu(g) * (u / s))"""
+    cache = down.__dict__.setdefault('_bigp_tail', {})
+    key = tuple(id(q) for q in ups)
+    if key not in cache:
+        V = down.V
+        dev, n, p = V.device, V.n, V.p
+        ident = torch.arange(n, device=dev)
+        inv_pin_v = ident if V.inv_pin is None else V.inv_pin.long()
+        ent = []
+        for i, q in enumerate(ups):
+            nat = ident if q.U.pin is None else q.U.pin.long()                  # natural index of the element at image position pos
+            pos_d = inv_pin_v[nat]
+            dest = ((pos_d % 16) * p + pos_d // 16).to(torch.int16).contiguous()   # n <= 16384: the bits of a uint16
+            bias_img = None if q.bias is None else bias16(q)[nat].contiguous()
+            post = None
+            if i == len(ups) - 1 and down.inv_scaleWH is not None:
+                post = down.inv_scaleWH.float()[nat].contiguous()
+            ent.append((dest, bias_img, post))
+        cache[key] = ent
+    return cache[key]
+
+
+def fused_bigp_tail(ups, down, ys, row_tiles_per_wave=0):
+    """Llama's MLP tail  down_proj(silu(gate_proj(x)) * up_proj(x))  behind the gate / up GEMM as TWO launches (csrc/decode_bigp.hip):
+        [U_gate^T y_gate -> g,  (U_up^T y_up) (/) s_down -> u]      quipamd_decode_bigp_u       (also zeroes the accumulator)
+        [x~ = V_down (silu(g) * u),  y_down += What_down x~]         quipamd_decode_bigp_v_gemm  (K-slices meet through fp32 atomics)
+    ups = [gate, up] (or one layer: no gating), ys = their fp16 outputs in ZT order (fused_stage with y_dtype=torch.float16).
+    Returns y_down fp32 [rows, m] in ZT order of down's U -- what fused_stage(prev=down, y_prev=...) / fused_u_only take."""
+    rows = ys[0].shape[0]
+    V = down.V
+    tabs = _bigp_tail_tables(ups, down)
+    dev = ys[0].device
+    imgs = torch.empty((len(ups), rows, V.n), dtype=torch.float16, device=dev)
+    yd = torch.empty((rows, down.outfeatures), dtype=torch.float32, device=dev)
+    ops.decode_bigp_u([(q.U, y, bias_img, post, dest, imgs[i]) for i, (q, y, (dest, bias_img, post)) in enumerate(zip(ups, ys, tabs))], rows, clear=yd)
+    ops.decode_bigp_v_gemm(V, imgs[0], imgs[1] if len(ups) == 2 else None, down.decode_qweight(), down.scales, yd, row_tiles_per_wave)
+    return yd
+
+
 def fused_u_only(ql, y, residual=None, relu=False):
     """out = [relu](U^T y + bias + residual), fp16: the output side of packed layer `ql` on its own; y fp16 in ZT order"""
     return ops.decode_u_only(ql.U, y, bias16(ql), residual=None if residual is None else residual.contiguous(), relu=relu)
@@ -668,7 +719,10 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
             if key not in cache:
                 cache[key] = ops.pair_tables(prev.U, q0.V, bias16(prev), kw['colscale'][0])
             kw.update(pair=cache[key])
-        kw.update(U=prev.U.fop(True), u_y=y_prev.to(torch.float16).contiguous(), u_bias=bias16(prev),
+        # an fp32 y_prev is rounded to fp16 -- inside the launch where a kernel for that exists (the accumulator of fused_bigp_tail
+        # feeding Llama's q / k / v), by a cast otherwise
+        in_kernel = (y_prev.dtype == torch.float32 and (q0.V.p, q0.V.q) == (64, 64) and residual is not None and lnp is not None and lnp[1] is None)
+        kw.update(U=prev.U.fop(True), u_y=(y_prev if in_kernel else y_prev.to(torch.float16)).contiguous(), u_bias=bias16(prev),
                   u_residual=None if residual is None else residual.contiguous(), u_relu=relu, t_out=t)
     ops.decode_fused_gemm(**kw)
     return ys, t

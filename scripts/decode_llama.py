@@ -30,7 +30,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quip_amd import ops, method  # noqa: E402
 from quip_amd.quant import (QuantLinear, packed_forward_fused, fused_stage, fused_ok, fused_attention, fused_attention_ok,  # noqa: E402
-                            fused_u_only, packed_u_stage, packed_v_stage_gate)
+                            fused_u_only, packed_u_stage, packed_v_stage_gate, fused_bigp_tail, bigp_tail_ok)
 import decode_opt as D  # noqa: E402  (time_decode: hipGraph capture + per-token timing)
 
 
@@ -102,12 +102,14 @@ class Decoder(nn.Module):
         b = self.blocks[0]
         qkv = [b.q_proj, b.k_proj, b.v_proj]
         return (isinstance(b.q_proj, QuantLinear) and fused_ok(qkv, bs, prev=b.down_proj) and fused_ok([b.o_proj], bs, norm=False)
-                and fused_ok([b.gate_proj, b.up_proj], bs, prev=b.o_proj) and b.down_proj.U is not None and b.down_proj.U.fused_ok)
+                and fused_ok([b.gate_proj, b.up_proj], bs, prev=b.o_proj) and b.down_proj.U is not None and b.down_proj.U.fused_ok
+                and bigp_tail_ok([b.gate_proj, b.up_proj], b.down_proj, bs))
 
     def step_v3(self, x, pos, caches):
-        """per block: [U_down^T(prev) + residual -> RMSNorm -> V_qkv -> GEMM q,k,v] [U_qkv^T + rotary + attention] [V_o -> GEMM o]
-        [U_o^T + residual -> RMSNorm -> V_gate/up -> GEMM gate, up] [U_gate^T, U_up^T: 688 x 16, K3] [V_down (silu * up on load), K3]
-        [GEMM down] [fp16 cast]; 11008 = 688 x 16 has no fused operator kernel (a 688 x 688 factor is 0.9 MB: not a workgroup's pass)"""
+        """per block, six launches: [U_down^T(prev) + residual -> RMSNorm -> V_qkv -> GEMM q,k,v] [U_qkv^T + rotary + attention]
+        [V_o -> GEMM o] [U_o^T + residual -> RMSNorm -> V_gate/up -> GEMM gate, up] [U_gate^T, U_up^T (/) s: 688 x 16, decode_bigp.hip]
+        [silu * up -> V_down -> GEMM down, K-slices through fp32 atomics]; a 688 x 688 factor is 0.9 MB, not a workgroup's pass: the
+        11008-wide operators are cut over the p index (csrc/decode_bigp.hip)"""
         h16 = torch.float16
         prev, yd = None, None
         for blk, (kc, vc) in zip(self.blocks, caches):
@@ -119,16 +121,10 @@ class Decoder(nn.Module):
             o = fused_attention(qkv, ys, kc, vc, pos, self.cos, self.sin)
             yo = fused_stage([blk.o_proj], x=o, y_dtype=h16)[0][0]
             gu = [blk.gate_proj, blk.up_proj]
-            ygu, x = fused_stage(gu, prev=blk.o_proj, y_prev=yo, residual=x, ln=blk.n2, store=True, y_dtype=torch.float32)
-            g, u = packed_u_stage(gu, ygu, h16)
-            # (fp16 x~ / y through this GEMM would save the cast launch, but K2's fp16 kernel for d = 11008 is 6 us slower than the bf16
-            #  tile kernel at batch 1: measured 378 vs 414 tok/s)
-            xt = packed_v_stage_gate(blk.down_proj, g, u)
-            yd32 = torch.empty((x.shape[0], blk.down_proj.outfeatures), dtype=torch.float32, device=x.device)
-            ops.dequant_gemm_grouped([xt], [blk.down_proj.decode_qweight()], 2, 'b', [blk.down_proj.scales], None, [yd32], blk.down_proj.outfeatures)
-            yd = yd32.to(h16)
+            ygu, x = fused_stage(gu, prev=blk.o_proj, y_prev=yo, residual=x, ln=blk.n2, store=True, y_dtype=h16)
+            yd = fused_bigp_tail(gu, blk.down_proj, ygu)                       # fp32 accumulator, ZT order of down_proj's U
             prev = blk.down_proj
-        return fused_u_only(prev, yd, residual=x)
+        return fused_u_only(prev, yd.to(h16), residual=x)
 
     def step(self, ids, pos, caches, arange):
         x = self.tok(ids)

@@ -1,0 +1,161 @@
+"""-m gpu: csrc/decode_bigp.hip -- the decode step around a packed layer whose Kronecker operator is p x 16 (Llama's 11008 = 688 x 16):
+quipamd_decode_bigp_u and quipamd_decode_bigp_v_gemm against the same chain in fp64 from the packed layers' own tensors
+
+    g = U_gate^T y_gate + b,   u = U_up^T y_up,   t = silu(g) * u (/) s_down,   x~ = V_down t,   y_down = What_down x~
+
+Gates as in test_gpu_decode_fused.py: operator outputs within 1e-3 (relative l2; fp16 factors, fp16 result), y within 3e-3 (x~ and the
+gated product are rounded to fp16 in front of the MFMAs).  The K-slices of the GEMM meet through fp32 atomics: two runs agree to fp32
+rounding, not bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_decode_fused import _layer, _dense, _RMS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _mlp(h, ffn, seed, bias=False):
+    gate = _layer(h, ffn, seed, bias=bias)
+    up = _layer(h, ffn, seed + 1, bias=False)
+    down = _layer(ffn, h, seed + 2, bias=False)
+    return gate, up, down
+
+
+def _tail64(gate, up, down, What_down, yg, yu):
+    """fp64 chain from the natural-order outputs of the gate / up GEMMs; the two fp16 roundings of the gated product are part of the contract"""
+    g = yg.double() @ _dense(gate.U, transpose=True).t() + (0 if gate.bias is None else gate.bias.double())
+    u = yu.double() @ _dense(up.U, transpose=True).t()
+    us = (u * down.inv_scaleWH.double())
+    t = (torch.nn.functional.silu(g.half().float()).half().float() * us.half().float()).half().double()
+    xt = t @ _dense(down.V).t()
+    return g, us, xt, xt @ What_down.t()
+
+
+@pytest.mark.parametrize("ffn,rows,bias", [(1280, 1, True), (1792, 3, False), (11008, 1, False), (11008, 2, True), (11008, 4, False)])
+def test_bigp_u_matches_the_dense_operator(ffn, rows, bias):
+    from quip_amd import ops
+    from quip_amd.quant import _bigp_tail_tables, bigp_tail_ok
+    h = 512
+    (gate, _), (up, _), (down, _) = _mlp(h, ffn, 900 + ffn % 89 + rows, bias=bias)
+    assert gate.U.bigp_fold_ok and not gate.U.fused_ok and bigp_tail_ok([gate, up], down, rows)
+    torch.manual_seed(rows + ffn)
+    yg = torch.randn(rows, ffn, device=DEV).half()
+    yu = torch.randn(rows, ffn, device=DEV).half()
+    tabs = _bigp_tail_tables([gate, up], down)
+    imgs = torch.full((2, rows, ffn), float("nan"), dtype=torch.float16, device=DEV)
+    clear = torch.full((rows, h), 7.0, device=DEV)
+    ops.decode_bigp_u([(q.U, q.to_zt(y), b_, p_, d_, imgs[i]) for i, (q, y, (d_, b_, p_)) in enumerate(zip((gate, up), (yg, yu), tabs))], rows, clear=clear)
+    assert float(clear.abs().max()) == 0.0
+    assert not torch.isnan(imgs).any()
+    V = down.V
+    inv_pin = torch.arange(V.n, device=DEV) if V.inv_pin is None else V.inv_pin.long()
+    timg = (inv_pin % 16) * V.p + inv_pin // 16                   # natural index -> place in the transposed input image of V_down
+    g64, us64, _, _ = _tail64(gate, up, down, torch.zeros(1, ffn, device=DEV, dtype=torch.float64), yg, yu)
+    for got, want in ((imgs[0][:, timg], g64), (imgs[1][:, timg], us64)):
+        rel = float((got.double() - want).norm() / want.norm())
+        assert rel <= 1e-3, rel
+        assert float((got.double() - want).abs().max()) <= 3e-3 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("ffn,h,rows,gated,nrt", [(1280, 512, 1, True, 0), (1280, 256, 2, False, 1), (1792, 1024, 4, True, 4), (1792, 512, 3, True, 2),
+                                                   (11008, 4096, 1, True, 0), (11008, 4096, 1, True, 2), (11008, 4096, 1, True, 1),
+                                                   (11008, 4096, 4, True, 0), (11008, 4096, 2, False, 0)])
+def test_bigp_v_gemm_matches_the_chain_in_fp64(ffn, h, rows, gated, nrt):
+    from quip_amd import ops
+    down, What = _layer(ffn, h, 700 + ffn % 61 + rows, bias=False)
+    V = down.V
+    torch.manual_seed(ffn + rows)
+    g = torch.randn(rows, ffn, device=DEV).half()
+    u = (torch.randn(rows, ffn, device=DEV) * down.inv_scaleWH).half() if gated else None
+    inv_pin = torch.arange(V.n, device=DEV) if V.inv_pin is None else V.inv_pin.long()
+    timg = (inv_pin % 16) * V.p + inv_pin // 16
+
+    def img(t):
+        out = torch.empty_like(t)
+        out[:, timg] = t
+        return out
+    y = torch.zeros(rows, h, device=DEV)
+    ops.decode_bigp_v_gemm(V, img(g), img(u) if gated else None, down.decode_qweight(), down.scales, y, nrt)
+    t = (torch.nn.functional.silu(g.float()).half().float() * u.float()).half().double() if gated else g.double()
+    want = (t @ _dense(V).t()) @ What.t()
+    got = down.from_zt(y).double()                               # rows of the packed codes are in ZT order of down's U
+    rel = float((got - want).norm() / want.norm())
+    assert rel <= 3e-3, rel
+    # accumulate contract: a second launch adds the same product again
+    ops.decode_bigp_v_gemm(V, img(g), img(u) if gated else None, down.decode_qweight(), down.scales, y, nrt)
+    rel2 = float((down.from_zt(y).double() - 2 * want).norm() / (2 * want).norm())
+    assert rel2 <= 3e-3, rel2
+
+
+@pytest.mark.parametrize("rows", [1, 2])
+def test_bigp_tail_whole_chain_and_the_round2_launches(rows):
+    """gate / up GEMM (fused launch, fp16 out in ZT order) -> fused_bigp_tail, against fp64 and against the round-2 launches
+    (ortho_bigp.hip twice + the tile GEMM) on the same packed layers"""
+    from quip_amd import ops
+    from quip_amd.quant import fused_stage, fused_bigp_tail, packed_u_stage, packed_v_stage_gate
+    h, ffn = 4096, 11008
+    (gate, Wg), (up, Wu), (down, Wd) = _mlp(h, ffn, 40 + rows)
+    torch.manual_seed(rows)
+    x = torch.randn(rows, h, device=DEV).half()
+    rms = _RMS((1 + 0.1 * torch.randn(h, device=DEV)).half(), 1e-5)
+    ygu, _ = fused_stage([gate, up], x=x, ln=rms, y_dtype=torch.float16)
+    yd = fused_bigp_tail([gate, up], down, ygu)
+    assert yd.dtype == torch.float32
+    yg, yu = gate.from_zt(ygu[0]), up.from_zt(ygu[1])             # natural order, the fp16 values the tail started from
+    _, _, _, want = _tail64(gate, up, down, Wd, yg, yu)
+    got = down.from_zt(yd).double()
+    rel = float((got - want).norm() / want.norm())
+    assert rel <= 3e-3, rel
+    # round 2: K3 p x 16 kernels (fp32 factors) + K2 on the natural-order codes
+    g2, u2 = packed_u_stage([gate, up], [yg.float(), yu.float()], torch.float16)
+    xt2 = packed_v_stage_gate(down, g2, u2)
+    y2 = torch.empty(rows, h, device=DEV)
+    ops.dequant_gemm_grouped([xt2], [down.qweight], 2, 'b', [down.scales], None, [y2], h)
+    rel_old = float((down.from_zt(yd).double() - y2.double()).norm() / y2.double().norm())
+    assert rel_old <= 4e-3, rel_old
+    # two runs: same K-slices, another summation order at most
+    yd_b = fused_bigp_tail([gate, up], down, ygu)
+    assert float((yd_b - yd).abs().max()) <= 1e-5 * float(yd.abs().max())
+
+
+def test_fp32_y_prev_is_rounded_inside_the_consuming_launch():
+    """the accumulator of fused_bigp_tail goes into the next block's q / k / v launch as fp32: same bits as a cast launch in between"""
+    from quip_amd.quant import fused_stage
+    d = 4096
+    qls = [_layer(d, d, 800 + i, bias=False)[0] for i in range(3)]
+    prev = _layer(11008, d, 810, bias=False)[0]
+    torch.manual_seed(3)
+    rms = _RMS((1 + 0.1 * torch.randn(d, device=DEV)).half(), 1e-5)
+    for rows in (1, 3):
+        y_prev = torch.randn(rows, d, device=DEV) * 0.5               # fp32, NOT representable in fp16
+        res = torch.randn(rows, d, device=DEV).half()
+        ys_a, t_a = fused_stage(qls, prev=prev, y_prev=y_prev, residual=res, ln=rms, store=True, y_dtype=torch.float16)
+        ys_b, t_b = fused_stage(qls, prev=prev, y_prev=y_prev.half(), residual=res, ln=rms, store=True, y_dtype=torch.float16)
+        assert torch.equal(t_a, t_b)
+        for a, b in zip(ys_a, ys_b):
+            assert torch.equal(a, b)
+
+
+def test_decode_qweight_folds_a_p_x_16_operator():
+    from quip_amd import ops
+    ql, _ = _layer(11008, 1280, 77, bias=False)                        # V 688 x 16, U 80 x 16
+    assert ql.U.bigp_fold_ok and ql.V.bigp_fold_ok
+    codes = ops.unpack(ql.qweight, 2, ops.LAYOUT_STREAM, 1280, 11008)
+    folded = ops.unpack(ql.decode_qweight(), 2, ops.LAYOUT_STREAM, 1280, 11008)
+    zt = ql.U.zt_rows()
+    img = ql.V.image_cols()
+    want = torch.empty_like(codes)
+    want[zt[:, None], img[None, :]] = codes
+    assert torch.equal(folded, want)
+
+
+def test_bigp_rejects():
+    from quip_amd import ops, _lib
+    down, _ = _layer(1280, 512, 5, bias=False)
+    g = torch.zeros(5, 1280, device=DEV).half()
+    with pytest.raises(_lib.QuipAmdError):                             # five rows
+        ops.decode_bigp_v_gemm(down.V, g, None, down.decode_qweight(), down.scales, torch.zeros(5, 512, device=DEV))
+    with pytest.raises(_lib.QuipAmdError):                             # row_tiles_per_wave 4 with m = 512
+        ops.decode_bigp_v_gemm(down.V, g[:1], None, down.decode_qweight(), down.scales, torch.zeros(1, 512, device=DEV), 4)
