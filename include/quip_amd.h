@@ -384,6 +384,44 @@ int quipamd_decode_bigp_supported(int p, int q);
 int quipamd_decode_bigp_u(const quipamd_bigp_u_op *ops, int nops, int p, int64_t rows, float *clear, int64_t clear_n, void *stream);
 int quipamd_decode_bigp_v_gemm(const quipamd_bigp_v_gemm_args *args, void *stream);
 
+/* ---- the two ends of a decode step around the decoder blocks (csrc/decode_head.hip; benchmark(), opt.py:431-482 / llama.py:418-471:
+ * one forward per token, logits of the last position, `torch.argmax` picks the next token), each as one launch.
+ * quipamd_decode_head:   t = U^T u_y + u_bias + u_residual  (has_u: the output side of the last packed layer, as in
+ *   quipamd_decode_fused_gemm: U the TRANSPOSED operator 64 x 32 / 64 x 64, u_y fp16 or fp32 [bs, n] in ZT order)   or   t = x;
+ *   h = LayerNorm (norm 1) / RMSNorm (norm 2) of t, rounded to fp16;   logits[r][v] = fp16( sum_k W[v][k] h[r][k] )   W fp16 [vocab, n];
+ *   part_val / part_idx [bs, nparts] (or both NULL): per workgroup the maximum of its rows' fp16 logits and the smallest row index that
+ *   attains it (index 0x7fffffff = the workgroup had no rows); nparts = the number of workgroups (0: 256); pos_inc: NULL, or a device
+ *   counter the launch increments by one when it is done (the step's position).  n = 2048 or 4096, bs <= 4.
+ * quipamd_decode_embed:  ids[r] = argmax over part_val[r][:] (ties: smallest index; entries with part_idx < 0 or 0x7fffffff are
+ *   skipped; when none is valid -- the first token -- ids[r] is kept as the caller set it), then
+ *   out[r][:] = tok_table[ids[r]][:] + pos_table[*pos + pos_offset][:]   (pos_table NULL: no position embedding), fp16. */
+typedef struct quipamd_head_args {
+    int has_u;
+    quipamd_fop U;
+    const void *u_y;
+    int u_y_dtype;
+    const void *u_bias, *u_residual;
+    int64_t ld_residual;
+    const void *x;
+    int64_t ldx;
+    int norm;
+    const void *ln_gamma, *ln_beta;
+    float ln_eps;
+    int64_t n, bs;
+    const void *W;
+    int64_t vocab;
+    void *logits;
+    int64_t ld_logits;
+    float *part_val;
+    int *part_idx;
+    int nparts;
+    int64_t *pos_inc;
+} quipamd_head_args;
+int quipamd_decode_head(const quipamd_head_args *args, void *stream);
+int quipamd_decode_embed(const void *tok_table, int64_t vocab, const void *pos_table, int64_t positions, int64_t pos_offset,
+                         const int64_t *pos, int64_t *ids, const float *part_val, const int *part_idx, int nparts, int64_t n,
+                         void *out, int64_t ld_out, int64_t bs, void *stream);
+
 /* Greedy token of a decode step: out[r] = argmax_i x[r, i] (int64, DEVICE), the smallest index among equal maxima like torch.argmax;
  * x: [rows, n] f32 / f16 / bf16 with row stride ld.  One workgroup per row (benchmark(), opt.py:463-480 picks the next token this way). */
 int quipamd_argmax_rows(const void *x, int dtype, int64_t rows, int64_t n, int64_t ld, int64_t *out, void *stream);

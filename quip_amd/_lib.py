@@ -61,6 +61,8 @@ SIGNATURES = {
     "quipamd_decode_bigp_supported": [c_int, c_int],
     "quipamd_decode_bigp_u": [c_vp, c_int, c_int, c_i64, c_vp, c_i64, c_vp],
     "quipamd_decode_bigp_v_gemm": [c_vp, c_vp],
+    "quipamd_decode_head": [c_vp, c_vp],
+    "quipamd_decode_embed": [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_i64, c_i64, c_vp],
     "quipamd_decode_u_only": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp],
     "quipamd_argmax_rows": [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp],
     "quipamd_decode_attention_fused": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_i64, c_float, c_i64, c_vp],

@@ -970,6 +970,71 @@ def argmax_rows(x, out=None):
     return out
 
 
+class HeadArgs(ctypes.Structure):
+    """mirror of `quipamd_head_args`"""
+    _fields_ = [("has_u", ctypes.c_int), ("U", Fop), ("u_y", ctypes.c_void_p), ("u_y_dtype", ctypes.c_int), ("u_bias", ctypes.c_void_p),
+                ("u_residual", ctypes.c_void_p), ("ld_residual", ctypes.c_int64), ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64),
+                ("norm", ctypes.c_int), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p), ("ln_eps", ctypes.c_float),
+                ("n", ctypes.c_int64), ("bs", ctypes.c_int64), ("W", ctypes.c_void_p), ("vocab", ctypes.c_int64), ("logits", ctypes.c_void_p),
+                ("ld_logits", ctypes.c_int64), ("part_val", ctypes.c_void_p), ("part_idx", ctypes.c_void_p), ("nparts", ctypes.c_int),
+                ("pos_inc", ctypes.c_void_p)]
+
+
+HEAD_PARTS = 256          # workgroups of the head launch = entries per row of the argmax partials
+
+
+def decode_head(W, logits, ln_gamma, ln_beta, ln_eps, x=None, U=None, u_y=None, u_bias=None, u_residual=None, part_val=None, part_idx=None,
+                pos_inc=None):
+    """ONE launch for the end of a decode step (quipamd_decode_head): t = U^T u_y + u_bias + u_residual (or t = x), the final LayerNorm
+    (ln_beta given) / RMSNorm (ln_beta None), logits = W h into `logits` (fp16 [bs, vocab]), per-workgroup argmax partials
+    (part_val fp32 / part_idx int32 [bs, HEAD_PARTS]), pos_inc (int64 [1]) += 1.  U: OrthoOp.fop(True); u_y fp16 or fp32 in ZT order."""
+    _need_gpu(W)
+    vocab, n = W.shape
+    a = HeadArgs()
+    a.has_u = int(U is not None)
+    if U is not None:
+        bs = u_y.shape[0]
+        assert u_y.dtype in (torch.float16, torch.float32) and u_y.is_contiguous() and u_y.shape[1] == n
+        assert u_bias.dtype == torch.float16 and u_bias.numel() == n
+        assert u_residual is None or (u_residual.dtype == torch.float16 and u_residual.stride(1) == 1)
+        a.U, a.u_y, a.u_y_dtype, a.u_bias = U, _ptr(u_y), _DT[u_y.dtype], _ptr(u_bias)
+        a.u_residual, a.ld_residual = _ptr(u_residual), 0 if u_residual is None else u_residual.stride(0)
+    else:
+        bs = x.shape[0]
+        assert x.dtype == torch.float16 and x.stride(1) == 1 and x.shape[1] == n
+        a.x, a.ldx = _ptr(x), x.stride(0)
+    assert W.dtype == torch.float16 and W.is_contiguous() and logits.dtype == torch.float16 and logits.stride(1) == 1 and logits.shape == (bs, vocab)
+    assert ln_gamma.dtype == torch.float16 and (ln_beta is None or ln_beta.dtype == torch.float16)
+    a.norm, a.ln_gamma, a.ln_beta, a.ln_eps = (1 if ln_beta is not None else 2), _ptr(ln_gamma), _ptr(ln_beta), float(ln_eps)
+    a.n, a.bs, a.W, a.vocab, a.logits, a.ld_logits = n, bs, _ptr(W), vocab, _ptr(logits), logits.stride(0)
+    a.nparts = HEAD_PARTS
+    if part_val is not None:
+        assert part_val.dtype == torch.float32 and part_idx.dtype == torch.int32 and part_val.shape == part_idx.shape == (bs, HEAD_PARTS)
+        assert part_val.is_contiguous() and part_idx.is_contiguous()
+        a.part_val, a.part_idx = _ptr(part_val), _ptr(part_idx)
+    if pos_inc is not None:
+        assert pos_inc.dtype == torch.int64 and pos_inc.numel() == 1
+        a.pos_inc = _ptr(pos_inc)
+    _lib.call("quipamd_decode_head", ctypes.byref(a), _stream())
+
+
+def decode_embed(tok_table, ids, out, pos_table=None, pos=None, pos_offset=0, part_val=None, part_idx=None):
+    """ONE launch for the start of a decode step (quipamd_decode_embed): ids[r] = argmax over the previous head launch's partials (when any
+    is valid), out[r] = tok_table[ids[r]] + pos_table[pos + pos_offset] (fp16)."""
+    _need_gpu(tok_table)
+    vocab, n = tok_table.shape
+    bs = ids.numel()
+    assert tok_table.dtype == torch.float16 and tok_table.is_contiguous() and ids.dtype == torch.int64 and ids.is_contiguous()
+    assert out.dtype == torch.float16 and out.stride(1) == 1 and out.shape == (bs, n)
+    assert pos_table is None or (pos_table.dtype == torch.float16 and pos_table.is_contiguous() and pos_table.shape[1] == n and pos.dtype == torch.int64)
+    if part_val is not None:
+        assert part_val.dtype == torch.float32 and part_idx.dtype == torch.int32 and part_val.shape == part_idx.shape and part_val.shape[0] == bs
+        assert part_val.is_contiguous() and part_idx.is_contiguous()
+    _lib.call("quipamd_decode_embed", _ptr(tok_table), vocab, _ptr(pos_table), 0 if pos_table is None else pos_table.shape[0], int(pos_offset),
+              _ptr(pos), _ptr(ids), _ptr(part_val), _ptr(part_idx), 0 if part_val is None else part_val.shape[1], n, _ptr(out), out.stride(0), bs,
+              _stream())
+
+
 def decode_u_only(U, y, bias16, residual=None, relu=False):
     """out = [relu](U^T y + bias + residual) as one small launch (quipamd_decode_u_only): y fp16 [bs, n] in ZT order of U"""
     _need_gpu(y)

@@ -677,6 +677,20 @@ def fused_u_only(ql, y, residual=None, relu=False):
     return ops.decode_u_only(ql.U, y, bias16(ql), residual=None if residual is None else residual.contiguous(), relu=relu)
 
 
+def fused_head_ok(ql, rows, ln):
+    """can `fused_head` finish a decode step behind packed layer `ql`?  (csrc/decode_head.hip: U 64 x 32 / 64 x 64, a norm, <= 4 rows)"""
+    return (ql.U is not None and ql.U.fused_ok and (ql.U.p, ql.U.q) in ((64, 32), (64, 64)) and rows <= ops.FUSED_MAX_ROWS and _ln_params(ln) is not None)
+
+
+def fused_head(ql, y, residual, ln, W, logits, part_val=None, part_idx=None, pos_inc=None):
+    """the end of a decode step as ONE launch (quipamd_decode_head): [U^T y + bias + residual] -> final norm -> logits = W h (+ the
+    argmax partials the next step's ops.decode_embed turns into the token, + pos += 1).  y: fp16 / fp32 in ZT order of ql's U."""
+    g, b, eps = _ln_params(ln)
+    ops.decode_head(W, logits, g, b, eps, U=ql.U.fop(True), u_y=y.contiguous(), u_bias=bias16(ql),
+                    u_residual=None if residual is None else residual.contiguous(), part_val=part_val, part_idx=part_idx, pos_inc=pos_inc)
+    return logits
+
+
 def fused_attention_ok(qkv, kcache):
     bs, heads, maxlen, hd = kcache.shape
     shapes = {(q.U.p, q.U.q) for q in qkv if q.U is not None}

@@ -30,7 +30,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quip_amd import ops, method  # noqa: E402
 from quip_amd.quant import (QuantLinear, packed_forward_fused, fused_stage, fused_ok, fused_attention, fused_attention_ok,  # noqa: E402
-                            fused_u_only, packed_u_stage, packed_v_stage_gate, fused_bigp_tail, bigp_tail_ok)
+                            fused_u_only, packed_u_stage, packed_v_stage_gate, fused_bigp_tail, bigp_tail_ok, fused_head)
 import decode_opt as D  # noqa: E402  (time_decode: hipGraph capture + per-token timing)
 
 
@@ -106,6 +106,19 @@ class Decoder(nn.Module):
                 and bigp_tail_ok([b.gate_proj, b.up_proj], b.down_proj, bs))
 
     def step_v3(self, x, pos, caches):
+        prev, yd, x = self.blocks_v3(x, pos, caches)
+        return fused_u_only(prev, yd.to(torch.float16), residual=x)
+
+    fused_head = False       # with v3: embedding (+ the previous step's argmax) and [U_down^T + residual -> final RMSNorm -> lm_head -> argmax
+                             # partials, pos += 1] as one launch each (csrc/decode_head.hip)
+
+    def step_fused_head(self, ids, pos, caches, logits, part_val, part_idx):
+        x = torch.empty((ids.numel(), self.h), dtype=torch.float16, device=ids.device)
+        ops.decode_embed(self.tok.weight, ids, x, part_val=part_val, part_idx=part_idx)
+        prev, yd, x = self.blocks_v3(x, pos, caches)
+        return fused_head(prev, yd, x, self.norm, self.lm_head.weight, logits, part_val, part_idx, pos_inc=pos)
+
+    def blocks_v3(self, x, pos, caches):
         """per block, six launches: [U_down^T(prev) + residual -> RMSNorm -> V_qkv -> GEMM q,k,v] [U_qkv^T + rotary + attention]
         [V_o -> GEMM o] [U_o^T + residual -> RMSNorm -> V_gate/up -> GEMM gate, up] [U_gate^T, U_up^T (/) s: 688 x 16, decode_bigp.hip]
         [silu * up -> V_down -> GEMM down, K-slices through fp32 atomics]; a 688 x 688 factor is 0.9 MB, not a workgroup's pass: the
@@ -124,7 +137,7 @@ class Decoder(nn.Module):
             ygu, x = fused_stage(gu, prev=blk.o_proj, y_prev=yo, residual=x, ln=blk.n2, store=True, y_dtype=h16)
             yd = fused_bigp_tail(gu, blk.down_proj, ygu)                       # fp32 accumulator, ZT order of down_proj's U
             prev = blk.down_proj
-        return fused_u_only(prev, yd.to(h16), residual=x)
+        return prev, yd, x
 
     def step(self, ids, pos, caches, arange):
         x = self.tok(ids)
@@ -199,7 +212,13 @@ def run(layers=32, bits=2, bs=1, prompt=64, tokens=64, with_dense=True):
         med, _, _ = D.time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, False)
         out["packed_w%d_v3" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
                                        "what": "csrc/decode_fused.hip / decode_attn.hip: operator chains in the prologues of the 4096-wide GEMMs and of the "
-                                               "attention launch (rotary included); the 11008-wide operators on the K3 kernels: 8 launches per block"}
+                                               "attention launch (rotary included); the 11008-wide operators cut over p (csrc/decode_bigp.hip): 6 launches per block"}
+        model.fused_head = True
+        med, _, _ = D.time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, False)
+        out["packed_w%d_v3_head" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+                                            "what": "as v3 + csrc/decode_head.hip: the embedding (with the previous step's argmax) and [U_down^T + residual -> "
+                                                    "RMSNorm -> lm_head -> argmax partials] as one launch each: 6 launches per block + 2 per token"}
+        model.fused_head = False
         model.v3 = False
     del model
     torch.cuda.empty_cache()

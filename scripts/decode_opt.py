@@ -30,7 +30,8 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quip_amd import ops, method  # noqa: E402
 from quip_amd.quant import (QuantLinear, packed_forward_fused, packed_v_stage, packed_gemm_stage, packed_u_stage,  # noqa: E402
-                            packed_u_then_v, packed_vgemm_stage, vgemm_fusable, fused_stage, fused_ok, fused_attention, fused_attention_ok, fused_u_only)
+                            packed_u_then_v, packed_vgemm_stage, vgemm_fusable, fused_stage, fused_ok, fused_attention, fused_attention_ok, fused_u_only,
+                            fused_head, fused_head_ok)
 
 
 class Block(nn.Module):
@@ -133,9 +134,22 @@ class Decoder(nn.Module):
                 and fused_ok([b.fc1], bs, prev=b.out_proj) and fused_ok([b.fc2], bs, prev=b.fc1, norm=False, residual=False))
 
     def step_v3(self, x, pos, caches):
-        """per block: [U_fc2^T(prev) + residual -> LN1 -> V_qkv -> GEMM qkv] [U_qkv^T (tiled)] [attention] [V_o -> GEMM o]
-        [U_o^T + residual -> LN2 -> V_fc1 -> GEMM fc1] [U_fc1^T + relu -> V_fc2 -> GEMM fc2]; the last block's U_fc2^T + residual is
-        one tiled operator launch."""
+        prev, y2, x = self.blocks_v3(x, pos, caches)
+        return fused_u_only(prev, y2, residual=x)
+
+    fused_head = False       # with v3: embedding (+ the previous step's argmax) and [U_fc2^T + residual -> final LN -> lm_head -> argmax partials,
+                             # pos += 1] as one launch each (csrc/decode_head.hip) instead of ~11 torch / rocBLAS launches per token
+
+    def step_fused_head(self, ids, pos, caches, logits, part_val, part_idx):
+        x = torch.empty((ids.numel(), self.h), dtype=torch.float16, device=ids.device)
+        ops.decode_embed(self.tok.weight, ids, x, pos_table=self.posemb.weight, pos=pos, pos_offset=2, part_val=part_val, part_idx=part_idx)
+        prev, y2, x = self.blocks_v3(x, pos, caches)
+        return fused_head(prev, y2, x, self.lnf, self.tok.weight, logits, part_val, part_idx, pos_inc=pos)
+
+    def blocks_v3(self, x, pos, caches):
+        """per block: [U_fc2^T(prev) + residual -> LN1 -> V_qkv -> GEMM qkv] [U_qkv^T + attention] [V_o -> GEMM o]
+        [U_o^T + residual -> LN2 -> V_fc1 -> GEMM fc1] [U_fc1^T + relu -> V_fc2 -> GEMM fc2]; returns (fc2 of the last block, its output
+        in the projected basis, the residual stream): the last U_fc2^T + residual belongs to whatever ends the step."""
         dt = x.dtype
         prev, y2 = None, None
         h16 = torch.float16                                     # y consumed by another fused launch: fp16 (its scatter rounds to fp16 anyway)
@@ -156,7 +170,7 @@ class Decoder(nn.Module):
             (y1,), x = fused_stage([blk.fc1], prev=blk.out_proj, y_prev=yo, residual=x, ln=blk.ln2, store=True, y_dtype=h16)
             y2 = fused_stage([blk.fc2], prev=blk.fc1, y_prev=y1, relu=True, y_dtype=h16)[0][0]
             prev = blk.fc2
-        return fused_u_only(prev, y2, residual=x)
+        return prev, y2, x
 
     tiled = False            # every operator application cut into 16 x 16 output tiles over 8-32 workgroups (csrc/ortho_tile.hip): 13 launches
 
@@ -228,7 +242,15 @@ def time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager):
     pos = torch.zeros(1, dtype=torch.int64, device=dev)
     logits_out = torch.zeros(bs, model.tok.weight.shape[0], dtype=dtype, device=dev)
 
+    fh = bool(getattr(model, 'fused_head', False) and getattr(model, 'v3', False))
+    if fh:        # the token comes out of the head launch's partials at the start of the next step; -1 = "none yet": the first step reads `ids`
+        part_val = torch.full((bs, ops.HEAD_PARTS), float("-inf"), dtype=torch.float32, device=dev)
+        part_idx = torch.full((bs, ops.HEAD_PARTS), -1, dtype=torch.int32, device=dev)
+
     def one():
+        if fh:
+            model.step_fused_head(ids, pos, caches, logits_out, part_val, part_idx)
+            return
         lg = model.step(ids, pos, caches, arange)
         logits_out.copy_(lg)
         if FAST_ARGMAX and lg.is_cuda:
@@ -318,6 +340,13 @@ def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense
                 med, mean, l3 = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
                 out[key] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
                             "logits_rel_diff_vs_chained": float((l3 - lc).norm() / lc.norm())}
+            if fused_head_ok(model.blocks[-1].fc2, bs, model.lnf):
+                model.fused_head = True                      # + csrc/decode_head.hip at both ends of the step: 5 launches per block + 2 per token
+                torch.manual_seed(7)
+                med, mean, lh3 = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+                out["packed_w%d_v3_head" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+                                                    "logits_rel_diff_vs_v3": float((lh3 - l3).norm() / l3.norm())}
+                model.fused_head = False
             model.v3 = False
         if v3_only:
             return out

@@ -111,7 +111,14 @@ def harness_logits(dec, toks, maxlen, dtype, graph=True):
     vocab = dec.tok.weight.shape[0]
     out = torch.zeros(1, vocab, dtype=torch.float32, device=DEV)
 
+    fh = bool(getattr(dec, 'fused_head', False) and dec.v3)    # csrc/decode_head.hip at both ends of the step (teacher-forced: no argmax partials)
+    out16 = torch.zeros(1, vocab, dtype=torch.float16, device=DEV)
+
     def one():
+        if fh:
+            dec.step_fused_head(ids, pos, caches, out16, None, None)      # increments pos itself
+            out.copy_(out16)
+            return
         out.copy_(dec.step(ids, pos, caches, arange))
         pos.add_(1)
     ids.fill_(toks[0])
@@ -180,6 +187,9 @@ def test_opt_decode_harness_matches_hf_with_past_key_values():
     assert dec.v3_ok(1)
     dec.v3 = True                                            # csrc/decode_fused.hip: 6 launches per block
     report["v3"] = _gate("v3", harness_logits(dec, toks, maxpos, dtype), ref, toks)
+    dec.fused_head = True                                    # + embedding and [U^T + residual -> final norm -> lm_head] as one launch each
+    report["v3_head"] = _gate("v3_head", harness_logits(dec, toks, maxpos, dtype), ref, toks)
+    dec.fused_head = False
     dec.v3 = False
     # and the dense harness (fp16 Linears with the twin weights): the architecture alone, no packed kernels
     dec.chained = dec.vfused = dec.split_handover = dec.tiled = False
@@ -215,6 +225,9 @@ def test_llama_decode_harness_matches_hf_with_past_key_values():
     assert dec.v3_ok(1)
     dec.v3 = True                                            # fused launches (64 x 32 operators at hidden 2048) + rotary in the attention prologue
     report["v3"] = _gate("v3", harness_logits(dec, toks, maxpos, dtype), ref, toks)
+    dec.fused_head = True                                    # + embedding and [U^T + residual -> final norm -> lm_head] as one launch each
+    report["v3_head"] = _gate("v3_head", harness_logits(dec, toks, maxpos, dtype), ref, toks)
+    dec.fused_head = False
     dec.v3 = False
     for li, blk in enumerate(dec.blocks):
         blk.fused = False
