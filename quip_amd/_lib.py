@@ -68,6 +68,7 @@ SIGNATURES = {
     "quipamd_decode_attention_fused": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_i64, c_float, c_i64, c_vp],
     "quipamd_rope_inplace": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_int, c_i64, c_i64, c_vp],
     "quipamd_cholesky_lt": [c_vp, c_vp, c_i64, c_vp, c_vp],
+    "quipamd_cholesky_config": [c_int, c_int],
     "quipamd_hessian_accum": [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp],
     "quipamd_hessian_finish": [c_vp, c_double, c_vp, c_i64, c_vp],
     "quipamd_hessian_fast_workspace": [c_i64, c_i64],
@@ -96,7 +97,7 @@ def load():
         except AttributeError as e:
             raise QuipAmdError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else None if name == "quipamd_vecquant_invalidate" else
+        fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else None if name in ("quipamd_vecquant_invalidate", "quipamd_cholesky_config") else
                       c_i64 if name in ("quipamd_hessian_fast_workspace", "quipamd_vecquant_workspace_bytes") else c_int)
     _lib = lib
     return lib

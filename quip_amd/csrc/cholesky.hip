@@ -27,6 +27,7 @@
 namespace {
 
 constexpr int NB = 64;
+bool g_chol_old_syrk = false;          // tests: force the guarded round-1 trailing-update kernel
 
 __device__ __forceinline__ float lane_bcast(float v, int lane)
 {
@@ -295,6 +296,91 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(float *A, int64_t d, 
             }
 }
 
+
+// The same update for tiles that lie wholly inside the matrix (every tile when d and `base` are multiples of the tile size: all of the
+// model shapes), written for the memory system: round 1's kernel guarded every element (r < d && c < d), which hipcc turns into one
+// branch + one dependent round trip per load -- 16 serial trips per stage and 64 serial read-modify-writes per wave in the epilogue,
+// ~118 us for a 7 us tile's worth of MFMAs (profiles/r03y_k8_trace.txt: 4.25 of 10.5 ms at d = 8192).  Here every load of a phase is in
+// flight at once (stage: 16 float4 per thread; epilogue: 64 dwords per lane), and the two workgroups of a CU cover each other's
+// memory phases with their MFMAs.  (Prefetching the C tile and the second panel under the first panel's MFMAs wants 256 registers.)
+template <int WT>
+__global__ __launch_bounds__(256, 2) void chol_syrk_full_kernel(float *A, int64_t d, int64_t prow0, int nk, int64_t base, int strip)
+{
+    constexpr int BN = 32 * WT, LDW = BN + 16, EPT = BN / 16, NV = EPT / 4, NP = NB / 16;
+    static_assert(EPT % 4 == 0, "float4 staging");
+    extern __shared__ __attribute__((aligned(16))) float cs[];     // [2 sides][NB][LDW]
+    int I, J;
+    if (strip) { I = 0; J = blockIdx.x; }
+    else tri_tile(blockIdx.x, I, J);
+    const bool diag = I == J;
+    const int64_t i0 = base + (int64_t)I * BN, j0 = base + (int64_t)J * BN;
+    const float *P = A + prow0 * d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int stok = tid >> 4, scol = (tid & 15) * EPT;
+
+    f32x4_t acc[WT][WT], cc[WT][WT];
+#pragma unroll
+    for (int x = 0; x < WT; ++x)
+#pragma unroll
+        for (int y = 0; y < WT; ++y) acc[x][y] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const float *As = cs + wi * (WT * 16) + (lane & 15);
+    const float *Bs = cs + NB * LDW + wj * (WT * 16) + (lane & 15);
+    float *Ct = A + (i0 + wi * (WT * 16) + 4 * (lane >> 4)) * d + j0 + wj * (WT * 16) + (lane & 15);   // D layout: col = lane & 15, row = 4 (lane >> 4) + reg
+
+    for (int sg = 0; sg < nk; ++sg) {
+        if (sg) __syncthreads();                                    // every read of the previous panel's stage retired
+        {
+            const float *Pp = P + (int64_t)sg * NB * d + (int64_t)stok * d + scol;
+            float4 s0[NP * NV], s1[NP * NV];
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float *row = Pp + (int64_t)(16 * ps) * d + 4 * v;
+                    s0[ps * NV + v] = *reinterpret_cast<const float4 *>(row + i0);
+                    s1[ps * NV + v] = *reinterpret_cast<const float4 *>(row + j0);     // (diag: the same lines again, L1 hits)
+                }
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    *reinterpret_cast<float4 *>(cs + (16 * ps + stok) * LDW + scol + 4 * v) = s0[ps * NV + v];
+                    *reinterpret_cast<float4 *>(cs + (NB + 16 * ps + stok) * LDW + scol + 4 * v) = s1[ps * NV + v];
+                }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            const int row = ks * 4 + (lane >> 4);
+            float a[WT], b[WT];
+#pragma unroll
+            for (int x = 0; x < WT; ++x) a[x] = As[row * LDW + x * 16];
+#pragma unroll
+            for (int y = 0; y < WT; ++y) b[y] = Bs[row * LDW + y * 16];
+#pragma unroll
+            for (int x = 0; x < WT; ++x)
+#pragma unroll
+                for (int y = 0; y < WT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+    }
+    (void)diag;
+    // the C tile: all 16 WT^2 loads of the lane in flight, then the subtractions, then the stores (the other workgroup of the CU has the
+    // matrix pipe meanwhile)
+#pragma unroll
+    for (int x = 0; x < WT; ++x)
+#pragma unroll
+        for (int y = 0; y < WT; ++y)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) cc[x][y][reg] = Ct[(int64_t)(x * 16 + reg) * d + y * 16];
+#pragma unroll
+    for (int x = 0; x < WT; ++x)
+#pragma unroll
+        for (int y = 0; y < WT; ++y)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Ct[(int64_t)(x * 16 + reg) * d + y * 16] = cc[x][y][reg] - acc[x][y][reg];
+}
+
 template <int WT> int launch_syrk(float *A, int64_t d, int64_t prow0, int nk, int64_t base, bool strip, hipStream_t s)
 {
     constexpr int BN = 32 * WT, LDW = BN + 16;
@@ -306,9 +392,21 @@ template <int WT> int launch_syrk(float *A, int64_t d, int64_t prow0, int nk, in
     if ((attr_done_d < 0 || !attr_done_dev.done[attr_done_d])) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: cannot reserve %zu B of LDS", lds);
+        if constexpr (WT >= 2) {
+            if (hipFuncSetAttribute((const void *)chol_syrk_full_kernel<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: cannot reserve %zu B of LDS", lds);
+        }
         if (attr_done_d >= 0) attr_done_dev.done[attr_done_d] = true;
     }
-    kern<<<(unsigned)(strip ? T : T * (T + 1) / 2), 256, lds, s>>>(A, d, prow0, nk, base, strip ? 1 : 0);
+    const unsigned grid = (unsigned)(strip ? T : T * (T + 1) / 2);
+    if constexpr (WT >= 2) {
+        // every tile inside the matrix, float4-aligned rows: the branch-free kernel
+        if (rem % BN == 0 && d % 4 == 0 && base % 4 == 0 && !g_chol_old_syrk) {
+            chol_syrk_full_kernel<WT><<<grid, 256, lds, s>>>(A, d, prow0, nk, base, strip ? 1 : 0);
+            return QUIPAMD_OK;
+        }
+    }
+    kern<<<grid, 256, lds, s>>>(A, d, prow0, nk, base, strip ? 1 : 0);
     return QUIPAMD_OK;
 }
 
@@ -331,7 +429,39 @@ __global__ __launch_bounds__(256) void chol_finish_kernel(float *A, int64_t d)
     for (int64_t j = threadIdx.x; j < d; j += 256) A[c * d + j] = (j > c) ? A[c * d + j] * rinv : 0.f;
 }
 
+// side stream + events of the look-ahead, one set per device, created on first use (never destroyed: process lifetime)
+struct ChoLook {
+    hipStream_t side = nullptr;
+    hipEvent_t panels[4] = {}, trail[4] = {};
+    hipEvent_t pending = nullptr;
+    bool ok = false;
+};
+ChoLook *chol_look()
+{
+    static ChoLook per_dev[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    ChoLook &L = per_dev[dev];
+    if (!L.ok) {
+        if (hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (int i = 0; i < 4; ++i)
+            if (hipEventCreateWithFlags(&L.panels[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&L.trail[i], hipEventDisableTiming) != hipSuccess)
+                return nullptr;
+        L.ok = true;
+    }
+    L.pending = nullptr;
+    return &L;
+}
+bool g_chol_no_lookahead = false;
+
 }   // namespace
+
+extern "C" void quipamd_cholesky_config(int old_syrk, int no_lookahead)
+{
+    g_chol_old_syrk = old_syrk != 0;
+    g_chol_no_lookahead = no_lookahead != 0;
+}
 
 extern "C" int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *info, void *stream)
 {
@@ -349,8 +479,13 @@ extern "C" int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *in
         else chol_diag_kernel<false><<<1, 64, 0, s>>>(LT, d, k0, info);
     };
     // two 64-row panels per trailing update: diag, panel, [64-row strip update so the second panel can be factored],
-    // diag, panel, then ONE rank-128 update of everything behind the pair
-    for (int64_t k0 = 0; k0 < d; k0 += 2 * NB) {
+    // diag, panel, then ONE rank-128 update of everything behind the pair.
+    // Look-ahead (round 3): the trailing update is cut in two.  The 128 rows the NEXT pair factors are updated on the caller's stream
+    // (a strip launch); everything below them goes to a side stream and runs under the next pair's diag / panel / strip / diag / panel
+    // chain (~75 us of launches that occupy one to a few dozen CUs): the factorisation is then as long as its serial chain.
+    ChoLook *look = (d >= 1024 && !g_chol_no_lookahead) ? chol_look() : nullptr;
+    int pair = 0;
+    for (int64_t k0 = 0; k0 < d; k0 += 2 * NB, ++pair) {
         diag(k0);
         if (d - k0 - NB <= 0) break;
         chol_panel_mfma_kernel<<<(unsigned)((d - k0 - NB + 63) / 64), 256, 0, s>>>(LT, d, k0);
@@ -359,8 +494,32 @@ extern "C" int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *in
         diag(k0 + NB);
         if (d - k0 - 2 * NB <= 0) break;
         chol_panel_mfma_kernel<<<(unsigned)((d - k0 - 2 * NB + 63) / 64), 256, 0, s>>>(LT, d, k0 + NB);
-        rc = trailing_update(LT, d, k0, 2, k0 + 2 * NB, s);
-        if (rc != QUIPAMD_OK) return rc;
+        const int64_t base = k0 + 2 * NB;
+        if (look && d - base > 2 * NB && (d - base) % (2 * NB) == 0) {
+            hipEvent_t evp = look->panels[pair & 3], evt = look->trail[pair & 3];
+            if (hipEventRecord(evp, s) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: event record failed");
+            // rows base .. base+127 wait for the previous pair's side-stream update of the same rows
+            if (pair > 0 && hipStreamWaitEvent(s, look->trail[(pair - 1) & 3], 0) != hipSuccess)
+                return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: stream wait failed");
+            rc = launch_syrk<4>(LT, d, k0, 2, base, true, s);
+            if (rc != QUIPAMD_OK) return rc;
+            if (hipStreamWaitEvent(look->side, evp, 0) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: stream wait failed");
+            rc = trailing_update(LT, d, k0, 2, base + 2 * NB, look->side);
+            if (rc != QUIPAMD_OK) return rc;
+            if (hipEventRecord(evt, look->side) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: event record failed");
+            look->pending = evt;
+        } else {
+            if (look && look->pending) {                                          // the tail of the matrix: back on one stream
+                if (hipStreamWaitEvent(s, look->pending, 0) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: stream wait failed");
+                look->pending = nullptr;
+            }
+            rc = trailing_update(LT, d, k0, 2, base, s);
+            if (rc != QUIPAMD_OK) return rc;
+        }
+    }
+    if (look && look->pending) {
+        if (hipStreamWaitEvent(s, look->pending, 0) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: stream wait failed");
+        look->pending = nullptr;
     }
     chol_finish_kernel<<<(unsigned)d, 256, 0, s>>>(LT, d);
     QA_LAUNCH_CHECK("cholesky_lt");

@@ -58,11 +58,9 @@ __global__ __launch_bounds__(1024) void head_kernel(HeadArgs G)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bs = G.bs;
     // this wave's rows: a contiguous run
-    const int64_t nwaves = (int64_t)gridDim.x * 16;
-    const int64_t per = (G.vocab + nwaves - 1) / nwaves;
-    const int64_t row_lo = ((int64_t)blockIdx.x * 16 + wave) * per;
-    int64_t row_hi = row_lo + per;
-    row_hi = row_hi < G.vocab ? row_hi : G.vocab;
+    // (runs differ by at most one row: with ceil(vocab / waves) rows each, 50272 rows left 15 of 256 workgroups without any)
+    const int64_t nwaves = (int64_t)gridDim.x * 16, wid = (int64_t)blockIdx.x * 16 + wave;
+    const int64_t row_lo = wid * G.vocab / nwaves, row_hi = (wid + 1) * G.vocab / nwaves;
 
     // ---- requests of the prologue, then the first weight rows --------------------------------------------------------------------------
     uint4 yc = make_uint4(0u, 0u, 0u, 0u), yc2 = yc;
@@ -108,17 +106,21 @@ __global__ __launch_bounds__(1024) void head_kernel(HeadArgs G)
     auto load_rows = [&](uint4 (&dst)[HD_RB][NI], int64_t r0) {
 #pragma unroll
         for (int rr = 0; rr < HD_RB; ++rr) {
-            int64_t row = r0 + rr;
-            row = row < G.vocab ? row : G.vocab - 1;                              // past the end: a valid row, result dropped
-            const uint4 *src = reinterpret_cast<const uint4 *>(G.W + row * N);
+            const int64_t row = r0 + rr;
+            if (row < row_hi) {                                                  // wave-uniform: rows past the run are not fetched (they are another wave's)
+                const uint4 *src = reinterpret_cast<const uint4 *>(G.W + row * N);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + lane + 64 * i));
-                dst[rr][i] = make_uint4(t[0], t[1], t[2], t[3]);
+                for (int i = 0; i < NI; ++i) {
+                    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + lane + 64 * i));
+                    dst[rr][i] = make_uint4(t[0], t[1], t[2], t[3]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) dst[rr][i] = make_uint4(0u, 0u, 0u, 0u);
             }
         }
     };
-    if (row_lo < row_hi) load_rows(w, row_lo);
+    load_rows(w, row_lo);
 
     // ---- prologue: t = U^T y + bias + residual -> norm -> H -----------------------------------------------------------------------------
     for (int b = 0; b < bs; ++b) {
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(1024) void head_kernel(HeadArgs G)
 #pragma unroll
     for (int b = 0; b < HD_MAXBS; ++b) { best[b] = -INFINITY; bidx[b] = 0x7fffffff; }
     for (int64_t r0 = row_lo; r0 < row_hi; r0 += HD_RB) {
-        load_rows(wn, r0 + HD_RB);                                               // the next batch travels while this one is multiplied (clamped past the end)
+        load_rows(wn, r0 + HD_RB);                                               // the next batch travels while this one is multiplied
         float keep[HD_MAXBS] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int b = 0; b < HD_MAXBS; ++b) {

@@ -849,6 +849,11 @@ def cholesky_lt(H, check=True):
     return LT
 
 
+def cholesky_config(old_syrk=False, no_lookahead=False):
+    """tests / A-B measurements: K8 with the guarded round-1 trailing-update kernel and / or on one stream (process-wide switch)"""
+    _lib.load().quipamd_cholesky_config(int(bool(old_syrk)), int(bool(no_lookahead)))
+
+
 def ldlq_round(Wgrid, LT, bits, eta=None, return_err=False):
     """LDLQ codes uint8 [m,d] (vector_balance.py:155-199 / 218-257)."""
     _need_gpu(Wgrid, LT)
