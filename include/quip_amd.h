@@ -515,8 +515,9 @@ int quipamd_hessian_accum_fast(const void *x, int x_dtype, int64_t ldx, int64_t 
  *   info: DEVICE int, 0 on success, else 1 + the first column whose pivot was not positive (LAPACK potrf convention) --
  *   the factor is then meaningless. */
 int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *info, void *stream);
-/* tests / A-B measurements: force the guarded round-1 trailing-update kernel and / or the single-stream schedule (process-wide). */
-void quipamd_cholesky_config(int old_syrk, int no_lookahead);
+/* tests / A-B measurements (process-wide): old_syrk != 0 forces the guarded round-1 trailing-update kernel; lookahead 0 = never use the
+ * two-stream schedule, 1 = from d = 1024, anything else = the default (from d = 12288, where it starts to pay). */
+void quipamd_cholesky_config(int old_syrk, int lookahead);
 
 /* Rotary position embedding of one decode step, in place on q [bs, heads * hd] and k [bs, kv_heads * hd] (row strides ldq, ldk)
  * at position *pos (DEVICE memory: the launch can be replayed in a hipGraph while the position advances):

@@ -134,10 +134,15 @@ __global__ __launch_bounds__(256) void chol_panel_mfma_kernel(float *A, int64_t 
     __shared__ __attribute__((aligned(16))) float Wi[4][16][20];         // Wi[i][r][k] = (U_ii^T)^-1 [r][k]
     {
         const float *U = A + k0 * d + k0;
+        constexpr int NU = NB * NB / 256;
+        const int r0 = threadIdx.x >> 6, cc = threadIdx.x & 63;
+        float t1[NU];
 #pragma unroll
-        for (int u = 0; u < NB * NB / 256; ++u) {
-            const int idx = u * 256 + threadIdx.x, r = idx >> 6, cc = idx & 63;
-            UT[cc][r] = cc >= r ? U[(int64_t)r * d + cc] : 0.f;
+        for (int u = 0; u < NU; ++u) t1[u] = U[(int64_t)(4 * u + r0) * d + cc];     // in flight together; the select comes after
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int r = 4 * u + r0;
+            UT[cc][r] = cc >= r ? t1[u] : 0.f;
         }
     }
     __syncthreads();
@@ -297,19 +302,52 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_kernel(float *A, int64_t d, 
 }
 
 
+// (the stage is written as macros: hipcc keeps the float4 arrays in registers only when the loads and the LDS writes are inlined text --
+//  behind a lambda or a forceinline function taking the arrays by reference they went through scratch memory)
+#define QA_SYRK_FETCH(S0, S1, PP)                                                                                  \
+    _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) _Pragma("unroll") for (int v = 0; v < NV; ++v)              \
+    {                                                                                                              \
+        const float *row_ = (PP) + (int64_t)(16 * ps) * d + 4 * v;                                                 \
+        S0[ps * NV + v] = *reinterpret_cast<const f32x4_t *>(row_ + i0);                                            \
+        S1[ps * NV + v] = *reinterpret_cast<const f32x4_t *>(row_ + j0); /* diagonal tile: the same lines, L1 hits */ \
+    }
+#define QA_SYRK_PUT(S0, S1)                                                                                        \
+    _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) _Pragma("unroll") for (int v = 0; v < NV; ++v)              \
+    {                                                                                                              \
+        *reinterpret_cast<f32x4_t *>(cput + (16 * ps) * LDW + 4 * v) = S0[ps * NV + v];                             \
+        *reinterpret_cast<f32x4_t *>(cput + (NB + 16 * ps) * LDW + 4 * v) = S1[ps * NV + v];                        \
+    }
+template <int WT, int LDW> __device__ __forceinline__ void syrk_mfmas(f32x4_t (&acc)[WT][WT], const float *As, const float *Bs, int lane)
+{
+#pragma unroll 4
+    for (int ks = 0; ks < NB / 4; ++ks) {
+        const int row = ks * 4 + (lane >> 4);
+        float a[WT], b[WT];
+#pragma unroll
+        for (int x = 0; x < WT; ++x) a[x] = As[row * LDW + x * 16];
+#pragma unroll
+        for (int y = 0; y < WT; ++y) b[y] = Bs[row * LDW + y * 16];
+#pragma unroll
+        for (int x = 0; x < WT; ++x)
+#pragma unroll
+            for (int y = 0; y < WT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b[y], acc[x][y], 0, 0, 0);
+    }
+}
+
 // The same update for tiles that lie wholly inside the matrix (every tile when d and `base` are multiples of the tile size: all of the
 // model shapes), written for the memory system: round 1's kernel guarded every element (r < d && c < d), which hipcc turns into one
 // branch + one dependent round trip per load -- 16 serial trips per stage and 64 serial read-modify-writes per wave in the epilogue,
 // ~118 us for a 7 us tile's worth of MFMAs (profiles/r03y_k8_trace.txt: 4.25 of 10.5 ms at d = 8192).  Here every load of a phase is in
 // flight at once (stage: 16 float4 per thread; epilogue: 64 dwords per lane), and the two workgroups of a CU cover each other's
 // memory phases with their MFMAs.  (Prefetching the C tile and the second panel under the first panel's MFMAs wants 256 registers.)
-template <int WT>
-__global__ __launch_bounds__(256, 2) void chol_syrk_full_kernel(float *A, int64_t d, int64_t prow0, int nk, int64_t base, int strip)
+template <int WT, int NK>
+__global__ __launch_bounds__(256, 2) void chol_syrk_full_kernel(float *A, int64_t d, int64_t prow0, int64_t base, int strip)
 {
     constexpr int BN = 32 * WT, LDW = BN + 16, EPT = BN / 16, NV = EPT / 4, NP = NB / 16;
     static_assert(EPT % 4 == 0, "float4 staging");
     extern __shared__ __attribute__((aligned(16))) float cs[];     // [2 sides][NB][LDW]
     int I, J;
+    const int abl = 0;
     if (strip) { I = 0; J = blockIdx.x; }
     else tri_tile(blockIdx.x, I, J);
     const bool diag = I == J;
@@ -328,51 +366,35 @@ __global__ __launch_bounds__(256, 2) void chol_syrk_full_kernel(float *A, int64_
     const float *Bs = cs + NB * LDW + wj * (WT * 16) + (lane & 15);
     float *Ct = A + (i0 + wi * (WT * 16) + 4 * (lane >> 4)) * d + j0 + wj * (WT * 16) + (lane & 15);   // D layout: col = lane & 15, row = 4 (lane >> 4) + reg
 
-    for (int sg = 0; sg < nk; ++sg) {
-        if (sg) __syncthreads();                                    // every read of the previous panel's stage retired
-        {
-            const float *Pp = P + (int64_t)sg * NB * d + (int64_t)stok * d + scol;
-            float4 s0[NP * NV], s1[NP * NV];
-#pragma unroll
-            for (int ps = 0; ps < NP; ++ps)
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const float *row = Pp + (int64_t)(16 * ps) * d + 4 * v;
-                    s0[ps * NV + v] = *reinterpret_cast<const float4 *>(row + i0);
-                    s1[ps * NV + v] = *reinterpret_cast<const float4 *>(row + j0);     // (diag: the same lines again, L1 hits)
-                }
-#pragma unroll
-            for (int ps = 0; ps < NP; ++ps)
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    *reinterpret_cast<float4 *>(cs + (16 * ps + stok) * LDW + scol + 4 * v) = s0[ps * NV + v];
-                    *reinterpret_cast<float4 *>(cs + (NB + 16 * ps + stok) * LDW + scol + 4 * v) = s1[ps * NV + v];
-                }
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int ks = 0; ks < NB / 4; ++ks) {
-            const int row = ks * 4 + (lane >> 4);
-            float a[WT], b[WT];
-#pragma unroll
-            for (int x = 0; x < WT; ++x) a[x] = As[row * LDW + x * 16];
-#pragma unroll
-            for (int y = 0; y < WT; ++y) b[y] = Bs[row * LDW + y * 16];
-#pragma unroll
-            for (int x = 0; x < WT; ++x)
-#pragma unroll
-                for (int y = 0; y < WT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], b[y], acc[x][y], 0, 0, 0);
-        }
-    }
+    // Software pipeline (the two workgroups of a CU start together and run the same phases: they do NOT cover each other's memory
+    // phases -- ablations at d = 8192: MFMAs 1.24 ms, staging 0.43, C read-modify-write 0.60, purely additive):
+    //   stage(panel 0) | [panel 1's loads in flight] MFMAs(panel 0) | stage(panel 1) | [the C tile's loads in flight] MFMAs(panel 1) | C - acc
+    // acc + one of {stage registers, C tile} live at a time: 128 + addressing registers, two waves per SIMD.
+    f32x4_t s0[NP * NV], s1[NP * NV];                                // (native vectors: arrays of HIP's float4 struct live across the MFMAs went to scratch)
     (void)diag;
-    // the C tile: all 16 WT^2 loads of the lane in flight, then the subtractions, then the stores (the other workgroup of the CU has the
-    // matrix pipe meanwhile)
+    (void)abl;
+    const float *Pp = P + (int64_t)stok * d + scol;
+    float *cput = cs + stok * LDW + scol;
+    QA_SYRK_FETCH(s0, s1, Pp)
+    QA_SYRK_PUT(s0, s1)
+    __syncthreads();
+    if constexpr (NK == 2) {
+        f32x4_t t0[NP * NV], t1[NP * NV];                           // (arrays of their own: one written on two paths goes to scratch)
+        QA_SYRK_FETCH(t0, t1, Pp + (int64_t)NB * d)
+        __builtin_amdgcn_sched_barrier(0);                          // (hipcc otherwise sinks these loads below the 256 MFMAs they are to travel under)
+        syrk_mfmas<WT, LDW>(acc, As, Bs, lane);
+        __syncthreads();                                            // every read of panel 0's stage retired
+        QA_SYRK_PUT(t0, t1)
+        __syncthreads();
+    }
 #pragma unroll
     for (int x = 0; x < WT; ++x)
 #pragma unroll
         for (int y = 0; y < WT; ++y)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) cc[x][y][reg] = Ct[(int64_t)(x * 16 + reg) * d + y * 16];
+    __builtin_amdgcn_sched_barrier(0);
+    syrk_mfmas<WT, LDW>(acc, As, Bs, lane);
 #pragma unroll
     for (int x = 0; x < WT; ++x)
 #pragma unroll
@@ -393,7 +415,8 @@ template <int WT> int launch_syrk(float *A, int64_t d, int64_t prow0, int nk, in
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: cannot reserve %zu B of LDS", lds);
         if constexpr (WT >= 2) {
-            if (hipFuncSetAttribute((const void *)chol_syrk_full_kernel<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            if (hipFuncSetAttribute((const void *)chol_syrk_full_kernel<WT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                hipFuncSetAttribute((const void *)chol_syrk_full_kernel<WT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: cannot reserve %zu B of LDS", lds);
         }
         if (attr_done_d >= 0) attr_done_dev.done[attr_done_d] = true;
@@ -402,7 +425,8 @@ template <int WT> int launch_syrk(float *A, int64_t d, int64_t prow0, int nk, in
     if constexpr (WT >= 2) {
         // every tile inside the matrix, float4-aligned rows: the branch-free kernel
         if (rem % BN == 0 && d % 4 == 0 && base % 4 == 0 && !g_chol_old_syrk) {
-            chol_syrk_full_kernel<WT><<<grid, 256, lds, s>>>(A, d, prow0, nk, base, strip ? 1 : 0);
+            if (nk == 2) chol_syrk_full_kernel<WT, 2><<<grid, 256, lds, s>>>(A, d, prow0, base, strip ? 1 : 0);
+            else chol_syrk_full_kernel<WT, 1><<<grid, 256, lds, s>>>(A, d, prow0, base, strip ? 1 : 0);
             return QUIPAMD_OK;
         }
     }
@@ -443,7 +467,11 @@ ChoLook *chol_look()
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     ChoLook &L = per_dev[dev];
     if (!L.ok) {
-        if (hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        // LOWEST priority: the side stream's grids fill every CU (2 workgroups each: 147 of 160 KB of LDS), and the chain's kernels on
+        // the caller's stream must win the slots those workgroups free
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+        if (hipStreamCreateWithPriority(&L.side, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
         for (int i = 0; i < 4; ++i)
             if (hipEventCreateWithFlags(&L.panels[i], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&L.trail[i], hipEventDisableTiming) != hipSuccess)
@@ -453,14 +481,15 @@ ChoLook *chol_look()
     L.pending = nullptr;
     return &L;
 }
-bool g_chol_no_lookahead = false;
+bool g_chol_no_lookahead = false, g_chol_force_lookahead = false;
 
 }   // namespace
 
-extern "C" void quipamd_cholesky_config(int old_syrk, int no_lookahead)
+extern "C" void quipamd_cholesky_config(int old_syrk, int lookahead)
 {
     g_chol_old_syrk = old_syrk != 0;
-    g_chol_no_lookahead = no_lookahead != 0;
+    g_chol_no_lookahead = lookahead == 0;
+    g_chol_force_lookahead = lookahead == 1;
 }
 
 extern "C" int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *info, void *stream)
@@ -482,8 +511,10 @@ extern "C" int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *in
     // diag, panel, then ONE rank-128 update of everything behind the pair.
     // Look-ahead (round 3): the trailing update is cut in two.  The 128 rows the NEXT pair factors are updated on the caller's stream
     // (a strip launch); everything below them goes to a side stream and runs under the next pair's diag / panel / strip / diag / panel
-    // chain (~75 us of launches that occupy one to a few dozen CUs): the factorisation is then as long as its serial chain.
-    ChoLook *look = (d >= 1024 && !g_chol_no_lookahead) ? chol_look() : nullptr;
+    // chain (~60 us of launches that occupy one to a few dozen CUs).  The three cross-stream hand-overs per pair cost ~15 us, and the
+    // chain's kernels share the CUs with the update: measured on one box (profiles/r03z2_k8_ab.txt) a loss up to d = 8192 (6.2 -> 6.8
+    // ms), even at 11008, a gain at 16384 (26.1 -> 24.8 ms) -- on from d = 12288 (g_chol_force_lookahead: the tests run it from 1024).
+    ChoLook *look = (d >= (g_chol_force_lookahead ? 1024 : 12288) && !g_chol_no_lookahead) ? chol_look() : nullptr;
     int pair = 0;
     for (int64_t k0 = 0; k0 < d; k0 += 2 * NB, ++pair) {
         diag(k0);

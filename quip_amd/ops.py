@@ -849,9 +849,10 @@ def cholesky_lt(H, check=True):
     return LT
 
 
-def cholesky_config(old_syrk=False, no_lookahead=False):
-    """tests / A-B measurements: K8 with the guarded round-1 trailing-update kernel and / or on one stream (process-wide switch)"""
-    _lib.load().quipamd_cholesky_config(int(bool(old_syrk)), int(bool(no_lookahead)))
+def cholesky_config(old_syrk=False, lookahead=None):
+    """tests / A-B measurements: K8 with the guarded round-1 trailing-update kernel and / or the two-stream look-ahead schedule forced on
+    (True: from d = 1024) or off (False); None = the default (from d = 12288).  Process-wide switch."""
+    _lib.load().quipamd_cholesky_config(int(bool(old_syrk)), -1 if lookahead is None else int(bool(lookahead)))
 
 
 def ldlq_round(Wgrid, LT, bits, eta=None, return_err=False):

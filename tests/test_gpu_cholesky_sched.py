@@ -1,6 +1,6 @@
-"""-m gpu: K8's round-3 schedule (branch-free trailing-update kernel for interior tiles, the trailing update cut in two with the far part on
-a side stream under the next pair's serial chain) against the round-1 form of the same factorisation: every tile performs the same
-operations in the same order, so the factors must agree BIT FOR BIT -- a lost dependency between the two streams would show here."""
+"""-m gpu: K8's round-3 schedule against the round-1 form of the same factorisation.  The branch-free, software-pipelined trailing-update
+kernel and the two-stream look-ahead perform, per tile, the same operations in the same order as the guarded single-stream form:
+the factors must agree BIT FOR BIT -- a lost dependency between the two streams would show here."""
 import pytest
 import torch
 
@@ -8,24 +8,26 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("d", [1024, 1152, 2048, 4096, 2176, 1100, 11008])
+@pytest.mark.parametrize("d", [128, 192, 1024, 1152, 2048, 4096, 2176, 1100, 11008, 12288])
 def test_schedule_is_bit_identical_to_the_single_stream_guarded_form(d):
     from quip_amd import ops
     torch.manual_seed(d)
     X = torch.randn(d + 256, d, device=DEV)
     H = X.T @ X / d + 0.01 * torch.eye(d, device=DEV)
     try:
-        ops.cholesky_config(old_syrk=True, no_lookahead=True)
+        ops.cholesky_config(old_syrk=True, lookahead=False)
         ref = ops.cholesky_lt(H)
-        ops.cholesky_config(old_syrk=False, no_lookahead=True)
+        ops.cholesky_config(old_syrk=False, lookahead=False)
         a = ops.cholesky_lt(H)
-        ops.cholesky_config(old_syrk=False, no_lookahead=False)
+        ops.cholesky_config(old_syrk=False, lookahead=True)
         outs = [ops.cholesky_lt(H) for _ in range(3)]             # repeated: a race would not lose every time
         side = torch.cuda.Stream()                                  # and from a non-default stream
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             outs.append(ops.cholesky_lt(H))
         torch.cuda.current_stream().wait_stream(side)
+        ops.cholesky_config()
+        outs.append(ops.cholesky_lt(H))                           # the default schedule
     finally:
         ops.cholesky_config()
     assert torch.equal(a, ref)
