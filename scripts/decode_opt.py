@@ -388,7 +388,14 @@ def run(layers=24, bits=2, bs=1, prompt=128, tokens=128, eager=False, with_dense
         med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
         out["packed_w%d_v3" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
                                        "what": "csrc/decode_fused.hip: U^T(prev) + residual -> norm -> V -> GEMM in ONE launch per packed layer group "
-                                               "(fp16 operator pass in the GEMM prologue); 6 launches per block"}
+                                               "(fp16 operator pass in the GEMM prologue); 5 launches per block"}
+        if fused_head_ok(model.blocks[-1].fc2, bs, model.lnf):
+            model.fused_head = True
+            med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
+            out["packed_w%d_v3_head" % bits] = {"ms_per_token_median": med * 1e3, "tok_per_s": bs / med,
+                                                "what": "as v3 + csrc/decode_head.hip: the embedding (with the previous step's argmax) and [U_fc2^T + residual -> "
+                                                        "final LayerNorm -> lm_head -> argmax partials] as one launch each: 5 launches per block + 2 per token"}
+            model.fused_head = False
         model.v3 = False
     model.tiled = True
     med, mean, _ = time_decode(model, bs, prompt, tokens, maxlen, dev, dtype, eager)
