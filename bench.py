@@ -101,9 +101,19 @@ def main():
     fn = lib.quipamd_dequant_gemm
     vp = ctypes.c_void_p
 
+    # lab switch (A/B runs of kernel configurations on one box, never set by the driver): QUIP_K2_CFG="family,p1,p2" routes the timed
+    # launches through quipamd_dequant_gemm_cfg with that configuration forced
+    k2cfg = os.environ.get("QUIP_K2_CFG")
+    cfg_arr = (ctypes.c_int32 * 4)(*([int(v) for v in k2cfg.split(",")] + [0])[:4]) if k2cfg else None
+    fn_cfg = lib.quipamd_dequant_gemm_cfg
+
     def launch(qw, stream):
-        rc = fn(vp(x.data_ptr()), 2, vp(qw.data_ptr()), BITS, 1, 1, vp(scale.data_ptr()), vp(0), vp(0),
-                vp(y.data_ptr()), 2, 0, BS, M, D, stream)
+        if cfg_arr is not None:
+            rc = fn_cfg(vp(x.data_ptr()), 2, vp(qw.data_ptr()), BITS, 1, 1, vp(scale.data_ptr()), vp(0), vp(0),
+                        vp(y.data_ptr()), 2, 0, BS, M, D, cfg_arr, stream)
+        else:
+            rc = fn(vp(x.data_ptr()), 2, vp(qw.data_ptr()), BITS, 1, 1, vp(scale.data_ptr()), vp(0), vp(0),
+                    vp(y.data_ptr()), 2, 0, BS, M, D, stream)
         if rc:
             raise RuntimeError(lib.quipamd_last_error())
 

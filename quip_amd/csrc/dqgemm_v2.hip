@@ -41,6 +41,7 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
             if (p1 == 0) { p1 = nkc <= 8 ? 8 : 8; p2 = nkc <= 8 ? 1 : 2; }
             if (p1 == 8 && p2 == 1 && nkc <= 8) return launch_h<2, ACT, 1, 8, 1>(A, s);
             if (p1 == 8 && p2 == 2) return launch_h<2, ACT, 1, 8, 2>(A, s);
+            if (p1 == 16 && p2 == 1 && nkc <= 16) return launch_h<2, ACT, 1, 16, 1>(A, s);
             if (p1 == 4 && p2 == 4) return launch_h<2, ACT, 1, 4, 4>(A, s);
         } else {
             if (p1 == 0) { p1 = 8; p2 = nkc <= 16 ? 2 : 4; }
