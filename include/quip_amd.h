@@ -507,6 +507,18 @@ int64_t quipamd_hessian_fast_workspace(int64_t tokens, int64_t d);
 int quipamd_hessian_accum_fast(const void *x, int x_dtype, int64_t ldx, int64_t tokens, int64_t d, double *Hacc,
                                void *workspace, void *stream);
 
+/* OPTQ / GPTQ with the qfn-b quantiser (`--quant gptq --incoh_processing`; gptq.py:56-93 with quant.py:10-15,158-160): every column is
+ * rounded on ITS OWN scale 2.4 sqrt(mean over all m rows of w'^2) + 1e-16, w' the column after the feedback of all earlier columns --
+ * d grid-wide reductions in series (csrc/gptq_qfnb.hip: co-resident workgroups exchange their partial sums through data-tagged granules).
+ *   q = scale * ((clamp(round((w' / scale + 1) / 2 * maxq), 0, maxq) / maxq) * 2 - 1);   r = w' - q;   w'_j += r FT[j'][c']  (j' < c')
+ * in the coordinates of quipamd_gptq_round (columns reversed, FT strictly upper), with W, Q held TRANSPOSED:
+ *   WT_rev: float [d, m] in / scratch (updated in place);  QT_rev: float [d, m] out;  colscale_rev: float [d] out, the scale of every
+ *   column;  workspace: quipamd_gptq_qfnb_workspace_bytes(m, d) bytes.  m <= 32768 (at most 256 workgroups wait for each other: the
+ *   launch assumes they are all resident, i.e. the GPU is not shared with another long-running grid).  Deterministic. */
+int64_t quipamd_gptq_qfnb_workspace_bytes(int64_t m, int64_t d);
+int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits, float *QT_rev, float *colscale_rev, void *workspace, int64_t m,
+                            int64_t d, void *stream);
+
 /* ---- K8: LDL factor for LDLQ ---------------------------------------------------------------------------
  * Replaces `L = torch.linalg.cholesky(H); L = L @ diag(1/diag(L))` (vector_balance.py:171-173) plus the transpose K4
  * wants:  LT[c][j] = U[c][j] * (1 / U[c][c]) for j > c, 0 elsewhere, where H = U^T U (U upper = C^T).

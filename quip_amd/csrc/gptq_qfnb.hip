@@ -1,0 +1,225 @@
+// gptq_qfnb.hip -- OPTQ / GPTQ with the qfn-b quantiser (`--quant gptq --incoh_processing`: gptq.py:56-93 with quant.py:148-151).
+//
+// Quantizer.quantize recomputes ONE scale from ALL rows of every column it is handed (scale = 2.4 sqrt(mean(w^2)) + 1e-16,
+// quant.py:158-160), and GPTQ hands it the columns one at a time, each already carrying the feedback of every earlier column: the sweep
+// is d grid-wide reductions in series.  K4 (ldlq.hip) gives a workgroup 16 rows for the whole sweep and cannot hold that; rounds 1-3a
+// ran this configuration as the reference's column walk in torch (~10 launches per column, ~0.4 s per 4096 x 4096 Linear).  Here:
+//
+//   gptqb_chain_kernel   one launch per 128-column lazy block, G = ceil(m / R) co-resident workgroups of R rows.  The block of W and the
+//                        128 x 128 tile of the feedback matrix live in LDS; per column: partial sum of squares of the workgroup's rows ->
+//                        a data-tagged 8-byte granule per workgroup in global memory (tag = column number: no counter, no fence, no
+//                        read-modify-write -- the form MI355X_MICROARCH.md measures fastest for an all-gather of small values) -> every
+//                        workgroup polls the G granules, sums them in a fixed order (deterministic), forms the scale, quantises its
+//                        rows, and feeds the residual to the block's remaining columns.  ~3 us per column.
+//   gptqb_far_kernel     W[:, before the block] += R_block @ FT[.., block]  on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32
+//                        fma chains), all CUs.
+//
+// Coordinates as in quipamd_gptq_round: columns REVERSED (c' = d-1-c), feedback FT[j'][c'] = -Hinv[c][j] / Hinv[c][c] strictly upper,
+// raw residual r = w - q, so the sweep runs c' = d-1 .. 0 and updates j' < c'.  W, Q and the residuals are held TRANSPOSED ([d][m]): a
+// column of the workgroup's rows is one contiguous run.
+#include "common.h"
+#include "fpass.h"
+
+namespace {
+
+constexpr int GB_NB = 128, GB_T = 256;
+
+struct GbArgs {
+    float *WT;                    // [d][m] reversed columns, updated in place
+    const float *FT;              // [d][d]
+    float *QT;                    // [d][m] out: dequantised weights
+    float *ET;                    // [128][m] residuals of the block
+    float *colscale;              // [d] out (reversed)
+    unsigned long long *gran;     // [2][G] granules {tag : 32, partial : 32}
+    int64_t m, d;
+    int b0, nb, G;
+    float maxq;
+};
+
+__device__ __forceinline__ float gb_quant(float w, float s, float maxq)
+{
+    // quantize_qfnb, quant.py:10-15, the operations in the reference's order (fp32)
+    float v = __fdiv_rn(w, s);
+    v = (v + 1.0f) * 0.5f;
+    v = v * maxq;
+    const float q = fminf(fmaxf(rintf(v), 0.0f), maxq);              // torch.round: half to even
+    float t = __fdiv_rn(q, maxq);
+    t = t * 2.0f - 1.0f;
+    return t * s;
+}
+
+template <int R>
+__global__ __launch_bounds__(GB_T) void gptqb_chain_kernel(GbArgs A)
+{
+    constexpr int NCG = GB_T / R;                                     // column groups: thread (r, cg) owns the columns == cg (mod NCG)
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float *W1 = gsm;                                                  // [128][R]
+    float *F1 = gsm + GB_NB * R;                                      // [128][128]: F1[jl][cl] = FT[b0 + jl][b0 + cl]
+    float *E = F1 + GB_NB * GB_NB;                                    // [R]
+    float *red = E + R;                                               // [R] squares, then [0] = the column's sum
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = tid % R, cg = tid / R;
+    const int wg = blockIdx.x, G = A.G, nb = A.nb, b0 = A.b0;
+    const int64_t row = (int64_t)wg * R + r;
+    const bool live = row < A.m;
+
+    const int64_t rowc = live ? row : A.m - 1;                        // (clamped address + select: a guarded load is a branch and a round trip)
+    for (int cl = cg; cl < nb; cl += NCG) {
+        const float v = A.WT[(int64_t)(b0 + cl) * A.m + rowc];
+        W1[cl * R + r] = live ? v : 0.f;
+    }
+    for (int i = tid; i < nb * nb; i += GB_T) {
+        const int jl = i / nb, cl = i - jl * nb;
+        F1[jl * GB_NB + cl] = A.FT[(int64_t)(b0 + jl) * A.d + b0 + cl];
+    }
+    __syncthreads();
+    const float fm = (float)A.m;
+    for (int cl = nb - 1; cl >= 0; --cl) {
+        const int cp = b0 + cl;                                       // reversed column index
+        const bool owner = cg == cl % NCG;
+        float w = 0.f;
+        if (owner) {
+            w = W1[cl * R + r];
+            red[r] = w * w;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float p = 0.f;
+            for (int i = lane; i < R; i += 64) p += red[i];
+            p = fg_wave_sum(p);
+            const unsigned tag = (unsigned)(A.d - cp);               // 1 .. d, unique per column of the sweep
+            unsigned long long *gr = A.gran + (size_t)(tag & 1) * G;
+            if (lane == 0)
+                __hip_atomic_store(gr + wg, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, p), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            // gather: lane l polls granules l, l + 64, ...; the values are summed in a fixed order
+            float s = 0.f;
+            for (int i = lane; i < G; i += 64) {
+                unsigned long long v;
+                do {
+                    v = __hip_atomic_load(gr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((unsigned)(v >> 32) != tag);
+                s += __builtin_bit_cast(float, (unsigned)v);
+            }
+            s = fg_wave_sum(s);
+            if (lane == 0) red[0] = s;
+        }
+        __syncthreads();
+        const float S = red[0];
+        const float scale = 2.4f * sqrtf(__fdiv_rn(S, fm)) + 1e-16f;     // quant.py:159
+        if (owner) {
+            const float q = gb_quant(w, scale, A.maxq);
+            const float res = live ? w - q : 0.f;                       // rows past m stay zero: they are part of every column's sum
+            if (live) A.QT[(int64_t)cp * A.m + row] = q;
+            W1[cl * R + r] = res;
+            E[r] = res;
+            if (wg == 0 && r == 0) A.colscale[cp] = scale;
+        }
+        __syncthreads();
+        const float e = E[r];
+        for (int jl = cg; jl < cl; jl += NCG) W1[jl * R + r] = fmaf(e, F1[jl * GB_NB + cl], W1[jl * R + r]);
+        // (the next column's owner reads what this very thread wrote; E and red are rewritten behind the next two barriers)
+    }
+    __syncthreads();
+    if (live)
+        for (int cl = cg; cl < nb; cl += NCG) A.ET[(int64_t)cl * A.m + row] = W1[cl * R + r];
+}
+
+// WT[j'][rows] += sum_cl FT[j'][b0 + cl] ET[cl][rows] for j' < b0.  Workgroup = 64 j' x 64 rows, wave = 16 j' x 64 rows (4 tiles).
+__global__ __launch_bounds__(256) void gptqb_far_kernel(GbArgs A)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int jc = lane & 15, g = lane >> 4;
+    const int64_t j0 = (int64_t)blockIdx.x * 64 + 16 * wave, r0 = (int64_t)blockIdx.y * 64;
+    if (j0 >= A.b0) return;
+    const int64_t ja = j0 + jc < A.b0 ? j0 + jc : A.b0 - 1;          // A operand row (clamped: its results are not stored)
+    const float *Fa = A.FT + ja * A.d + A.b0;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int nb = A.nb;
+    for (int kk = 0; kk < nb; kk += 16) {
+        float a[4], b[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = kk + 4 * g + s;                              // this lane group's k of instruction s
+            const int kc = k < nb ? k : nb - 1;                        // clamped addresses, selects afterwards: every load in flight at once
+            const float av = Fa[kc];
+            a[s] = k < nb ? av : 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int64_t rr = r0 + 16 * t + jc, rc = rr < A.m ? rr : A.m - 1;
+                b[s][t] = A.ET[(int64_t)kc * A.m + rc];                // (rows past m: garbage columns of D, not stored)
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s][t], acc[t], 0, 0, 0);
+    }
+    // D: col = rows (jc), row = j' = 4g + reg
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t jj = j0 + 4 * g + reg, rr = r0 + 16 * t + jc;
+            if (jj < A.b0 && rr < A.m) A.WT[jj * A.m + rr] += acc[t][reg];
+        }
+}
+
+template <int R> int gb_chain(const GbArgs &A, hipStream_t s)
+{
+    const size_t lds = (size_t)(GB_NB * R + GB_NB * GB_NB + 2 * R) * sizeof(float);
+    auto kern = gptqb_chain_kernel<R>;
+    static QaPerDevice attr;
+    const int dv = attr.dev();
+    if (lds > 64 * 1024 && (dv < 0 || !attr.done[dv])) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: cannot raise dynamic LDS to %zu", lds);
+        if (dv >= 0) attr.done[dv] = true;
+    }
+    kern<<<(unsigned)A.G, GB_T, lds, s>>>(A);
+    return QUIPAMD_OK;
+}
+
+}   // namespace
+
+extern "C" int64_t quipamd_gptq_qfnb_workspace_bytes(int64_t m, int64_t d)
+{
+    (void)d;
+    return (int64_t)GB_NB * m * 4 + 2 * 256 * 8;                      // residuals of a block + the granules
+}
+
+extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits, float *QT_rev, float *colscale_rev, void *workspace,
+                                       int64_t m, int64_t d, void *stream)
+{
+    QA_REQUIRE(m >= 0 && d >= 0, QUIPAMD_ERR_SHAPE, "gptq_round_qfnb: bad shape");
+    if (m == 0 || d == 0) return QUIPAMD_OK;
+    QA_REQUIRE(WT_rev && FT && QT_rev && colscale_rev && workspace, QUIPAMD_ERR_ARG, "gptq_round_qfnb: null pointer");
+    QA_REQUIRE(bits >= 1 && bits <= 8, QUIPAMD_ERR_ARG, "gptq_round_qfnb: bits");
+    // rows per workgroup: every workgroup of a launch must be resident at once (they wait for each other): at most 256
+    const int R = m > 128 * 128 ? 128 : m > 64 * 128 ? 64 : m > 32 * 64 ? 32 : 16;
+    const int64_t G = (m + R - 1) / R;
+    QA_REQUIRE(G <= 256, QUIPAMD_ERR_UNSUPPORTED, "gptq_round_qfnb: m = %lld rows need more than 256 co-resident workgroups", (long long)m);
+    hipStream_t s = (hipStream_t)stream;
+    GbArgs A;
+    A.WT = WT_rev; A.FT = FT; A.QT = QT_rev; A.colscale = colscale_rev;
+    A.ET = (float *)workspace;
+    A.gran = (unsigned long long *)((char *)workspace + (size_t)GB_NB * m * 4);
+    A.m = m; A.d = d; A.G = (int)G; A.maxq = (float)((1 << bits) - 1);
+    if (hipMemsetAsync(A.gran, 0, 2 * 256 * 8, s) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: memset failed");
+    // lazy blocks from the top of the reversed order; block edges at multiples of 128, so a remainder of d is the FIRST block (where a
+    // block ends only decides when its residuals reach the columns behind it, not what they are)
+    int64_t b1 = d;
+    while (b1 > 0) {
+        const int64_t nb = (b1 % GB_NB) ? (b1 % GB_NB) : GB_NB;
+        const int64_t b0 = b1 - nb;
+        A.b0 = (int)b0; A.nb = (int)nb;
+        int rc = R == 128 ? gb_chain<128>(A, s) : R == 64 ? gb_chain<64>(A, s) : R == 32 ? gb_chain<32>(A, s) : gb_chain<16>(A, s);
+        if (rc != QUIPAMD_OK) return rc;
+        if (b0 > 0) gptqb_far_kernel<<<dim3((unsigned)((b0 + 63) / 64), (unsigned)((m + 63) / 64)), 256, 0, s>>>(A);
+        b1 = b0;
+    }
+    QA_LAUNCH_CHECK("quipamd_gptq_round_qfnb");
+    return QUIPAMD_OK;
+}

@@ -9,8 +9,10 @@ matrix pipe instead of gptq.py:51-54's three rocSOLVER factorisations):
                            like gptq.py:72-75) and qfn c, in weight units with the reference's quantiser formula;
 (nn.Linear is the only layer kind the reference's own preproc / error_compute survive: method.py:187 and :232 index a
 Conv1D / Conv2d weight as if it were [out, in].)
-What the kernel cannot hold is qfn b -- Quantizer.quantize recomputes ONE scale from all rows of every updated column
-(quant.py:158-160), a grid-wide reduction per column -- and debug_equiv's float64: `_column_walk` serves those.
+  * ops.gptq_round_qfnb    qfn b (`--incoh_processing`): Quantizer.quantize recomputes ONE scale from all rows of every updated column
+                           (quant.py:158-160) -- d grid-wide reductions in series, which K4's 16-rows-per-workgroup sweep cannot hold:
+                           csrc/gptq_qfnb.hip (co-resident workgroups, data-tagged granules, ~3 us per column).
+`_column_walk` (the reference's loop, in torch) serves what is left: debug_equiv's float64, more than 32768 rows, in_features % 16 != 0.
 """
 import time
 
@@ -63,13 +65,22 @@ class GPTQ(QuantMethod):
         triangular inverse (ops.gptq_feedback) -- the Cholesky / inverse / Cholesky of gptq.py:51-54 is never formed."""
         qz = self.quantizer
         mq = int(qz.maxq.item()) if torch.is_tensor(qz.maxq) else int(qz.maxq)
-        ok = (USE_KERNEL and not debug_equiv and W.is_cuda and W.dim() == 2 and W.shape[1] % 16 == 0 and qz.qfn in ('a', 'c')
+        ok = (USE_KERNEL and not debug_equiv and W.is_cuda and W.dim() == 2 and W.shape[1] % 16 == 0 and qz.qfn in ('a', 'b', 'c')
               and mq in (1, 3, 7, 15, 255))
         if not ok:
             return None
         from . import ops
         m, d = W.shape
         bits = (mq + 1).bit_length() - 1
+        if qz.qfn == 'b':
+            # every column on its own scale, recomputed from all rows of the updated column (quant.py:158-160): whatever find_params left
+            # in the quantiser -- per group or not -- is overwritten before it is used, so one kernel serves every groupsize
+            if m > 32768:
+                return None
+            Q, colscale = ops.gptq_round_qfnb(W.float().contiguous(), ops.gptq_feedback(H.float()), bits)
+            qz.scale = colscale[-1].clone()                           # what the reference's quantiser is left holding: the last column's
+            self.column_scale = colscale
+            return Q.to(W.dtype)
         if groupsize == -1:
             if qz.scale.numel() not in (1, m):
                 return None

@@ -831,6 +831,22 @@ def gptq_round_groups(W, Hinv, bits, groupsize=-1, sym=False, qfn='a', scale=Non
     return out + (codes.flip(1).contiguous(),) if return_codes else out
 
 
+def gptq_round_qfnb(W, FT, bits):
+    """OPTQ with the qfn-b quantiser in the loop (gptq.py:56-93 + quant.py:10-15,158-160: every column on its own scale, recomputed from all
+    rows of the updated column) as csrc/gptq_qfnb.hip runs it.  W float32 [m, d], FT = gptq_feedback(H).  Returns (Q float32 [m, d], the
+    per-column scales float32 [d])."""
+    _need_gpu(W, FT)
+    assert W.dtype == torch.float32 and W.dim() == 2
+    m, d = W.shape
+    assert FT.shape == (d, d) and FT.dtype == torch.float32 and FT.is_contiguous()
+    wt = W.flip(1).t().contiguous()                                   # [d, m], columns reversed
+    qt = torch.empty_like(wt)
+    cs = torch.empty(d, dtype=torch.float32, device=W.device)
+    ws = torch.empty(int(_lib.load().quipamd_gptq_qfnb_workspace_bytes(m, d)), dtype=torch.uint8, device=W.device)
+    _lib.call("quipamd_gptq_round_qfnb", _p(wt), _p(FT), int(bits), _p(qt), _p(cs), _p(ws), m, d, _stream())
+    return qt.t().flip(1).contiguous(), cs.flip(0).contiguous()
+
+
 def cholesky_lt(H, check=True):
     """LT = D^-1 U strictly upper with H = U^T U: the unit-lower LDL factor of vector_balance.py:171-173, transposed,
     by the blocked fp32 factorisation of quip_amd/csrc/cholesky.hip (K8).  Raises torch.linalg.LinAlgError like

@@ -157,14 +157,15 @@ def test_gptq_groups_and_qfn_against_reference_golden(case):
     name, d, m, bits, gs, qfn, sym, kind = _golden_cases()[case]
     got, meth = _run_case(g, name, d, m, bits, gs, qfn, sym)
     ref = g[f"{name}_Q"]
-    kernel = qfn != 'b'
-    assert hasattr(meth, "group_scale") == (kernel and gs != -1)           # the K4 launch served it (not the column walk)
+    kernel = True                                                            # (round 3: qfn b runs on csrc/gptq_qfnb.hip)
+    assert hasattr(meth, "group_scale") == (qfn != 'b' and gs != -1)       # the K4 launch served it (not the column walk) ...
+    assert hasattr(meth, "column_scale") == (qfn == 'b')                   # ... or the per-column-scale kernel
     # a flipped code moves one weight by a whole grid step; everything after it in the row follows a slightly different path
     step = float(np.abs(ref).max()) / (2 ** bits - 1)
     flipped = np.abs(got - ref) > 0.25 * step
     assert flipped.mean() <= (1e-2 if kernel else 2e-2), flipped.mean()
     assert abs(meth.error - float(g[f"{name}_error"])) <= 2e-2 * float(g[f"{name}_error"])
-    if gs != -1 and kernel:                                                   # the quantiser left behind is the LAST group's
+    if gs != -1 and qfn != 'b':                                               # the quantiser left behind is the LAST group's
         np.testing.assert_allclose(meth.quantizer.scale.cpu().numpy().reshape(-1), g[f"{name}_scale"].reshape(-1), rtol=2e-2)
 
 
