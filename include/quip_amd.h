@@ -507,6 +507,16 @@ int64_t quipamd_hessian_fast_workspace(int64_t tokens, int64_t d);
 int quipamd_hessian_accum_fast(const void *x, int x_dtype, int64_t ldx, int64_t tokens, int64_t d, double *Hacc,
                                void *workspace, void *stream);
 
+/* ---- the elementwise / reduction chains of QuantMethod.preproc (method.py:134-193; csrc/preproc.hip) -------------------------------------
+ * quipamd_preproc_rescale (method.py:140-156):   H /= max|H|;   s = clamp(sqrt(sqrt(clamp(diag H, 1e-8) / clamp(diag(W^T W), 1e-8))), 1e-8);
+ *   W <- W s[None, :] rounded to its dtype;   H <- (H / s[None, :]) / s[:, None]       -- every operation in the reference's order, IEEE
+ *   divisions; the column sums of squares are fp32 sums in a fixed order (64-row partials, then the partials).
+ *   H: float [d, d] in place;  W: [m, d] of w_dtype in place;  s_out: float [d];  workspace: quipamd_preproc_workspace_bytes(m, d).
+ * quipamd_preproc_trace_ridge (method.py:165):   H <- H * (d / (trace(H) + 1e-8)) + ridge * I,   in place; workspace >= 4 bytes. */
+int64_t quipamd_preproc_workspace_bytes(int64_t m, int64_t d);
+int quipamd_preproc_rescale(float *H, void *W, int w_dtype, int64_t m, int64_t d, float *s_out, void *workspace, void *stream);
+int quipamd_preproc_trace_ridge(float *H, int64_t d, float ridge, void *workspace, void *stream);
+
 /* OPTQ / GPTQ with the qfn-b quantiser (`--quant gptq --incoh_processing`; gptq.py:56-93 with quant.py:10-15,158-160): every column is
  * rounded on ITS OWN scale 2.4 sqrt(mean over all m rows of w'^2) + 1e-16, w' the column after the feedback of all earlier columns --
  * d grid-wide reductions in series (csrc/gptq_qfnb.hip: co-resident workgroups exchange their partial sums through data-tagged granules).

@@ -68,6 +68,9 @@ SIGNATURES = {
     "quipamd_decode_attention_fused": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_i64, c_float, c_i64, c_vp],
     "quipamd_rope_inplace": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_i64, c_int, c_int, c_int, c_i64, c_i64, c_vp],
     "quipamd_cholesky_lt": [c_vp, c_vp, c_i64, c_vp, c_vp],
+    "quipamd_preproc_workspace_bytes": [c_i64, c_i64],
+    "quipamd_preproc_rescale": [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp],
+    "quipamd_preproc_trace_ridge": [c_vp, c_i64, c_float, c_vp, c_vp],
     "quipamd_gptq_qfnb_workspace_bytes": [c_i64, c_i64],
     "quipamd_gptq_round_qfnb": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp],
     "quipamd_cholesky_config": [c_int, c_int],
@@ -100,7 +103,7 @@ def load():
             raise QuipAmdError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else None if name in ("quipamd_vecquant_invalidate", "quipamd_cholesky_config") else
-                      c_i64 if name in ("quipamd_hessian_fast_workspace", "quipamd_vecquant_workspace_bytes", "quipamd_gptq_qfnb_workspace_bytes") else c_int)
+                      c_i64 if name in ("quipamd_hessian_fast_workspace", "quipamd_vecquant_workspace_bytes", "quipamd_gptq_qfnb_workspace_bytes", "quipamd_preproc_workspace_bytes") else c_int)
     _lib = lib
     return lib
 

@@ -21,6 +21,7 @@ import transformers
 from . import ops
 
 DEBUG = False
+FUSED_PREPROC = True      # False: preproc's rescale / trace-ridge chains as the torch elementwise ops they are in the reference
 HESSIAN_FAST = False     # True: K7's opt-in 16-bit-MFMA mode for add_batch (f16 / bf16 inputs; see include/quip_amd.h)
 DEVICE_RNG = False       # True: draw the Gaussians of the SO(p) sampler with torch's device generator instead of numpy's
                          # legacy stream -- same distribution (Haar), NOT the reference's seeded operators; removes the
@@ -230,18 +231,31 @@ class QuantMethod:
         written back in the layer's dtype after every stage exactly like the reference (method.py:155,179,191)."""
         self.preproc_gptqH, self.preproc_rescale, self.preproc_proj = preproc_gptqH, preproc_rescale, preproc_proj
         wdtype = self.layer.weight.data.dtype
+        fused = FUSED_PREPROC and self.layer.weight.data.is_cuda and self.layer.weight.data.dim() == 2 and \
+            self.layer.weight.data.dtype in (torch.float16, torch.bfloat16, torch.float32)
         if preproc_rescale:
-            w = self.layer.weight.data.to(torch.float32)
-            H = self.H.to(torch.float32)
-            H = H / H.abs().max()
-            diagH = torch.diag(H).clamp(min=1e-8)
-            diagW2 = (w * w).sum(0).clamp(min=1e-8)             # = diag(w^T w) without the d x d product
-            s = (diagH / diagW2).sqrt().sqrt().to(torch.float32).clamp(min=1e-8)
-            w = w * s[None, :]
-            H = (H / s[None, :]) / s[:, None]
-            self.scaleWH = s.cpu()
-            self.layer.weight.data = w.to(wdtype)
-            self.H = H.to(torch.float32)
+            if fused:
+                # the same operations in the same order as the torch chain below, in three launches (csrc/preproc.hip)
+                w = self.layer.weight.data.contiguous()
+                H = self.H.to(torch.float32).contiguous()
+                if H.data_ptr() == self.H.data_ptr():
+                    H = H.clone()                                   # the torch chain leaves the caller's H untouched too
+                s = ops.preproc_rescale(w, H)
+                self.scaleWH = s.cpu()
+                self.layer.weight.data = w
+                self.H = H
+            else:
+                w = self.layer.weight.data.to(torch.float32)
+                H = self.H.to(torch.float32)
+                H = H / H.abs().max()
+                diagH = torch.diag(H).clamp(min=1e-8)
+                diagW2 = (w * w).sum(0).clamp(min=1e-8)             # = diag(w^T w) without the d x d product
+                s = (diagH / diagW2).sqrt().sqrt().to(torch.float32).clamp(min=1e-8)
+                w = w * s[None, :]
+                H = (H / s[None, :]) / s[:, None]
+                self.scaleWH = s.cpu()
+                self.layer.weight.data = w.to(wdtype)
+                self.H = H.to(torch.float32)
         if preproc_proj:
             w = self.layer.weight.data.to(torch.float32)
             H = self.H.to(torch.float32)
@@ -251,7 +265,10 @@ class QuantMethod:
             U, V = ops.OrthoOp(self.projU, w.device), ops.OrthoOp(self.projV, w.device)
             self._U, self._V = U, V
             n = H.shape[0]
-            H = H * (n / (torch.trace(H) + 1e-8)) + 1e-2 * torch.eye(n, device=w.device)
+            if fused:
+                H = ops.preproc_trace_ridge(H.clone() if H.data_ptr() == self.H.data_ptr() else H.contiguous(), 1e-2)
+            else:
+                H = H * (n / (torch.trace(H) + 1e-8)) + 1e-2 * torch.eye(n, device=w.device)
             w = U.apply_cols(V.apply_rows(w))                    # U w V^T
             H = V.apply_rows(V.apply_rows(H).t().contiguous())   # V H V^T (H symmetric)
             self.layer.weight.data = w.to(wdtype)

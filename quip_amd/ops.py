@@ -831,6 +831,28 @@ def gptq_round_groups(W, Hinv, bits, groupsize=-1, sym=False, qfn='a', scale=Non
     return out + (codes.flip(1).contiguous(),) if return_codes else out
 
 
+def preproc_rescale(w, H):
+    """the diagonal rescale of QuantMethod.preproc (method.py:140-156) in three launches (csrc/preproc.hip):
+    H /= max|H|;  s = clamp((clamp(diag H) / clamp(diag W^T W)) ** 0.25);  W <- W s (columns, rounded to W's dtype);  H <- H / s_j / s_i.
+    w [m, d] (fp16 / bf16 / fp32) and H [d, d] fp32 are rewritten IN PLACE; returns s (fp32 [d])."""
+    _need_gpu(w, H)
+    m, d = w.shape
+    assert H.dtype == torch.float32 and H.shape == (d, d) and H.is_contiguous() and w.is_contiguous()
+    s = torch.empty(d, dtype=torch.float32, device=w.device)
+    ws = torch.empty(int(_lib.load().quipamd_preproc_workspace_bytes(m, d)), dtype=torch.uint8, device=w.device)
+    _lib.call("quipamd_preproc_rescale", _p(H), _p(w), _dtype(w), m, d, _p(s), _p(ws), _stream())
+    return s
+
+
+def preproc_trace_ridge(H, ridge):
+    """H <- H * (n / (trace(H) + 1e-8)) + ridge * I in place (method.py:165), two launches"""
+    _need_gpu(H)
+    assert H.dtype == torch.float32 and H.dim() == 2 and H.shape[0] == H.shape[1] and H.is_contiguous()
+    ws = torch.empty(64, dtype=torch.uint8, device=H.device)
+    _lib.call("quipamd_preproc_trace_ridge", _p(H), H.shape[0], float(ridge), _p(ws), _stream())
+    return H
+
+
 def gptq_round_qfnb(W, FT, bits):
     """OPTQ with the qfn-b quantiser in the loop (gptq.py:56-93 + quant.py:10-15,158-160: every column on its own scale, recomputed from all
     rows of the updated column) as csrc/gptq_qfnb.hip runs it.  W float32 [m, d], FT = gptq_feedback(H).  Returns (Q float32 [m, d], the
