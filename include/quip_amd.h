@@ -438,6 +438,8 @@ int quipamd_argmax_rows(const void *x, int dtype, int64_t rows, int64_t n, int64
  * Requires d % 16 == 0. */
 int quipamd_ldlq_round(const float *Wgrid, const float *LT, const float *eta, int bits, uint8_t *codes,
                        float *err_ws, int64_t m, int64_t d, void *stream);
+/* tests / A-B runs: K4 with 1 or 2 groups of 16 rows per workgroup forced (0: by the row count, 2 from 8192 rows on).  Process-wide. */
+void quipamd_ldlq_config(int row_groups);
 
 /* ---- OPTQ / GPTQ rounding on the K4 machinery -----------------------------------
  * Replaces the column loop + lazy block update of GPTQ.fasterquant (gptq.py:56-93, groupsize = -1):

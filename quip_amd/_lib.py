@@ -74,6 +74,7 @@ SIGNATURES = {
     "quipamd_gptq_qfnb_workspace_bytes": [c_i64, c_i64],
     "quipamd_gptq_round_qfnb": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp],
     "quipamd_cholesky_config": [c_int, c_int],
+    "quipamd_ldlq_config": [c_int],
     "quipamd_hessian_accum": [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp],
     "quipamd_hessian_finish": [c_vp, c_double, c_vp, c_i64, c_vp],
     "quipamd_hessian_fast_workspace": [c_i64, c_i64],
@@ -102,7 +103,7 @@ def load():
         except AttributeError as e:
             raise QuipAmdError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else None if name in ("quipamd_vecquant_invalidate", "quipamd_cholesky_config") else
+        fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else None if name in ("quipamd_vecquant_invalidate", "quipamd_cholesky_config", "quipamd_ldlq_config") else
                       c_i64 if name in ("quipamd_hessian_fast_workspace", "quipamd_vecquant_workspace_bytes", "quipamd_gptq_qfnb_workspace_bytes", "quipamd_preproc_workspace_bytes") else c_int)
     _lib = lib
     return lib

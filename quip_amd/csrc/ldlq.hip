@@ -73,20 +73,27 @@ __device__ __forceinline__ float round_col(float w, float acc, float eta, float 
 // (quant.py:57-94, perchannel, mse off) from the columns of the group as they stand when the group's 128-column block
 // starts -- far field of all finished blocks applied, nothing of the current block (gptq.py:72-75 reads the block-lazy W,
 // not W1): exactly the value `w + Ftile` the chain starts from.  Groups must not straddle a block: groupsize | 128.
-template <int MODE>
+// RG (round 3): row groups of 16 per workgroup.  At m >= 8192 a workgroup owns 32 rows: the 4 far waves multiply every staged LT slab
+// against the error rows of BOTH groups -- 16 KiB of slabs per 64 MFMAs instead of 12 KiB per 32 -- because the far field is bound by what
+// a CU can pull from L2 (every workgroup streams all of L: 21 B/clk/CU at 4096^2), not by the matrix pipe; the 4 chain waves run the
+// in-block chain of the two groups one after the other (it hides under the far field wherever a few thousand columns lie above the
+// block; 8 chain waves would cap the kernel at 168 registers, 8 rows per wave at once spilled 33).  The summation order of every row is
+// unchanged (the kernel-order oracle still matches bit for bit).
+template <int MODE, int RG>
 __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
 {
+    constexpr int NCH = 4, ROWS = 16 * RG, NSL = RG + 2;            // chain waves; rows per workgroup; slabs per far wave [A x RG | B0 | B1]
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ldiag = smem;                       // [BS][LDS_LD]: Ldiag[i][c] = L[i1+i][i1+c] (c < i), else 0
-    float *Ftile2 = smem + BS * LDS_LD;        // 2 x [16][BS] far-field results (block k is read while k+1 is produced)
-    char *slabs = reinterpret_cast<char *>(smem + BS * LDS_LD + 2 * 16 * BS);   // 4 far waves x 3 slabs x 4 KiB
+    float *Ftile = smem + BS * LDS_LD;         // [ROWS][BS] far-field results: written in phase Y, read at the start of the next phase X
+    char *slabs = reinterpret_cast<char *>(smem + BS * LDS_LD + ROWS * BS);     // 4 far waves x NSL slabs x 4 KiB
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool is_chain = wave < 4;
-    const int cw = wave & 3;                               // chain: row group; far: column-tile pair
+    const bool is_chain = wave < NCH;
+    const int cw = wave & 3;                               // chain: rows 4cw .. 4cw+3 of a group; far: column-tile pair
     const int64_t d = A.d;
-    const int64_t r0 = (int64_t)blockIdx.x * 16;
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS;
     const int fr = lane & 15, kq = lane >> 4;              // MFMA fragment coordinates
 
     // ---- diagonal block of L (strictly lower part) -> LDS, by the 256 threads of the chain waves ----------------------
@@ -121,12 +128,14 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
     // XOR-swizzled through the DMA's source address so the ds_read_b128 fragment reads are conflict free; the fragments
     // of a step are read into registers, THEN the next step's DMA is issued, so it flies under the 32 MFMAs.
     // k order: step k0 (64 wide), sub-step ss, lane group kq, element s -> k = k0 + 16 ss + 4 kq + s (oracle: ldlq_oracle.c).
-    auto far_accumulate = [&](f32x4_t &acc0, f32x4_t &acc1, int64_t kbeg, int64_t kend, int64_t nb1, int nbcnt) {
+    auto far_accumulate = [&](f32x4_t (&acc)[RG][2], int64_t kbeg, int64_t kend, int64_t nb1, int nbcnt) {
         const int t0 = cw, t1 = cw + 4, nt = nbcnt / 16;
         const bool v0 = t0 < nt, v1 = t1 < nt;
         if (!v0 || kbeg >= kend) return;
-        char *sl = slabs + cw * (3 * SLAB);                                         // [A | B0 | B1], 4 KiB each
-        const int64_t erows = (A.m - r0) < 16 ? (A.m - r0) : 16;
+        char *sl = slabs + cw * (NSL * SLAB);                                       // [A (x RG) | B0 | B1], 4 KiB each
+        // ONE descriptor for the workgroup's error rows (rows past m are past its end and read zeros); one per group spilled scalars into
+        // the DMA loop
+        const int64_t erows = (A.m - r0) < ROWS ? (A.m - r0) : ROWS;
         __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc((void *)(A.E + r0 * d), 0, (int)(erows * d * 4), 0x00020000);
         __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void *)(A.LT + nb1 * d), 0, (int)((int64_t)nbcnt * d * 4), 0x00020000);
         // DMA instruction q (0..3) moves rows 4q .. 4q+3: lane L -> row 4q + (L >> 4), physical 16-B column L & 15,
@@ -142,47 +151,54 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
                 const uint32_t row = 4 * q + drow;
                 const uint32_t kcol = (uint32_t)k0 + 4 * ((dpc ^ row) & 15);
                 const bool kin = kcol < (uint32_t)kend;
-                const uint32_t off = kin ? (row * (uint32_t)d + kcol) * 4u : OOB;          // out of range reads 0
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ers, (lds_void_t *)(sl + q * 1024), 16, off, 0, 0, 0);
+#pragma unroll
+                for (int gp = 0; gp < RG; ++gp) {
+                    const uint32_t off = kin ? ((16 * gp + row) * (uint32_t)d + kcol) * 4u : OOB;      // out of range reads 0
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ers, (lds_void_t *)(sl + gp * SLAB + q * 1024), 16, off, 0, 0, 0);
+                }
                 const uint32_t off0 = kin ? ((16 * t0 + row) * (uint32_t)d + kcol) * 4u : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void_t *)(sl + SLAB + q * 1024), 16, off0, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void_t *)(sl + RG * SLAB + q * 1024), 16, off0, 0, 0, 0);
                 if (v1) {
                     const uint32_t off1 = kin ? ((16 * t1 + row) * (uint32_t)d + kcol) * 4u : OOB;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void_t *)(sl + 2 * SLAB + q * 1024), 16, off1, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void_t *)(sl + (RG + 1) * SLAB + q * 1024), 16, off1, 0, 0, 0);
                 }
             }
         };
         issue(kbeg);
         for (int64_t k0 = kbeg; k0 < kend; k0 += 64) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // wave-private slabs: no barrier
-            float4 fa[4], fb0[4], fb1[4];
+            float4 fa[RG][4], fb0[4], fb1[4];
 #pragma unroll
             for (int ss = 0; ss < 4; ++ss) {
-                fa[ss] = *reinterpret_cast<const float4 *>(sl + rd[ss]);
-                fb0[ss] = *reinterpret_cast<const float4 *>(sl + SLAB + rd[ss]);
-                fb1[ss] = v1 ? *reinterpret_cast<const float4 *>(sl + 2 * SLAB + rd[ss]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int gp = 0; gp < RG; ++gp) fa[gp][ss] = *reinterpret_cast<const float4 *>(sl + gp * SLAB + rd[ss]);
+                fb0[ss] = *reinterpret_cast<const float4 *>(sl + RG * SLAB + rd[ss]);
+                fb1[ss] = v1 ? *reinterpret_cast<const float4 *>(sl + (RG + 1) * SLAB + rd[ss]) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // slab reads retired before it is refilled
             if (k0 + 64 < kend) issue(k0 + 64);
 #pragma unroll
             for (int ss = 0; ss < 4; ++ss) {
                 if (k0 + 16 * ss >= kend) break;                                    // wave-uniform; padded k would only add 0*0
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].x, fb0[ss].x, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].y, fb0[ss].y, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].z, fb0[ss].z, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].w, fb0[ss].w, acc0, 0, 0, 0);
-                if (v1) {
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].x, fb1[ss].x, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].y, fb1[ss].y, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].z, fb1[ss].z, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ss].w, fb1[ss].w, acc1, 0, 0, 0);
+#pragma unroll
+                for (int gp = 0; gp < RG; ++gp) {
+                    acc[gp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[gp][ss].x, fb0[ss].x, acc[gp][0], 0, 0, 0);
+                    acc[gp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[gp][ss].y, fb0[ss].y, acc[gp][0], 0, 0, 0);
+                    acc[gp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[gp][ss].z, fb0[ss].z, acc[gp][0], 0, 0, 0);
+                    acc[gp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[gp][ss].w, fb0[ss].w, acc[gp][0], 0, 0, 0);
+                    if (v1) {
+                        acc[gp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[gp][ss].x, fb1[ss].x, acc[gp][1], 0, 0, 0);
+                        acc[gp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[gp][ss].y, fb1[ss].y, acc[gp][1], 0, 0, 0);
+                        acc[gp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[gp][ss].z, fb1[ss].z, acc[gp][1], 0, 0, 0);
+                        acc[gp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[gp][ss].w, fb1[ss].w, acc[gp][1], 0, 0, 0);
+                    }
                 }
             }
         }
     };
 
     // ---- in-block sequential error feedback of block [i1, i1 + cnt), chain wave cw = rows 4cw .. 4cw+3 --------------------
-    auto chain = [&](int64_t i1, int cnt, const float *Ftile) {
+    auto chain = [&](int64_t i1, int cnt, const float *Ft, int gp) {
         float acc[4][2], wv[4][2], et[4][2];
         constexpr bool UPD = MODE == 1 || MODE == 3;
         float sc[4][2] = {}, zr[4][2] = {};                   // mode 3: quantiser of (row, this lane's column)
@@ -204,12 +220,12 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
         };
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int64_t row = r0 + 4 * cw + rr;
+            const int64_t row = r0 + 16 * gp + 4 * cw + rr;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int c = lane + 64 * h;
                 const bool ok = (c < cnt) && (row < A.m);
-                acc[rr][h] = (c < cnt) ? Ftile[(4 * cw + rr) * BS + c] : 0.f;
+                acc[rr][h] = (c < cnt) ? Ft[(16 * gp + 4 * cw + rr) * BS + c] : 0.f;
                 wv[rr][h] = ok ? A.W[row * d + i1 + c] : 0.f;
                 et[rr][h] = (ok && A.eta) ? A.eta[row * d + i1 + c] : (MODE == 2 ? 0.f : 0.5f);
             }
@@ -218,7 +234,7 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
             const int gs = A.groupsize;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int64_t row = r0 + 4 * cw + rr;
+                const int64_t row = r0 + 16 * gp + 4 * cw + rr;
                 if (gs <= 0) {
                     const float s1 = row < A.m ? A.gscale[row] : 1.f, z1 = row < A.m ? A.gzero[row] : 0.f;
                     sc[rr][0] = sc[rr][1] = s1;
@@ -293,7 +309,7 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
         // every column is final now (later steps only added err * 0): emit codes and errors
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int64_t row = r0 + 4 * cw + rr;
+            const int64_t row = r0 + 16 * gp + 4 * cw + rr;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int c = lane + 64 * h;
@@ -314,38 +330,42 @@ __global__ __launch_bounds__(512) void ldlq_kernel(LdlqArgs A)
     {
         const int64_t i1 = d - BS > 0 ? d - BS : 0;
         if (is_chain) stage_diag(i1, (int)(d - i1));
-        else for (int idx = (int)threadIdx.x - 256; idx < 16 * BS; idx += 256) Ftile2[idx] = 0.f;
+        else for (int idx = (int)threadIdx.x - 256; idx < ROWS * BS; idx += 256) Ftile[idx] = 0.f;
     }
     __syncthreads();
-    int buf = 0;
     for (int64_t i2 = d; i2 > 0; i2 -= BS) {
         const int64_t i1 = i2 - BS > 0 ? i2 - BS : 0;
         const int cnt = (int)(i2 - i1);
         const bool has_next = i1 > 0;
         const int64_t n1 = i1 - BS > 0 ? i1 - BS : 0;              // next block [n1, i1)
         const int ncnt = (int)(i1 - n1);
-        f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4_t acc[RG][2];
+#pragma unroll
+        for (int gp = 0; gp < RG; ++gp) acc[gp][0] = acc[gp][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         // phase X: chain(k)  ||  far(k+1) over the columns that are already final (>= i2)
-        if (is_chain) chain(i1, cnt, Ftile2 + buf * 16 * BS);
-        else if (has_next) far_accumulate(acc0, acc1, i2, d, n1, ncnt);
-        __syncthreads();                                           // block k's errors are written; Ldiag is free
+        if (is_chain) {
+#pragma unroll 1
+            for (int gp = 0; gp < RG; ++gp) chain(i1, cnt, Ftile, gp);             // one group of 16 rows after the other: the registers of ONE
+        }
+        else if (has_next) far_accumulate(acc, i2, d, n1, ncnt);
+        __syncthreads();                                           // block k's errors are written; Ldiag and Ftile are free
         // phase Y: stage the next diagonal block  ||  add block k's own columns to far(k+1) and publish it
         if (has_next) {
             if (is_chain) stage_diag(n1, ncnt);
             else {
-                far_accumulate(acc0, acc1, i1, i2, n1, ncnt);
-                float *Fn = Ftile2 + (buf ^ 1) * 16 * BS;
+                far_accumulate(acc, i1, i2, n1, ncnt);
                 const int t0 = cw, t1 = cw + 4, nt = ncnt / 16;
                 // D layout: col = lane & 15, row = 4*(lane>>4) + reg
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    if (t0 < nt) Fn[(4 * kq + reg) * BS + t0 * 16 + fr] = acc0[reg];
-                    if (t1 < nt) Fn[(4 * kq + reg) * BS + t1 * 16 + fr] = acc1[reg];
-                }
+                for (int gp = 0; gp < RG; ++gp)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        if (t0 < nt) Ftile[(16 * gp + 4 * kq + reg) * BS + t0 * 16 + fr] = acc[gp][0][reg];
+                        if (t1 < nt) Ftile[(16 * gp + 4 * kq + reg) * BS + t1 * 16 + fr] = acc[gp][1][reg];
+                    }
             }
         }
         __syncthreads();
-        buf ^= 1;
     }
 }
 
@@ -373,6 +393,8 @@ __global__ __launch_bounds__(256) void unit_lower_t_kernel(const float *__restri
 }   // namespace
 
 struct QuantSpec { float *scale, *zero; int groupsize, sym, qfn_c; };
+static int g_ldlq_rg = 0;        // tests / A-B runs: 1 or 2 row groups per workgroup forced, 0 = by the row count
+extern "C" void quipamd_ldlq_config(int row_groups) { g_ldlq_rg = row_groups == 1 || row_groups == 2 ? row_groups : 0; }
 
 template <int MODE>
 static int launch_ldlq(const float *Wgrid, const float *LT, const float *eta, int bits, uint8_t *codes, float *err_ws, int64_t m,
@@ -389,15 +411,22 @@ static int launch_ldlq(const float *Wgrid, const float *LT, const float *eta, in
     A.hd = hd; A.Wout = wout;
     A.gscale = A.gzero = nullptr; A.groupsize = 0; A.sym = 0; A.qfn_c = 0;
     if (quant) { A.gscale = quant->scale; A.gzero = quant->zero; A.groupsize = quant->groupsize; A.sym = quant->sym; A.qfn_c = quant->qfn_c; }
-    const size_t lds = (size_t)(BS * LDS_LD + 2 * 16 * BS) * sizeof(float) + 4 * 3 * SLAB;
+    // two row groups per workgroup from 8192 rows on (>= 256 workgroups of 32 rows): the LT slabs are then shared by twice the MFMAs
+    // (a 32-row workgroup takes ~1.6 x as long as a 16-row one and one workgroup fits a CU: fewer, longer rounds of 256 must pay --
+    //  8192 rows: 1 round instead of 2; 28672: 4 instead of 7; 11008: 2 instead of 3 does not)
+    const int64_t rounds1 = ((m + 15) / 16 + 255) / 256, rounds2 = ((m + 31) / 32 + 255) / 256;
+    const bool rg2 = (g_ldlq_rg == 2) || (g_ldlq_rg == 0 && m >= 8192 && 13 * rounds2 < 8 * rounds1);
+    const size_t lds1 = (size_t)(BS * LDS_LD + 16 * BS) * sizeof(float) + 4 * 3 * SLAB, lds2 = (size_t)(BS * LDS_LD + 32 * BS) * sizeof(float) + 4 * 4 * SLAB;
     static QaPerDevice attr_set_dev;                                  // per instantiation
     const int attr_set_d = attr_set_dev.dev();
     if ((attr_set_d < 0 || !attr_set_dev.done[attr_set_d])) {
-        if (hipFuncSetAttribute((const void *)ldlq_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return qa_fail(QUIPAMD_ERR_LAUNCH, "%s: cannot raise dynamic LDS to %zu", who, lds);
+        if (hipFuncSetAttribute((const void *)ldlq_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess ||
+            hipFuncSetAttribute((const void *)ldlq_kernel<MODE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "%s: cannot raise dynamic LDS to %zu", who, lds2);
         if (attr_set_d >= 0) attr_set_dev.done[attr_set_d] = true;
     }
-    ldlq_kernel<MODE><<<(unsigned)((m + 15) / 16), 512, lds, (hipStream_t)stream>>>(A);
+    if (rg2) ldlq_kernel<MODE, 2><<<(unsigned)((m + 31) / 32), 512, lds2, (hipStream_t)stream>>>(A);
+    else ldlq_kernel<MODE, 1><<<(unsigned)((m + 15) / 16), 512, lds1, (hipStream_t)stream>>>(A);
     QA_LAUNCH_CHECK(who);
     return QUIPAMD_OK;
 }

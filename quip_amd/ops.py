@@ -893,6 +893,11 @@ def cholesky_config(old_syrk=False, lookahead=None):
     _lib.load().quipamd_cholesky_config(int(bool(old_syrk)), -1 if lookahead is None else int(bool(lookahead)))
 
 
+def ldlq_config(row_groups=0):
+    """tests / A-B runs: K4 with 1 or 2 groups of 16 rows per workgroup forced (0 = by the row count).  Process-wide switch."""
+    _lib.load().quipamd_ldlq_config(int(row_groups))
+
+
 def ldlq_round(Wgrid, LT, bits, eta=None, return_err=False):
     """LDLQ codes uint8 [m,d] (vector_balance.py:155-199 / 218-257)."""
     _need_gpu(Wgrid, LT)
