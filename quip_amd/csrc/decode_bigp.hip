@@ -166,12 +166,13 @@ __device__ __forceinline__ uint32_t bg_gate2(uint32_t g2, uint32_t u2)
 template <int BS, int NRT, bool GATE>
 __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_over_maxq, float c0)
 {
-    typedef DeqT<2, ActF16> DQ;
+    typedef DeqME2<ActF16> DQ;                                                  // multi-exponent dequantisation (dq_common.h): needs sum OFF_k x~_k
     constexpr int XTS = 256 + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint16_t *XT = reinterpret_cast<uint16_t *>(smem);                          // [4][256 + 8] f16: x~ of the slice, k = 16 a_local + b
-    float *red = reinterpret_cast<float *>(smem + BG_MAXBS * XTS * 2);           // [4] sum x~
-    float *park = red + 4;                                                      // [16 waves][NRT][4][16]
+    float *red = reinterpret_cast<float *>(smem + BG_MAXBS * XTS * 2);           // [4] sum x~, [4] sum OFF x~
+    float *park = red + 8;                                                      // [16 waves][NRT][4][16]
+    const typename DQ::Consts qc = DQ::make_consts();
     float4 *part = reinterpret_cast<float4 *>(park + 16 * NRT * 64);            // [BS][nwp][64]
     asm volatile("" ::"s"(G.F0), "s"(G.M1), "s"(G.gate), "s"(G.up), "s"(G.ldx), "s"(G.qw), "s"(G.scale), "s"(G.y), "s"(G.m), "s"(G.p), "s"(G.ks));
     const int tid = threadIdx.x, lane = tid & 63;
@@ -243,9 +244,14 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
         pk.x = pack_f16x2(z2[0], z2[1]);
         pk.y = pack_f16x2(z2[2], z2[3]);
         *reinterpret_cast<uint2 *>(XT + r * XTS + 16 * j + 4 * g) = pk;
-        const float4 rv = f16x4_to_f32(pk);                                      // the sum the epilogue subtracts is the sum of what the MFMAs see
+        const float4 rv = f16x4_to_f32(pk);                                      // the sums the epilogue subtracts are sums of what the MFMAs see
         const float s = fg_wave_sum((rv.x + rv.y) + (rv.z + rv.w));
-        if (lane == 0) red[r] = s;
+        const int k0 = 16 * j + 4 * g;
+        const float so = fg_wave_sum(fmaf(me2_off_f16(k0), rv.x, fmaf(me2_off_f16(k0 + 1), rv.y, fmaf(me2_off_f16(k0 + 2), rv.z, me2_off_f16(k0 + 3) * rv.w))));
+        if (lane == 0) {
+            red[r] = s;
+            red[4 + r] = so;
+        }
     }
     __syncthreads();
 
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
     for (int k = 0; k < NRT; ++k)
 #pragma unroll
         for (int t = 0; t < DQ::NT; ++t) {
-            const u32x4 a = DQ::frag(u32x4{w[k].x, w[k].y, w[k].z, w[k].w}, t);
+            const u32x4 a = DQ::frag(u32x4{w[k].x, w[k].y, w[k].z, w[k].w}, t, qc);
             acc[k] = ActF16::mfma(a, u32x4{xf[t].x, xf[t].y, xf[t].z, xf[t].w}, acc[k]);
         }
     // D[row = 4g + reg][col = j]: lanes j < BS park their 4 rows; the wave re-reads them as 16 NRT consecutive rows per batch row
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
             const int k = l >> 4, wr = l & 15;
 #pragma unroll
             for (int r = 0; r < BS; ++r) {
-                const float val = alpha * (mine[(k * 4 + r) * 16 + wr] - c0 * red[r]);
+                const float val = alpha * ((mine[(k * 4 + r) * 16 + wr] - red[4 + r]) - c0 * red[r]);
                 unsafeAtomicAdd(G.y + (int64_t)r * G.m + (int64_t)rt0 * 16 + l, val);
             }
         }
@@ -348,13 +354,13 @@ extern "C" int quipamd_decode_bigp_v_gemm(const quipamd_bigp_v_gemm_args *a, voi
     QA_REQUIRE((nrt == 1 || nrt == 2 || nrt == 4) && a->m % (256 * nrt) == 0, QUIPAMD_ERR_ARG, "decode_bigp_v_gemm: row_tiles_per_wave 0 / 1 / 2 / 4 with m %% (256 x it) == 0");
     BVArgs A{(const uint4 *)a->F0, a->M1, (const uint16_t *)a->gate, (const uint16_t *)a->up, a->ldx, (const uint4 *)a->qweight, a->scale, a->y, a->m, p, (p + 31) / 32};
     const int nwp = (A.ks + 1) / 2, bs = (int)a->rows;
-    const float two_over_maxq = 2.0f / 3.0f, c0 = DeqT<2, ActF16>::OFF + 1.5f;
+    const float two_over_maxq = 2.0f / 3.0f, c0 = 1.5f;                            // maxq / 2: the per-field offsets are subtracted as sum OFF_k x~_k
     const dim3 grid((unsigned)(p / 16), (unsigned)(a->m / (256 * nrt)));
     hipStream_t s = (hipStream_t)stream;
 #define QA_BV(BS, NRT, GT)                                                                                                           \
     do {                                                                                                                             \
         auto kern = bigp_v_gemm_kernel<BS, NRT, GT>;                                                                                 \
-        const size_t lds = (size_t)BG_MAXBS * 264 * 2 + 16 + (size_t)16 * NRT * 64 * 4 + (size_t)BS * nwp * 64 * sizeof(float4);     \
+        const size_t lds = (size_t)BG_MAXBS * 264 * 2 + 32 + (size_t)16 * NRT * 64 * 4 + (size_t)BS * nwp * 64 * sizeof(float4);     \
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_bigp_v_gemm: cannot raise dynamic LDS to %zu", lds);                          \
         kern<<<grid, 1024, lds, s>>>(A, two_over_maxq, c0);                                                                          \

@@ -30,6 +30,14 @@ namespace {
 
 constexpr int FG_MAXG = 3, FG_MAXBS = 4, FG_NW = 16;
 
+// dequantiser of a launch: multi-exponent (DeqME2) or the uniform-offset form, behind one interface
+template <bool ME> struct DeqSelME : DeqME2<ActF16> {};
+template <> struct DeqSelME<false> : DeqT<2, ActF16> {
+    struct Consts { };
+    static __device__ __forceinline__ Consts make_consts() { return Consts{}; }
+    static __device__ __forceinline__ u32x4 frag(const u32x4 &w, int t, const Consts &) { return DeqT<2, ActF16>::frag(w, t); }
+};
+
 // lab builds (scripts/fusedlab.hip, -DFG_PROBE): s_memtime stamps of wave 0 of workgroup (FG_PROBE_WG, 0) at the phase boundaries
 #ifdef FG_PROBE
 __device__ unsigned long long fg_probe_buf[32];
@@ -107,7 +115,11 @@ template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int
 __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two_over_maxq, float c0)
 {
     typedef PassDims<P, Q> D;
-    typedef DeqT<2, ActF16> DQ;
+    // Multi-exponent dequantisation (dq_common.h: 10 instead of 16 VALU per packed dword, paid for with sum OFF_k x~_k in the prologue and
+    // the reducer) where a wave converts several row tiles against one x~ (Llama's NRT = 4 / 8: the conversion is 3.4 us of VALU issue in
+    // the gate/up launch); with one tile per wave (OPT) the bookkeeping costs more than it saves (measured, profiles/r03E).
+    constexpr bool ME = NRT >= 4;
+    typedef DeqSelME<ME> DQ;
     constexpr int N = D::N, NV = D::NV, NS = FG_NW / RT, NCH = N / 256, XTS = N + 8;      // x~ row stride (halves)
     constexpr int PB = NRT < 4 ? NRT : 4;                                       // row tiles (per parallel row slot) parked per batch
     constexpr bool EARLY = NV == 1;
@@ -120,7 +132,8 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     float *ZF = reinterpret_cast<float *>(pass + D::ZT_B + D::Z1_B);
     float *park = reinterpret_cast<float *>(pass);                              // [NS][RT PB][4][64]: after the last pass
     constexpr size_t PARK_B = (size_t)(FG_NW * PB * 256) * 4;
-    float *red = reinterpret_cast<float *>(pass + (D::BYTES > PARK_B ? D::BYTES : PARK_B));            // [2][16] norm, [bs][16] sum x~
+    float *red = reinterpret_cast<float *>(pass + (D::BYTES > PARK_B ? D::BYTES : PARK_B));            // [2][16] norm, [bs][16] sum x~, [bs][16] sum OFF x~
+    const typename DQ::Consts qc = DQ::make_consts();
 
     const int gi = blockIdx.y;
     const FGroup &Gg = G.g[gi];
@@ -358,9 +371,13 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         FG_STAMP(9);
         __syncthreads();
         FG_STAMP(10);
-        float xpart = mix_stage2_xt<P, Q>(Z1, XT + (size_t)b * XTS, frV, wave, lane);   // x~ in image order = the order of the weights' columns
-        xpart = fg_wave_sum(xpart);
-        if (lane == 0) red[2 * FG_NW + b * FG_NW + wave] = xpart;              // waves without tiles publish 0
+        const XtSums xp = mix_stage2_xt<P, Q, 16, ME>(Z1, XT + (size_t)b * XTS, frV, wave, lane);   // x~ in image order = the order of the weights' columns
+        const float xs1 = fg_wave_sum(xp.s1);
+        if (lane == 0) red[2 * FG_NW + b * FG_NW + wave] = xs1;                // waves without tiles publish 0
+        if constexpr (ME) {
+            const float xso = fg_wave_sum(xp.soff);
+            if (lane == 0) red[(2 + FG_MAXBS) * FG_NW + b * FG_NW + wave] = xso;
+        }
         FG_STAMP(11);
         __syncthreads();                                                        // x~ row complete; ZT / Z1 free for the next row (or park)
         FG_STAMP(12);
@@ -383,7 +400,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         for (int k = 0; k < NRT; ++k)
 #pragma unroll
             for (int t = 0; t < DQ::NT; ++t) {
-                const u32x4 a = DQ::frag(u32x4{w[k][i].x, w[k][i].y, w[k][i].z, w[k][i].w}, t);
+                const u32x4 a = DQ::frag(u32x4{w[k][i].x, w[k][i].y, w[k][i].z, w[k][i].w}, t, qc);
                 acc[k] = ActF16::mfma(a, u32x4{xf[t].x, xf[t].y, xf[t].z, xf[t].w}, acc[k]);
             }
     }
@@ -403,13 +420,16 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         if (wave < RT * PB) {                                                   // one reducer wave per parked row tile: lane = (batch row, row in tile)
             const int pr = wave, bb = lane >> 4, wr = lane & 15;                // pr = kk RT + r
             const int src = (wr & 3) * 64 + bb + 16 * (wr >> 2);               // [acc component][mfma lane (j = bb, g = wr / 4)]
-            float a = 0.f, xsum = 0.f;
+            float a = 0.f, xsum = 0.f, xoff = 0.f;
 #pragma unroll
             for (int v = 0; v < NS; ++v) a += park[(v * PB * RT + pr) * 256 + src];
 #pragma unroll
-            for (int v = 0; v < FG_NW; ++v) xsum += red[2 * FG_NW + bb * FG_NW + v];         // every wave published its part of sum x~
+            for (int v = 0; v < FG_NW; ++v) {                                     // every wave published its part of sum x~ (and sum OFF x~)
+                xsum += red[2 * FG_NW + bb * FG_NW + v];
+                if constexpr (ME) xoff += red[(2 + FG_MAXBS) * FG_NW + bb * FG_NW + v];
+            }
             const int64_t row = ((int64_t)blockIdx.x * (RT * NRT) + h * PB * RT + pr) * 16 + wr;
-            const float val = e_sc * two_over_maxq * (a - c0 * xsum);
+            const float val = e_sc * two_over_maxq * ((a - xoff) - (ME ? c0 : c0 + DeqT<2, ActF16>::OFF) * xsum);   // c0 = maxq / 2; ME: the offsets went with xoff
             if (bb < bs) {
                 if (G.y_f16) reinterpret_cast<uint16_t *>(Gg.y)[(int64_t)bb * G.m + row] = f32_to_f16_bits(val);
                 else reinterpret_cast<float *>(Gg.y)[(int64_t)bb * G.m + row] = val;
@@ -551,7 +571,7 @@ __global__ __launch_bounds__(1024) void fused_pair_kernel(FusedArgs G, float two
         FG_STAMP(9);
         __syncthreads();
         FG_STAMP(10);
-        float xpart = mix_stage2_xt<P, Q>(Z1, XT + (size_t)b * XTS, fr, wave, lane);
+        float xpart = mix_stage2_xt<P, Q>(Z1, XT + (size_t)b * XTS, fr, wave, lane).s1;
         xpart = fg_wave_sum(xpart);
         if (lane == 0) red[b * FG_NW + wave] = xpart;
         FG_STAMP(11);
@@ -621,7 +641,7 @@ template <int P, int Q, int NRT> constexpr size_t fused_lds()
 {
     typedef PassDims<P, Q> D;
     const size_t parkb = (size_t)(FG_NW * (NRT < 4 ? NRT : 4) * 256) * 4;
-    return (size_t)FG_MAXBS * (D::N + 8) * 2 + (D::BYTES > parkb ? D::BYTES : parkb) + (2 + FG_MAXBS) * FG_NW * 4 + 64;
+    return (size_t)FG_MAXBS * (D::N + 8) * 2 + (D::BYTES > parkb ? D::BYTES : parkb) + (2 + 2 * FG_MAXBS) * FG_NW * 4 + 64;
 }
 
 template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT, bool YF32 = false>
@@ -637,7 +657,7 @@ int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
         if (d >= 0) attr.done[d] = true;
     }
     const float maxq = 3.f;
-    kern<<<dim3((unsigned)(A.m / 16 / (RT * NRT)), (unsigned)ngroups), 1024, lds, s>>>(A, 2.0f / maxq, DeqT<2, ActF16>::OFF + 0.5f * maxq);
+    kern<<<dim3((unsigned)(A.m / 16 / (RT * NRT)), (unsigned)ngroups), 1024, lds, s>>>(A, 2.0f / maxq, 0.5f * maxq);
     QA_LAUNCH_CHECK("quipamd_decode_fused_gemm");
     return QUIPAMD_OK;
 }

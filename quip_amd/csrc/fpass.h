@@ -157,12 +157,25 @@ __device__ __forceinline__ void mix_stage2(const uint16_t *Z1, float *ZF, const 
 // permutation of V is folded into the packing, free at pack time), so the image IS x~: every lane rounds its four results to f16 and
 // writes them straight into the GEMM's operand row XT[a * Q + b] -- no fp32 image, no gather, no barrier in between.  Returns the
 // lane's sum of the rounded values (the epilogue's sum_k x~[k]).
-template <int P, int Q, int NW = 16>
-__device__ __forceinline__ float mix_stage2_xt(const uint16_t *Z1, uint16_t *XT, const PassFrags<P, Q> &fr, int wave, int lane)
+// The launches that read x~ dequantise their 2-bit codes with the multi-exponent scheme of dq_common.h (DeqME2: 10 instead of 16 VALU
+// per packed dword): the constant a code rides on depends on where it sits in its 16-bit half, so the epilogue needs
+// S_off = sum_k OFF_k x~_k beside S_1 = sum_k x~_k.  OFF_k for the element at index k of x~ (fp16 path): field i = 4 ((k >> 5) & 1) +
+// ((k & 7) >> 1) of the STREAM word, OFF = 2^(10 - pos(i)) = 64, 16, 64, 16, 4, 64, 16, 4.
+__device__ __forceinline__ float me2_off_f16(int k)
+{
+    const int i = ((k >> 3) & 4) | ((k & 7) >> 1);
+    const int p = MEField<ActF16>::pos(i);
+    return (float)(1 << (MEField<ActF16>::M - p));
+}
+struct XtSums {
+    float s1, soff;
+};
+template <int P, int Q, int NW = 16, bool OFFS = false>      // OFFS: also sum OFF_k x~_k (the consumer dequantises with DeqME2)
+__device__ __forceinline__ XtSums mix_stage2_xt(const uint16_t *Z1, uint16_t *XT, const PassFrags<P, Q> &fr, int wave, int lane)
 {
     typedef PassDims<P, Q, NW> D;
     const int j = lane & 15, g = lane >> 4;
-    float part = 0.f;
+    XtSums part = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < D::TPW; ++i) {
         const int tile = wave + NW * i;
@@ -178,8 +191,11 @@ __device__ __forceinline__ float mix_stage2_xt(const uint16_t *Z1, uint16_t *XT,
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const uint16_t h = f32_to_f16_bits(acc[reg]);
-                XT[(16 * at + 4 * g + reg) * Q + 16 * bt + j] = h;
-                part += f16_bits_to_f32(h);
+                const int k = (16 * at + 4 * g + reg) * Q + 16 * bt + j;
+                XT[k] = h;
+                const float hv = f16_bits_to_f32(h);
+                part.s1 += hv;
+                if constexpr (OFFS) part.soff = fmaf(me2_off_f16(k), hv, part.soff);
             }
         }
     }
