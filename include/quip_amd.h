@@ -539,7 +539,8 @@ int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits, float *QT_
  *   info: DEVICE int, 0 on success, else 1 + the first column whose pivot was not positive (LAPACK potrf convention) --
  *   the factor is then meaningless. */
 int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *info, void *stream);
-/* tests / A-B measurements (process-wide): old_syrk != 0 forces the guarded round-1 trailing-update kernel; lookahead 0 = never use the
+/* tests / A-B measurements (process-wide): old_syrk bit 0 forces the guarded round-1 trailing-update kernel, bit 1 the unblocked 64-step
+ * factorisation of the diagonal block; lookahead 0 = never use the
  * two-stream schedule, 1 = from d = 1024, anything else = the default (from d = 12288, where it starts to pay). */
 void quipamd_cholesky_config(int old_syrk, int lookahead);
 

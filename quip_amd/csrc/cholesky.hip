@@ -28,6 +28,7 @@ namespace {
 
 constexpr int NB = 64;
 bool g_chol_old_syrk = false;          // tests: force the guarded round-1 trailing-update kernel
+bool g_chol_unblocked_diag = false;    // tests / A-B: the 64-step single-wave factorisation of rounds 1-2 for the diagonal block
 
 __device__ __forceinline__ float lane_bcast(float v, int lane)
 {
@@ -90,10 +91,72 @@ template <int J> __device__ __forceinline__ void factor_rows(float (&a)[NB], int
     }
 }
 
+// ---- the blocked form of the same factorisation (round 3) --------------------------------------------------------------------------------
+// factor_rows is 2016 dependent (v_readlane, v_fma) pairs at ~13 cycles each: 11 us of one wave's instruction stream, 128 times per
+// d = 8192 on the serial chain.  Blocked 4 x 16 rows: the 16 rows of a block are factored the same way (120 pairs), everything below
+// them is updated at once on the matrix pipe -- S = U_blk^T U_blk (fp32 MFMA chains, operands from a 16 x 64 LDS image of the finished
+// rows), subtracted from the register image through LDS (the D layout holds 4 rows of a column per lane group, the register image one
+// column per lane).  Same arithmetic up to the order of the 16 products per element.
+template <int J, int I, int END> __device__ __forceinline__ void row_update_to(float (&a)[NB])
+{
+    if constexpr (I + 4 <= END) {
+        upd4<J, I>(a);
+        row_update_to<J, I + 4, END>(a);
+    } else if constexpr (I < END) {
+        upd1<J, I>(a);
+        row_update_to<J, I + 1, END>(a);
+    }
+}
+template <int J, int END> __device__ __forceinline__ void factor_block(float (&a)[NB], int l, int64_t k0, int *info)
+{
+    if constexpr (J < END) {
+        const float piv = lane_bcast(a[J], J);
+        if (!(piv > 0.f) && l == 0) atomicCAS(info, 0, (int)(k0 + J + 1));
+        float r = __builtin_amdgcn_rsqf(piv);
+        r = fmaf(0.5f * r, fmaf(-piv * r, r, 1.f), r);
+        a[J] = (l >= J) ? a[J] * r : 0.f;
+        row_update_to<J, J + 1, END>(a);                          // only the rows of this 16-row block
+        factor_block<J + 1, END>(a, l, k0, info);
+    }
+}
+template <int KB> __device__ __forceinline__ void blocked_steps(float (&a)[NB], int l, int64_t k0, int *info, float (*Ub)[NB + 1], float (*Sf)[NB + 1])
+{
+    if constexpr (KB < 4) {
+        constexpr int R0 = 16 * KB, R1 = R0 + 16;
+        factor_block<R0, R1>(a, l, k0, info);
+        if constexpr (KB < 3) {
+            const int j = l & 15, g = l >> 4;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Ub[k][l] = a[R0 + k];        // finished rows (0 left of the diagonal)
+            __syncthreads();
+            // S[i][c] = sum_k U[R0 + k][i] U[R0 + k][c] for the tiles (ti, tj), KB < ti <= tj
+#pragma unroll
+            for (int ti = KB + 1; ti < 4; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < 4; ++tj) {
+                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ub[4 * s4 + g][16 * ti + j], Ub[4 * s4 + g][16 * tj + j], acc, 0, 0, 0);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) Sf[16 * ti + 4 * g + reg][16 * tj + j] = acc[reg];     // D: row 4g + reg, col j
+                }
+            __syncthreads();
+            const int tjl = l >> 4;                                    // this lane's column tile: rows of the tiles ti <= tjl are its upper part
+#pragma unroll
+            for (int i = R1; i < NB; ++i)
+                if ((i >> 4) <= tjl) a[i] -= Sf[i][l];
+            __syncthreads();                                           // Ub / Sf are rewritten by the next block
+        }
+        blocked_steps<KB + 1>(a, l, k0, info, Ub, Sf);
+    }
+}
+
 // FULL: the block lies inside the matrix (every step but a ragged last one): unconditional loads, no per-row branches.
-template <bool FULL>
+template <bool FULL, bool BLOCKED>
 __global__ __launch_bounds__(64) void chol_diag_kernel(float *A, int64_t d, int64_t k0, int *info)
 {
+    __shared__ float Ub[BLOCKED ? 16 : 1][NB + 1], Sf[BLOCKED ? NB : 1][NB + 1];
     const int l = threadIdx.x;
     const int64_t c = k0 + l;
     float *Ac = A + k0 * d + (FULL ? c : (c < d ? c : k0));
@@ -108,7 +171,8 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(float *A, int64_t d, int6
             a[r] = in ? v : (r == l ? 1.f : 0.f);
         }
     }
-    factor_rows<0>(a, l, k0, info);
+    if constexpr (BLOCKED) blocked_steps<0>(a, l, k0, info, Ub, Sf);
+    else factor_rows<0>(a, l, k0, info);
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
         if constexpr (FULL) {
@@ -487,6 +551,8 @@ bool g_chol_no_lookahead = false, g_chol_force_lookahead = false;
 
 extern "C" void quipamd_cholesky_config(int old_syrk, int lookahead)
 {
+    g_chol_unblocked_diag = (old_syrk & 2) != 0;
+    old_syrk &= 1;
     g_chol_old_syrk = old_syrk != 0;
     g_chol_no_lookahead = lookahead == 0;
     g_chol_force_lookahead = lookahead == 1;
@@ -504,8 +570,12 @@ extern "C" int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *in
         return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: copy failed");
     if (hipMemsetAsync(info, 0, sizeof(int), s) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: memset failed");
     auto diag = [&](int64_t k0) {
-        if (k0 + NB <= d) chol_diag_kernel<true><<<1, 64, 0, s>>>(LT, d, k0, info);
-        else chol_diag_kernel<false><<<1, 64, 0, s>>>(LT, d, k0, info);
+        if (k0 + NB <= d) {
+            if (g_chol_unblocked_diag) chol_diag_kernel<true, false><<<1, 64, 0, s>>>(LT, d, k0, info);
+            else chol_diag_kernel<true, true><<<1, 64, 0, s>>>(LT, d, k0, info);
+        } else {
+            chol_diag_kernel<false, false><<<1, 64, 0, s>>>(LT, d, k0, info);
+        }
     };
     // two 64-row panels per trailing update: diag, panel, [64-row strip update so the second panel can be factored],
     // diag, panel, then ONE rank-128 update of everything behind the pair.

@@ -887,10 +887,11 @@ def cholesky_lt(H, check=True):
     return LT
 
 
-def cholesky_config(old_syrk=False, lookahead=None):
-    """tests / A-B measurements: K8 with the guarded round-1 trailing-update kernel and / or the two-stream look-ahead schedule forced on
-    (True: from d = 1024) or off (False); None = the default (from d = 12288).  Process-wide switch."""
-    _lib.load().quipamd_cholesky_config(int(bool(old_syrk)), -1 if lookahead is None else int(bool(lookahead)))
+def cholesky_config(old_syrk=False, lookahead=None, unblocked_diag=False):
+    """tests / A-B measurements: K8 with the guarded round-1 trailing-update kernel, the unblocked 64-step factorisation of the diagonal
+    block (rounds 1-2) and / or the two-stream look-ahead schedule forced on (True: from d = 1024) or off (False); None = the default
+    (from d = 12288).  Process-wide switch."""
+    _lib.load().quipamd_cholesky_config(int(bool(old_syrk)) | (2 if unblocked_diag else 0), -1 if lookahead is None else int(bool(lookahead)))
 
 
 def ldlq_config(row_groups=0):

@@ -33,3 +33,37 @@ def test_schedule_is_bit_identical_to_the_single_stream_guarded_form(d):
     assert torch.equal(a, ref)
     for o in outs:
         assert torch.equal(o, ref)
+
+
+@pytest.mark.parametrize("d", [64, 128, 1024, 1100, 4096])
+def test_blocked_diagonal_factorisation(d):
+    """round 3: the 64 x 64 diagonal block factored 4 x 16 rows with the updates below each block on the matrix pipe, against the 64-step
+    form of rounds 1-2: the same factor up to the order of the 16 products per element, and no further from the fp64 factor"""
+    from quip_amd import ops
+    torch.manual_seed(d)
+    X = torch.randn(d + 256, d, device=DEV)
+    H = X.T @ X / d + 0.01 * torch.eye(d, device=DEV)
+    try:
+        ops.cholesky_config(unblocked_diag=True)
+        old = ops.cholesky_lt(H)
+        ops.cholesky_config()
+        new = ops.cholesky_lt(H)
+    finally:
+        ops.cholesky_config()
+    L64 = torch.linalg.cholesky(H.double())
+    want = torch.triu((L64 @ torch.diag(1.0 / torch.diag(L64))).T.contiguous(), 1)
+    e_new = float((new.double() - want).norm() / want.norm())
+    e_old = float((old.double() - want).norm() / want.norm())
+    assert e_new <= 1.5 * e_old + 1e-7, (e_new, e_old)
+    assert float((new - old).norm() / old.norm()) <= 20 * e_old + 1e-6
+    # a matrix that is not positive definite is reported at the same column
+    Hbad = H.clone()
+    Hbad[d // 2, d // 2] = -1.0
+    for unb in (True, False):
+        ops.cholesky_config(unblocked_diag=unb)
+        try:
+            with pytest.raises(torch.linalg.LinAlgError) as ei:
+                ops.cholesky_lt(Hbad)
+            assert f"order {d // 2 + 1} " in str(ei.value)
+        finally:
+            ops.cholesky_config()
