@@ -235,8 +235,13 @@ struct AttnUArgs {
     float scale;
 };
 
-template <int HD, int P, int Q>
-__global__ __launch_bounds__(256) void decode_attn_u_kernel(AttnUArgs G)
+// 768 threads: waves 0-3 / 4-7 / 8-11 run the operator pass of q / k / v side by side (round 3a ran the three passes one after the other on
+// four waves: two passes' worth of copy, stage 1 and stage 2 on the launch's critical path); waves 4-11 leave after their pass, the first
+// 256 threads go on to the gather, the rotary embedding and the attention itself.
+// (HD = 128 keeps NGRP = 1, the three passes one after the other on 256 threads: its 128 query registers do not fit the 168 of a
+//  768-thread workgroup -- measured 605 -> 594 tok/s on Llama with 43 registers spilled.)
+template <int HD, int P, int Q, int NGRP>
+__global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
 {
     typedef uint16_t S;
     typedef F16 TI;
@@ -260,18 +265,25 @@ __global__ __launch_bounds__(256) void decode_attn_u_kernel(AttnUArgs G)
     S *kcb = G.kc + ((int64_t)b * G.heads + head) * G.maxlen * HD, *vcb = G.vc + ((int64_t)b * G.heads + head) * G.maxlen * HD;
 
     // ---- prologue: q, k, v slices of this head ---------------------------------------------------------------------------------------
-    constexpr int NCV = N / 8 / 256;                                  // 16-byte chunks of one projection's output row per thread
+    constexpr int NCV = N / 8 / 256;                                  // 16-byte chunks of one projection's output row per thread of a group
     static_assert(NCV * 256 * 8 == N, "n = 2048 or 4096");
-    uint4 yc[3][NCV];                                                 // y_q, y_k, y_v arrive in ZT order (fpass.h copy_chunk_zt): no index vectors
+    const int grp = wave >> 2, w4 = wave & 3, t4 = tid & 255;         // NGRP = 3: operator of this wave group (0 q, 1 k, 2 v); wave / thread within it
+    constexpr int NOP = 3 / NGRP;                                     // operators a wave group runs
+    uint4 yc[NOP][NCV];                                               // y arrives in ZT order (fpass.h copy_chunk_zt): no index vectors
+    PassFrags<P, Q> fr[NOP];
 #pragma unroll
-    for (int o = 0; o < 3; ++o)
+    for (int oi = 0; oi < NOP; ++oi) {
+        const int o = NGRP == 3 ? grp : oi;
+        const uint16_t *ysrc = o == 0 ? G.y[0] : o == 1 ? G.y[1] : G.y[2];
 #pragma unroll
-        for (int u = 0; u < NCV; ++u) yc[o][u] = *reinterpret_cast<const uint4 *>((G.y[o] + (int64_t)b * N) + 8 * (uint32_t)(tid + 256 * u));
-    PassFrags<P, Q> fr[3];
+        for (int u = 0; u < NCV; ++u) yc[oi][u] = *reinterpret_cast<const uint4 *>((ysrc + (int64_t)b * N) + 8 * (uint32_t)(t4 + 256 * u));
+    }
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        load_f0<P, Q, NW>(G.U[o], wave, lane, fr[o]);
-        load_f1<P, Q, NW>(G.U[o], wave, lane, fr[o]);
+    for (int oi = 0; oi < NOP; ++oi) {
+        const int o = NGRP == 3 ? grp : oi;
+        const Fop &Ug = o == 0 ? G.U[0] : o == 1 ? G.U[1] : G.U[2];
+        load_f0<P, Q, NW>(Ug, w4, lane, fr[oi]);
+        load_f1<P, Q, NW>(Ug, w4, lane, fr[oi]);
     }
     // the gather of the head's slice: element t < 3 HD = (op = t / HD, e = t % HD), owned by thread t % 256 (HD = 128: two rounds)
     constexpr int GR = (3 * HD + 255) / 256;
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(256) void decode_attn_u_kernel(AttnUArgs G)
     for (int it = 0; it < GR; ++it) {
         const int t = tid + 256 * it;
         gst[it] = 0; gbi[it] = 0; rc[it] = 1.f; rs_[it] = 0.f;
-        if (t < 3 * HD) {
+        if (wave < 4 && t < 3 * HD) {                               // (the gather is the first 256 threads' job)
             const int gop = t / HD, ge = t - gop * HD, i = head * HD + ge;
             gst[it] = gop == 0 ? G.U[0].store_idx[i] : gop == 1 ? G.U[1].store_idx[i] : G.U[2].store_idx[i];
             gbi[it] = gop == 0 ? G.bias[0][i] : gop == 1 ? G.bias[1][i] : G.bias[2][i];
@@ -293,25 +305,29 @@ __global__ __launch_bounds__(256) void decode_attn_u_kernel(AttnUArgs G)
         }
     }
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
+    for (int oi = 0; oi < NOP; ++oi) {
+        const int o = NGRP == 3 ? grp : oi;
         uint16_t *ZT = reinterpret_cast<uint16_t *>(img + o * D::BYTES);
 #pragma unroll
-        for (int u = 0; u < NCV; ++u) copy_chunk_zt<P, Q>(ZT, yc[o][u], tid + 256 * u);
+        for (int u = 0; u < NCV; ++u) copy_chunk_zt<P, Q>(ZT, yc[oi][u], t4 + 256 * u);
     }
     __syncthreads();
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
+    for (int oi = 0; oi < NOP; ++oi) {
+        const int o = NGRP == 3 ? grp : oi;
         uint16_t *ZT = reinterpret_cast<uint16_t *>(img + o * D::BYTES), *Z1 = reinterpret_cast<uint16_t *>(img + o * D::BYTES + D::ZT_B);
-        mix_stage1<P, Q, NW>(ZT, Z1, fr[o], wave, lane);
+        mix_stage1<P, Q, NW>(ZT, Z1, fr[oi], w4, lane);
     }
     __syncthreads();
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
+    for (int oi = 0; oi < NOP; ++oi) {
+        const int o = NGRP == 3 ? grp : oi;
         uint16_t *Z1 = reinterpret_cast<uint16_t *>(img + o * D::BYTES + D::ZT_B);
         float *ZF = reinterpret_cast<float *>(img + o * D::BYTES + D::ZT_B + D::Z1_B);
-        mix_stage2<P, Q, NW>(Z1, ZF, fr[o], wave, lane);
+        mix_stage2<P, Q, NW>(Z1, ZF, fr[oi], w4, lane);
     }
     __syncthreads();
+    if (NGRP == 3 && wave >= 4) return;                               // the k and v groups are done (hardware barriers count live waves only)
 #pragma unroll
     for (int it = 0; it < GR; ++it) {
         const int t = tid + 256 * it;
@@ -440,7 +456,8 @@ template <int HD, int P, int Q> int launch_attn_u(const AttnUArgs &A, int64_t bs
 {
     typedef PassDims<P, Q, 4> D;
     const size_t lds = 3 * D::BYTES + 3 * HD * 2 + 32 + (size_t)(A.maxlen + 8 + 4 * HD) * sizeof(float);
-    auto kern = decode_attn_u_kernel<HD, P, Q>;
+    constexpr int NGRP = HD == 64 ? 3 : 1;
+    auto kern = decode_attn_u_kernel<HD, P, Q, NGRP>;
     static size_t reserved[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -451,7 +468,7 @@ template <int HD, int P, int Q> int launch_attn_u(const AttnUArgs &A, int64_t bs
             return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_attention_fused: cannot reserve %zu B of LDS", lds);
         if (known) reserved[dev] = lds;
     }
-    kern<<<(unsigned)(bs * A.heads), 256, lds, s>>>(A);
+    kern<<<(unsigned)(bs * A.heads), 256 * NGRP, lds, s>>>(A);
     QA_LAUNCH_CHECK("decode_attention_fused");
     return QUIPAMD_OK;
 }
