@@ -121,7 +121,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     constexpr bool ME = NRT >= 4;
     typedef DeqSelME<ME> DQ;
     constexpr int N = D::N, NV = D::NV, NS = FG_NW / RT, NCH = N / 256, XTS = N + 8;      // x~ row stride (halves)
-    constexpr int PB = NRT < 4 ? NRT : 4;                                       // row tiles (per parallel row slot) parked per batch
+    constexpr int PB = NRT == 6 ? 3 : NRT < 4 ? NRT : 4;                        // row tiles (per parallel row slot) parked per batch
     constexpr bool EARLY = NV == 1;
     static_assert(NS * CPW == NCH, "chunks = slots x chunks per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     const int slot = wave / RT, r = wave - slot * RT;
     const int j = lane & 15, g = lane >> 4;
     const uint32_t rt0 = blockIdx.x * (RT * NRT) + r;                          // row tile of iteration k: rt0 + k RT
+    const uint32_t rtmax = (uint32_t)(G.m / 16) - 1;                           // (the last workgroup of a ragged launch re-reads the last tile; its rows are not stored)
     const int bs = G.bs;
     FG_STAMP(0);
 
@@ -246,7 +247,8 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     for (int k = 0; k < NRT; ++k)
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {                                         // HBM, streamed once: nt
-            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Gg.qw + ((uint64_t)(rt0 + k * RT) * NCH + (slot * CPW + i)) * 64 + lane));
+            const uint32_t rtk = rt0 + k * RT < rtmax ? rt0 + k * RT : rtmax;
+            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Gg.qw + ((uint64_t)rtk * NCH + (slot * CPW + i)) * 64 + lane));
             w[k][i] = make_uint4(t[0], t[1], t[2], t[3]);
         }
     const float e_sc = Gg.scale[0];                                             // needed by the reducer only
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
             }
             const int64_t row = ((int64_t)blockIdx.x * (RT * NRT) + h * PB * RT + pr) * 16 + wr;
             const float val = e_sc * two_over_maxq * ((a - xoff) - (ME ? c0 : c0 + DeqT<2, ActF16>::OFF) * xsum);   // c0 = maxq / 2; ME: the offsets went with xoff
-            if (bb < bs) {
+            if (bb < bs && row < G.m) {
                 if (G.y_f16) reinterpret_cast<uint16_t *>(Gg.y)[(int64_t)bb * G.m + row] = f32_to_f16_bits(val);
                 else reinterpret_cast<float *>(Gg.y)[(int64_t)bb * G.m + row] = val;
             }
@@ -657,7 +659,7 @@ int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
         if (d >= 0) attr.done[d] = true;
     }
     const float maxq = 3.f;
-    kern<<<dim3((unsigned)(A.m / 16 / (RT * NRT)), (unsigned)ngroups), 1024, lds, s>>>(A, 2.0f / maxq, 0.5f * maxq);
+    kern<<<dim3((unsigned)((A.m / 16 + RT * NRT - 1) / (RT * NRT)), (unsigned)ngroups), 1024, lds, s>>>(A, 2.0f / maxq, 0.5f * maxq);
     QA_LAUNCH_CHECK("quipamd_decode_fused_gemm");
     return QUIPAMD_OK;
 }
@@ -731,13 +733,18 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
     }
     if (p == 64 && q == 64) {
         QA_REQUIRE(a->m > 0 && a->m % 16 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 16 (m = %lld)", (long long)a->m);
-        // row tiles per wave: as many as keep the grid within one round of 256 workgroups (each repeats the prologue)
-        const int64_t tiles = a->m / 16 * a->ngroups;
-        const int nrt = (tiles > 4 * 256 && a->m % 128 == 0) ? 8 : (tiles > 256 && a->m % 64 == 0) ? 4 : 1;
+        // row tiles per wave: as few as keep the grid within one round of 256 workgroups (each repeats the prologue; the conversion of a
+        // tile is ~1 us of a wave's VALU time): 11008 x 2 rows = 1376 tiles: 6 per wave = 230 workgroups (the last one of each group ragged)
+        // instead of 8 = 172
+        const int64_t tpg = a->m / 16;
+        auto wgs = [&](int n) { return (tpg + n - 1) / n * a->ngroups; };
+        const int nrt = wgs(1) <= 256 ? 1 : wgs(4) <= 256 ? 4 : wgs(6) <= 256 ? 6 : 8;
         if (yf32) return nrt == 8 ? launch_fused<64, 64, true, true, 2, 1, 1, 8, true>(A, a->ngroups, s)
+                       : nrt == 6 ? launch_fused<64, 64, true, true, 2, 1, 1, 6, true>(A, a->ngroups, s)
                        : nrt == 4 ? launch_fused<64, 64, true, true, 2, 1, 1, 4, true>(A, a->ngroups, s)
                                   : launch_fused<64, 64, true, true, 2, 1, 1, 1, true>(A, a->ngroups, s);
         return nrt == 8 ? dispatch_fused<64, 64, 1, 1, 8>(A, u, res, a->norm, a->ngroups, s)
+             : nrt == 6 ? dispatch_fused<64, 64, 1, 1, 6>(A, u, res, a->norm, a->ngroups, s)
              : nrt == 4 ? dispatch_fused<64, 64, 1, 1, 4>(A, u, res, a->norm, a->ngroups, s)
                         : dispatch_fused<64, 64, 1, 1, 1>(A, u, res, a->norm, a->ngroups, s);
     }
