@@ -238,8 +238,8 @@ struct AttnUArgs {
 // 768 threads: waves 0-3 / 4-7 / 8-11 run the operator pass of q / k / v side by side (round 3a ran the three passes one after the other on
 // four waves: two passes' worth of copy, stage 1 and stage 2 on the launch's critical path); waves 4-11 leave after their pass, the first
 // 256 threads go on to the gather, the rotary embedding and the attention itself.
-// (HD = 128 keeps NGRP = 1, the three passes one after the other on 256 threads: its 128 query registers do not fit the 168 of a
-//  768-thread workgroup -- measured 605 -> 594 tok/s on Llama with 43 registers spilled.)
+// (NGRP = 1 is the round-3a form: the three passes one after the other on 256 threads.  With q held as fp32 head dim 128 did not fit the 168
+//  registers of a 768-thread workgroup -- 43 spilled, 605 -> 594 tok/s on Llama -- so q is held as packed fp16 pairs now.)
 template <int HD, int P, int Q, int NGRP>
 __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
 {
@@ -370,13 +370,13 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     }
     __syncthreads();
 
-    float qr[HD];
+    // q as packed fp16 pairs (half the registers of an fp32 copy: head dim 128 then fits the 768-thread form), scores on v_dot2_f32_f16
+    // (exact products, fp32 accumulation), the 1 / sqrt(hd) applied to the finished score
+    uint32_t qp[HD / 2];
 #pragma unroll
     for (int e8 = 0; e8 < HD; e8 += 8) {
-        S raw[8];
-        *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(qkv + e8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qr[e8 + e] = DT<TI>::load(raw, e) * G.scale;
+        const uint4 r4 = *reinterpret_cast<const uint4 *>(qkv + e8);
+        qp[e8 / 2 + 0] = r4.x; qp[e8 / 2 + 1] = r4.y; qp[e8 / 2 + 2] = r4.z; qp[e8 / 2 + 3] = r4.w;
     }
     constexpr int CH = HD / 8, RS = 64 / CH;
     const int ch = lane % CH, rsub = lane / CH;
@@ -389,14 +389,16 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     float mx = -INFINITY;
     for (int64_t t = tid; t < T; t += 256) {
         const S *row = kcb + t * HD;
-        float acc = 0.f;
+        float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
         for (int e8 = 0; e8 < HD; e8 += 8) {
-            S raw[8];
-            *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(row + e8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc = fmaf(qr[e8 + e], DT<TI>::load(raw, e), acc);
+            const uint4 k4 = *reinterpret_cast<const uint4 *>(row + e8);
+            acc0 = ActF16::dot2(qp[e8 / 2 + 0], k4.x, acc0);
+            acc1 = ActF16::dot2(qp[e8 / 2 + 1], k4.y, acc1);
+            acc0 = ActF16::dot2(qp[e8 / 2 + 2], k4.z, acc0);
+            acc1 = ActF16::dot2(qp[e8 / 2 + 3], k4.w, acc1);
         }
+        const float acc = (acc0 + acc1) * G.scale;
         scores[t] = acc;
         mx = fmaxf(mx, acc);
     }
@@ -456,7 +458,7 @@ template <int HD, int P, int Q> int launch_attn_u(const AttnUArgs &A, int64_t bs
 {
     typedef PassDims<P, Q, 4> D;
     const size_t lds = 3 * D::BYTES + 3 * HD * 2 + 32 + (size_t)(A.maxlen + 8 + 4 * HD) * sizeof(float);
-    constexpr int NGRP = HD == 64 ? 3 : 1;
+    constexpr int NGRP = 3;
     auto kern = decode_attn_u_kernel<HD, P, Q, NGRP>;
     static size_t reserved[64] = {};
     int dev = 0;
