@@ -437,6 +437,42 @@ def main():
         except Exception as ex:
             out["hessian"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
+    # ---- the quantisation side of a Linear: LDL factor (K8), LDLQ rounding (K4), OPTQ with the qfn-b quantiser -------
+    if rank == 0 and world == 1 and not args.no_ldlq:
+        try:
+            def ev_time2(fn, reps):
+                fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                e1.synchronize()
+                return e0.elapsed_time(e1) / reps
+            ql = {}
+            for dq in (4096, 8192):
+                torch.manual_seed(dq)
+                Xq = torch.randn(dq + 256, dq, device=dev)
+                Hq = Xq.T @ Xq / dq + 0.01 * torch.eye(dq, device=dev)
+                del Xq
+                t8 = ev_time2(lambda: ops.cholesky_lt(Hq, check=False), 3)
+                LTq = ops.cholesky_lt(Hq)
+                Wq = torch.rand(dq, dq, device=dev) * 3
+                t4 = ev_time2(lambda: ops.ldlq_round(Wq, LTq, BITS), 3)
+                ql[f"{dq}x{dq}"] = {"cholesky_lt_ms": round(t8, 3), "cholesky_TFLOPs": round(dq ** 3 / 3 / t8 / 1e9, 1),
+                                    "ldlq_round_ms": round(t4, 3), "ldlq_far_field_TFLOPs": round(dq ** 3 / t4 / 1e9, 1)}
+                if dq == 4096:
+                    FTq = ops.gptq_feedback(Hq)
+                    tg = ev_time2(lambda: ops.gptq_round_qfnb(Wq - 1.5, FTq, BITS), 2)
+                    ql[f"{dq}x{dq}"]["gptq_qfnb_ms"] = round(tg, 3)
+                    del FTq
+                del Hq, LTq, Wq
+            out["quantise_linear"] = {"what": "K8 LDL factor (fp32 flops d^3 / 3 against the 157 TFLOP/s fp32 matrix pipe), K4 LDLQ rounding w2 (far field m d^2), "
+                                              "OPTQ with the per-column qfn-b scale (csrc/gptq_qfnb.hip)", **ql}
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            out["quantise_linear"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
     # ---- the other half of BASELINE.json's metric: OPT-1.3B w2 decode tok/s on one GPU (configs[2]) -----------------
     if rank == 0 and world == 1 and not args.no_decode:
         import importlib.util
