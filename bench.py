@@ -65,6 +65,16 @@ def parse():
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  RCCL writes a version banner to stdout through C stdio whenever a communicator is created
+    # (every rank of an N > 1 run; the one-rank group of the sharded_block leg), flushed at process exit, i.e. after python's line.  So
+    # file descriptor 1 is pointed at stderr for the whole run and the JSON line goes out through a private copy of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    def emit(line):
+        real_stdout.write(line + "\n")
+        real_stdout.flush()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -204,7 +214,7 @@ def main():
     t_cold = timed(ring, args.steps, args.warmup)
     if args.profile_cold_only:
         if rank == 0:
-            print(json.dumps({"profile_cold_only": True, "us_per_launch": t_cold / args.steps * 1e6}))
+            emit(json.dumps({"profile_cold_only": True, "us_per_launch": t_cold / args.steps * 1e6}))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -326,7 +336,7 @@ def main():
         if printed.acquire(blocking=False):
             if rank == 0:
                 out.setdefault("side_measurements", "watchdog fired: a side leg did not finish within 420 s")
-                print(json.dumps(out), flush=True)
+                emit(json.dumps(out))
             os._exit(0)
     watchdog = threading.Timer(420.0, emit_and_exit)
     watchdog.daemon = True
@@ -583,7 +593,7 @@ def main():
     if not printed.acquire(blocking=False):
         return                                   # the watchdog is printing
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
