@@ -176,6 +176,11 @@ class QuantLinear(nn.Module):
         """codes uint8 [out,in] on the GPU; scale float[1] (qfn b) or [out] (qfn a); U/V reference-style
         (B, p_in, p_out) tuples or ops.OrthoOp."""
         dev = codes.device
+        # what the decode launches derive from the packed state (decode_qweight, bias16, the layer-pair tables) is rebuilt on next use;
+        # tables other layers keep about THIS one are keyed by its generation
+        for k in ('_qweight_d', '_bias16', '_pair_tables', '_bigp_tail'):
+            self.__dict__.pop(k, None)
+        self.__dict__['_pack_gen'] = self.__dict__.get('_pack_gen', 0) + 1
         self.qweight = ops.pack(codes, self.bits, ops.LAYOUT_STREAM)
         self.scales = scale.to(dev, torch.float32).reshape(-1).clone()
         self.zeros = None if zero is None else zero.to(dev, torch.float32).reshape(-1).clone()
@@ -635,7 +640,7 @@ def _bigp_tail_tables(ups, down):
     of the consumer's V (b * p + a of the position inv_pin_V[i] natural index i lands on), its bias in image order, and -- on the last
     producer -- 1 / scaleWH of the consumer in image order (the column rescale rides on `up`: silu(g) * (u / s))"""
     cache = down.__dict__.setdefault('_bigp_tail', {})
-    key = tuple(id(q) for q in ups)
+    key = tuple((id(q), q.__dict__.get('_pack_gen', 0)) for q in ups)
     if key not in cache:
         V = down.V
         dev, n, p = V.device, V.n, V.p
@@ -729,7 +734,7 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
         if (q0.V.p, q0.V.q) == (128, 64) and len(qls) == 1 and residual is None and lnp is None and rows <= 2 and not store:
             # n = 8192 (OPT fc1 -> fc2): the layer pair's per-lane tables turn gather + scale + scatter into one scatter (decode_fused.hip)
             cache = q0.__dict__.setdefault('_pair_tables', {})
-            key = id(prev)
+            key = (id(prev), prev.__dict__.get('_pack_gen', 0))
             if key not in cache:
                 cache[key] = ops.pair_tables(prev.U, q0.V, bias16(prev), kw['colscale'][0])
             kw.update(pair=cache[key])

@@ -237,3 +237,19 @@ def test_decode_qweight_is_the_layer_with_both_permutations_folded_in():
     zt, img = ql.U.zt_rows(), ql.V.image_cols()
     assert torch.equal(c1[zt][:, img], c0)                  # row zt[i], column img[k] of the decode copy = (i, k) of the layer
     assert sorted(zt.tolist()) == list(range(2048)) and sorted(img.tolist()) == list(range(2048))
+
+
+def test_repacking_a_layer_rebuilds_what_the_decode_launches_derived_from_it():
+    from quip_amd import ops
+    from quip_amd.quant import bias16
+    ql, _ = _layer(2048, 2048, 901)
+    qd0, b0 = ql.decode_qweight().clone(), bias16(ql).clone()
+    torch.manual_seed(5)
+    codes = torch.randint(0, 4, (2048, 2048), device=DEV, dtype=torch.uint8)
+    ql.pack(codes, ql.scales, None, bias=torch.randn(2048, device=DEV), scaleWH=1.0 / ql.inv_scaleWH, U=ql.U, V=ql.V)
+    qd1 = ql.decode_qweight()
+    assert not torch.equal(qd0, qd1) and not torch.equal(b0, bias16(ql))
+    folded = ops.unpack(qd1, 2, ops.LAYOUT_STREAM, 2048, 2048)
+    want = torch.empty_like(codes)
+    want[ql.U.zt_rows()[:, None], ql.V.image_cols()[None, :]] = codes
+    assert torch.equal(folded, want)
