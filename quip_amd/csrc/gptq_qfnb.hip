@@ -187,7 +187,7 @@ template <int R> int gb_chain(const GbArgs &A, hipStream_t s)
 extern "C" int64_t quipamd_gptq_qfnb_workspace_bytes(int64_t m, int64_t d)
 {
     (void)d;
-    return (int64_t)GB_NB * m * 4 + 2 * 256 * 8;                      // residuals of a block + the granules
+    return (int64_t)GB_NB * m * 4 + 2 * ((m + 15) / 16) * 8 + 64;     // residuals of a block + two granules per possible workgroup
 }
 
 extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits, float *QT_rev, float *colscale_rev, void *workspace,
@@ -197,17 +197,33 @@ extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits,
     if (m == 0 || d == 0) return QUIPAMD_OK;
     QA_REQUIRE(WT_rev && FT && QT_rev && colscale_rev && workspace, QUIPAMD_ERR_ARG, "gptq_round_qfnb: null pointer");
     QA_REQUIRE(bits >= 1 && bits <= 8, QUIPAMD_ERR_ARG, "gptq_round_qfnb: bits");
-    // rows per workgroup: every workgroup of a launch must be resident at once (they wait for each other): at most 256
-    const int R = m > 128 * 128 ? 128 : m > 64 * 128 ? 64 : m > 32 * 64 ? 32 : 16;
+    // rows per workgroup: every workgroup of a launch must be RESIDENT at once (they wait for each other): the smallest R whose grid fits
+    // the device as the occupancy query sees it (256 CUs x 1-2 workgroups here; a partitioned or masked device has fewer)
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+        return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: cannot query the device");
+    auto fits = [&](int R, const void *kern) {
+        const size_t lds = (size_t)(GB_NB * R + GB_NB * GB_NB + 2 * R) * sizeof(float);
+        if (lds > 64 * 1024 && hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, GB_T, lds) != hipSuccess) return false;
+        return (m + R - 1) / R <= (int64_t)per_cu * ncu;
+    };
+    int R = 0;
+    if (m <= 32 * 64 && fits(16, (const void *)gptqb_chain_kernel<16>)) R = 16;
+    else if (m <= 64 * 128 && fits(32, (const void *)gptqb_chain_kernel<32>)) R = 32;
+    else if (m <= 128 * 128 && fits(64, (const void *)gptqb_chain_kernel<64>)) R = 64;
+    else if (fits(128, (const void *)gptqb_chain_kernel<128>)) R = 128;
+    QA_REQUIRE(R != 0, QUIPAMD_ERR_UNSUPPORTED, "gptq_round_qfnb: %lld rows do not fit this device as one grid of co-resident workgroups (%d CUs)",
+               (long long)m, ncu);
     const int64_t G = (m + R - 1) / R;
-    QA_REQUIRE(G <= 256, QUIPAMD_ERR_UNSUPPORTED, "gptq_round_qfnb: m = %lld rows need more than 256 co-resident workgroups", (long long)m);
     hipStream_t s = (hipStream_t)stream;
     GbArgs A;
     A.WT = WT_rev; A.FT = FT; A.QT = QT_rev; A.colscale = colscale_rev;
     A.ET = (float *)workspace;
     A.gran = (unsigned long long *)((char *)workspace + (size_t)GB_NB * m * 4);
     A.m = m; A.d = d; A.G = (int)G; A.maxq = (float)((1 << bits) - 1);
-    if (hipMemsetAsync(A.gran, 0, 2 * 256 * 8, s) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: memset failed");
+    if (hipMemsetAsync(A.gran, 0, (size_t)2 * G * 8, s) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: memset failed");
     // lazy blocks from the top of the reversed order; block edges at multiples of 128, so a remainder of d is the FIRST block (where a
     // block ends only decides when its residuals reach the columns behind it, not what they are)
     int64_t b1 = d;

@@ -75,9 +75,13 @@ class GPTQ(QuantMethod):
         if qz.qfn == 'b':
             # every column on its own scale, recomputed from all rows of the updated column (quant.py:158-160): whatever find_params left
             # in the quantiser -- per group or not -- is overwritten before it is used, so one kernel serves every groupsize
-            if m > 32768:
+            from ._lib import QuipAmdError
+            try:
+                Q, colscale = ops.gptq_round_qfnb(W.float().contiguous(), ops.gptq_feedback(H.float()), bits)
+            except QuipAmdError as e:                                 # more rows than co-resident workgroups on this device: the column walk
+                if "co-resident" not in str(e):
+                    raise
                 return None
-            Q, colscale = ops.gptq_round_qfnb(W.float().contiguous(), ops.gptq_feedback(H.float()), bits)
             qz.scale = colscale[-1].clone()                           # what the reference's quantiser is left holding: the last column's
             self.column_scale = colscale
             return Q.to(W.dtype)
