@@ -1,5 +1,5 @@
 // preproc.hip -- the elementwise / reduction chains of QuantMethod.preproc (method.py:134-193) as a few launches instead of ~15 torch
-// ones over the d x d Hessian and the m x d weights (0.3-0.5 ms of a 5 ms Linear at 4096^2):
+// ones over the d x d Hessian and the m x d weights (rescale 0.24 -> 0.15 ms, trace + ridge 0.11 -> 0.06 ms at 4096^2):
 //
 //   rescale (method.py:140-156):   H /= max|H|;  s = clamp(sqrt(sqrt(clamp(diag H, 1e-8) / clamp(diag(W^T W), 1e-8))), 1e-8);
 //                                  W <- W s (columns), rounded to the layer's dtype;   H <- (H / s_j) / s_i
