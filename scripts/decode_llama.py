@@ -96,7 +96,7 @@ class Decoder(nn.Module):
         self.cos, self.sin = cos.to(self.tok.weight.device), sin.to(self.tok.weight.device)
         return self
 
-    v3 = False               # csrc/decode_fused.hip + decode_attn.hip: 8 launches per block (13+ in the round-2 fused variant)
+    v3 = False               # csrc/decode_fused.hip + decode_attn.hip + decode_bigp.hip: 6 launches per block (13+ in the round-2 fused variant)
 
     def v3_ok(self, bs):
         b = self.blocks[0]

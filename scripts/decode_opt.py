@@ -126,7 +126,7 @@ class Decoder(nn.Module):
     split_handover = False
 
     v3_attn = True           # with v3: the output-side operators of q / k / v in the attention launch (csrc/decode_attn.hip) -- 5 launches
-    v3 = False               # csrc/decode_fused.hip: everything between two GEMMs in the consuming GEMM's prologue -- 6 launches per block
+    v3 = False               # csrc/decode_fused.hip: everything between two GEMMs in the consuming GEMM's prologue -- 5 launches per block (6 with v3_attn off)
 
     def v3_ok(self, bs):
         b = self.blocks[0]

@@ -185,7 +185,7 @@ def test_opt_decode_harness_matches_hf_with_past_key_values():
         dec.vfused, dec.split_handover = True, True
         report["vfused_split_handover"] = _gate("vfused", harness_logits(dec, toks, maxpos, dtype), ref, toks)
     assert dec.v3_ok(1)
-    dec.v3 = True                                            # csrc/decode_fused.hip: 6 launches per block
+    dec.v3 = True                                            # csrc/decode_fused.hip: 5 launches per block
     report["v3"] = _gate("v3", harness_logits(dec, toks, maxpos, dtype), ref, toks)
     dec.fused_head = True                                    # + embedding and [U^T + residual -> final norm -> lm_head] as one launch each
     report["v3_head"] = _gate("v3_head", harness_logits(dec, toks, maxpos, dtype), ref, toks)

@@ -23,7 +23,7 @@ def _mod():
 def test_packed_decode_step_matches_its_dense_twin():
     e_plain, e_fused, e_fused_attn, chained_equal, e_v3 = _mod().decode_check(layers=2, bits=2)
     assert e_plain <= 1e-2 and e_fused <= 1e-2 and e_fused_attn <= 1e-2, (e_plain, e_fused, e_fused_attn)
-    assert e_v3 is not None and e_v3 <= 1e-2, e_v3          # csrc/decode_fused.hip: 6 launches per block, batch 2
+    assert e_v3 is not None and e_v3 <= 1e-2, e_v3          # csrc/decode_fused.hip: 5 launches per block, batch 2
     assert chained_equal, "chained hand-over launches must reproduce the unchained step bit for bit"
 
 
