@@ -1,0 +1,60 @@
+"""CPU test (needs hipcc, no GPU): no kernel of the library goes through scratch memory unnoticed.
+
+Round 3 lost time to kernels that were correct and slow because a register array had silently become a stack object -- no spill
+reported, a `private_segment` of exactly the array's size, `scratch_store` right behind the loads (K8's stage registers as HIP `float4`
+structs; an array written on two control-flow paths; K4 with eight chain waves).  Every kernel's `.private_segment_fixed_size` is read
+from the generated gfx950 assembly (same flags as __graft_entry__.build); anything above zero must be on the list below, with a bound."""
+import os
+import re
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "quip_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# kernel (demangled-name fragment as it appears in the mangled symbol) -> bytes of scratch tolerated, and why
+ALLOWED = [
+    (r"chol_syrk_full_kernelILi4E", 32, "5 registers of addressing at 256 VGPRs; outside the MFMA loop"),
+    (r"fused_gemm_kernelILi64ELi64ELb1ELb1ELi1E", 96, "64 x 64 with LayerNorm (no model of this repo's benchmarks: OPT-1.3B is 64 x 32, Llama RMSNorm)"),
+    (r"fused_gemm_kernelILi128ELi64ELb1ELb0ELi0ELi1ELi2ELi1E", 16, "the generic n = 8192 launch (bs 3-4; bs <= 2 runs fused_pair_kernel)"),
+    (r"dq_pf_kernelINS_\w+ELi256ELi256E", 48, "forced-only prefill experiment (slower than the mb kernel, DESIGN.md K2)"),
+    (r"hsyrk_fast_kernel", 8, "opt-in Hessian mode"),
+    (r"ortho_small_split_kernel", 340, "round-2 operator kernels with run-time (p, q); the decode path uses the compile-time fpass.h forms"),
+]
+
+
+def _compile(src, outdir):
+    out = os.path.join(outdir, os.path.basename(src)[:-4] + ".s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S",
+                           "-I", os.path.join(ROOT, "include"), "-I", CSRC, src, "-o", out], stderr=subprocess.DEVNULL)
+    return out
+
+
+def test_no_kernel_uses_scratch_memory_beyond_the_listed_ones(tmp_path):
+    if not shutil.which(HIPCC) and not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    srcs = sorted(f for f in (os.path.join(CSRC, n) for n in os.listdir(CSRC)) if f.endswith(".hip"))
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
+        outs = list(ex.map(lambda s: _compile(s, str(tmp_path)), srcs))
+    nkern, offenders = 0, []
+    for path in outs:
+        name = None
+        for ln in open(path):
+            m = re.match(r"\s+\.name:\s+(\S+)", ln)
+            if m:
+                name = m.group(1)
+            m = re.match(r"\s+\.private_segment_fixed_size:\s+(\d+)", ln)
+            if m and name:
+                nkern += 1
+                size = int(m.group(1))
+                if size:
+                    bound = max([b for pat, b, _ in ALLOWED if re.search(pat, name)], default=0)
+                    if size > bound:
+                        offenders.append((os.path.basename(path), name, size, bound))
+                name = None
+    assert nkern > 300                                            # the metadata was found
+    assert not offenders, offenders
