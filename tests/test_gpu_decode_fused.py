@@ -73,6 +73,8 @@ CASES = [
     (8192, 2048, 1, True, None, True, False, 2),
     (8192, 2048, 1, True, None, True, False, 3),
     (4096, 4096, 3, True, "rms", False, True, 1),
+    (4096, 4096, 3, True, "ln", False, True, 2),              # hidden 4096 with LayerNorm (the OPT-6.7B geometry)
+    (4096, 16384 // 16 * 16, 1, True, "ln", False, True, 1),
     (2048, 2048, 1, True, None, False, True, 2),
     (4096, 11008 // 16 * 16, 2, False, "rms", False, False, 2),
 ]
