@@ -28,124 +28,23 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from quip_amd import ops, method  # noqa: E402
+from quip_amd import ops, method, decode  # noqa: E402
 from quip_amd.quant import (QuantLinear, packed_forward_fused, fused_stage, fused_ok, fused_attention, fused_attention_ok,  # noqa: E402
                             fused_u_only, packed_u_stage, packed_v_stage_gate, fused_bigp_tail, bigp_tail_ok, fused_head)
 import decode_opt as D  # noqa: E402  (time_decode: hipGraph capture + per-token timing)
 
 
-class RMSNorm(nn.Module):
-    def __init__(self, h, eps, dtype):
-        super().__init__()
-        self.weight = nn.Parameter(torch.ones(h, dtype=dtype))
-        self.eps = eps
-
-    def forward(self, x):                                   # HF LlamaRMSNorm: fp32 statistics, cast, then the gain
-        xf = x.float()
-        return self.weight * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + self.eps)).to(x.dtype)
+RMSNorm = decode.RMSNorm
 
 
-class Block(nn.Module):
-    def __init__(self, h, ffn, heads, eps, dtype):
-        super().__init__()
-        self.h, self.heads, self.hd = h, heads, h // heads
-        self.n1, self.n2 = RMSNorm(h, eps, dtype), RMSNorm(h, eps, dtype)
-        mk = lambda i, o: nn.Linear(i, o, bias=False, dtype=dtype)
-        self.q_proj, self.k_proj, self.v_proj, self.o_proj = mk(h, h), mk(h, h), mk(h, h), mk(h, h)
-        self.gate_proj, self.up_proj, self.down_proj = mk(h, ffn), mk(h, ffn), mk(ffn, h)
-        self.fused = False
-
-    def forward(self, x, kc, vc, pos, cos, sin):
-        """x [bs, h]; kc / vc [bs, heads, maxlen, hd]; pos int64 [1] on the device; cos / sin fp32 [maxpos, hd]."""
-        if self.fused:
-            q, k, v = packed_forward_fused([self.q_proj, self.k_proj, self.v_proj], x, ln=self.n1)
-        else:
-            hn = self.n1(x)
-            q, k, v = self.q_proj(hn), self.k_proj(hn), self.v_proj(hn)
-        ops.rope_inplace(q, k, cos, sin, pos, self.heads)
-        o = ops.decode_attention(q, k, v, kc, vc, pos)
-        if self.fused:
-            x = packed_forward_fused([self.o_proj], o, residual=x)[0]
-            g, u = packed_forward_fused([self.gate_proj, self.up_proj], x, ln=self.n2)
-            return packed_forward_fused([self.down_proj], g, residual=x, gate_up=u)[0]       # silu(g) * u formed inside the V launch
-        x = x + self.o_proj(o)
-        hn = self.n2(x)
-        return x + self.down_proj(F.silu(self.gate_proj(hn)) * self.up_proj(hn))
-
-
-class Decoder(nn.Module):
-    NAMES = ["q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"]
+class Decoder(decode.LlamaDecoder):
+    """quip_amd.decode.LlamaDecoder (plain / fused / v3 / fused-head steps live in the package) over random-init modules"""
 
     def __init__(self, layers=32, h=4096, ffn=11008, heads=32, vocab=32000, maxpos=4096, eps=1e-5, theta=10000.0, dtype=torch.float16):
-        super().__init__()
-        self.h, self.layers_n, self.heads = h, layers, heads
-        self.tok = nn.Embedding(vocab, h, dtype=dtype)
-        self.blocks = nn.ModuleList([Block(h, ffn, heads, eps, dtype) for _ in range(layers)])
-        self.norm = RMSNorm(h, eps, dtype)
-        self.lm_head = nn.Linear(h, vocab, bias=False, dtype=dtype)
         hd = h // heads
         inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))          # LlamaRotaryEmbedding
-        fr = torch.outer(torch.arange(maxpos, dtype=torch.float32), inv)
-        emb = torch.cat((fr, fr), dim=-1)
-        self.register_buffer("cos", emb.cos().contiguous(), persistent=False)
-        self.register_buffer("sin", emb.sin().contiguous(), persistent=False)
-
-    def _apply(self, fn, recurse=True):                     # .to(dev) / .half() must not narrow the rotary tables
-        cos, sin = self.cos, self.sin
-        super()._apply(fn, recurse)
-        self.cos, self.sin = cos.to(self.tok.weight.device), sin.to(self.tok.weight.device)
-        return self
-
-    v3 = False               # csrc/decode_fused.hip + decode_attn.hip + decode_bigp.hip: 6 launches per block (13+ in the round-2 fused variant)
-
-    def v3_ok(self, bs):
-        b = self.blocks[0]
-        qkv = [b.q_proj, b.k_proj, b.v_proj]
-        return (isinstance(b.q_proj, QuantLinear) and fused_ok(qkv, bs, prev=b.down_proj) and fused_ok([b.o_proj], bs, norm=False)
-                and fused_ok([b.gate_proj, b.up_proj], bs, prev=b.o_proj) and b.down_proj.U is not None and b.down_proj.U.fused_ok
-                and bigp_tail_ok([b.gate_proj, b.up_proj], b.down_proj, bs))
-
-    def step_v3(self, x, pos, caches):
-        prev, yd, x = self.blocks_v3(x, pos, caches)
-        return fused_u_only(prev, yd.to(torch.float16), residual=x)
-
-    fused_head = False       # with v3: embedding (+ the previous step's argmax) and [U_down^T + residual -> final RMSNorm -> lm_head -> argmax
-                             # partials, pos += 1] as one launch each (csrc/decode_head.hip)
-
-    def step_fused_head(self, ids, pos, caches, logits, part_val, part_idx):
-        x = torch.empty((ids.numel(), self.h), dtype=torch.float16, device=ids.device)
-        ops.decode_embed(self.tok.weight, ids, x, part_val=part_val, part_idx=part_idx)
-        prev, yd, x = self.blocks_v3(x, pos, caches)
-        return fused_head(prev, yd, x, self.norm, self.lm_head.weight, logits, part_val, part_idx, pos_inc=pos)
-
-    def blocks_v3(self, x, pos, caches):
-        """per block, six launches: [U_down^T(prev) + residual -> RMSNorm -> V_qkv -> GEMM q,k,v] [U_qkv^T + rotary + attention]
-        [V_o -> GEMM o] [U_o^T + residual -> RMSNorm -> V_gate/up -> GEMM gate, up] [U_gate^T, U_up^T (/) s: 688 x 16, decode_bigp.hip]
-        [silu * up -> V_down -> GEMM down, K-slices through fp32 atomics]; a 688 x 688 factor is 0.9 MB, not a workgroup's pass: the
-        11008-wide operators are cut over the p index (csrc/decode_bigp.hip)"""
-        h16 = torch.float16
-        prev, yd = None, None
-        for blk, (kc, vc) in zip(self.blocks, caches):
-            qkv = [blk.q_proj, blk.k_proj, blk.v_proj]
-            if prev is None:
-                ys, _ = fused_stage(qkv, x=x, ln=blk.n1, y_dtype=h16)
-            else:
-                ys, x = fused_stage(qkv, prev=prev, y_prev=yd, residual=x, ln=blk.n1, store=True, y_dtype=h16)
-            o = fused_attention(qkv, ys, kc, vc, pos, self.cos, self.sin)
-            yo = fused_stage([blk.o_proj], x=o, y_dtype=h16)[0][0]
-            gu = [blk.gate_proj, blk.up_proj]
-            ygu, x = fused_stage(gu, prev=blk.o_proj, y_prev=yo, residual=x, ln=blk.n2, store=True, y_dtype=h16)
-            yd = fused_bigp_tail(gu, blk.down_proj, ygu)                       # fp32 accumulator, ZT order of down_proj's U
-            prev = blk.down_proj
-        return prev, yd, x
-
-    def step(self, ids, pos, caches, arange):
-        x = self.tok(ids)
-        if self.v3:
-            return self.lm_head(self.norm(self.step_v3(x, pos, caches)))
-        for blk, (kc, vc) in zip(self.blocks, caches):
-            x = blk(x, kc, vc, pos, self.cos, self.sin)
-        return self.lm_head(self.norm(x))
+        super().__init__(nn.Embedding(vocab, h, dtype=dtype), [decode.LlamaBlock.random(h, ffn, heads, eps, dtype) for _ in range(layers)],
+                         RMSNorm(h, eps, dtype), nn.Linear(h, vocab, bias=False, dtype=dtype), heads, inv, maxpos)
 
 
 def pack_model(model, bits, dev, seed=0, twin=True):

@@ -28,57 +28,21 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from quip_amd import ops, method  # noqa: E402
+from quip_amd import ops, method, decode  # noqa: E402
 from quip_amd.quant import (QuantLinear, packed_forward_fused, packed_v_stage, packed_gemm_stage, packed_u_stage,  # noqa: E402
                             packed_u_then_v, packed_vgemm_stage, vgemm_fusable, fused_stage, fused_ok, fused_attention, fused_attention_ok, fused_u_only,
                             fused_head, fused_head_ok)
 
 
-class Block(nn.Module):
-    def __init__(self, h, ffn, heads, dtype):
-        super().__init__()
-        self.h, self.heads, self.hd = h, heads, h // heads
-        self.ln1, self.ln2 = nn.LayerNorm(h, dtype=dtype), nn.LayerNorm(h, dtype=dtype)
-        mk = lambda i, o: nn.Linear(i, o, bias=True, dtype=dtype)
-        self.k_proj, self.v_proj, self.q_proj, self.out_proj = mk(h, h), mk(h, h), mk(h, h), mk(h, h)
-        self.fc1, self.fc2 = mk(h, ffn), mk(ffn, h)
-        self.fused = False      # packed layers: q/k/v grouped, LayerNorm / residual / ReLU folded into the operator launches
-        self.fused_attn = False  # cache append + q K^T + softmax + p V as one launch (quip_amd/csrc/decode_attn.hip)
+class Decoder(decode.OPTDecoder):
+    """quip_amd.decode.OPTDecoder (the package's engine: plain / fused / v3 / fused-head steps) built from random-init modules of the
+    given geometry, plus the launch sequences of rounds 1-2 kept here as timing variants (chained, vfused, tiled)."""
 
-    def forward(self, x, kc, vc, pos, mask):
-        """x [bs, h]; kc / vc [bs, heads, maxlen, hd]; pos int64 [1] on the device; mask [maxlen] additive."""
-        bs = x.shape[0]
-        if self.fused:
-            q, k, v = packed_forward_fused([self.q_proj, self.k_proj, self.v_proj], x, ln=self.ln1)
-        else:
-            hn = self.ln1(x)
-            q, k, v = self.q_proj(hn), self.k_proj(hn), self.v_proj(hn)
-        if self.fused_attn:
-            o = ops.decode_attention(q, k, v, kc, vc, pos)
-        else:                                               # the eager chain of HF's attention: nine launches
-            q, k, v = (t.view(bs, self.heads, 1, self.hd) for t in (q, k, v))
-            kc.index_copy_(2, pos, k)
-            vc.index_copy_(2, pos, v)
-            att = torch.matmul(q, kc.transpose(2, 3)) * (1.0 / math.sqrt(self.hd)) + mask    # [bs, heads, 1, maxlen]
-            att = torch.softmax(att.float(), -1).to(x.dtype)
-            o = torch.matmul(att, vc).reshape(bs, self.h)
-        if self.fused:
-            x = packed_forward_fused([self.out_proj], o, residual=x)[0]
-            hmid = packed_forward_fused([self.fc1], x, ln=self.ln2, relu=True)[0]
-            return packed_forward_fused([self.fc2], hmid, residual=x)[0]
-        x = x + self.out_proj(o)
-        x = x + self.fc2(F.relu(self.fc1(self.ln2(x))))
-        return x
-
-
-class Decoder(nn.Module):
     def __init__(self, layers=24, h=2048, ffn=8192, heads=32, vocab=50272, maxpos=2048, dtype=torch.float16):
-        super().__init__()
-        self.h, self.layers_n, self.heads = h, layers, heads
-        self.tok = nn.Embedding(vocab, h, dtype=dtype)
-        self.posemb = nn.Embedding(maxpos + 2, h, dtype=dtype)
-        self.blocks = nn.ModuleList([Block(h, ffn, heads, dtype) for _ in range(layers)])
-        self.lnf = nn.LayerNorm(h, dtype=dtype)
+        blocks = [decode.OPTBlock.random(h, ffn, heads, dtype) for _ in range(layers)]
+        for b in blocks:
+            b.fused_attn = False     # the variants below switch the single-launch attention on themselves
+        super().__init__(nn.Embedding(vocab, h, dtype=dtype), nn.Embedding(maxpos + 2, h, dtype=dtype), blocks, nn.LayerNorm(h, dtype=dtype), heads)
 
     chained = False          # packed + fused attention + U^T->LN->V chains across layers: 10 launches per block
 
@@ -125,53 +89,6 @@ class Decoder(nn.Module):
 
     split_handover = False
 
-    v3_attn = True           # with v3: the output-side operators of q / k / v in the attention launch (csrc/decode_attn.hip) -- 5 launches
-    v3 = False               # csrc/decode_fused.hip: everything between two GEMMs in the consuming GEMM's prologue -- 5 launches per block (6 with v3_attn off)
-
-    def v3_ok(self, bs):
-        b = self.blocks[0]
-        return (fused_ok([b.q_proj, b.k_proj, b.v_proj], bs, prev=b.fc2) and fused_ok([b.out_proj], bs, norm=False)
-                and fused_ok([b.fc1], bs, prev=b.out_proj) and fused_ok([b.fc2], bs, prev=b.fc1, norm=False, residual=False))
-
-    def step_v3(self, x, pos, caches):
-        prev, y2, x = self.blocks_v3(x, pos, caches)
-        return fused_u_only(prev, y2, residual=x)
-
-    fused_head = False       # with v3: embedding (+ the previous step's argmax) and [U_fc2^T + residual -> final LN -> lm_head -> argmax partials,
-                             # pos += 1] as one launch each (csrc/decode_head.hip) instead of ~11 torch / rocBLAS launches per token
-
-    def step_fused_head(self, ids, pos, caches, logits, part_val, part_idx):
-        x = torch.empty((ids.numel(), self.h), dtype=torch.float16, device=ids.device)
-        ops.decode_embed(self.tok.weight, ids, x, pos_table=self.posemb.weight, pos=pos, pos_offset=2, part_val=part_val, part_idx=part_idx)
-        prev, y2, x = self.blocks_v3(x, pos, caches)
-        return fused_head(prev, y2, x, self.lnf, self.tok.weight, logits, part_val, part_idx, pos_inc=pos)
-
-    def blocks_v3(self, x, pos, caches):
-        """per block: [U_fc2^T(prev) + residual -> LN1 -> V_qkv -> GEMM qkv] [U_qkv^T + attention] [V_o -> GEMM o]
-        [U_o^T + residual -> LN2 -> V_fc1 -> GEMM fc1] [U_fc1^T + relu -> V_fc2 -> GEMM fc2]; returns (fc2 of the last block, its output
-        in the projected basis, the residual stream): the last U_fc2^T + residual belongs to whatever ends the step."""
-        dt = x.dtype
-        prev, y2 = None, None
-        h16 = torch.float16                                     # y consumed by another fused launch: fp16 (its scatter rounds to fp16 anyway)
-        for blk, (kc, vc) in zip(self.blocks, caches):
-            qkv = [blk.q_proj, blk.k_proj, blk.v_proj]
-            attn_u = self.v3_attn and fused_attention_ok(qkv, kc)
-            ydt = h16 if attn_u else torch.float32
-            if prev is None:
-                ys, _ = fused_stage(qkv, x=x, ln=blk.ln1, y_dtype=ydt)
-            else:
-                ys, x = fused_stage(qkv, prev=prev, y_prev=y2, residual=x, ln=blk.ln1, store=True, y_dtype=ydt)
-            if attn_u:                                          # U_q^T, U_k^T, U_v^T + bias in the attention launch's prologue: 5 launches per block
-                o = fused_attention(qkv, ys, kc, vc, pos)
-            else:                                               # (the fused launches hand y over in ZT order: K3 wants the natural one)
-                q, k, v = packed_u_stage(qkv, [l.from_zt(y) for l, y in zip(qkv, ys)], dt)
-                o = ops.decode_attention(q, k, v, kc, vc, pos)
-            yo = fused_stage([blk.out_proj], x=o, y_dtype=h16)[0][0]
-            (y1,), x = fused_stage([blk.fc1], prev=blk.out_proj, y_prev=yo, residual=x, ln=blk.ln2, store=True, y_dtype=h16)
-            y2 = fused_stage([blk.fc2], prev=blk.fc1, y_prev=y1, relu=True, y_dtype=h16)[0][0]
-            prev = blk.fc2
-        return prev, y2, x
-
     tiled = False            # every operator application cut into 16 x 16 output tiles over 8-32 workgroups (csrc/ortho_tile.hip): 13 launches
 
     def step_tiled(self, x, pos, caches):
@@ -188,19 +105,15 @@ class Decoder(nn.Module):
 
     def step(self, ids, pos, caches, arange):
         """one token for every batch row: ids int64 [bs], pos int64 [1]; returns logits [bs, vocab]."""
-        x = self.tok(ids) + self.posemb(pos + 2)
-        if self.v3:
-            return F.linear(self.lnf(self.step_v3(x, pos, caches)), self.tok.weight)
-        if self.tiled:
-            return F.linear(self.lnf(self.step_tiled(x, pos, caches)), self.tok.weight)
-        if self.vfused:
-            return F.linear(self.lnf(self.step_vfused(x, pos, caches)), self.tok.weight)
-        if self.chained:
-            return F.linear(self.lnf(self.step_chained(x, pos, caches)), self.tok.weight)
-        mask = torch.where(arange <= pos, 0.0, float("-inf")).to(x.dtype)
-        for blk, (kc, vc) in zip(self.blocks, caches):
-            x = blk(x, kc, vc, pos, mask)
-        return F.linear(self.lnf(x), self.tok.weight)
+        if not self.v3:
+            x = self.embed(ids, pos)
+            if self.tiled:
+                return self.head(self.step_tiled(x, pos, caches))
+            if self.vfused:
+                return self.head(self.step_vfused(x, pos, caches))
+            if self.chained:
+                return self.head(self.step_chained(x, pos, caches))
+        return super().step(ids, pos, caches, arange)
 
 
 def pack_model(model, bits, dev, seed=0):

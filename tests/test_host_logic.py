@@ -103,3 +103,64 @@ def test_share_hessian_between_layers_with_the_same_input():
         assert qm.nsamples == 4 and qm.H.dtype == torch.float32
         assert torch.equal(qm.H, ref.H)
     assert f1.H.data_ptr() != lead.H.data_ptr() and f2.H.data_ptr() != lead.H.data_ptr()
+
+
+# ---- quip_amd.decode: the host side of the decode engine (no kernel runs here) -------------------------------------------------
+def _tiny_hf(arch, **kw):
+    if arch == "opt":
+        from transformers import OPTConfig, OPTForCausalLM
+        cfg = dict(hidden_size=64, ffn_dim=128, num_hidden_layers=2, num_attention_heads=4, word_embed_proj_dim=64, vocab_size=96,
+                   max_position_embeddings=16)
+        cfg.update(kw)
+        return OPTForCausalLM(OPTConfig(**cfg))
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = dict(hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4, vocab_size=96,
+               max_position_embeddings=16, tie_word_embeddings=False)
+    cfg.update(kw)
+    return LlamaForCausalLM(LlamaConfig(**cfg))
+
+
+def test_decoder_from_hf_shares_the_models_modules():
+    """from_hf builds its block records over the Hugging Face model's own modules (no copies): what make_quant swapped in is
+    what the engine runs (reference: benchmark() drives the model object it was handed, opt.py:431-482)"""
+    from quip_amd import decode
+    m = _tiny_hf("opt")
+    d = decode.decoder_from_hf(m)
+    assert d.arch == "opt" and d.layers_n == 2 and d.heads == 4 and d.h == 64
+    assert d.tok is m.model.decoder.embed_tokens and d.blocks[1].fc2 is m.model.decoder.layers[1].fc2
+    assert d.head_weight.data_ptr() == m.model.decoder.embed_tokens.weight.data_ptr()        # tied head
+    assert not d.packed() and decode.best_mode(d, 1, torch.float16) == "plain"
+    m = _tiny_hf("llama")
+    d = decode.decoder_from_hf(m, max_len=16)
+    assert d.arch == "llama" and d.blocks[0].down_proj is m.model.layers[0].mlp.down_proj and d.head_weight is m.lm_head.weight
+    assert d.cos.shape == (16, 16) and d.cos.dtype == torch.float32
+    inv = m.model.rotary_emb.inv_freq.float()
+    np.testing.assert_allclose(d.sin[3, :8].numpy(), torch.sin(3 * inv).numpy(), rtol=1e-6)
+    d.half()                                                  # a dtype change must not narrow the rotary tables
+    assert d.cos.dtype == torch.float32
+
+
+def test_decode_engine_refuses_what_it_cannot_serve():
+    import pytest
+    from quip_amd import decode
+    with pytest.raises(NotImplementedError):
+        decode.decoder_from_hf(_tiny_hf("opt", word_embed_proj_dim=32))            # projected embeddings (opt-350m's form)
+    with pytest.raises(NotImplementedError):
+        decode.decoder_from_hf(_tiny_hf("opt", do_layer_norm_before=False))
+    with pytest.raises(NotImplementedError):
+        decode.decoder_from_hf(_tiny_hf("llama", num_key_value_heads=2))           # grouped-query attention
+    with pytest.raises(RuntimeError):
+        decode.DecodeEngine.from_hf(_tiny_hf("opt").half(), device="cpu")          # no CPU path
+
+
+def test_collect_packed_patches_free_only_while_active():
+    from quip_amd import decode, method
+    orig = method.QuantMethod.free
+    lin = torch.nn.Linear(8, 8)
+    with decode.collect_packed() as packed:
+        assert method.QuantMethod.free is not orig
+        m = method.QuantMethod(lin)
+        m.free()                                              # no integer codes on this method: skipped, free() still runs
+        assert m.H is None and packed.layers == []
+    assert method.QuantMethod.free is orig
+    assert packed.named(torch.nn.Sequential(lin)) == {}
