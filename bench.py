@@ -20,8 +20,10 @@ add_batch call of the calibration pass (K7, fp64 X^T X at the OPT-1.3B fc2 input
 `roofline.traffic` is the PMC-measured HBM traffic per launch of the last committed rocprofv3 pass
 (profiles/k2_pmc_latest.json, FETCH_SIZE corrected x2 as MI355X_MICROARCH.md prescribes), or null.
 `cpu_baseline` = what the reference actually runs at inference (dense fake-quant nn.Linear: torch CPU
-F.linear, fp32) on the host cores, a bounded sample, rank 0 / N=1 only ("port": same library call, not
-the reference's files).
+F.linear, fp32) on the host cores, a bounded sample, rank 0 / N=1 only (kind "reference": the reference has no packed
+CPU GEMM, this library call IS its inference op).  `ldlq_cpu_reference`: the reference's own bal.py / vector_balance.py
+(staged copies, oracle/ref_ldlq_time.py in a subprocess) timed on the same host cores; `ldlq_cpu_port`: the oracle's C
+restatement beside it.
 """
 import argparse
 import ctypes
@@ -517,6 +519,9 @@ def main():
                          "dense_fp16_eager_torch_attention_tok_per_s": round(dres["dense_fp16"]["tok_per_s"], 1),
                          "packed_weight_MB": round(dres["packed_w2"]["packed_weight_MB"], 1),
                          "hbm_bound_tok_per_s": round(dres["packed_w2"]["hbm_bound_tok_per_s"]),
+                         "roofline": {"bound": "hbm", "what": "packed codes + fp16 head read once per token at 8 TB/s", "achieved": round(dres[best]["tok_per_s"], 1),
+                                      "peak": round(dres["packed_w2"]["hbm_bound_tok_per_s"]), "unit": "tok/s",
+                                      "frac": round(dres[best]["tok_per_s"] / dres["packed_w2"]["hbm_bound_tok_per_s"], 4)},
                          "data": "random-init OPT-1.3B architecture, nearest-rounded qfn-b codes (scripts/decode_opt.py)"}
 
     # ---- the Llama half of the decode row (llama.py:418-471): Llama-2-7B architecture, w2, batch 1 (scripts/decode_llama.py) ----
@@ -543,6 +548,9 @@ def main():
                                    "dense_fp16_same_harness_tok_per_s": round(lres["dense_fp16"]["tok_per_s"], 1),
                                    "packed_weight_MB": round(lres["packed_w2"]["packed_weight_MB"], 1),
                                    "hbm_bound_tok_per_s": round(lres["packed_w2"]["hbm_bound_tok_per_s"]),
+                                   "roofline": {"bound": "hbm", "what": "packed codes + fp16 head read once per token at 8 TB/s", "achieved": round(lres[lbest]["tok_per_s"], 1),
+                                                "peak": round(lres["packed_w2"]["hbm_bound_tok_per_s"]), "unit": "tok/s",
+                                                "frac": round(lres[lbest]["tok_per_s"] / lres["packed_w2"]["hbm_bound_tok_per_s"], 4)},
                                    "data": "random-init Llama-2-7B architecture, nearest-rounded qfn-b codes (scripts/decode_llama.py)"}
         except Exception as ex:
             out["decode_llama"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
@@ -583,9 +591,30 @@ def main():
                                     "kind": "port"}
         except Exception as ex:
             out["ldlq_cpu_port"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+        try:        # the reference's OWN files (bal.py, vector_balance.py, method.py, quant.py staged into oracle/_ref/cpu) on the host cores
+            import subprocess
+            here = os.path.dirname(os.path.abspath(__file__))
+            script = os.path.join(here, "oracle", "ref_ldlq_time.py")
+            if os.path.exists(os.path.join(here, "oracle", "_ref", "cpu", "bal.py")):
+                pr = subprocess.run([sys.executable, script, "--sizes", "2048,4096", "--budget", "75"], capture_output=True, text=True, timeout=240)
+                rows = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")]
+                done = [r for r in rows if "fasterquant_time_attr_s" in r]
+                out["ldlq_cpu_reference"] = {
+                    "what": "the reference's Balance.fasterquant (bal.py:21-48 -> vector_balance.py:155-199 round_ldl / 218-291 round_ldl_block), its own "
+                            "files run unmodified on this box's host cores: w2 qfn b, W = 0.02 randn fp16, H = X^T X / (d + 256), preproc(gptqH, rescale, "
+                            "proj, extra 0) -- BASELINE.md section 2's recipe; seconds = the `.time` attribute fasterquant sets",
+                    "kind": "reference", "cores": (done[0]["threads"] if done else None), "logical_cpus": os.cpu_count(),
+                    "runs": rows, "sample": "2048^2 and 4096^2, lazy_batch False and True, each layer whole, once (a run is skipped when 75 s have passed)"}
+            else:
+                out["ldlq_cpu_reference"] = {"error": "oracle/_ref/cpu not staged (no reference checkout when build() ran)"}
+        except Exception as ex:
+            out["ldlq_cpu_reference"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
         out["cpu_baseline"] = {"value": round(FLOPS / dt / 1e12, 4), "unit": "TFLOP/s", "cores": cores,
                                "cores_note": f"torch.get_num_threads() = the threads F.linear used; {os.cpu_count()} logical CPUs on the box",
-                               "kind": "port",
+                               "kind": "reference",
+                               "kind_note": "the reference has no packed CPU GEMM: at inference it runs Hugging Face's dense nn.Linear on the "
+                                            "fake-quantised weights, i.e. this very torch F.linear call (opt.py:193-299); the reference's LDLQ is "
+                                            "timed from its own files in `ldlq_cpu_reference`, the C restatement in `ldlq_cpu_port`",
                                "sample": f"{n} calls of torch CPU F.linear fp32 x[16,4096] @ What[4096,4096]^T "
                                          f"(dense fake-quant weights, what the reference runs at inference), "
                                          f"{dt * 1e3:.3f} ms/call"}
