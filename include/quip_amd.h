@@ -526,8 +526,18 @@ int quipamd_preproc_trace_ridge(float *H, int64_t d, float ridge, void *workspac
  * in the coordinates of quipamd_gptq_round (columns reversed, FT strictly upper), with W, Q held TRANSPOSED:
  *   WT_rev: float [d, m] in / scratch (updated in place);  QT_rev: float [d, m] out;  colscale_rev: float [d] out, the scale of every
  *   column;  workspace: quipamd_gptq_qfnb_workspace_bytes(m, d) bytes.  m <= 32768 (at most 256 workgroups wait for each other: the
- *   launch assumes they are all resident, i.e. the GPU is not shared with another long-running grid).  Deterministic. */
+ *   launch assumes they are all resident, i.e. the GPU is not shared with another long-running grid).  Deterministic.
+ * Co-residency is inferred from the occupancy query, not guaranteed: NOTHING ELSE may hold compute units of the device while the sweep
+ * runs (another stream's grid, an RCCL collective of a sharded run, a CU-masked queue).  The wait is therefore BOUNDED: a workgroup that has
+ * polled one granule ~4 M times (seconds) raises an abort word in the workspace and every workgroup of the sweep leaves; the results are
+ * then undefined.  The call is asynchronous, so the caller reads that word once the stream has drained:
+ *   int32 at byte quipamd_gptq_qfnb_info_offset(m, d) of `workspace`: 0 = the sweep completed, 1 = abandoned (treat as QUIPAMD_ERR_LAUNCH;
+ *   quip_amd.ops.gptq_round_qfnb raises, quip_amd.gptq falls back to the column walk).
+ * quipamd_gptq_qfnb_debug(short_grid, spin_limit): test hook -- launch `short_grid` workgroups too few and give up after `spin_limit` polls
+ * (0, 0 restores the defaults); exercises the abandon path on a healthy device. */
 int64_t quipamd_gptq_qfnb_workspace_bytes(int64_t m, int64_t d);
+int64_t quipamd_gptq_qfnb_info_offset(int64_t m, int64_t d);
+void quipamd_gptq_qfnb_debug(int short_grid, int64_t spin_limit);
 int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits, float *QT_rev, float *colscale_rev, void *workspace, int64_t m,
                             int64_t d, void *stream);
 

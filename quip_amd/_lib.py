@@ -72,6 +72,8 @@ SIGNATURES = {
     "quipamd_preproc_rescale": [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp],
     "quipamd_preproc_trace_ridge": [c_vp, c_i64, c_float, c_vp, c_vp],
     "quipamd_gptq_qfnb_workspace_bytes": [c_i64, c_i64],
+    "quipamd_gptq_qfnb_info_offset": [c_i64, c_i64],
+    "quipamd_gptq_qfnb_debug": [c_int, c_i64],
     "quipamd_gptq_round_qfnb": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp],
     "quipamd_cholesky_config": [c_int, c_int],
     "quipamd_ldlq_config": [c_int],
@@ -103,8 +105,8 @@ def load():
         except AttributeError as e:
             raise QuipAmdError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else None if name in ("quipamd_vecquant_invalidate", "quipamd_cholesky_config", "quipamd_ldlq_config") else
-                      c_i64 if name in ("quipamd_hessian_fast_workspace", "quipamd_vecquant_workspace_bytes", "quipamd_gptq_qfnb_workspace_bytes", "quipamd_preproc_workspace_bytes") else c_int)
+        fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else None if name in ("quipamd_vecquant_invalidate", "quipamd_cholesky_config", "quipamd_ldlq_config", "quipamd_gptq_qfnb_debug") else
+                      c_i64 if name in ("quipamd_hessian_fast_workspace", "quipamd_vecquant_workspace_bytes", "quipamd_gptq_qfnb_workspace_bytes", "quipamd_gptq_qfnb_info_offset", "quipamd_preproc_workspace_bytes") else c_int)
     _lib = lib
     return lib
 

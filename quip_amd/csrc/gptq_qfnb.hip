@@ -31,6 +31,9 @@ struct GbArgs {
     float *ET;                    // [128][m] residuals of the block
     float *colscale;              // [d] out (reversed)
     unsigned long long *gran;     // [2][G] granules {tag : 32, partial : 32}
+    int *abort_flag;              // device int: set when a poll ran out of patience (a workgroup of the grid never became resident); every
+                                  // workgroup then leaves, later launches of the sweep return at once, the host reports QUIPAMD_ERR_LAUNCH
+    long long spin_limit;         // polls of one granule before giving up
     int64_t m, d;
     int b0, nb, G;
     float maxq;
@@ -57,11 +60,14 @@ __global__ __launch_bounds__(GB_T) void gptqb_chain_kernel(GbArgs A)
     float *F1 = gsm + GB_NB * R;                                      // [128][128]: F1[jl][cl] = FT[b0 + jl][b0 + cl]
     float *E = F1 + GB_NB * GB_NB;                                    // [R]
     float *red = E + R;                                               // [R] squares, then [0] = the column's sum
+    float *gaveup = red + R;                                          // [1] != 0: the sweep was abandoned (bounded poll below)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = tid % R, cg = tid / R;
     const int wg = blockIdx.x, G = A.G, nb = A.nb, b0 = A.b0;
     const int64_t row = (int64_t)wg * R + r;
     const bool live = row < A.m;
+    if (tid == 0)                                                     // an earlier block of this sweep gave up: leave (read once per workgroup,
+        gaveup[0] = __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;   // so that the exit is uniform)
 
     const int64_t rowc = live ? row : A.m - 1;                        // (clamped address + select: a guarded load is a branch and a round trip)
     for (int cl = cg; cl < nb; cl += NCG) {
@@ -73,6 +79,7 @@ __global__ __launch_bounds__(GB_T) void gptqb_chain_kernel(GbArgs A)
         F1[jl * GB_NB + cl] = A.FT[(int64_t)(b0 + jl) * A.d + b0 + cl];
     }
     __syncthreads();
+    if (gaveup[0] != 0.f) return;
     const float fm = (float)A.m;
     for (int cl = nb - 1; cl >= 0; --cl) {
         const int cp = b0 + cl;                                       // reversed column index
@@ -93,18 +100,35 @@ __global__ __launch_bounds__(GB_T) void gptqb_chain_kernel(GbArgs A)
                 __hip_atomic_store(gr + wg, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, p), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             // gather: lane l polls granules l, l + 64, ...; the values are summed in a fixed order
+            // The poll is BOUNDED: co-residency of the G workgroups is inferred from the occupancy query, not guaranteed (another stream's
+            // kernel, an RCCL collective, a masked device can keep a workgroup off the chip).  A lane that has polled one granule
+            // spin_limit times -- or sees the sweep's abort flag -- gives up; the wave raises the flag and the workgroup leaves.
             float s = 0.f;
-            for (int i = lane; i < G; i += 64) {
+            bool bad = false;
+            for (int i = lane; i < G && !bad; i += 64) {
                 unsigned long long v;
-                do {
+                long long spins = 0;
+                for (;;) {
                     v = __hip_atomic_load(gr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((unsigned)(v >> 32) != tag);
+                    if ((unsigned)(v >> 32) == tag) break;
+                    if (++spins >= A.spin_limit ||
+                        ((spins & 255) == 0 && __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        bad = true;
+                        break;
+                    }
+                }
                 s += __builtin_bit_cast(float, (unsigned)v);
             }
+            const bool dead = __any(bad);
+            if (dead && lane == 0) __hip_atomic_store(A.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s = fg_wave_sum(s);
-            if (lane == 0) red[0] = s;
+            if (lane == 0) {
+                red[0] = s;
+                if (dead) gaveup[0] = 1.f;
+            }
         }
         __syncthreads();
+        if (gaveup[0] != 0.f) return;                                     // (uniform: every thread reads the same word behind the barrier)
         const float S = red[0];
         const float scale = 2.4f * sqrtf(__fdiv_rn(S, fm)) + 1e-16f;     // quant.py:159
         if (owner) {
@@ -167,9 +191,14 @@ __global__ __launch_bounds__(256) void gptqb_far_kernel(GbArgs A)
         }
 }
 
+// test hooks (quipamd_gptq_qfnb_debug): launch that many workgroups too few -- the rest wait for granules nobody writes -- and the poll budget
+int g_gb_debug_short_grid = 0;
+constexpr long long GB_SPIN_LIMIT = 1ll << 22;                        // ~0.5 us per poll: a few seconds; a healthy wait is a few polls
+long long g_gb_spin_limit = GB_SPIN_LIMIT;
+
 template <int R> int gb_chain(const GbArgs &A, hipStream_t s)
 {
-    const size_t lds = (size_t)(GB_NB * R + GB_NB * GB_NB + 2 * R) * sizeof(float);
+    const size_t lds = (size_t)(GB_NB * R + GB_NB * GB_NB + 2 * R + 4) * sizeof(float);
     auto kern = gptqb_chain_kernel<R>;
     static QaPerDevice attr;
     const int dv = attr.dev();
@@ -178,11 +207,23 @@ template <int R> int gb_chain(const GbArgs &A, hipStream_t s)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: cannot raise dynamic LDS to %zu", lds);
         if (dv >= 0) attr.done[dv] = true;
     }
-    kern<<<(unsigned)A.G, GB_T, lds, s>>>(A);
+    kern<<<(unsigned)(A.G - g_gb_debug_short_grid > 0 ? A.G - g_gb_debug_short_grid : 1), GB_T, lds, s>>>(A);
     return QUIPAMD_OK;
 }
 
 }   // namespace
+
+extern "C" void quipamd_gptq_qfnb_debug(int short_grid, int64_t spin_limit)
+{
+    g_gb_debug_short_grid = short_grid > 0 ? short_grid : 0;
+    g_gb_spin_limit = spin_limit > 0 ? spin_limit : GB_SPIN_LIMIT;
+}
+
+extern "C" int64_t quipamd_gptq_qfnb_info_offset(int64_t m, int64_t d)
+{
+    (void)d;
+    return (int64_t)GB_NB * m * 4 + 2 * ((m + 15) / 16) * 8;          // the 64 spare bytes behind the granules
+}
 
 extern "C" int64_t quipamd_gptq_qfnb_workspace_bytes(int64_t m, int64_t d)
 {
@@ -203,7 +244,7 @@ extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits,
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
         return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: cannot query the device");
     auto fits = [&](int R, const void *kern) {
-        const size_t lds = (size_t)(GB_NB * R + GB_NB * GB_NB + 2 * R) * sizeof(float);
+        const size_t lds = (size_t)(GB_NB * R + GB_NB * GB_NB + 2 * R + 4) * sizeof(float);
         if (lds > 64 * 1024 && hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, GB_T, lds) != hipSuccess) return false;
@@ -223,7 +264,10 @@ extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits,
     A.ET = (float *)workspace;
     A.gran = (unsigned long long *)((char *)workspace + (size_t)GB_NB * m * 4);
     A.m = m; A.d = d; A.G = (int)G; A.maxq = (float)((1 << bits) - 1);
-    if (hipMemsetAsync(A.gran, 0, (size_t)2 * G * 8, s) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: memset failed");
+    A.abort_flag = (int *)((char *)workspace + quipamd_gptq_qfnb_info_offset(m, d));
+    A.spin_limit = g_gb_spin_limit;
+    // granules AND the abort flag behind them (2 * ceil(m / 16) * 8 bytes of granule space + 64 spare, all zeroed)
+    if (hipMemsetAsync(A.gran, 0, (size_t)(2 * ((m + 15) / 16) * 8 + 64), s) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: memset failed");
     // lazy blocks from the top of the reversed order; block edges at multiples of 128, so a remainder of d is the FIRST block (where a
     // block ends only decides when its residuals reach the columns behind it, not what they are)
     int64_t b1 = d;

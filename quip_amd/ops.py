@@ -864,9 +864,21 @@ def gptq_round_qfnb(W, FT, bits):
     wt = W.flip(1).t().contiguous()                                   # [d, m], columns reversed
     qt = torch.empty_like(wt)
     cs = torch.empty(d, dtype=torch.float32, device=W.device)
-    ws = torch.empty(int(_lib.load().quipamd_gptq_qfnb_workspace_bytes(m, d)), dtype=torch.uint8, device=W.device)
+    lib = _lib.load()
+    ws = torch.empty(int(lib.quipamd_gptq_qfnb_workspace_bytes(m, d)), dtype=torch.uint8, device=W.device)
     _lib.call("quipamd_gptq_round_qfnb", _p(wt), _p(FT), int(bits), _p(qt), _p(cs), _p(ws), m, d, _stream())
+    # the sweep's workgroups wait for each other behind a BOUNDED poll (include/quip_amd.h): the abort word is read once the stream has
+    # drained -- the callers synchronise right behind this call anyway (gptq.py: torch.cuda.synchronize() closes fasterquant's timer)
+    off = int(lib.quipamd_gptq_qfnb_info_offset(m, d))
+    if m and d and int(ws[off:off + 4].view(torch.int32).item()) != 0:
+        raise _lib.QuipAmdError("quipamd_gptq_round_qfnb: the sweep was abandoned -- its workgroups were not all co-resident "
+                                "(is another grid / an RCCL collective holding compute units of this device?)")
     return qt.t().flip(1).contiguous(), cs.flip(0).contiguous()
+
+
+def gptq_qfnb_debug(short_grid=0, spin_limit=0):
+    """test hook of csrc/gptq_qfnb.hip (quipamd_gptq_qfnb_debug): launch `short_grid` workgroups too few, give up after `spin_limit` polls"""
+    _lib.load().quipamd_gptq_qfnb_debug(int(short_grid), int(spin_limit))
 
 
 def cholesky_lt(H, check=True):

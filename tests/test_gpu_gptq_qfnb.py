@@ -67,3 +67,28 @@ def test_fasterquant_takes_the_kernel_for_qfn_b():
         assert hasattr(meth, "column_scale") == use
         outs[use] = (lin.weight.data.float().clone(), meth.error)
     assert abs(outs[True][1] - outs[False][1]) <= 2e-2 * outs[False][1]
+
+
+def test_a_grid_that_is_not_co_resident_is_an_error_not_a_hang():
+    """the chain kernel's workgroups wait for each other.  With the test hook launching one workgroup too few, the
+    others poll granules nobody writes: the bounded poll gives up, the abort word is raised, ops raises, and GPTQ.fasterquant falls back
+    to the column walk (the 'co-resident' route of gptq._kernel_round) -- within seconds, with the device still usable."""
+    import time
+    from quip_amd import _lib
+    torch.manual_seed(3)
+    m, d = 256, 256
+    W = (torch.randn(m, d, device=DEV) * 0.02).contiguous()
+    X = torch.randn(2 * d, d, device=DEV)
+    H = X.T @ X / (2 * d) + 0.01 * torch.eye(d, device=DEV)
+    FT = ops.gptq_feedback(H)
+    good, _ = ops.gptq_round_qfnb(W.clone(), FT, 2)
+    ops.gptq_qfnb_debug(short_grid=1, spin_limit=20000)
+    try:
+        t0 = time.time()
+        with pytest.raises(_lib.QuipAmdError, match="co-resident"):
+            ops.gptq_round_qfnb(W.clone(), FT, 2)
+        assert time.time() - t0 < 30.0
+    finally:
+        ops.gptq_qfnb_debug(0, 0)
+    again, _ = ops.gptq_round_qfnb(W.clone(), FT, 2)                  # the device and the library are fine afterwards
+    assert torch.equal(again, good)
