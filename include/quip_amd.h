@@ -113,11 +113,15 @@ int quipamd_dequant_gemm(const void *x, int x_dtype, const int32_t *qweight, int
  * vec: float [d] (one token); mat: the reference's CANONICAL packing ([d/32*3, m] 3-bit, [d/8, m] 4-bit); mul: float [m],
  * pre-filled by the caller (with the bias) and accumulated into; scales: float [m]; zeros: float [m] = zero * scale.
  * Adapters over quipamd_repack_canonical_to_stream + quipamd_dequant_gemm: the repacked weights, the split activations and
- * the integer zeros live in `workspace` (quipamd_vecquant_workspace_bytes).  The O(m d) repack runs once per
- * (workspace, mat, bits, m, d, stream): the library remembers (host side) what a workspace's STREAM words were repacked from, so
- * a decode loop calling with the same layer and workspace pays it on the first token only.  After rewriting `mat` IN PLACE, or
- * using the workspace for anything else, call quipamd_vecquant_invalidate(workspace) (NULL: forget every workspace). */
+ * the integer zeros live in `workspace` (quipamd_vecquant_workspace_bytes).  The entry points are STATELESS: the O(m d) repack
+ * runs on every call, so the same pointers with new contents give the new result -- unless the caller opts in:
+ *   quipamd_vecquant_prepare(bits, mat, m, d, workspace, workspace_bytes, stream) repacks once and registers (host side)
+ *   workspace -> (mat, bits, m, d, stream); calls with exactly that layer, workspace and stream then skip the repack (a decode loop
+ *   pays it once, not per token).  The registration is the caller's promise that `mat` does not change: after rewriting `mat` IN
+ *   PLACE, freeing it, or using the workspace for anything else, prepare again or call quipamd_vecquant_invalidate(workspace)
+ *   (NULL: forget every workspace). */
 int64_t quipamd_vecquant_workspace_bytes(int bits, int64_t m, int64_t d);
+int quipamd_vecquant_prepare(int bits, const int32_t *mat, int64_t m, int64_t d, void *workspace, int64_t workspace_bytes, void *stream);
 void quipamd_vecquant_invalidate(const void *workspace);
 int quipamd_vecquant3matmul(const float *vec, const int32_t *mat, float *mul, const float *scales, const float *zeros,
                             int64_t m, int64_t d, void *workspace, int64_t workspace_bytes, void *stream);
@@ -128,9 +132,8 @@ int quipamd_vecquant4matmul(const float *vec, const int32_t *mat, float *mul, co
  * benchmarks and the forced-kernel parity tests; never needed for correctness.  cfg = int32[4] {family, p1, p2, 0}
  * (NULL or all 0 = heuristic): family 1 = round-1 kernels; 2 = "h" (bs <= 16, d <= 4096: p1 = waves, p2 = chunks per
  * wave); 3 = "s" (bs <= 16 weight stream: p1 = row tiles per workgroup, p2 = k-split); 4 = "mb" (bs > 16: p1 = 44 | 22,
- * the tile shape); 5 = "pf" (prefill: every 2-bit tile dequantised ONCE per workgroup into LDS, 32x32x16 MFMA mainloop; 2-bit qfn b,
- * m % 256 == 0, d % 256 == 0: p1 = 21 (256 x 128 tile) | 22 (256 x 256)) -- the heuristic's choice from 256 batch rows on.
- * An unsupported combination fails with QUIPAMD_ERR_UNSUPPORTED.  Per call, thread safe. */
+ * the tile shape).  (Family 5, the round-3 prefill kernel, lost to "mb" at every shape and is no longer in the library:
+ * scripts/dqgemm_pf_lab.hip.)  An unsupported combination fails with QUIPAMD_ERR_UNSUPPORTED.  Per call, thread safe. */
 int quipamd_dequant_gemm_cfg(const void *x, int x_dtype, const int32_t *qweight, int bits, int layout, int qfn,
                              const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
                              int accumulate, int64_t bs, int64_t m, int64_t d, const int32_t *cfg, void *stream);

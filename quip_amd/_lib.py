@@ -24,6 +24,7 @@ SIGNATURES = {
     "quipamd_unpack": [c_vp, c_int, c_int, c_vp, c_i64, c_i64, c_vp],
     "quipamd_repack_canonical_to_stream": [c_vp, c_int, c_vp, c_i64, c_i64, c_vp],
     "quipamd_vecquant_workspace_bytes": [c_int, c_i64, c_i64],
+    "quipamd_vecquant_prepare": [c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
     "quipamd_vecquant_invalidate": [c_vp],
     "quipamd_vecquant3matmul": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
     "quipamd_vecquant4matmul": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],

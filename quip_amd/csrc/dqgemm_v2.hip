@@ -81,10 +81,9 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
 int k2v2_launch(const K2Call &c, void *stream)
 {
     if (c.cfg[0] == K2_FAM_OLD) return K2V2_NOT_TAKEN;
-    // dqgemm_pf.hip (every 2-bit tile dequantised once per workgroup into LDS, 32x32x16 mainloop) runs only when forced: measured
-    // SLOWER than the mb kernel at every prefill shape (profiles/r03t_k2_prefill.jsonl: 686 vs 924 TFLOP/s at 4096^2 x 2048, 697 vs 938 at
-    // 28672 x 7168 x 256; dense bf16 rocBLAS 1058 / 825) -- see the header of that file for why.
-    if (c.cfg[0] == K2_FAM_PF) return k2pf_launch(c, stream);
+    // (family 5, the round-3 prefill kernel -- every 2-bit tile dequantised once per workgroup into LDS, 32x32x16 mainloop -- measured SLOWER
+    //  than the mb kernel at every prefill shape, profiles/r03t_k2_prefill.jsonl, and left the library in round 4: scripts/dqgemm_pf_lab.hip)
+    if (c.cfg[0] == K2_FAM_PF) return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: kernel family 5 (prefill lab) is not part of the library");
     K2Args A;
     A.x = (const uint16_t *)c.x; A.qw = (const u32x4 *)c.qweight; A.d = c.d;
     EpiArgs &e = A.e;

@@ -18,6 +18,3 @@ struct K2Call {
 // returns K2V2_NOT_TAKEN (use the round-1 kernels), QUIPAMD_OK, or an error status
 int k2v2_launch(const K2Call &c, void *stream);
 
-// dqgemm_pf.hip: the prefill kernel (weights dequantised once per workgroup into LDS, 32x32x16 MFMA mainloop); 2-bit qfn b only
-bool k2pf_supported(const K2Call &c);
-int k2pf_launch(const K2Call &c, void *stream);

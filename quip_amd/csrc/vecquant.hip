@@ -5,10 +5,12 @@
 // quant.py:192-220; [d/8, m] for 4 bit, zeroShot/models/quant.py:190-199), mul fp32 [m] pre-filled by the caller with the
 // bias and ACCUMULATED into, scales fp32 [m], zeros fp32 [m] = zero * scale (quant.py:186, zeroShot/models/quant.py:187):
 //     mul[r] += sum_k (scales[r] * q[r,k] - zeros[r]) * vec[k]
-// They are adapters: the weights are repacked CANONICAL -> STREAM on the device into the caller's workspace -- ONCE per
-// (workspace, mat, bits, m, d, stream): a host-side table remembers what each workspace holds, so a decode loop that calls
-// the symbol token after token with the same layer and workspace pays the O(m d) repack on the first token only
-// (quipamd_vecquant_invalidate(workspace) after rewriting `mat` in place or reusing the workspace for something else) --,
+// They are adapters: the weights are repacked CANONICAL -> STREAM on the device into the caller's workspace on EVERY call (the
+// entry points are stateless: the same pointers with rewritten contents give the new result) -- unless the caller has OPTED IN
+// with quipamd_vecquant_prepare(bits, mat, m, d, workspace, ..): that call repacks once and registers (workspace -> mat, bits, m,
+// d, stream); a decode loop that then calls the symbol token after token with the same layer and workspace skips the O(m d)
+// repack.  The registration is the caller's promise that `mat` does not change: prepare again (or
+// quipamd_vecquant_invalidate(workspace)) after rewriting `mat` in place or reusing the workspace --,
 // vec is split into two bf16 terms hi + lo (relative error 2^-16, the reference multiplies in fp32) and K2 runs once per
 // term under the accumulate contract.  The source of quant_cuda is not in the reference tree (un-vendored IST-DASLab/gptq):
 // the contract above is re-derived from the pack formulas and the call sites -- "parity unpinned" at this one boundary.
@@ -66,11 +68,9 @@ int vecquant(int bits, const float *vec, const int32_t *mat, float *mul, const f
         cached = it != g_repacked.end() && it->second == key;
         if (!cached) g_repacked.erase(workspace);
     }
-    if (!cached) {
+    if (!cached) {                                                 // not prepared for exactly this layer: repack, remember nothing
         rc = quipamd_repack_canonical_to_stream(mat, bits, qs, m, d, stream);
         if (rc) return rc;
-        std::lock_guard<std::mutex> lock(g_repack_mutex);
-        g_repacked[workspace] = key;
     }
     const int64_t n = m > d ? m : d;
     vecquant_prep_kernel<<<qa_div_up(n, 256), 256, 0, (hipStream_t)stream>>>(vec, hi, lo, d, scales, zeros, zint, m);
@@ -88,6 +88,21 @@ extern "C" int64_t quipamd_vecquant_workspace_bytes(int bits, int64_t m, int64_t
 {
     const int cb = bits == 3 ? 4 : bits;
     return (int64_t)(align256((size_t)m * d * cb / 8) + 2 * align256((size_t)d * 2) + align256((size_t)m * 4));
+}
+
+extern "C" int quipamd_vecquant_prepare(int bits, const int32_t *mat, int64_t m, int64_t d, void *workspace, int64_t ws_bytes, void *stream)
+{
+    QA_REQUIRE(mat && workspace && (bits == 3 || bits == 4), QUIPAMD_ERR_ARG, "vecquant_prepare: null pointer / bits");
+    QA_REQUIRE(ws_bytes >= quipamd_vecquant_workspace_bytes(bits, m, d), QUIPAMD_ERR_ARG, "vecquant_prepare: workspace too small");
+    {
+        std::lock_guard<std::mutex> lock(g_repack_mutex);
+        g_repacked.erase(workspace);
+    }
+    const int rc = quipamd_repack_canonical_to_stream(mat, bits, (int32_t *)workspace, m, d, stream);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(g_repack_mutex);
+    g_repacked[workspace] = RepackKey{mat, bits, m, d, stream};
+    return QUIPAMD_OK;
 }
 
 extern "C" void quipamd_vecquant_invalidate(const void *workspace)

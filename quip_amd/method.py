@@ -236,7 +236,9 @@ class QuantMethod:
         if preproc_rescale:
             if fused:
                 # the same operations in the same order as the torch chain below, in three launches (csrc/preproc.hip)
-                w = self.layer.weight.data.contiguous()
+                # a NEW tensor, like the torch chain below and the reference (method.py:155 rebinds weight.data): the launch rewrites W in
+                # place, and an alias of the old weight (a `full_W = layer.weight.data` kept for error_compute, tied weights) must not move
+                w = self.layer.weight.data.clone(memory_format=torch.contiguous_format)
                 H = self.H.to(torch.float32).contiguous()
                 if H.data_ptr() == self.H.data_ptr():
                     H = H.clone()                                   # the torch chain leaves the caller's H untouched too

@@ -87,9 +87,11 @@ _VQ_WORKSPACES = {}      # mat.data_ptr() -> (weakref to mat, mat._version, bits
 def vecquantmatmul(bits, vec, mat, mul, scales, zeros):
     """quant_cuda.vecquant{3,4}matmul(vec, mat, mul, scales, zeros) (quant.py:229, zeroShot/models/quant.py:207): accumulates
     into `mul` (float32 [m], pre-filled with the bias) and returns None like the reference's extension.  Every `mat` keeps its
-    own workspace alive for as long as the tensor lives, so the CANONICAL -> STREAM repack inside the library runs on the first
-    call only (a decode loop calls this once per token per layer); an in-place change of `mat` (torch's version counter) or a
-    new tensor at the same address invalidates it."""
+    own workspace alive for as long as the tensor lives and registers it with quipamd_vecquant_prepare, so the CANONICAL -> STREAM
+    repack runs on the first call only (a decode loop calls this once per token per layer); an in-place change of `mat` that torch's
+    version counter sees, or a new tensor at the same address, prepares again.  NOT seen: writes through `mat.data` / `.detach()`
+    views and raw-pointer writes (they do not bump `_version`) -- call `ops.vecquant_forget(mat)` after those.  The C entry points
+    themselves are stateless unless prepared (include/quip_amd.h)."""
     import weakref
     _need_gpu(vec, mat, mul)
     assert bits in (3, 4) and mul.dtype == torch.float32 and mul.is_contiguous() and mat.dtype == torch.int32
@@ -111,12 +113,22 @@ def vecquantmatmul(bits, vec, mat, mul, scales, zeros):
             for k in [k for k, e in _VQ_WORKSPACES.items() if e[0]() is None]:        # layers that are gone
                 lib.quipamd_vecquant_invalidate(_p(_VQ_WORKSPACES.pop(k)[3]))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=mul.device)
-            lib.quipamd_vecquant_invalidate(_p(ws))                # the allocator may hand back an address the library remembers
+            _lib.call("quipamd_vecquant_prepare", bits, _p(matc), m, d, _p(ws), nbytes, _stream())   # opt in: repack once, here
             _VQ_WORKSPACES[mat.data_ptr()] = (weakref.ref(mat), mat._version, bits, ws)
     else:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=mul.device)
         lib.quipamd_vecquant_invalidate(_p(ws))
     _lib.call(f"quipamd_vecquant{bits}matmul", _p(vec), _p(matc), _p(mul), _p(sc), _p(zs), m, d, _p(ws), nbytes, _stream())
+
+
+def vecquant_forget(mat=None):
+    """drop the prepared workspace of `mat` (all of them when None): the next vecquantmatmul repacks from the tensor's current contents"""
+    lib = _lib.load()
+    keys = list(_VQ_WORKSPACES) if mat is None else [mat.data_ptr()]
+    for k in keys:
+        ent = _VQ_WORKSPACES.pop(k, None)
+        if ent is not None:
+            lib.quipamd_vecquant_invalidate(_p(ent[3]))
 
 
 # ------------------------------------------------------------------------------------------------- K5

@@ -157,6 +157,7 @@ class QuantLinear(nn.Module):
         self.register_buffer('inv_scaleWH', None)
         self.U = None     # ops.OrthoOp over out features
         self.V = None     # ops.OrthoOp over in features
+        self._drop_derived()
 
     _F32_BUFFERS = ('scales', 'zeros', 'bias', 'inv_scaleWH')
 
@@ -164,7 +165,10 @@ class QuantLinear(nn.Module):
         """model.half() / .to(dtype) must not narrow the grid parameters: the kernels read them as float32 (and fp16 could
         not hold them).  Device moves are followed, dtype changes of these buffers are undone without a round trip."""
         keep = {n: getattr(self, n, None) for n in self._F32_BUFFERS}
+        dev0 = self.qweight.device
         super()._apply(fn, recurse)
+        if self.qweight.device != dev0:       # everything the decode launches derived from the packed state holds device pointers
+            self._drop_derived()
         for n, old in keep.items():
             new = getattr(self, n, None)
             if old is not None and new is not None and new.dtype != torch.float32:
@@ -178,9 +182,7 @@ class QuantLinear(nn.Module):
         dev = codes.device
         # what the decode launches derive from the packed state (decode_qweight, bias16, the layer-pair tables) is rebuilt on next use;
         # tables other layers keep about THIS one are keyed by its generation
-        for k in ('_qweight_d', '_bias16', '_pair_tables', '_bigp_tail'):
-            self.__dict__.pop(k, None)
-        self.__dict__['_pack_gen'] = self.__dict__.get('_pack_gen', 0) + 1
+        self._drop_derived()
         self.qweight = ops.pack(codes, self.bits, ops.LAYOUT_STREAM)
         self.scales = scale.to(dev, torch.float32).reshape(-1).clone()
         self.zeros = None if zero is None else zero.to(dev, torch.float32).reshape(-1).clone()
@@ -188,6 +190,30 @@ class QuantLinear(nn.Module):
         self.inv_scaleWH = None if scaleWH is None else (1.0 / scaleWH.to(dev, torch.float32))
         self.U = U if (U is None or isinstance(U, ops.OrthoOp)) else ops.OrthoOp(U, dev)
         self.V = V if (V is None or isinstance(V, ops.OrthoOp)) else ops.OrthoOp(V, dev)
+        return self
+
+    _GEN = [0]
+
+    def _drop_derived(self):
+        """forget what the decode launches derived from the packed state (decode_qweight, bias16, the layer-pair / MLP-tail tables) and take a
+        new generation number: tables OTHER layers keep about this one are keyed by it (process-wide counter: a recycled id() cannot
+        collide with a dead layer's entry), and a device move invalidates them like a re-pack does"""
+        for k in ('_qweight_d', '_bias16', '_pair_tables', '_bigp_tail'):
+            self.__dict__.pop(k, None)
+        QuantLinear._GEN[0] += 1
+        self.__dict__['_pack_gen'] = QuantLinear._GEN[0]
+
+    def packed_bytes(self):
+        """bytes of codes this layer holds on its device: the STREAM words, plus the decode-order copy once a fused decode launch built it"""
+        qd = self.__dict__.get('_qweight_d')
+        return self.qweight.numel() * 4 + (0 if qd is None else qd.numel() * 4)
+
+    @torch.no_grad()
+    def decode_only(self):
+        """keep ONLY the decode-order codes (the fused decode launches read nothing else): frees the natural-order STREAM words, after which
+        forward() / the K3-side stages of this layer raise.  For serving from the fused engine at 2 bits per weight instead of 4."""
+        self.decode_qweight()
+        self.qweight = torch.empty(0, dtype=torch.int32, device=self.qweight.device)
         return self
 
     @classmethod
@@ -212,6 +238,8 @@ class QuantLinear(nn.Module):
         of U, columns in image order of V -- built once (unpack, index, pack on the device) and kept beside `qweight`"""
         qd = self.__dict__.get('_qweight_d')
         if qd is None or qd.device != self.qweight.device:
+            if self.qweight.numel() == 0:
+                raise RuntimeError("QuantLinear.decode_only() dropped the natural-order codes: re-pack the layer to rebuild its decode copy")
             m, d = self.outfeatures, self.infeatures
             codes = ops.unpack(self.qweight, self.bits, ops.LAYOUT_STREAM, m, d)
             if self.U is not None and self.U.fold_ok:         # (an operator no decode launch can run keeps the natural order: its side
@@ -254,6 +282,7 @@ class QuantLinear(nn.Module):
         ql.bias, ql.inv_scaleWH = dev(st["bias"]), dev(st["inv_scaleWH"])
         ql.U = None if st["U"] is None else ops.OrthoOp(st["U"], device)
         ql.V = None if st["V"] is None else ops.OrthoOp(st["V"], device)
+        ql._drop_derived()
         return ql
 
     def act_dtype(self, x):
@@ -267,6 +296,8 @@ class QuantLinear(nn.Module):
         return torch.bfloat16
 
     def forward(self, x):
+        if self.qweight.numel() == 0 and self.infeatures * self.outfeatures:
+            raise RuntimeError("QuantLinear.decode_only() kept the decode-order codes only: this layer runs through the fused decode launches")
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
         adt = self.act_dtype(x)
@@ -640,7 +671,7 @@ def _bigp_tail_tables(ups, down):
     of the consumer's V (b * p + a of the position inv_pin_V[i] natural index i lands on), its bias in image order, and -- on the last
     producer -- 1 / scaleWH of the consumer in image order (the column rescale rides on `up`: silu(g) * (u / s))"""
     cache = down.__dict__.setdefault('_bigp_tail', {})
-    key = tuple((id(q), q.__dict__.get('_pack_gen', 0)) for q in ups)
+    key = tuple((id(q), q.__dict__.get('_pack_gen', 0)) for q in ups) + (str(down.V.device),)
     if key not in cache:
         V = down.V
         dev, n, p = V.device, V.n, V.p
@@ -734,7 +765,7 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
         if (q0.V.p, q0.V.q) == (128, 64) and len(qls) == 1 and residual is None and lnp is None and rows <= 2 and not store:
             # n = 8192 (OPT fc1 -> fc2): the layer pair's per-lane tables turn gather + scale + scatter into one scatter (decode_fused.hip)
             cache = q0.__dict__.setdefault('_pair_tables', {})
-            key = (id(prev), prev.__dict__.get('_pack_gen', 0))
+            key = (id(prev), prev.__dict__.get('_pack_gen', 0), str(dev))
             if key not in cache:
                 cache[key] = ops.pair_tables(prev.U, q0.V, bias16(prev), kw['colscale'][0])
             kw.update(pair=cache[key])

@@ -198,7 +198,7 @@ class ShardedLDLQ:
         """spmd=True: every rank runs the same driver loop and joins each collective by itself (worker_round): no job announcements"""
         self.group, self.src, self.compute, self.force_exchange, self.spmd = group, src, compute, force_exchange, spmd
         self._lt_ready = None      # (key, (LT, work)): the coming job's LT, already broadcast under the previous job's rounding
-        self._queue = []           # [(key, LT)] of the coming round() calls, in call order (queue_LTs)
+        self._queue = []           # [(key, LT, H)] of the coming round() calls, in call order (queue_LTs); H held so that its address stays its own
         self.desyncs = 0           # how often a round() call did not match the head of the queue (the queue is dropped then)
 
     def _announce(self, op):
@@ -214,7 +214,9 @@ class ShardedLDLQ:
         (ldlqRG's permuted copy of H, a Linear that took the greedy-pass path, a skipped layer) drops the queue and the
         prefetched LT and factors / broadcasts its own H: slower, never wrong."""
         assert not self._queue and self._lt_ready is None, "queue_LTs: the previous block's queue was not consumed"
-        self._queue = [(h_key(H), LT) for H, LT in items]
+        # the entry KEEPS H alive: as long as it is queued its storage cannot be freed and handed to another tensor of the same shape
+        # (ldlqRG's permuted copy ...), so the (address, shape) key cannot match a different Hessian (ADVICE r3)
+        self._queue = [(h_key(H), LT, H) for H, LT in items]
 
     def queued(self, key=None):
         """is the next round() call served from the queue?  key = h_key(H) of the H about to be rounded"""
@@ -225,7 +227,7 @@ class ShardedLDLQ:
             self._announce(_OP_LDLQ)
         ready = None
         if self._queue and self._queue[0][0] == key and key is not None:
-            _, LT = self._queue.pop(0)
+            _, LT, _ = self._queue.pop(0)
             if self._lt_ready is not None and self._lt_ready[0] == key:
                 ready = self._lt_ready[1]
         elif self._queue or self._lt_ready is not None:              # not what the queue describes: never round with its factor
@@ -235,7 +237,7 @@ class ShardedLDLQ:
         if stale is not None and stale[1][1] is not None:
             stale[1][1].wait()                                        # a prefetch nobody will use: let it land, then forget it
         assert LT is not None, "round(): no LT given and none queued for this H"
-        nxt_key, nxt = self._queue[0] if self._queue else (None, None)
+        nxt_key, nxt, _ = self._queue[0] if self._queue else (None, None, None)
         out = ldlq_round_sharded(wgrid, LT, bits, eta=eta, src=self.src, group=self.group, compute=self.compute,
                                  force_exchange=self.force_exchange, lt_ready=ready, next_LT=nxt)
         if nxt is not None:
@@ -332,7 +334,8 @@ def all_reduce_hessians(methods, group=None):
 
 
 def h_key(H):
-    """identity of the Hessian a queued LT was factored from: the tensor's storage address and shape"""
+    """identity of the Hessian a queued LT was factored from: the tensor's storage address and shape (unique while the tensor is
+    alive -- ShardedLDLQ's queue holds a reference to every H it describes)"""
     return (int(H.data_ptr()), tuple(H.shape))
 
 

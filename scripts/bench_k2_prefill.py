@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""K2 at prefill-sized batches: the prefill kernel (csrc/dqgemm_pf.hip, family 5) next to the round-2 MB kernel (family 4) and the dense
+"""K2 at prefill-sized batches: the round-2 MB kernel (family 4; the round-3 prefill kernel it beat is scripts/dqgemm_pf_lab.hip, no longer in the library) and the dense
 fp16 / bf16 rocBLAS GEMM of the same shape, cold-ish operands (weights cycled over several copies), HIP events around graph-captured
 launches.  Fractions against the 2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md)."""
 import json
@@ -47,7 +47,7 @@ def main():
         for dt in (torch.bfloat16,):
             x = torch.randn(bs, d, device=dev).to(dt)
             y = torch.empty(bs, m, dtype=dt, device=dev)
-            for name, cfg in (("mb", (4, 44)), ("pf_256x128", (5, 21)), ("pf_256x256", (5, 22)), ("auto", None)):
+            for name, cfg in (("mb", (4, 44)), ("auto", None)):
                 it = [0]
 
                 def f():

@@ -1,3 +1,7 @@
+// LAB RECORD (round 4: moved out of the library).  The round-3 prefill kernel: correct, tested, and SLOWER than the mb family at every
+// prefill shape (profiles/r03t_k2_prefill.jsonl: 686 vs 924 TFLOP/s at 4096^2 x 2048).  It shipped as a forced-only family (cfg family 5)
+// that the heuristic never picked; it is kept here as the negative result it is, not built by __graft_entry__.build().
+// To rebuild it as a lab: hipcc --offload-arch=gfx950 -O3 -I include -I quip_amd/csrc -c scripts/dqgemm_pf_lab.hip
 // dqgemm_pf.hip -- K2 for prefill-sized batches (bs >= 256): y[b, r] = alpha (sum_k (OFF + q[r,k]) x[b,k] - c0 sum_k x[b,k]) + bias[r]
 // (quant.py:222-233 with the qfn-b grid of quant.py:10-15; the contract of quipamd_dequant_gemm).
 //

@@ -119,6 +119,18 @@ def test_ldlq_pack_decode_matches_the_fake_quant_model_under_hf(arch, extra):
         got2 = torch.stack([e2.forward(t)[0].float().clone() for t in toks])
         report[mode] = _gate(f"{arch}-extra{extra}-{mode}", got2, ref, toks)[0]
     decode.set_mode(eng.dec, eng.mode)
+    if extra == 1:
+        # serving form: only the decode-order codes stay resident (2 bits per weight, not 4); the fused engine does not notice,
+        # the layer-by-layer paths refuse loudly
+        before = sum(q.packed_bytes() for q in named.values())
+        for q in named.values():
+            q.decode_only()
+        assert sum(q.packed_bytes() for q in named.values()) * 2 == before
+        eng.reset()
+        got3 = torch.stack([eng.forward(t)[0].float().clone() for t in toks])
+        assert torch.equal(got3, got)
+        with pytest.raises(RuntimeError):
+            next(iter(named.values()))(torch.zeros(1, next(iter(named.values())).infeatures, dtype=torch.float16, device=DEV))
     print(f"e2e {arch} pre_proj_extra={extra}:", report)
 
 

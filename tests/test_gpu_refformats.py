@@ -78,6 +78,54 @@ def test_vecquant_matmul_by_the_references_signature(ops, O, bits, m, d):
     assert np.linalg.norm(mul3.cpu().numpy() - want3) / np.linalg.norm(want3) <= 1e-4
 
 
+def test_vecquant_c_entry_is_stateless_unless_prepared(ops, O):
+    """the C entry point called with the SAME workspace / mat addresses after the contents of `mat` changed must use the new
+    contents (it used to remember the repack per address).  With quipamd_vecquant_prepare the caller opts into the remembered repack --
+    and then a silent change of `mat` is the caller's to announce (prepare again / invalidate)."""
+    import ctypes
+    from quip_amd import _lib
+    bits, m, d = 4, 64, 512
+    rng = np.random.default_rng(11)
+    scales = torch.full((m,), 0.01, device=DEV)
+    zeros = torch.full((m,), 0.08, device=DEV)                          # zero * scale, zero = 8
+    vec = torch.from_numpy(rng.standard_normal(d).astype(np.float32)).to(DEV)
+    c1 = rng.integers(0, 16, (m, d)).astype(np.uint8)
+    c2 = (15 - c1).astype(np.uint8)
+    mat = ops.pack(torch.from_numpy(c1).to(DEV), bits, ops.LAYOUT_CANONICAL)
+    lib = _lib.load()
+    nbytes = int(lib.quipamd_vecquant_workspace_bytes(bits, m, d))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    lib.quipamd_vecquant_invalidate(ctypes.c_void_p(ws.data_ptr()))
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def run():
+        mul = torch.zeros(m, device=DEV)
+        _lib.call("quipamd_vecquant4matmul", vp(vec), vp(mat), vp(mul), vp(scales), vp(zeros), m, d, vp(ws), nbytes, st)
+        return mul.cpu().numpy().astype(np.float64)
+
+    def want(c):
+        return (0.01 * c.astype(np.float64) - 0.08) @ vec.cpu().numpy().astype(np.float64)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel(run(), want(c1)) <= 1e-4
+    mat.data.copy_(ops.pack(torch.from_numpy(c2).to(DEV), bits, ops.LAYOUT_CANONICAL))      # through .data: no version bump, same address
+    assert rel(run(), want(c2)) <= 1e-4                                  # stateless: the new contents
+    _lib.call("quipamd_vecquant_prepare", bits, vp(mat), m, d, vp(ws), nbytes, st)          # opt in
+    assert rel(run(), want(c2)) <= 1e-4
+    mat.data.copy_(ops.pack(torch.from_numpy(c1).to(DEV), bits, ops.LAYOUT_CANONICAL))
+    assert rel(run(), want(c2)) <= 1e-4                                  # prepared: the repack of the prepare call is what runs (documented)
+    lib.quipamd_vecquant_invalidate(vp(ws))
+    assert rel(run(), want(c1)) <= 1e-4
+    # the Python wrapper's guard is torch's version counter; a write through .data needs ops.vecquant_forget
+    mul = torch.zeros(m, device=DEV)
+    ops.vecquantmatmul(bits, vec, mat, mul, scales, zeros)
+    mat.data.copy_(ops.pack(torch.from_numpy(c2).to(DEV), bits, ops.LAYOUT_CANONICAL))
+    ops.vecquant_forget(mat)
+    mul = torch.zeros(m, device=DEV)
+    ops.vecquantmatmul(bits, vec, mat, mul, scales, zeros)
+    assert rel(mul.cpu().numpy().astype(np.float64), want(c2)) <= 1e-4
+
+
 def test_reference_quant3linear_checkpoint_loads(ops, O):
     """state dict with the reference Quant3Linear's buffers (quant.py:176-197) -> quip_amd.quant.Quant3Linear, via make_quant3 +
     load_state_dict like opt.py:350-381 load_quant3 does."""

@@ -164,3 +164,22 @@ def test_collect_packed_patches_free_only_while_active():
         assert m.H is None and packed.layers == []
     assert method.QuantMethod.free is orig
     assert packed.named(torch.nn.Sequential(lin)) == {}
+
+
+def test_lt_queue_keeps_its_hessians_alive():
+    """a queued LT is matched by (address, shape) of its H; the queue must hold H, or a freed H's address can be handed to a
+    different Hessian of the same shape (ldlqRG's permuted copy) that then matches the stale entry"""
+    import gc
+    import weakref
+    from quip_amd import shard
+    h = shard.ShardedLDLQ()
+    H1 = torch.randn(64, 64)
+    ref = weakref.ref(H1)
+    key = shard.h_key(H1)
+    h.queue_LTs([(H1, torch.zeros(64, 64))])
+    del H1
+    gc.collect()
+    assert ref() is not None                                   # still alive: held by the queue
+    others = [torch.randn(64, 64) for _ in range(32)]          # none of them can sit at the queued address
+    assert all(shard.h_key(t) != key for t in others)
+    assert h.queued(key) and not h.queued(shard.h_key(others[0]))
