@@ -28,6 +28,9 @@ DEVICE_RNG = False       # True: draw the Gaussians of the SO(p) sampler with to
                          # host RNG that bounds preproc (0.8 M / 3.8 M normals per n = 8192 / 11008 operator)
 
 
+OPERATOR_PREFETCH = False  # True: sample the operators of the Linears whose QuantMethod objects already exist on a host thread (below)
+
+
 def _prime_factors(n):
     """ascending prime factors (stands in for primefac.primefac, method.py:17; not installed here)."""
     out, f = [], 2
@@ -146,6 +149,148 @@ def rand_ortho_butterfly_nopermute(n):
 _GENERATORS = {0: gen_rand_ortho_butterfly, 1: gen_rand_ortho_butterfly_noblock, 2: gen_rand_ortho_butterfly_nopermute}
 
 
+class _OperatorPrefetcher:
+    """Operator sampling off the critical path, on the SAME random streams (opt-in: OPERATOR_PREFETCH).
+
+    `gen_rand_orthos` is host work on numpy's legacy Gaussian stream (kept for seed parity with the reference, method.py:20-31) plus a
+    chain of small batched GEMMs: 80 ms per OPT-1.3B block, 0.23 s per Llama-2-7B block (profiles/r04a: 7.3 of 58 s) -- all of it inside
+    `preproc`, between two GPU phases, with the GPU idle.  The reference's drivers create every QuantMethod of a block BEFORE they run the
+    block's calibration forwards (opt.py:99-129 then :141-143; llama.py:91-116 then :130-131) and call `preproc` on them in that same order
+    (opt.py:151, llama.py:138).  So when a QuantMethod is constructed its (rows, columns) are queued here, and a host thread draws the
+    operators of the queued Linears -- in queue order, U before V, exactly the draws `preproc` would make (numpy's and torch's global
+    generators are only ever touched by these draws while a driver runs) -- while the main thread feeds the GPU with the block's forwards
+    and Hessian launches.  `preproc` then takes its pair from the head of the queue.
+
+    What the thread cannot know is the generator `preproc` will be asked for (`preproc_proj_extra`) or whether it will project at all: it
+    assumes the arguments of the previous `preproc` call (nothing is prefetched before the first one).  Every speculative draw is preceded
+    by a snapshot of both generator states; a `preproc` that does not find what it needs at the head of the queue (other flags, another
+    call order, a method that was dropped) rewinds numpy and torch to the snapshot in front of the oldest unconsumed draw, forgets the
+    queue and samples synchronously -- the streams are then exactly where the reference's would be.  Seeded runs therefore reproduce the
+    same operators with and without the prefetcher (tests/test_host_logic.py)."""
+
+    def __init__(self):
+        import threading
+        self.lock = threading.Condition()
+        self.pending = []            # [(key, rows, cols)] not yet sampled
+        self.ready = []              # [(key, extra, projU, projV, snapshot)] sampled, in draw order
+        self.busy = None             # key being sampled
+        self.flags = None            # (extra,) of the last projecting preproc call, or None
+        self.thread = None
+        self.stop = False
+        self.stats = {"prefetched": 0, "rewinds": 0, "sync": 0, "wait_s": 0.0}
+
+    # -- main thread ---------------------------------------------------------------------------------------------------------------
+    def request(self, key, rows, cols):
+        import threading
+        with self.lock:
+            if self.flags is None:
+                return
+            self.pending.append((key, rows, cols))
+            if self.thread is None or not self.thread.is_alive():
+                self.stop = False
+                self.thread = threading.Thread(target=self._run, name="quip_amd-operator-prefetch", daemon=True)
+                self.thread.start()
+            self.lock.notify_all()
+
+    def take(self, key, extra):
+        """(projU, projV) for the method `key` drawn with generator `extra`, or None after rewinding (the caller samples itself)"""
+        import time
+        t0 = time.perf_counter()
+        with self.lock:
+            while True:
+                if self.ready and self.ready[0][0] == key and self.ready[0][1] == extra:
+                    _, _, U, V, _ = self.ready.pop(0)
+                    self.stats["prefetched"] += 1
+                    self.stats["wait_s"] += time.perf_counter() - t0
+                    return U, V
+                head_is_mine = (not self.ready and ((self.busy == key) or (self.busy is None and self.pending and self.pending[0][0] == key)))
+                if head_is_mine and self.flags == (extra,):
+                    self.lock.wait(0.05)                 # being sampled / next in line with the right generator: wait for it
+                    continue
+                self._rewind_locked()
+                self.stats["sync"] += 1
+                return None
+
+    def note_flags(self, proj, extra):
+        with self.lock:
+            self.flags = (extra,) if proj else None
+
+    def drain(self):
+        """forget everything queued and rewind the generators to where a run without the prefetcher would have left them"""
+        with self.lock:
+            self._rewind_locked()
+
+    def shutdown(self):
+        with self.lock:
+            self._rewind_locked()
+            self.stop = True
+            self.lock.notify_all()
+        if self.thread is not None:
+            self.thread.join(timeout=10)
+
+    def _rewind_locked(self):
+        self.pending.clear()
+        while self.busy is not None:                     # let the draw in flight finish: its snapshot is the one to go back to
+            self.lock.wait(0.05)
+        if self.ready:
+            np_state, torch_state = self.ready[0][4]
+            np.random.set_state(np_state)
+            torch.set_rng_state(torch_state)
+            self.ready.clear()
+            self.stats["rewinds"] += 1
+
+    # -- the thread ------------------------------------------------------------------------------------------------------------------
+    def _run(self):
+        side = torch.cuda.Stream() if torch.cuda.is_available() else None
+        while True:
+            with self.lock:
+                while not self.pending and not self.stop:
+                    self.lock.wait(0.5)
+                if self.stop:
+                    return
+                key, rows, cols = self.pending.pop(0)
+                extra = self.flags[0] if self.flags is not None else None
+                if extra is None:
+                    continue
+                self.busy = key
+                snap = (np.random.get_state(), torch.get_rng_state())
+            try:
+                gen = _GENERATORS[extra]
+                if side is not None:
+                    with torch.cuda.stream(side):
+                        U, V = gen(rows), gen(cols)
+                else:
+                    U, V = gen(rows), gen(cols)
+                item = (key, extra, U, V, snap)
+            except Exception:                              # a failed draw: hand the stream position back, preproc samples itself
+                item = None
+                np.random.set_state(snap[0])
+                torch.set_rng_state(snap[1])
+            with self.lock:
+                if item is not None:
+                    self.ready.append(item)
+                self.busy = None
+                self.lock.notify_all()
+
+
+_prefetcher = None
+
+
+def operator_prefetcher():
+    global _prefetcher
+    if _prefetcher is None:
+        _prefetcher = _OperatorPrefetcher()
+    return _prefetcher
+
+
+def operator_prefetch_stop():
+    """stop the prefetch thread and rewind the generators past nothing that was not consumed (call when a driver run ends)"""
+    global _prefetcher
+    if _prefetcher is not None:
+        _prefetcher.shutdown()
+        _prefetcher = None
+
+
 class QuantMethod:
     """Base class for the rounding methods (method.py:80-233)."""
 
@@ -161,6 +306,8 @@ class QuantMethod:
         self.H = torch.zeros((self.columns, self.columns), dtype=torch.float64, device=self.dev)
         self.nsamples = 0
         self.preproc_done = False
+        if OPERATOR_PREFETCH and not isinstance(layer, nn.Conv2d):
+            operator_prefetcher().request(id(self), self.rows, self.columns)
 
     # ---- Hessian accumulation (method.py:98-123) ------------------------------------------------------
     # On the GPU, Linear / Conv1D inputs go through K7 (quip_amd/csrc/hessian.hip): fp64 X^T X of the block-lower
@@ -230,6 +377,11 @@ class QuantMethod:
         2 blocked without permutation), then the GPTQ dead-column / damping fix -- in that order.  W is
         written back in the layer's dtype after every stage exactly like the reference (method.py:155,179,191)."""
         self.preproc_gptqH, self.preproc_rescale, self.preproc_proj = preproc_gptqH, preproc_rescale, preproc_proj
+        if OPERATOR_PREFETCH:
+            pf = operator_prefetcher()
+            if not preproc_proj:
+                pf.drain()                                       # nothing to take: whatever was drawn ahead for this call is handed back
+            pf.note_flags(preproc_proj, preproc_proj_extra)
         wdtype = self.layer.weight.data.dtype
         fused = FUSED_PREPROC and self.layer.weight.data.is_cuda and self.layer.weight.data.dim() == 2 and \
             self.layer.weight.data.dtype in (torch.float16, torch.bfloat16, torch.float32)
@@ -262,8 +414,12 @@ class QuantMethod:
             w = self.layer.weight.data.to(torch.float32)
             H = self.H.to(torch.float32)
             gen = _GENERATORS[preproc_proj_extra]
-            self.projU = gen(w.shape[0])                         # rows first, then columns (method.py:162-163)
-            self.projV = gen(w.shape[1])
+            pre = operator_prefetcher().take(id(self), preproc_proj_extra) if OPERATOR_PREFETCH else None
+            if pre is not None:
+                self.projU, self.projV = pre
+            else:
+                self.projU = gen(w.shape[0])                     # rows first, then columns (method.py:162-163)
+                self.projV = gen(w.shape[1])
             U, V = ops.OrthoOp(self.projU, w.device), ops.OrthoOp(self.projV, w.device)
             self._U, self._V = U, V
             n = H.shape[0]

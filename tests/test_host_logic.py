@@ -183,3 +183,76 @@ def test_lt_queue_keeps_its_hessians_alive():
     others = [torch.randn(64, 64) for _ in range(32)]          # none of them can sit at the queued address
     assert all(shard.h_key(t) != key for t in others)
     assert h.queued(key) and not h.queued(shard.h_key(others[0]))
+
+
+def _draw_pairs(M, shapes, extra):
+    gen = M._GENERATORS[extra]
+    return [(gen(r), gen(c)) for r, c in shapes]
+
+
+def _same_op(a, b):
+    (Ba, pia, poa), (Bb, pib, pob) = a, b
+    return all(torch.equal(x, y) for x, y in zip(Ba, Bb)) and torch.equal(pia, pib) and torch.equal(poa, pob)
+
+
+def test_operator_prefetcher_draws_the_same_operators_from_the_same_streams():
+    """method.OPERATOR_PREFETCH: the host thread makes exactly the draws preproc would make, in the same order, on numpy's and torch's
+    global generators -- a seeded run gives the same operators with and without it, and leaves both streams at the same position"""
+    from quip_amd import method as M
+    shapes = [(48, 48), (48, 40), (40, 192), (6, 48)]
+    for extra in (0, 1):
+        np.random.seed(7)
+        torch.manual_seed(7)
+        want = _draw_pairs(M, shapes, extra)
+        tail_np, tail_t = np.random.normal(size=3), torch.randperm(11)
+        np.random.seed(7)
+        torch.manual_seed(7)
+        pf = M._OperatorPrefetcher()
+        pf.note_flags(True, extra)
+        for i, (r, c) in enumerate(shapes):
+            pf.request(i, r, c)
+        got = [pf.take(i, extra) for i in range(len(shapes))]
+        assert all(g is not None for g in got) and pf.stats["prefetched"] == len(shapes)
+        for (gu, gv), (wu, wv) in zip(got, want):
+            assert _same_op(gu, wu) and _same_op(gv, wv)
+        pf.shutdown()
+        np.testing.assert_array_equal(np.random.normal(size=3), tail_np)
+        assert torch.equal(torch.randperm(11), tail_t)
+
+
+def test_operator_prefetcher_rewinds_when_its_guess_was_wrong():
+    """a preproc that does not find its pair at the head of the queue (another generator, another call order, no projection at all) gets the
+    streams back exactly where a run without the prefetcher would have them"""
+    from quip_amd import method as M
+    shapes = [(48, 48), (40, 48), (48, 40)]
+    np.random.seed(3)
+    torch.manual_seed(3)
+    first = _draw_pairs(M, shapes[:1], 0)
+    rest_as_kron = _draw_pairs(M, shapes[1:], 1)                 # the run we must reproduce: generator 0 once, then generator 1
+    np.random.seed(3)
+    torch.manual_seed(3)
+    pf = M._OperatorPrefetcher()
+    pf.note_flags(True, 0)
+    for i, (r, c) in enumerate(shapes):
+        pf.request(i, r, c)
+    u, v = pf.take(0, 0)
+    assert _same_op(u, first[0][0]) and _same_op(v, first[0][1])
+    assert pf.take(1, 1) is None                                 # drawn (or being drawn) with generator 0: rewind, caller samples
+    got = _draw_pairs(M, shapes[1:], 1)
+    for (gu, gv), (wu, wv) in zip(got, rest_as_kron):
+        assert _same_op(gu, wu) and _same_op(gv, wv)
+    assert pf.stats["sync"] == 1
+    # out-of-order take and a drain behave the same way
+    np.random.seed(5)
+    torch.manual_seed(5)
+    want = _draw_pairs(M, shapes[:2], 0)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    pf.note_flags(True, 0)
+    for i, (r, c) in enumerate(shapes):
+        pf.request(10 + i, r, c)
+    assert pf.take(11, 0) is None                                # 10 is at the head, not 11
+    got = _draw_pairs(M, shapes[:2], 0)
+    for (gu, gv), (wu, wv) in zip(got, want):
+        assert _same_op(gu, wu) and _same_op(gv, wv)
+    pf.shutdown()
