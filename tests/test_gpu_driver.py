@@ -253,6 +253,26 @@ def test_llama_ldlq_w2_with_incoherence_processing_matches_the_reference_driver(
     assert (errors > 0).all() and int(np.argmax(errors[7:])) == 6
 
 
+def test_operator_prefetch_changes_no_result():
+    """method.OPERATOR_PREFETCH (operators drawn on a host thread while the block's forwards run, from the same numpy / torch streams):
+    the driver run with it reproduces the run without it EXACTLY -- same operators, hence same weights, errors and logits -- on the
+    incoherence-processing config, through the reference's own opt.py when staged"""
+    import quip_amd.method as M
+    model0, _, e0, l0 = _run("ldlq_w2_incoh")
+    M.OPERATOR_PREFETCH = True
+    try:
+        model1, _, e1, l1 = _run("ldlq_w2_incoh")
+        stats = dict(M.operator_prefetcher().stats)
+    finally:
+        M.OPERATOR_PREFETCH = False
+        M.operator_prefetch_stop()
+    assert stats["prefetched"] >= 6, stats                    # block 1's six Linears at least (block 0's methods exist before the first preproc)
+    np.testing.assert_array_equal(e0, e1)
+    np.testing.assert_array_equal(l0, l1)
+    for (k0, p0), (k1, p1) in zip(model0.named_parameters(), model1.named_parameters()):
+        assert torch.equal(p0, p1), k0
+
+
 def test_zz_report_which_driver_ran():
     """not a gate: prints which driver file executed for every run above (visible with -rA / in the gpurun log)"""
     print("drivers executed:", RAN)
