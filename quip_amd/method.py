@@ -443,6 +443,23 @@ class QuantMethod:
             self.H = H
         self.preproc_done = True
 
+    def skip_operators(self, preproc_proj=True, preproc_proj_extra=0):
+        """consume exactly the random draws `preproc(preproc_proj=..., preproc_proj_extra=...)` would make for this layer and throw them
+        away: a rank that does NOT own this Linear (shard.block_owner_per_linear) keeps numpy's and torch's generators in step with a
+        single-owner run, so the operators of the Linears it does own are the seeded ones"""
+        if OPERATOR_PREFETCH:
+            pf = operator_prefetcher()
+            if not preproc_proj:
+                pf.drain()
+            pf.note_flags(preproc_proj, preproc_proj_extra)
+        if not preproc_proj:
+            return
+        if OPERATOR_PREFETCH and operator_prefetcher().take(id(self), preproc_proj_extra) is not None:
+            return
+        gen = _GENERATORS[preproc_proj_extra]
+        gen(self.rows)
+        gen(self.columns)
+
     def postproc(self):
         """exact inverse of the projection, then of the rescale (method.py:195-214)."""
         assert self.preproc_done is True

@@ -218,6 +218,15 @@ class ShardedLDLQ:
         # (ldlqRG's permuted copy ...), so the (address, shape) key cannot match a different Hessian
         self._queue = [(h_key(H), LT, H) for H, LT in items]
 
+    def preload(self, H, LT, ready):
+        """ONE coming round() call, for the Hessian `H`, whose LT every rank already holds: `ready` = (LT on the comm device, work | None)
+        from a broadcast the caller issued itself (block_owner_per_linear: all LTs of a block travel as soon as their owners have
+        factored them).  The job's header then says "prefetched" and no LT is broadcast inside it."""
+        assert not self._queue and self._lt_ready is None, "preload: the previous queue was not consumed"
+        k = h_key(H)
+        self._queue = [(k, LT, H)]
+        self._lt_ready = (k, ready)
+
     def queued(self, key=None):
         """is the next round() call served from the queue?  key = h_key(H) of the H about to be rounded"""
         return bool(self._queue) and (key is None or self._queue[0][0] == key)
@@ -290,6 +299,110 @@ def broadcast_weights(layers, group=None, src=0):
             lin.weight.data.copy_(buf)
         nbytes += buf.numel() * buf.element_size()
     return nbytes
+
+
+# ------------------------------------------------------------------------------------- one owner PER LINEAR
+def assign_owners(shapes, world):
+    """owner rank of every Linear of a block: what couples the rows of a Linear -- post_batch, preproc (rescale, the projection of W and
+    of H), the LDL factor -- runs on ONE rank per Linear, different Linears on different ranks at the same time (round 3 ran all of
+    them on rank 0: 26 % of a block, capping 8 GPUs at 2.3x).  shapes: [(rows, columns)] in call order.  Longest-processing-time-first
+    on the cost model  columns^3 / 3 (factor) + 2 columns^2 (p + q) (V H V^T) + 2 rows columns (p + q) (U W V^T)  with p + q ~ 2 sqrt(n);
+    ties go to the lowest rank, so every rank computes the same assignment from the shapes alone."""
+    def cost(r, c):
+        return c ** 3 / 3.0 + 4.0 * c * c * (c ** 0.5) + 2.0 * r * c * ((r ** 0.5) + (c ** 0.5))
+    order = sorted(range(len(shapes)), key=lambda i: (-cost(*shapes[i]), i))
+    load = [0.0] * world
+    owners = [0] * len(shapes)
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owners[i] = r
+        load[r] += cost(*shapes[i])
+    return owners
+
+
+def block_owner_per_linear(methods, layers, owners, prepare, skip, finish, group=None, compute=None, force_exchange=False, timers=None):
+    """One transformer block's Linears quantised with ONE OWNER PER LINEAR (SPMD: every rank calls this with the same lists).
+
+      methods   the block's QuantMethod objects in the driver's call order (opt.py:147-170), Hessians already all-reduced
+      layers    their nn.Linear modules (same order); on return every rank holds every owner's quantised weights
+      owners    assign_owners(...) -- owner rank per Linear
+      prepare(m) -> (H, LT)   on the OWNER: post_batch + preproc, then the transposed unit LDL factor of the preprocessed H
+      skip(m)                 on every other rank: consume exactly the random draws prepare(m) makes (QuantMethod.skip_operators), so
+                              that the operators of the Linears this rank DOES own are the ones a single-owner run would have drawn
+      finish(m) -> float      on the OWNER: fasterquant (its rounding is routed through shard.active()); returns the proxy error
+
+    Phases: (A) every rank walks the Linears in order, preparing its own and skipping the others -- the owners work in parallel;
+    (B) every LT is broadcast from its owner (asynchronously, back to back: they travel while later owners still factor and while
+    earlier Linears round); (C) per Linear, in order: rows scattered from ITS owner, K4 on every rank, codes gathered there, the owner
+    finishes (postproc, error); (D) the owner's fp16 weights to everyone; (E) the errors to everyone.  No collective moves arithmetic:
+    broadcast / scatter / gather only, as the north_star asks.  Returns [error per Linear]."""
+    import time
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = _comm_device(group)
+    exchange = world > 1 or force_exchange
+    n = len(methods)
+
+    def tick():
+        if timers is None:
+            return 0.0
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        return time.perf_counter()
+    t0 = tick()
+    prepared = {}
+    for j, m in enumerate(methods):                                    # (A)
+        if owners[j] == rank:
+            prepared[j] = prepare(m)
+        else:
+            skip(m)
+    t1 = tick()
+    ready = [None] * n
+    if exchange:                                                       # (B)
+        dims = torch.zeros(n, dtype=torch.int64, device=dev)
+        for j, (H, LT) in prepared.items():
+            dims[j] = LT.shape[0]
+        if world > 1:
+            dist.all_reduce(dims, group=group)                         # every rank learns every factor's size (one entry per owner)
+        for j in range(n):
+            d = int(dims[j])
+            if owners[j] == rank:
+                buf = prepared[j][1].to(dev, torch.float32).contiguous()
+            else:
+                buf = torch.empty(d, d, dtype=torch.float32, device=dev)
+            ready[j] = (buf, dist.broadcast(buf, src=owners[j], group=group, async_op=True))
+    t2 = tick()
+    errors = torch.zeros(n, dtype=torch.float64, device=dev)
+    prev = active()
+    try:
+        for j, m in enumerate(methods):                                # (C)
+            if owners[j] == rank:
+                handle = ShardedLDLQ(group=group, src=rank, compute=compute, force_exchange=force_exchange, spmd=True)
+                H, LT = prepared.pop(j)
+                if exchange:
+                    handle.preload(H, LT, ready[j])
+                else:
+                    handle.queue_LTs([(H, LT)])
+                activate(handle)
+                errors[j] = float(finish(m))
+                activate(None)
+                assert handle.desyncs == 0 and not handle.queued(), "block_owner_per_linear: finish() did not round the prepared Hessian"
+            elif exchange:
+                worker_round(ready[j], group=group, src=owners[j], compute=compute)
+            ready[j] = None
+    finally:
+        activate(prev)
+    t3 = tick()
+    nbytes = 0
+    if world > 1:                                                      # (D), (E)
+        for j, lin in enumerate(layers):
+            nbytes += broadcast_weights([lin], group=group, src=owners[j])
+        dist.all_reduce(errors, group=group)
+    t4 = tick()
+    if timers is not None:
+        for k, v in (("owner_preproc_factor_s", t1 - t0), ("broadcast_LT_s", t2 - t1), ("round_s", t3 - t2), ("broadcast_weights_s", t4 - t3)):
+            timers[k] = timers.get(k, 0.0) + v
+        timers["bytes_broadcast_weights"] = timers.get("bytes_broadcast_weights", 0) + nbytes
+    return [float(e) for e in errors.tolist()]
 
 
 # ------------------------------------------------------------------------------------- calibration-sample sharding

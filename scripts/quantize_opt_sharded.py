@@ -13,6 +13,11 @@ opt.py:131-145, method.py:98-120, so THAT is what has to scale):
     (ShardedLDLQ.queue_LTs: LT of Linear k+1 travels while all ranks round k)  ->  per Linear: rows scattered, K4 on every rank, packed
     codes gathered (shard.ldlq_round_sharded; the other ranks join with shard.worker_round)  ->  the owner's quantised fp16 weights
     are broadcast (shard.broadcast_weights)  ->  every rank re-forwards its own samples through the quantised block (opt.py:172-174).
+--owners per-linear (default, round 4): what couples the rows of a Linear (post_batch, preproc, the LDL factor) runs on ONE rank PER LINEAR,
+    the six Linears of a block on up to six ranks at once (shard.assign_owners / shard.block_owner_per_linear); every LT is broadcast from
+    its owner, the rows of Linear j are scattered from / gathered at owner(j), and owner(j) broadcasts its quantised weights.  Ranks that do
+    not own a Linear consume its random draws (QuantMethod.skip_operators), so the operators are the ones a single-owner run draws:
+    per-Linear errors are identical.  --owners rank0 is round 3's single owner (the baseline of the phase split).
 --calibration owner (round 2): rank 0 does forwards, Hessians, preproc and factors alone, the others sit in shard.serve() and only
     round -- kept as the baseline the phase split is compared with (Amdahl: <= 1.15x at 8 GPUs for OPT-1.3B).
 Blocks stay sequential (their Hessians depend on the quantised predecessors).  With one process (plain `python`) the collectives
@@ -45,6 +50,7 @@ def main(argv=None):
     ap.add_argument("--force-exchange", action="store_true", help="run the collectives even with one rank")
     ap.add_argument("--quiet", action="store_true", help="do not print the JSON line (bench.py calls main() and reads the dict)")
     ap.add_argument("--calibration", default="sharded", choices=["sharded", "owner"], help="who forwards the calibration samples (see the module docstring)")
+    ap.add_argument("--owners", default="per-linear", choices=["per-linear", "rank0"], help="who runs preproc + the LDL factor of a Linear (see the module docstring)")
     ap.add_argument("--backend", default="nccl")
     args = ap.parse_args(argv)
 
@@ -108,6 +114,10 @@ def main(argv=None):
         report, totals = [], {"bytes_broadcast_LT": 0, "bytes_broadcast_next_LT": 0, "bytes_scatter": 0, "bytes_gather": 0}
         phases = {"forward_hessian_s": 0.0, "allreduce_s": 0.0, "owner_preproc_factor_s": 0.0, "round_s": 0.0, "broadcast_weights_s": 0.0,
                   "reforward_s": 0.0}
+        per_linear = spmd and args.owners == "per-linear"
+        if per_linear:
+            phases["broadcast_LT_s"] = 0.0
+        owner_table = None
         bytes_weights = 0
 
         def tick():
@@ -141,6 +151,40 @@ def main(argv=None):
                 if spmd:                                           # ONE exchange step per block: fp64 partial Hessians, summed
                     shard.all_reduce_hessians(list(methods.values()))
                 t2 = tick()
+                if per_linear:
+                    mlist = list(methods.values())
+                    owners = shard.assign_owners([(m.rows, m.columns) for m in mlist], world)
+                    owner_table = owners
+                    blk = {}
+
+                    def prepare(m):
+                        m.post_batch()
+                        m.preproc(preproc_gptqH=True, percdamp=0.01, preproc_rescale=args.incoh, preproc_proj=args.incoh, preproc_proj_extra=0)
+                        return m.H, vector_balance._ldl_transposed(m.H)
+
+                    def finish(m):
+                        m.fasterquant(lazy_batch=False)
+                        for k in totals:
+                            totals[k] += shard.last_stats.get(k, 0)
+                        return m.error
+                    errs = shard.block_owner_per_linear(mlist, list(subset.values()), owners, prepare,
+                                                        lambda m: m.skip_operators(args.incoh, 0), finish,
+                                                        force_exchange=args.force_exchange, timers=blk)
+                    for name, e in zip(methods, errs):
+                        report.append({"layer": i, "name": name, "error": float(e)})
+                    for m in mlist:
+                        m.free()
+                    t6a = tick()
+                    run_block(layer, inps, outs)
+                    t6 = tick()
+                    inps, outs = outs, inps
+                    phases["forward_hessian_s"] += t1 - t0
+                    phases["allreduce_s"] += t2 - t1
+                    for k in ("owner_preproc_factor_s", "broadcast_LT_s", "round_s", "broadcast_weights_s"):
+                        phases[k] += blk.get(k, 0.0)
+                    bytes_weights += blk.get("bytes_broadcast_weights", 0)
+                    phases["reforward_s"] += t6 - t6a
+                    continue
                 if rank == 0:
                     for m in methods.values():                     # everything that couples rows: owner only
                         m.post_batch()
@@ -179,7 +223,8 @@ def main(argv=None):
             return {"rank": rank, "samples": mine}
         out = {"world": world, "backend": args.backend, "calibration": args.calibration, "wall_s": round(wall, 3), "linears": len(report),
                "mean_proxy_error": float(np.mean([r["error"] for r in report])), "errors": [r["error"] for r in report], **totals,
-               "bytes_broadcast_weights": bytes_weights, "samples_rank0": mine,
+               "bytes_broadcast_weights": bytes_weights, "samples_rank0": mine, "owners": args.owners if spmd else "rank0",
+               "owner_of_each_linear_last_block": owner_table,
                "phase_seconds_rank0": {k: round(v, 4) for k, v in phases.items()},
                "config": {k: v for k, v in vars(args).items()}}
         if not args.quiet:

@@ -75,6 +75,7 @@ def test_sharded_driver_script_one_rank(nccl_group):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     argv = ["--hidden", "256", "--ffn", "1024", "--heads", "4", "--layers", "2", "--nsamples", "4", "--seqlen", "64", "--vocab", "512", "--incoh"]
+    argv = argv + ["--owners", "rank0"]                       # round 3's single owner: the LT prefetch queue and its byte counters
     a = mod.main(argv + ["--force-exchange"])
     b = mod.main(argv)
     assert a["linears"] == b["linears"] == 12
@@ -88,3 +89,11 @@ def test_sharded_driver_script_one_rank(nccl_group):
     ph = a["phase_seconds_rank0"]
     assert set(ph) == {"forward_hessian_s", "allreduce_s", "owner_preproc_factor_s", "round_s", "broadcast_weights_s", "reforward_s"}
     assert ph["forward_hessian_s"] > 0 and ph["round_s"] > 0
+    # round 4: one owner PER LINEAR (shard.block_owner_per_linear).  With one rank every Linear is rank 0's, the LTs go through the
+    # explicit broadcasts and the preloaded jobs: the same per-Linear errors as the single-owner loop, number for number
+    base = [x for x in argv if x not in ("--owners", "rank0")]
+    p = mod.main(base + ["--force-exchange"])
+    q = mod.main(base)
+    assert p["owners"] == "per-linear" and p["errors"] == a["errors"] and q["errors"] == a["errors"]
+    assert set(p["phase_seconds_rank0"]) == set(ph) | {"broadcast_LT_s"} and p["owner_of_each_linear_last_block"] == [0] * 6
+    assert p["bytes_scatter"] > 0 and p["bytes_gather"] > 0 and p["bytes_broadcast_LT"] == 0      # LTs travel outside the rounding jobs

@@ -217,3 +217,113 @@ def test_calibration_samples_split_over_ranks(tmp_path):
     out = str(tmp_path / "h.pt")
     mp.spawn(_hessian_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert torch.load(out)["ok"]
+
+
+# ---- round 4: one owner PER LINEAR (shard.assign_owners / shard.block_owner_per_linear) ------------------------------------------------
+_PL_SHAPES = [(32, 64), (32, 64), (48, 64), (32, 128), (64, 32)]          # (rows, columns) of a block's Linears in call order
+
+
+class _FakeMethod:
+    """what block_owner_per_linear needs of a QuantMethod: the layer, rows / columns, an H to key the prepared factor by"""
+
+    def __init__(self, lin):
+        self.layer, self.rows, self.columns = lin, lin.weight.shape[0], lin.weight.shape[1]
+        self.H = torch.zeros(2, 2)
+
+
+def _pl_draw(m):
+    """the random draws `prepare` makes (numpy's and torch's global streams, like gen_rand_orthos + randperm): returns a per-Linear
+    perturbation of the fixture's factor, so a rank that skipped a draw or made it out of order rounds with a different LT"""
+    a = float(np.random.normal())
+    p = torch.randperm(m.columns)
+    return a, p
+
+
+def _pl_factor(m, j, draw):
+    _, LT, _ = _fixture(m.rows, m.columns, seed=20 + j)
+    a, p = draw
+    return (LT * (1.0 + 0.05 * a) + 1e-3 * torch.triu(p.float()[None, :].expand(m.columns, -1) / m.columns, diagonal=1)).contiguous()
+
+
+def _pl_reference():
+    """the block in ONE process: every Linear prepared in call order on the same streams, rounded by the oracle"""
+    np.random.seed(11)
+    torch.manual_seed(11)
+    out = []
+    lins = [torch.nn.Linear(c, r, bias=False).half() for r, c in _PL_SHAPES]      # (their initialisers draw from torch's stream: as in the workers)
+    for j, (r, c) in enumerate(_PL_SHAPES):
+        m = _FakeMethod(lins[j])
+        W, _, _ = _fixture(r, c, seed=20 + j)
+        codes = _oracle_compute(W, _pl_factor(m, j, _pl_draw(m)), 2, None)
+        out.append(codes)
+    return out
+
+
+def _pl_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quip_amd import shard
+    try:
+        np.random.seed(11)                                               # every rank seeds alike (the drivers do)
+        torch.manual_seed(11)
+        lins = [torch.nn.Linear(c, r, bias=False).half() for r, c in _PL_SHAPES]
+        methods = [_FakeMethod(l) for l in lins]
+        idx = {id(m): j for j, m in enumerate(methods)}
+        owners = shard.assign_owners(_PL_SHAPES, world)
+        prepared_by, srcs = [], []
+
+        def prepare(m):
+            j = idx[id(m)]
+            prepared_by.append(j)
+            return m.H, _pl_factor(m, j, _pl_draw(m))
+
+        def skip(m):
+            _pl_draw(m)
+
+        def finish(m):
+            j = idx[id(m)]
+            W, _, _ = _fixture(m.rows, m.columns, seed=20 + j)
+            codes = shard.active().round(W, None, 2, key=shard.h_key(m.H))      # what quantize_weight_vecbal does with a queued H
+            srcs.append(shard.last_stats["world"])
+            m.layer.weight.data = codes.to(torch.float16)                # fasterquant leaves a NEW tensor on the owner
+            return float(codes.double().sum())
+        timers = {}
+        errs = shard.block_owner_per_linear(methods, lins, owners, prepare, skip, finish, compute=_oracle_compute, timers=timers)
+        assert prepared_by == [j for j in range(len(methods)) if owners[j] == rank]            # own Linears only, in call order
+        assert shard.active() is None and set(timers) >= {"owner_preproc_factor_s", "broadcast_LT_s", "round_s", "broadcast_weights_s"}
+        torch.save({"owners": owners, "errs": errs, "weights": [l.weight.data.clone() for l in lins]}, f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_owner_per_linear_reproduces_the_single_owner_block(tmp_path, world):
+    """every Linear prepared on its own owner in parallel, LTs broadcast from their owners, rows scattered from / gathered at owner(j), weights
+    and errors to everyone: on EVERY rank the block's weights and per-Linear errors equal the one-process run -- which also proves that
+    the ranks consumed the random streams in step (a skipped or reordered draw changes a factor)"""
+    from quip_amd import shard
+    out = str(tmp_path / "pl.pt")
+    mp.spawn(_pl_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    want = _pl_reference()
+    owners = shard.assign_owners(_PL_SHAPES, world)
+    assert len(set(owners)) == min(world, len(_PL_SHAPES))               # the work really is spread
+    for rank in range(world):
+        res = torch.load(f"{out}.{rank}")
+        assert res["owners"] == owners
+        for j, codes in enumerate(want):
+            assert torch.equal(res["weights"][j], codes.to(torch.float16)), (rank, j)
+            assert res["errs"][j] == float(codes.double().sum())
+
+
+def test_assign_owners_balances_by_cost():
+    from quip_amd import shard
+    opt = [(2048, 2048)] * 4 + [(8192, 2048), (2048, 8192)]             # OPT-1.3B block: fc2's factor (d = 8192) dwarfs the rest
+    o2 = shard.assign_owners(opt, 2)
+    assert o2[5] != o2[4] and all(o == o2[4] for o in o2[:5])           # fc2 alone, everything else on the other rank
+    o8 = shard.assign_owners(opt, 8)
+    assert sorted(o8) == list(range(6))                                 # six Linears, six different owners
+    assert shard.assign_owners(opt, 1) == [0] * 6
+    llama = [(4096, 4096)] * 4 + [(11008, 4096)] * 2 + [(4096, 11008)]
+    o3 = shard.assign_owners(llama, 3)
+    assert len(set(o3)) == 3 and o3 == shard.assign_owners(llama, 3)    # deterministic: every rank computes the same table
