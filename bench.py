@@ -596,15 +596,29 @@ def main():
             here = os.path.dirname(os.path.abspath(__file__))
             script = os.path.join(here, "oracle", "ref_ldlq_time.py")
             if os.path.exists(os.path.join(here, "oracle", "_ref", "cpu", "bal.py")):
-                pr = subprocess.run([sys.executable, script, "--sizes", "2048,4096", "--budget", "75"], capture_output=True, text=True, timeout=240)
+                # thread count: torch's default on this box (one per physical core) is the WRONG setting for this code -- round_ldl is d
+                # dependent steps of small mat-vecs, and 128 threads spend their time in the fork / join of each (profiles/r04b: 43.3 s
+                # for 2048^2 against 1.5 s on 8 cores) -- so the reference is timed at 8 threads, BASELINE.md section 2's setting, and
+                # a small default-thread probe records the ratio
+                pr = subprocess.run([sys.executable, script, "--sizes", "2048,4096", "--budget", "70", "--threads", "8"], capture_output=True, text=True, timeout=240)
                 rows = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")]
                 done = [r for r in rows if "fasterquant_time_attr_s" in r]
+                probe = []
+                try:
+                    for th in ("8", "0"):
+                        pp = subprocess.run([sys.executable, script, "--sizes", "1024", "--budget", "20", "--threads", th], capture_output=True, text=True, timeout=120)
+                        probe += [json.loads(l) for l in pp.stdout.splitlines() if l.startswith("{")]
+                except Exception as ex:
+                    probe.append({"error": f"{type(ex).__name__}: {ex}"[:120]})
                 out["ldlq_cpu_reference"] = {
                     "what": "the reference's Balance.fasterquant (bal.py:21-48 -> vector_balance.py:155-199 round_ldl / 218-291 round_ldl_block), its own "
                             "files run unmodified on this box's host cores: w2 qfn b, W = 0.02 randn fp16, H = X^T X / (d + 256), preproc(gptqH, rescale, "
                             "proj, extra 0) -- BASELINE.md section 2's recipe; seconds = the `.time` attribute fasterquant sets",
                     "kind": "reference", "cores": (done[0]["threads"] if done else None), "logical_cpus": os.cpu_count(),
-                    "runs": rows, "sample": "2048^2 and 4096^2, lazy_batch False and True, each layer whole, once (a run is skipped when 75 s have passed)"}
+                    "cores_note": "8 torch threads (BASELINE.md section 2's setting): the box's default, one thread per physical core, is far slower for "
+                                  "this chain of small mat-vecs -- see thread_probe_1024 (8 threads vs the default)",
+                    "runs": rows, "thread_probe_1024": probe,
+                    "sample": "2048^2 and 4096^2, lazy_batch False and True, each layer whole, once (a run is skipped when 70 s have passed)"}
             else:
                 out["ldlq_cpu_reference"] = {"error": "oracle/_ref/cpu not staged (no reference checkout when build() ran)"}
         except Exception as ex:

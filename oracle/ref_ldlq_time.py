@@ -26,7 +26,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="2048,4096")
     ap.add_argument("--budget", type=float, default=120.0, help="stop starting new measurements after this many seconds")
-    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0, help="torch.set_num_threads (0: torch's default = the box's physical cores)")
+    ap.add_argument("--order", default="as-given", choices=["as-given", "lazy-first"])
     a = ap.parse_args()
     cpu = os.path.join(HERE, "_ref", "cpu")
     if not os.path.exists(os.path.join(cpu, "bal.py")):
@@ -43,9 +44,12 @@ def main():
     import quant as ref_quant
     assert os.path.dirname(os.path.abspath(ref_bal.__file__)) == cpu and os.path.dirname(os.path.abspath(ref_quant.__file__)) == cpu
     t_start = time.perf_counter()
-    for d in [int(v) for v in a.sizes.split(",")]:
+    cases = [(int(v), lazy) for v in a.sizes.split(",") for lazy in (False, True)]
+    if a.order == "lazy-first":                                    # the cheaper half of every size first (a time budget then cuts the dearer one)
+        cases = sorted(cases, key=lambda c: (c[0], not c[1]))
+    for d, lazy in cases:
         m = d
-        for lazy in (False, True):
+        if True:
             if time.perf_counter() - t_start > a.budget:
                 print(json.dumps({"m": m, "d": d, "lazy_batch": lazy, "skipped": "time budget"}), flush=True)
                 continue

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""quip_amd.decode.DecodeEngine at full model size, for the packed configurations the fused launches do NOT cover -- the measured statement
+of what such a model decodes at (VERDICT r3 next #2b):
+
+    --blocked        operators from gen_rand_ortho_butterfly (preproc_proj_extra = 0: what the reference's --incoh_processing really
+                     selects, opt.py:596 sets an unused `proj_extra`): factor storage n (p + q) values per side instead of p^2 + q^2, a
+                     workgroup cannot redo the pass in its prologue -> engine mode "fused" (operator / grouped GEMM / operator launches;
+                     the blocked operators on the general two-stage K3 kernel)
+    --bits 4         w4 qfn b (csrc/decode_fused.hip is 2-bit): mode "fused" as well
+    (neither)        the Kronecker w2 model: mode v3_head, the number bench.py reports
+
+    python scripts/decode_engine_bench.py --arch opt|llama [--blocked] [--bits 4] [--layers N] [--tokens 64] [--prompt 64]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+from quip_amd import decode  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--arch", default="opt", choices=["opt", "llama"])
+    ap.add_argument("--layers", type=int, default=0)
+    ap.add_argument("--bits", type=int, default=2)
+    ap.add_argument("--blocked", action="store_true")
+    ap.add_argument("--prompt", type=int, default=64)
+    ap.add_argument("--tokens", type=int, default=64)
+    ap.add_argument("--mode", default="auto")
+    a = ap.parse_args()
+    dev, dtype = torch.device("cuda:0"), torch.float16
+    torch.manual_seed(0)
+    if a.arch == "opt":
+        import decode_opt as D
+        model = D.Decoder(layers=a.layers or 24, dtype=dtype).to(dev).eval()
+        arch = "OPT-1.3B (hidden 2048, ffn 8192, heads 32, vocab 50272)"
+    else:
+        import decode_llama as D
+        model = D.Decoder(layers=a.layers or 32, dtype=dtype).to(dev).eval()
+        arch = "Llama-2-7B (hidden 4096, intermediate 11008, heads 32 x 128, vocab 32000)"
+    for p_ in model.parameters():
+        if p_.dim() > 1:
+            p_.data.normal_(0, 0.02)
+    if a.arch == "opt":
+        _, nbytes = D.pack_model(model, a.bits, dev, blocked=a.blocked, twin=False)
+    else:
+        if a.blocked:
+            from quip_amd import method
+            keep = method.gen_rand_ortho_butterfly_noblock
+            method.gen_rand_ortho_butterfly_noblock = method.gen_rand_ortho_butterfly     # decode_llama.pack_model draws through this name
+            try:
+                _, nbytes = D.pack_model(model, a.bits, dev, twin=False)
+            finally:
+                method.gen_rand_ortho_butterfly_noblock = keep
+        else:
+            _, nbytes = D.pack_model(model, a.bits, dev, twin=False)
+    maxlen = a.prompt + a.tokens + 8
+    eng = decode.DecodeEngine(model, bs=1, max_len=maxlen, mode=a.mode)
+    ids = torch.randint(0, 30000, (1, a.prompt + a.tokens), device=dev)
+    res = eng.benchmark(ids)
+    lat = res["times"][a.prompt:]
+    med = float(np.median(lat))
+    head = model.head_weight.numel() * 2
+    fact = 0
+    for blk in model.blocks:
+        for m in blk.modules():
+            if isinstance(m, decode.QuantLinear):
+                for op in (m.U, m.V):
+                    fact += (op._B0.numel() + op._B1.numel()) * 2      # what a decode launch would read as fp16
+    out = {"arch": arch, "layers": len(model.blocks), "bits": a.bits, "operators": "blocked butterfly (extra 0)" if a.blocked else "Kronecker (extra 1)",
+           "engine_mode": eng.mode, "prompt": a.prompt, "tokens": a.tokens, "ms_per_token_median": med * 1e3, "tok_per_s": 1.0 / med,
+           "packed_weight_MB": nbytes / 1e6, "operator_factor_MB_fp16": fact / 1e6,
+           "hbm_bound_tok_per_s": 8e12 / (nbytes + head + fact), "frac_of_byte_bound": (1.0 / med) / (8e12 / (nbytes + head + fact))}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -116,8 +116,11 @@ class Decoder(decode.OPTDecoder):
         return super().step(ids, pos, caches, arange)
 
 
-def pack_model(model, bits, dev, seed=0):
-    """replace the 6 Linears of every block by packed QuantLinear; returns a dense twin state for the logits check."""
+def pack_model(model, bits, dev, seed=0, blocked=False, twin=True):
+    """replace the 6 Linears of every block by packed QuantLinear; returns a dense twin state for the logits check.
+    blocked: operators from gen_rand_ortho_butterfly (preproc_proj_extra = 0, what opt.py's --incoh_processing really selects) instead
+    of the Kronecker form"""
+    gen = method.gen_rand_ortho_butterfly if blocked else method.gen_rand_ortho_butterfly_noblock
     np.random.seed(seed)
     torch.manual_seed(seed)
     maxq = 2 ** bits - 1
@@ -130,16 +133,17 @@ def pack_model(model, bits, dev, seed=0):
             W = lin.weight.data                                                  # plays the role of the PROJECTED weights
             s = ops.qfnb_scale(W)
             What, codes = ops.quantize(W, 'b', s, None, maxq, want_codes=True)
-            U = ops.OrthoOp(method.gen_rand_ortho_butterfly_noblock(m), dev)
-            V = ops.OrthoOp(method.gen_rand_ortho_butterfly_noblock(d), dev)
+            U = ops.OrthoOp(gen(m), dev)
+            V = ops.OrthoOp(gen(d), dev)
             sWH = (0.5 + torch.rand(d)).to(dev)
             ql = QuantLinear(d, m, bits=bits, qfn='b').to(dev)
             ql.pack(codes, s, None, bias=lin.bias, scaleWH=sWH, U=U, V=V)
             setattr(blk, name, ql)
             nbytes += ql.qweight.numel() * 4
-            # dense equivalent: W_dense = U^T What V diag(1/s)   (rows of What V^T... computed with the same operators)
-            Wd = U.apply_cols(V.apply_rows(What.float(), transpose=True), transpose=True) / sWH[None, :]
-            dense_twin[(li, name)] = (Wd.to(W.dtype), lin.bias.data.clone())
+            if twin:
+                # dense equivalent: W_dense = U^T What V diag(1/s)   (rows of What V^T... computed with the same operators)
+                Wd = U.apply_cols(V.apply_rows(What.float(), transpose=True), transpose=True) / sWH[None, :]
+                dense_twin[(li, name)] = (Wd.to(W.dtype), lin.bias.data.clone())
     return dense_twin, nbytes
 
 

@@ -70,6 +70,7 @@ class Phases:
     def __init__(self):
         self.t = {k: 0.0 for k in ("post_batch", "operator_sampling", "preproc", "rounding", "free")}
         self.events = []
+        self.offpath = 0.0           # seconds of operator sampling done by the prefetch thread (not part of the wall-clock split)
         self.calls = {"add_batch": 0, "linears": 0}
         self.per_linear = []
 
@@ -106,11 +107,17 @@ class Phases:
         M.QuantMethod.add_batch = add_batch_ev
         M.QuantMethod.post_batch = timed("post_batch", M.QuantMethod.post_batch)
         gen = M.gen_rand_orthos
+        import threading
+        main_thread = threading.get_ident()
 
         def gen_timed(m, p):
             t0 = time.perf_counter()
             out = gen(m, p)
-            ph.t["operator_sampling"] += time.perf_counter() - t0
+            dt = time.perf_counter() - t0
+            if threading.get_ident() == main_thread:
+                ph.t["operator_sampling"] += dt                 # on the critical path, inside preproc
+            else:
+                ph.offpath += dt                                # method.OPERATOR_PREFETCH: on the host thread, under the GPU phases
             return out
         M.gen_rand_orthos = gen_timed
         M.QuantMethod.preproc = timed("preproc", M.QuantMethod.preproc)
@@ -139,7 +146,9 @@ class Phases:
         t["preproc"] -= t["operator_sampling"]                  # sampling runs inside preproc
         t["hessian"] = hess
         t["forwards_and_moves"] = wall - sum(t.values())
-        return {k: round(v, 3) for k, v in t.items()}
+        out = {k: round(v, 3) for k, v in t.items()}
+        out["operator_sampling_on_prefetch_thread_not_in_wall"] = round(self.offpath, 3)
+        return out
 
 
 def main():
@@ -193,6 +202,7 @@ def main():
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         phases = ph.report(wall)
+    pf_stats = dict(M.operator_prefetcher().stats) if a.prefetch_operators else None
     if hasattr(M, "operator_prefetch_stop"):
         M.operator_prefetch_stop()
     errs = [float(e) for e in errors]
@@ -200,7 +210,7 @@ def main():
            if is_ref else "scripts/quantize_opt.py (restatement)", "nsamples": a.nsamples, "seqlen": a.seqlen,
            "args": {k: v for k, v in vars(args).items()}, "opt_ins": {"HESSIAN_FAST": M.HESSIAN_FAST, "DEVICE_RNG": M.DEVICE_RNG,
                                                                         "OPERATOR_PREFETCH": bool(getattr(M, "OPERATOR_PREFETCH", False))},
-           "wall_s": round(wall, 2), "model_build_s": round(t_build, 2), "phases_s": phases, "add_batch_calls": ph.calls["add_batch"],
+           "operator_prefetch_stats": pf_stats, "wall_s": round(wall, 2), "model_build_s": round(t_build, 2), "phases_s": phases, "add_batch_calls": ph.calls["add_batch"],
            "linears": ph.calls["linears"], "peak_device_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
            "errors_finite": bool(np.all(np.isfinite(errs))), "error_sum": float(np.sum(errs)),
            "per_block_error_sum": [float(np.sum(errs[i:i + len(errs) // spec["layers"]])) for i in range(0, len(errs), len(errs) // spec["layers"])],

@@ -74,7 +74,7 @@ def test_a_grid_that_is_not_co_resident_is_an_error_not_a_hang():
     others poll granules nobody writes: the bounded poll gives up, the abort word is raised, ops raises, and GPTQ.fasterquant falls back
     to the column walk (the 'co-resident' route of gptq._kernel_round) -- within seconds, with the device still usable."""
     import time
-    from quip_amd import _lib
+    from quip_amd import _lib, ops
     torch.manual_seed(3)
     m, d = 256, 256
     W = (torch.randn(m, d, device=DEV) * 0.02).contiguous()
