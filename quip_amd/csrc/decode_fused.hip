@@ -31,12 +31,12 @@ namespace {
 constexpr int FG_MAXG = 3, FG_MAXBS = 4, FG_NW = 16;
 
 // dequantiser of a launch: multi-exponent (DeqME2) or the uniform-offset form, behind one interface
-template <bool ME> struct DeqSelME : DeqME2<ActF16> {};
-template <> struct DeqSelME<false> : DeqT<2, ActF16> {
+template <bool ME, int BITS = 2> struct DeqSelME : DeqT<BITS, ActF16> {        // uniform offset: 2-bit with one tile per wave, and every 4-bit launch
     struct Consts { };
     static __device__ __forceinline__ Consts make_consts() { return Consts{}; }
-    static __device__ __forceinline__ u32x4 frag(const u32x4 &w, int t, const Consts &) { return DeqT<2, ActF16>::frag(w, t); }
+    static __device__ __forceinline__ u32x4 frag(const u32x4 &w, int t, const Consts &) { return DeqT<BITS, ActF16>::frag(w, t); }
 };
+template <> struct DeqSelME<true, 2> : DeqME2<ActF16> {};
 
 // lab builds (scripts/fusedlab.hip, -DFG_PROBE): s_memtime stamps of wave 0 of workgroup (FG_PROBE_WG, 0) at the phase boundaries
 #ifdef FG_PROBE
@@ -111,16 +111,19 @@ __device__ __forceinline__ float fg_block_sum(float v, float *red)
 // NRT: row tiles a wave handles one after the other against the same x~ fragments (Llama's m = 4096 x 3 and 11008 x 2 would otherwise
 // be 768 / 1376 workgroups on 256 CUs, each repeating the prologue): a workgroup owns 16 RT NRT rows.
 // YF32: u_y is fp32 (the accumulator of quipamd_decode_bigp_v_gemm) and is rounded to fp16 on load -- what a cast launch in between would do.
-template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT, bool YF32 = false>
+// BITS: 2, or 4 (the 4-bit STREAM container: --wbits 4 and, with maxq = 7, --wbits 3): a 1 KiB tile is then 16 rows x 128 columns, a wave owns
+// twice as many chunks of the same K range, the conversion is the uniform-offset one (value = 16 + code).
+template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT, bool YF32 = false, int BITS = 2>
 __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two_over_maxq, float c0)
 {
     typedef PassDims<P, Q> D;
     // Multi-exponent dequantisation (dq_common.h: 10 instead of 16 VALU per packed dword, paid for with sum OFF_k x~_k in the prologue and
     // the reducer) where a wave converts several row tiles against one x~ (Llama's NRT = 4 / 8: the conversion is 3.4 us of VALU issue in
     // the gate/up launch); with one tile per wave (OPT) the bookkeeping costs more than it saves (measured, profiles/r03E).
-    constexpr bool ME = NRT >= 4;
-    typedef DeqSelME<ME> DQ;
-    constexpr int N = D::N, NV = D::NV, NS = FG_NW / RT, NCH = N / 256, XTS = N + 8;      // x~ row stride (halves)
+    constexpr bool ME = NRT >= 4 && BITS == 2;
+    typedef DeqSelME<ME, BITS> DQ;
+    constexpr int KC = 512 / BITS;                                              // columns of a 1 KiB tile
+    constexpr int N = D::N, NV = D::NV, NS = FG_NW / RT, NCH = N / KC, XTS = N + 8;       // x~ row stride (halves)
     constexpr int PB = NRT == 6 ? 3 : NRT < 4 ? NRT : 4;                        // row tiles (per parallel row slot) parked per batch
     constexpr bool EARLY = NV == 1;
     static_assert(NS * CPW == NCH, "chunks = slots x chunks per wave");
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         const int c = slot * CPW + i;
         uint4 xf[DQ::NT];
 #pragma unroll
-        for (int t = 0; t < DQ::NT; ++t) xf[t] = *reinterpret_cast<const uint4 *>(xrow + c * 256 + 32 * t);
+        for (int t = 0; t < DQ::NT; ++t) xf[t] = *reinterpret_cast<const uint4 *>(xrow + c * KC + 32 * t);
 #pragma unroll
         for (int k = 0; k < NRT; ++k)
 #pragma unroll
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                 if constexpr (ME) xoff += red[(2 + FG_MAXBS) * FG_NW + bb * FG_NW + v];
             }
             const int64_t row = ((int64_t)blockIdx.x * (RT * NRT) + h * PB * RT + pr) * 16 + wr;
-            const float val = e_sc * two_over_maxq * ((a - xoff) - (ME ? c0 : c0 + DeqT<2, ActF16>::OFF) * xsum);   // c0 = maxq / 2; ME: the offsets went with xoff
+            const float val = e_sc * two_over_maxq * ((a - xoff) - (ME ? c0 : c0 + DeqT<BITS, ActF16>::OFF) * xsum);   // c0 = maxq / 2; ME: the offsets went with xoff
             if (bb < bs && row < G.m) {
                 if (G.y_f16) reinterpret_cast<uint16_t *>(Gg.y)[(int64_t)bb * G.m + row] = f32_to_f16_bits(val);
                 else reinterpret_cast<float *>(Gg.y)[(int64_t)bb * G.m + row] = val;
@@ -452,12 +455,13 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
 //     and 1 / s that go with it, are per-lane tables the host prepares once per layer pair in the lane order of the MFMA result
 //     (pair_sig: LDS offset in ZT_V, pair_bias, pair_cs: fp16; entry [(wave * 64 + lane) * 8 + 4 i + reg] for tile wave + 16 i).
 // bs <= 2 (x~ rows, 2 images and 80 KiB of fragments share the LDS).
-template <int P, int Q>
+template <int P, int Q, int BITS = 2>
 __global__ __launch_bounds__(1024) void fused_pair_kernel(FusedArgs G, float two_over_maxq, float c0)
 {
     typedef PassDims<P, Q> D;
-    typedef DeqT<2, ActF16> DQ;
-    constexpr int N = D::N, NS = FG_NW, NCH = N / 256, CPW = NCH / NS, XTS = N + 8, MAXBS = 2;
+    typedef DeqT<BITS, ActF16> DQ;
+    constexpr int KC = 512 / BITS;
+    constexpr int N = D::N, NS = FG_NW, NCH = N / KC, CPW = NCH / NS, XTS = N + 8, MAXBS = 2;
     constexpr int NF0 = (P / 16) * D::S0, NF1 = (Q / 16) * D::S1, NFR = NF0 + NF1;        // 1 KiB fragment pieces per operator (32 + 8)
     constexpr int FPT = (NFR * 64 + 1023) / 1024;                                          // uint4 per thread per operator
     static_assert(D::TPW == 2 && N / 8 == 1024, "128 x 64");
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(1024) void fused_pair_kernel(FusedArgs G, float two
         const int c = wave * CPW + i;
         uint4 xf[DQ::NT];
 #pragma unroll
-        for (int t = 0; t < DQ::NT; ++t) xf[t] = *reinterpret_cast<const uint4 *>(xrow + c * 256 + 32 * t);
+        for (int t = 0; t < DQ::NT; ++t) xf[t] = *reinterpret_cast<const uint4 *>(xrow + c * KC + 32 * t);
 #pragma unroll
         for (int t = 0; t < DQ::NT; ++t) {
             const u32x4 a = DQ::frag(u32x4{w[i].x, w[i].y, w[i].z, w[i].w}, t);
@@ -620,12 +624,12 @@ __global__ __launch_bounds__(1024) void fused_pair_kernel(FusedArgs G, float two
     FG_STAMP(15);
 }
 
-template <int P, int Q> int launch_pair(const FusedArgs &A, hipStream_t s)
+template <int P, int Q, int BITS> int launch_pair(const FusedArgs &A, float maxq, hipStream_t s)
 {
     typedef PassDims<P, Q> D;
     constexpr int NFR = (P / 16) * D::S0 + (Q / 16) * D::S1;
     const size_t lds = (size_t)2 * (D::N + 8) * 2 + D::ZT_B + D::Z1_B + (size_t)2 * NFR * 1024 + 2 * FG_NW * 4 + 64;
-    auto kern = fused_pair_kernel<P, Q>;
+    auto kern = fused_pair_kernel<P, Q, BITS>;
     static QaPerDevice attr;
     const int d = attr.dev();
     if (d < 0 || !attr.done[d]) {
@@ -633,8 +637,7 @@ template <int P, int Q> int launch_pair(const FusedArgs &A, hipStream_t s)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_fused_gemm (pair): cannot raise dynamic LDS to %zu", lds);
         if (d >= 0) attr.done[d] = true;
     }
-    const float maxq = 3.f;
-    kern<<<dim3((unsigned)(A.m / 16), 1), 1024, lds, s>>>(A, 2.0f / maxq, DeqT<2, ActF16>::OFF + 0.5f * maxq);
+    kern<<<dim3((unsigned)(A.m / 16), 1), 1024, lds, s>>>(A, 2.0f / maxq, DeqT<BITS, ActF16>::OFF + 0.5f * maxq);
     QA_LAUNCH_CHECK("quipamd_decode_fused_gemm (pair)");
     return QUIPAMD_OK;
 }
@@ -646,11 +649,13 @@ template <int P, int Q, int NRT> constexpr size_t fused_lds()
     return (size_t)FG_MAXBS * (D::N + 8) * 2 + (D::BYTES > parkb ? D::BYTES : parkb) + (2 + 2 * FG_MAXBS) * FG_NW * 4 + 64;
 }
 
-template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT, bool YF32 = false>
+thread_local float g_fused_maxq = 3.f;      // set by the entry point right before the dispatch (same thread): 3, 7 (3-bit codes in the 4-bit container) or 15
+
+template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT, bool YF32 = false, int BITS = 2>
 int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
 {
     const size_t lds = fused_lds<P, Q, NRT>();
-    auto kern = fused_gemm_kernel<P, Q, HAS_U, HAS_RES, NORM, RT, CPW, NRT, YF32>;
+    auto kern = fused_gemm_kernel<P, Q, HAS_U, HAS_RES, NORM, RT, CPW, NRT, YF32, BITS>;
     static QaPerDevice attr;
     const int d = attr.dev();
     if (d < 0 || !attr.done[d]) {
@@ -658,7 +663,7 @@ int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
             return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_fused_gemm: cannot raise dynamic LDS to %zu", lds);
         if (d >= 0) attr.done[d] = true;
     }
-    const float maxq = 3.f;
+    const float maxq = g_fused_maxq;
     kern<<<dim3((unsigned)((A.m / 16 + RT * NRT - 1) / (RT * NRT)), (unsigned)ngroups), 1024, lds, s>>>(A, 2.0f / maxq, 0.5f * maxq);
     QA_LAUNCH_CHECK("quipamd_decode_fused_gemm");
     return QUIPAMD_OK;
@@ -667,15 +672,15 @@ int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
 // the combinations a decoder block needs (each is a 1300-line kernel):
 //   64 x 32 (d = 2048) and 64 x 64 (d = 4096):  [U + residual | no U] x [no norm | LayerNorm | RMSNorm]
 //   128 x 64 (OPT d = 8192):                    [U, no residual, no norm]  [no U, no norm]
-template <int P, int Q, int RT, int CPW, int NRT>
+template <int P, int Q, int RT, int CPW, int NRT, int BITS = 2>
 int dispatch_fused(const FusedArgs &A, bool u, bool res, int norm, int ngroups, hipStream_t s)
 {
-    if (u && res) return norm == 0 ? launch_fused<P, Q, true, true, 0, RT, CPW, NRT>(A, ngroups, s)
-                       : norm == 1 ? launch_fused<P, Q, true, true, 1, RT, CPW, NRT>(A, ngroups, s)
-                                   : launch_fused<P, Q, true, true, 2, RT, CPW, NRT>(A, ngroups, s);
-    if (!u) return norm == 0 ? launch_fused<P, Q, false, false, 0, RT, CPW, NRT>(A, ngroups, s)
-                 : norm == 1 ? launch_fused<P, Q, false, false, 1, RT, CPW, NRT>(A, ngroups, s)
-                             : launch_fused<P, Q, false, false, 2, RT, CPW, NRT>(A, ngroups, s);
+    if (u && res) return norm == 0 ? launch_fused<P, Q, true, true, 0, RT, CPW, NRT, false, BITS>(A, ngroups, s)
+                       : norm == 1 ? launch_fused<P, Q, true, true, 1, RT, CPW, NRT, false, BITS>(A, ngroups, s)
+                                   : launch_fused<P, Q, true, true, 2, RT, CPW, NRT, false, BITS>(A, ngroups, s);
+    if (!u) return norm == 0 ? launch_fused<P, Q, false, false, 0, RT, CPW, NRT, false, BITS>(A, ngroups, s)
+                 : norm == 1 ? launch_fused<P, Q, false, false, 1, RT, CPW, NRT, false, BITS>(A, ngroups, s)
+                             : launch_fused<P, Q, false, false, 2, RT, CPW, NRT, false, BITS>(A, ngroups, s);
     return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: %d x %d has no kernel for (U %d, residual %d, norm %d)", P, Q, (int)u, (int)res, norm);
 }
 
@@ -687,7 +692,9 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
 {
     QA_REQUIRE(a, QUIPAMD_ERR_ARG, "decode_fused_gemm: null args");
     QA_REQUIRE(a->act_dtype == QUIPAMD_F16, QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: fp16 activations only");
-    QA_REQUIRE(a->bits == 2, QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: 2-bit qfn-b codes only");
+    QA_REQUIRE(a->bits >= 2 && a->bits <= 4, QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm: 2-, 3- or 4-bit qfn-b codes (bits = %d)", a->bits);
+    const bool w4 = a->bits != 2;                                               // 3-bit codes ride in the 4-bit container (maxq = 7)
+    g_fused_maxq = (float)((1 << a->bits) - 1);
     QA_REQUIRE(a->ngroups >= 1 && a->ngroups <= FG_MAXG, QUIPAMD_ERR_ARG, "decode_fused_gemm: 1..%d groups", FG_MAXG);
     QA_REQUIRE(a->bs >= 0 && a->bs <= FG_MAXBS, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: bs %lld > %d", (long long)a->bs, FG_MAXBS);
     if (a->bs == 0) return QUIPAMD_OK;
@@ -725,10 +732,11 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
     const bool yf32 = u && a->u_y_dtype == QUIPAMD_F32;
     QA_REQUIRE(!u || yf32 || a->u_y_dtype == QUIPAMD_F16, QUIPAMD_ERR_ARG, "decode_fused_gemm: u_y_dtype f16 or f32");
     // fp32 u_y = the accumulator of quipamd_decode_bigp_v_gemm: Llama's down_proj -> next block's q / k / v
-    QA_REQUIRE(!yf32 || (p == 64 && q == 64 && res && a->norm == 2), QUIPAMD_ERR_UNSUPPORTED,
-               "decode_fused_gemm: fp32 u_y has a kernel for 64 x 64 with residual and RMSNorm only");
+    QA_REQUIRE(!yf32 || (p == 64 && q == 64 && res && a->norm == 2 && !w4), QUIPAMD_ERR_UNSUPPORTED,
+               "decode_fused_gemm: fp32 u_y has a kernel for 2-bit 64 x 64 with residual and RMSNorm only");
     if (p == 64 && q == 32) {
         QA_REQUIRE(a->m > 0 && a->m % 32 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 32 (m = %lld)", (long long)a->m);
+        if (w4) return dispatch_fused<64, 32, 2, 2, 1, 4>(A, u, res, a->norm, a->ngroups, s);
         return dispatch_fused<64, 32, 2, 1, 1>(A, u, res, a->norm, a->ngroups, s);
     }
     if (p == 64 && q == 64) {
@@ -739,6 +747,8 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
         const int64_t tpg = a->m / 16;
         auto wgs = [&](int n) { return (tpg + n - 1) / n * a->ngroups; };
         const int nrt = wgs(1) <= 256 ? 1 : wgs(4) <= 256 ? 4 : wgs(6) <= 256 ? 6 : 8;
+        if (w4)         // (twice the packed dwords per row tile: at most 4 tiles per wave stay in registers)
+            return nrt == 1 ? dispatch_fused<64, 64, 1, 2, 1, 4>(A, u, res, a->norm, a->ngroups, s) : dispatch_fused<64, 64, 1, 2, 4, 4>(A, u, res, a->norm, a->ngroups, s);
         if (yf32) return nrt == 8 ? launch_fused<64, 64, true, true, 2, 1, 1, 8, true>(A, a->ngroups, s)
                        : nrt == 6 ? launch_fused<64, 64, true, true, 2, 1, 1, 6, true>(A, a->ngroups, s)
                        : nrt == 4 ? launch_fused<64, 64, true, true, 2, 1, 1, 4, true>(A, a->ngroups, s)
@@ -752,7 +762,11 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
         QA_REQUIRE(a->m > 0 && a->m % 16 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 16 (m = %lld)", (long long)a->m);
         if (u && !res && a->norm == 0 && a->pair_sig && a->pair_bias && a->pair_cs && a->bs <= 2 && a->ngroups == 1 && !a->t_out) {
             A.pair_sig = (const uint4 *)a->pair_sig; A.pair_bias = (const uint4 *)a->pair_bias; A.pair_cs = (const uint4 *)a->pair_cs;
-            return launch_pair<128, 64>(A, s);
+            return w4 ? launch_pair<128, 64, 4>(A, g_fused_maxq, s) : launch_pair<128, 64, 2>(A, g_fused_maxq, s);
+        }
+        if (w4) {
+            if (u && !res && a->norm == 0) return launch_fused<128, 64, true, false, 0, 1, 4, 1, false, 4>(A, a->ngroups, s);
+            if (!u && a->norm == 0) return launch_fused<128, 64, false, false, 0, 1, 4, 1, false, 4>(A, a->ngroups, s);
         }
         if (u && !res && a->norm == 0) return launch_fused<128, 64, true, false, 0, 1, 2, 1>(A, a->ngroups, s);
         if (!u && a->norm == 0) return launch_fused<128, 64, false, false, 0, 1, 2, 1>(A, a->ngroups, s);

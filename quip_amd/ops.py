@@ -476,11 +476,11 @@ def pair_tables(Uop, Vop, bias16, colscale):
 
 
 def decode_fused_gemm(*, V, colscale, qweight, scale, y, m, bs, x=None, U=None, u_y=None, u_bias=None, u_residual=None, u_relu=False,
-                      t_out=None, norm=0, ln_gamma=None, ln_beta=None, ln_eps=0.0, pair=None):
+                      t_out=None, norm=0, ln_gamma=None, ln_beta=None, ln_eps=0.0, pair=None, bits=2):
     """one launch of quipamd_decode_fused_gemm.  V / colscale / qweight / scale / y: lists (1..3 groups); V, U: Fop records
     (OrthoOp.fop); 16-bit tensors fp16.  See include/quip_amd.h for the contract."""
     a = FusedGemmArgs()
-    a.act_dtype, a.bits = _DT[torch.float16], 2
+    a.act_dtype, a.bits = _DT[torch.float16], int(bits)
     a.has_u = int(U is not None)
     if U is not None:
         a.U = U

@@ -606,15 +606,15 @@ def packed_u_then_v(qa, y, dtype, qbs, residual=None, relu=False, ln=None, store
 
 
 def fused_ok(qls, rows, x_dtype=torch.float16, prev=None, norm=True, residual=True):
-    """can `fused_stage` run these layers?  (csrc/decode_fused.hip: 2-bit qfn-b layers of one shape sharing their input, Kronecker
+    """can `fused_stage` run these layers?  (csrc/decode_fused.hip: 2- / 3- / 4-bit qfn-b layers of one shape sharing their input, Kronecker
     operators of a decode shape on both sides, fp16 activations, a handful of rows; `prev`: the packed layer whose output-side
     operator rides in the prologue -- its U must have the consumers' V shape.  Kernels exist for the combinations a decoder block
     needs: d = 2048 / 4096: (prev + residual, norm or not), (no prev, norm or not); d = 8192: (prev, no residual, no norm),
     (no prev, no norm).)"""
     q0 = qls[0]
     ok = (1 <= len(qls) <= 3 and rows <= ops.FUSED_MAX_ROWS and x_dtype == torch.float16
-          and all(q.bits == 2 and q.qfn == 'b' and q.V is not None and q.V.fused_ok and q.scales.numel() == 1 for q in qls)
-          and len({(q.infeatures, q.outfeatures, q.V.p, q.V.q) for q in qls}) == 1
+          and all(q.bits in (2, 3, 4) and q.qfn == 'b' and q.V is not None and q.V.fused_ok and q.scales.numel() == 1 for q in qls)
+          and len({(q.infeatures, q.outfeatures, q.V.p, q.V.q, q.bits) for q in qls}) == 1
           and q0.outfeatures % (32 if (q0.V.p, q0.V.q) == (64, 32) else 16) == 0)
     if ok and prev is not None:
         ok = prev.U is not None and prev.U.fused_ok and (prev.U.p, prev.U.q) == (q0.V.p, q0.V.q)
@@ -752,7 +752,7 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
     m, d = q0.outfeatures, q0.infeatures
     ys = [torch.empty((rows, m), dtype=y_dtype, device=dev) for _ in qls]
     kw = dict(V=[q.V.fop(False) for q in qls], colscale=[q.inv_scaleWH if q.inv_scaleWH is not None else q.V.one_scale() for q in qls],
-              qweight=[q.decode_qweight() for q in qls], scale=[q.scales for q in qls], y=ys, m=m, bs=rows)
+              qweight=[q.decode_qweight() for q in qls], scale=[q.scales for q in qls], y=ys, m=m, bs=rows, bits=q0.bits)
     lnp = _ln_params(ln)
     if lnp is not None:
         g, b, eps = lnp
@@ -771,7 +771,8 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
             kw.update(pair=cache[key])
         # an fp32 y_prev is rounded to fp16 -- inside the launch where a kernel for that exists (the accumulator of fused_bigp_tail
         # feeding Llama's q / k / v), by a cast otherwise
-        in_kernel = (y_prev.dtype == torch.float32 and (q0.V.p, q0.V.q) == (64, 64) and residual is not None and lnp is not None and lnp[1] is None)
+        in_kernel = (y_prev.dtype == torch.float32 and (q0.V.p, q0.V.q) == (64, 64) and residual is not None and lnp is not None and lnp[1] is None
+                     and q0.bits == 2)
         kw.update(U=prev.U.fop(True), u_y=(y_prev if in_kernel else y_prev.to(torch.float16)).contiguous(), u_bias=bias16(prev),
                   u_residual=None if residual is None else residual.contiguous(), u_relu=relu, t_out=t)
     ops.decode_fused_gemm(**kw)

@@ -27,6 +27,13 @@ def test_packed_decode_step_matches_its_dense_twin():
     assert chained_equal, "chained hand-over launches must reproduce the unchained step bit for bit"
 
 
+def test_packed_w4_decode_step_runs_on_the_fused_launches():
+    """round 4: --wbits 4 qfn-b models on the same five launches per block (csrc/decode_fused.hip templated on the container width)"""
+    e_plain, e_fused, e_fused_attn, chained_equal, e_v3 = _mod().decode_check(layers=2, bits=4)
+    assert e_plain <= 1e-2 and e_fused <= 1e-2 and e_fused_attn <= 1e-2, (e_plain, e_fused, e_fused_attn)
+    assert e_v3 is not None and e_v3 <= 1e-2, e_v3
+
+
 def test_llama_decode_step_matches_its_dense_twin():
     """the Llama block (scripts/decode_llama.py: RMSNorm folded into the activation-side operator launch, one-launch rotary,
     gate / up grouped, 11008-wide operators on the general K3 path) against dense fp16 twins, 4 tokens, batch 2"""

@@ -21,7 +21,7 @@ ALLOWED = [
     (r"chol_syrk_full_kernelILi4E", 32, "5 registers of addressing at 256 VGPRs; outside the MFMA loop"),
     (r"fused_gemm_kernelILi64ELi64ELb1ELb1ELi1E", 96, "64 x 64 with LayerNorm (no model of this repo's benchmarks: OPT-1.3B is 64 x 32, Llama RMSNorm)"),
     (r"fused_gemm_kernelILi128ELi64ELb1ELb0ELi0ELi1ELi2ELi1E", 16, "the generic n = 8192 launch (bs 3-4; bs <= 2 runs fused_pair_kernel)"),
-    (r"dq_pf_kernelINS_\w+ELi256ELi256E", 48, "forced-only prefill experiment (slower than the mb kernel, DESIGN.md K2)"),
+    (r"fused_gemm_kernelILi128ELi64ELb1ELb0ELi0ELi1ELi4ELi1ELb0ELi4E", 64, "the same launch for the 4-bit container (round 4; bs 3-4 only, like the 2-bit one)"),
     (r"hsyrk_fast_kernel", 8, "opt-in Hessian mode"),
     (r"ortho_small_split_kernel", 340, "round-2 operator kernels with run-time (p, q); the decode path uses the compile-time fpass.h forms"),
 ]
