@@ -536,11 +536,12 @@ int quipamd_preproc_trace_ridge(float *H, int64_t d, float ridge, void *workspac
  * then undefined.  The call is asynchronous, so the caller reads that word once the stream has drained:
  *   int32 at byte quipamd_gptq_qfnb_info_offset(m, d) of `workspace`: 0 = the sweep completed, 1 = abandoned (treat as QUIPAMD_ERR_LAUNCH;
  *   quip_amd.ops.gptq_round_qfnb raises, quip_amd.gptq falls back to the column walk).
- * quipamd_gptq_qfnb_debug(short_grid, spin_limit): test hook -- launch `short_grid` workgroups too few and give up after `spin_limit` polls
- * (0, 0 restores the defaults); exercises the abandon path on a healthy device. */
+ * quipamd_gptq_qfnb_debug(short_grid, spin_limit, force_rows): test / lab hook -- launch `short_grid` workgroups too few and give up after
+ * `spin_limit` polls (exercises the abandon path on a healthy device); force_rows = 16 | 32 | 64 | 128 rows per workgroup instead of the
+ * heuristic's choice (fewer, fatter workgroups = a cheaper all-gather per column).  (0, 0, 0) restores the defaults. */
 int64_t quipamd_gptq_qfnb_workspace_bytes(int64_t m, int64_t d);
 int64_t quipamd_gptq_qfnb_info_offset(int64_t m, int64_t d);
-void quipamd_gptq_qfnb_debug(int short_grid, int64_t spin_limit);
+void quipamd_gptq_qfnb_debug(int short_grid, int64_t spin_limit, int force_rows);
 int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits, float *QT_rev, float *colscale_rev, void *workspace, int64_t m,
                             int64_t d, void *stream);
 

@@ -74,7 +74,7 @@ SIGNATURES = {
     "quipamd_preproc_trace_ridge": [c_vp, c_i64, c_float, c_vp, c_vp],
     "quipamd_gptq_qfnb_workspace_bytes": [c_i64, c_i64],
     "quipamd_gptq_qfnb_info_offset": [c_i64, c_i64],
-    "quipamd_gptq_qfnb_debug": [c_int, c_i64],
+    "quipamd_gptq_qfnb_debug": [c_int, c_i64, c_int],
     "quipamd_gptq_round_qfnb": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp],
     "quipamd_cholesky_config": [c_int, c_int],
     "quipamd_ldlq_config": [c_int],

@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void gptqb_far_kernel(GbArgs A)
 int g_gb_debug_short_grid = 0;
 constexpr long long GB_SPIN_LIMIT = 1ll << 22;                        // ~0.5 us per poll: a few seconds; a healthy wait is a few polls
 long long g_gb_spin_limit = GB_SPIN_LIMIT;
+int g_gb_force_rows = 0;                                              // lab: rows per workgroup (16 / 32 / 64 / 128) instead of the heuristic's
 
 template <int R> int gb_chain(const GbArgs &A, hipStream_t s)
 {
@@ -213,10 +214,11 @@ template <int R> int gb_chain(const GbArgs &A, hipStream_t s)
 
 }   // namespace
 
-extern "C" void quipamd_gptq_qfnb_debug(int short_grid, int64_t spin_limit)
+extern "C" void quipamd_gptq_qfnb_debug(int short_grid, int64_t spin_limit, int force_rows)
 {
     g_gb_debug_short_grid = short_grid > 0 ? short_grid : 0;
     g_gb_spin_limit = spin_limit > 0 ? spin_limit : GB_SPIN_LIMIT;
+    g_gb_force_rows = (force_rows == 16 || force_rows == 32 || force_rows == 64 || force_rows == 128) ? force_rows : 0;
 }
 
 extern "C" int64_t quipamd_gptq_qfnb_info_offset(int64_t m, int64_t d)
@@ -251,7 +253,11 @@ extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits,
         return (m + R - 1) / R <= (int64_t)per_cu * ncu;
     };
     int R = 0;
-    if (m <= 32 * 64 && fits(16, (const void *)gptqb_chain_kernel<16>)) R = 16;
+    if (g_gb_force_rows == 16 && fits(16, (const void *)gptqb_chain_kernel<16>)) R = 16;
+    else if (g_gb_force_rows == 32 && fits(32, (const void *)gptqb_chain_kernel<32>)) R = 32;
+    else if (g_gb_force_rows == 64 && fits(64, (const void *)gptqb_chain_kernel<64>)) R = 64;
+    else if (g_gb_force_rows == 128 && fits(128, (const void *)gptqb_chain_kernel<128>)) R = 128;
+    else if (m <= 32 * 64 && fits(16, (const void *)gptqb_chain_kernel<16>)) R = 16;
     else if (m <= 64 * 128 && fits(32, (const void *)gptqb_chain_kernel<32>)) R = 32;
     else if (m <= 128 * 128 && fits(64, (const void *)gptqb_chain_kernel<64>)) R = 64;
     else if (fits(128, (const void *)gptqb_chain_kernel<128>)) R = 128;

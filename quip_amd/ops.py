@@ -888,9 +888,10 @@ def gptq_round_qfnb(W, FT, bits):
     return qt.t().flip(1).contiguous(), cs.flip(0).contiguous()
 
 
-def gptq_qfnb_debug(short_grid=0, spin_limit=0):
-    """test hook of csrc/gptq_qfnb.hip (quipamd_gptq_qfnb_debug): launch `short_grid` workgroups too few, give up after `spin_limit` polls"""
-    _lib.load().quipamd_gptq_qfnb_debug(int(short_grid), int(spin_limit))
+def gptq_qfnb_debug(short_grid=0, spin_limit=0, force_rows=0):
+    """test / lab hook of csrc/gptq_qfnb.hip (quipamd_gptq_qfnb_debug): launch `short_grid` workgroups too few, give up after `spin_limit`
+    polls, `force_rows` rows per workgroup"""
+    _lib.load().quipamd_gptq_qfnb_debug(int(short_grid), int(spin_limit), int(force_rows))
 
 
 def cholesky_lt(H, check=True):

@@ -89,6 +89,6 @@ def test_a_grid_that_is_not_co_resident_is_an_error_not_a_hang():
             ops.gptq_round_qfnb(W.clone(), FT, 2)
         assert time.time() - t0 < 30.0
     finally:
-        ops.gptq_qfnb_debug(0, 0)
+        ops.gptq_qfnb_debug(0, 0, 0)
     again, _ = ops.gptq_round_qfnb(W.clone(), FT, 2)                  # the device and the library are fine afterwards
     assert torch.equal(again, good)
