@@ -192,6 +192,44 @@ int quipamd_ortho_apply_small(const float *M0, const float *M1, const int32_t *l
                               const void *x, int x_dtype, int64_t ldx, void *out, int out_dtype, int64_t ldo,
                               int64_t rows, void *stream);
 
+/* The BLOCKED butterfly operator (method.py:34-35 gen_rand_ortho_butterfly: B0 [q, p, p], B1 [p, q, q]; what opt.py's --incoh_processing
+ * really selects, opt.py:596) applied to a handful of rows -- the decode step of a model quantised by the shipped flag (csrc/ortho_blk.hip).
+ *     out = [relu]( Q . ( colscale * Norm( silu(x) * gate_up | x ) ) + bias + residual ),      Q = P_out S1 S0 P_in  or its transpose
+ * Two launches (the two mixing stages meet all-to-all), workgroup = (factor block, 16 output rows), factors streamed once as fp16,
+ * activations as fp16 hi + lo, fp32 accumulate: ~3e-4 per stage (the tolerance class of the fused decode launches, NOT the 1e-3
+ * contract of quipamd_ortho_apply_rows, which stays the path of quantisation and of every caller that does not ask for this one).
+ *   F_first / F_second: fp16 [G][P][P] (out index, in index) of the stage that runs first / second; first_mixes_a != 0: the first stage
+ *     mixes the index a (G = q blocks of p x p: B0 for Q), the second the index b (G = p blocks of q x q: B1); 0: the other way round
+ *     (Q^T: first B1[a]^T, then B0[b]^T).  Image position of (a, b) = a q + b.
+ *   in_idx: int32 [n] or NULL, image position pos reads x[in_idx[pos]] (Q: perm_in; Q^T: argsort(perm_out));
+ *   out_idx: int32 [n] or NULL, image position pos is written to out[out_idx[pos]] (Q: argsort(perm_out); Q^T: perm_in).
+ *   x [rows, ld_x] of x_dtype; gate_up: same dtype / stride or NULL; norm: 0 none, 1 LayerNorm, 2 RMSNorm (HF's: x rsqrt(mean x^2 + eps)
+ *   rounded to x_dtype, then gamma) with fp16 ln_gamma / ln_beta [n] in natural order; colscale / bias: float [n] or NULL;
+ *   residual [rows, ld_residual] of residual_dtype or NULL; out [rows, ld_out] of out_dtype; rows <= 8;
+ *   workspace: float [rows * p * q].  p, q multiples of 16, <= 768 (quipamd_ortho_blocked_supported). */
+typedef struct quipamd_blk_op {
+    const void *F_first, *F_second;
+    int first_mixes_a, p, q;
+    const int32_t *in_idx, *out_idx;
+    const void *x;
+    int x_dtype;
+    int64_t ld_x;
+    void *out;
+    int out_dtype;
+    int64_t ld_out, rows;
+    const void *gate_up;
+    int norm;
+    const void *ln_gamma, *ln_beta;
+    float ln_eps;
+    const float *colscale, *bias;
+    const void *residual;
+    int residual_dtype;
+    int64_t ld_residual;
+    int relu;
+} quipamd_blk_op;
+int quipamd_ortho_blocked_supported(int p, int q);
+int quipamd_ortho_blocked_rows(const quipamd_blk_op *op, void *workspace, void *stream);
+
 /* One small-batch operator application with the elementwise work of its neighbours in the decoder block fused in
  * (a decode step is launch-latency bound):  out = [relu]( Q . ( colscale * [LayerNorm](x) ) + bias + residual ).
  * Fields as in quipamd_ortho_apply_small; ln_gamma / ln_beta (dtype ln_dtype, ln_gamma NULL = no normalisation, statistics in

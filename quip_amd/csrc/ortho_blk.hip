@@ -1,0 +1,247 @@
+// ortho_blk.hip -- the BLOCKED butterfly operator (method.py:34-35 gen_rand_ortho_butterfly: B0 [q, p, p], B1 [p, q, q] -- what the
+// reference's `--incoh_processing` really selects, opt.py:596 sets an unused `proj_extra`) applied to a HANDFUL of rows: the decode step
+// of a model quantised by the shipped flag.
+//
+// A blocked operator stores n (p + q) factor values per side (n = 2048: 393 KB in fp16; n = 11008 = 688 x 16: 15.5 MB), not the
+// p^2 + q^2 of the Kronecker form, so the fused decode launches (decode_fused.hip: every workgroup redoes the whole pass in its
+// prologue) cannot take it, and round 3 sent such a model through the general two-stage K3 launches (ortho.hip: fp32 factors, rows padded
+// to 16, a 4-byte global gather per element): 171 tok/s for OPT-1.3B, 29 tok/s for Llama-2-7B (profiles/r04c_decode_engine.jsonl).
+// With one row the operator is a chain of two batched mat-vecs that is bound by the factor bytes, so it is laid out as a stream:
+//
+//   stage "mix a"  (q groups b, p x p each)   out[a, b] = sum_a' F[b][a][a'] in[a', b]
+//   stage "mix b"  (p groups a, q x q each)   out[a, b] = sum_b' F[a][b][b'] in[a, b']
+//
+// one launch per stage (the stages meet all-to-all), workgroup = (group, 16 output rows), its four waves split K, factors read ONCE as
+// fp16 rows (16 bytes per lane = 8 consecutive k of one output row: the v_mfma_f32_16x16x32_f16 A fragment straight from row-major
+// memory), the input vector of the group staged in LDS as fp16 hi + lo (two MFMAs per step: the activations keep 22 bits, the
+// factors carry the 2^-12 of fp16 -- the tolerance class of the fused decode launches, ~3e-4 per stage), fp32 accumulate.
+// The first stage gathers through the operator's input permutation and applies what sits in front of the operator in a decoder block
+// (silu(gate) * up, LayerNorm / RMSNorm, the 1 / scaleWH column scale); the second scatters through the output permutation and applies
+// what follows it (bias, residual, ReLU) -- the operand set of the Kronecker small-batch kernels (ortho_small.hip).
+// Forward = mix a (B0) then mix b (B1); transpose = mix b (B1^T) then mix a (B0^T): the host hands over the factor arrays of the
+// orientation it wants (ops.OrthoOp.blk_factors).
+#include "common.h"
+
+namespace {
+
+constexpr int BK_T = 256, BK_MAXR = 8;
+
+struct BlkStage {
+    const uint16_t *F;            // [G][P][P] fp16, (out index, in index)
+    int mix_a;                    // 1: groups are b (G = q), P = p, position (i, g) = i q + g;  0: groups are a (G = p), P = q, position g q + i
+    int p, q;
+    const int32_t *in_idx;        // gather: element at image position pos is in[in_idx[pos]] (null: in[pos])
+    const int32_t *out_idx;       // scatter: image position pos goes to out[out_idx[pos]] (null: out[pos])
+    const void *in;               // [rows, ld_in] of IN
+    int64_t ld_in;
+    void *out;                    // [rows, ld_out] of OUT
+    int64_t ld_out;
+    // in front of the operator (first stage only; indexed by the NATURAL input index)
+    const void *gate_up;          // IN [rows, ld_in] or null: value = silu(in) * gate_up
+    int norm;                     // 0 none, 1 LayerNorm, 2 RMSNorm over the n input elements of a row
+    const uint16_t *gamma, *beta; // fp16 [n]
+    float eps;
+    const float *colscale;        // fp32 [n] or null
+    // behind it (last stage only; indexed by the NATURAL output index)
+    const float *bias;            // fp32 [n] or null
+    const void *residual;         // [rows, ld_res] of RES dtype or null
+    int res_dtype;
+    int64_t ld_res;
+    int relu;
+    int rows;
+};
+
+__device__ __forceinline__ float bk_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float bk_block_sum(float v, float *red)       // 4 waves; `red` [4] is rewritten by the next call behind two barriers
+{
+    v = bk_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+typedef _Float16 bk_f16x8 __attribute__((ext_vector_type(8)));
+
+template <class IN, class OUT>
+__global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStage S)
+{
+    extern __shared__ __attribute__((aligned(16))) char bk_smem[];
+    const int P = S.mix_a ? S.p : S.q, q = S.q, n = S.p * S.q;
+    const int PS = P + 8;                                              // LDS row stride (halves): 16-byte rows, banks staggered
+    uint16_t *XH = reinterpret_cast<uint16_t *>(bk_smem);             // [BK_MAXR][PS] hi
+    uint16_t *XL = XH + BK_MAXR * PS;                                 // [BK_MAXR][PS] lo
+    float *part = reinterpret_cast<float *>(XL + BK_MAXR * PS);       // [4 waves][4][64]
+    float *red = part + 4 * 256;                                      // [4]
+    float *stat = red + 4;                                            // [BK_MAXR][2] mean, rstd
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = P / 16;
+    const int g = blockIdx.x / tiles, tile = blockIdx.x - g * tiles;
+    const int R = S.rows;
+
+    // ---- the factor fragments of this wave's k-steps: requested first (the only HBM traffic of the launch) -------------------------
+    const int nk = (P + 31) / 32;                                     // k-steps of 32; the last one may be half (P % 32 == 16)
+    const int i = lane & 15, g4 = lane >> 4;
+    const uint16_t *Frow = S.F + ((int64_t)g * P + (tile * 16 + i)) * P + 8 * g4;
+    constexpr int MAXS = 6;                                           // k-steps per wave held in registers: P <= 768
+    uint4 af[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        const int ks = wave + 4 * s;
+        const bool ok = ks < nk && ks * 32 + 8 * g4 < P;
+        const int ksc = ok ? ks : 0;                                   // clamped address + select: every load unconditional, all in flight
+        const uint4 v = *reinterpret_cast<const uint4 *>(Frow + (ok ? ksc * 32 : -8 * g4));
+        af[s] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+
+    // ---- statistics of the rows (first stage with a norm): every workgroup reduces the whole row -- n <= 16384 values from L2 ---------
+    if (S.norm) {
+        for (int r = 0; r < R; ++r) {
+            float s1 = 0.f;
+            for (int e = tid; e < n; e += BK_T) s1 += DT<IN>::load(S.in, (int64_t)r * S.ld_in + e);
+            const float mean = S.norm == 1 ? bk_block_sum(s1, red) / (float)n : 0.f;
+            float s2 = 0.f;
+            for (int e = tid; e < n; e += BK_T) {
+                const float dv = DT<IN>::load(S.in, (int64_t)r * S.ld_in + e) - mean;
+                s2 += dv * dv;
+            }
+            const float var = bk_block_sum(s2, red) / (float)n;
+            if (tid == 0) {
+                stat[2 * r] = mean;
+                stat[2 * r + 1] = rsqrtf(var + S.eps);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- the group's input vector, rows r < R (rows R .. 7 are zeros: MFMA columns nobody stores) ---------------------------------------
+    for (int e = tid; e < BK_MAXR * P; e += BK_T) {
+        const int r = e / P, k = e - r * P;
+        float v = 0.f;
+        if (r < R) {
+            const int pos = S.mix_a ? k * q + g : g * q + k;
+            const int src = S.in_idx ? S.in_idx[pos] : pos;
+            v = DT<IN>::load(S.in, (int64_t)r * S.ld_in + src);
+            if (S.gate_up) {
+                const float u = DT<IN>::load(S.gate_up, (int64_t)r * S.ld_in + src);
+                v = DT<IN>::rnd(v / (1.0f + __expf(-v))) * u;             // silu rounded to the activation dtype like torch's op, then the product
+                v = DT<IN>::rnd(v);
+            }
+            if (S.norm == 1) {                                           // torch LayerNorm: fp32 inside, one rounding to the model's dtype
+                v = DT<IN>::rnd((v - stat[2 * r]) * stat[2 * r + 1] * f16_bits_to_f32(S.gamma[src]) + f16_bits_to_f32(S.beta[src]));
+            } else if (S.norm == 2) {                                    // HF LlamaRMSNorm: (x rsqrt(..)).to(dtype), then weight * that
+                v = DT<IN>::rnd(DT<IN>::rnd(v * stat[2 * r + 1]) * f16_bits_to_f32(S.gamma[src]));
+            }
+            if (S.colscale) v *= S.colscale[src];
+        }
+        const uint16_t hi = f32_to_f16_bits(v);
+        XH[r * PS + k] = hi;
+        XL[r * PS + k] = f32_to_f16_bits(v - f16_bits_to_f32(hi));
+    }
+    __syncthreads();
+
+    // ---- this wave's k-steps: D[16 out rows][16 columns = batch rows] ------------------------------------------------------------------
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const int col = lane & (BK_MAXR - 1);
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        const int ks = wave + 4 * s;
+        if (ks < nk) {                                                   // (uniform per wave)
+            const int k0 = ks * 32 + 8 * g4;
+            uint4 bh = make_uint4(0u, 0u, 0u, 0u), bl = bh;
+            if (k0 < P) {
+                bh = *reinterpret_cast<const uint4 *>(XH + col * PS + k0);
+                bl = *reinterpret_cast<const uint4 *>(XL + col * PS + k0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(bk_f16x8, af[s]), __builtin_bit_cast(bk_f16x8, bh), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(bk_f16x8, af[s]), __builtin_bit_cast(bk_f16x8, bl), acc, 0, 0, 0);
+        }
+    }
+    float *pw = part + wave * 256 + lane;
+    pw[0] = acc[0]; pw[64] = acc[1]; pw[128] = acc[2]; pw[192] = acc[3];
+    __syncthreads();
+    if (wave == 0) {
+        // D: column = lane & 15 (batch row), row = 4 (lane >> 4) + reg
+        const int r = lane & 15;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            float v = (part[reg * 64 + lane] + part[256 + reg * 64 + lane]) + (part[512 + reg * 64 + lane] + part[768 + reg * 64 + lane]);
+            if (r < R) {
+                const int io = tile * 16 + 4 * g4 + reg;
+                const int pos = S.mix_a ? io * q + g : g * q + io;
+                const int dst = S.out_idx ? S.out_idx[pos] : pos;
+                if (S.bias) v += S.bias[dst];
+                if (S.residual) {
+                    const int64_t ri = (int64_t)r * S.ld_res + dst;
+                    v += S.res_dtype == QUIPAMD_F32 ? ((const float *)S.residual)[ri]
+                         : S.res_dtype == QUIPAMD_F16 ? f16_bits_to_f32(((const uint16_t *)S.residual)[ri]) : bf16_bits_to_f32(((const uint16_t *)S.residual)[ri]);
+                }
+                if (S.relu) v = fmaxf(v, 0.f);
+                DT<OUT>::store(S.out, (int64_t)r * S.ld_out + dst, v);
+            }
+        }
+    }
+}
+
+template <class IN, class OUT> int launch_stage(const BlkStage &S, hipStream_t s)
+{
+    const int P = S.mix_a ? S.p : S.q, G = S.mix_a ? S.q : S.p;
+    const size_t lds = (size_t)2 * BK_MAXR * (P + 8) * 2 + (4 * 256 + 4 + 2 * BK_MAXR) * 4 + 64;
+    blk_stage_kernel<IN, OUT><<<(unsigned)(G * (P / 16)), BK_T, lds, s>>>(S);
+    return QUIPAMD_OK;
+}
+
+}   // namespace
+
+extern "C" int quipamd_ortho_blocked_supported(int p, int q)
+{
+    return p >= 16 && q >= 16 && p % 16 == 0 && q % 16 == 0 && p <= 768 && q <= 768;
+}
+
+extern "C" int quipamd_ortho_blocked_rows(const quipamd_blk_op *op, void *workspace, void *stream)
+{
+    QA_REQUIRE(op, QUIPAMD_ERR_ARG, "ortho_blocked_rows: null op");
+    QA_REQUIRE(quipamd_ortho_blocked_supported(op->p, op->q), QUIPAMD_ERR_UNSUPPORTED, "ortho_blocked_rows: factors %d x %d (multiples of 16, <= 768)", op->p, op->q);
+    QA_REQUIRE(op->rows >= 0 && op->rows <= BK_MAXR, QUIPAMD_ERR_SHAPE, "ortho_blocked_rows: %lld rows > %d", (long long)op->rows, BK_MAXR);
+    if (op->rows == 0) return QUIPAMD_OK;
+    QA_REQUIRE(op->F_first && op->F_second && op->x && op->out && workspace, QUIPAMD_ERR_ARG, "ortho_blocked_rows: null pointer");
+    const int64_t n = (int64_t)op->p * op->q;
+    QA_REQUIRE(op->ld_x >= n && op->ld_out >= n, QUIPAMD_ERR_SHAPE, "ortho_blocked_rows: row strides");
+    QA_REQUIRE(op->norm >= 0 && op->norm <= 2 && (op->norm == 0 || op->ln_gamma) && (op->norm != 1 || op->ln_beta), QUIPAMD_ERR_ARG,
+               "ortho_blocked_rows: norm %d needs gamma (and beta for LayerNorm)", op->norm);
+    QA_REQUIRE(!op->residual || (op->ld_residual >= n && (op->residual_dtype == QUIPAMD_F32 || op->residual_dtype == QUIPAMD_F16 || op->residual_dtype == QUIPAMD_BF16)),
+               QUIPAMD_ERR_ARG, "ortho_blocked_rows: residual stride / dtype");
+    hipStream_t s = (hipStream_t)stream;
+    BlkStage A;
+    A.F = (const uint16_t *)op->F_first; A.mix_a = op->first_mixes_a; A.p = op->p; A.q = op->q;
+    A.in_idx = op->in_idx; A.out_idx = nullptr; A.in = op->x; A.ld_in = op->ld_x; A.out = workspace; A.ld_out = n;
+    A.gate_up = op->gate_up; A.norm = op->norm; A.gamma = (const uint16_t *)op->ln_gamma; A.beta = (const uint16_t *)op->ln_beta; A.eps = op->ln_eps;
+    A.colscale = op->colscale; A.bias = nullptr; A.residual = nullptr; A.res_dtype = 0; A.ld_res = 0; A.relu = 0; A.rows = (int)op->rows;
+    BlkStage B = A;
+    B.F = (const uint16_t *)op->F_second; B.mix_a = !op->first_mixes_a; B.in_idx = nullptr; B.out_idx = op->out_idx; B.in = workspace; B.ld_in = n;
+    B.out = op->out; B.ld_out = op->ld_out; B.gate_up = nullptr; B.norm = 0; B.colscale = nullptr;
+    B.bias = op->bias; B.residual = op->residual; B.res_dtype = op->residual_dtype; B.ld_res = op->ld_residual; B.relu = op->relu;
+    int rc;
+    switch (op->x_dtype) {
+    case QUIPAMD_F32: rc = launch_stage<F32, F32>(A, s); break;
+    case QUIPAMD_F16: rc = launch_stage<F16, F32>(A, s); break;
+    case QUIPAMD_BF16: rc = launch_stage<BF16, F32>(A, s); break;
+    default: return qa_fail(QUIPAMD_ERR_ARG, "ortho_blocked_rows: x dtype %d", op->x_dtype);
+    }
+    if (rc) return rc;
+    switch (op->out_dtype) {
+    case QUIPAMD_F32: rc = launch_stage<F32, F32>(B, s); break;
+    case QUIPAMD_F16: rc = launch_stage<F32, F16>(B, s); break;
+    case QUIPAMD_BF16: rc = launch_stage<F32, BF16>(B, s); break;
+    default: return qa_fail(QUIPAMD_ERR_ARG, "ortho_blocked_rows: out dtype %d", op->out_dtype);
+    }
+    if (rc) return rc;
+    QA_LAUNCH_CHECK("quipamd_ortho_blocked_rows");
+    return QUIPAMD_OK;
+}

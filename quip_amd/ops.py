@@ -515,6 +515,19 @@ def decode_fused_gemm(*, V, colscale, qweight, scale, y, m, bs, x=None, U=None, 
     _lib.call("quipamd_decode_fused_gemm", ctypes.byref(a), _stream())
 
 
+class BlkOp(ctypes.Structure):
+    """mirror of `quipamd_blk_op` (include/quip_amd.h): the blocked butterfly on a handful of rows (csrc/ortho_blk.hip)"""
+    _fields_ = [("F_first", ctypes.c_void_p), ("F_second", ctypes.c_void_p), ("first_mixes_a", ctypes.c_int), ("p", ctypes.c_int), ("q", ctypes.c_int),
+                ("in_idx", ctypes.c_void_p), ("out_idx", ctypes.c_void_p), ("x", ctypes.c_void_p), ("x_dtype", ctypes.c_int), ("ld_x", ctypes.c_int64),
+                ("out", ctypes.c_void_p), ("out_dtype", ctypes.c_int), ("ld_out", ctypes.c_int64), ("rows", ctypes.c_int64), ("gate_up", ctypes.c_void_p),
+                ("norm", ctypes.c_int), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p), ("ln_eps", ctypes.c_float),
+                ("colscale", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("residual_dtype", ctypes.c_int),
+                ("ld_residual", ctypes.c_int64), ("relu", ctypes.c_int)]
+
+
+BLK_MAX_ROWS = 8
+
+
 def _mfma_b_frags(M):
     """M [C, P, P] (out index i, in index k) -> float [C, NT, NT, 64, 4] in v_mfma_f32_16x16x4_f32 B-fragment order
     (include/quip_amd.h): element [c][nt][S][lane][s] = M[c][16 nt + (lane & 15)][16 S + 4 (lane >> 4) + s]."""
@@ -570,6 +583,8 @@ class OrthoOp:
                     hi = M.to(torch.bfloat16)
                     return hi.contiguous(), (M - hi.float()).to(torch.bfloat16).contiguous()
                 self._Msplit = {k: hl(m0) + hl(m1) for k, (m0, m1) in self._M.items()}
+        # csrc/ortho_blk.hip: the BLOCKED butterfly on a handful of rows (decode of a model quantised by the shipped --incoh_processing)
+        self.blk_ok = bool(self.blocked and self.p % 16 == 0 and self.q % 16 == 0 and self.p <= 768 and self.q <= 768)
         # csrc/ortho_tile.hip: one workgroup per 16 x 16 output tile for a handful of rows (decode)
         self.tile_ok = self.split_ok and (self.p, self.q) in ((64, 32), (64, 64), (128, 64))
         self.tile_supported = self.split_ok and (self.p, self.q) in ((64, 32), (64, 64), (128, 64))
@@ -637,6 +652,52 @@ class OrthoOp:
             cache[key] = (_f16_b_frags_padded(M0), M1.to(torch.float32).contiguous())
         return cache[key]
 
+    def blk_factors(self, transpose):
+        """(F_first, F_second, first_mixes_a) for csrc/ortho_blk.hip: fp16 [G][P][P] (out index, in index) of the stage that runs first /
+        second.  Q: B0 [q, p, p] (mixes a) then B1 [p, q, q]; Q^T: B1^T then B0^T.  Built once per orientation, kept on the device."""
+        cache = self.__dict__.setdefault('_blk_factors', {})
+        key = bool(transpose)
+        if key not in cache:
+            assert self.blk_ok
+            h = lambda t: t.to(torch.float16).contiguous()
+            if key:
+                cache[key] = (h(self._B1.transpose(1, 2)), h(self._B0.transpose(1, 2)), 0)
+            else:
+                cache[key] = (h(self._B0), h(self._B1), 1)
+        return cache[key]
+
+    def apply_rows_blocked(self, x, transpose=False, colscale=None, out_dtype=None, bias=None, ln=None, residual=None, relu=False, gate_up=None):
+        """out = [relu]( Q ( colscale * Norm( silu(x) * gate_up | x ) ) + bias + residual ) for <= 8 rows of a BLOCKED operator, two launches
+        (quipamd_ortho_blocked_rows; fp16 factors: the fused decode launches' tolerance class).  ln = (gamma, beta | None, eps) with fp16
+        gamma / beta; colscale / bias fp32 [n]; residual [rows, n] fp16 / bf16 / fp32; gate_up like x."""
+        _need_gpu(x)
+        rows = x.shape[0]
+        assert self.blk_ok and x.dim() == 2 and x.shape[1] == self.n and x.stride(1) == 1 and rows <= BLK_MAX_ROWS and x.dtype in _DT
+        out = torch.empty((rows, self.n), dtype=out_dtype or x.dtype, device=x.device)
+        F1, F2, first_a = self.blk_factors(transpose)
+        gather, scatter = (self.inv_pout, self.pin) if transpose else (self.pin, self.inv_pout)
+        a = BlkOp()
+        a.F_first, a.F_second, a.first_mixes_a, a.p, a.q = F1.data_ptr(), F2.data_ptr(), first_a, self.p, self.q
+        a.in_idx, a.out_idx = _ptr(gather), _ptr(scatter)
+        a.x, a.x_dtype, a.ld_x = x.data_ptr(), _dtype(x), x.stride(0)
+        a.out, a.out_dtype, a.ld_out, a.rows = out.data_ptr(), _dtype(out), out.stride(0), rows
+        if gate_up is not None:
+            assert gate_up.dtype == x.dtype and gate_up.shape == x.shape and gate_up.stride() == x.stride()
+            a.gate_up = gate_up.data_ptr()
+        if ln is not None:
+            g, b, eps = ln
+            assert g.dtype == torch.float16 and (b is None or b.dtype == torch.float16) and g.numel() == self.n
+            a.norm, a.ln_gamma, a.ln_beta, a.ln_eps = (1 if b is not None else 2), g.data_ptr(), _ptr(b), float(eps)
+        cs, bs_ = _f32vec(colscale, x.device), _f32vec(bias, x.device)
+        a.colscale, a.bias = _ptr(cs), _ptr(bs_)
+        if residual is not None:
+            assert residual.shape == (rows, self.n) and residual.stride(1) == 1 and residual.dtype in _DT
+            a.residual, a.residual_dtype, a.ld_residual = residual.data_ptr(), _dtype(residual), residual.stride(0)
+        a.relu = int(bool(relu))
+        ws = torch.empty(rows * self.n, dtype=torch.float32, device=x.device)
+        _lib.call("quipamd_ortho_blocked_rows", ctypes.byref(a), _p(ws), _stream())
+        return out
+
     def store_inv(self, transpose):
         """image position -> output index: the inverse of the `store_idx` small_op() hands to the kernels"""
         return self.pin if transpose else self.inv_pout
@@ -659,11 +720,15 @@ class OrthoOp:
     SMALL_ROWS = 64
     use_split = True      # small-batch path: split-bf16 factors on the bf16 matrix pipe (~1e-5 rel.) when the shape allows
 
-    def apply_rows(self, x, transpose=False, colscale=None, out_dtype=None, bias=None):
-        """out[r] = Q x[r] (Q^T if transpose) with x[r] multiplied elementwise by colscale first and bias added last."""
+    def apply_rows(self, x, transpose=False, colscale=None, out_dtype=None, bias=None, fast16=False):
+        """out[r] = Q x[r] (Q^T if transpose) with x[r] multiplied elementwise by colscale first and bias added last.
+        fast16: the caller is a decode step (a handful of activation rows): a BLOCKED operator may then take csrc/ortho_blk.hip (fp16
+        factors, ~3e-4 per stage) instead of the general fp32 launches; quantisation (W, H) never passes it."""
         _need_gpu(x)
         assert x.dim() == 2 and x.shape[1] == self.n and x.stride(1) == 1
         rows = x.shape[0]
+        if fast16 and self.blk_ok and 0 < rows <= BLK_MAX_ROWS and x.dtype in _DT:
+            return self.apply_rows_blocked(x, transpose=transpose, colscale=colscale, out_dtype=out_dtype, bias=bias)
         out = torch.empty((rows, self.n), dtype=out_dtype or x.dtype, device=x.device)
         cs = _f32vec(colscale, x.device)
         if self.small_ok and x.stride(0) % 4 == 0:

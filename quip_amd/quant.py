@@ -301,8 +301,9 @@ class QuantLinear(nn.Module):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
         adt = self.act_dtype(x)
+        few = x2.shape[0] <= ops.BLK_MAX_ROWS                  # a decode step: blocked operators may take csrc/ortho_blk.hip
         if self.V is not None:
-            xt = self.V.apply_rows(x2.contiguous(), colscale=self.inv_scaleWH, out_dtype=adt)
+            xt = self.V.apply_rows(x2.contiguous(), colscale=self.inv_scaleWH, out_dtype=adt, fast16=few)
         else:
             xt = x2.to(adt)
             if self.inv_scaleWH is not None:
@@ -313,7 +314,7 @@ class QuantLinear(nn.Module):
         else:
             y = ops.dequant_gemm(xt, self.qweight, self.bits, self.qfn, self.scales, self.zeros, None,
                                  out_dtype=torch.float32, m=self.outfeatures)
-            y = self.U.apply_rows(y, transpose=True, out_dtype=x.dtype, bias=self.bias)   # fp32 in, caller's dtype out
+            y = self.U.apply_rows(y, transpose=True, out_dtype=x.dtype, bias=self.bias, fast16=few)   # fp32 in, caller's dtype out
         return y.to(x.dtype).reshape(*shape[:-1], self.outfeatures)
 
 
@@ -482,8 +483,11 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False, gate_up=Non
     assert x.dim() == 2
     if gate_up is not None:
         one = len(qls) == 1 and qls[0].V is not None and qls[0].U is not None and qls[0].qfn == 'b'
-        if not (one and ln is None and qls[0].V.bigp_ok and not qls[0].V.small_ok and rows <= ops.TILE_ROWS and x.dtype == torch.float16
-                and x.stride(0) == gate_up.stride(0) and gate_up.dtype == torch.float16):
+        in_kernel = (one and ln is None and qls[0].V.bigp_ok and not qls[0].V.small_ok and rows <= ops.TILE_ROWS and x.dtype == torch.float16
+                     and x.stride(0) == gate_up.stride(0) and gate_up.dtype == torch.float16)
+        in_blk = (one and ln is None and qls[0].V.blk_ok and rows <= ops.BLK_MAX_ROWS and x.dtype in ops._DT and gate_up.dtype == x.dtype
+                  and x.is_contiguous() and gate_up.is_contiguous())
+        if not (in_kernel or in_blk):
             x, gate_up = torch.nn.functional.silu(x) * gate_up, None
     same = len({(q.infeatures, q.outfeatures, q.bits) for q in qls}) == 1
     if not same or any(q.U is None or q.V is None or q.qfn != 'b' for q in qls) or rows > ops.OrthoOp.SMALL_ROWS:
@@ -514,8 +518,15 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False, gate_up=Non
             v_entries = [(q.V, q.V.small_op(x, xt, colscale=c, ln=lnp), False) for q, xt, c in zip(qls, xts, cs)]
         if not launchable(v_entries):
             v_entries = None
+    blk = lambda o, dt: o.blk_ok and rows <= ops.BLK_MAX_ROWS and dt in ops._DT
     if v_entries is not None:
         ops.ortho_apply_ops(v_entries, rows)
+    elif all(blk(q.V, x.dtype) for q in qls) and (ln is None or _ln_params(ln)[0].dtype == torch.float16):
+        # blocked butterfly (what --incoh_processing really yields): two launches per operator with the norm / silu * up / column scale of
+        # the block fused into the first (csrc/ortho_blk.hip)
+        xts = [q.V.apply_rows_blocked(x, colscale=q.inv_scaleWH, out_dtype=torch.bfloat16, ln=_ln_params(ln),
+                                      gate_up=None if gate_up is None else gate_up.contiguous()) for q in qls]
+        gate_up = None
     else:
         if gate_up is not None:
             x, gate_up = torch.nn.functional.silu(x) * gate_up, None
@@ -533,6 +544,8 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False, gate_up=Non
         if launchable(u_entries):
             ops.ortho_apply_ops(u_entries, rows)
             return outs
+    if all(blk(q.U, torch.float32) for q in qls):              # bias + residual + ReLU in the second launch of the blocked operator
+        return [q.U.apply_rows_blocked(y, transpose=True, out_dtype=x.dtype, bias=q.bias, residual=res, relu=relu) for q, y in zip(qls, ys)]
     outs = [q.U.apply_rows(y, transpose=True, out_dtype=x.dtype, bias=q.bias) for q, y in zip(qls, ys)]
     if res is not None:
         outs = [o + res for o in outs]
