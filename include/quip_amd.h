@@ -229,6 +229,9 @@ typedef struct quipamd_blk_op {
 } quipamd_blk_op;
 int quipamd_ortho_blocked_supported(int p, int q);
 int quipamd_ortho_blocked_rows(const quipamd_blk_op *op, void *workspace, void *stream);
+/* nops (1..3) operators of one shape / row count / dtypes / orientation in the SAME two launches (q / k / v, gate / up): `ops` a host array,
+ * workspace float [nops * rows * p * q]. */
+int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int nops, void *workspace, void *stream);
 
 /* One small-batch operator application with the elementwise work of its neighbours in the decoder block fused in
  * (a decode step is launch-latency bound):  out = [relu]( Q . ( colscale * [LayerNorm](x) ) + bias + residual ).

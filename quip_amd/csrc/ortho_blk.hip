@@ -69,9 +69,15 @@ __device__ __forceinline__ float bk_block_sum(float v, float *red)       // 4 wa
 
 typedef _Float16 bk_f16x8 __attribute__((ext_vector_type(8)));
 
+constexpr int BK_MAXOPS = 3;                                          // operators of one launch (q / k / v, gate / up): blockIdx.y
+struct BlkStages {
+    BlkStage s[BK_MAXOPS];
+};
+
 template <class IN, class OUT>
-__global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStage S)
+__global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
 {
+    const BlkStage &S = SS.s[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) char bk_smem[];
     const int P = S.mix_a ? S.p : S.q, q = S.q, n = S.p * S.q;
     const int PS = P + 8;                                              // LDS row stride (halves): 16-byte rows, banks staggered
@@ -189,11 +195,12 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStage S)
     }
 }
 
-template <class IN, class OUT> int launch_stage(const BlkStage &S, hipStream_t s)
+template <class IN, class OUT> int launch_stage(const BlkStages &SS, int nops, hipStream_t s)
 {
+    const BlkStage &S = SS.s[0];
     const int P = S.mix_a ? S.p : S.q, G = S.mix_a ? S.q : S.p;
     const size_t lds = (size_t)2 * BK_MAXR * (P + 8) * 2 + (4 * 256 + 4 + 2 * BK_MAXR) * 4 + 64;
-    blk_stage_kernel<IN, OUT><<<(unsigned)(G * (P / 16)), BK_T, lds, s>>>(S);
+    blk_stage_kernel<IN, OUT><<<dim3((unsigned)(G * (P / 16)), (unsigned)nops), BK_T, lds, s>>>(SS);
     return QUIPAMD_OK;
 }
 
@@ -204,44 +211,60 @@ extern "C" int quipamd_ortho_blocked_supported(int p, int q)
     return p >= 16 && q >= 16 && p % 16 == 0 && q % 16 == 0 && p <= 768 && q <= 768;
 }
 
-extern "C" int quipamd_ortho_blocked_rows(const quipamd_blk_op *op, void *workspace, void *stream)
+extern "C" int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int nops, void *workspace, void *stream)
 {
-    QA_REQUIRE(op, QUIPAMD_ERR_ARG, "ortho_blocked_rows: null op");
-    QA_REQUIRE(quipamd_ortho_blocked_supported(op->p, op->q), QUIPAMD_ERR_UNSUPPORTED, "ortho_blocked_rows: factors %d x %d (multiples of 16, <= 768)", op->p, op->q);
-    QA_REQUIRE(op->rows >= 0 && op->rows <= BK_MAXR, QUIPAMD_ERR_SHAPE, "ortho_blocked_rows: %lld rows > %d", (long long)op->rows, BK_MAXR);
-    if (op->rows == 0) return QUIPAMD_OK;
-    QA_REQUIRE(op->F_first && op->F_second && op->x && op->out && workspace, QUIPAMD_ERR_ARG, "ortho_blocked_rows: null pointer");
-    const int64_t n = (int64_t)op->p * op->q;
-    QA_REQUIRE(op->ld_x >= n && op->ld_out >= n, QUIPAMD_ERR_SHAPE, "ortho_blocked_rows: row strides");
-    QA_REQUIRE(op->norm >= 0 && op->norm <= 2 && (op->norm == 0 || op->ln_gamma) && (op->norm != 1 || op->ln_beta), QUIPAMD_ERR_ARG,
-               "ortho_blocked_rows: norm %d needs gamma (and beta for LayerNorm)", op->norm);
-    QA_REQUIRE(!op->residual || (op->ld_residual >= n && (op->residual_dtype == QUIPAMD_F32 || op->residual_dtype == QUIPAMD_F16 || op->residual_dtype == QUIPAMD_BF16)),
-               QUIPAMD_ERR_ARG, "ortho_blocked_rows: residual stride / dtype");
+    QA_REQUIRE(ops && nops >= 1 && nops <= BK_MAXOPS, QUIPAMD_ERR_ARG, "ortho_blocked_rows: 1..%d operators per launch", BK_MAXOPS);
+    const quipamd_blk_op &o0 = ops[0];
+    QA_REQUIRE(quipamd_ortho_blocked_supported(o0.p, o0.q), QUIPAMD_ERR_UNSUPPORTED, "ortho_blocked_rows: factors %d x %d (multiples of 16, <= 768)", o0.p, o0.q);
+    QA_REQUIRE(o0.rows >= 0 && o0.rows <= BK_MAXR, QUIPAMD_ERR_SHAPE, "ortho_blocked_rows: %lld rows > %d", (long long)o0.rows, BK_MAXR);
+    if (o0.rows == 0) return QUIPAMD_OK;
+    QA_REQUIRE(workspace, QUIPAMD_ERR_ARG, "ortho_blocked_rows: null workspace");
+    const int64_t n = (int64_t)o0.p * o0.q;
+    BlkStages A, B;
+    for (int k = 0; k < BK_MAXOPS; ++k) {
+        const quipamd_blk_op *op = &ops[k < nops ? k : 0];
+        QA_REQUIRE(op->p == o0.p && op->q == o0.q && op->rows == o0.rows && op->x_dtype == o0.x_dtype && op->out_dtype == o0.out_dtype &&
+                       op->first_mixes_a == o0.first_mixes_a, QUIPAMD_ERR_ARG, "ortho_blocked_rows: the operators of one launch share shape, rows, dtypes and orientation");
+        QA_REQUIRE(op->F_first && op->F_second && op->x && op->out, QUIPAMD_ERR_ARG, "ortho_blocked_rows: null pointer");
+        QA_REQUIRE(op->ld_x >= n && op->ld_out >= n, QUIPAMD_ERR_SHAPE, "ortho_blocked_rows: row strides");
+        QA_REQUIRE(op->norm >= 0 && op->norm <= 2 && (op->norm == 0 || op->ln_gamma) && (op->norm != 1 || op->ln_beta), QUIPAMD_ERR_ARG,
+                   "ortho_blocked_rows: norm %d needs gamma (and beta for LayerNorm)", op->norm);
+        QA_REQUIRE(!op->residual || (op->ld_residual >= n && (op->residual_dtype == QUIPAMD_F32 || op->residual_dtype == QUIPAMD_F16 || op->residual_dtype == QUIPAMD_BF16)),
+                   QUIPAMD_ERR_ARG, "ortho_blocked_rows: residual stride / dtype");
+        float *ws = (float *)workspace + (int64_t)(k < nops ? k : 0) * o0.rows * n;
+        BlkStage &a = A.s[k];
+        a.F = (const uint16_t *)op->F_first; a.mix_a = op->first_mixes_a; a.p = op->p; a.q = op->q;
+        a.in_idx = op->in_idx; a.out_idx = nullptr; a.in = op->x; a.ld_in = op->ld_x; a.out = ws; a.ld_out = n;
+        a.gate_up = op->gate_up; a.norm = op->norm; a.gamma = (const uint16_t *)op->ln_gamma; a.beta = (const uint16_t *)op->ln_beta; a.eps = op->ln_eps;
+        a.colscale = op->colscale; a.bias = nullptr; a.residual = nullptr; a.res_dtype = 0; a.ld_res = 0; a.relu = 0; a.rows = (int)op->rows;
+        BlkStage &b = B.s[k];
+        b = a;
+        b.F = (const uint16_t *)op->F_second; b.mix_a = !op->first_mixes_a; b.in_idx = nullptr; b.out_idx = op->out_idx; b.in = ws; b.ld_in = n;
+        b.out = op->out; b.ld_out = op->ld_out; b.gate_up = nullptr; b.norm = 0; b.colscale = nullptr;
+        b.bias = op->bias; b.residual = op->residual; b.res_dtype = op->residual_dtype; b.ld_res = op->ld_residual; b.relu = op->relu;
+    }
     hipStream_t s = (hipStream_t)stream;
-    BlkStage A;
-    A.F = (const uint16_t *)op->F_first; A.mix_a = op->first_mixes_a; A.p = op->p; A.q = op->q;
-    A.in_idx = op->in_idx; A.out_idx = nullptr; A.in = op->x; A.ld_in = op->ld_x; A.out = workspace; A.ld_out = n;
-    A.gate_up = op->gate_up; A.norm = op->norm; A.gamma = (const uint16_t *)op->ln_gamma; A.beta = (const uint16_t *)op->ln_beta; A.eps = op->ln_eps;
-    A.colscale = op->colscale; A.bias = nullptr; A.residual = nullptr; A.res_dtype = 0; A.ld_res = 0; A.relu = 0; A.rows = (int)op->rows;
-    BlkStage B = A;
-    B.F = (const uint16_t *)op->F_second; B.mix_a = !op->first_mixes_a; B.in_idx = nullptr; B.out_idx = op->out_idx; B.in = workspace; B.ld_in = n;
-    B.out = op->out; B.ld_out = op->ld_out; B.gate_up = nullptr; B.norm = 0; B.colscale = nullptr;
-    B.bias = op->bias; B.residual = op->residual; B.res_dtype = op->residual_dtype; B.ld_res = op->ld_residual; B.relu = op->relu;
     int rc;
-    switch (op->x_dtype) {
-    case QUIPAMD_F32: rc = launch_stage<F32, F32>(A, s); break;
-    case QUIPAMD_F16: rc = launch_stage<F16, F32>(A, s); break;
-    case QUIPAMD_BF16: rc = launch_stage<BF16, F32>(A, s); break;
-    default: return qa_fail(QUIPAMD_ERR_ARG, "ortho_blocked_rows: x dtype %d", op->x_dtype);
+    switch (o0.x_dtype) {
+    case QUIPAMD_F32: rc = launch_stage<F32, F32>(A, nops, s); break;
+    case QUIPAMD_F16: rc = launch_stage<F16, F32>(A, nops, s); break;
+    case QUIPAMD_BF16: rc = launch_stage<BF16, F32>(A, nops, s); break;
+    default: return qa_fail(QUIPAMD_ERR_ARG, "ortho_blocked_rows: x dtype %d", o0.x_dtype);
     }
     if (rc) return rc;
-    switch (op->out_dtype) {
-    case QUIPAMD_F32: rc = launch_stage<F32, F32>(B, s); break;
-    case QUIPAMD_F16: rc = launch_stage<F32, F16>(B, s); break;
-    case QUIPAMD_BF16: rc = launch_stage<F32, BF16>(B, s); break;
-    default: return qa_fail(QUIPAMD_ERR_ARG, "ortho_blocked_rows: out dtype %d", op->out_dtype);
+    switch (o0.out_dtype) {
+    case QUIPAMD_F32: rc = launch_stage<F32, F32>(B, nops, s); break;
+    case QUIPAMD_F16: rc = launch_stage<F32, F16>(B, nops, s); break;
+    case QUIPAMD_BF16: rc = launch_stage<F32, BF16>(B, nops, s); break;
+    default: return qa_fail(QUIPAMD_ERR_ARG, "ortho_blocked_rows: out dtype %d", o0.out_dtype);
     }
     if (rc) return rc;
     QA_LAUNCH_CHECK("quipamd_ortho_blocked_rows");
     return QUIPAMD_OK;
+}
+
+extern "C" int quipamd_ortho_blocked_rows(const quipamd_blk_op *op, void *workspace, void *stream)
+{
+    QA_REQUIRE(op, QUIPAMD_ERR_ARG, "ortho_blocked_rows: null op");
+    return quipamd_ortho_blocked_rows_multi(op, 1, workspace, stream);
 }

@@ -515,6 +515,22 @@ def decode_fused_gemm(*, V, colscale, qweight, scale, y, m, bs, x=None, U=None, 
     _lib.call("quipamd_decode_fused_gemm", ctypes.byref(a), _stream())
 
 
+def ortho_blocked_multi(entries, out_dtype):
+    """1..3 blocked operators of one shape in the SAME two launches (quipamd_ortho_blocked_rows_multi: q / k / v, gate / up).
+    entries = [(OrthoOp, x, kwargs of OrthoOp.blk_desc)]; returns the outputs [rows, n] in out_dtype."""
+    op0, x0, _ = entries[0]
+    rows, n = x0.shape
+    outs = [torch.empty((rows, n), dtype=out_dtype, device=x0.device) for _ in entries]
+    arr = (BlkOp * len(entries))()
+    keep = []
+    for i, ((op, x, kw), out) in enumerate(zip(entries, outs)):
+        arr[i], k = op.blk_desc(x, out, **kw)
+        keep.append(k)
+    ws = torch.empty(len(entries) * rows * n, dtype=torch.float32, device=x0.device)
+    _lib.call("quipamd_ortho_blocked_rows_multi", arr, len(entries), _p(ws), _stream())
+    return outs
+
+
 class BlkOp(ctypes.Structure):
     """mirror of `quipamd_blk_op` (include/quip_amd.h): the blocked butterfly on a handful of rows (csrc/ortho_blk.hip)"""
     _fields_ = [("F_first", ctypes.c_void_p), ("F_second", ctypes.c_void_p), ("first_mixes_a", ctypes.c_int), ("p", ctypes.c_int), ("q", ctypes.c_int),
@@ -666,14 +682,10 @@ class OrthoOp:
                 cache[key] = (h(self._B0), h(self._B1), 1)
         return cache[key]
 
-    def apply_rows_blocked(self, x, transpose=False, colscale=None, out_dtype=None, bias=None, ln=None, residual=None, relu=False, gate_up=None):
-        """out = [relu]( Q ( colscale * Norm( silu(x) * gate_up | x ) ) + bias + residual ) for <= 8 rows of a BLOCKED operator, two launches
-        (quipamd_ortho_blocked_rows; fp16 factors: the fused decode launches' tolerance class).  ln = (gamma, beta | None, eps) with fp16
-        gamma / beta; colscale / bias fp32 [n]; residual [rows, n] fp16 / bf16 / fp32; gate_up like x."""
-        _need_gpu(x)
+    def blk_desc(self, x, out, transpose=False, colscale=None, bias=None, ln=None, residual=None, relu=False, gate_up=None):
+        """(BlkOp record, tensors it points at) for apply_rows_blocked / ops.ortho_blocked_multi"""
         rows = x.shape[0]
         assert self.blk_ok and x.dim() == 2 and x.shape[1] == self.n and x.stride(1) == 1 and rows <= BLK_MAX_ROWS and x.dtype in _DT
-        out = torch.empty((rows, self.n), dtype=out_dtype or x.dtype, device=x.device)
         F1, F2, first_a = self.blk_factors(transpose)
         gather, scatter = (self.inv_pout, self.pin) if transpose else (self.pin, self.inv_pout)
         a = BlkOp()
@@ -694,9 +706,15 @@ class OrthoOp:
             assert residual.shape == (rows, self.n) and residual.stride(1) == 1 and residual.dtype in _DT
             a.residual, a.residual_dtype, a.ld_residual = residual.data_ptr(), _dtype(residual), residual.stride(0)
         a.relu = int(bool(relu))
-        ws = torch.empty(rows * self.n, dtype=torch.float32, device=x.device)
-        _lib.call("quipamd_ortho_blocked_rows", ctypes.byref(a), _p(ws), _stream())
-        return out
+        return a, (cs, bs_, F1, F2)
+
+    def apply_rows_blocked(self, x, transpose=False, colscale=None, out_dtype=None, bias=None, ln=None, residual=None, relu=False, gate_up=None):
+        """out = [relu]( Q ( colscale * Norm( silu(x) * gate_up | x ) ) + bias + residual ) for <= 8 rows of a BLOCKED operator, two launches
+        (quipamd_ortho_blocked_rows; fp16 factors: the fused decode launches' tolerance class).  ln = (gamma, beta | None, eps) with fp16
+        gamma / beta; colscale / bias fp32 [n]; residual [rows, n] fp16 / bf16 / fp32; gate_up like x."""
+        _need_gpu(x)
+        return ortho_blocked_multi([(self, x, dict(transpose=transpose, colscale=colscale, bias=bias, ln=ln, residual=residual, relu=relu,
+                                                   gate_up=gate_up))], out_dtype or x.dtype)[0]
 
     def store_inv(self, transpose):
         """image position -> output index: the inverse of the `store_idx` small_op() hands to the kernels"""

@@ -524,8 +524,10 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False, gate_up=Non
     elif all(blk(q.V, x.dtype) for q in qls) and (ln is None or _ln_params(ln)[0].dtype == torch.float16):
         # blocked butterfly (what --incoh_processing really yields): two launches per operator with the norm / silu * up / column scale of
         # the block fused into the first (csrc/ortho_blk.hip)
-        xts = [q.V.apply_rows_blocked(x, colscale=q.inv_scaleWH, out_dtype=torch.bfloat16, ln=_ln_params(ln),
-                                      gate_up=None if gate_up is None else gate_up.contiguous()) for q in qls]
+        lnp, gu = _ln_params(ln), (None if gate_up is None else gate_up.contiguous())
+        xts = []
+        for i in range(0, len(qls), 3):                         # up to three operators per launch pair (q / k / v, gate / up)
+            xts += ops.ortho_blocked_multi([(q.V, x, dict(colscale=q.inv_scaleWH, ln=lnp, gate_up=gu)) for q in qls[i:i + 3]], torch.bfloat16)
         gate_up = None
     else:
         if gate_up is not None:
@@ -545,7 +547,10 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False, gate_up=Non
             ops.ortho_apply_ops(u_entries, rows)
             return outs
     if all(blk(q.U, torch.float32) for q in qls):              # bias + residual + ReLU in the second launch of the blocked operator
-        return [q.U.apply_rows_blocked(y, transpose=True, out_dtype=x.dtype, bias=q.bias, residual=res, relu=relu) for q, y in zip(qls, ys)]
+        outs = []
+        for i in range(0, len(qls), 3):
+            outs += ops.ortho_blocked_multi([(q.U, y, dict(transpose=True, bias=q.bias, residual=res, relu=relu)) for q, y in zip(qls[i:i + 3], ys[i:i + 3])], x.dtype)
+        return outs
     outs = [q.U.apply_rows(y, transpose=True, out_dtype=x.dtype, bias=q.bias) for q, y in zip(qls, ys)]
     if res is not None:
         outs = [o + res for o in outs]

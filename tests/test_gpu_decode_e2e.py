@@ -130,8 +130,9 @@ def test_ldlq_pack_decode_matches_the_fake_quant_model_under_hf(arch, extra):
         got3 = torch.stack([eng.forward(t)[0].float().clone() for t in toks])
         if arch == "opt":
             assert torch.equal(got3, got)
-        else:       # Llama's down_proj K-slices meet through fp32 atomics: two runs agree to ~1e-5, not bit for bit (csrc/decode_bigp.hip)
-            assert float((got3 - got).norm() / got.norm()) <= 1e-4
+        else:       # Llama's down_proj K-slices meet through fp32 atomics (csrc/decode_bigp.hip): two runs of ONE launch agree to ~1e-5, and an
+            #         fp16 rounding downstream turns that into single-ulp flips: logits of two runs agree to ~1e-3 (measured), not bit for bit
+            assert float((got3 - got).norm() / got.norm()) <= 3e-3
         with pytest.raises(RuntimeError):
             next(iter(named.values()))(torch.zeros(1, next(iter(named.values())).infeatures, dtype=torch.float16, device=DEV))
     print(f"e2e {arch} pre_proj_extra={extra}:", report)
