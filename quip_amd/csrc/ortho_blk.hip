@@ -58,15 +58,6 @@ __device__ __forceinline__ float bk_wave_sum(float v)
     return v;
 }
 
-__device__ __forceinline__ float bk_block_sum(float v, float *red)       // 4 waves; `red` [4] is rewritten by the next call behind two barriers
-{
-    v = bk_wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
-
 typedef _Float16 bk_f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK_MAXOPS = 3;                                          // operators of one launch (q / k / v, gate / up): blockIdx.y
@@ -84,8 +75,8 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
     uint16_t *XH = reinterpret_cast<uint16_t *>(bk_smem);             // [BK_MAXR][PS] hi
     uint16_t *XL = XH + BK_MAXR * PS;                                 // [BK_MAXR][PS] lo
     float *part = reinterpret_cast<float *>(XL + BK_MAXR * PS);       // [4 waves][4][64]
-    float *red = part + 4 * 256;                                      // [4]
-    float *stat = red + 4;                                            // [BK_MAXR][2] mean, rstd
+    float *red = part + 4 * 256;                                      // [8]
+    float *stat = red + 8;                                            // [BK_MAXR][2] mean, rstd
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = P / 16;
     const int g = blockIdx.x / tiles, tile = blockIdx.x - g * tiles;
@@ -108,22 +99,30 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
 
     // ---- statistics of the rows (first stage with a norm): every workgroup reduces the whole row -- n <= 16384 values from L2 ---------
     if (S.norm) {
+        // ONE pass over the row: sums of (x - c) and (x - c)^2 with c = the row's first element (a shift removes the cancellation of
+        // E[x^2] - mean^2), both reduced behind the same pair of barriers
         for (int r = 0; r < R; ++r) {
-            float s1 = 0.f;
-            for (int e = tid; e < n; e += BK_T) s1 += DT<IN>::load(S.in, (int64_t)r * S.ld_in + e);
-            const float mean = S.norm == 1 ? bk_block_sum(s1, red) / (float)n : 0.f;
-            float s2 = 0.f;
+            const float c = S.norm == 1 ? DT<IN>::load(S.in, (int64_t)r * S.ld_in) : 0.f;
+            float s1 = 0.f, s2 = 0.f;
             for (int e = tid; e < n; e += BK_T) {
-                const float dv = DT<IN>::load(S.in, (int64_t)r * S.ld_in + e) - mean;
+                const float dv = DT<IN>::load(S.in, (int64_t)r * S.ld_in + e) - c;
+                s1 += dv;
                 s2 += dv * dv;
             }
-            const float var = bk_block_sum(s2, red) / (float)n;
-            if (tid == 0) {
-                stat[2 * r] = mean;
-                stat[2 * r + 1] = rsqrtf(var + S.eps);
+            s1 = bk_wave_sum(s1);
+            s2 = bk_wave_sum(s2);
+            if (lane == 0) {
+                red[wave] = s1;
+                red[4 + wave] = s2;
             }
+            __syncthreads();
+            if (tid == 0) {
+                const float m1 = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n, m2 = ((red[4] + red[5]) + (red[6] + red[7])) / (float)n;
+                stat[2 * r] = c + m1;
+                stat[2 * r + 1] = rsqrtf(fmaxf(m2 - m1 * m1, 0.f) + S.eps);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // ---- the group's input vector, rows r < R (rows R .. 7 are zeros: MFMA columns nobody stores) ---------------------------------------
@@ -199,7 +198,7 @@ template <class IN, class OUT> int launch_stage(const BlkStages &SS, int nops, h
 {
     const BlkStage &S = SS.s[0];
     const int P = S.mix_a ? S.p : S.q, G = S.mix_a ? S.q : S.p;
-    const size_t lds = (size_t)2 * BK_MAXR * (P + 8) * 2 + (4 * 256 + 4 + 2 * BK_MAXR) * 4 + 64;
+    const size_t lds = (size_t)2 * BK_MAXR * (P + 8) * 2 + (4 * 256 + 8 + 2 * BK_MAXR) * 4 + 64;
     blk_stage_kernel<IN, OUT><<<dim3((unsigned)(G * (P / 16)), (unsigned)nops), BK_T, lds, s>>>(SS);
     return QUIPAMD_OK;
 }

@@ -29,8 +29,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t opaque(uint32_t v) { asm("" : "+v"(v)); return v; }
 
 // ---- 1. layout check -------------------------------------------------------------------------------------------------------------
-// hypothesis: lane l holds row / column (l & 15) and the 32 consecutive k = 32 (l >> 4) .. + 31; fp4: nibble j of the lane's 128 bits =
-// k offset j (low nibble first); fp8: byte j of the lane's 256 bits = k offset j.  scale operand: byte `opsel` of the VGPR, E8M0.
+// layout (measured slot by slot with scripts/fp4layout.hip, profiles/r04e_fp4layout.txt -- the two formats differ):
+//   fp4 operand: lane l holds row (l & 15), nibble j of its 128 bits (low nibble first) = k 32 (l >> 4) + j          -- 32 consecutive k
+//   fp8 operand: lane l holds column (l & 15), byte j of its 256 bits = k 16 (l >> 4) + j for j < 16, 64 + 16 (l >> 4) + (j - 16) above
+//                (two K = 64 halves of 16 bytes each, like two v_mfma 16x16x64 operands back to back)
+// scale operand: byte `opsel` of the VGPR, E8M0 (127 = 1.0).
 __global__ void layout_kernel(const uint32_t *A4, const uint32_t *B8, float *D, int sa, int sb)
 {
     const int l = threadIdx.x;
@@ -166,7 +169,8 @@ int main()
                 int byte = next() & 0xff;
                 if ((byte & 0x7f) == 0x7f) byte &= 0xf7;                       // no NaN
                 B[l * 8 + j / 4] |= (uint32_t)byte << (8 * (j % 4));
-                Bf[(32 * (l >> 4) + j) * 16 + (l & 15)] = e4m3(byte);
+                const int kb = j < 16 ? 16 * (l >> 4) + j : 64 + 16 * (l >> 4) + (j - 16);   // fp8: two K = 64 halves of 16 bytes per lane group (fp4layout.hip)
+                Bf[kb * 16 + (l & 15)] = e4m3(byte);
             }
         }
         uint32_t *dA, *dB; float *dD;
@@ -185,7 +189,7 @@ int main()
                     worst = std::fmax(worst, std::fabs(r - D[i * 16 + j]));
                     norm = std::fmax(norm, std::fabs(r));
                 }
-            printf("layout check (A fp4 nibbles k = 32 (lane >> 4) + j, B fp8 bytes likewise, scale_b E8M0 %d): max |err| %.3g of max |ref| %.3g -> %s\n", sb, worst, norm,
+            printf("layout check (A fp4: k = 32 (lane >> 4) + nibble; B fp8: k = 16 (lane >> 4) + byte | 64 + ..; scale_b E8M0 %d): max |err| %.3g of max |ref| %.3g -> %s\n", sb, worst, norm,
                    worst <= 1e-3 * norm ? "MATCH" : "MISMATCH");
         }
     }
