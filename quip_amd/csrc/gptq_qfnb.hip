@@ -257,8 +257,10 @@ extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits,
     else if (g_gb_force_rows == 32 && fits(32, (const void *)gptqb_chain_kernel<32>)) R = 32;
     else if (g_gb_force_rows == 64 && fits(64, (const void *)gptqb_chain_kernel<64>)) R = 64;
     else if (g_gb_force_rows == 128 && fits(128, (const void *)gptqb_chain_kernel<128>)) R = 128;
-    else if (m <= 32 * 64 && fits(16, (const void *)gptqb_chain_kernel<16>)) R = 16;
-    else if (m <= 64 * 128 && fits(32, (const void *)gptqb_chain_kernel<32>)) R = 32;
+    // (round 4 A/B, profiles/r04d_gptq_qfnb_rows.jsonl: the per-column all-gather over G = m / R granules is the cost, and 64 rows per workgroup
+    //  beat 16 / 32 from 2048 rows on -- 2048^2 3.64 -> 3.08 us per column, 4096^2 4.16 -> 3.83, 8192 x 2048 4.86 -> 4.08, 2048 x 8192 4.02 -> 3.51)
+    else if (m < 1024 && fits(16, (const void *)gptqb_chain_kernel<16>)) R = 16;
+    else if (m < 2048 && fits(32, (const void *)gptqb_chain_kernel<32>)) R = 32;
     else if (m <= 128 * 128 && fits(64, (const void *)gptqb_chain_kernel<64>)) R = 64;
     else if (fits(128, (const void *)gptqb_chain_kernel<128>)) R = 128;
     QA_REQUIRE(R != 0, QUIPAMD_ERR_UNSUPPORTED, "gptq_round_qfnb: %lld rows do not fit this device as one grid of co-resident workgroups (%d CUs)",

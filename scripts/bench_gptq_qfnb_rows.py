@@ -18,7 +18,8 @@ for (m, d) in [(2048, 2048), (4096, 4096), (8192, 2048), (2048, 8192), (11008, 4
     H = X.T @ X / (d + 256) + 0.01 * torch.eye(d, device=dev)
     W = 0.02 * torch.randn(m, d, device=dev)
     FT = ops.gptq_feedback(H)
-    ref, _ = ops.gptq_round_qfnb(W.clone(), FT, 2)
+    ref, cs_ref = ops.gptq_round_qfnb(W.clone(), FT, 2)
+    step = 2.0 * cs_ref[None, :] / 3                                # grid step of every column (the criterion of tests/test_gpu_gptq_qfnb.py)
     row = {"shape": f"{m}x{d}"}
     for R in (0, 16, 32, 64, 128):
         ops.gptq_qfnb_debug(0, 0, R)
@@ -34,7 +35,7 @@ for (m, d) in [(2048, 2048), (4096, 4096), (8192, 2048), (2048, 8192), (11008, 4
                 ops.gptq_round_qfnb(W.clone(), FT, 2)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 2
-            row[f"R{R}"] = {"ms": round(dt * 1e3, 2), "us_per_column": round(dt * 1e6 / d, 2), "flipped_vs_default": float((q != ref).float().mean())}
+            row[f"R{R}"] = {"ms": round(dt * 1e3, 2), "us_per_column": round(dt * 1e6 / d, 2), "flipped_vs_default": float(((q - ref).abs() > 0.25 * step).float().mean())}
         finally:
             ops.gptq_qfnb_debug(0, 0, 0)
     print(json.dumps(row), flush=True)
