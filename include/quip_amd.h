@@ -321,7 +321,15 @@ int quipamd_dequant_gemm_vop(const quipamd_small_op *vops, const int32_t *const 
  * load_idx / store_idx with the meaning they have in quipamd_small_op, as uint16 [n] (an output-side operator needs store_idx only,
  * an activation-side one load_idx only: the other permutation lives in the packing).  One fp16 product per factor entry: ~3e-4 relative per
  * stage, below the 16-bit rounding of the pass's output (x~ feeds the fp16 MFMA, t is the fp16 residual stream).
- * Shapes: U and V must both be p x q in {64 x 32, 64 x 64, 128 x 64}, d = p q; 2-bit qfn-b STREAM codes; scale[i] float [1];
+ * NUMERICAL CONTRACT of the decode launches (this entry point, quipamd_decode_attention_fused, quipamd_decode_u_only, quipamd_decode_bigp_*,
+ * quipamd_decode_head, quipamd_ortho_blocked_rows): every y_i within 2e-3 and t within 1e-3 (relative l2) of the same chain evaluated in
+ * fp64 from the layer's own tensors (tests/test_gpu_decode_fused.py; measured 4e-4 .. 1.2e-3) -- NOT the 1e-3 of quipamd_dequant_gemm and
+ * quipamd_ortho_apply_*: the operator pass runs on fp16 factors and x~ is rounded to fp16 in front of the MFMA, like the fp16 model the
+ * reference decodes with.  End to end: logits within 1e-2 of the Hugging Face model holding the dense equivalents, greedy tokens equal
+ * (tests/test_gpu_decode_hf.py, test_gpu_decode_e2e.py: measured 2.5e-3 .. 8e-3).  A caller that needs the 1e-3 contract per layer uses
+ * QuantLinear.forward on more than 8 rows or the K3 entry points directly (split-bf16 / fp32 operator arithmetic).
+ * Shapes: U and V must both be p x q in {64 x 32, 64 x 64, 128 x 64}, d = p q; qfn-b STREAM codes, bits 2, or 4 / 3 (the 4-bit container;
+ * fp32 u_y is 2-bit only); scale[i] float [1];
  * colscale[i] float [d] (ones when the layer has no rescale); m % 32 == 0 (64 x 32) or m % 16 == 0; all 16-bit tensors fp16;
  * t_out must not alias u_residual (other workgroups still read it).  `args` is a HOST struct. */
 typedef struct quipamd_fop {
