@@ -119,7 +119,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
             if (tid == 0) {
                 const float m1 = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n, m2 = ((red[4] + red[5]) + (red[6] + red[7])) / (float)n;
                 stat[2 * r] = c + m1;
-                stat[2 * r + 1] = rsqrtf(fmaxf(m2 - m1 * m1, 0.f) + S.eps);
+                stat[2 * r + 1] = rsqrtf((S.norm == 1 ? fmaxf(m2 - m1 * m1, 0.f) : m2) + S.eps);      // RMSNorm: mean of x^2, nothing subtracted
             }
             __syncthreads();
         }
