@@ -28,6 +28,9 @@ DEVICE_RNG = False       # True: draw the Gaussians of the SO(p) sampler with to
                          # host RNG that bounds preproc (0.8 M / 3.8 M normals per n = 8192 / 11008 operator)
 
 
+SHARE_IDENTICAL_INPUTS = True   # Linears that are handed THE SAME input tensor (q / k / v of an attention block, gate / up of a gated MLP) accumulate
+                                # its X^T X once: the later ones count samples and take a copy of the first one's Hessian at post_batch
+                                # (bit-identical to accumulating it again -- same numbers, same kernel, same order -- at a third of the work)
 OPERATOR_PREFETCH = False  # True: sample the operators of the Linears whose QuantMethod objects already exist on a host thread (below)
 
 
@@ -291,6 +294,13 @@ def operator_prefetch_stop():
         _prefetcher = None
 
 
+_last_inputs = {}      # input signature -> (weakref to the method that accumulated it last, the tensor itself, that method's nsamples afterwards)
+
+
+def _input_signature(t):
+    return (str(t.device), int(t.data_ptr()), tuple(t.shape), tuple(t.stride()), t.dtype)
+
+
 class QuantMethod:
     """Base class for the rounding methods (method.py:80-233)."""
 
@@ -321,11 +331,13 @@ class QuantMethod:
         then modifies it per layer, method.py:139-176).  Call before the first add_batch."""
         assert leader is not self and self.nsamples == 0 and leader.columns == self.columns
         self._leader = leader
+        leader._followers = getattr(leader, "_followers", 0) + 1
         self.H = None
 
     def add_batch(self, inp, out):
         if DEBUG:
             self.inp1, self.out1 = inp, out
+        keep = inp                                 # (the tensor as it was handed in: what a sibling Linear would be handed too)
         if inp.dim() == 2:
             inp = inp.unsqueeze(0)
         n_calls = inp.shape[0]                     # nsamples counts hook calls' batch dim, not tokens
@@ -333,6 +345,32 @@ class QuantMethod:
             self.nsamples += n_calls
             return
         linear = isinstance(self.layer, (nn.Linear, transformers.Conv1D))
+        sig = None
+        if SHARE_IDENTICAL_INPUTS and type(self.layer) is nn.Linear and inp.dtype in (torch.float16, torch.bfloat16, torch.float32):
+            # The drivers hook every Linear of a block (opt.py:131-140) and HF hands q / k / v (gate / up) the very same tensor: its X^T X is
+            # identical, bit for bit, for all of them.  The method that sees a tensor FIRST accumulates it and keeps it alive until its own
+            # next sample (so the address cannot be handed to another tensor); a method whose every call so far found its input already
+            # accumulated by that same leader, sample for sample, never accumulates.  (Assumes nobody rewrites the shared input in place
+            # between the sibling Linears -- HF's OPT / Llama blocks do not; SHARE_IDENTICAL_INPUTS = False restores one X^T X per Linear.)
+            sig = _input_signature(keep)
+            ent = _last_inputs.get(sig)
+            lead = ent[0]() if ent is not None else None
+            auto = getattr(self, "_auto_leader", None)
+            if auto is not None:
+                if lead is auto and ent[2] == self.nsamples + n_calls:
+                    self.nsamples += n_calls
+                    return
+                raise RuntimeError("add_batch: this layer shared its input with another one so far (method.SHARE_IDENTICAL_INPUTS) and now "
+                                   "receives a different tensor; set quip_amd.method.SHARE_IDENTICAL_INPUTS = False for this model")
+            if (self.nsamples == 0 and getattr(self, "_followers", 0) == 0 and lead is not None and lead is not self
+                    and lead.columns == self.columns and ent[2] == n_calls
+                    and getattr(lead, "_auto_leader", None) is None and getattr(lead, "_leader", None) is None
+                    and lead.H is not None and lead.H.dtype == torch.float64 and type(lead.layer) is nn.Linear):
+                self._auto_leader = lead
+                lead._followers = getattr(lead, "_followers", 0) + 1
+                self.H = None
+                self.nsamples += n_calls
+                return
         if linear and inp.dim() == 3:
             inp = inp.reshape(-1, inp.shape[-1])
         if (linear and inp.is_cuda and inp.dim() == 2 and inp.dtype in ops._DT and self.H.dtype == torch.float64
@@ -340,6 +378,7 @@ class QuantMethod:
             self.nsamples += n_calls
             self._tri = True
             ops.hessian_accum(self.H, inp, fast=HESSIAN_FAST)   # raises if the HIP library is missing: no fallback on the GPU
+            self._remember_input(sig, keep)
             return
         if getattr(self, "_tri", False):
             raise RuntimeError("add_batch: Hessian accumulation started on the HIP path; cannot mix input kinds")
@@ -352,23 +391,48 @@ class QuantMethod:
         self.nsamples += n_calls
         inp = inp.to(torch.float64)
         self.H.addmm_(inp, inp.t())
+        self._remember_input(sig, keep)
+
+    def _remember_input(self, sig, tensor):
+        """this method accumulated `tensor` as its latest sample: siblings that are handed the same memory may skip theirs"""
+        import weakref
+        prev = getattr(self, "_last_sig", None)
+        if prev is not None and prev in _last_inputs and _last_inputs[prev][0]() is self:
+            del _last_inputs[prev]
+        self._last_sig = sig
+        if sig is not None:
+            _last_inputs[sig] = (weakref.ref(self), tensor, self.nsamples)
+
+    def _forget_input(self):
+        prev = getattr(self, "_last_sig", None)
+        if prev is not None and prev in _last_inputs and _last_inputs[prev][0]() is self:
+            del _last_inputs[prev]
+        self._last_sig = None
 
     def post_batch(self):
-        leader = getattr(self, "_leader", None)
+        self._forget_input()
+        leader = getattr(self, "_leader", None) or getattr(self, "_auto_leader", None)
         if leader is not None:
-            assert leader.nsamples == self.nsamples, "share_hessian_from: leader and follower saw different samples"
-            if leader.H.dtype == torch.float64:                 # leader not finished yet: finish a copy from its accumulator
+            assert leader.nsamples == self.nsamples, "shared Hessian: leader and follower saw different samples"
+            raw = getattr(leader, "_shared_raw", None)
+            if raw is not None:                                 # the leader is finished (and may have preprocessed its own copy since)
+                self.H = raw.clone()
+            else:                                               # leader not finished yet: finish a copy from its accumulator
+                assert leader.H is not None and leader.H.dtype == torch.float64, "shared Hessian: the leader's accumulator is gone"
                 self.H = (ops.hessian_finish(leader.H, leader.nsamples) if getattr(leader, "_tri", False)
                           else (leader.H / leader.nsamples).to(torch.float32))
-            else:
-                self.H = leader.H.clone()
-            self._leader = None
+            leader._followers = getattr(leader, "_followers", 1) - 1
+            if leader._followers <= 0:
+                leader._shared_raw = None
+            self._leader = self._auto_leader = None
             return
         if getattr(self, "_tri", False):
             self.H = ops.hessian_finish(self.H, self.nsamples)
             self._tri = False
-            return
-        self.H = (self.H / self.nsamples).to(torch.float32)
+        else:
+            self.H = (self.H / self.nsamples).to(torch.float32)
+        if getattr(self, "_followers", 0) > 0:                  # followers still to come: they copy THIS tensor (preproc / fasterquant never
+            self._shared_raw = self.H                           # write into it: they rebind self.H to new tensors)
 
     # ---- preprocessing (method.py:125-193) -------------------------------------------------------------
     def preproc(self, preproc_gptqH=False, percdamp=.01, preproc_rescale=False, preproc_proj=False,
@@ -482,6 +546,7 @@ class QuantMethod:
     def free(self):
         if DEBUG:
             self.inp1 = self.out1 = None
+        self._forget_input()
         self.H = None
         self.Losses = None
         self.Trace = None

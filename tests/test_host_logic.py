@@ -256,3 +256,66 @@ def test_operator_prefetcher_rewinds_when_its_guess_was_wrong():
     for (gu, gv), (wu, wv) in zip(got, want):
         assert _same_op(gu, wu) and _same_op(gv, wv)
     pf.shutdown()
+
+
+def test_identical_inputs_are_accumulated_once():
+    """method.SHARE_IDENTICAL_INPUTS: Linears that are handed the SAME tensor (q / k / v, gate / up -- the drivers hook each of them,
+    opt.py:131-140) accumulate its X^T X once; the others take a copy of that Hessian at post_batch -- bit-identical to accumulating it
+    again, whatever the order of the post_batch / preproc calls (opt.py finishes k and v before q; llama.py finishes all, then preprocesses)"""
+    from quip_amd import method as M
+    from quip_amd.method import QuantMethod
+    torch.manual_seed(1)
+    lq, lk, lv, lo = (torch.nn.Linear(24, 8) for _ in range(4))
+    X = [torch.randn(1, 10, 24) for _ in range(5)]
+    Y = [torch.randn(1, 10, 24) for _ in range(5)]          # out_proj's input: another tensor of the same shape
+
+    def run(share):
+        M.SHARE_IDENTICAL_INPUTS = share
+        try:
+            ms = [QuantMethod(l) for l in (lq, lk, lv, lo)]
+            calls = 0
+            orig = torch.Tensor.addmm_
+            def counting(self, *a, **k):
+                nonlocal calls
+                calls += 1
+                return orig(self, *a, **k)
+            torch.Tensor.addmm_ = counting
+            try:
+                for j in range(5):
+                    x = X[j].clone()                         # a fresh activation per sample, like a block forward produces
+                    for m in ms[:3]:
+                        m.add_batch(x.data, None)            # the drivers pass inp[0].data: a new tensor object over the same memory
+                    ms[3].add_batch(Y[j].clone().data, None)
+                    del x
+            finally:
+                torch.Tensor.addmm_ = orig
+            # opt.py's order: k, v finish (and are preprocessed) before q, the leader
+            ms[1].post_batch(); ms[1].preproc(preproc_gptqH=True)
+            ms[2].post_batch()
+            ms[0].post_batch(); ms[0].preproc(preproc_gptqH=True)
+            ms[3].post_batch()
+            return ms, calls
+        finally:
+            M.SHARE_IDENTICAL_INPUTS = True
+    shared, n_shared = run(True)
+    plain, n_plain = run(False)
+    assert n_plain == 20 and n_shared == 10                  # q (leader) and out_proj only
+    assert [m.nsamples for m in shared] == [5, 5, 5, 5]
+    for a, b in zip(shared, plain):
+        assert a.H.dtype == torch.float32 and torch.equal(a.H, b.H)
+    assert shared[2].H.data_ptr() != shared[0].H.data_ptr()
+    assert not M._last_inputs                                # nothing is kept alive past post_batch
+
+
+def test_a_shared_input_that_stops_being_shared_is_an_error_not_a_wrong_hessian():
+    import pytest
+    from quip_amd.method import QuantMethod
+    a, b = QuantMethod(torch.nn.Linear(16, 4)), QuantMethod(torch.nn.Linear(16, 4))
+    x = torch.randn(1, 6, 16)
+    a.add_batch(x, None)
+    b.add_batch(x, None)                                     # b now relies on a
+    y = torch.randn(1, 6, 16)
+    a.add_batch(x, None)
+    with pytest.raises(RuntimeError, match="SHARE_IDENTICAL_INPUTS"):
+        b.add_batch(y, None)
+    a.free(); b.free()
