@@ -33,7 +33,11 @@ def main():
     ap.add_argument("--prompt", type=int, default=64)
     ap.add_argument("--tokens", type=int, default=64)
     ap.add_argument("--mode", default="auto")
-    a = ap.parse_args()
+    print(json.dumps(run(ap.parse_args())))
+
+
+def run(a):
+    """a: namespace with arch, layers, bits, blocked, prompt, tokens, mode (bench.py builds one for its `decode_blocked` leg)"""
     dev, dtype = torch.device("cuda:0"), torch.float16
     torch.manual_seed(0)
     if a.arch == "opt":
@@ -77,7 +81,9 @@ def main():
            "engine_mode": eng.mode, "prompt": a.prompt, "tokens": a.tokens, "ms_per_token_median": med * 1e3, "tok_per_s": 1.0 / med,
            "packed_weight_MB": nbytes / 1e6, "operator_factor_MB_fp16": fact / 1e6,
            "hbm_bound_tok_per_s": 8e12 / (nbytes + head + fact), "frac_of_byte_bound": (1.0 / med) / (8e12 / (nbytes + head + fact))}
-    print(json.dumps(out))
+    del eng, model
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

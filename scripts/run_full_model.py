@@ -167,6 +167,17 @@ def main():
     ap.add_argument("--prefetch-operators", action="store_true", help="method.OPERATOR_PREFETCH: sample the next operators on a host thread")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
+    out = run(a)
+    line = json.dumps(out)
+    print(line)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as fh:
+            fh.write(line + "\n")
+
+
+def run(a):
+    """a: namespace with the fields of main()'s parser (bench.py builds one for its `quantise_model` leg)"""
     spec = dict(MODELS[a.model])
     if a.layers:
         spec["layers"] = a.layers
@@ -215,12 +226,12 @@ def main():
            "errors_finite": bool(np.all(np.isfinite(errs))), "error_sum": float(np.sum(errs)),
            "per_block_error_sum": [float(np.sum(errs[i:i + len(errs) // spec["layers"]])) for i in range(0, len(errs), len(errs) // spec["layers"])],
            "per_linear_first_block": ph.per_linear[:len(errs) // spec["layers"]], "per_linear_last_block": ph.per_linear[-(len(errs) // spec["layers"]):]}
-    line = json.dumps(out)
-    print(line)
-    if a.out:
-        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
-        with open(a.out, "w") as fh:
-            fh.write(line + "\n")
+    if a.prefetch_operators:
+        M.OPERATOR_PREFETCH = False
+    M.HESSIAN_FAST = M.DEVICE_RNG = False
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":
