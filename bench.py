@@ -640,9 +640,18 @@ def main():
                 # dependent steps of small mat-vecs, and 128 threads spend their time in the fork / join of each (profiles/r04b: 43.3 s
                 # for 2048^2 against 1.5 s on 8 cores) -- so the reference is timed at 8 threads, BASELINE.md section 2's setting, and
                 # a small default-thread probe records the ratio
-                pr = subprocess.run([sys.executable, script, "--sizes", "2048,4096", "--budget", "70", "--threads", "8"], capture_output=True, text=True, timeout=240)
+                pr = subprocess.run([sys.executable, script, "--sizes", "2048", "--budget", "40", "--threads", "8"], capture_output=True, text=True, timeout=240)
                 rows = [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")]
                 done = [r for r in rows if "fasterquant_time_attr_s" in r]
+                # 4096^2 costs ~12.5 x 2048^2 (d^2 m; measured 75 s vs 6 s on a slow box, 20 s vs 1.5 s on a fast one): run it only where the
+                # whole leg then stays under a minute, and say so otherwise
+                t2048 = sum(r["fasterquant_time_attr_s"] for r in done) if done else 1e9
+                if 12.5 * t2048 <= 45.0:
+                    pr = subprocess.run([sys.executable, script, "--sizes", "4096", "--budget", "30", "--threads", "8"], capture_output=True, text=True, timeout=240)
+                    rows += [json.loads(l) for l in pr.stdout.splitlines() if l.startswith("{")]
+                else:
+                    rows.append({"m": 4096, "d": 4096, "skipped": f"predicted {12.5 * t2048:.0f} s on this host (12.5 x the 2048^2 runs): over the leg's budget; "
+                                                                  "profiles/r04Y_bench.json has one such run (75 s for lazy_batch False)"})
                 probe = []
                 try:
                     for th in ("8", "0"):
@@ -658,7 +667,7 @@ def main():
                     "cores_note": "8 torch threads (BASELINE.md section 2's setting): the box's default, one thread per physical core, is far slower for "
                                   "this chain of small mat-vecs -- see thread_probe_1024 (8 threads vs the default)",
                     "runs": rows, "thread_probe_1024": probe,
-                    "sample": "2048^2 and 4096^2, lazy_batch False and True, each layer whole, once (a run is skipped when 70 s have passed)"}
+                    "sample": "2048^2 (and 4096^2 where the host is fast enough for the leg to stay under a minute), lazy_batch False and True, each layer whole, once"}
             else:
                 out["ldlq_cpu_reference"] = {"error": "oracle/_ref/cpu not staged (no reference checkout when build() ran)"}
         except Exception as ex:
