@@ -163,10 +163,20 @@ __device__ __forceinline__ uint32_t bg_gate2(uint32_t g2, uint32_t u2)
 }
 
 // grid = (p / 16 K-slices, m / (256 NRT) row groups); 1024 threads: wave w owns row tiles (16 blockIdx.y + w) NRT + k of the K-slice
-template <int BS, int NRT, bool GATE>
+// BITS 4: the 4-bit STREAM container (--wbits 4, and 3 with maxq = 7): the slice's 256 columns are TWO 1 KiB tiles per row tile, uniform-offset
+// conversion (value = 16 + code; no per-field offsets to subtract)
+template <bool ME> struct BgDq : DeqME2<ActF16> {};
+template <> struct BgDq<false> : DeqT<4, ActF16> {
+    struct Consts { };
+    static __device__ __forceinline__ Consts make_consts() { return Consts{}; }
+    static __device__ __forceinline__ u32x4 frag(const u32x4 &w, int t, const Consts &) { return DeqT<4, ActF16>::frag(w, t); }
+};
+
+template <int BS, int NRT, bool GATE, int BITS = 2>
 __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_over_maxq, float c0)
 {
-    typedef DeqME2<ActF16> DQ;                                                  // multi-exponent dequantisation (dq_common.h): needs sum OFF_k x~_k
+    typedef BgDq<BITS == 2> DQ;                                                 // 2 bits: multi-exponent dequantisation (dq_common.h): needs sum OFF_k x~_k
+    constexpr int TPS = BITS == 2 ? 1 : 2;                                       // 1 KiB tiles per (row tile, K-slice of 256 columns)
     constexpr int XTS = 256 + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint16_t *XT = reinterpret_cast<uint16_t *>(smem);                          // [4][256 + 8] f16: x~ of the slice, k = 16 a_local + b
@@ -208,12 +218,14 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
     }
     float4 m1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wave < BS) m1 = *reinterpret_cast<const float4 *>(G.M1 + j * 16 + 4 * g);
-    uint4 w[NRT];
+    uint4 w[NRT][TPS];
 #pragma unroll
-    for (int k = 0; k < NRT; ++k) {                                              // HBM, streamed once: nt; requested LAST (in-order vmcnt)
-        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(G.qw + ((uint64_t)(rt0 + k) * nch + at) * 64 + lane));
-        w[k] = make_uint4(t[0], t[1], t[2], t[3]);
-    }
+    for (int k = 0; k < NRT; ++k)                                                // HBM, streamed once: nt; requested LAST (in-order vmcnt)
+#pragma unroll
+        for (int h = 0; h < TPS; ++h) {
+            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(G.qw + ((uint64_t)(rt0 + k) * (nch * TPS) + at * TPS + h) * 64 + lane));
+            w[k][h] = make_uint4(t[0], t[1], t[2], t[3]);
+        }
     const float e_sc = G.scale[0];
     if (!two) fb[1] = make_uint4(0u, 0u, 0u, 0u);
 
@@ -247,7 +259,8 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
         const float4 rv = f16x4_to_f32(pk);                                      // the sums the epilogue subtracts are sums of what the MFMAs see
         const float s = fg_wave_sum((rv.x + rv.y) + (rv.z + rv.w));
         const int k0 = 16 * j + 4 * g;
-        const float so = fg_wave_sum(fmaf(me2_off_f16(k0), rv.x, fmaf(me2_off_f16(k0 + 1), rv.y, fmaf(me2_off_f16(k0 + 2), rv.z, me2_off_f16(k0 + 3) * rv.w))));
+        const float so = BITS == 2 ? fg_wave_sum(fmaf(me2_off_f16(k0), rv.x, fmaf(me2_off_f16(k0 + 1), rv.y, fmaf(me2_off_f16(k0 + 2), rv.z, me2_off_f16(k0 + 3) * rv.w))))
+                                   : 0.f;                                        // 4 bits: one offset for every field, folded into c0
         if (lane == 0) {
             red[r] = s;
             red[4 + r] = so;
@@ -260,16 +273,19 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
 #pragma unroll
     for (int k = 0; k < NRT; ++k) acc[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const uint16_t *xrow = XT + (j & (BG_MAXBS - 1)) * XTS + 8 * g;
-    uint4 xf[DQ::NT];
+    uint4 xf[8];                                                                // the slice's 256 k = 8 MFMA steps, whatever the container
 #pragma unroll
-    for (int t = 0; t < DQ::NT; ++t) xf[t] = *reinterpret_cast<const uint4 *>(xrow + 32 * t);
+    for (int t = 0; t < 8; ++t) xf[t] = *reinterpret_cast<const uint4 *>(xrow + 32 * t);
 #pragma unroll
     for (int k = 0; k < NRT; ++k)
 #pragma unroll
-        for (int t = 0; t < DQ::NT; ++t) {
-            const u32x4 a = DQ::frag(u32x4{w[k].x, w[k].y, w[k].z, w[k].w}, t, qc);
-            acc[k] = ActF16::mfma(a, u32x4{xf[t].x, xf[t].y, xf[t].z, xf[t].w}, acc[k]);
-        }
+        for (int h = 0; h < TPS; ++h)
+#pragma unroll
+            for (int t = 0; t < DQ::NT; ++t) {
+                const u32x4 a = DQ::frag(u32x4{w[k][h].x, w[k][h].y, w[k][h].z, w[k][h].w}, t, qc);
+                const uint4 &xv = xf[h * DQ::NT + t];
+                acc[k] = ActF16::mfma(a, u32x4{xv.x, xv.y, xv.z, xv.w}, acc[k]);
+            }
     // D[row = 4g + reg][col = j]: lanes j < BS park their 4 rows; the wave re-reads them as 16 NRT consecutive rows per batch row
     float *mine = park + wave * (NRT * 64);
     if (j < BS) {
@@ -344,7 +360,9 @@ extern "C" int quipamd_decode_bigp_v_gemm(const quipamd_bigp_v_gemm_args *a, voi
     QA_REQUIRE(a, QUIPAMD_ERR_ARG, "decode_bigp_v_gemm: null args");
     const int p = a->p;
     QA_REQUIRE(quipamd_decode_bigp_supported(p, 16), QUIPAMD_ERR_UNSUPPORTED, "decode_bigp_v_gemm: p = %d (wants p %% 16 == 0, 64 <= p <= %d)", p, 32 * BG_MAXKS);
-    QA_REQUIRE(a->bits == 2, QUIPAMD_ERR_UNSUPPORTED, "decode_bigp_v_gemm: 2-bit qfn-b codes");
+    QA_REQUIRE(a->bits >= 2 && a->bits <= 4, QUIPAMD_ERR_UNSUPPORTED, "decode_bigp_v_gemm: 2-, 3- or 4-bit qfn-b codes (bits = %d)", a->bits);
+    const bool w4 = a->bits != 2;                                                // 3-bit codes ride in the 4-bit container (maxq = 7)
+    const float maxq = (float)((1 << a->bits) - 1);
     QA_REQUIRE(a->rows >= 1 && a->rows <= BG_MAXBS, QUIPAMD_ERR_SHAPE, "decode_bigp_v_gemm: 1..%d rows", BG_MAXBS);
     QA_REQUIRE(a->F0 && a->M1 && a->gate && a->qweight && a->scale && a->y && a->ldx >= (int64_t)p * 16 && a->ldx % 8 == 0, QUIPAMD_ERR_ARG,
                "decode_bigp_v_gemm: fragments, M1, input, codes, scale, y wanted; ldx >= n, ldx %% 8 == 0");
@@ -354,12 +372,13 @@ extern "C" int quipamd_decode_bigp_v_gemm(const quipamd_bigp_v_gemm_args *a, voi
     QA_REQUIRE((nrt == 1 || nrt == 2 || nrt == 4) && a->m % (256 * nrt) == 0, QUIPAMD_ERR_ARG, "decode_bigp_v_gemm: row_tiles_per_wave 0 / 1 / 2 / 4 with m %% (256 x it) == 0");
     BVArgs A{(const uint4 *)a->F0, a->M1, (const uint16_t *)a->gate, (const uint16_t *)a->up, a->ldx, (const uint4 *)a->qweight, a->scale, a->y, a->m, p, (p + 31) / 32};
     const int nwp = (A.ks + 1) / 2, bs = (int)a->rows;
-    const float two_over_maxq = 2.0f / 3.0f, c0 = 1.5f;                            // maxq / 2: the per-field offsets are subtracted as sum OFF_k x~_k
+    // c0 = maxq / 2 (2 bits: the per-field offsets are subtracted as sum OFF_k x~_k; 4-bit container: + the uniform offset 16)
+    const float two_over_maxq = 2.0f / maxq, c0 = 0.5f * maxq + (w4 ? 16.0f : 0.0f);
     const dim3 grid((unsigned)(p / 16), (unsigned)(a->m / (256 * nrt)));
     hipStream_t s = (hipStream_t)stream;
 #define QA_BV(BS, NRT, GT)                                                                                                           \
     do {                                                                                                                             \
-        auto kern = bigp_v_gemm_kernel<BS, NRT, GT>;                                                                                 \
+        auto kern = w4 ? bigp_v_gemm_kernel<BS, NRT, GT, 4> : bigp_v_gemm_kernel<BS, NRT, GT, 2>;                                    \
         const size_t lds = (size_t)BG_MAXBS * 264 * 2 + 32 + (size_t)16 * NRT * 64 * 4 + (size_t)BS * nwp * 64 * sizeof(float4);     \
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_bigp_v_gemm: cannot raise dynamic LDS to %zu", lds);                          \

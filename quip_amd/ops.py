@@ -436,7 +436,7 @@ def decode_bigp_u(entries, rows, clear=None):
     _lib.call("quipamd_decode_bigp_u", arr, len(entries), U0.p, rows, _p(clear), 0 if clear is None else clear.numel(), _stream())
 
 
-def decode_bigp_v_gemm(V, gate, up, qweight_d, scale, y, row_tiles_per_wave=0):
+def decode_bigp_v_gemm(V, gate, up, qweight_d, scale, y, row_tiles_per_wave=0, bits=2):
     """y += What V(silu(gate) * up) for a 2-bit qfn-b layer whose activation-side operator V is p x 16 (quipamd_decode_bigp_v_gemm):
     gate / up fp16 [rows, n] as the transposed image of V's input (up None: the input is `gate` itself), qweight_d the codes with their
     columns in image order of V (QuantLinear.decode_qweight()), y fp32 [rows, m] ACCUMULATED with atomics (zero it first)."""
@@ -446,7 +446,7 @@ def decode_bigp_v_gemm(V, gate, up, qweight_d, scale, y, row_tiles_per_wave=0):
     assert up is None or (up.dtype == torch.float16 and up.shape == gate.shape and up.stride() == gate.stride())
     assert y.dtype == torch.float32 and y.is_contiguous() and scale.dtype == torch.float32 and scale.numel() == 1
     F0, M1 = V.bigp_frags(False)
-    a = BigpVGemmArgs(_p(F0), _p(M1), _p(gate), _p(up), gate.stride(0), _p(qweight_d), _p(scale), 2, _p(y), m, V.p, rows, int(row_tiles_per_wave))
+    a = BigpVGemmArgs(_p(F0), _p(M1), _p(gate), _p(up), gate.stride(0), _p(qweight_d), _p(scale), int(bits), _p(y), m, V.p, rows, int(row_tiles_per_wave))
     _lib.call("quipamd_decode_bigp_v_gemm", ctypes.byref(a), _stream())
 
 

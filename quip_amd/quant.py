@@ -679,7 +679,7 @@ def bigp_tail_ok(ups, down, rows):
     """can `fused_bigp_tail` run this MLP tail?  (csrc/decode_bigp.hip: 1..2 producers whose output-side operators are p x 16 with the
     shape of the consumer's activation-side operator, 2-bit qfn-b consumer with one scale, a handful of rows)"""
     V = down.V
-    return (1 <= len(ups) <= 2 and rows <= ops.BIGP_MAX_ROWS and V is not None and V.bigp_fold_ok and down.bits == 2 and down.qfn == 'b'
+    return (1 <= len(ups) <= 2 and rows <= ops.BIGP_MAX_ROWS and V is not None and V.bigp_fold_ok and down.bits in (2, 3, 4) and down.qfn == 'b'
             and down.scales.numel() == 1 and down.outfeatures % 256 == 0
             and all(q.U is not None and q.U.bigp_fold_ok and (q.U.p, q.U.q) == (V.p, V.q) for q in ups))
 
@@ -722,7 +722,7 @@ def fused_bigp_tail(ups, down, ys, row_tiles_per_wave=0):
     imgs = torch.empty((len(ups), rows, V.n), dtype=torch.float16, device=dev)
     yd = torch.empty((rows, down.outfeatures), dtype=torch.float32, device=dev)
     ops.decode_bigp_u([(q.U, y, bias_img, post, dest, imgs[i]) for i, (q, y, (dest, bias_img, post)) in enumerate(zip(ups, ys, tabs))], rows, clear=yd)
-    ops.decode_bigp_v_gemm(V, imgs[0], imgs[1] if len(ups) == 2 else None, down.decode_qweight(), down.scales, yd, row_tiles_per_wave)
+    ops.decode_bigp_v_gemm(V, imgs[0], imgs[1] if len(ups) == 2 else None, down.decode_qweight(), down.scales, yd, row_tiles_per_wave, bits=down.bits)
     return yd
 
 

@@ -62,9 +62,13 @@ def test_bigp_u_matches_the_dense_operator(ffn, rows, bias):
 @pytest.mark.parametrize("ffn,h,rows,gated,nrt", [(1280, 512, 1, True, 0), (1280, 256, 2, False, 1), (1792, 1024, 4, True, 4), (1792, 512, 3, True, 2),
                                                    (11008, 4096, 1, True, 0), (11008, 4096, 1, True, 2), (11008, 4096, 1, True, 1),
                                                    (11008, 4096, 4, True, 0), (11008, 4096, 2, False, 0)])
-def test_bigp_v_gemm_matches_the_chain_in_fp64(ffn, h, rows, gated, nrt):
+@pytest.mark.parametrize("bits", [2, 4, 3])
+def test_bigp_v_gemm_matches_the_chain_in_fp64(ffn, h, rows, gated, nrt, bits):
+    """bits 4 / 3 (round 4): the slice's 256 columns are two 1 KiB tiles of the 4-bit container per row tile"""
     from quip_amd import ops
-    down, What = _layer(ffn, h, 700 + ffn % 61 + rows, bias=False)
+    if bits == 3 and not (ffn == 1792 and rows == 4):
+        pytest.skip("3-bit codes ride in the 4-bit container: one shape covers the only difference (maxq = 7 in the epilogue)")
+    down, What = _layer(ffn, h, 700 + ffn % 61 + rows, bias=False, bits=bits)
     V = down.V
     torch.manual_seed(ffn + rows)
     g = torch.randn(rows, ffn, device=DEV).half()
@@ -77,14 +81,14 @@ def test_bigp_v_gemm_matches_the_chain_in_fp64(ffn, h, rows, gated, nrt):
         out[:, timg] = t
         return out
     y = torch.zeros(rows, h, device=DEV)
-    ops.decode_bigp_v_gemm(V, img(g), img(u) if gated else None, down.decode_qweight(), down.scales, y, nrt)
+    ops.decode_bigp_v_gemm(V, img(g), img(u) if gated else None, down.decode_qweight(), down.scales, y, nrt, bits=bits)
     t = (torch.nn.functional.silu(g.float()).half().float() * u.float()).half().double() if gated else g.double()
     want = (t @ _dense(V).t()) @ What.t()
     got = down.from_zt(y).double()                               # rows of the packed codes are in ZT order of down's U
     rel = float((got - want).norm() / want.norm())
     assert rel <= 3e-3, rel
     # accumulate contract: a second launch adds the same product again
-    ops.decode_bigp_v_gemm(V, img(g), img(u) if gated else None, down.decode_qweight(), down.scales, y, nrt)
+    ops.decode_bigp_v_gemm(V, img(g), img(u) if gated else None, down.decode_qweight(), down.scales, y, nrt, bits=bits)
     rel2 = float((down.from_zt(y).double() - 2 * want).norm() / (2 * want).norm())
     assert rel2 <= 3e-3, rel2
 

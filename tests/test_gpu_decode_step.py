@@ -34,6 +34,17 @@ def test_packed_w4_decode_step_runs_on_the_fused_launches():
     assert e_v3 is not None and e_v3 <= 1e-2, e_v3
 
 
+def test_llama_w4_decode_step_runs_on_the_fused_launches():
+    """round 4: the 11008-wide tail (csrc/decode_bigp.hip) takes the 4-bit container too: a --wbits 4 Llama decodes on the six launches per block"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "decode_llama.py")
+    spec = importlib.util.spec_from_file_location("decode_llama", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    e_plain, e_fused, e_v3 = mod.decode_check(layers=2, bits=4)
+    assert e_plain <= 1e-2 and e_fused <= 1e-2, (e_plain, e_fused)
+    assert e_v3 is not None and e_v3 <= 1e-2, e_v3
+
+
 def test_llama_decode_step_matches_its_dense_twin():
     """the Llama block (scripts/decode_llama.py: RMSNorm folded into the activation-side operator launch, one-launch rotary,
     gate / up grouped, 11008-wide operators on the general K3 path) against dense fp16 twins, 4 tokens, batch 2"""
