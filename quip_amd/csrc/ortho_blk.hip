@@ -69,6 +69,11 @@ template <class IN, class OUT>
 __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
 {
     const BlkStage &S = SS.s[blockIdx.y];
+    // every kernarg field the kernel reads, in ONE scalar round trip (hipcc fetches kernarg fields lazily, one s_load + s_waitcnt per first
+    // use: this 5 us launch would open with a dozen serial round trips -- DESIGN.md lessons, round 3)
+    asm volatile("" ::"s"(S.F), "s"(S.mix_a), "s"(S.p), "s"(S.q), "s"(S.in_idx), "s"(S.out_idx), "s"(S.in), "s"(S.ld_in), "s"(S.out), "s"(S.ld_out),
+                 "s"(S.gate_up), "s"(S.norm), "s"(S.gamma), "s"(S.beta), "s"(S.eps), "s"(S.colscale), "s"(S.bias), "s"(S.residual), "s"(S.res_dtype),
+                 "s"(S.ld_res), "s"(S.relu), "s"(S.rows));
     extern __shared__ __attribute__((aligned(16))) char bk_smem[];
     const int P = S.mix_a ? S.p : S.q, q = S.q, n = S.p * S.q;
     const int PS = P + 8;                                              // LDS row stride (halves): 16-byte rows, banks staggered
