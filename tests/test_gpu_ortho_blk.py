@@ -1,6 +1,6 @@
 """-m gpu: csrc/ortho_blk.hip -- the BLOCKED butterfly (method.py:34-35; what the reference's --incoh_processing really selects) on a handful of
 rows, with the decoder block's neighbouring elementwise work fused in -- against the same chain evaluated in fp64 from the operator's dense
-matrix (built with the general fp32 K3 launches, themselves pinned to the reference's mul_ortho_butterfly by tests/golden/butterfly.npz).
+matrix (built from the generator tuple with torch.einsum in float64: the reference's index form, no kernel of this repo).
 
 Gate: 1e-3 relative l2 per application (measured ~3e-4: fp16 factors; the activations travel as fp16 hi + lo), exact zeros where the
 operator's support says so is not claimed.  QuantLinear.forward / packed_forward_fused on blocked operators are covered end to end by
@@ -20,9 +20,7 @@ def _op(n, seed):
     return ops.OrthoOp(method.gen_rand_ortho_butterfly(n), DEV)
 
 
-def _dense(op):
-    eye = torch.eye(op.n, device=DEV, dtype=torch.float32)
-    return op.apply_rows(eye).double().t().contiguous()      # Q: apply_rows(e_r) = Q e_r = column r
+from test_gpu_decode_fused import _dense                   # the operator's dense fp64 matrix from its generator tuple (torch.einsum, no kernel of ours)
 
 
 @pytest.mark.parametrize("n", [768, 2048, 4096, 8192, 11008])
