@@ -102,6 +102,58 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         af[s] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
     }
 
+    // ---- everything else this workgroup will read from memory is requested NOW, before the statistics and the MFMAs: the launch is a chain
+    // of dependent round trips (index -> value; index -> bias / residual), and requested early they travel under each other --------------
+    // (a) the group's input vector: element e = r P + k of the R real rows; the first NPF x 256 of them are prefetched (all of them up to
+    //     R P = 768), with the operands of what precedes the operator (null pointers read a dummy address: a branch around a load is a
+    //     round trip of its own)
+    constexpr int NPF = 3;
+    const int RP = R * P;
+    const bool has_gu = S.gate_up != nullptr, has_cs = S.colscale != nullptr;
+    const void *gup = has_gu ? S.gate_up : S.in;
+    const uint16_t *gmp = S.norm ? S.gamma : S.F, *btp = S.norm == 1 ? S.beta : S.F;
+    const float *csp = has_cs ? S.colscale : reinterpret_cast<const float *>(S.F);
+    float pv[NPF], pu[NPF], pc[NPF];
+    uint16_t pg[NPF], pb[NPF];
+#pragma unroll
+    for (int c = 0; c < NPF; ++c) {
+        const int e = tid + BK_T * c, ec = e < RP ? e : 0;
+        const int r = ec / P, k = ec - r * P;
+        const int pos = S.mix_a ? k * q + g : g * q + k;
+        const int src = S.in_idx ? S.in_idx[pos] : pos;
+        pv[c] = DT<IN>::load(S.in, (int64_t)r * S.ld_in + src);
+        pu[c] = DT<IN>::load(gup, (int64_t)r * S.ld_in + src);
+        pg[c] = gmp[S.norm ? src : 0];
+        pb[c] = btp[S.norm == 1 ? src : 0];
+        pc[c] = csp[has_cs ? src : 0];
+    }
+    // (b) wave 0 finishes the tile: where its four results per lane go, and the bias / residual that go with them
+    int tdst[4];
+    float tbias[4], tres[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        tdst[reg] = 0;
+        tbias[reg] = tres[reg] = 0.f;
+    }
+    if (wave == 0 && (lane & 15) < R) {
+        const int r = lane & 15;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int io = tile * 16 + 4 * g4 + reg;
+            const int pos = S.mix_a ? io * q + g : g * q + io;
+            tdst[reg] = S.out_idx ? S.out_idx[pos] : pos;
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            if (S.bias) tbias[reg] = S.bias[tdst[reg]];
+            if (S.residual) {
+                const int64_t ri = (int64_t)r * S.ld_res + tdst[reg];
+                tres[reg] = S.res_dtype == QUIPAMD_F32 ? ((const float *)S.residual)[ri]
+                            : S.res_dtype == QUIPAMD_F16 ? f16_bits_to_f32(((const uint16_t *)S.residual)[ri]) : bf16_bits_to_f32(((const uint16_t *)S.residual)[ri]);
+            }
+        }
+    }
+
     // ---- statistics of the rows (first stage with a norm): every workgroup reduces the whole row -- n <= 16384 values from L2 ---------
     if (S.norm) {
         // ONE pass over the row: sums of (x - c) and (x - c)^2 with c = the row's first element (a shift removes the cancellation of
@@ -130,30 +182,39 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         }
     }
 
-    // ---- the group's input vector, rows r < R (rows R .. 7 are zeros: MFMA columns nobody stores) ---------------------------------------
-    for (int e = tid; e < BK_MAXR * P; e += BK_T) {
-        const int r = e / P, k = e - r * P;
-        float v = 0.f;
-        if (r < R) {
-            const int pos = S.mix_a ? k * q + g : g * q + k;
-            const int src = S.in_idx ? S.in_idx[pos] : pos;
-            v = DT<IN>::load(S.in, (int64_t)r * S.ld_in + src);
-            if (S.gate_up) {
-                const float u = DT<IN>::load(S.gate_up, (int64_t)r * S.ld_in + src);
-                v = DT<IN>::rnd(v / (1.0f + __expf(-v))) * u;             // silu rounded to the activation dtype like torch's op, then the product
-                v = DT<IN>::rnd(v);
-            }
-            if (S.norm == 1) {                                           // torch LayerNorm: fp32 inside, one rounding to the model's dtype
-                v = DT<IN>::rnd((v - stat[2 * r]) * stat[2 * r + 1] * f16_bits_to_f32(S.gamma[src]) + f16_bits_to_f32(S.beta[src]));
-            } else if (S.norm == 2) {                                    // HF LlamaRMSNorm: (x rsqrt(..)).to(dtype), then weight * that
-                v = DT<IN>::rnd(DT<IN>::rnd(v * stat[2 * r + 1]) * f16_bits_to_f32(S.gamma[src]));
-            }
-            if (S.colscale) v *= S.colscale[src];
+    // ---- the group's input vector into LDS as fp16 hi + lo; rows R .. 7 are zeros (MFMA columns nobody stores) --------------------------
+    auto finish = [&](float v, float u, uint16_t gm, uint16_t bt, float cs, int r) {
+        if (has_gu) {
+            v = DT<IN>::rnd(v / (1.0f + __expf(-v))) * u;                 // silu rounded to the activation dtype like torch's op, then the product
+            v = DT<IN>::rnd(v);
         }
+        if (S.norm == 1) {                                               // torch LayerNorm: fp32 inside, one rounding to the model's dtype
+            v = DT<IN>::rnd((v - stat[2 * r]) * stat[2 * r + 1] * f16_bits_to_f32(gm) + f16_bits_to_f32(bt));
+        } else if (S.norm == 2) {                                        // HF LlamaRMSNorm: (x rsqrt(..)).to(dtype), then weight * that
+            v = DT<IN>::rnd(DT<IN>::rnd(v * stat[2 * r + 1]) * f16_bits_to_f32(gm));
+        }
+        if (has_cs) v *= cs;
+        return v;
+    };
+    auto put = [&](int e, float v) {
+        const int r = e / P, k = e - r * P;
         const uint16_t hi = f32_to_f16_bits(v);
         XH[r * PS + k] = hi;
         XL[r * PS + k] = f32_to_f16_bits(v - f16_bits_to_f32(hi));
+    };
+#pragma unroll
+    for (int c = 0; c < NPF; ++c) {
+        const int e = tid + BK_T * c;
+        if (e < RP) put(e, finish(pv[c], pu[c], pg[c], pb[c], pc[c], e / P));
     }
+    for (int e = tid + BK_T * NPF; e < RP; e += BK_T) {                  // (more than 768 real elements: 4+ rows of a wide operator)
+        const int r = e / P, k = e - r * P;
+        const int pos = S.mix_a ? k * q + g : g * q + k;
+        const int src = S.in_idx ? S.in_idx[pos] : pos;
+        put(e, finish(DT<IN>::load(S.in, (int64_t)r * S.ld_in + src), DT<IN>::load(gup, (int64_t)r * S.ld_in + src), gmp[S.norm ? src : 0],
+                      btp[S.norm == 1 ? src : 0], csp[has_cs ? src : 0], r));
+    }
+    for (int e = RP + tid; e < BK_MAXR * P; e += BK_T) put(e, 0.f);
     __syncthreads();
 
     // ---- this wave's k-steps: D[16 out rows][16 columns = batch rows] ------------------------------------------------------------------
@@ -177,23 +238,15 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
     pw[0] = acc[0]; pw[64] = acc[1]; pw[128] = acc[2]; pw[192] = acc[3];
     __syncthreads();
     if (wave == 0) {
-        // D: column = lane & 15 (batch row), row = 4 (lane >> 4) + reg
+        // D: column = lane & 15 (batch row), row = 4 (lane >> 4) + reg; destination, bias and residual were fetched at the top
         const int r = lane & 15;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             float v = (part[reg * 64 + lane] + part[256 + reg * 64 + lane]) + (part[512 + reg * 64 + lane] + part[768 + reg * 64 + lane]);
             if (r < R) {
-                const int io = tile * 16 + 4 * g4 + reg;
-                const int pos = S.mix_a ? io * q + g : g * q + io;
-                const int dst = S.out_idx ? S.out_idx[pos] : pos;
-                if (S.bias) v += S.bias[dst];
-                if (S.residual) {
-                    const int64_t ri = (int64_t)r * S.ld_res + dst;
-                    v += S.res_dtype == QUIPAMD_F32 ? ((const float *)S.residual)[ri]
-                         : S.res_dtype == QUIPAMD_F16 ? f16_bits_to_f32(((const uint16_t *)S.residual)[ri]) : bf16_bits_to_f32(((const uint16_t *)S.residual)[ri]);
-                }
+                v = (v + tbias[reg]) + tres[reg];
                 if (S.relu) v = fmaxf(v, 0.f);
-                DT<OUT>::store(S.out, (int64_t)r * S.ld_out + dst, v);
+                DT<OUT>::store(S.out, (int64_t)r * S.ld_out + tdst[reg], v);
             }
         }
     }
