@@ -417,6 +417,10 @@ class DecodeEngine:
         w = decoder.tok.weight
         if not w.is_cuda:
             raise RuntimeError("DecodeEngine needs the model on a GPU (there is no CPU path)")
+        if getattr(decoder, "arch", None) == "opt":       # learned positions: the table (offset 2) bounds the sequence
+            max_len = min(max_len, decoder.posemb.weight.shape[0] - 2)
+        elif getattr(decoder, "arch", None) == "llama":
+            max_len = min(max_len, decoder.cos.shape[0])
         self.dev, self.dtype, self.bs, self.max_len = w.device, w.dtype, bs, max_len
         self.mode = best_mode(decoder, bs, self.dtype) if mode == "auto" else mode
         set_mode(decoder, self.mode)
