@@ -268,6 +268,8 @@ class QuantLinear(nn.Module):
     def packed_state(self):
         """everything needed to rebuild the layer, as CPU tensors / plain Python (the packed checkpoint record):
         STREAM-layout codes, grid parameters, bias, 1/scaleWH and the generator tuples of U and V."""
+        if self.qweight.numel() == 0 and self.infeatures * self.outfeatures:
+            raise RuntimeError("QuantLinear.decode_only() dropped the natural-order codes this record is made of: save the packed checkpoint first")
         cpu = lambda t: None if t is None else t.detach().cpu()
         return {"infeatures": self.infeatures, "outfeatures": self.outfeatures, "bits": self.bits, "qfn": self.qfn,
                 "qweight": cpu(self.qweight), "scales": cpu(self.scales), "zeros": cpu(self.zeros), "bias": cpu(self.bias),
