@@ -232,6 +232,10 @@ int quipamd_ortho_blocked_rows(const quipamd_blk_op *op, void *workspace, void *
 /* nops (1..3) operators of one shape / row count / dtypes / orientation in the SAME two launches (q / k / v, gate / up): `ops` a host array,
  * workspace float [nops * rows * p * q]. */
 int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int nops, void *workspace, void *stream);
+/* Where rows * p * q * 4 bytes of input fit a workgroup's LDS (<= ~120 KiB: one row of any supported operator, four of n = 8192) the two
+ * stages run as ONE launch: the workgroups of the second stage compute the slice of the first stage they read in their prologue
+ * (csrc/ortho_blk.hip).  quipamd_ortho_blocked_config(0) forces the two-launch form (A/B runs, tests); (1) restores the default. */
+void quipamd_ortho_blocked_config(int fused);
 
 /* One small-batch operator application with the elementwise work of its neighbours in the decoder block fused in
  * (a decode step is launch-latency bound):  out = [relu]( Q . ( colscale * [LayerNorm](x) ) + bias + residual ).

@@ -28,6 +28,7 @@ constexpr int BK_T = 256, BK_MAXR = 8;
 
 struct BlkStage {
     const uint16_t *F;            // [G][P][P] fp16, (out index, in index)
+    const uint16_t *F1;           // FUSED launches: the factors of the OTHER stage ([G1][P1][P1]), whose slice the prologue computes
     int mix_a;                    // 1: groups are b (G = q), P = p, position (i, g) = i q + g;  0: groups are a (G = p), P = q, position g q + i
     int p, q;
     const int32_t *in_idx;        // gather: element at image position pos is in[in_idx[pos]] (null: in[pos])
@@ -65,13 +66,20 @@ struct BlkStages {
     BlkStage s[BK_MAXOPS];
 };
 
-template <class IN, class OUT>
+// FUSED: ONE launch per operator.  The workgroups are those of the SECOND stage; each computes, in its prologue, the slice of the first
+// stage its block reads -- for every input element k of the block one dot product of length P1 between a contiguous factor row and
+// entries of the (pre-processed) input row, which the workgroup holds whole in LDS as fp32:
+//     second stage mixes a (block b = g):   in2[a'] = sum_j F1[a'][g][j] x[a' q + j]            (first stage = mix b, F1 [p][q][q])
+//     second stage mixes b (block a = g):   in2[b'] = sum_j F1[b'][g][j] x[j q + b']            (first stage = mix a, F1 [q][p][p])
+// n MACs and n factor values per workgroup and row: the first stage's factors are read (q / 16) or (p / 16) times in total instead of once,
+// and the all-to-all between the stages -- a launch boundary plus a round trip through memory -- is gone.
+template <class IN, class OUT, bool FUSED = false>
 __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
 {
     const BlkStage &S = SS.s[blockIdx.y];
     // every kernarg field the kernel reads, in ONE scalar round trip (hipcc fetches kernarg fields lazily, one s_load + s_waitcnt per first
     // use: this 5 us launch would open with a dozen serial round trips -- DESIGN.md lessons, round 3)
-    asm volatile("" ::"s"(S.F), "s"(S.mix_a), "s"(S.p), "s"(S.q), "s"(S.in_idx), "s"(S.out_idx), "s"(S.in), "s"(S.ld_in), "s"(S.out), "s"(S.ld_out),
+    asm volatile("" ::"s"(S.F), "s"(S.F1), "s"(S.mix_a), "s"(S.p), "s"(S.q), "s"(S.in_idx), "s"(S.out_idx), "s"(S.in), "s"(S.ld_in), "s"(S.out), "s"(S.ld_out),
                  "s"(S.gate_up), "s"(S.norm), "s"(S.gamma), "s"(S.beta), "s"(S.eps), "s"(S.colscale), "s"(S.bias), "s"(S.residual), "s"(S.res_dtype),
                  "s"(S.ld_res), "s"(S.relu), "s"(S.rows));
     extern __shared__ __attribute__((aligned(16))) char bk_smem[];
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
     float pv[NPF], pu[NPF], pc[NPF];
     uint16_t pg[NPF], pb[NPF];
 #pragma unroll
-    for (int c = 0; c < NPF; ++c) {
+    for (int c = 0; c < (FUSED ? 0 : NPF); ++c) {
         const int e = tid + BK_T * c, ec = e < RP ? e : 0;
         const int r = ec / P, k = ec - r * P;
         const int pos = S.mix_a ? k * q + g : g * q + k;
@@ -202,12 +210,42 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         XH[r * PS + k] = hi;
         XL[r * PS + k] = f32_to_f16_bits(v - f16_bits_to_f32(hi));
     };
+    if constexpr (FUSED) {
+        float *XIN = stat + 2 * BK_MAXR;                                 // [R][n] fp32: the pre-processed input rows in image order
+#pragma unroll 4
+        for (int e = tid; e < R * n; e += BK_T) {
+            const int r = e / n, pos = e - r * n;
+            const int src = S.in_idx ? S.in_idx[pos] : pos;
+            XIN[e] = finish(DT<IN>::load(S.in, (int64_t)r * S.ld_in + src), DT<IN>::load(gup, (int64_t)r * S.ld_in + src), gmp[S.norm ? src : 0],
+                            btp[S.norm == 1 ? src : 0], csp[has_cs ? src : 0], r);
+        }
+        __syncthreads();
+        const int P1 = S.mix_a ? q : S.p, l16 = tid & 15;
+        for (int dd = tid >> 4; dd < RP; dd += BK_T / 16) {              // 16 lanes per dot product, 16 dot products per pass
+            const int r = dd / P, k = dd - r * P;
+            const uint16_t *frow = S.F1 + ((int64_t)k * P1 + g) * P1;
+            const float *xin = XIN + r * n;
+            float acc1 = 0.f;
+            for (int j = 2 * l16; j < P1; j += 32) {
+                const uint32_t f2 = *reinterpret_cast<const uint32_t *>(frow + j);
+                const int p0 = S.mix_a ? k * q + j : j * q + k;
+                const int p1 = S.mix_a ? p0 + 1 : p0 + q;
+                acc1 = fmaf(f16_bits_to_f32((uint16_t)(f2 & 0xffffu)), xin[p0], acc1);
+                acc1 = fmaf(f16_bits_to_f32((uint16_t)(f2 >> 16)), xin[p1], acc1);
+            }
+            acc1 += __shfl_xor(acc1, 8);
+            acc1 += __shfl_xor(acc1, 4);
+            acc1 += __shfl_xor(acc1, 2);
+            acc1 += __shfl_xor(acc1, 1);
+            if (l16 == 0) put(dd, acc1);
+        }
+    }
 #pragma unroll
-    for (int c = 0; c < NPF; ++c) {
+    for (int c = 0; c < (FUSED ? 0 : NPF); ++c) {
         const int e = tid + BK_T * c;
         if (e < RP) put(e, finish(pv[c], pu[c], pg[c], pb[c], pc[c], e / P));
     }
-    for (int e = tid + BK_T * NPF; e < RP; e += BK_T) {                  // (more than 768 real elements: 4+ rows of a wide operator)
+    for (int e = tid + BK_T * NPF; e < (FUSED ? 0 : RP); e += BK_T) {   // (more than 768 real elements: 4+ rows of a wide operator)
         const int r = e / P, k = e - r * P;
         const int pos = S.mix_a ? k * q + g : g * q + k;
         const int src = S.in_idx ? S.in_idx[pos] : pos;
@@ -252,14 +290,33 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
     }
 }
 
-template <class IN, class OUT> int launch_stage(const BlkStages &SS, int nops, hipStream_t s)
+size_t blk_lds(const BlkStage &S, bool fused)
+{
+    const int P = S.mix_a ? S.p : S.q;
+    return (size_t)2 * BK_MAXR * (P + 8) * 2 + (4 * 256 + 8 + 2 * BK_MAXR) * 4 + 64 + (fused ? (size_t)S.rows * S.p * S.q * 4 : 0);
+}
+
+template <class IN, class OUT, bool FUSED = false> int launch_stage(const BlkStages &SS, int nops, hipStream_t s)
 {
     const BlkStage &S = SS.s[0];
     const int P = S.mix_a ? S.p : S.q, G = S.mix_a ? S.q : S.p;
-    const size_t lds = (size_t)2 * BK_MAXR * (P + 8) * 2 + (4 * 256 + 8 + 2 * BK_MAXR) * 4 + 64;
-    blk_stage_kernel<IN, OUT><<<dim3((unsigned)(G * (P / 16)), (unsigned)nops), BK_T, lds, s>>>(SS);
+    const size_t lds = blk_lds(S, FUSED);
+    auto kern = blk_stage_kernel<IN, OUT, FUSED>;
+    if (lds > 64 * 1024) {
+        static QaPerDevice attr;
+        static size_t raised[64] = {};
+        const int dv = attr.dev();
+        if (dv < 0 || raised[dv] < lds) {
+            if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return qa_fail(QUIPAMD_ERR_LAUNCH, "ortho_blocked_rows: cannot raise dynamic LDS to %zu", lds);
+            if (dv >= 0) raised[dv] = lds;
+        }
+    }
+    kern<<<dim3((unsigned)(G * (P / 16)), (unsigned)nops), BK_T, lds, s>>>(SS);
     return QUIPAMD_OK;
 }
+
+int g_blk_fused = 1;      // quipamd_ortho_blocked_config: 0 = always two launches per operator (A/B, tests)
 
 }   // namespace
 
@@ -290,7 +347,7 @@ extern "C" int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int n
                    QUIPAMD_ERR_ARG, "ortho_blocked_rows: residual stride / dtype");
         float *ws = (float *)workspace + (int64_t)(k < nops ? k : 0) * o0.rows * n;
         BlkStage &a = A.s[k];
-        a.F = (const uint16_t *)op->F_first; a.mix_a = op->first_mixes_a; a.p = op->p; a.q = op->q;
+        a.F = (const uint16_t *)op->F_first; a.F1 = nullptr; a.mix_a = op->first_mixes_a; a.p = op->p; a.q = op->q;
         a.in_idx = op->in_idx; a.out_idx = nullptr; a.in = op->x; a.ld_in = op->ld_x; a.out = ws; a.ld_out = n;
         a.gate_up = op->gate_up; a.norm = op->norm; a.gamma = (const uint16_t *)op->ln_gamma; a.beta = (const uint16_t *)op->ln_beta; a.eps = op->ln_eps;
         a.colscale = op->colscale; a.bias = nullptr; a.residual = nullptr; a.res_dtype = 0; a.ld_res = 0; a.relu = 0; a.rows = (int)op->rows;
@@ -302,6 +359,28 @@ extern "C" int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int n
     }
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    // one launch per operator when the input rows fit a workgroup's LDS beside the stage's own buffers, for the dtype pairs a decode step uses
+    const bool pair_ok = (o0.x_dtype == QUIPAMD_F32) || (o0.x_dtype == QUIPAMD_F16 && o0.out_dtype != QUIPAMD_F32) ||
+                         (o0.x_dtype == QUIPAMD_BF16 && o0.out_dtype == QUIPAMD_BF16);
+    if (g_blk_fused && pair_ok && blk_lds(B.s[0], true) <= 150 * 1024) {
+        BlkStages Fz = B;
+        for (int k = 0; k < BK_MAXOPS; ++k) {
+            BlkStage &f = Fz.s[k];
+            const BlkStage &a = A.s[k];
+            f.F1 = a.F; f.in = a.in; f.ld_in = a.ld_in; f.in_idx = a.in_idx;
+            f.gate_up = a.gate_up; f.norm = a.norm; f.gamma = a.gamma; f.beta = a.beta; f.eps = a.eps; f.colscale = a.colscale;
+        }
+        if (o0.x_dtype == QUIPAMD_F32)
+            rc = o0.out_dtype == QUIPAMD_F16 ? launch_stage<F32, F16, true>(Fz, nops, s)
+                 : o0.out_dtype == QUIPAMD_BF16 ? launch_stage<F32, BF16, true>(Fz, nops, s) : launch_stage<F32, F32, true>(Fz, nops, s);
+        else if (o0.x_dtype == QUIPAMD_F16)
+            rc = o0.out_dtype == QUIPAMD_F16 ? launch_stage<F16, F16, true>(Fz, nops, s) : launch_stage<F16, BF16, true>(Fz, nops, s);
+        else
+            rc = launch_stage<BF16, BF16, true>(Fz, nops, s);
+        if (rc) return rc;
+        QA_LAUNCH_CHECK("quipamd_ortho_blocked_rows (fused)");
+        return QUIPAMD_OK;
+    }
     switch (o0.x_dtype) {
     case QUIPAMD_F32: rc = launch_stage<F32, F32>(A, nops, s); break;
     case QUIPAMD_F16: rc = launch_stage<F16, F32>(A, nops, s); break;
@@ -318,6 +397,11 @@ extern "C" int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int n
     if (rc) return rc;
     QA_LAUNCH_CHECK("quipamd_ortho_blocked_rows");
     return QUIPAMD_OK;
+}
+
+extern "C" void quipamd_ortho_blocked_config(int fused)
+{
+    g_blk_fused = fused != 0;
 }
 
 extern "C" int quipamd_ortho_blocked_rows(const quipamd_blk_op *op, void *workspace, void *stream)

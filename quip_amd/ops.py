@@ -531,6 +531,11 @@ def ortho_blocked_multi(entries, out_dtype):
     return outs
 
 
+def ortho_blocked_config(fused=True):
+    """csrc/ortho_blk.hip: one launch per operator (default, where the input rows fit LDS) or always two (A/B runs, tests)"""
+    _lib.load().quipamd_ortho_blocked_config(int(bool(fused)))
+
+
 class BlkOp(ctypes.Structure):
     """mirror of `quipamd_blk_op` (include/quip_amd.h): the blocked butterfly on a handful of rows (csrc/ortho_blk.hip)"""
     _fields_ = [("F_first", ctypes.c_void_p), ("F_second", ctypes.c_void_p), ("first_mixes_a", ctypes.c_int), ("p", ctypes.c_int), ("q", ctypes.c_int),

@@ -13,6 +13,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(params=["one launch per operator", "two launches"], autouse=True)
+def _launch_form(request):
+    """every test runs in both forms: the second stage's workgroups computing their slice of the first stage in the prologue (default where the
+    input rows fit LDS), and the two stage launches with the fp32 image in between"""
+    from quip_amd import ops
+    ops.ortho_blocked_config(request.param == "one launch per operator")
+    yield
+    ops.ortho_blocked_config(True)
+
+
 def _op(n, seed):
     from quip_amd import ops, method
     np.random.seed(seed)
