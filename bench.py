@@ -572,10 +572,26 @@ def main():
                                      "roofline": {"bound": "hbm", "what": "codes + fp16 operator factors + fp16 head once per token at 8 TB/s",
                                                   "achieved": round(eres["tok_per_s"], 1), "peak": round(eres["hbm_bound_tok_per_s"]), "unit": "tok/s",
                                                   "frac": round(eres["frac_of_byte_bound"], 4)},
-                                     "what": "operator / grouped GEMM / operator launches per packed layer group; the blocked operators on csrc/ortho_blk.hip (two "
-                                             "launches each, q / k / v in one pair); round 3 ran this model on the general K3 launches: 171 tok/s"}
+                                     "what": "operator / grouped GEMM / operator launches per packed layer group; the blocked operators on csrc/ortho_blk.hip (one "
+                                             "launch per operator at n = 2048, two at n = 8192; q / k / v share theirs); round 3 ran this model on the general K3 "
+                                             "launches: 171 tok/s"}
         except Exception as ex:
             out["decode_blocked"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        # several sequences side by side on the same launches (the prologue of every fused launch runs once per sequence, the weights stream once)
+        try:
+            torch.cuda.empty_cache()
+            ns = _types.SimpleNamespace(arch="opt", layers=0, bits=BITS, blocked=False, prompt=32, tokens=32, mode="auto", bs=1, blk_fused_n=-1)
+            built, rows = None, {}
+            for nb in (2, 4):
+                ns.bs = nb
+                r_, built = emod.run(ns, model=built, keep=True)
+                rows[f"bs{nb}"] = {"tok_per_s": round(r_["tok_per_s"], 1), "ms_per_step": round(r_["ms_per_step_median"], 3), "engine_mode": r_["engine_mode"]}
+            del built
+            torch.cuda.empty_cache()
+            out["decode_batch"] = {"metric": "OPT-1.3B w2 (Kronecker operators) decode, aggregate tok/s with 2 / 4 sequences per step (quip_amd.decode.DecodeEngine, "
+                                             "one hipGraph per step); batch 1 is the `decode` leg", **rows}
+        except Exception as ex:
+            out["decode_batch"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     # ---- a whole model through the reference's own driver (opt.py:29-190, staged copy) on quip_amd: OPT-1.3B, 24 blocks, 128 x 2048 tokens ----
     if rank == 0 and world == 1 and not args.no_ldlq:

@@ -232,10 +232,11 @@ int quipamd_ortho_blocked_rows(const quipamd_blk_op *op, void *workspace, void *
 /* nops (1..3) operators of one shape / row count / dtypes / orientation in the SAME two launches (q / k / v, gate / up): `ops` a host array,
  * workspace float [nops * rows * p * q]. */
 int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int nops, void *workspace, void *stream);
-/* Where rows * p * q * 4 bytes of input fit a workgroup's LDS (<= ~120 KiB: one row of any supported operator, four of n = 8192) the two
- * stages run as ONE launch: the workgroups of the second stage compute the slice of the first stage they read in their prologue
- * (csrc/ortho_blk.hip).  quipamd_ortho_blocked_config(0) forces the two-launch form (A/B runs, tests); (1) restores the default. */
-void quipamd_ortho_blocked_config(int fused);
+/* Up to n = p q = max_fused_n (default 2048; the rows, the permutation and the chunk partials must fit a workgroup's LDS, pointers and row
+ * strides 16-byte aligned) the two stages run as ONE launch: the workgroups of the second stage compute the slice of the first stage they
+ * read in their prologue (csrc/ortho_blk.hip).  Every workgroup then reads ~8-10 n bytes from L2, which from n = 4096 on costs more than
+ * the launch it saves (measured, profiles/r04k_decode_engine.jsonl).  quipamd_ortho_blocked_config(0) forces the two-launch form. */
+void quipamd_ortho_blocked_config(int max_fused_n);
 
 /* One small-batch operator application with the elementwise work of its neighbours in the decoder block fused in
  * (a decode step is launch-latency bound):  out = [relu]( Q . ( colscale * [LayerNorm](x) ) + bias + residual ).

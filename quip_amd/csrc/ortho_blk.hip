@@ -61,6 +61,28 @@ __device__ __forceinline__ float bk_wave_sum(float v)
 
 typedef _Float16 bk_f16x8 __attribute__((ext_vector_type(8)));
 
+// eight consecutive elements (16-byte aligned) as floats
+template <class T> __device__ __forceinline__ void bk_load8(const void *p, int64_t i, float (&v)[8]);
+template <> __device__ __forceinline__ void bk_load8<F32>(const void *p, int64_t i, float (&v)[8])
+{
+    const float4 a = *reinterpret_cast<const float4 *>((const float *)p + i), b = *reinterpret_cast<const float4 *>((const float *)p + i + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void bk_load8<F16>(const void *p, int64_t i, float (&v)[8])
+{
+    const uint4 a = *reinterpret_cast<const uint4 *>((const uint16_t *)p + i);
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = f16_bits_to_f32((uint16_t)(w[k >> 1] >> (16 * (k & 1))));
+}
+template <> __device__ __forceinline__ void bk_load8<BF16>(const void *p, int64_t i, float (&v)[8])
+{
+    const uint4 a = *reinterpret_cast<const uint4 *>((const uint16_t *)p + i);
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = bf16_bits_to_f32((uint16_t)(w[k >> 1] >> (16 * (k & 1))));
+}
+
 constexpr int BK_MAXOPS = 3;                                          // operators of one launch (q / k / v, gate / up): blockIdx.y
 struct BlkStages {
     BlkStage s[BK_MAXOPS];
@@ -163,7 +185,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
     }
 
     // ---- statistics of the rows (first stage with a norm): every workgroup reduces the whole row -- n <= 16384 values from L2 ---------
-    if (S.norm) {
+    if (!FUSED && S.norm) {
         // ONE pass over the row: sums of (x - c) and (x - c)^2 with c = the row's first element (a shift removes the cancellation of
         // E[x^2] - mean^2), both reduced behind the same pair of barriers
         for (int r = 0; r < R; ++r) {
@@ -211,33 +233,125 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         XL[r * PS + k] = f32_to_f16_bits(v - f16_bits_to_f32(hi));
     };
     if constexpr (FUSED) {
-        float *XIN = stat + 2 * BK_MAXR;                                 // [R][n] fp32: the pre-processed input rows in image order
-#pragma unroll 4
-        for (int e = tid; e < R * n; e += BK_T) {
-            const int r = e / n, pos = e - r * n;
-            const int src = S.in_idx ? S.in_idx[pos] : pos;
-            XIN[e] = finish(DT<IN>::load(S.in, (int64_t)r * S.ld_in + src), DT<IN>::load(gup, (int64_t)r * S.ld_in + src), gmp[S.norm ? src : 0],
-                            btp[S.norm == 1 ? src : 0], csp[has_cs ? src : 0], r);
+        // Everything the prologue reads from memory is a 16-byte load at an address that depends on nothing loaded before: the factor
+        // chunks, the input rows in their NATURAL order (the gather permutation is applied from LDS, where a dependent read costs 64 cycles
+        // instead of a round trip through L2), the permutation itself as 16-bit entries.  (The first form of this prologue gathered from
+        // memory -- index, then value, n / 256 times in sequence -- and walked its dot products 16 at a time: 14-55 us per launch.)
+        float *XIN = stat + 2 * BK_MAXR;                                 // [R][n] fp32: the pre-processed input rows, natural order
+        const int n8 = n >> 3;
+        float *PART = XIN + R * n;                                       // [R][n / 8]: partial dot products, one per factor chunk
+        uint16_t *IDX = reinterpret_cast<uint16_t *>(PART + R * n8);    // [n]: image position -> source column
+        const int P1 = S.mix_a ? q : S.p;                               // length of the first stage's dot products
+        const int C = P1 >> 3;                                           // 16-byte chunks per factor row; P C = n / 8 work items
+        constexpr int MAXI = 8;                                          // items per thread held in registers: n <= 16384
+        uint4 fi[MAXI];
+#pragma unroll
+        for (int c = 0; c < MAXI; ++c) {
+            const int w = tid + BK_T * c, wc = w < n8 ? w : 0;
+            const int k = wc / C, ch = wc - k * C;
+            fi[c] = *reinterpret_cast<const uint4 *>(S.F1 + ((int64_t)k * P1 + g) * P1 + 8 * ch);
+        }
+#pragma unroll 2
+        for (int e8 = tid; e8 < R * n8; e8 += BK_T) {
+            const int r = e8 / n8, c8 = e8 - r * n8;
+            float v[8], u[8];
+            bk_load8<IN>(S.in, (int64_t)r * S.ld_in + 8 * c8, v);
+            if (has_gu) {
+                bk_load8<IN>(gup, (int64_t)r * S.ld_in + 8 * c8, u);
+#pragma unroll
+                for (int i8 = 0; i8 < 8; ++i8) v[i8] = DT<IN>::rnd(DT<IN>::rnd(v[i8] / (1.0f + __expf(-v[i8]))) * u[i8]);
+            }
+            float4 *dst = reinterpret_cast<float4 *>(XIN + r * n + 8 * c8);
+            dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+            dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        if (S.in_idx) {
+#pragma unroll 2
+            for (int e4 = tid; e4 < (n >> 2); e4 += BK_T) {
+                const int4 ix = reinterpret_cast<const int4 *>(S.in_idx)[e4];
+                *reinterpret_cast<uint2 *>(IDX + 4 * e4) = make_uint2((uint32_t)ix.x | ((uint32_t)ix.y << 16), (uint32_t)ix.z | ((uint32_t)ix.w << 16));
+            }
         }
         __syncthreads();
-        const int P1 = S.mix_a ? q : S.p, l16 = tid & 15;
-        for (int dd = tid >> 4; dd < RP; dd += BK_T / 16) {              // 16 lanes per dot product, 16 dot products per pass
-            const int r = dd / P, k = dd - r * P;
-            const uint16_t *frow = S.F1 + ((int64_t)k * P1 + g) * P1;
-            const float *xin = XIN + r * n;
-            float acc1 = 0.f;
-            for (int j = 2 * l16; j < P1; j += 32) {
-                const uint32_t f2 = *reinterpret_cast<const uint32_t *>(frow + j);
-                const int p0 = S.mix_a ? k * q + j : j * q + k;
-                const int p1 = S.mix_a ? p0 + 1 : p0 + q;
-                acc1 = fmaf(f16_bits_to_f32((uint16_t)(f2 & 0xffffu)), xin[p0], acc1);
-                acc1 = fmaf(f16_bits_to_f32((uint16_t)(f2 >> 16)), xin[p1], acc1);
+        if (S.norm) {                                                    // the statistics from LDS: one pass, shifted like the two-launch form
+            for (int r = 0; r < R; ++r) {
+                const float c0 = S.norm == 1 ? XIN[r * n] : 0.f;
+                float s1 = 0.f, s2 = 0.f;
+                for (int e = tid; e < n; e += BK_T) {
+                    const float dv = XIN[r * n + e] - c0;
+                    s1 += dv;
+                    s2 += dv * dv;
+                }
+                s1 = bk_wave_sum(s1);
+                s2 = bk_wave_sum(s2);
+                if (lane == 0) {
+                    part[(r * 4 + wave) * 2] = s1;
+                    part[(r * 4 + wave) * 2 + 1] = s2;
+                }
             }
-            acc1 += __shfl_xor(acc1, 8);
-            acc1 += __shfl_xor(acc1, 4);
-            acc1 += __shfl_xor(acc1, 2);
-            acc1 += __shfl_xor(acc1, 1);
-            if (l16 == 0) put(dd, acc1);
+            __syncthreads();
+            if (tid < R) {
+                const float *pr = part + tid * 8;
+                const float c0 = S.norm == 1 ? XIN[tid * n] : 0.f;
+                const float m1 = ((pr[0] + pr[2]) + (pr[4] + pr[6])) / (float)n, m2 = ((pr[1] + pr[3]) + (pr[5] + pr[7])) / (float)n;
+                stat[2 * tid] = c0 + m1;
+                stat[2 * tid + 1] = rsqrtf((S.norm == 1 ? fmaxf(m2 - m1 * m1, 0.f) : m2) + S.eps);
+            }
+            __syncthreads();
+        }
+        if (S.norm || has_cs) {                                          // gains / column scale in place, per column chunk for all rows
+#pragma unroll 2
+            for (int c8 = tid; c8 < n8; c8 += BK_T) {
+                const uint4 gm4 = *reinterpret_cast<const uint4 *>(gmp + (S.norm ? 8 * c8 : 0));
+                const uint4 bt4 = *reinterpret_cast<const uint4 *>(btp + (S.norm == 1 ? 8 * c8 : 0));
+                const float4 csa = *reinterpret_cast<const float4 *>(csp + (has_cs ? 8 * c8 : 0)), csb = *reinterpret_cast<const float4 *>(csp + (has_cs ? 8 * c8 + 4 : 0));
+                const uint32_t gmw[4] = {gm4.x, gm4.y, gm4.z, gm4.w}, btw[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
+                const float csv[8] = {csa.x, csa.y, csa.z, csa.w, csb.x, csb.y, csb.z, csb.w};
+                for (int r = 0; r < R; ++r) {
+                    float *xr = XIN + r * n + 8 * c8;
+#pragma unroll
+                    for (int i8 = 0; i8 < 8; ++i8) {
+                        const uint16_t gm = (uint16_t)(gmw[i8 >> 1] >> (16 * (i8 & 1))), bt = (uint16_t)(btw[i8 >> 1] >> (16 * (i8 & 1)));
+                        float v = xr[i8];
+                        if (S.norm == 1) v = DT<IN>::rnd((v - stat[2 * r]) * stat[2 * r + 1] * f16_bits_to_f32(gm) + f16_bits_to_f32(bt));
+                        else if (S.norm == 2) v = DT<IN>::rnd(DT<IN>::rnd(v * stat[2 * r + 1]) * f16_bits_to_f32(gm));
+                        if (has_cs) v *= csv[i8];
+                        xr[i8] = v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // the work items: factor chunk (k, ch) against the 8 entries of the input it meets, for every row
+#pragma unroll
+        for (int c = 0; c < MAXI; ++c) {
+            const int w = tid + BK_T * c;
+            if (w < n8) {
+                const int k = w / C, ch = w - k * C;
+                const uint32_t fw[4] = {fi[c].x, fi[c].y, fi[c].z, fi[c].w};
+                int src[8];
+#pragma unroll
+                for (int i8 = 0; i8 < 8; ++i8) {
+                    const int j = 8 * ch + i8;
+                    const int pos = S.mix_a ? k * q + j : j * q + k;
+                    src[i8] = S.in_idx ? (int)IDX[pos] : pos;
+                }
+                for (int r = 0; r < R; ++r) {
+                    const float *xin = XIN + r * n;
+                    float a1 = 0.f;
+#pragma unroll
+                    for (int i8 = 0; i8 < 8; ++i8) a1 = fmaf(f16_bits_to_f32((uint16_t)(fw[i8 >> 1] >> (16 * (i8 & 1)))), xin[src[i8]], a1);
+                    PART[r * n8 + w] = a1;
+                }
+            }
+        }
+        __syncthreads();
+        for (int dd = tid; dd < RP; dd += BK_T) {                        // chunk partials in a fixed order: deterministic
+            const int r = dd / P, k = dd - r * P;
+            const float *pp = PART + r * n8 + k * C;
+            float a1 = 0.f;
+            for (int ch = 0; ch < C; ++ch) a1 += pp[ch];
+            put(dd, a1);
         }
     }
 #pragma unroll
@@ -293,7 +407,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
 size_t blk_lds(const BlkStage &S, bool fused)
 {
     const int P = S.mix_a ? S.p : S.q;
-    return (size_t)2 * BK_MAXR * (P + 8) * 2 + (4 * 256 + 8 + 2 * BK_MAXR) * 4 + 64 + (fused ? (size_t)S.rows * S.p * S.q * 4 : 0);
+    return (size_t)2 * BK_MAXR * (P + 8) * 2 + (4 * 256 + 8 + 2 * BK_MAXR) * 4 + 64 + (fused ? (size_t)S.p * S.q * 4 * S.rows + (size_t)(S.p * S.q / 8) * 4 * S.rows + (size_t)S.p * S.q * 2 + 64 : 0);
 }
 
 template <class IN, class OUT, bool FUSED = false> int launch_stage(const BlkStages &SS, int nops, hipStream_t s)
@@ -316,7 +430,11 @@ template <class IN, class OUT, bool FUSED = false> int launch_stage(const BlkSta
     return QUIPAMD_OK;
 }
 
-int g_blk_fused = 1;      // quipamd_ortho_blocked_config: 0 = always two launches per operator (A/B, tests)
+int g_blk_fused_n = 2048;   // quipamd_ortho_blocked_config: one launch per operator up to this n = p q (0: always two launches).  Every workgroup of the
+                           // single launch reads the whole input row, the permutation and n first-stage factors -- ~8-10 n bytes from L2, n / 16
+                           // workgroups per operator.  Measured inside a decode step (profiles/r04k_decode_engine.jsonl): n = 2048 6.0 us against
+                           // 2 x 5 (OPT-1.3B blocked 381 -> 427 tok/s); n = 4096 already slower than the pair (Llama-2-7B 198 -> 183 tok/s);
+                           // n = 8192 / 11008 10-18 / 55-73 us
 
 }   // namespace
 
@@ -362,7 +480,15 @@ extern "C" int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int n
     // one launch per operator when the input rows fit a workgroup's LDS beside the stage's own buffers, for the dtype pairs a decode step uses
     const bool pair_ok = (o0.x_dtype == QUIPAMD_F32) || (o0.x_dtype == QUIPAMD_F16 && o0.out_dtype != QUIPAMD_F32) ||
                          (o0.x_dtype == QUIPAMD_BF16 && o0.out_dtype == QUIPAMD_BF16);
-    if (g_blk_fused && pair_ok && blk_lds(B.s[0], true) <= 150 * 1024) {
+    bool vec_ok = n % 256 == 0 && n < 65536;                          // 16-byte loads of rows, permutation, gains; 16-bit permutation in LDS
+    const int esz = o0.x_dtype == QUIPAMD_F32 ? 4 : 2;
+    for (int k = 0; k < nops; ++k) {
+        const quipamd_blk_op &op = ops[k];
+        const uintptr_t bits = (uintptr_t)op.x | (uintptr_t)op.gate_up | (uintptr_t)op.in_idx | (uintptr_t)op.ln_gamma | (uintptr_t)op.ln_beta |
+                               (uintptr_t)op.colscale | (uintptr_t)op.F_first | (uintptr_t)((int64_t)op.ld_x * esz);
+        vec_ok = vec_ok && (bits & 15) == 0;
+    }
+    if (n <= g_blk_fused_n && vec_ok && pair_ok && blk_lds(B.s[0], true) <= 150 * 1024) {
         BlkStages Fz = B;
         for (int k = 0; k < BK_MAXOPS; ++k) {
             BlkStage &f = Fz.s[k];
@@ -399,9 +525,9 @@ extern "C" int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int n
     return QUIPAMD_OK;
 }
 
-extern "C" void quipamd_ortho_blocked_config(int fused)
+extern "C" void quipamd_ortho_blocked_config(int max_fused_n)
 {
-    g_blk_fused = fused != 0;
+    g_blk_fused_n = max_fused_n < 0 ? 0 : max_fused_n;
 }
 
 extern "C" int quipamd_ortho_blocked_rows(const quipamd_blk_op *op, void *workspace, void *stream)

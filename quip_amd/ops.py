@@ -531,9 +531,15 @@ def ortho_blocked_multi(entries, out_dtype):
     return outs
 
 
-def ortho_blocked_config(fused=True):
-    """csrc/ortho_blk.hip: one launch per operator (default, where the input rows fit LDS) or always two (A/B runs, tests)"""
-    _lib.load().quipamd_ortho_blocked_config(int(bool(fused)))
+BLK_FUSED_N = 2048                 # csrc/ortho_blk.hip's default: one launch per blocked operator up to this n = p q
+
+
+def ortho_blocked_config(max_fused_n=BLK_FUSED_N):
+    """csrc/ortho_blk.hip: one launch per operator for n = p q up to `max_fused_n` (where the input rows fit LDS), two stage launches beyond;
+    0 / False = always two, True = wherever it fits (A/B runs, tests)"""
+    if max_fused_n is True:
+        max_fused_n = 1 << 20
+    _lib.load().quipamd_ortho_blocked_config(int(max_fused_n))
 
 
 class BlkOp(ctypes.Structure):

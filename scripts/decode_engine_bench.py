@@ -33,11 +33,39 @@ def main():
     ap.add_argument("--prompt", type=int, default=64)
     ap.add_argument("--tokens", type=int, default=64)
     ap.add_argument("--mode", default="auto")
-    print(json.dumps(run(ap.parse_args())))
+    ap.add_argument("--bs", type=int, default=1, help="sequences decoded side by side (1..4 on the fused launches); tok/s is the aggregate")
+    ap.add_argument("--blk-fused-n", type=int, default=-1, help="csrc/ortho_blk.hip: one launch per blocked operator up to this n (0: never)")
+    ap.add_argument("--sweep", default="", help="'bs:fused_n,bs:fused_n,...' -- the model is built once, one JSON line per entry")
+    a = ap.parse_args()
+    if a.sweep:
+        model = None
+        for item in a.sweep.split(","):
+            b, f = item.split(":")
+            a.bs, a.blk_fused_n = int(b), int(f)
+            try:
+                res, model = run(a, model=model, keep=True)
+            except Exception as e:                                    # a batch size a mode does not take: say so, go on
+                res = {"bs": a.bs, "blk_fused_n": a.blk_fused_n, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                if model is None:
+                    raise
+            print(json.dumps(res), flush=True)
+        return
+    print(json.dumps(run(a)))
 
 
-def run(a):
+def run(a, model=None, keep=False):
     """a: namespace with arch, layers, bits, blocked, prompt, tokens, mode (bench.py builds one for its `decode_blocked` leg)"""
+    if model is None:
+        model = build(a)
+    out = measure(a, *model)
+    if keep:
+        return out, model
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+def build(a):
     dev, dtype = torch.device("cuda:0"), torch.float16
     torch.manual_seed(0)
     if a.arch == "opt":
@@ -64,9 +92,18 @@ def run(a):
                 method.gen_rand_ortho_butterfly_noblock = keep
         else:
             _, nbytes = D.pack_model(model, a.bits, dev, twin=False)
+    return model, nbytes, arch
+
+
+def measure(a, model, nbytes, arch):
+    dev = torch.device("cuda:0")
+    bs = getattr(a, "bs", 1)
+    if getattr(a, "blk_fused_n", -1) >= 0:
+        from quip_amd import ops
+        ops.ortho_blocked_config(a.blk_fused_n)
     maxlen = a.prompt + a.tokens + 8
-    eng = decode.DecodeEngine(model, bs=1, max_len=maxlen, mode=a.mode)
-    ids = torch.randint(0, 30000, (1, a.prompt + a.tokens), device=dev)
+    eng = decode.DecodeEngine(model, bs=bs, max_len=maxlen, mode=a.mode)
+    ids = torch.randint(0, 30000, (bs, a.prompt + a.tokens), device=dev)
     res = eng.benchmark(ids)
     lat = res["times"][a.prompt:]
     med = float(np.median(lat))
@@ -78,10 +115,11 @@ def run(a):
                 for op in (m.U, m.V):
                     fact += (op._B0.numel() + op._B1.numel()) * 2      # what a decode launch would read as fp16
     out = {"arch": arch, "layers": len(model.blocks), "bits": a.bits, "operators": "blocked butterfly (extra 0)" if a.blocked else "Kronecker (extra 1)",
-           "engine_mode": eng.mode, "prompt": a.prompt, "tokens": a.tokens, "ms_per_token_median": med * 1e3, "tok_per_s": 1.0 / med,
+           "engine_mode": eng.mode, "bs": bs, "blk_fused_n": getattr(a, "blk_fused_n", -1), "prompt": a.prompt, "tokens": a.tokens,
+           "ms_per_step_median": med * 1e3, "ms_per_token_median": med * 1e3 / bs, "tok_per_s": bs / med,
            "packed_weight_MB": nbytes / 1e6, "operator_factor_MB_fp16": fact / 1e6,
-           "hbm_bound_tok_per_s": 8e12 / (nbytes + head + fact), "frac_of_byte_bound": (1.0 / med) / (8e12 / (nbytes + head + fact))}
-    del eng, model
+           "hbm_bound_tok_per_s": bs * 8e12 / (nbytes + head + fact), "frac_of_byte_bound": (1.0 / med) / (8e12 / (nbytes + head + fact))}
+    del eng
     torch.cuda.empty_cache()
     return out
 

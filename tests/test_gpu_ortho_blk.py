@@ -15,12 +15,12 @@ DEV = "cuda:0"
 
 @pytest.fixture(params=["one launch per operator", "two launches"], autouse=True)
 def _launch_form(request):
-    """every test runs in both forms: the second stage's workgroups computing their slice of the first stage in the prologue (default where the
-    input rows fit LDS), and the two stage launches with the fp32 image in between"""
+    """every test runs in both forms: the second stage's workgroups computing their slice of the first stage in the prologue (default up to
+    n = 2048), and the two stage launches with the fp32 image in between"""
     from quip_amd import ops
-    ops.ortho_blocked_config(request.param == "one launch per operator")
+    ops.ortho_blocked_config(request.param == "one launch per operator")      # True: wherever the rows fit LDS, not only up to the default n
     yield
-    ops.ortho_blocked_config(True)
+    ops.ortho_blocked_config()
 
 
 def _op(n, seed):
