@@ -205,7 +205,7 @@ int quipamd_ortho_apply_small(const float *M0, const float *M1, const int32_t *l
  *   out_idx: int32 [n] or NULL, image position pos is written to out[out_idx[pos]] (Q: argsort(perm_out); Q^T: perm_in).
  *   x [rows, ld_x] of x_dtype; gate_up: same dtype / stride or NULL; norm: 0 none, 1 LayerNorm, 2 RMSNorm (HF's: x rsqrt(mean x^2 + eps)
  *   rounded to x_dtype, then gamma) with fp16 ln_gamma / ln_beta [n] in natural order; colscale / bias: float [n] or NULL;
- *   residual [rows, ld_residual] of residual_dtype or NULL; out [rows, ld_out] of out_dtype; rows <= 8;
+ *   residual [rows, ld_residual] of residual_dtype or NULL; out [rows, ld_out] of out_dtype; rows <= 64 (16 per workgroup, the groups side by side in the launch);
  *   workspace: float [rows * p * q].  p, q multiples of 16, <= 768 (quipamd_ortho_blocked_supported). */
 typedef struct quipamd_blk_op {
     const void *F_first, *F_second;

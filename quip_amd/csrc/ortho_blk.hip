@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int BK_T = 256, BK_MAXR = 8;
+constexpr int BK_T = 256, BK_MAXR = 16, BK_MAXROWS = 64;   // rows per workgroup (the MFMA's 16 columns); rows per call (blockIdx.z walks groups of 16)
 
 struct BlkStage {
     const uint16_t *F;            // [G][P][P] fp16, (out index, in index)
@@ -115,7 +115,8 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = P / 16;
     const int g = blockIdx.x / tiles, tile = blockIdx.x - g * tiles;
-    const int R = S.rows;
+    const int gr0 = blockIdx.z * BK_MAXR;                              // this workgroup's rows: gr0 .. gr0 + R - 1
+    const int R = S.rows - gr0 < BK_MAXR ? S.rows - gr0 : BK_MAXR;
 
     // ---- the factor fragments of this wave's k-steps: requested first (the only HBM traffic of the launch) -------------------------
     const int nk = (P + 31) / 32;                                     // k-steps of 32; the last one may be half (P % 32 == 16)
@@ -151,8 +152,8 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         const int r = ec / P, k = ec - r * P;
         const int pos = S.mix_a ? k * q + g : g * q + k;
         const int src = S.in_idx ? S.in_idx[pos] : pos;
-        pv[c] = DT<IN>::load(S.in, (int64_t)r * S.ld_in + src);
-        pu[c] = DT<IN>::load(gup, (int64_t)r * S.ld_in + src);
+        pv[c] = DT<IN>::load(S.in, (int64_t)(gr0 + r) * S.ld_in + src);
+        pu[c] = DT<IN>::load(gup, (int64_t)(gr0 + r) * S.ld_in + src);
         pg[c] = gmp[S.norm ? src : 0];
         pb[c] = btp[S.norm == 1 ? src : 0];
         pc[c] = csp[has_cs ? src : 0];
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         for (int reg = 0; reg < 4; ++reg) {
             if (S.bias) tbias[reg] = S.bias[tdst[reg]];
             if (S.residual) {
-                const int64_t ri = (int64_t)r * S.ld_res + tdst[reg];
+                const int64_t ri = (int64_t)(gr0 + r) * S.ld_res + tdst[reg];
                 tres[reg] = S.res_dtype == QUIPAMD_F32 ? ((const float *)S.residual)[ri]
                             : S.res_dtype == QUIPAMD_F16 ? f16_bits_to_f32(((const uint16_t *)S.residual)[ri]) : bf16_bits_to_f32(((const uint16_t *)S.residual)[ri]);
             }
@@ -189,10 +190,10 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         // ONE pass over the row: sums of (x - c) and (x - c)^2 with c = the row's first element (a shift removes the cancellation of
         // E[x^2] - mean^2), both reduced behind the same pair of barriers
         for (int r = 0; r < R; ++r) {
-            const float c = S.norm == 1 ? DT<IN>::load(S.in, (int64_t)r * S.ld_in) : 0.f;
+            const float c = S.norm == 1 ? DT<IN>::load(S.in, (int64_t)(gr0 + r) * S.ld_in) : 0.f;
             float s1 = 0.f, s2 = 0.f;
             for (int e = tid; e < n; e += BK_T) {
-                const float dv = DT<IN>::load(S.in, (int64_t)r * S.ld_in + e) - c;
+                const float dv = DT<IN>::load(S.in, (int64_t)(gr0 + r) * S.ld_in + e) - c;
                 s1 += dv;
                 s2 += dv * dv;
             }
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         }
     }
 
-    // ---- the group's input vector into LDS as fp16 hi + lo; rows R .. 7 are zeros (MFMA columns nobody stores) --------------------------
+    // ---- the group's input vector into LDS as fp16 hi + lo; rows R .. 15 are zeros (MFMA columns nobody stores) --------------------------
     auto finish = [&](float v, float u, uint16_t gm, uint16_t bt, float cs, int r) {
         if (has_gu) {
             v = DT<IN>::rnd(v / (1.0f + __expf(-v))) * u;                 // silu rounded to the activation dtype like torch's op, then the product
@@ -255,9 +256,9 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         for (int e8 = tid; e8 < R * n8; e8 += BK_T) {
             const int r = e8 / n8, c8 = e8 - r * n8;
             float v[8], u[8];
-            bk_load8<IN>(S.in, (int64_t)r * S.ld_in + 8 * c8, v);
+            bk_load8<IN>(S.in, (int64_t)(gr0 + r) * S.ld_in + 8 * c8, v);
             if (has_gu) {
-                bk_load8<IN>(gup, (int64_t)r * S.ld_in + 8 * c8, u);
+                bk_load8<IN>(gup, (int64_t)(gr0 + r) * S.ld_in + 8 * c8, u);
 #pragma unroll
                 for (int i8 = 0; i8 < 8; ++i8) v[i8] = DT<IN>::rnd(DT<IN>::rnd(v[i8] / (1.0f + __expf(-v[i8]))) * u[i8]);
             }
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         const int r = e / P, k = e - r * P;
         const int pos = S.mix_a ? k * q + g : g * q + k;
         const int src = S.in_idx ? S.in_idx[pos] : pos;
-        put(e, finish(DT<IN>::load(S.in, (int64_t)r * S.ld_in + src), DT<IN>::load(gup, (int64_t)r * S.ld_in + src), gmp[S.norm ? src : 0],
+        put(e, finish(DT<IN>::load(S.in, (int64_t)(gr0 + r) * S.ld_in + src), DT<IN>::load(gup, (int64_t)(gr0 + r) * S.ld_in + src), gmp[S.norm ? src : 0],
                       btp[S.norm == 1 ? src : 0], csp[has_cs ? src : 0], r));
     }
     for (int e = RP + tid; e < BK_MAXR * P; e += BK_T) put(e, 0.f);
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
             if (r < R) {
                 v = (v + tbias[reg]) + tres[reg];
                 if (S.relu) v = fmaxf(v, 0.f);
-                DT<OUT>::store(S.out, (int64_t)r * S.ld_out + tdst[reg], v);
+                DT<OUT>::store(S.out, (int64_t)(gr0 + r) * S.ld_out + tdst[reg], v);
             }
         }
     }
@@ -407,7 +408,8 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
 size_t blk_lds(const BlkStage &S, bool fused)
 {
     const int P = S.mix_a ? S.p : S.q;
-    return (size_t)2 * BK_MAXR * (P + 8) * 2 + (4 * 256 + 8 + 2 * BK_MAXR) * 4 + 64 + (fused ? (size_t)S.p * S.q * 4 * S.rows + (size_t)(S.p * S.q / 8) * 4 * S.rows + (size_t)S.p * S.q * 2 + 64 : 0);
+    const size_t rw = S.rows < BK_MAXR ? S.rows : BK_MAXR;           // rows a workgroup holds
+    return (size_t)2 * BK_MAXR * (P + 8) * 2 + (4 * 256 + 8 + 2 * BK_MAXR) * 4 + 64 + (fused ? (size_t)S.p * S.q * 4 * rw + (size_t)(S.p * S.q / 8) * 4 * rw + (size_t)S.p * S.q * 2 + 64 : 0);
 }
 
 template <class IN, class OUT, bool FUSED = false> int launch_stage(const BlkStages &SS, int nops, hipStream_t s)
@@ -426,7 +428,7 @@ template <class IN, class OUT, bool FUSED = false> int launch_stage(const BlkSta
             if (dv >= 0) raised[dv] = lds;
         }
     }
-    kern<<<dim3((unsigned)(G * (P / 16)), (unsigned)nops), BK_T, lds, s>>>(SS);
+    kern<<<dim3((unsigned)(G * (P / 16)), (unsigned)nops, (unsigned)((S.rows + BK_MAXR - 1) / BK_MAXR)), BK_T, lds, s>>>(SS);
     return QUIPAMD_OK;
 }
 
@@ -448,7 +450,7 @@ extern "C" int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int n
     QA_REQUIRE(ops && nops >= 1 && nops <= BK_MAXOPS, QUIPAMD_ERR_ARG, "ortho_blocked_rows: 1..%d operators per launch", BK_MAXOPS);
     const quipamd_blk_op &o0 = ops[0];
     QA_REQUIRE(quipamd_ortho_blocked_supported(o0.p, o0.q), QUIPAMD_ERR_UNSUPPORTED, "ortho_blocked_rows: factors %d x %d (multiples of 16, <= 768)", o0.p, o0.q);
-    QA_REQUIRE(o0.rows >= 0 && o0.rows <= BK_MAXR, QUIPAMD_ERR_SHAPE, "ortho_blocked_rows: %lld rows > %d", (long long)o0.rows, BK_MAXR);
+    QA_REQUIRE(o0.rows >= 0 && o0.rows <= BK_MAXROWS, QUIPAMD_ERR_SHAPE, "ortho_blocked_rows: %lld rows > %d", (long long)o0.rows, BK_MAXROWS);
     if (o0.rows == 0) return QUIPAMD_OK;
     QA_REQUIRE(workspace, QUIPAMD_ERR_ARG, "ortho_blocked_rows: null workspace");
     const int64_t n = (int64_t)o0.p * o0.q;

@@ -283,6 +283,9 @@ def ortho_small_ops(op_list, rows):
 
 
 TILE_ROWS = 8          # up to this many rows a Kronecker operator is cut into 16 x 16 output tiles, one workgroup each
+BIGP_ROWS = 64         # p x 16 operators (Llama's 11008 = 688 x 16) stay on csrc/ortho_bigp.hip -- one workgroup per (16 of p, row) -- up to this many
+                       # rows: the general two-launch kernel gives the 688-deep mix to 16 workgroups per 16 rows (~240 us per application;
+                       # profiles/r04l: a Llama-2-7B step went from 3.9 ms at 8 sequences to 27 ms at 16)
 USE_TILES = True
 
 
@@ -324,7 +327,7 @@ def ortho_apply_ops(entries, rows):
     a handful of rows (decode), one workgroup per row otherwise."""
     forms = {_tile_form(d) for _, d, _ in entries}
     if all(o.bigp_ok and not o.small_ok for o, _, _ in entries):
-        assert rows <= TILE_ROWS and len(forms) == 1 and None not in forms and not any(d.ln_gamma for _, d, _ in entries), \
+        assert rows <= BIGP_ROWS and len(forms) == 1 and None not in forms and not any(d.ln_gamma for _, d, _ in entries), \
             "p x 16 operators: a handful of rows, activation-side or output-side operand set, no normalisation"
         ortho_bigp_ops([d for _, d, _ in entries], [o.store_inv(t) for o, _, t in entries], rows)
         return
@@ -552,7 +555,7 @@ class BlkOp(ctypes.Structure):
                 ("ld_residual", ctypes.c_int64), ("relu", ctypes.c_int)]
 
 
-BLK_MAX_ROWS = 8
+BLK_MAX_ROWS = 64      # csrc/ortho_blk.hip: 16 rows per workgroup (the MFMA's columns), groups of 16 side by side in the same launch
 
 
 def _mfma_b_frags(M):
@@ -772,7 +775,7 @@ class OrthoOp:
             finally:
                 self.use_split = split
             return out
-        if self.bigp_ok and rows <= TILE_ROWS and x.stride(0) % 4 == 0 and x.dtype in (torch.float16, torch.float32) \
+        if self.bigp_ok and rows <= BIGP_ROWS and x.stride(0) % 4 == 0 and x.dtype in (torch.float16, torch.float32) \
                 and self.pin is not None and self.pout is not None:
             if x.dtype == torch.float16:            # activation-side operand set: (x f16, colscale); a bias is added afterwards
                 ones = cs if cs is not None else self.one_scale()

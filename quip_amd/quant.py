@@ -485,7 +485,7 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False, gate_up=Non
     assert x.dim() == 2
     if gate_up is not None:
         one = len(qls) == 1 and qls[0].V is not None and qls[0].U is not None and qls[0].qfn == 'b'
-        in_kernel = (one and ln is None and qls[0].V.bigp_ok and not qls[0].V.small_ok and rows <= ops.TILE_ROWS and x.dtype == torch.float16
+        in_kernel = (one and ln is None and qls[0].V.bigp_ok and not qls[0].V.small_ok and rows <= ops.BIGP_ROWS and x.dtype == torch.float16
                      and x.stride(0) == gate_up.stride(0) and gate_up.dtype == torch.float16)
         in_blk = (one and ln is None and qls[0].V.blk_ok and rows <= ops.BLK_MAX_ROWS and x.dtype in ops._DT and gate_up.dtype == x.dtype
                   and x.is_contiguous() and gate_up.is_contiguous())
@@ -501,7 +501,7 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False, gate_up=Non
     dev, m, d = x.device, qls[0].outfeatures, qls[0].infeatures
     x = x.contiguous()
     # launch 1
-    fast = lambda o, norm: o.small_ok or (o.bigp_ok and norm is None and rows <= ops.TILE_ROWS)
+    fast = lambda o, norm: o.small_ok or (o.bigp_ok and norm is None and rows <= ops.BIGP_ROWS)
 
     def launchable(entries):
         """a p x 16-only operator exists for the compiled operand sets of csrc/ortho_bigp.hip alone (ops._tile_form): any other
@@ -666,7 +666,7 @@ def packed_v_stage_gate(ql, gate, up, out_dtype=torch.bfloat16):
     (csrc/ortho_bigp.hip for the 688 x 16 operator; torch ops + the general K3 launch otherwise)"""
     rows = gate.shape[0]
     V = ql.V
-    if (V.bigp_ok and not V.small_ok and rows <= ops.TILE_ROWS and gate.dtype == torch.float16 and up.dtype == torch.float16
+    if (V.bigp_ok and not V.small_ok and rows <= ops.BIGP_ROWS and gate.dtype == torch.float16 and up.dtype == torch.float16
             and gate.stride(0) == up.stride(0)):
         xt = torch.empty((rows, ql.infeatures), dtype=out_dtype, device=gate.device)
         cs = ql.inv_scaleWH if ql.inv_scaleWH is not None else V.one_scale()

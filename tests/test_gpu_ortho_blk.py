@@ -34,7 +34,7 @@ from test_gpu_decode_fused import _dense                   # the operator's dens
 
 
 @pytest.mark.parametrize("n", [768, 2048, 4096, 8192, 11008])
-@pytest.mark.parametrize("rows", [1, 3, 8])
+@pytest.mark.parametrize("rows", [1, 3, 8, 16, 21, 64])          # 16 per workgroup; 21 = a full group + a ragged one; 64 = the limit
 def test_blocked_operator_small_rows(n, rows):
     op = _op(n, n + rows)
     assert op.blocked and op.blk_ok
@@ -58,12 +58,12 @@ def test_blocked_operator_small_rows(n, rows):
     assert torch.equal(a, op.apply_rows_blocked(x, out_dtype=torch.float32))
 
 
+@pytest.mark.parametrize("rows", [2, 19])
 @pytest.mark.parametrize("n,norm", [(2048, "ln"), (4096, "rms"), (2048, None)])
-def test_activation_side_with_the_norm_and_scale_in_front(n, norm):
+def test_activation_side_with_the_norm_and_scale_in_front(n, norm, rows):
     """x~ = V (Norm(x) (/) s) in bf16 -- what packed_forward_fused hands to the grouped GEMM"""
     op = _op(n, 5)
     Q = _dense(op)
-    rows = 2
     torch.manual_seed(n)
     x = (torch.randn(rows, n, device=DEV) * 2 + 0.3).half()
     g = (1 + 0.1 * torch.randn(n, device=DEV)).half()
@@ -83,8 +83,9 @@ def test_activation_side_with_the_norm_and_scale_in_front(n, norm):
     assert float((got.double() - want).norm() / want.norm()) <= 3e-3                        # bf16 output: 2^-9
 
 
-def test_output_side_with_bias_residual_relu_and_the_gated_input():
-    n, rows = 11008, 2
+@pytest.mark.parametrize("rows", [2, 18])
+def test_output_side_with_bias_residual_relu_and_the_gated_input(rows):
+    n = 11008
     op = _op(n, 9)
     Q = _dense(op)
     torch.manual_seed(1)
@@ -108,7 +109,7 @@ def test_blocked_rows_refuses_what_it_cannot_run():
     from quip_amd import _lib, ops
     op = _op(2048, 3)
     with pytest.raises(AssertionError):
-        op.apply_rows_blocked(torch.zeros(9, 2048, device=DEV))                  # more than 8 rows: the general launches' job
+        op.apply_rows_blocked(torch.zeros(65, 2048, device=DEV))                 # more than 64 rows: the general launches' job
     lib = _lib.load()
     assert lib.quipamd_ortho_blocked_supported(688, 16) == 1 and lib.quipamd_ortho_blocked_supported(43, 16) == 0
     a = ops.BlkOp()

@@ -121,7 +121,7 @@ def test_tiles_refuse_other_shapes():
 # ---- p x 16 operators with a large p (csrc/ortho_bigp.hip; Llama's 11008 = 688 x 16) ------------------------------------------------
 @pytest.mark.parametrize("n", [11008, 2048 * 3])                 # 688 x 16;  6144 = 2^11 * 3 -> 192 x 32?  (see the skip)
 @pytest.mark.parametrize("transpose", [False, True])
-@pytest.mark.parametrize("rows", [1, 4])
+@pytest.mark.parametrize("rows", [1, 4, 16, 40])           # up to ops.BIGP_ROWS: a batch of sequences in the decode engine
 def test_bigp_equals_the_general_two_launch_kernel(n, transpose, rows):
     from quip_amd import ops
     op = _op(n, seed=n % 97 + rows)
@@ -133,8 +133,8 @@ def test_bigp_equals_the_general_two_launch_kernel(n, transpose, rows):
     cs = (0.5 + torch.rand(n, generator=g)).to(DEV)
     bias = torch.randn(n, generator=g).to(DEV)
     res = torch.randn(rows, n, generator=g).to(DEV).half()
-    # reference: the general kernel (rows > TILE_ROWS is never sent to the p x 16 kernel: pad the batch)
-    pad = lambda t: torch.cat([t, torch.zeros(ops.TILE_ROWS + 1 - rows, n, dtype=t.dtype, device=DEV)], 0)
+    # reference: the general kernel (rows > BIGP_ROWS is never sent to the p x 16 kernel: pad the batch)
+    pad = lambda t: torch.cat([t, torch.zeros(ops.BIGP_ROWS + 1 - rows, n, dtype=t.dtype, device=DEV)], 0)
     ref_v = op.apply_rows(pad(x.half()), transpose=transpose, colscale=cs, out_dtype=torch.float32)[:rows]
     ref_u = op.apply_rows(pad(x), transpose=transpose, out_dtype=torch.float32, bias=bias)[:rows]
     got_v = op.apply_rows(x.half(), transpose=transpose, colscale=cs, out_dtype=torch.float32)
