@@ -235,8 +235,9 @@ int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int nops, void *
 /* Up to n = p q = max_fused_n (default 2048; the rows, the permutation and the chunk partials must fit a workgroup's LDS, pointers and row
  * strides 16-byte aligned) the two stages run as ONE launch: the workgroups of the second stage compute the slice of the first stage they
  * read in their prologue (csrc/ortho_blk.hip).  Every workgroup then reads ~8-10 n bytes from L2, which from n = 4096 on costs more than
- * the launch it saves (measured, profiles/r04k_decode_engine.jsonl).  quipamd_ortho_blocked_config(0) forces the two-launch form. */
-void quipamd_ortho_blocked_config(int max_fused_n);
+ * the launch it saves (measured, profiles/r04k_decode_engine.jsonl), and only up to max_fused_rows rows (default 4: the prologue's work
+ * grows with the rows, profiles/r04n).  quipamd_ortho_blocked_config(0, 0) forces the two-launch form. */
+void quipamd_ortho_blocked_config(int max_fused_n, int max_fused_rows);
 
 /* One small-batch operator application with the elementwise work of its neighbours in the decoder block fused in
  * (a decode step is launch-latency bound):  out = [relu]( Q . ( colscale * [LayerNorm](x) ) + bias + residual ).

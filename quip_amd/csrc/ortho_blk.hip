@@ -432,6 +432,7 @@ template <class IN, class OUT, bool FUSED = false> int launch_stage(const BlkSta
     return QUIPAMD_OK;
 }
 
+int g_blk_fused_rows = 4;   // ... and up to this many rows (see the dispatch below)
 int g_blk_fused_n = 2048;   // quipamd_ortho_blocked_config: one launch per operator up to this n = p q (0: always two launches).  Every workgroup of the
                            // single launch reads the whole input row, the permutation and n first-stage factors -- ~8-10 n bytes from L2, n / 16
                            // workgroups per operator.  Measured inside a decode step (profiles/r04k_decode_engine.jsonl): n = 2048 6.0 us against
@@ -490,7 +491,9 @@ extern "C" int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int n
                                (uintptr_t)op.colscale | (uintptr_t)op.F_first | (uintptr_t)((int64_t)op.ld_x * esz);
         vec_ok = vec_ok && (bits & 15) == 0;
     }
-    if (n <= g_blk_fused_n && vec_ok && pair_ok && blk_lds(B.s[0], true) <= 150 * 1024) {
+    // ... and only for a few rows: the prologue's work grows with the rows (profiles/r04n: blocked OPT-1.3B at 8 sequences 4.44 ms per step in this
+    // form, 4.70 ms at 16 sequences in the two-launch form; the forms tie at 4)
+    if (n <= g_blk_fused_n && o0.rows <= g_blk_fused_rows && vec_ok && pair_ok && blk_lds(B.s[0], true) <= 150 * 1024) {
         BlkStages Fz = B;
         for (int k = 0; k < BK_MAXOPS; ++k) {
             BlkStage &f = Fz.s[k];
@@ -527,9 +530,10 @@ extern "C" int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int n
     return QUIPAMD_OK;
 }
 
-extern "C" void quipamd_ortho_blocked_config(int max_fused_n)
+extern "C" void quipamd_ortho_blocked_config(int max_fused_n, int max_fused_rows)
 {
     g_blk_fused_n = max_fused_n < 0 ? 0 : max_fused_n;
+    g_blk_fused_rows = max_fused_rows < 0 ? 0 : max_fused_rows;
 }
 
 extern "C" int quipamd_ortho_blocked_rows(const quipamd_blk_op *op, void *workspace, void *stream)

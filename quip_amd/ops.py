@@ -537,12 +537,15 @@ def ortho_blocked_multi(entries, out_dtype):
 BLK_FUSED_N = 2048                 # csrc/ortho_blk.hip's default: one launch per blocked operator up to this n = p q
 
 
-def ortho_blocked_config(max_fused_n=BLK_FUSED_N):
-    """csrc/ortho_blk.hip: one launch per operator for n = p q up to `max_fused_n` (where the input rows fit LDS), two stage launches beyond;
-    0 / False = always two, True = wherever it fits (A/B runs, tests)"""
+BLK_FUSED_ROWS = 4                 # ... and up to this many rows
+
+
+def ortho_blocked_config(max_fused_n=BLK_FUSED_N, max_fused_rows=BLK_FUSED_ROWS):
+    """csrc/ortho_blk.hip: one launch per operator for n = p q up to `max_fused_n` and `max_fused_rows` rows (where the input rows fit LDS),
+    two stage launches beyond; 0 / False = always two, True = wherever it fits (A/B runs, tests)"""
     if max_fused_n is True:
-        max_fused_n = 1 << 20
-    _lib.load().quipamd_ortho_blocked_config(int(max_fused_n))
+        max_fused_n, max_fused_rows = 1 << 20, 64
+    _lib.load().quipamd_ortho_blocked_config(int(max_fused_n), int(max_fused_rows))
 
 
 class BlkOp(ctypes.Structure):

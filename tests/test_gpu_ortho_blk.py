@@ -16,7 +16,7 @@ DEV = "cuda:0"
 @pytest.fixture(params=["one launch per operator", "two launches"], autouse=True)
 def _launch_form(request):
     """every test runs in both forms: the second stage's workgroups computing their slice of the first stage in the prologue (default up to
-    n = 2048), and the two stage launches with the fp32 image in between"""
+    n = 2048 and 4 rows), and the two stage launches with the fp32 image in between"""
     from quip_amd import ops
     ops.ortho_blocked_config(request.param == "one launch per operator")      # True: wherever the rows fit LDS, not only up to the default n
     yield
