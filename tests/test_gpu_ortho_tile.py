@@ -121,7 +121,7 @@ def test_tiles_refuse_other_shapes():
 # ---- p x 16 operators with a large p (csrc/ortho_bigp.hip; Llama's 11008 = 688 x 16) ------------------------------------------------
 @pytest.mark.parametrize("n", [11008, 2048 * 3])                 # 688 x 16;  6144 = 2^11 * 3 -> 192 x 32?  (see the skip)
 @pytest.mark.parametrize("transpose", [False, True])
-@pytest.mark.parametrize("rows", [1, 4, 16, 40])           # up to ops.BIGP_ROWS: a batch of sequences in the decode engine
+@pytest.mark.parametrize("rows", [1, 4, 9, 16, 40])        # up to ops.BIGP_ROWS: a batch of sequences in the decode engine
 def test_bigp_equals_the_general_two_launch_kernel(n, transpose, rows):
     from quip_amd import ops
     op = _op(n, seed=n % 97 + rows)
