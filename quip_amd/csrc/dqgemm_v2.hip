@@ -55,8 +55,12 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
         if (p1 == 0) {
             // one workgroup per CU and whole rounds: 7 row tiles per workgroup fit 1792 tiles (28672 rows) exactly, 8 fit 2048
             // (32768 rows: 18.0 us with 8 x 256 workgroups, 27 us with 293 workgroups of 7 -- profiles/r02l_k2lab_s.log)
-            const int64_t r7 = ((ntile + 6) / 7 + 255) / 256, r8 = ((ntile + 7) / 8 + 255) / 256;
-            if (r8 * 8 < r7 * 7) { p1 = 8; p2 = 1; } else { p1 = 7; p2 = 2; }
+            // and 4 fit 1024 (16384 rows: 13.1 us with 256 workgroups of 4, 15.0 with 147 of 7 -- profiles/r04q_k2_s_cfgs.jsonl).  Cost = rounds of
+            // 256 workgroups x tiles per workgroup; ties go to the larger workgroup (32768 rows: 8 x 256 18.8 us, 4 x 512 25.5)
+            const int64_t r4 = ((ntile + 3) / 4 + 255) / 256, r7 = ((ntile + 6) / 7 + 255) / 256, r8 = ((ntile + 7) / 8 + 255) / 256;
+            if (r4 * 4 < r7 * 7 && r4 * 4 < r8 * 8) { p1 = 4; p2 = 2; }
+            else if (r8 * 8 < r7 * 7) { p1 = 8; p2 = 1; }
+            else { p1 = 7; p2 = 2; }
         }
         if (p1 == 7 && p2 == 2) return launch_s<BITS, ACT, 7, 2, 1, 3>(A, s);
         if (p1 == 4 && p2 == 2) return launch_s<BITS, ACT, 4, 2, 1, 4>(A, s);
