@@ -213,7 +213,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         }
     }
 
-    // ---- the group's input vector into LDS as fp16 hi + lo; rows R .. 15 are zeros (MFMA columns nobody stores) --------------------------
+    // ---- the group's input vector into LDS as fp16 hi + lo; rows R .. 15 are whatever LDS held (MFMA columns nobody stores) --------------------------
     auto finish = [&](float v, float u, uint16_t gm, uint16_t bt, float cs, int r) {
         if (has_gu) {
             v = DT<IN>::rnd(v / (1.0f + __expf(-v))) * u;                 // silu rounded to the activation dtype like torch's op, then the product
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         put(e, finish(DT<IN>::load(S.in, (int64_t)(gr0 + r) * S.ld_in + src), DT<IN>::load(gup, (int64_t)(gr0 + r) * S.ld_in + src), gmp[S.norm ? src : 0],
                       btp[S.norm == 1 ? src : 0], csp[has_cs ? src : 0], r));
     }
-    for (int e = RP + tid; e < BK_MAXR * P; e += BK_T) put(e, 0.f);
+    // (rows R .. 15 of XH / XL stay as they are: MFMA column j depends on B[:, j] only, and columns >= R are never stored)
     __syncthreads();
 
     // ---- this wave's k-steps: D[16 out rows][16 columns = batch rows] ------------------------------------------------------------------
