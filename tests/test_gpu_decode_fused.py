@@ -226,6 +226,16 @@ def test_argmax_rows_is_torch_argmax(dtype):
     got = ops.argmax_rows(x)
     assert torch.equal(got, x.float().argmax(-1)) and int(got[1]) == 777 and int(got[2]) == 0
     assert ops.argmax_rows(x[:0]).numel() == 0
+    # rows that do not start on a 16-byte boundary, a length that is not a multiple of 8, the maximum in the ragged tail, -inf everywhere
+    y = torch.randn(2, 50283, device=DEV).to(dtype)
+    v = y[:, 3:50278]                                        # 50275 entries per row from an odd offset
+    v[0, 50274] = 60.0
+    v[1] = float("-inf")
+    got = ops.argmax_rows(v)
+    assert torch.equal(got, v.float().argmax(-1)) and int(got[0]) == 50274 and int(got[1]) == 0
+    w = torch.randn(2, 50280, device=DEV).to(dtype)[:, :50277]          # aligned rows, ragged tail
+    w[1, 50276] = 60.0
+    assert torch.equal(ops.argmax_rows(w), w.float().argmax(-1))
 
 
 @pytest.mark.parametrize("n,m_in,relu,residual,bs", [(2048, 8192, False, True, 1), (8192, 2048, True, False, 2), (4096, 4096, False, True, 3)])
