@@ -65,8 +65,56 @@ def parse():
     return ap.parse_args()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def respawn_if_needed(args, argv=None):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: start the N ranks ourselves -- the same command line the driver
+    uses, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` -- pass
+    rank 0's JSON line through, and leave with the launcher's exit code.  Returns None when this process IS a rank (or N == 1)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    sys.stderr.write("bench.py: no launcher environment, starting the ranks: " + " ".join(cmd) + "\n")
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_selftest(args):
+    """QUIP_BENCH_SELFTEST=1 (tests/test_bench_launcher.py; never set by the driver): the launch path alone, on CPU -- rendezvous on gloo,
+    the barrier + MAX-over-ranks timing reduction of `timed`, and rank 0's single line -- with every GPU leg left out.  The line says so."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher only: no GPU leg ran", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "max_over_ranks": float(t.item())}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    rc = respawn_if_needed(args)
+    if rc is not None:
+        sys.exit(rc)
+    if os.environ.get("QUIP_BENCH_SELFTEST") == "1":
+        return launcher_selftest(args)
     # The contract is ONE JSON line on stdout.  RCCL writes a version banner to stdout through C stdio whenever a communicator is created
     # (every rank of an N > 1 run; the one-rank group of the sharded_block leg), flushed at process exit, i.e. after python's line.  So
     # file descriptor 1 is pointed at stderr for the whole run and the JSON line goes out through a private copy of the real stdout.

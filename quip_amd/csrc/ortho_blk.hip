@@ -493,7 +493,8 @@ extern "C" int quipamd_ortho_blocked_rows_multi(const quipamd_blk_op *ops, int n
     }
     // ... and only for a few rows: the prologue's work grows with the rows (profiles/r04n: blocked OPT-1.3B at 8 sequences 4.44 ms per step in this
     // form, 4.70 ms at 16 sequences in the two-launch form; the forms tie at 4)
-    if (n <= g_blk_fused_n && o0.rows <= g_blk_fused_rows && vec_ok && pair_ok && blk_lds(B.s[0], true) <= 150 * 1024) {
+    // (n <= 16384: the fused prologue keeps its first-stage factor chunks in registers, 8 per thread x 256 threads x 8 values -- MAXI in the kernel)
+    if (n <= g_blk_fused_n && n <= 8 * 8 * BK_T && o0.rows <= g_blk_fused_rows && vec_ok && pair_ok && blk_lds(B.s[0], true) <= 150 * 1024) {
         BlkStages Fz = B;
         for (int k = 0; k < BK_MAXOPS; ++k) {
             BlkStage &f = Fz.s[k];

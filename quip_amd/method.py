@@ -191,6 +191,9 @@ class _OperatorPrefetcher:
             self.pending.append((key, rows, cols))
             if self.thread is None or not self.thread.is_alive():
                 self.stop = False
+                # a new thread's current device is cuda:0 whatever the creating thread selected: hand ours over (rank r of an N-GPU run
+                # must sample on GPU r, not pile its side stream onto GPU 0)
+                self.device = torch.cuda.current_device() if torch.cuda.is_available() else None
                 self.thread = threading.Thread(target=self._run, name="quip_amd-operator-prefetch", daemon=True)
                 self.thread.start()
             self.lock.notify_all()
@@ -244,6 +247,8 @@ class _OperatorPrefetcher:
 
     # -- the thread ------------------------------------------------------------------------------------------------------------------
     def _run(self):
+        if getattr(self, "device", None) is not None:
+            torch.cuda.set_device(self.device)
         side = torch.cuda.Stream() if torch.cuda.is_available() else None
         while True:
             with self.lock:

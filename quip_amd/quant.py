@@ -166,9 +166,15 @@ class QuantLinear(nn.Module):
         not hold them).  Device moves are followed, dtype changes of these buffers are undone without a round trip."""
         keep = {n: getattr(self, n, None) for n in self._F32_BUFFERS}
         dev0 = self.qweight.device
+        only_decode = self.qweight.numel() == 0 and self.infeatures * self.outfeatures > 0
+        qd = self.__dict__.get('_qweight_d')
         super()._apply(fn, recurse)
         if self.qweight.device != dev0:       # everything the decode launches derived from the packed state holds device pointers
             self._drop_derived()
+            if only_decode and qd is not None:
+                # after decode_only() the decode-order words are the ONLY copy of the weights: they travel with the module (the tables
+                # derived from them are still rebuilt on the new device)
+                self.__dict__['_qweight_d'] = qd.to(self.qweight.device)
         for n, old in keep.items():
             new = getattr(self, n, None)
             if old is not None and new is not None and new.dtype != torch.float32:
@@ -303,7 +309,9 @@ class QuantLinear(nn.Module):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
         adt = self.act_dtype(x)
-        few = x2.shape[0] <= ops.BLK_MAX_ROWS                  # a decode step: blocked operators may take csrc/ortho_blk.hip
+        # a decode step: blocked operators may take csrc/ortho_blk.hip (fp16 factors, ~3e-4 per stage) -- never for a float32 caller, who
+        # gets the fp32-factor K3 launches whatever the row count
+        few = x2.shape[0] <= ops.BLK_MAX_ROWS and x.dtype != torch.float32
         if self.V is not None:
             xt = self.V.apply_rows(x2.contiguous(), colscale=self.inv_scaleWH, out_dtype=adt, fast16=few)
         else:

@@ -432,6 +432,27 @@ def all_reduce_hessians(methods, group=None):
     dist.all_reduce(counts, group=group)
     tri = torch.tensor([1.0 if getattr(m, "_tri", False) else 0.0 for m in methods], dtype=torch.float64, device=dev)
     dist.all_reduce(tri, op=dist.ReduceOp.MAX, group=group)
+    # Who skips its collective is decided BY ALL RANKS TOGETHER.  method.SHARE_IDENTICAL_INPUTS turns q / k / v into followers inside
+    # add_batch -- on the ranks that forwarded a sample.  A rank whose share of the calibration set is empty (nsamples < world) never
+    # gets there and would issue one all-reduce per Linear while the others issue one per leader: the calls would pair different
+    # Linears' Hessians.  So: every rank reports the leader (as a position in `methods`) of each method, MAX over ranks, and a rank
+    # that has not seen the sharing adopts it before the Hessians move.
+    def _leader_of(m):
+        lead = getattr(m, "_leader", None) or getattr(m, "_auto_leader", None)
+        if lead is None:
+            return -1.0
+        for k, o in enumerate(methods):
+            if o is lead:
+                return float(k)
+        raise RuntimeError("all_reduce_hessians: a method shares the Hessian of a leader that is not in the list")
+    lead_ix = torch.tensor([_leader_of(m) for m in methods], dtype=torch.float64, device=dev)
+    dist.all_reduce(lead_ix, op=dist.ReduceOp.MAX, group=group)
+    for m, k in zip(methods, lead_ix.tolist()):
+        if k >= 0 and m.H is not None:
+            if m.nsamples != 0 or getattr(m, "_followers", 0) > 0:
+                raise RuntimeError("all_reduce_hessians: the ranks disagree on which Linears share a Hessian, and this rank has "
+                                   "already accumulated samples into its own (set method.SHARE_IDENTICAL_INPUTS = False)")
+            m.share_hessian_from(methods[int(k)])
     for m, n, t in zip(methods, counts.tolist(), tri.tolist()):
         if m.H is None:                     # a follower of QuantMethod.share_hessian_from (q/k/v share one accumulator): its
             m.nsamples = int(round(n))      # leader's H is reduced once; only the sample count is per method

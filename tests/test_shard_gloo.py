@@ -219,6 +219,55 @@ def test_calibration_samples_split_over_ranks(tmp_path):
     assert torch.load(out)["ok"]
 
 
+def _empty_rank_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quip_amd import shard, method
+    from quip_amd.method import QuantMethod
+    try:
+        assert method.SHARE_IDENTICAL_INPUTS
+        torch.manual_seed(0)
+        d, nsamp = 48, 2                                               # fewer samples than ranks: the last rank forwards nothing
+        q, k, v, o = (torch.nn.Linear(d, 8) for _ in range(4))
+        X = torch.randn(nsamp, 12, d).half()
+        Xo = torch.randn(nsamp, 12, d).half()
+        qms = [QuantMethod(l) for l in (q, k, v, o)]
+        a, b = shard.sample_partition(nsamp, world)[rank]
+        for j in range(a, b):
+            xin = X[j].unsqueeze(0)
+            for qm in qms[:3]:                                         # q / k / v are handed THE SAME tensor (HF attention)
+                qm.add_batch(xin, None)
+            qms[3].add_batch(Xo[j].unsqueeze(0), None)
+        if b > a:
+            assert qms[1].H is None and qms[2].H is None               # followers of q on the ranks that saw a sample
+        else:
+            assert all(qm.H is not None for qm in qms)                 # the empty rank knows nothing of the sharing yet
+        shard.all_reduce_hessians(qms)
+        assert qms[1].H is None and qms[2].H is None                   # ... and has adopted it: 2 collectives everywhere, not 4 vs 2
+        for qm in qms:
+            qm.post_batch()
+        ok = True
+        for qm, l, x in zip(qms, (q, k, v, o), (X, X, X, Xo)):
+            ref = QuantMethod(l)
+            for j in range(nsamp):
+                ref.add_batch(x[j].unsqueeze(0).clone(), None)         # (a clone: no sharing in the reference run)
+            ref.post_batch()
+            ok = ok and qm.nsamples == nsamp and torch.allclose(qm.H, ref.H, rtol=1e-6, atol=0)
+        torch.save({"ok": bool(ok)}, os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_without_samples_joins_the_same_collectives(tmp_path):
+    """nsamples < world leaves a rank that never forwarded, hence never learned that q / k / v share one accumulator
+    (method.SHARE_IDENTICAL_INPUTS); all_reduce_hessians must still issue the SAME collectives on every rank and give every rank the
+    full Hessians."""
+    mp.spawn(_empty_rank_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    for r in range(3):
+        assert torch.load(str(tmp_path / f"r{r}.pt"))["ok"], f"rank {r}"
+
+
 # ---- round 4: one owner PER LINEAR (shard.assign_owners / shard.block_owner_per_linear) ------------------------------------------------
 _PL_SHAPES = [(32, 64), (32, 64), (48, 64), (32, 128), (64, 32)]          # (rows, columns) of a block's Linears in call order
 
