@@ -437,6 +437,10 @@ typedef struct quipamd_bigp_v_gemm_args {
     int p;
     int64_t rows;
     int row_tiles_per_wave;
+    float *partials;                 /* NULL: the K-slices meet in y through fp32 atomics (y zero on entry).  Else fp32 [p/16, rows, m]
+                                        scratch: the slices meet in a fixed order (deterministic; y need not be cleared) ...            */
+    unsigned *arrived;               /* ... with one arrival counter per row group, [m / 256] (enough for any row_tiles_per_wave), zero
+                                        on entry; the launch leaves them zero                                                         */
 } quipamd_bigp_v_gemm_args;
 int quipamd_decode_bigp_supported(int p, int q);
 int quipamd_decode_bigp_u(const quipamd_bigp_u_op *ops, int nops, int p, int64_t rows, float *clear, int64_t clear_n, void *stream);

@@ -21,7 +21,8 @@
 //   * bigp_v_gemm: a workgroup's 16 image rows are 256 consecutive columns of the packed matrix (columns in image order) = one STREAM
 //     chunk of every row tile, so the operator output goes straight into the 2-bit GEMM of that K-slice; the K-slices meet in y
 //     through fp32 atomics (64 consecutive floats per instruction).  y must be ZERO on entry: bigp_u clears it (`clear`) -- it runs
-//     between y's previous reader and this launch.
+//     between y's previous reader and this launch.  With `partials` / `arrived` set the slices meet in a FIXED order instead (each stores
+//     its partial, the last arriver of a row group sums slices 0 .. p/16 - 1): bit-identical runs, one more L2 round trip.
 // Rows (batch) <= 4, compile-time.
 #include "common.h"
 #include "dq_common.h"
@@ -150,6 +151,8 @@ struct BVArgs {
     float *y;                     // fp32 [bs][m], accumulated
     int64_t m;
     int p, ks;
+    float *partials;              // fixed-order meet: [p/16 slices][bs][m] fp32, or null (atomics)
+    unsigned *arrived;            // [row groups] arrival counters, zero on entry, left zero on exit
 };
 
 __device__ __forceinline__ uint32_t bg_gate2(uint32_t g2, uint32_t u2)
@@ -294,6 +297,25 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
     }
     __syncthreads();
     const float alpha = e_sc * two_over_maxq;
+    if (G.partials == nullptr) {
+#pragma unroll
+        for (int o = 0; o < (16 * NRT + 63) / 64; ++o) {
+            const int l = lane + 64 * o;
+            if (l < 16 * NRT) {
+                const int k = l >> 4, wr = l & 15;
+#pragma unroll
+                for (int r = 0; r < BS; ++r) {
+                    const float val = alpha * ((mine[(k * 4 + r) * 16 + wr] - red[4 + r]) - c0 * red[r]);
+                    unsafeAtomicAdd(G.y + (int64_t)r * G.m + (int64_t)rt0 * 16 + l, val);
+                }
+            }
+        }
+        return;
+    }
+    // ---- fixed-order meet (opt-in: greedy decoding must not depend on the order atomics land in).  Every K-slice stores its partial; the
+    // workgroup that arrives LAST at its row group's counter sums the slices 0 .. p/16 - 1 in that order and stores y (no clear needed);
+    // it also hands the counter back at zero for the next launch.  Device scope: the slices of a row group sit on different XCDs.
+    float *slab = G.partials + (int64_t)at * BS * G.m;
 #pragma unroll
     for (int o = 0; o < (16 * NRT + 63) / 64; ++o) {
         const int l = lane + 64 * o;
@@ -302,9 +324,29 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
 #pragma unroll
             for (int r = 0; r < BS; ++r) {
                 const float val = alpha * ((mine[(k * 4 + r) * 16 + wr] - red[4 + r]) - c0 * red[r]);
-                unsafeAtomicAdd(G.y + (int64_t)r * G.m + (int64_t)rt0 * 16 + l, val);
+                __hip_atomic_store(slab + (int64_t)r * G.m + (int64_t)rt0 * 16 + l, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+    }
+    __shared__ unsigned last_flag;
+    __threadfence();                                                            // this thread's partial stores are visible device-wide ...
+    __syncthreads();                                                            // ... and so are every thread's of the workgroup
+    if (tid == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(G.arrived + blockIdx.y, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = prev == (unsigned)(nch - 1);
+        if (last_flag) __hip_atomic_store(G.arrived + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();
+    const int64_t r0 = (int64_t)blockIdx.y * 16 * NRT * 16;                     // the row group's first row; 256 NRT rows, BS batch rows
+    for (int e = tid; e < BS * 256 * NRT; e += 1024) {
+        const int r = e / (256 * NRT), row = e - r * (256 * NRT);
+        const float *src = G.partials + (int64_t)r * G.m + r0 + row;
+        float sum = 0.f;
+        for (int sl = 0; sl < nch; ++sl)
+            sum += __hip_atomic_load(src + (int64_t)sl * BS * G.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        G.y[(int64_t)r * G.m + r0 + row] = sum;
     }
 }
 
@@ -370,7 +412,9 @@ extern "C" int quipamd_decode_bigp_v_gemm(const quipamd_bigp_v_gemm_args *a, voi
     int nrt = a->row_tiles_per_wave;
     if (nrt == 0) nrt = a->m % 1024 == 0 ? 4 : a->m % 512 == 0 ? 2 : 1;
     QA_REQUIRE((nrt == 1 || nrt == 2 || nrt == 4) && a->m % (256 * nrt) == 0, QUIPAMD_ERR_ARG, "decode_bigp_v_gemm: row_tiles_per_wave 0 / 1 / 2 / 4 with m %% (256 x it) == 0");
-    BVArgs A{(const uint4 *)a->F0, a->M1, (const uint16_t *)a->gate, (const uint16_t *)a->up, a->ldx, (const uint4 *)a->qweight, a->scale, a->y, a->m, p, (p + 31) / 32};
+    QA_REQUIRE((a->partials == nullptr) == (a->arrived == nullptr), QUIPAMD_ERR_ARG, "decode_bigp_v_gemm: partials and arrived go together (both null: atomics)");
+    BVArgs A{(const uint4 *)a->F0, a->M1, (const uint16_t *)a->gate, (const uint16_t *)a->up, a->ldx, (const uint4 *)a->qweight, a->scale, a->y, a->m, p, (p + 31) / 32,
+             a->partials, a->arrived};
     const int nwp = (A.ks + 1) / 2, bs = (int)a->rows;
     // c0 = maxq / 2 (2 bits: the per-field offsets are subtracted as sum OFF_k x~_k; 4-bit container: + the uniform offset 16)
     const float two_over_maxq = 2.0f / maxq, c0 = 0.5f * maxq + (w4 ? 16.0f : 0.0f);

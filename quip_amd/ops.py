@@ -411,7 +411,8 @@ class BigpVGemmArgs(ctypes.Structure):
     """quipamd_bigp_v_gemm_args"""
     _fields_ = [("F0", ctypes.c_void_p), ("M1", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("up", ctypes.c_void_p), ("ldx", ctypes.c_int64),
                 ("qweight", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("bits", ctypes.c_int), ("y", ctypes.c_void_p), ("m", ctypes.c_int64),
-                ("p", ctypes.c_int), ("rows", ctypes.c_int64), ("row_tiles_per_wave", ctypes.c_int)]
+                ("p", ctypes.c_int), ("rows", ctypes.c_int64), ("row_tiles_per_wave", ctypes.c_int), ("partials", ctypes.c_void_p),
+                ("arrived", ctypes.c_void_p)]
 
 
 BIGP_MAX_ROWS = 4
@@ -439,17 +440,23 @@ def decode_bigp_u(entries, rows, clear=None):
     _lib.call("quipamd_decode_bigp_u", arr, len(entries), U0.p, rows, _p(clear), 0 if clear is None else clear.numel(), _stream())
 
 
-def decode_bigp_v_gemm(V, gate, up, qweight_d, scale, y, row_tiles_per_wave=0, bits=2):
+def decode_bigp_v_gemm(V, gate, up, qweight_d, scale, y, row_tiles_per_wave=0, bits=2, partials=None, arrived=None):
     """y += What V(silu(gate) * up) for a 2-bit qfn-b layer whose activation-side operator V is p x 16 (quipamd_decode_bigp_v_gemm):
     gate / up fp16 [rows, n] as the transposed image of V's input (up None: the input is `gate` itself), qweight_d the codes with their
-    columns in image order of V (QuantLinear.decode_qweight()), y fp32 [rows, m] ACCUMULATED with atomics (zero it first)."""
+    columns in image order of V (QuantLinear.decode_qweight()), y fp32 [rows, m] ACCUMULATED with atomics (zero it first).
+    partials fp32 [p / 16, rows, m] + arrived int32 [m / 256] (zero): the K-slices meet in a fixed order instead -- y is STORED, runs are
+    bit-identical (quant.DETERMINISTIC_SPLITK)."""
     _need_gpu(gate)
     rows, m = y.shape
     assert V.bigp_fold_ok and gate.dtype == torch.float16 and gate.shape == (rows, V.n) and gate.stride(1) == 1
     assert up is None or (up.dtype == torch.float16 and up.shape == gate.shape and up.stride() == gate.stride())
     assert y.dtype == torch.float32 and y.is_contiguous() and scale.dtype == torch.float32 and scale.numel() == 1
     F0, M1 = V.bigp_frags(False)
-    a = BigpVGemmArgs(_p(F0), _p(M1), _p(gate), _p(up), gate.stride(0), _p(qweight_d), _p(scale), int(bits), _p(y), m, V.p, rows, int(row_tiles_per_wave))
+    if partials is not None:
+        assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.numel() >= (V.p // 16) * rows * m
+        assert arrived is not None and arrived.dtype == torch.int32 and arrived.numel() >= m // 256
+    a = BigpVGemmArgs(_p(F0), _p(M1), _p(gate), _p(up), gate.stride(0), _p(qweight_d), _p(scale), int(bits), _p(y), m, V.p, rows, int(row_tiles_per_wave),
+                      _p(partials), _p(arrived))
     _lib.call("quipamd_decode_bigp_v_gemm", ctypes.byref(a), _stream())
 
 

@@ -137,6 +137,12 @@ class Quantizer(nn.Module):
         return self.scale is not None and bool(torch.all(self.scale != 0))
 
 
+# Llama's down_proj is a split-K launch (csrc/decode_bigp.hip): by default its K-slices meet in y through fp32 atomics, and two runs of the
+# same step can differ in the last bits (then, after an fp16 rounding downstream, in a greedy token near a tie).  True: the slices meet in a
+# fixed order through a scratch buffer -- bit-identical runs, one more L2 round trip per MLP tail.  Set it before the engine captures.
+DETERMINISTIC_SPLITK = False
+
+
 class QuantLinear(nn.Module):
     """Packed 2/4-bit Linear (the runnable successor of Quant3Linear / Quant4Linear, quant.py:173-233,
     zeroShot/models/quant.py:183-212).  Holds codes in the STREAM layout plus, when the layer was quantised
@@ -204,7 +210,7 @@ class QuantLinear(nn.Module):
         """forget what the decode launches derived from the packed state (decode_qweight, bias16, the layer-pair / MLP-tail tables) and take a
         new generation number: tables OTHER layers keep about this one are keyed by it (process-wide counter: a recycled id() cannot
         collide with a dead layer's entry), and a device move invalidates them like a re-pack does"""
-        for k in ('_qweight_d', '_bias16', '_pair_tables', '_bigp_tail'):
+        for k in ('_qweight_d', '_bias16', '_pair_tables', '_bigp_tail', '_splitk_ws'):
             self.__dict__.pop(k, None)
         QuantLinear._GEN[0] += 1
         self.__dict__['_pack_gen'] = QuantLinear._GEN[0]
@@ -731,6 +737,19 @@ def fused_bigp_tail(ups, down, ys, row_tiles_per_wave=0):
     dev = ys[0].device
     imgs = torch.empty((len(ups), rows, V.n), dtype=torch.float16, device=dev)
     yd = torch.empty((rows, down.outfeatures), dtype=torch.float32, device=dev)
+    if DETERMINISTIC_SPLITK:
+        # the K-slices of down_proj meet in slice order through a scratch the layer keeps (a hipGraph replays the same pointers); the arrival
+        # counters are zeroed once and handed back at zero by every launch
+        key = (rows, str(dev))
+        ws = down.__dict__.setdefault('_splitk_ws', {})
+        if key not in ws:
+            ws[key] = (torch.empty((V.p // 16, rows, down.outfeatures), dtype=torch.float32, device=dev),
+                       torch.zeros(down.outfeatures // 256, dtype=torch.int32, device=dev))
+        partials, arrived = ws[key]
+        ops.decode_bigp_u([(q.U, y, bias_img, post, dest, imgs[i]) for i, (q, y, (dest, bias_img, post)) in enumerate(zip(ups, ys, tabs))], rows)
+        ops.decode_bigp_v_gemm(V, imgs[0], imgs[1] if len(ups) == 2 else None, down.decode_qweight(), down.scales, yd, row_tiles_per_wave, bits=down.bits,
+                               partials=partials, arrived=arrived)
+        return yd
     ops.decode_bigp_u([(q.U, y, bias_img, post, dest, imgs[i]) for i, (q, y, (dest, bias_img, post)) in enumerate(zip(ups, ys, tabs))], rows, clear=yd)
     ops.decode_bigp_v_gemm(V, imgs[0], imgs[1] if len(ups) == 2 else None, down.decode_qweight(), down.scales, yd, row_tiles_per_wave, bits=down.bits)
     return yd

@@ -36,6 +36,7 @@ MODELS = {
     "opt-125m": dict(arch="opt", hidden=768, ffn=3072, layers=12, heads=12, vocab=50272),
     "opt-1.3b": dict(arch="opt", hidden=2048, ffn=8192, layers=24, heads=32, vocab=50272),
     "opt-6.7b": dict(arch="opt", hidden=4096, ffn=16384, layers=32, heads=32, vocab=50272),
+    "opt-30b": dict(arch="opt", hidden=7168, ffn=28672, layers=48, heads=56, vocab=50272),      # BASELINE configs[4]; use --layers 1..N
 }
 
 
