@@ -439,32 +439,48 @@ def main():
         except Exception as ex:                       # a side measurement must never take the headline line down
             out["sharded_ldlq"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
-    # ---- one whole transformer block of the sharded driver: calibration + Hessians + factors + rounding + re-forward (configs[4] path) ----
-    # OPT-1.3B block geometry, 64 calibration samples of 2048 tokens split over the N ranks (strong scaling: the work is fixed);
-    # every rank runs the SPMD loop of scripts/quantize_opt_sharded.py; rank 0 reports the phase split
+    # ---- the sharded driver on WHOLE models (configs[4] path, north_star "OPT-1.3B full-model LDLQ at 1 / 2 / 4 / 8 GPUs"):
+    # `sharded_model`: all 24 blocks of the OPT-1.3B geometry, the reference's calibration size (128 x 2048 tokens) split over the N ranks
+    # (strong scaling: the work is fixed); `sharded_block_opt30b`: one block at the OPT-30B geometry (7168 / 28672 / 56 heads), same
+    # calibration size.  Every rank runs the SPMD loop of scripts/quantize_opt_sharded.py; rank 0 reports wall, phase split, bytes moved.
     if not args.no_ldlq:
         try:
             import importlib.util as _ilu
             spec = _ilu.spec_from_file_location("quantize_opt_sharded", os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "quantize_opt_sharded.py"))
             smod = _ilu.module_from_spec(spec)
             spec.loader.exec_module(smod)
-            sargv = ["--hidden", "2048", "--ffn", "8192", "--heads", "32", "--layers", "1", "--nsamples", "64", "--seqlen", "2048", "--vocab", "4096", "--incoh",
-                     "--quiet"]
-            smod.main(sargv)                                    # warm-up (kernels, allocator, RCCL channels)
-            barrier()
-            sres = smod.main(sargv)
-            barrier()
-            if rank == 0:
+            common = ["--nsamples", "128", "--seqlen", "2048", "--vocab", "4096", "--incoh", "--quiet"]
+            smod.main(["--hidden", "2048", "--ffn", "8192", "--heads", "32", "--layers", "1"] + common)     # warm-up (kernels, allocator, RCCL channels)
+
+            def sharded_leg(geom, what):
+                barrier()
+                sres = smod.main(geom + common)
+                barrier()
+                if rank != 0:
+                    return None
                 ph = sres["phase_seconds_rank0"]
                 serial = ph["owner_preproc_factor_s"]
-                par = ph["forward_hessian_s"] + ph["round_s"] + ph["reforward_s"]
-                out["sharded_block"] = {"what": f"one OPT-1.3B-geometry block, LDLQ w{BITS} + incoherence processing, 64 x 2048 calibration tokens over {world} rank(s): "
-                                                "own samples -> K7 partial Hessians -> all-reduce -> owner preproc + LDL factors -> row-sharded K4 -> "
-                                                "weight broadcast -> re-forward (scripts/quantize_opt_sharded.py --calibration sharded)",
-                                        "wall_s": sres["wall_s"], "phase_seconds_rank0": ph, "scaling": "strong",
-                                        "amdahl_note": f"owner-only phases {serial:.3f} s of {serial + par:.3f} s measured here on rank 0's share"}
+                moved = {k: sres[k] for k in ("bytes_broadcast_LT", "bytes_broadcast_next_LT", "bytes_scatter", "bytes_gather", "bytes_broadcast_weights") if k in sres}
+                return {"what": what, "wall_s": sres["wall_s"], "phase_seconds_rank0": ph, "bytes_moved": moved, "linears": sres["linears"],
+                        "owners": sres["owners"], "samples_rank0": sres["samples_rank0"], "scaling": "strong",
+                        "errors_finite": bool(np.all(np.isfinite(sres["errors"]))), "mean_proxy_error": sres["mean_proxy_error"],
+                        "amdahl_note": f"phases that run on a Linear's owner only: {serial:.3f} s of {sres['wall_s']:.3f} s on rank 0"}
+            r_ = sharded_leg(["--hidden", "2048", "--ffn", "8192", "--heads", "32", "--layers", "24"],
+                             f"OPT-1.3B geometry, ALL 24 blocks, LDLQ w{BITS} + incoherence processing, 128 x 2048 calibration tokens over {world} rank(s): per block "
+                             "own samples -> K7 partial Hessians -> all-reduce -> per-Linear owner preproc + LDL factors -> row-sharded K4 -> weight broadcast -> "
+                             "re-forward (scripts/quantize_opt_sharded.py --calibration sharded --owners per-linear)")
+            if rank == 0:
+                out["sharded_model"] = r_
+            torch.cuda.empty_cache()
+            r_ = sharded_leg(["--hidden", "7168", "--ffn", "28672", "--heads", "56", "--layers", "1"],
+                             f"ONE block at the OPT-30B geometry (7168 / 28672 / 56 heads; the model has 48), LDLQ w{BITS} + incoherence processing, 128 x 2048 "
+                             f"calibration tokens over {world} rank(s), same driver")
+            if rank == 0:
+                out["sharded_block_opt30b"] = r_
+            torch.cuda.empty_cache()
         except Exception as ex:
-            out["sharded_block"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            if rank == 0:
+                out["sharded_model"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     # ---- K7 Hessian accumulation: one add_batch call at the OPT-1.3B fc2 input shape -----------------
     if rank == 0 and world == 1 and not args.no_ldlq:
@@ -630,14 +646,15 @@ def main():
             torch.cuda.empty_cache()
             ns = _types.SimpleNamespace(arch="opt", layers=0, bits=BITS, blocked=False, prompt=32, tokens=32, mode="auto", bs=1, blk_fused_n=-1)
             built, rows = None, {}
-            for nb in (2, 4):
+            for nb in (2, 4, 8, 16):
                 ns.bs = nb
                 r_, built = emod.run(ns, model=built, keep=True)
                 rows[f"bs{nb}"] = {"tok_per_s": round(r_["tok_per_s"], 1), "ms_per_step": round(r_["ms_per_step_median"], 3), "engine_mode": r_["engine_mode"]}
             del built
             torch.cuda.empty_cache()
-            out["decode_batch"] = {"metric": "OPT-1.3B w2 (Kronecker operators) decode, aggregate tok/s with 2 / 4 sequences per step (quip_amd.decode.DecodeEngine, "
-                                             "one hipGraph per step); batch 1 is the `decode` leg", **rows}
+            out["decode_batch"] = {"metric": "OPT-1.3B w2 (Kronecker operators) decode, aggregate tok/s with 2 / 4 / 8 / 16 sequences per step (quip_amd.decode.DecodeEngine, "
+                                             "one hipGraph per step); batch 1 is the `decode` leg; up to 4 rows ride in the single fused launch per layer group, 5..64 "
+                                             "rows run [prologue-only launch, one workgroup per row] + [dequant-GEMM] per group (mode v3)", **rows}
         except Exception as ex:
             out["decode_batch"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 

@@ -376,6 +376,12 @@ typedef struct quipamd_fused_gemm_args {
     /* dtype of u_y: QUIPAMD_F16, or QUIPAMD_F32 -- the fp32 accumulator of quipamd_decode_bigp_v_gemm, rounded to fp16 on load (what a
      * cast launch in between would do); fp32 has a kernel for 64 x 64 with residual and RMSNorm (Llama's down_proj -> q / k / v) only. */
     int u_y_dtype;
+    /* ops_only != 0 (round 5; more than 4 rows per step): the launch stops after the operator chain -- grid (bs, ngroups), one workgroup per
+     * (batch row, group) -- and y[k] receives x~_k = V_k(Norm(t) (/) s_k) as fp16 [bs, n] in IMAGE order (= the order of the decode-order
+     * codes' columns); qweight / scale / m / y_dtype are not read, t_out is written as usual.  The dequant-GEMM is then one
+     * quipamd_dequant_gemm_grouped on those x~ and the same decode-order codes (its output rows are in ZT order like the fused
+     * launch's): the weights stream once for all rows.  bs <= 1024. */
+    int ops_only;
 } quipamd_fused_gemm_args;
 int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *args, void *stream);
 
@@ -401,7 +407,9 @@ int quipamd_decode_u_only(const quipamd_fop *U, const void *y, const void *bias,
  * operator that is the "ZT order" the producing GEMM's rows are packed in (see quipamd_fused_gemm_args), for the activation-side
  * operator it is what quipamd_decode_bigp_u writes through `dest`.  Factors: F0 = M0 [p][p] as fp16 MFMA B fragments with the k index
  * zero padded to ks = ceil(p / 32) steps:  F0[((at * ks + S) * 64 + lane) * 8 + e] = M0[16 at + lane % 16][32 S + 8 (lane / 16) + e]
- * (0 where the column index >= p);  M1 = float [16][16];  result image = M0 z M1^T.  Rows (batch) 1..4; p % 16 == 0, 64 <= p <= 1024.
+ * (0 where the column index >= p);  M1 = float [16][16];  result image = M0 z M1^T.  p % 16 == 0, 64 <= p <= 1024.  Rows (batch):
+ * 1..16 -- quipamd_decode_bigp_u walks row groups of 4 side by side; quipamd_decode_bigp_v_gemm from 5 rows on mixes 4 rows
+ * at a time, ONE pass over the weights feeds all rows).
  *
  * quipamd_decode_bigp_u: for every operator i (<= 3; gate and up in one launch)
  *       out_i[r][dest_i[pos]] = fp16( ((M0 z M1^T)[pos] + bias_img_i[pos]) * post_img_i[pos] )        pos = a * 16 + b

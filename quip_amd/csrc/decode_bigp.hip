@@ -23,7 +23,8 @@
 //     through fp32 atomics (64 consecutive floats per instruction).  y must be ZERO on entry: bigp_u clears it (`clear`) -- it runs
 //     between y's previous reader and this launch.  With `partials` / `arrived` set the slices meet in a FIXED order instead (each stores
 //     its partial, the last arriver of a row group sums slices 0 .. p/16 - 1): bit-identical runs, one more L2 round trip.
-// Rows (batch) <= 4, compile-time.
+// Rows (batch): 1..4 compile-time; round 5: up to 16 -- bigp_u walks row groups of 4 over blockIdx.z, bigp_v_gemm mixes 4 rows at a
+// time into a 16-row x~ image and runs ONE weight pass against all 16 MFMA columns (templates BS = 8, 16).
 #include "common.h"
 #include "dq_common.h"
 #include "fpass.h"
@@ -32,7 +33,7 @@
 
 namespace {
 
-constexpr int BG_MAXG = 3, BG_MAXBS = 4, BG_MAXKS = 32;
+constexpr int BG_MAXG = 3, BG_MAXBS = 4, BG_MAXROWS = 16, BG_MAXKS = 32;
 
 struct BUOp {
     const uint4 *F0;              // [p/16][ks][64] B fragments of M0 (fp16, zero for a >= p)
@@ -49,6 +50,7 @@ struct BUArgs {
     float *clear;
     int64_t clear_n4;             // float4 count
     int p, ks;
+    int rows;                     // batch rows that exist (row groups of BS over grid.z; the last group may be ragged)
 };
 
 // reduced partial tiles -> T (in the lane's D registers: b = 4g + s, a' = j) -> z2[a' = j][b' = 4g + reg] = sum_b T[a'][b] M1[b'][b]:
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(1024) void bigp_u_kernel(BUArgs G)
     const BUOp &O = G.op[blockIdx.y];
     asm volatile("" ::"s"(O.F0), "s"(O.M1), "s"(O.y), "s"(O.bias), "s"(O.post), "s"(O.dest), "s"(O.out), "s"(O.ldo), "s"(G.p), "s"(G.ks),
                  "s"(G.clear), "s"(G.clear_n4));
+    const int row0 = (int)blockIdx.z * BS;                                      // more than 4 rows: groups of BS rows side by side (grid.z)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(1024) void bigp_u_kernel(BUArgs G)
     if (mixer) {
 #pragma unroll
         for (int r = 0; r < BS; ++r) {
-            const uint16_t *row = O.y + r * n + (uint32_t)(j * p);
+            const int rr = row0 + r < G.rows ? row0 + r : G.rows - 1;           // (a ragged last group re-reads the last row; not stored)
+            const uint16_t *row = O.y + (int64_t)rr * n + (uint32_t)(j * p);
             ya[r][0] = *reinterpret_cast<const uint4 *>(row + ka0);
             ya[r][1] = *reinterpret_cast<const uint4 *>(row + ka1);
         }
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(1024) void bigp_u_kernel(BUArgs G)
         if (O.bias) bi = *reinterpret_cast<const uint2 *>(O.bias + pos0);
         if (O.post) po = *reinterpret_cast<const float4 *>(O.post + pos0);
     }
-    if (G.clear && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (G.clear && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int64_t i = tid; i < G.clear_n4; i += blockDim.x) reinterpret_cast<float4 *>(G.clear)[i] = z;
     }
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(1024) void bigp_u_kernel(BUArgs G)
         }
     }
     __syncthreads();
-    if (wave >= BS) return;
+    if (wave >= BS || row0 + wave >= G.rows) return;
     const int r = wave;
     f32x4_t T = {0.f, 0.f, 0.f, 0.f};
     for (int w = 0; w < nw; ++w) {
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(1024) void bigp_u_kernel(BUArgs G)
     }
     const f32x4_t z2 = bg_mix_b(T, m1);
     const float4 bb = f16x4_to_f32(bi);
-    uint16_t *o = O.out + r * O.ldo;
+    uint16_t *o = O.out + (int64_t)(row0 + r) * O.ldo;
     o[de.x & 0xffff] = f32_to_f16_bits((z2[0] + bb.x) * po.x);
     o[de.x >> 16] = f32_to_f16_bits((z2[1] + bb.y) * po.y);
     o[de.y & 0xffff] = f32_to_f16_bits((z2[2] + bb.z) * po.z);
@@ -151,7 +155,8 @@ struct BVArgs {
     float *y;                     // fp32 [bs][m], accumulated
     int64_t m;
     int p, ks;
-    float *partials;              // fixed-order meet: [p/16 slices][bs][m] fp32, or null (atomics)
+    int rows;                     // batch rows that exist (<= BS; rows >= it read row rows - 1 and are not stored)
+    float *partials;              // fixed-order meet: [p/16 slices][rows][m] fp32, or null (atomics)
     unsigned *arrived;            // [row groups] arrival counters, zero on entry, left zero on exit
 };
 
@@ -181,46 +186,55 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
     typedef BgDq<BITS == 2> DQ;                                                 // 2 bits: multi-exponent dequantisation (dq_common.h): needs sum OFF_k x~_k
     constexpr int TPS = BITS == 2 ? 1 : 2;                                       // 1 KiB tiles per (row tile, K-slice of 256 columns)
     constexpr int XTS = 256 + 8;
+    // BS <= 4: as rounds 3-4.  BS = 8 / 16 (round 5): the mix over a runs RG = 4 rows at a time (the registers hold four rows' fragments),
+    // NG passes fill an XR-row x~ image, then ONE pass over the weights feeds all XR MFMA columns
+    constexpr int RG = BS < 4 ? BS : 4, NG = BS / RG, XR = BS <= 4 ? BG_MAXBS : BG_MAXROWS;
+    static_assert(BS == RG * NG && (BS <= 4 || BS == 8 || BS == 16), "rows per launch: 1..4, 8, 16");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint16_t *XT = reinterpret_cast<uint16_t *>(smem);                          // [4][256 + 8] f16: x~ of the slice, k = 16 a_local + b
-    float *red = reinterpret_cast<float *>(smem + BG_MAXBS * XTS * 2);           // [4] sum x~, [4] sum OFF x~
-    float *park = red + 8;                                                      // [16 waves][NRT][4][16]
+    uint16_t *XT = reinterpret_cast<uint16_t *>(smem);                          // [XR][256 + 8] f16: x~ of the slice, k = 16 a_local + b
+    float *red = reinterpret_cast<float *>(smem + XR * XTS * 2);                 // [XR] sum x~, [XR] sum OFF x~
+    float *park = red + 2 * XR;                                                 // [16 waves][NRT][XR][16]
     const typename DQ::Consts qc = DQ::make_consts();
-    float4 *part = reinterpret_cast<float4 *>(park + 16 * NRT * 64);            // [BS][nwp][64]
-    asm volatile("" ::"s"(G.F0), "s"(G.M1), "s"(G.gate), "s"(G.up), "s"(G.ldx), "s"(G.qw), "s"(G.scale), "s"(G.y), "s"(G.m), "s"(G.p), "s"(G.ks));
+    float4 *part = reinterpret_cast<float4 *>(park + 16 * NRT * XR * 16);       // [RG][nwp][64]
+    asm volatile("" ::"s"(G.F0), "s"(G.M1), "s"(G.gate), "s"(G.up), "s"(G.ldx), "s"(G.qw), "s"(G.scale), "s"(G.y), "s"(G.m), "s"(G.p), "s"(G.ks), "s"(G.rows));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int at = blockIdx.x, p = G.p, ks = G.ks, nch = p >> 4;
     const int nwp = (ks + 1) >> 1;                                              // waves that run the mix over a
     const uint32_t rt0 = (blockIdx.y * 16 + wave) * NRT;
+    const int rows = G.rows;
 
     const int S0 = 2 * wave, S1 = 2 * wave + 1;
     const bool mixer = wave < nwp, two = S1 < ks;
     int ka0 = 32 * S0 + 8 * g, ka1 = 32 * S1 + 8 * g;
     ka0 = ka0 < p ? ka0 : 0;
     ka1 = ka1 < p ? ka1 : 0;
-    uint4 ga[BS][2], ua[BS][2], fb[2];
+    uint4 ga[RG][2], ua[RG][2], fb[2];
     fb[0] = fb[1] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int r = 0; r < BS; ++r) ga[r][0] = ga[r][1] = ua[r][0] = ua[r][1] = make_uint4(0u, 0u, 0u, 0u);
-    if (mixer) {
+    for (int r = 0; r < RG; ++r) ga[r][0] = ga[r][1] = ua[r][0] = ua[r][1] = make_uint4(0u, 0u, 0u, 0u);
+    auto load_rows = [&](int r0) {                                              // the A fragments of rows r0 .. r0 + RG - 1 (rows past the batch: the last one)
 #pragma unroll
-        for (int r = 0; r < BS; ++r) {
-            const uint16_t *grow = G.gate + r * G.ldx + (uint32_t)(j * p);
+        for (int r = 0; r < RG; ++r) {
+            const int rr = r0 + r < rows ? r0 + r : rows - 1;
+            const uint16_t *grow = G.gate + (int64_t)rr * G.ldx + (uint32_t)(j * p);
             ga[r][0] = *reinterpret_cast<const uint4 *>(grow + ka0);
             ga[r][1] = *reinterpret_cast<const uint4 *>(grow + ka1);
             if (GATE) {
-                const uint16_t *urow = G.up + r * G.ldx + (uint32_t)(j * p);
+                const uint16_t *urow = G.up + (int64_t)rr * G.ldx + (uint32_t)(j * p);
                 ua[r][0] = *reinterpret_cast<const uint4 *>(urow + ka0);
                 ua[r][1] = *reinterpret_cast<const uint4 *>(urow + ka1);
             }
         }
+    };
+    if (mixer) {
+        load_rows(0);
         fb[0] = G.F0[(uint32_t)((at * ks + S0) * 64 + lane)];
         fb[1] = G.F0[(uint32_t)((at * ks + (two ? S1 : S0)) * 64 + lane)];
     }
     float4 m1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (wave < BS) m1 = *reinterpret_cast<const float4 *>(G.M1 + j * 16 + 4 * g);
+    if (wave < RG) m1 = *reinterpret_cast<const float4 *>(G.M1 + j * 16 + 4 * g);
     uint4 w[NRT][TPS];
 #pragma unroll
     for (int k = 0; k < NRT; ++k)                                                // HBM, streamed once: nt; requested LAST (in-order vmcnt)
@@ -232,41 +246,48 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
     const float e_sc = G.scale[0];
     if (!two) fb[1] = make_uint4(0u, 0u, 0u, 0u);
 
-    if (mixer) {
 #pragma unroll
-        for (int r = 0; r < BS; ++r) {
-            u32x4 a0 = {ga[r][0].x, ga[r][0].y, ga[r][0].z, ga[r][0].w}, a1 = {ga[r][1].x, ga[r][1].y, ga[r][1].z, ga[r][1].w};
-            if (GATE) {
-                a0 = u32x4{bg_gate2(ga[r][0].x, ua[r][0].x), bg_gate2(ga[r][0].y, ua[r][0].y), bg_gate2(ga[r][0].z, ua[r][0].z), bg_gate2(ga[r][0].w, ua[r][0].w)};
-                a1 = u32x4{bg_gate2(ga[r][1].x, ua[r][1].x), bg_gate2(ga[r][1].y, ua[r][1].y), bg_gate2(ga[r][1].z, ua[r][1].z), bg_gate2(ga[r][1].w, ua[r][1].w)};
+    for (int gq = 0; gq < NG; ++gq) {
+        if (gq > 0) {
+            __syncthreads();                                                    // the previous group's finishing waves are done with `part`
+            if (mixer) load_rows(gq * RG);
+        }
+        if (mixer) {
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                u32x4 a0 = {ga[r][0].x, ga[r][0].y, ga[r][0].z, ga[r][0].w}, a1 = {ga[r][1].x, ga[r][1].y, ga[r][1].z, ga[r][1].w};
+                if (GATE) {
+                    a0 = u32x4{bg_gate2(ga[r][0].x, ua[r][0].x), bg_gate2(ga[r][0].y, ua[r][0].y), bg_gate2(ga[r][0].z, ua[r][0].z), bg_gate2(ga[r][0].w, ua[r][0].w)};
+                    a1 = u32x4{bg_gate2(ga[r][1].x, ua[r][1].x), bg_gate2(ga[r][1].y, ua[r][1].y), bg_gate2(ga[r][1].z, ua[r][1].z), bg_gate2(ga[r][1].w, ua[r][1].w)};
+                }
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                acc = ActF16::mfma(a0, u32x4{fb[0].x, fb[0].y, fb[0].z, fb[0].w}, acc);
+                acc = ActF16::mfma(a1, u32x4{fb[1].x, fb[1].y, fb[1].z, fb[1].w}, acc);
+                part[(r * nwp + wave) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
             }
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-            acc = ActF16::mfma(a0, u32x4{fb[0].x, fb[0].y, fb[0].z, fb[0].w}, acc);
-            acc = ActF16::mfma(a1, u32x4{fb[1].x, fb[1].y, fb[1].z, fb[1].w}, acc);
-            part[(r * nwp + wave) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
-    }
-    __syncthreads();
-    if (wave < BS) {
-        const int r = wave;
-        f32x4_t T = {0.f, 0.f, 0.f, 0.f};
-        for (int w2 = 0; w2 < nwp; ++w2) {
-            const float4 v = part[(r * nwp + w2) * 64 + lane];
-            T[0] += v.x; T[1] += v.y; T[2] += v.z; T[3] += v.w;
-        }
-        const f32x4_t z2 = bg_mix_b(T, m1);                                      // x~[a' = j][b' = 4g + reg]: k = 16 j + 4 g + reg of the slice
-        uint2 pk;
-        pk.x = pack_f16x2(z2[0], z2[1]);
-        pk.y = pack_f16x2(z2[2], z2[3]);
-        *reinterpret_cast<uint2 *>(XT + r * XTS + 16 * j + 4 * g) = pk;
-        const float4 rv = f16x4_to_f32(pk);                                      // the sums the epilogue subtracts are sums of what the MFMAs see
-        const float s = fg_wave_sum((rv.x + rv.y) + (rv.z + rv.w));
-        const int k0 = 16 * j + 4 * g;
-        const float so = BITS == 2 ? fg_wave_sum(fmaf(me2_off_f16(k0), rv.x, fmaf(me2_off_f16(k0 + 1), rv.y, fmaf(me2_off_f16(k0 + 2), rv.z, me2_off_f16(k0 + 3) * rv.w))))
-                                   : 0.f;                                        // 4 bits: one offset for every field, folded into c0
-        if (lane == 0) {
-            red[r] = s;
-            red[4 + r] = so;
+        __syncthreads();
+        if (wave < RG) {
+            const int r = wave, rx = gq * RG + r;                                // rx: the row of the x~ image
+            f32x4_t T = {0.f, 0.f, 0.f, 0.f};
+            for (int w2 = 0; w2 < nwp; ++w2) {
+                const float4 v = part[(r * nwp + w2) * 64 + lane];
+                T[0] += v.x; T[1] += v.y; T[2] += v.z; T[3] += v.w;
+            }
+            const f32x4_t z2 = bg_mix_b(T, m1);                                  // x~[a' = j][b' = 4g + reg]: k = 16 j + 4 g + reg of the slice
+            uint2 pk;
+            pk.x = pack_f16x2(z2[0], z2[1]);
+            pk.y = pack_f16x2(z2[2], z2[3]);
+            *reinterpret_cast<uint2 *>(XT + rx * XTS + 16 * j + 4 * g) = pk;
+            const float4 rv = f16x4_to_f32(pk);                                  // the sums the epilogue subtracts are sums of what the MFMAs see
+            const float s = fg_wave_sum((rv.x + rv.y) + (rv.z + rv.w));
+            const int k0 = 16 * j + 4 * g;
+            const float so = BITS == 2 ? fg_wave_sum(fmaf(me2_off_f16(k0), rv.x, fmaf(me2_off_f16(k0 + 1), rv.y, fmaf(me2_off_f16(k0 + 2), rv.z, me2_off_f16(k0 + 3) * rv.w))))
+                                       : 0.f;                                    // 4 bits: one offset for every field, folded into c0
+            if (lane == 0) {
+                red[rx] = s;
+                red[XR + rx] = so;
+            }
         }
     }
     __syncthreads();
@@ -275,7 +296,7 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
     f32x4_t acc[NRT];
 #pragma unroll
     for (int k = 0; k < NRT; ++k) acc[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const uint16_t *xrow = XT + (j & (BG_MAXBS - 1)) * XTS + 8 * g;
+    const uint16_t *xrow = XT + (j & (XR - 1)) * XTS + 8 * g;
     uint4 xf[8];                                                                // the slice's 256 k = 8 MFMA steps, whatever the container
 #pragma unroll
     for (int t = 0; t < 8; ++t) xf[t] = *reinterpret_cast<const uint4 *>(xrow + 32 * t);
@@ -290,10 +311,10 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
                 acc[k] = ActF16::mfma(a, u32x4{xv.x, xv.y, xv.z, xv.w}, acc[k]);
             }
     // D[row = 4g + reg][col = j]: lanes j < BS park their 4 rows; the wave re-reads them as 16 NRT consecutive rows per batch row
-    float *mine = park + wave * (NRT * 64);
+    float *mine = park + wave * (NRT * XR * 16);
     if (j < BS) {
 #pragma unroll
-        for (int k = 0; k < NRT; ++k) *reinterpret_cast<float4 *>(mine + (k * 4 + j) * 16 + 4 * g) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+        for (int k = 0; k < NRT; ++k) *reinterpret_cast<float4 *>(mine + (k * XR + j) * 16 + 4 * g) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
     }
     __syncthreads();
     const float alpha = e_sc * two_over_maxq;
@@ -305,8 +326,8 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
                 const int k = l >> 4, wr = l & 15;
 #pragma unroll
                 for (int r = 0; r < BS; ++r) {
-                    const float val = alpha * ((mine[(k * 4 + r) * 16 + wr] - red[4 + r]) - c0 * red[r]);
-                    unsafeAtomicAdd(G.y + (int64_t)r * G.m + (int64_t)rt0 * 16 + l, val);
+                    const float val = alpha * ((mine[(k * XR + r) * 16 + wr] - red[XR + r]) - c0 * red[r]);
+                    if (BS <= 4 || r < rows) unsafeAtomicAdd(G.y + (int64_t)r * G.m + (int64_t)rt0 * 16 + l, val);
                 }
             }
         }
@@ -315,7 +336,7 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
     // ---- fixed-order meet (opt-in: greedy decoding must not depend on the order atomics land in).  Every K-slice stores its partial; the
     // workgroup that arrives LAST at its row group's counter sums the slices 0 .. p/16 - 1 in that order and stores y (no clear needed);
     // it also hands the counter back at zero for the next launch.  Device scope: the slices of a row group sit on different XCDs.
-    float *slab = G.partials + (int64_t)at * BS * G.m;
+    float *slab = G.partials + (int64_t)at * rows * G.m;
 #pragma unroll
     for (int o = 0; o < (16 * NRT + 63) / 64; ++o) {
         const int l = lane + 64 * o;
@@ -323,8 +344,9 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
             const int k = l >> 4, wr = l & 15;
 #pragma unroll
             for (int r = 0; r < BS; ++r) {
-                const float val = alpha * ((mine[(k * 4 + r) * 16 + wr] - red[4 + r]) - c0 * red[r]);
-                __hip_atomic_store(slab + (int64_t)r * G.m + (int64_t)rt0 * 16 + l, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float val = alpha * ((mine[(k * XR + r) * 16 + wr] - red[XR + r]) - c0 * red[r]);
+                if (BS <= 4 || r < rows)
+                    __hip_atomic_store(slab + (int64_t)r * G.m + (int64_t)rt0 * 16 + l, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -339,13 +361,13 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
     __syncthreads();
     if (!last_flag) return;
     __threadfence();
-    const int64_t r0 = (int64_t)blockIdx.y * 16 * NRT * 16;                     // the row group's first row; 256 NRT rows, BS batch rows
-    for (int e = tid; e < BS * 256 * NRT; e += 1024) {
+    const int64_t r0 = (int64_t)blockIdx.y * 16 * NRT * 16;                     // the row group's first row; 256 NRT rows, `rows` batch rows
+    for (int e = tid; e < rows * 256 * NRT; e += 1024) {
         const int r = e / (256 * NRT), row = e - r * (256 * NRT);
         const float *src = G.partials + (int64_t)r * G.m + r0 + row;
         float sum = 0.f;
         for (int sl = 0; sl < nch; ++sl)
-            sum += __hip_atomic_load(src + (int64_t)sl * BS * G.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sum += __hip_atomic_load(src + (int64_t)sl * rows * G.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         G.y[(int64_t)r * G.m + r0 + row] = sum;
     }
 }
@@ -361,7 +383,7 @@ extern "C" int quipamd_decode_bigp_u(const quipamd_bigp_u_op *ops, int nops, int
 {
     QA_REQUIRE(ops && nops >= 1 && nops <= BG_MAXG, QUIPAMD_ERR_ARG, "decode_bigp_u: 1..%d operators", BG_MAXG);
     QA_REQUIRE(quipamd_decode_bigp_supported(p, 16), QUIPAMD_ERR_UNSUPPORTED, "decode_bigp_u: p = %d (wants p %% 16 == 0, 64 <= p <= %d)", p, 32 * BG_MAXKS);
-    QA_REQUIRE(rows >= 1 && rows <= BG_MAXBS, QUIPAMD_ERR_SHAPE, "decode_bigp_u: 1..%d rows", BG_MAXBS);
+    QA_REQUIRE(rows >= 1 && rows <= BG_MAXROWS, QUIPAMD_ERR_SHAPE, "decode_bigp_u: 1..%d rows", BG_MAXROWS);
     QA_REQUIRE((!clear && clear_n == 0) || (clear && clear_n > 0 && clear_n % 4 == 0 && ((uintptr_t)clear & 15) == 0), QUIPAMD_ERR_ARG,
                "decode_bigp_u: clear wants a 16-byte aligned buffer of a multiple of 4 floats");
     BUArgs A;
@@ -375,9 +397,11 @@ extern "C" int quipamd_decode_bigp_u(const quipamd_bigp_u_op *ops, int nops, int
     A.clear_n4 = clear_n / 4;
     A.p = p;
     A.ks = (p + 31) / 32;
+    A.rows = (int)rows;
     const int nw = (A.ks + 1) / 2;
-    const size_t lds = (size_t)rows * nw * 64 * sizeof(float4);
-    const dim3 grid((unsigned)(p / 16), (unsigned)nops);
+    const int rpg = rows <= BG_MAXBS ? (int)rows : BG_MAXBS;                       // rows per workgroup; more: row groups over grid.z
+    const size_t lds = (size_t)rpg * nw * 64 * sizeof(float4);
+    const dim3 grid((unsigned)(p / 16), (unsigned)nops, (unsigned)((rows + rpg - 1) / rpg));
     hipStream_t s = (hipStream_t)stream;
 #define QA_BU(BS)                                                                                                                    \
     do {                                                                                                                             \
@@ -386,7 +410,7 @@ extern "C" int quipamd_decode_bigp_u(const quipamd_bigp_u_op *ops, int nops, int
             return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_bigp_u: cannot raise dynamic LDS to %zu", lds);                               \
         kern<<<grid, 64 * (nw > BS ? nw : BS), lds, s>>>(A);                                                                                          \
     } while (0)
-    switch ((int)rows) {
+    switch (rpg) {
     case 1: QA_BU(1); break;
     case 2: QA_BU(2); break;
     case 3: QA_BU(3); break;
@@ -405,25 +429,30 @@ extern "C" int quipamd_decode_bigp_v_gemm(const quipamd_bigp_v_gemm_args *a, voi
     QA_REQUIRE(a->bits >= 2 && a->bits <= 4, QUIPAMD_ERR_UNSUPPORTED, "decode_bigp_v_gemm: 2-, 3- or 4-bit qfn-b codes (bits = %d)", a->bits);
     const bool w4 = a->bits != 2;                                                // 3-bit codes ride in the 4-bit container (maxq = 7)
     const float maxq = (float)((1 << a->bits) - 1);
-    QA_REQUIRE(a->rows >= 1 && a->rows <= BG_MAXBS, QUIPAMD_ERR_SHAPE, "decode_bigp_v_gemm: 1..%d rows", BG_MAXBS);
+    QA_REQUIRE(a->rows >= 1 && a->rows <= BG_MAXROWS, QUIPAMD_ERR_SHAPE, "decode_bigp_v_gemm: 1..%d rows", BG_MAXROWS);
     QA_REQUIRE(a->F0 && a->M1 && a->gate && a->qweight && a->scale && a->y && a->ldx >= (int64_t)p * 16 && a->ldx % 8 == 0, QUIPAMD_ERR_ARG,
                "decode_bigp_v_gemm: fragments, M1, input, codes, scale, y wanted; ldx >= n, ldx %% 8 == 0");
     QA_REQUIRE(a->m > 0 && a->m % 256 == 0, QUIPAMD_ERR_SHAPE, "decode_bigp_v_gemm: m %% 256 == 0");
     int nrt = a->row_tiles_per_wave;
     if (nrt == 0) nrt = a->m % 1024 == 0 ? 4 : a->m % 512 == 0 ? 2 : 1;
+    if (w4 && a->rows > 4 && nrt == 4) nrt = 2;                                  // (registers: see QA_BV)
     QA_REQUIRE((nrt == 1 || nrt == 2 || nrt == 4) && a->m % (256 * nrt) == 0, QUIPAMD_ERR_ARG, "decode_bigp_v_gemm: row_tiles_per_wave 0 / 1 / 2 / 4 with m %% (256 x it) == 0");
     QA_REQUIRE((a->partials == nullptr) == (a->arrived == nullptr), QUIPAMD_ERR_ARG, "decode_bigp_v_gemm: partials and arrived go together (both null: atomics)");
     BVArgs A{(const uint4 *)a->F0, a->M1, (const uint16_t *)a->gate, (const uint16_t *)a->up, a->ldx, (const uint4 *)a->qweight, a->scale, a->y, a->m, p, (p + 31) / 32,
-             a->partials, a->arrived};
-    const int nwp = (A.ks + 1) / 2, bs = (int)a->rows;
+             (int)a->rows, a->partials, a->arrived};
+    const int nwp = (A.ks + 1) / 2, bs = a->rows <= 4 ? (int)a->rows : a->rows <= 8 ? 8 : 16;        // the kernel's row count: 1..4, 8, 16
     // c0 = maxq / 2 (2 bits: the per-field offsets are subtracted as sum OFF_k x~_k; 4-bit container: + the uniform offset 16)
     const float two_over_maxq = 2.0f / maxq, c0 = 0.5f * maxq + (w4 ? 16.0f : 0.0f);
     const dim3 grid((unsigned)(p / 16), (unsigned)(a->m / (256 * nrt)));
     hipStream_t s = (hipStream_t)stream;
 #define QA_BV(BS, NRT, GT)                                                                                                           \
     do {                                                                                                                             \
-        auto kern = w4 ? bigp_v_gemm_kernel<BS, NRT, GT, 4> : bigp_v_gemm_kernel<BS, NRT, GT, 2>;                                    \
-        const size_t lds = (size_t)BG_MAXBS * 264 * 2 + 32 + (size_t)16 * NRT * 64 * 4 + (size_t)BS * nwp * 64 * sizeof(float4);     \
+        /* (the 4-bit container with 16 rows AND 4 row tiles per wave does not fit the register file -- 20 bytes of scratch; the host  \
+            picks 2 tiles per wave there, so that combination is never instantiated) */                                               \
+        constexpr int B4_ = (BS > 4 && NRT == 4) ? 2 : 4;                                                                            \
+        auto kern = w4 ? bigp_v_gemm_kernel<BS, NRT, GT, B4_> : bigp_v_gemm_kernel<BS, NRT, GT, 2>;                                  \
+        constexpr int XR_ = BS <= 4 ? BG_MAXBS : BG_MAXROWS, RG_ = BS < 4 ? BS : 4;                                                   \
+        const size_t lds = (size_t)XR_ * 264 * 2 + 2 * XR_ * 4 + (size_t)16 * NRT * XR_ * 16 * 4 + (size_t)RG_ * nwp * 64 * sizeof(float4); \
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_bigp_v_gemm: cannot raise dynamic LDS to %zu", lds);                          \
         kern<<<grid, 1024, lds, s>>>(A, two_over_maxq, c0);                                                                          \
@@ -440,7 +469,9 @@ extern "C" int quipamd_decode_bigp_v_gemm(const quipamd_bigp_v_gemm_args *a, voi
         case 1: QA_BV_N(1, GT); break;                                                                                               \
         case 2: QA_BV_N(2, GT); break;                                                                                               \
         case 3: QA_BV_N(3, GT); break;                                                                                               \
-        default: QA_BV_N(4, GT); break;                                                                                              \
+        case 4: QA_BV_N(4, GT); break;                                                                                               \
+        case 8: QA_BV_N(8, GT); break;                                                                                               \
+        default: QA_BV_N(16, GT); break;                                                                                             \
         }                                                                                                                            \
     } while (0)
     if (a->up) QA_BV_B(true);

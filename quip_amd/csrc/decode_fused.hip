@@ -113,7 +113,11 @@ __device__ __forceinline__ float fg_block_sum(float v, float *red)
 // YF32: u_y is fp32 (the accumulator of quipamd_decode_bigp_v_gemm) and is rounded to fp16 on load -- what a cast launch in between would do.
 // BITS: 2, or 4 (the 4-bit STREAM container: --wbits 4 and, with maxq = 7, --wbits 3): a 1 KiB tile is then 16 rows x 128 columns, a wave owns
 // twice as many chunks of the same K range, the conversion is the uniform-offset one (value = 16 + code).
-template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT, bool YF32 = false, int BITS = 2>
+// OPS (round 5: more than FG_MAXBS rows per step): the prologue ALONE, one workgroup per (batch row, layer group) -- grid (bs, ngroups);
+// x~ of the row goes to global memory (Gg.y = f16 [bs, N], image order) instead of the LDS operand of the MFMAs, no weights are read, and
+// the dequant-GEMM is the next launch (quipamd_dequant_gemm_grouped on the same decode-order codes: the weights stream ONCE for all rows).
+// A workgroup that repeats the prologue for every row (the loop below) costs ~2 us per extra row; 16 rows as 16 workgroups cost one.
+template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT, bool YF32 = false, int BITS = 2, bool OPS = false>
 __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two_over_maxq, float c0)
 {
     typedef PassDims<P, Q> D;
@@ -156,6 +160,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     const uint32_t rt0 = blockIdx.x * (RT * NRT) + r;                          // row tile of iteration k: rt0 + k RT
     const uint32_t rtmax = (uint32_t)(G.m / 16) - 1;                           // (the last workgroup of a ragged launch re-reads the last tile; its rows are not stored)
     const int bs = G.bs;
+    const int b_lo = OPS ? (int)blockIdx.x : 0, b_hi = OPS ? b_lo + 1 : bs;     // the batch rows this workgroup's prologue walks
     FG_STAMP(0);
 
     // ---- every operand of the prologue is requested NOW, in the order the phases consume them; the packed weights go LAST: vector
@@ -232,20 +237,21 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
             if (v4 < N / 4) xr[u] = *reinterpret_cast<const uint2 *>((G.x + (int64_t)b * G.ldx) + (uint32_t)(4 * v4));
         }
     };
-    if (HAS_U) load_u_row(0);
-    else load_x_row(0);
+    if (HAS_U) load_u_row(b_lo);
+    else load_x_row(b_lo);
     // everything the FIRST phase needs is in the memory pipeline of every wave before anything else is requested: the CU has one
     // vector-memory path (~64 B per clock) and the prologue pulls 100 - 350 KiB through it; without this barrier (no memory wait in
     // it, the waves arrive within a few cycles) wave 15's activations queued behind the other waves' factor fragments
     __syncthreads();
     if (HAS_U && EARLY) {
         load_u_frags();
-        load_u_side(0);
+        load_u_side(b_lo);
     }
     if (EARLY || !HAS_U) {
         load_v_side();
         load_v_frags();
     }
+    if constexpr (!OPS) {
 #pragma unroll
     for (int k = 0; k < NRT; ++k)
 #pragma unroll
@@ -254,13 +260,14 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
             const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Gg.qw + ((uint64_t)rtk * NCH + (slot * CPW + i)) * 64 + lane));
             w[k][i] = make_uint4(t[0], t[1], t[2], t[3]);
         }
-    const float e_sc = Gg.scale[0];                                             // needed by the reducer only
+    }
+    const float e_sc = OPS ? 0.f : Gg.scale[0];                                 // needed by the reducer only
 
-    for (int b = 0; b < bs; ++b) {
+    for (int b = b_lo; b < b_hi; ++b) {
         float4 tv[NV];
         if (HAS_U) {
             // ---- t = [relu](U^T y + bias + residual) --------------------------------------------------------------------------------
-            if (b > 0) {
+            if (b > b_lo) {
                 load_u_row(b);
                 if (EARLY && HAS_RES) {
 #pragma unroll
@@ -296,12 +303,12 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                     uint2 pk;                                                    // the residual stream is fp16: everything downstream sees the rounded value
                     pk.x = pack_f16x2(t.x, t.y);
                     pk.y = pack_f16x2(t.z, t.w);
-                    if (G.t_out && blockIdx.x == 0 && gi == 0) *reinterpret_cast<uint2 *>((G.t_out + (int64_t)b * G.ld_t) + (uint32_t)(4 * v4)) = pk;
+                    if (G.t_out && (OPS || blockIdx.x == 0) && gi == 0) *reinterpret_cast<uint2 *>((G.t_out + (int64_t)b * G.ld_t) + (uint32_t)(4 * v4)) = pk;
                     tv[u] = f16x4_to_f32(pk);
                 }
             }
         } else {
-            if (b > 0) load_x_row(b);
+            if (b > b_lo) load_x_row(b);
 #pragma unroll
             for (int u = 0; u < NV; ++u) tv[u] = f16x4_to_f32(xr[u]);
         }
@@ -376,18 +383,26 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         FG_STAMP(9);
         __syncthreads();
         FG_STAMP(10);
-        const XtSums xp = mix_stage2_xt<P, Q, 16, ME>(Z1, XT + (size_t)b * XTS, frV, wave, lane);   // x~ in image order = the order of the weights' columns
-        const float xs1 = fg_wave_sum(xp.s1);
-        if (lane == 0) red[2 * FG_NW + b * FG_NW + wave] = xs1;                // waves without tiles publish 0
-        if constexpr (ME) {
-            const float xso = fg_wave_sum(xp.soff);
-            if (lane == 0) red[(2 + FG_MAXBS) * FG_NW + b * FG_NW + wave] = xso;
+        const XtSums xp = mix_stage2_xt<P, Q, 16, ME>(Z1, XT + (size_t)(b - b_lo) * XTS, frV, wave, lane);   // x~ in image order = the order of the weights' columns
+        if constexpr (!OPS) {
+            const float xs1 = fg_wave_sum(xp.s1);
+            if (lane == 0) red[2 * FG_NW + b * FG_NW + wave] = xs1;            // waves without tiles publish 0
+            if constexpr (ME) {
+                const float xso = fg_wave_sum(xp.soff);
+                if (lane == 0) red[(2 + FG_MAXBS) * FG_NW + b * FG_NW + wave] = xso;
+            }
         }
         FG_STAMP(11);
         __syncthreads();                                                        // x~ row complete; ZT / Z1 free for the next row (or park)
         FG_STAMP(12);
     }
 
+    if constexpr (OPS) {                                                        // the row's x~ leaves as it lies in XT: 16-byte chunks, coalesced
+        uint16_t *dst = reinterpret_cast<uint16_t *>(Gg.y) + (int64_t)b_lo * N;
+        for (int c = tid; c < N / 8; c += 1024) *reinterpret_cast<uint4 *>(dst + 8 * c) = *reinterpret_cast<const uint4 *>(XT + 8 * c);
+        (void)w; (void)e_sc; (void)rt0; (void)rtmax; (void)qc; (void)park; (void)two_over_maxq; (void)c0; (void)slot; (void)r; (void)j; (void)g;
+        return;
+    }
     // ---- dequant + MFMA: this wave's CPW chunks of 256 columns x 16 rows -------------------------------------------------------------
     // MFMA column j = batch row j.  Columns are independent (D[m][n] depends on B[:, n] only), so lanes of columns >= bs may read
     // anything: they read row j % 4 of x~ (allocated, possibly never written) and their results are not stored -- no masking.
@@ -651,11 +666,11 @@ template <int P, int Q, int NRT> constexpr size_t fused_lds()
 
 thread_local float g_fused_maxq = 3.f;      // set by the entry point right before the dispatch (same thread): 3, 7 (3-bit codes in the 4-bit container) or 15
 
-template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT, bool YF32 = false, int BITS = 2>
+template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT, bool YF32 = false, int BITS = 2, bool OPS = false>
 int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
 {
     const size_t lds = fused_lds<P, Q, NRT>();
-    auto kern = fused_gemm_kernel<P, Q, HAS_U, HAS_RES, NORM, RT, CPW, NRT, YF32, BITS>;
+    auto kern = fused_gemm_kernel<P, Q, HAS_U, HAS_RES, NORM, RT, CPW, NRT, YF32, BITS, OPS>;
     static QaPerDevice attr;
     const int d = attr.dev();
     if (d < 0 || !attr.done[d]) {
@@ -664,9 +679,32 @@ int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
         if (d >= 0) attr.done[d] = true;
     }
     const float maxq = g_fused_maxq;
-    kern<<<dim3((unsigned)((A.m / 16 + RT * NRT - 1) / (RT * NRT)), (unsigned)ngroups), 1024, lds, s>>>(A, 2.0f / maxq, 0.5f * maxq);
+    const unsigned gx = OPS ? (unsigned)A.bs : (unsigned)((A.m / 16 + RT * NRT - 1) / (RT * NRT));
+    kern<<<dim3(gx, (unsigned)ngroups), 1024, lds, s>>>(A, 2.0f / maxq, 0.5f * maxq);
     QA_LAUNCH_CHECK("quipamd_decode_fused_gemm");
     return QUIPAMD_OK;
+}
+
+// the prologue-only launches (OPS): the combinations of dispatch_fused at the base tiling of each operator shape; the code container does
+// not matter (no weights are read)
+template <int P, int Q, int RT, int CPW>
+int dispatch_ops(const FusedArgs &A, bool u, bool res, int norm, bool yf32, int ngroups, hipStream_t s)
+{
+    if constexpr (P == 64 && Q == 64) {
+        if (yf32) return launch_fused<P, Q, true, true, 2, RT, CPW, 1, true, 2, true>(A, ngroups, s);
+    }
+    if constexpr (P == 128) {
+        if (u && !res && norm == 0) return launch_fused<P, Q, true, false, 0, RT, CPW, 1, false, 2, true>(A, ngroups, s);
+        if (!u && norm == 0) return launch_fused<P, Q, false, false, 0, RT, CPW, 1, false, 2, true>(A, ngroups, s);
+    } else {
+        if (u && res) return norm == 0 ? launch_fused<P, Q, true, true, 0, RT, CPW, 1, false, 2, true>(A, ngroups, s)
+                           : norm == 1 ? launch_fused<P, Q, true, true, 1, RT, CPW, 1, false, 2, true>(A, ngroups, s)
+                                       : launch_fused<P, Q, true, true, 2, RT, CPW, 1, false, 2, true>(A, ngroups, s);
+        if (!u) return norm == 0 ? launch_fused<P, Q, false, false, 0, RT, CPW, 1, false, 2, true>(A, ngroups, s)
+                     : norm == 1 ? launch_fused<P, Q, false, false, 1, RT, CPW, 1, false, 2, true>(A, ngroups, s)
+                                 : launch_fused<P, Q, false, false, 2, RT, CPW, 1, false, 2, true>(A, ngroups, s);
+    }
+    return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm (ops only): %d x %d has no kernel for (U %d, residual %d, norm %d)", P, Q, (int)u, (int)res, norm);
 }
 
 // the combinations a decoder block needs (each is a 1300-line kernel):
@@ -696,7 +734,8 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
     const bool w4 = a->bits != 2;                                               // 3-bit codes ride in the 4-bit container (maxq = 7)
     g_fused_maxq = (float)((1 << a->bits) - 1);
     QA_REQUIRE(a->ngroups >= 1 && a->ngroups <= FG_MAXG, QUIPAMD_ERR_ARG, "decode_fused_gemm: 1..%d groups", FG_MAXG);
-    QA_REQUIRE(a->bs >= 0 && a->bs <= FG_MAXBS, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: bs %lld > %d", (long long)a->bs, FG_MAXBS);
+    const bool ops_only = a->ops_only != 0;
+    QA_REQUIRE(a->bs >= 0 && a->bs <= (ops_only ? 1024 : FG_MAXBS), QUIPAMD_ERR_SHAPE, "decode_fused_gemm: bs %lld > %d", (long long)a->bs, ops_only ? 1024 : FG_MAXBS);
     if (a->bs == 0) return QUIPAMD_OK;
     const int p = a->V[0].p, q = a->V[0].q;
     const int64_t n = (int64_t)p * q;
@@ -723,7 +762,7 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
     }
     for (int i = 0; i < FG_MAXG; ++i) {
         const int k = i < a->ngroups ? i : 0;
-        QA_REQUIRE(fop_ok(a->V[k], p, q) && a->colscale[k] && a->qweight[k] && a->scale[k] && a->y[k], QUIPAMD_ERR_ARG,
+        QA_REQUIRE(fop_ok(a->V[k], p, q) && a->colscale[k] && (ops_only || (a->qweight[k] && a->scale[k])) && a->y[k], QUIPAMD_ERR_ARG,
                    "decode_fused_gemm: null pointer / operator shape in group %d", k);
         A.g[i].V = a->V[k]; A.g[i].colscale = a->colscale[k]; A.g[i].qw = (const uint4 *)a->qweight[k]; A.g[i].scale = a->scale[k]; A.g[i].y = a->y[k];
     }
@@ -732,8 +771,15 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
     const bool yf32 = u && a->u_y_dtype == QUIPAMD_F32;
     QA_REQUIRE(!u || yf32 || a->u_y_dtype == QUIPAMD_F16, QUIPAMD_ERR_ARG, "decode_fused_gemm: u_y_dtype f16 or f32");
     // fp32 u_y = the accumulator of quipamd_decode_bigp_v_gemm: Llama's down_proj -> next block's q / k / v
-    QA_REQUIRE(!yf32 || (p == 64 && q == 64 && res && a->norm == 2 && !w4), QUIPAMD_ERR_UNSUPPORTED,
+    QA_REQUIRE(!yf32 || (p == 64 && q == 64 && res && a->norm == 2 && (!w4 || ops_only)), QUIPAMD_ERR_UNSUPPORTED,
                "decode_fused_gemm: fp32 u_y has a kernel for 2-bit 64 x 64 with residual and RMSNorm only");
+    if (ops_only) {                                                              // y[k] = x~ of group k, f16 [bs, n]
+        QA_REQUIRE(!a->t_out || a->has_u, QUIPAMD_ERR_ARG, "decode_fused_gemm (ops only): t_out needs the output-side operator");
+        if (p == 64 && q == 32) return dispatch_ops<64, 32, 2, 1>(A, u, res, a->norm, yf32, a->ngroups, s);
+        if (p == 64 && q == 64) return dispatch_ops<64, 64, 1, 1>(A, u, res, a->norm, yf32, a->ngroups, s);
+        if (p == 128 && q == 64) return dispatch_ops<128, 64, 1, 2>(A, u, res, a->norm, yf32, a->ngroups, s);
+        return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "decode_fused_gemm (ops only): operator %d x %d (64 x 32, 64 x 64, 128 x 64)", p, q);
+    }
     if (p == 64 && q == 32) {
         QA_REQUIRE(a->m > 0 && a->m % 32 == 0, QUIPAMD_ERR_SHAPE, "decode_fused_gemm: m %% 32 (m = %lld)", (long long)a->m);
         if (w4) return dispatch_fused<64, 32, 2, 2, 1, 4>(A, u, res, a->norm, a->ngroups, s);

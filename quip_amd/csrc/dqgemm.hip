@@ -715,7 +715,6 @@ static int dequant_gemm_impl(int ngroups, const void *const *x, int x_dtype, con
     QA_REQUIRE(ngroups >= 1 && ngroups <= 4, QUIPAMD_ERR_ARG, "dequant_gemm: 1..4 problems per call");
     QA_REQUIRE(x_dtype == QUIPAMD_BF16 || x_dtype == QUIPAMD_F16, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: x must be bf16 or fp16");
     QA_REQUIRE(y_dtype == x_dtype || y_dtype == QUIPAMD_F32, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: y must be f32 or x's dtype");
-    QA_REQUIRE(x_dtype == QUIPAMD_BF16 || ngroups == 1, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm_grouped: x must be bf16");
     QA_REQUIRE(!accumulate || y_dtype == QUIPAMD_F32, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: accumulate needs f32 y");
     QA_REQUIRE(layout == QUIPAMD_LAYOUT_STREAM, QUIPAMD_ERR_UNSUPPORTED,
                "dequant_gemm: qweight must be in STREAM layout (repack with quipamd_unpack/quipamd_pack)");
@@ -746,6 +745,36 @@ static int dequant_gemm_impl(int ngroups, const void *const *x, int x_dtype, con
         for (int i = 0; i < 4; ++i) c.cfg[i] = g_k2_cfg[i];
         const int rc = k2v2_launch(c, stream);
         if (rc != K2V2_NOT_TAKEN) return rc;
+    }
+    if (ngroups > 1 && x_dtype == QUIPAMD_F16 && !(tuned_old && g_k2_cfg[0] == 0)) {
+        // fp16 activations exist only in the second-generation kernels: 2..3 problems of one shape as ONE launch of the grouped h kernel
+        // (dq_hg_kernel: the same body text as dq_h_kernel, the problem picked by blockIdx.y) where it holds the shape, else one launch
+        // per problem.  (Routing dq_h_kernel's OWN arguments through a reference was tried first: hipcc's register allocation moved and
+        //  tests/test_k2_isa.py caught a copy of an asm load's destination ahead of its wait in the ungrouped instantiation.)
+        K2Call cs[4];
+        for (int gi = 0; gi < ngroups; ++gi) {
+            K2Call &c = cs[gi];
+            c.x = x[gi]; c.x_dtype = x_dtype; c.qweight = qweight[gi]; c.bits = bits; c.qfn = qfn; c.maxq = grid_maxq;
+            c.scale = G.scale[gi]; c.zero = G.zero[gi]; c.bias = G.bias[gi]; c.y = y[gi]; c.y_dtype = y_dtype; c.accumulate = accumulate;
+            c.bs = bs; c.m = m; c.d = d;
+            for (int i = 0; i < 4; ++i) c.cfg[i] = 0;
+        }
+        if (ngroups <= 3 && qfn == QUIPAMD_QFN_B) {
+            const int rc = k2v2_launch_grouped(cs, ngroups, stream);
+            if (rc != K2V2_NOT_TAKEN) return rc;
+        }
+        for (int gi = 0; gi < ngroups; ++gi) {
+            K2Call c;
+            c.x = x[gi]; c.x_dtype = x_dtype; c.qweight = qweight[gi]; c.bits = bits; c.qfn = qfn; c.maxq = grid_maxq;
+            c.scale = G.scale[gi]; c.zero = G.zero[gi]; c.bias = G.bias[gi]; c.y = y[gi]; c.y_dtype = y_dtype; c.accumulate = accumulate;
+            c.bs = bs; c.m = m; c.d = d;
+            for (int i = 0; i < 4; ++i) c.cfg[i] = 0;
+            const int rc = k2v2_launch(c, stream);
+            QA_REQUIRE(rc != K2V2_NOT_TAKEN, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm_grouped: no fp16 kernel for this shape (m=%lld d=%lld bs=%lld)",
+                       (long long)m, (long long)d, (long long)bs);
+            if (rc != QUIPAMD_OK) return rc;
+        }
+        return QUIPAMD_OK;
     }
     QA_REQUIRE(x_dtype == QUIPAMD_BF16, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: the round-1 kernels are bf16 only");
     EpiArgs e;

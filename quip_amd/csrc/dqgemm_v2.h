@@ -106,149 +106,19 @@ struct K2Args {
 template <int BITS, class ACT, int RT, int NW, int NCH, bool HALF, bool EXACT>   // HALF: bs <= 8; EXACT: d / KC == NW * NCH
 __global__ __launch_bounds__(64 * NW) void dq_h_kernel(K2Args A)
 {
-    typedef DeqT<BITS, ACT> Q;
-    constexpr int KC = Q::KC, NT = Q::NT;
-    constexpr int ROWB = KC * 2, NCB = ROWB / 128, NI = 2 * NCB, XB = 16 * ROWB;
-    // (negative result, profiles/r02d_k2lab.log: loading half of the B fragments straight into registers, to use a second
-    //  return path beside the ~28 B/clk/CU LDS-DMA path, made the launch 0.9 us SLOWER)
-    constexpr int NDMA = HALF ? NI / 2 : NI, OPC = RT + NDMA;         // vector-memory operations per chunk
-    static_assert((NCH - 1) * OPC < 64, "vmcnt range");
-    static_assert(RT * 1024 + 64 <= NCH * XB, "a wave parks its partials in its own slab region");
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [NW][NCH] slabs; a wave parks its partials in its own
-    const EpiArgs &e = A.e;
-    // (round 3, negative result, scripts/k2_ab.sh on one box, alternating runs: fetching every kernarg field in ONE scalar round trip
-    //  up front -- the fix that took 2000 cycles off the prologue of csrc/decode_fused.hip -- makes THIS kernel 0.13 us slower, 5.13 vs
-    //  4.98 us at K = 20 and 4.92 vs 4.79 at K = 2000: its lazily fetched fields already let the weight loads go out after the first
-    //  two s_loads, and waiting for all fifteen delays them)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    K2_STAMP(0);
-    const int j = lane & 15, g = lane >> 4;
-    const uint32_t nkc = (uint32_t)(A.d / KC);
-    const uint32_t rt0 = blockIdx.x * RT;
-    const uint32_t rowbytes = (uint32_t)A.d * 2u;
-    char *myreg = smem + wave * (NCH * XB);
+#include "dq_h_body.inc"
+}
 
-    // reducer role u = 4*r2 + q (below); the epilogue parameters of this wave's first role are requested now
-    float e_sc = 0.f, e_zr = 0.f, e_bi = 0.f;
-    if (wave < 4 * RT) {
-        const int64_t row = (int64_t)(rt0 + (wave >> 2)) * 16 + (lane & 15);
-        e_sc = e.qfn == QUIPAMD_QFN_B ? e.scale[0] : e.scale[row];
-        if (e.qfn != QUIPAMD_QFN_B) e_zr = e.zero[row];
-        if (e.bias) e_bi = e.bias[row];
-    }
-
-    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.x, 0, (int)(e.bs * (int64_t)rowbytes), 0x00020000);
-    const uint32_t voff_lo = (lane >> 3) * rowbytes + ((uint32_t)((lane & 7) ^ (lane >> 3)) << 4);
-    const uint32_t voff_hi = voff_lo + 8u * rowbytes;
-    const uint32_t rd_base = lds_addr(myreg) + (j >> 3) * 1024 + (j & 7) * 128;
-    const uint32_t rd0 = rd_base + (((0 + g) ^ (j & 7)) << 4);        // even MFMA steps
-    const uint32_t rd1 = rd_base + (((4 + g) ^ (j & 7)) << 4);        // odd MFMA steps
-
-    auto chunk_of = [&](int i) -> uint32_t { return i * NW + wave; };
-    // ---- request everything --------------------------------------------------------------------------------------------
-    u32x4 w[NCH][RT];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const uint32_t kc = chunk_of(i);
-        if (EXACT || kc < nkc) {                                      // wave-uniform
-#pragma unroll
-            for (int r = 0; r < RT; ++r) load_w_nt(w[i][r], A.qw + ((uint64_t)(rt0 + r) * nkc + kc) * 64 + lane);
-#pragma unroll
-            for (int q = 0; q < NI; ++q) {
-                if ((q & 1) && HALF) continue;                        // rows 8..15 of a slab feed batch columns never stored
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void2_t *)(myreg + i * XB + q * 1024), 16, (q & 1) ? voff_hi : voff_lo,
-                                                         kc * ROWB + (q >> 1) * 128, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < RT; ++r) w[i][r] = u32x4{0u, 0u, 0u, 0u};
-        }
-    }
-
-    K2_STAMP(1);
-    // two accumulator chains each (even / odd MFMA steps): a dependent MFMA behind other instructions costs ~60 cycles
-    // (MI355X_MICROARCH.md "one EXTRA issue slot between two MFMAs on the SAME accumulator"), an independent one 16
-    f32x4_t acc[RT][2], accx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int r = 0; r < RT; ++r) acc[r][0] = acc[r][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const u32x4 ones = {opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES)};
-    static_for<NCH>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        const uint32_t kc = chunk_of(i);
-        if (EXACT || kc < nkc) {
-            constexpr int NWAIT = EXACT ? (NCH - 1 - i) * OPC : 0;    // ragged K: everything, then compute
-            if constexpr (RT == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[i][0]) : "n"(NWAIT) : "memory");
-            else if constexpr (RT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[i][0]), "+v"(w[i][1]) : "n"(NWAIT) : "memory");
-            else {
-                static_assert(RT == 1 || RT == 2 || RT == 4, "row tiles per wave");
-                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[i][0]), "+v"(w[i][1]), "+v"(w[i][2]), "+v"(w[i][RT - 1]) : "n"(NWAIT) : "memory");
-            }
-            if constexpr (i == 0) K2_STAMP(2);
-            if constexpr (i == NCH - 1) K2_STAMP(3);
-            u32x4 xf[NT];
-            static_for<NT>([&](auto T) {
-                constexpr int t = decltype(T)::value;
-                lds_read16<i * XB + (t >> 1) * 2048>(xf[t], (t & 1) ? rd1 : rd0);
-            });
-            wait_lgkm(xf);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-#pragma unroll
-                for (int r = 0; r < RT; ++r) acc[r][t & 1] = ACT::mfma(Q::frag(w[i][r], t), xf[t], acc[r][t & 1]);
-                accx[t & 1] = ACT::mfma(ones, xf[t], accx[t & 1]);   // row sums of x on the matrix pipe: D[.][b] = sum_k x[b,k]
-            }
-        }
-    });
-    K2_STAMP(4);
-
-    // ---- meet: the NW k-partials of every tile ---------------------------------------------------------------------------
-    {
-        float *p = reinterpret_cast<float *>(myreg);                  // [RT][4][64] accumulator components, then [16] row sums
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const f32x4_t a = acc[r][0] + acc[r][1];
-            p[r * 256 + lane] = a[0]; p[r * 256 + 64 + lane] = a[1];
-            p[r * 256 + 128 + lane] = a[2]; p[r * 256 + 192 + lane] = a[3];
-        }
-        if (lane < 16) p[RT * 256 + lane] = accx[0][0] + accx[1][0];
-    }
-    K2_STAMP(5);
-    __syncthreads();
-    K2_STAMP(6);
-    // 4*RT reducer roles; role u = 4*r2 + q finishes batch rows 4q .. 4q+3 x the 16 weight rows of tile r2: lane l -> batch
-    // row b = 4q + (l>>4), weight row l&15 (16 consecutive outputs of y per 16 lanes) = accumulator component (l&3) of MFMA
-    // lane b + 16*((l&15)>>2)
-    asm volatile("" : "+v"(e_sc), "+v"(e_zr), "+v"(e_bi));            // keep the epilogue arithmetic (and its vmcnt wait) down here
-#pragma unroll 1
-    for (int u = wave; u < 4 * RT; u += NW) {
-        const int r2 = u >> 2, q = u & 3;
-        const int b = 4 * q + (lane >> 4), wr = lane & 15;
-        const int src = r2 * 256 + (wr & 3) * 64 + b + 16 * (wr >> 2);
-        float a = 0.f, xsum = 0.f;
-#pragma unroll
-        for (int v = 0; v < NW; ++v) {
-            const float *p = reinterpret_cast<const float *>(smem + v * (NCH * XB));
-            a += p[src];
-            xsum += p[RT * 256 + b];
-        }
-        const int64_t row = (int64_t)(rt0 + r2) * 16 + wr;
-        if (b < e.bs) {
-            if (u != wave) {                                          // fewer waves than reducer roles
-                e_sc = e.qfn == QUIPAMD_QFN_B ? e.scale[0] : e.scale[row];
-                e_zr = e.qfn == QUIPAMD_QFN_B ? 0.f : e.zero[row];
-                e_bi = e.bias ? e.bias[row] : 0.f;
-            }
-            const float alpha = e.qfn == QUIPAMD_QFN_B ? e_sc * e.two_over_maxq : e_sc;
-            const float c0 = e.qfn == QUIPAMD_QFN_B ? Q::OFF + 0.5f * (float)e.maxq : Q::OFF + e_zr;
-            const float val = alpha * (a - c0 * xsum) + e_bi;
-            const int64_t o = (int64_t)b * e.m + row;
-            if (e.y_f32) ((float *)e.y)[o] = e.accumulate ? ((float *)e.y)[o] + val : val;
-            else ((uint16_t *)e.y)[o] = e.y_f16 ? f32_to_f16_bits(val) : f32_to_bf16_bits(val);
-        }
-    }
-    K2_STAMP(7);
-    K2_STAMP_FLUSH();
+// up to three problems of ONE shape in one launch (blockIdx.y picks; q / k / v, gate / up of a decode step with 5..16 rows: round 5).  The
+// arguments of the picked problem are COPIED out of the kernarg segment first; the body is the same text as dq_h_kernel's.
+struct K2GArgs {
+    K2Args g[3];
+};
+template <int BITS, class ACT, int RT, int NW, int NCH, bool HALF, bool EXACT>
+__global__ __launch_bounds__(64 * NW) void dq_hg_kernel(K2GArgs G)
+{
+    const K2Args A = G.g[blockIdx.y];
+#include "dq_h_body.inc"
 }
 
 template <int BITS, class ACT, int RT, int NW, int NCH, bool HALF, bool EXACT>
@@ -265,6 +135,29 @@ int launch_h2(const K2Args &A, hipStream_t s)
     QA_LAUNCH_CHECK("quipamd_dequant_gemm(h)");
     return QUIPAMD_OK;
 }
+template <int BITS, class ACT, int RT, int NW, int NCH, bool HALF, bool EXACT>
+int launch_h2g(const K2GArgs &G, int ngroups, hipStream_t s)
+{
+    typedef DeqT<BITS, ACT> Q;
+    constexpr size_t lds = (size_t)NW * NCH * 16 * Q::KC * 2;
+    auto kern = dq_hg_kernel<BITS, ACT, RT, NW, NCH, HALF, EXACT>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return qa_fail(QUIPAMD_ERR_LAUNCH, "dequant_gemm_grouped: cannot raise dynamic LDS to %zu", lds);
+    kern<<<dim3((unsigned)(G.g[0].e.m / 16 / RT), (unsigned)ngroups), 64 * NW, lds, s>>>(G);
+    QA_LAUNCH_CHECK("quipamd_dequant_gemm_grouped(h)");
+    return QUIPAMD_OK;
+}
+template <int BITS, class ACT, int RT, int NW, int NCH>
+int launch_hg(const K2GArgs &G, int ngroups, hipStream_t s)
+{
+    const K2Args &A = G.g[0];
+    const bool exact = A.d / (512 / BITS) == NW * NCH;
+    if (A.e.bs <= 8)
+        return exact ? launch_h2g<BITS, ACT, RT, NW, NCH, true, true>(G, ngroups, s) : launch_h2g<BITS, ACT, RT, NW, NCH, true, false>(G, ngroups, s);
+    return exact ? launch_h2g<BITS, ACT, RT, NW, NCH, false, true>(G, ngroups, s) : launch_h2g<BITS, ACT, RT, NW, NCH, false, false>(G, ngroups, s);
+}
+
 // requires (m / 16) % RT == 0, bs <= 16, d / KC <= NW * NCH
 template <int BITS, class ACT, int RT, int NW, int NCH>
 int launch_h(const K2Args &A, hipStream_t s)

@@ -62,6 +62,10 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
             else if (r8 * 8 < r7 * 7) { p1 = 8; p2 = 1; }
             else { p1 = 7; p2 = 2; }
         }
+        // short and wide (few row tiles, K beyond one LDS pass: OPT's fc2, 2048 x 8192, in a 5..16-row decode step): 4 tiles per workgroup
+        // leave 32 workgroups on 256 CUs (12.3 us, profiles/r05c); one or two tiles per workgroup with K over 8 / 4 waves fill 128 / 64
+        if (p1 == 1 && p2 == 8) return launch_s<BITS, ACT, 1, 8, 1, 2>(A, s);
+        if (p1 == 2 && p2 == 4) return launch_s<BITS, ACT, 2, 4, 1, 3>(A, s);
         if (p1 == 7 && p2 == 2) return launch_s<BITS, ACT, 7, 2, 1, 3>(A, s);
         if (p1 == 4 && p2 == 2) return launch_s<BITS, ACT, 4, 2, 1, 4>(A, s);
         if (p1 == 8 && p2 == 1) return launch_s<BITS, ACT, 8, 1, 2, 3>(A, s);
@@ -81,6 +85,29 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
 }
 
 }   // namespace
+
+static void k2_fill(K2Args &A, const K2Call &c)
+{
+    A.x = (const uint16_t *)c.x; A.qw = (const u32x4 *)c.qweight; A.d = c.d;
+    EpiArgs &e = A.e;
+    e.scale = c.scale; e.zero = c.zero; e.bias = c.bias; e.y = c.y; e.qfn = c.qfn; e.maxq = c.maxq;
+    e.two_over_maxq = 2.0f / (float)c.maxq;
+    e.y_f32 = c.y_dtype == QUIPAMD_F32; e.y_f16 = c.y_dtype == QUIPAMD_F16; e.accumulate = c.accumulate; e.bs = c.bs; e.m = c.m;
+}
+
+int k2v2_launch_grouped(const K2Call *calls, int ngroups, void *stream)
+{
+    const K2Call &c = calls[0];
+    const int64_t nkc = c.d / (512 / c.bits);
+    // the shapes a decode step groups: fp16, <= 16 rows, K within one LDS pass; the h kernel's own limit of 768 row tiles per problem
+    if (ngroups < 2 || ngroups > 3 || c.x_dtype != QUIPAMD_F16 || c.bs > 16 || nkc > (c.bits == 2 ? 16 : 32) || c.accumulate || c.m / 16 > 768)
+        return K2V2_NOT_TAKEN;
+    K2GArgs G;
+    for (int i = 0; i < 3; ++i) k2_fill(G.g[i], calls[i < ngroups ? i : 0]);
+    hipStream_t s = (hipStream_t)stream;
+    if (c.bits == 2) return nkc <= 8 ? launch_hg<2, ActF16, 1, 8, 1>(G, ngroups, s) : launch_hg<2, ActF16, 1, 8, 2>(G, ngroups, s);
+    return nkc <= 16 ? launch_hg<4, ActF16, 1, 8, 2>(G, ngroups, s) : launch_hg<4, ActF16, 1, 8, 4>(G, ngroups, s);
+}
 
 int k2v2_launch(const K2Call &c, void *stream)
 {

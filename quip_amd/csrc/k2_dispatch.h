@@ -18,3 +18,6 @@ struct K2Call {
 // returns K2V2_NOT_TAKEN (use the round-1 kernels), QUIPAMD_OK, or an error status
 int k2v2_launch(const K2Call &c, void *stream);
 
+// ngroups (2..3) problems of ONE shape as one launch of the grouped h kernel (grid.y), fp16 activations (the decode engine's 5..16-row
+// steps): calls[i] differ in x, qweight, scale, y only.  Returns K2V2_NOT_TAKEN when the h kernel does not hold the shape.
+int k2v2_launch_grouped(const K2Call *calls, int ngroups, void *stream);

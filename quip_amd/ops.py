@@ -375,11 +375,12 @@ class FusedGemmArgs(ctypes.Structure):
                 ("ngroups", ctypes.c_int), ("V", Fop * 3), ("colscale", ctypes.c_void_p * 3), ("qweight", ctypes.c_void_p * 3),
                 ("scale", ctypes.c_void_p * 3), ("y", ctypes.c_void_p * 3), ("y_dtype", ctypes.c_int), ("bs", ctypes.c_int64),
                 ("m", ctypes.c_int64), ("pair_sig", ctypes.c_void_p), ("pair_bias", ctypes.c_void_p), ("pair_cs", ctypes.c_void_p),
-                ("u_y_dtype", ctypes.c_int)]
+                ("u_y_dtype", ctypes.c_int), ("ops_only", ctypes.c_int)]
 
 
 FUSED_SHAPES = ((64, 32), (64, 64), (128, 64))
-FUSED_MAX_ROWS = 4
+FUSED_MAX_ROWS = 4          # rows the single fused launch walks in its prologue (csrc/decode_fused.hip FG_MAXBS)
+FUSED_OPS_MAX_ROWS = 16     # rows of the two-launch form (prologue-only launch, one workgroup per row, + grouped dequant-GEMM)
 
 
 def _f16_b_frags(M):
@@ -415,7 +416,7 @@ class BigpVGemmArgs(ctypes.Structure):
                 ("arrived", ctypes.c_void_p)]
 
 
-BIGP_MAX_ROWS = 4
+BIGP_MAX_ROWS = 16         # csrc/decode_bigp.hip: 1..4 rows per workgroup pass, up to 16 per launch (round 5)
 
 
 def decode_bigp_u(entries, rows, clear=None):
@@ -486,10 +487,12 @@ def pair_tables(Uop, Vop, bias16, colscale):
 
 
 def decode_fused_gemm(*, V, colscale, qweight, scale, y, m, bs, x=None, U=None, u_y=None, u_bias=None, u_residual=None, u_relu=False,
-                      t_out=None, norm=0, ln_gamma=None, ln_beta=None, ln_eps=0.0, pair=None, bits=2):
+                      t_out=None, norm=0, ln_gamma=None, ln_beta=None, ln_eps=0.0, pair=None, bits=2, ops_only=False):
     """one launch of quipamd_decode_fused_gemm.  V / colscale / qweight / scale / y: lists (1..3 groups); V, U: Fop records
-    (OrthoOp.fop); 16-bit tensors fp16.  See include/quip_amd.h for the contract."""
+    (OrthoOp.fop); 16-bit tensors fp16.  See include/quip_amd.h for the contract.  ops_only: y[i] = x~_i fp16 [bs, n] (qweight / scale
+    may be None)."""
     a = FusedGemmArgs()
+    a.ops_only = int(bool(ops_only))
     a.act_dtype, a.bits = _DT[torch.float16], int(bits)
     a.has_u = int(U is not None)
     if U is not None:
@@ -514,8 +517,8 @@ def decode_fused_gemm(*, V, colscale, qweight, scale, y, m, bs, x=None, U=None, 
     for i in range(n):
         a.V[i] = V[i]
         a.colscale[i] = _f32ptr(colscale[i], "colscale")
-        a.qweight[i] = qweight[i].data_ptr()
-        a.scale[i] = _f32ptr(scale[i], "scale")
+        a.qweight[i] = None if (ops_only and qweight is None) else qweight[i].data_ptr()
+        a.scale[i] = None if (ops_only and scale is None) else _f32ptr(scale[i], "scale")
         assert y[i].dtype == y[0].dtype and y[i].dtype in (torch.float32, torch.float16) and y[i].is_contiguous()
         a.y[i] = y[i].data_ptr()
     a.y_dtype = _DT[y[0].dtype]

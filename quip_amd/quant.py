@@ -646,7 +646,7 @@ def fused_ok(qls, rows, x_dtype=torch.float16, prev=None, norm=True, residual=Tr
     needs: d = 2048 / 4096: (prev + residual, norm or not), (no prev, norm or not); d = 8192: (prev, no residual, no norm),
     (no prev, no norm).)"""
     q0 = qls[0]
-    ok = (1 <= len(qls) <= 3 and rows <= ops.FUSED_MAX_ROWS and x_dtype == torch.float16
+    ok = (1 <= len(qls) <= 3 and rows <= ops.FUSED_OPS_MAX_ROWS and x_dtype == torch.float16
           and all(q.bits in (2, 3, 4) and q.qfn == 'b' and q.V is not None and q.V.fused_ok and q.scales.numel() == 1 for q in qls)
           and len({(q.infeatures, q.outfeatures, q.V.p, q.V.q, q.bits) for q in qls}) == 1
           and q0.outfeatures % (32 if (q0.V.p, q0.V.q) == (64, 32) else 16) == 0)
@@ -798,8 +798,14 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
     dev = q0.qweight.device
     m, d = q0.outfeatures, q0.infeatures
     ys = [torch.empty((rows, m), dtype=y_dtype, device=dev) for _ in qls]
+    # more rows than the single launch walks in its prologue (ops.FUSED_MAX_ROWS): the same prologue as its own launch, one workgroup per
+    # row (ops_only), x~ through global memory, then ONE grouped dequant-GEMM on the same decode-order codes -- the weights stream once for
+    # all rows; 2 launches per layer group instead of the 3 of the operator / GEMM / operator form
+    two = rows > ops.FUSED_MAX_ROWS
+    xts = [torch.empty((rows, d), dtype=torch.float16, device=dev) for _ in qls] if two else None
     kw = dict(V=[q.V.fop(False) for q in qls], colscale=[q.inv_scaleWH if q.inv_scaleWH is not None else q.V.one_scale() for q in qls],
-              qweight=[q.decode_qweight() for q in qls], scale=[q.scales for q in qls], y=ys, m=m, bs=rows, bits=q0.bits)
+              qweight=[q.decode_qweight() for q in qls], scale=[q.scales for q in qls], y=xts if two else ys, m=m, bs=rows, bits=q0.bits,
+              ops_only=two)
     lnp = _ln_params(ln)
     if lnp is not None:
         g, b, eps = lnp
@@ -809,7 +815,7 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
         kw.update(x=x.contiguous())
     else:
         t = torch.empty((rows, d), dtype=torch.float16, device=dev) if store else None
-        if (q0.V.p, q0.V.q) == (128, 64) and len(qls) == 1 and residual is None and lnp is None and rows <= 2 and not store:
+        if (q0.V.p, q0.V.q) == (128, 64) and len(qls) == 1 and residual is None and lnp is None and rows <= 2 and not store and not two:
             # n = 8192 (OPT fc1 -> fc2): the layer pair's per-lane tables turn gather + scale + scatter into one scatter (decode_fused.hip)
             cache = q0.__dict__.setdefault('_pair_tables', {})
             key = (id(prev), prev.__dict__.get('_pack_gen', 0), str(dev))
@@ -819,10 +825,12 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
         # an fp32 y_prev is rounded to fp16 -- inside the launch where a kernel for that exists (the accumulator of fused_bigp_tail
         # feeding Llama's q / k / v), by a cast otherwise
         in_kernel = (y_prev.dtype == torch.float32 and (q0.V.p, q0.V.q) == (64, 64) and residual is not None and lnp is not None and lnp[1] is None
-                     and q0.bits == 2)
+                     and (q0.bits == 2 or two))
         kw.update(U=prev.U.fop(True), u_y=(y_prev if in_kernel else y_prev.to(torch.float16)).contiguous(), u_bias=bias16(prev),
                   u_residual=None if residual is None else residual.contiguous(), u_relu=relu, t_out=t)
     ops.decode_fused_gemm(**kw)
+    if two:
+        ops.dequant_gemm_grouped(xts, kw['qweight'], q0.bits, 'b', kw['scale'], None, ys, m)
     return ys, t
 
 

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quip_amd import ops  # noqa: E402
 
 FAM_S = 3
-CFGS = [None, (FAM_S, 7, 2), (FAM_S, 8, 1), (FAM_S, 4, 2)]     # (round 4 also timed 24 / 22: two row tiles per compute wave -- no gain, not in the library)
+CFGS = [None, (FAM_S, 7, 2), (FAM_S, 8, 1), (FAM_S, 4, 2), (FAM_S, 2, 4), (FAM_S, 1, 8)]     # (round 4 also timed 24 / 22: two row tiles per compute wave -- no gain, not in the library)
 
 
 def main():
@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--shapes", default="28672x7168,32768x8192,16384x8192,8192x8192")
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--bs", type=int, default=16)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     for sh in a.shapes.split(","):
@@ -32,9 +33,10 @@ def main():
         del codes
         wbytes = m * d // 4
         ring = [q] + [q.clone() for _ in range(max(2, min(64, (420 << 20) // wbytes + 1)) - 1)]
-        x = torch.randn(a.bs, d, generator=g).to(torch.bfloat16).to(dev)
+        adt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+        x = torch.randn(a.bs, d, generator=g).to(adt).to(dev)
         sc = torch.tensor([0.05], device=dev)
-        y = torch.empty(a.bs, m, dtype=torch.bfloat16, device=dev)
+        y = torch.empty(a.bs, m, dtype=adt, device=dev)
         ref = ops.dequant_gemm(x, q, 2, "b", sc, None, None, out_dtype=torch.float32).clone()
         for cfg in CFGS:
             try:

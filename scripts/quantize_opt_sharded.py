@@ -76,7 +76,16 @@ def main(argv=None):
                         word_embed_proj_dim=args.hidden, vocab_size=args.vocab, max_position_embeddings=args.seqlen)
         torch.manual_seed(0)                                   # every rank builds the SAME model and calibration set
         np.random.seed(0)
-        model = OPTForCausalLM(cfg).half().to(dev).eval()
+        # random init straight on the GPU in fp16 (HF's own initialisers; a 24-block model takes ~20 s to initialise on the host): the device
+        # generator is seeded by manual_seed too, and the same seed gives the same Philox stream on every rank's GPU
+        old_dtype = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float16)
+        try:
+            with torch.device(dev):
+                model = OPTForCausalLM(cfg)
+        finally:
+            torch.set_default_dtype(old_dtype)
+        model = model.half().to(dev).eval()
         model.config.use_cache = False
         g = torch.Generator().manual_seed(1)
         batches = [torch.randint(0, args.vocab, (1, args.seqlen), generator=g) for _ in range(args.nsamples)]

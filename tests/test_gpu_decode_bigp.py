@@ -33,7 +33,8 @@ def _tail64(gate, up, down, What_down, yg, yu):
     return g, us, xt, xt @ What_down.t()
 
 
-@pytest.mark.parametrize("ffn,rows,bias", [(1280, 1, True), (1792, 3, False), (11008, 1, False), (11008, 2, True), (11008, 4, False)])
+@pytest.mark.parametrize("ffn,rows,bias", [(1280, 1, True), (1792, 3, False), (11008, 1, False), (11008, 2, True), (11008, 4, False),
+                                           (1792, 5, True), (11008, 8, False), (11008, 13, True), (11008, 16, True)])   # > 4 rows: round 5 (row groups of 4)
 def test_bigp_u_matches_the_dense_operator(ffn, rows, bias):
     from quip_amd import ops
     from quip_amd.quant import _bigp_tail_tables, bigp_tail_ok
@@ -61,12 +62,14 @@ def test_bigp_u_matches_the_dense_operator(ffn, rows, bias):
 
 @pytest.mark.parametrize("ffn,h,rows,gated,nrt", [(1280, 512, 1, True, 0), (1280, 256, 2, False, 1), (1792, 1024, 4, True, 4), (1792, 512, 3, True, 2),
                                                    (11008, 4096, 1, True, 0), (11008, 4096, 1, True, 2), (11008, 4096, 1, True, 1),
-                                                   (11008, 4096, 4, True, 0), (11008, 4096, 2, False, 0)])
+                                                   (11008, 4096, 4, True, 0), (11008, 4096, 2, False, 0),
+                                                   # round 5: 5..16 rows -- the mix 4 rows at a time, one weight pass for all rows (templates 8 / 16)
+                                                   (1792, 1024, 7, True, 4), (11008, 4096, 8, False, 2), (11008, 4096, 16, True, 0), (1280, 256, 11, True, 1)])
 @pytest.mark.parametrize("bits", [2, 4, 3])
 def test_bigp_v_gemm_matches_the_chain_in_fp64(ffn, h, rows, gated, nrt, bits):
     """bits 4 / 3 (round 4): the slice's 256 columns are two 1 KiB tiles of the 4-bit container per row tile"""
     from quip_amd import ops
-    if bits == 3 and not (ffn == 1792 and rows == 4):
+    if bits == 3 and not (ffn == 1792 and rows in (4, 7)):
         pytest.skip("3-bit codes ride in the 4-bit container: one shape covers the only difference (maxq = 7 in the epilogue)")
     down, What = _layer(ffn, h, 700 + ffn % 61 + rows, bias=False, bits=bits)
     V = down.V
@@ -94,7 +97,8 @@ def test_bigp_v_gemm_matches_the_chain_in_fp64(ffn, h, rows, gated, nrt, bits):
 
 
 @pytest.mark.parametrize("ffn,h,rows,gated,nrt,bits", [(1280, 512, 1, True, 0, 2), (1792, 1024, 4, True, 4, 2), (11008, 4096, 1, True, 0, 2),
-                                                         (11008, 4096, 4, True, 0, 2), (11008, 4096, 2, False, 1, 4), (1792, 512, 3, True, 2, 3)])
+                                                         (11008, 4096, 4, True, 0, 2), (11008, 4096, 2, False, 1, 4), (1792, 512, 3, True, 2, 3),
+                                                         (11008, 4096, 16, True, 0, 2), (1792, 1024, 6, True, 4, 4)])
 def test_bigp_v_gemm_fixed_order_meet_is_deterministic(ffn, h, rows, gated, nrt, bits):
     """round 5 (VERDICT r4 weak #1c): with a partials scratch + arrival counters the K-slices meet in slice order -- y is STORED (no clear,
     garbage in y beforehand must not matter), repeated launches agree BIT FOR BIT, the counters come back at zero, and the result is the
@@ -199,8 +203,8 @@ def test_decode_qweight_folds_a_p_x_16_operator():
 def test_bigp_rejects():
     from quip_amd import ops, _lib
     down, _ = _layer(1280, 512, 5, bias=False)
-    g = torch.zeros(5, 1280, device=DEV).half()
-    with pytest.raises(_lib.QuipAmdError):                             # five rows
-        ops.decode_bigp_v_gemm(down.V, g, None, down.decode_qweight(), down.scales, torch.zeros(5, 512, device=DEV))
+    g = torch.zeros(17, 1280, device=DEV).half()
+    with pytest.raises(_lib.QuipAmdError):                             # seventeen rows (1..16 since round 5)
+        ops.decode_bigp_v_gemm(down.V, g, None, down.decode_qweight(), down.scales, torch.zeros(17, 512, device=DEV))
     with pytest.raises(_lib.QuipAmdError):                             # row_tiles_per_wave 4 with m = 512
         ops.decode_bigp_v_gemm(down.V, g[:1], None, down.decode_qweight(), down.scales, torch.zeros(1, 512, device=DEV), 4)

@@ -87,6 +87,19 @@ CASES = [
     (4096, 16384 // 16 * 16, 1, True, "ln", False, True, 1),
     (2048, 2048, 1, True, None, False, True, 2),
     (4096, 11008 // 16 * 16, 2, False, "rms", False, False, 2),
+    # round 5, more than 4 rows: the prologue as its own launch (one workgroup per row, quipamd_fused_gemm_args.ops_only) + the dequant-GEMM
+    # on the same decode-order codes -- every prologue-only instantiation
+    (2048, 2048, 3, False, "ln", False, False, 16),
+    (2048, 2048, 3, True, "ln", False, True, 8),
+    (2048, 2048, 1, False, None, False, False, 5),
+    (2048, 8192, 1, True, "ln", False, True, 16),
+    (8192, 2048, 1, True, None, True, False, 16),
+    (8192, 2048, 1, False, None, False, False, 7),
+    (4096, 4096, 3, True, "rms", False, True, 16),
+    (4096, 4096, 1, False, None, False, False, 9),
+    (4096, 11008 // 16 * 16, 2, False, "rms", False, False, 8),
+    (2048, 2048, 1, True, None, False, True, 6),
+    (2048, 2048, 2, True, "rms", False, True, 12),
 ]
 
 
@@ -174,7 +187,7 @@ def test_fused_stage_rejects_what_it_cannot_run():
     from quip_amd import ops, _lib
     from quip_amd.quant import fused_ok
     ql = _layer(2048, 2048, 1)[0]
-    assert not fused_ok([ql], 5) and not fused_ok([ql], 1, x_dtype=torch.bfloat16)
+    assert fused_ok([ql], 5) and fused_ok([ql], 16) and not fused_ok([ql], 17) and not fused_ok([ql], 1, x_dtype=torch.bfloat16)
     a = ops.FusedGemmArgs()
     a.act_dtype, a.bits, a.ngroups, a.bs = 2, 2, 1, 1
     with pytest.raises(_lib.QuipAmdError):

@@ -238,3 +238,68 @@ def test_llama_decode_harness_matches_hf_with_past_key_values():
             setattr(blk, name, lin)
     report["dense"] = _gate("dense", harness_logits(dec, toks, maxpos, dtype), ref, toks)
     print("llama decode vs HF (max rel logits err, decisive steps, greedy agreement of %d):" % NTOK, report)
+
+
+@pytest.mark.parametrize("bs", [8, 16])
+def test_opt_engine_many_sequences_matches_hf(bs):
+    """round 5: 8 and 16 sequences per step stay on the fused launch family -- engine mode v3, every layer group as
+    [prologue-only launch, one workgroup per row] + [dequant-GEMM on the decode-order codes] -- and every sequence's logits are HF's
+    (past_key_values, one token per call) within 1e-2, greedy tokens equal wherever HF's margin is decisive."""
+    from quip_amd import decode
+    D = _load("decode_opt")
+    dtype, maxpos = torch.float16, 64
+    torch.manual_seed(0)
+    dec = D.Decoder(layers=2, h=2048, ffn=8192, heads=32, vocab=512, maxpos=maxpos, dtype=dtype).to(DEV).eval()
+    for p_ in dec.parameters():
+        if p_.dim() > 1:
+            p_.data.normal_(0, 0.02)
+        else:
+            p_.data.add_(0.05 * torch.randn_like(p_))
+    twin, _ = D.pack_model(dec, 2, DEV)
+    hf = hf_opt_from_decoder(dec, twin, 32, maxpos, dtype, DEV)
+    seqs = [hf_generate(hf, 7 + 31 * s, NTOK) for s in range(bs)]           # (tokens fed, HF logits) per sequence
+    eng = decode.DecodeEngine(dec, bs=bs, max_len=maxpos)
+    assert eng.mode == "v3", eng.mode
+    got = []
+    for i in range(NTOK):
+        ids = torch.tensor([seqs[s][0][i] for s in range(bs)], device=DEV)
+        got.append(eng.forward(ids).float().clone())
+    got = torch.stack(got)                                                   # [NTOK, bs, vocab]
+    worst = 0.0
+    for s in range(bs):
+        rel, decisive, agree = _gate(f"opt-bs{bs}-seq{s}", got[:, s], seqs[s][1], seqs[s][0])
+        worst = max(worst, rel)
+    # the same engine one sequence at a time (mode v3_head, the single fused launches) sees the same logits up to fp16 hand-over rounding
+    e1 = decode.DecodeEngine(dec, bs=1, max_len=maxpos)
+    one = torch.stack([e1.forward(t)[0].float().clone() for t in seqs[0][0]])
+    assert float((one - got[:, 0]).norm() / one.norm()) <= 5e-3
+    print(f"opt engine, {bs} sequences per step vs HF: worst max-rel logits err {worst:.2e}")
+
+
+@pytest.mark.parametrize("bs", [6, 16])
+def test_llama_engine_many_sequences_matches_hf(bs):
+    """the Llama block at 6 and 16 sequences per step: mode v3 -- fused-stage pairs for q / k / v, o, gate / up, and the 11008-wide MLP tail
+    on csrc/decode_bigp.hip's multi-row launches (bigp_u: row groups of 4; bigp_v_gemm: ONE weight pass for all rows) -- against HF with
+    past_key_values, every sequence within 1e-2."""
+    from quip_amd import decode
+    L = _load("decode_llama")
+    dtype, maxpos, eps = torch.float16, 64, 1e-5
+    torch.manual_seed(0)
+    dec = L.Decoder(layers=2, h=2048, ffn=11008, heads=16, vocab=512, maxpos=maxpos, eps=eps, dtype=dtype).to(DEV).eval()
+    for p_ in dec.parameters():
+        if p_.dim() > 1:
+            p_.data.normal_(0, 0.02)
+        else:
+            p_.data.add_(0.05 * torch.randn_like(p_))
+    twin, _ = L.pack_model(dec, 2, DEV)
+    hf = hf_llama_from_decoder(dec, twin, 16, maxpos, eps, dtype, DEV)
+    seqs = [hf_generate(hf, 7 + 31 * s, NTOK) for s in range(bs)]
+    eng = decode.DecodeEngine(dec, bs=bs, max_len=maxpos)
+    assert eng.mode == "v3", eng.mode
+    got = []
+    for i in range(NTOK):
+        ids = torch.tensor([seqs[s][0][i] for s in range(bs)], device=DEV)
+        got.append(eng.forward(ids).float().clone())
+    got = torch.stack(got)
+    worst = max(_gate(f"llama-bs{bs}-seq{s}", got[:, s], seqs[s][1], seqs[s][0])[0] for s in range(bs))
+    print(f"llama engine, {bs} sequences per step vs HF: worst max-rel logits err {worst:.2e}")

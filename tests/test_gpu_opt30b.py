@@ -69,9 +69,13 @@ def test_k8_factor_backward_error_d28672(ops, factor):
     left = (MS * d2[:, None]).t().contiguous()                                                      # [|S|, d] = M[:, S]^T D^2
     R = left @ LT.double()                                                                          # M = LT + I: add the I part below
     R += left                                                                                       # (left @ I)
-    resid = (R - H[S, :].double()).abs().max().item() / H.abs().max().item()
-    print(f"[opt30b] K8 backward error on {S.numel()} sampled columns: {resid:.2e}")
-    assert resid < 2e-5, resid
+    E = (R - H[S, :].double()).abs()
+    resid = E.max().item() / H.abs().max().item()
+    hd = H.diag().double()
+    comp = (E / (hd[S][:, None] * hd[None, :]).sqrt()).max().item()           # |dH_ij| / sqrt(H_ii H_jj): scale-free (H's columns span 170 x)
+    print(f"[opt30b] K8 backward error on {S.numel()} sampled columns: {resid:.2e} of max|H|, {comp:.2e} componentwise (of sqrt(H_ii H_jj))")
+    assert resid < 5e-9, resid                                                  # measured 3.1e-10 (profiles/r05a_pytest_opt30b.log)
+    assert comp < 1e-4, comp
     # the trailing block is where every earlier panel's error has accumulated: its own residual, separately
     T = slice(D - 64, D)
     rT = (R[-64:, T] - H[T, T].double()).abs().max().item() / H[T, T].abs().max().item()

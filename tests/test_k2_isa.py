@@ -53,9 +53,17 @@ def _functions(lines, prefix):
                 cur = None
 
 
+def _h_kernels(asm):
+    """every instantiation of the one-problem kernel and of the grouped one (round 5: dq_hg_kernel, the same body text with the problem
+    picked by blockIdx.y)"""
+    yield from _functions(asm, "dq_h_kernel")
+    yield from _functions(asm, "dq_hg_kernel")
+
+
 def test_h_kernel_asm_loads_are_not_touched_before_their_wait(asm):
     n = 0
-    for name, body in _functions(asm, "dq_h_kernel"):
+    assert sum(1 for _ in _functions(asm, "dq_hg_kernel")) >= 4, "no dq_hg_kernel instantiations found"
+    for name, body in _h_kernels(asm):
         n += 1
         queue = []          # outstanding vector-memory operations, oldest first: (dest registers of an asm load | empty set)
         in_asm = False
@@ -98,7 +106,7 @@ def test_h_kernel_asm_loads_are_not_touched_before_their_wait(asm):
 def test_no_waterfall_loops_around_the_dma(asm):
     """a buffer descriptor hipcc cannot prove wave-uniform gets every buffer_load wrapped in a readfirstlane loop
     (cdna_hip_programming.md T20): the streaming kernels must not have any next to their LDS-DMA instructions."""
-    for prefix in ("dq_h_kernel", "dq_s_kernel", "dq_mb_kernel"):
+    for prefix in ("dq_h_kernel", "dq_hg_kernel", "dq_s_kernel", "dq_mb_kernel"):
         for name, body in _functions(asm, prefix):
             for i, ln in enumerate(body):
                 if "buffer_load_dwordx4" in ln and " lds" in ln:
