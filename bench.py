@@ -667,7 +667,7 @@ def main():
             fmod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(fmod)
             fres = fmod.run(_types.SimpleNamespace(model="opt-1.3b", nsamples=128, seqlen=2048, layers=0, wbits=None, quant="ldlq", no_incoh=False, extra=0,
-                                                   restatement=False, fast_hessian=False, device_rng=False, prefetch_operators=False, out=None))
+                                                   restatement=False, fast_hessian=False, device_rng=False, prefetch_operators=True, out=None))
             out["quantise_model"] = {"what": "OPT-1.3B architecture (random init, fp16), LDLQ w2 + incoherence processing, 128 x 2048 calibration tokens, all 24 blocks "
                                              "through the block-sequential driver on ONE MI355X; BASELINE.md section 2 derives ~28 min of CPU LDLQ + ~1 h of CPU "
                                              "Hessian accumulation for the reference on 8 cores",
@@ -762,6 +762,16 @@ def main():
                                "sample": f"{n} calls of torch CPU F.linear fp32 x[16,4096] @ What[4096,4096]^T "
                                          f"(dense fake-quant weights, what the reference runs at inference), "
                                          f"{dt * 1e3:.3f} ms/call"}
+    # configs[2] is "OPT-1.3B w2 --incoh_processing": the shipped flag leaves pre_proj_extra = 0 (opt.py:596 sets an unused `proj_extra`), i.e.
+    # BLOCKED butterfly operators -- so the `decode` object leads with that model, and the Kronecker model (pre_proj_extra = 1, what the
+    # north_star's "--pre_proj" text describes and the fused launches serve) sits beside it
+    if rank == 0 and isinstance(out.get("decode_blocked"), dict) and "value" in out["decode_blocked"] and isinstance(out.get("decode"), dict) and "value" in out["decode"]:
+        kron = out.pop("decode")
+        blk = out.pop("decode_blocked")
+        blk["operators"] = "blocked butterfly, pre_proj_extra = 0: what opt.py --incoh_processing yields (configs[2] as shipped)"
+        blk["kronecker_operators"] = kron
+        blk["kronecker_operators"]["operators"] = "Kronecker, pre_proj_extra = 1 (fused launches: csrc/decode_fused.hip)"
+        out["decode"] = blk
     watchdog.cancel()
     if not printed.acquire(blocking=False):
         return                                   # the watchdog is printing

@@ -446,9 +446,13 @@ typedef struct quipamd_bigp_v_gemm_args {
     int64_t rows;
     int row_tiles_per_wave;
     float *partials;                 /* NULL: the K-slices meet in y through fp32 atomics (y zero on entry).  Else fp32 [p/16, rows, m]
-                                        scratch: the slices meet in a fixed order (deterministic; y need not be cleared) ...            */
-    unsigned *arrived;               /* ... with one arrival counter per row group, [m / 256] (enough for any row_tiles_per_wave), zero
-                                        on entry; the launch leaves them zero                                                         */
+                                        scratch, 16-byte aligned like y: every slice stores its partial and a second launch of the same call
+                                        sums them in slice order into y (deterministic; y need not be cleared; faster than the atomics
+                                        from 5 rows on)                                                                                */
+    void *xt;                        /* NULL, or fp16 [rows, 16 p] scratch, 16-byte aligned: the TWO-LAUNCH form -- the operator pass alone writes
+                                        x~ there (one workgroup per 16 image rows and 4 batch rows), then quipamd_dequant_gemm runs on it and
+                                        the same codes; y is STORED (deterministic, need not be cleared).  The form for 5..16 rows: the
+                                        one-launch kernel repeats the whole activation-side pass in every workgroup (49 us at 16 rows).  */
 } quipamd_bigp_v_gemm_args;
 int quipamd_decode_bigp_supported(int p, int q);
 int quipamd_decode_bigp_u(const quipamd_bigp_u_op *ops, int nops, int p, int64_t rows, float *clear, int64_t clear_n, void *stream);

@@ -21,8 +21,8 @@
 //   * bigp_v_gemm: a workgroup's 16 image rows are 256 consecutive columns of the packed matrix (columns in image order) = one STREAM
 //     chunk of every row tile, so the operator output goes straight into the 2-bit GEMM of that K-slice; the K-slices meet in y
 //     through fp32 atomics (64 consecutive floats per instruction).  y must be ZERO on entry: bigp_u clears it (`clear`) -- it runs
-//     between y's previous reader and this launch.  With `partials` / `arrived` set the slices meet in a FIXED order instead (each stores
-//     its partial, the last arriver of a row group sums slices 0 .. p/16 - 1): bit-identical runs, one more L2 round trip.
+//     between y's previous reader and this launch.  With `partials` set the slices meet in a FIXED order instead (each stores its partial,
+//     a small second launch sums slices 0 .. p/16 - 1): bit-identical runs, and faster than the atomics from 5 rows on.
 // Rows (batch): 1..4 compile-time; round 5: up to 16 -- bigp_u walks row groups of 4 over blockIdx.z, bigp_v_gemm mixes 4 rows at a
 // time into a 16-row x~ image and runs ONE weight pass against all 16 MFMA columns (templates BS = 8, 16).
 #include "common.h"
@@ -157,7 +157,7 @@ struct BVArgs {
     int p, ks;
     int rows;                     // batch rows that exist (<= BS; rows >= it read row rows - 1 and are not stored)
     float *partials;              // fixed-order meet: [p/16 slices][rows][m] fp32, or null (atomics)
-    unsigned *arrived;            // [row groups] arrival counters, zero on entry, left zero on exit
+    uint16_t *xt_out;             // MIX ONLY (grid (p/16, row groups of BS)): x~ f16 [rows][16 p] in image order; no weights, no GEMM
 };
 
 __device__ __forceinline__ uint32_t bg_gate2(uint32_t g2, uint32_t u2)
@@ -204,6 +204,8 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
     const int nwp = (ks + 1) >> 1;                                              // waves that run the mix over a
     const uint32_t rt0 = (blockIdx.y * 16 + wave) * NRT;
     const int rows = G.rows;
+    const bool mixonly = G.xt_out != nullptr;                                   // (uniform) blockIdx.y is then a group of BS batch rows
+    const int rowbase = mixonly ? (int)blockIdx.y * BS : 0;
 
     const int S0 = 2 * wave, S1 = 2 * wave + 1;
     const bool mixer = wave < nwp, two = S1 < ks;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
     auto load_rows = [&](int r0) {                                              // the A fragments of rows r0 .. r0 + RG - 1 (rows past the batch: the last one)
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
-            const int rr = r0 + r < rows ? r0 + r : rows - 1;
+            const int rr = rowbase + r0 + r < rows ? rowbase + r0 + r : rows - 1;
             const uint16_t *grow = G.gate + (int64_t)rr * G.ldx + (uint32_t)(j * p);
             ga[r][0] = *reinterpret_cast<const uint4 *>(grow + ka0);
             ga[r][1] = *reinterpret_cast<const uint4 *>(grow + ka1);
@@ -236,14 +238,22 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
     float4 m1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wave < RG) m1 = *reinterpret_cast<const float4 *>(G.M1 + j * 16 + 4 * g);
     uint4 w[NRT][TPS];
+    float e_sc = 0.f;
+    if (!mixonly) {
 #pragma unroll
-    for (int k = 0; k < NRT; ++k)                                                // HBM, streamed once: nt; requested LAST (in-order vmcnt)
+        for (int k = 0; k < NRT; ++k)                                            // HBM, streamed once: nt; requested LAST (in-order vmcnt)
 #pragma unroll
-        for (int h = 0; h < TPS; ++h) {
-            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(G.qw + ((uint64_t)(rt0 + k) * (nch * TPS) + at * TPS + h) * 64 + lane));
-            w[k][h] = make_uint4(t[0], t[1], t[2], t[3]);
-        }
-    const float e_sc = G.scale[0];
+            for (int h = 0; h < TPS; ++h) {
+                const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(G.qw + ((uint64_t)(rt0 + k) * (nch * TPS) + at * TPS + h) * 64 + lane));
+                w[k][h] = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+        e_sc = G.scale[0];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NRT; ++k)
+#pragma unroll
+            for (int h = 0; h < TPS; ++h) w[k][h] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if (!two) fb[1] = make_uint4(0u, 0u, 0u, 0u);
 
 #pragma unroll
@@ -279,6 +289,8 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
             pk.x = pack_f16x2(z2[0], z2[1]);
             pk.y = pack_f16x2(z2[2], z2[3]);
             *reinterpret_cast<uint2 *>(XT + rx * XTS + 16 * j + 4 * g) = pk;
+            if (mixonly && rowbase + rx < rows)                                 // the slice of x~ leaves for the dequant-GEMM launch behind this one
+                *reinterpret_cast<uint2 *>(G.xt_out + (int64_t)(rowbase + rx) * ((int64_t)p * 16) + (uint32_t)(at * 256 + 16 * j + 4 * g)) = pk;
             const float4 rv = f16x4_to_f32(pk);                                  // the sums the epilogue subtracts are sums of what the MFMAs see
             const float s = fg_wave_sum((rv.x + rv.y) + (rv.z + rv.w));
             const int k0 = 16 * j + 4 * g;
@@ -290,6 +302,7 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
             }
         }
     }
+    if (mixonly) return;
     __syncthreads();
 
     // ---- 2-bit GEMM of this K-slice: MFMA column j = batch row j (columns >= BS read allocated garbage and are not stored) ----------------
@@ -333,9 +346,10 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
         }
         return;
     }
-    // ---- fixed-order meet (opt-in: greedy decoding must not depend on the order atomics land in).  Every K-slice stores its partial; the
-    // workgroup that arrives LAST at its row group's counter sums the slices 0 .. p/16 - 1 in that order and stores y (no clear needed);
-    // it also hands the counter back at zero for the next launch.  Device scope: the slices of a row group sit on different XCDs.
+    // ---- fixed-order meet: every K-slice STORES its partial (64 consecutive floats per instruction, no atomics); bigp_reduce_kernel, the
+    // next launch of the same call, sums the slices 0 .. p/16 - 1 in that order.  Bit-identical runs -- and, from 5 rows on, FASTER than the
+    // atomics: 43 slices x 16 rows x 4096 outputs are 2.8 M atomic adds that resolve outside the L2s (49 us at 16 rows, 7.4 at one row;
+    // profiles/r05e_bigp_tail.jsonl) against 11 MB of plain stores and one pass over them.
     float *slab = G.partials + (int64_t)at * rows * G.m;
 #pragma unroll
     for (int o = 0; o < (16 * NRT + 63) / 64; ++o) {
@@ -345,31 +359,29 @@ __global__ __launch_bounds__(1024) void bigp_v_gemm_kernel(BVArgs G, float two_o
 #pragma unroll
             for (int r = 0; r < BS; ++r) {
                 const float val = alpha * ((mine[(k * XR + r) * 16 + wr] - red[XR + r]) - c0 * red[r]);
-                if (BS <= 4 || r < rows)
-                    __hip_atomic_store(slab + (int64_t)r * G.m + (int64_t)rt0 * 16 + l, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (BS <= 4 || r < rows) slab[(int64_t)r * G.m + (int64_t)rt0 * 16 + l] = val;
             }
         }
     }
-    __shared__ unsigned last_flag;
-    __threadfence();                                                            // this thread's partial stores are visible device-wide ...
-    __syncthreads();                                                            // ... and so are every thread's of the workgroup
-    if (tid == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(G.arrived + blockIdx.y, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last_flag = prev == (unsigned)(nch - 1);
-        if (last_flag) __hip_atomic_store(G.arrived + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// y[r][c] = sum over slices sl = 0 .. nsl - 1, in that order, of partials[sl][r][c]      (n = rows * m floats per slice, n % 4 == 0)
+__global__ __launch_bounds__(256) void bigp_reduce_kernel(const f32x4_t *__restrict__ partials, f32x4_t *__restrict__ y, int64_t n4, int nsl)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const f32x4_t *p = partials + i;
+    int sl = 0;
+    for (; sl + 8 <= nsl; sl += 8) {                                             // eight loads in flight, summed in slice order
+        f32x4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + (int64_t)(sl + u) * n4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    __syncthreads();
-    if (!last_flag) return;
-    __threadfence();
-    const int64_t r0 = (int64_t)blockIdx.y * 16 * NRT * 16;                     // the row group's first row; 256 NRT rows, `rows` batch rows
-    for (int e = tid; e < rows * 256 * NRT; e += 1024) {
-        const int r = e / (256 * NRT), row = e - r * (256 * NRT);
-        const float *src = G.partials + (int64_t)r * G.m + r0 + row;
-        float sum = 0.f;
-        for (int sl = 0; sl < nch; ++sl)
-            sum += __hip_atomic_load(src + (int64_t)sl * rows * G.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        G.y[(int64_t)r * G.m + r0 + row] = sum;
-    }
+    for (; sl < nsl; ++sl) acc += __builtin_nontemporal_load(p + (int64_t)sl * n4);
+    y[i] = acc;
 }
 
 }   // namespace
@@ -437,14 +449,28 @@ extern "C" int quipamd_decode_bigp_v_gemm(const quipamd_bigp_v_gemm_args *a, voi
     if (nrt == 0) nrt = a->m % 1024 == 0 ? 4 : a->m % 512 == 0 ? 2 : 1;
     if (w4 && a->rows > 4 && nrt == 4) nrt = 2;                                  // (registers: see QA_BV)
     QA_REQUIRE((nrt == 1 || nrt == 2 || nrt == 4) && a->m % (256 * nrt) == 0, QUIPAMD_ERR_ARG, "decode_bigp_v_gemm: row_tiles_per_wave 0 / 1 / 2 / 4 with m %% (256 x it) == 0");
-    QA_REQUIRE((a->partials == nullptr) == (a->arrived == nullptr), QUIPAMD_ERR_ARG, "decode_bigp_v_gemm: partials and arrived go together (both null: atomics)");
+    QA_REQUIRE(!a->partials || (((uintptr_t)a->partials | (uintptr_t)a->y) & 15) == 0, QUIPAMD_ERR_ARG, "decode_bigp_v_gemm: partials and y 16-byte aligned");
     BVArgs A{(const uint4 *)a->F0, a->M1, (const uint16_t *)a->gate, (const uint16_t *)a->up, a->ldx, (const uint4 *)a->qweight, a->scale, a->y, a->m, p, (p + 31) / 32,
-             (int)a->rows, a->partials, a->arrived};
-    const int nwp = (A.ks + 1) / 2, bs = a->rows <= 4 ? (int)a->rows : a->rows <= 8 ? 8 : 16;        // the kernel's row count: 1..4, 8, 16
+             (int)a->rows, a->partials, nullptr};
+    const int nwp = (A.ks + 1) / 2;
+    int bs = a->rows <= 4 ? (int)a->rows : a->rows <= 8 ? 8 : 16;                  // the kernel's row count: 1..4, 8, 16
     // c0 = maxq / 2 (2 bits: the per-field offsets are subtracted as sum OFF_k x~_k; 4-bit container: + the uniform offset 16)
     const float two_over_maxq = 2.0f / maxq, c0 = 0.5f * maxq + (w4 ? 16.0f : 0.0f);
-    const dim3 grid((unsigned)(p / 16), (unsigned)(a->m / (256 * nrt)));
+    dim3 grid((unsigned)(p / 16), (unsigned)(a->m / (256 * nrt)));
     hipStream_t s = (hipStream_t)stream;
+    // Two-launch form (xt scratch given; the Python side picks it from 5 rows on): the operator pass ALONE -- one workgroup per (16 image
+    // rows, group of 4 batch rows) writes its slice of x~ -- and then the ordinary dequant-GEMM on the same decode-order codes.  In the
+    // one-launch form every workgroup redoes silu(gate) * up and the mix over a for ALL of its rows (44 KB of input and 11008 gate values
+    // per row), m / 1024 times per K-slice: 7.4 us at one row, 49 us at 16 (profiles/r05f_bigp_tail.jsonl) -- the atomics were not it.
+    const bool two_launch = a->xt != nullptr;
+    if (two_launch) {
+        QA_REQUIRE(((uintptr_t)a->xt & 15) == 0, QUIPAMD_ERR_ARG, "decode_bigp_v_gemm: xt 16-byte aligned");
+        A.xt_out = (uint16_t *)a->xt;
+        A.partials = nullptr;
+        bs = a->rows < 4 ? (int)a->rows : 4;
+        nrt = 1;
+        grid = dim3((unsigned)(p / 16), (unsigned)((a->rows + bs - 1) / bs));
+    }
 #define QA_BV(BS, NRT, GT)                                                                                                           \
     do {                                                                                                                             \
         /* (the 4-bit container with 16 rows AND 4 row tiles per wave does not fit the register file -- 20 bytes of scratch; the host  \
@@ -479,6 +505,14 @@ extern "C" int quipamd_decode_bigp_v_gemm(const quipamd_bigp_v_gemm_args *a, voi
 #undef QA_BV_B
 #undef QA_BV_N
 #undef QA_BV
+    if (two_launch) {
+        const int rc = quipamd_dequant_gemm(a->xt, QUIPAMD_F16, (const int32_t *)a->qweight, a->bits, QUIPAMD_LAYOUT_STREAM, QUIPAMD_QFN_B, a->scale, nullptr,
+                                            nullptr, a->y, QUIPAMD_F32, 0, a->rows, a->m, (int64_t)p * 16, stream);
+        if (rc != QUIPAMD_OK) return rc;
+    } else if (a->partials) {                                                     // the second launch of the fixed-order meet
+        const int64_t n4 = a->rows * a->m / 4;
+        bigp_reduce_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, s>>>((const f32x4_t *)a->partials, (f32x4_t *)a->y, n4, p / 16);
+    }
     QA_LAUNCH_CHECK("quipamd_decode_bigp_v_gemm");
     return QUIPAMD_OK;
 }

@@ -58,7 +58,12 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
             // and 4 fit 1024 (16384 rows: 13.1 us with 256 workgroups of 4, 15.0 with 147 of 7 -- profiles/r04q_k2_s_cfgs.jsonl).  Cost = rounds of
             // 256 workgroups x tiles per workgroup; ties go to the larger workgroup (32768 rows: 8 x 256 18.8 us, 4 x 512 25.5)
             const int64_t r4 = ((ntile + 3) / 4 + 255) / 256, r7 = ((ntile + 6) / 7 + 255) / 256, r8 = ((ntile + 7) / 8 + 255) / 256;
-            if (r4 * 4 < r7 * 7 && r4 * 4 < r8 * 8) { p1 = 4; p2 = 2; }
+            // short and wide (reached with fp16 activations only: a 5..16-row decode step's fc2 / down_proj GEMM): fill the CUs first --
+            // 2048 x 8192: 12.1 us with 4 tiles per workgroup (32 workgroups), 7.8 with 2, 7.1 with 1; 4096 x 11008: 15.5 / 9.9 / 9.95
+            // (profiles/r05d_k2_s_shortwide.jsonl)
+            if (ntile <= 128) { p1 = 1; p2 = 8; }
+            else if (ntile <= 256) { p1 = 2; p2 = 4; }
+            else if (r4 * 4 < r7 * 7 && r4 * 4 < r8 * 8) { p1 = 4; p2 = 2; }
             else if (r8 * 8 < r7 * 7) { p1 = 8; p2 = 1; }
             else { p1 = 7; p2 = 2; }
         }

@@ -31,7 +31,11 @@ DEVICE_RNG = False       # True: draw the Gaussians of the SO(p) sampler with to
 SHARE_IDENTICAL_INPUTS = True   # Linears that are handed THE SAME input tensor (q / k / v of an attention block, gate / up of a gated MLP) accumulate
                                 # its X^T X once: the later ones count samples and take a copy of the first one's Hessian at post_batch
                                 # (bit-identical to accumulating it again -- same numbers, same kernel, same order -- at a third of the work)
-OPERATOR_PREFETCH = False  # True: sample the operators of the Linears whose QuantMethod objects already exist on a host thread (below)
+OPERATOR_PREFETCH = False  # True: sample the operators of the Linears whose QuantMethod objects already exist on a host thread (below).
+                           # Exact -- the same draws from the same streams -- PROVIDED nobody reseeds numpy / torch between constructing a method
+                           # and its preproc (a draw made ahead of a reseed would be taken as if made behind it).  The reference's drivers
+                           # never do; tests and notebooks do.  So the library default is off and the whole-model drivers of this repo
+                           # (scripts/run_full_model.py, bench.py's quantise_model leg) switch it on.
 
 
 def _prime_factors(n):

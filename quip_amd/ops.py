@@ -413,7 +413,7 @@ class BigpVGemmArgs(ctypes.Structure):
     _fields_ = [("F0", ctypes.c_void_p), ("M1", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("up", ctypes.c_void_p), ("ldx", ctypes.c_int64),
                 ("qweight", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("bits", ctypes.c_int), ("y", ctypes.c_void_p), ("m", ctypes.c_int64),
                 ("p", ctypes.c_int), ("rows", ctypes.c_int64), ("row_tiles_per_wave", ctypes.c_int), ("partials", ctypes.c_void_p),
-                ("arrived", ctypes.c_void_p)]
+                ("xt", ctypes.c_void_p)]
 
 
 BIGP_MAX_ROWS = 16         # csrc/decode_bigp.hip: 1..4 rows per workgroup pass, up to 16 per launch (round 5)
@@ -441,12 +441,14 @@ def decode_bigp_u(entries, rows, clear=None):
     _lib.call("quipamd_decode_bigp_u", arr, len(entries), U0.p, rows, _p(clear), 0 if clear is None else clear.numel(), _stream())
 
 
-def decode_bigp_v_gemm(V, gate, up, qweight_d, scale, y, row_tiles_per_wave=0, bits=2, partials=None, arrived=None):
+def decode_bigp_v_gemm(V, gate, up, qweight_d, scale, y, row_tiles_per_wave=0, bits=2, partials=None, xt=None):
     """y += What V(silu(gate) * up) for a 2-bit qfn-b layer whose activation-side operator V is p x 16 (quipamd_decode_bigp_v_gemm):
     gate / up fp16 [rows, n] as the transposed image of V's input (up None: the input is `gate` itself), qweight_d the codes with their
     columns in image order of V (QuantLinear.decode_qweight()), y fp32 [rows, m] ACCUMULATED with atomics (zero it first).
-    partials fp32 [p / 16, rows, m] + arrived int32 [m / 256] (zero): the K-slices meet in a fixed order instead -- y is STORED, runs are
-    bit-identical (quant.DETERMINISTIC_SPLITK)."""
+    partials fp32 [p / 16, rows, m]: the K-slices meet in a fixed order instead (stores + a second small launch) -- y is STORED, runs are
+    bit-identical (quant.DETERMINISTIC_SPLITK).  xt fp16 [rows, n] scratch: the two-launch form -- the operator pass alone, then the
+    dequant-GEMM on x~ -- y STORED, deterministic; what quant.fused_bigp_tail uses from 5 rows on (the one-launch kernel repeats the whole
+    activation-side pass in every workgroup: 49 us at 16 rows against ~15)."""
     _need_gpu(gate)
     rows, m = y.shape
     assert V.bigp_fold_ok and gate.dtype == torch.float16 and gate.shape == (rows, V.n) and gate.stride(1) == 1
@@ -455,9 +457,10 @@ def decode_bigp_v_gemm(V, gate, up, qweight_d, scale, y, row_tiles_per_wave=0, b
     F0, M1 = V.bigp_frags(False)
     if partials is not None:
         assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.numel() >= (V.p // 16) * rows * m
-        assert arrived is not None and arrived.dtype == torch.int32 and arrived.numel() >= m // 256
+    if xt is not None:
+        assert xt.dtype == torch.float16 and xt.is_contiguous() and xt.shape == (rows, V.n)
     a = BigpVGemmArgs(_p(F0), _p(M1), _p(gate), _p(up), gate.stride(0), _p(qweight_d), _p(scale), int(bits), _p(y), m, V.p, rows, int(row_tiles_per_wave),
-                      _p(partials), _p(arrived))
+                      _p(partials), _p(xt))
     _lib.call("quipamd_decode_bigp_v_gemm", ctypes.byref(a), _stream())
 
 

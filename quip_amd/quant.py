@@ -737,18 +737,26 @@ def fused_bigp_tail(ups, down, ys, row_tiles_per_wave=0):
     dev = ys[0].device
     imgs = torch.empty((len(ups), rows, V.n), dtype=torch.float16, device=dev)
     yd = torch.empty((rows, down.outfeatures), dtype=torch.float32, device=dev)
+    if rows > 4:
+        # from 5 rows on: the activation-side pass as its own launch (x~ through a scratch the layer keeps: a hipGraph replays the same
+        # pointers), then the ordinary dequant-GEMM -- no atomics, deterministic
+        key = ('xt', rows, str(dev))
+        ws = down.__dict__.setdefault('_splitk_ws', {})
+        if key not in ws:
+            ws[key] = torch.empty((rows, V.n), dtype=torch.float16, device=dev)
+        ops.decode_bigp_u([(q.U, y, bias_img, post, dest, imgs[i]) for i, (q, y, (dest, bias_img, post)) in enumerate(zip(ups, ys, tabs))], rows)
+        ops.decode_bigp_v_gemm(V, imgs[0], imgs[1] if len(ups) == 2 else None, down.decode_qweight(), down.scales, yd, row_tiles_per_wave, bits=down.bits,
+                               xt=ws[key])
+        return yd
     if DETERMINISTIC_SPLITK:
-        # the K-slices of down_proj meet in slice order through a scratch the layer keeps (a hipGraph replays the same pointers); the arrival
-        # counters are zeroed once and handed back at zero by every launch
+        # the K-slices of down_proj meet in slice order through a scratch the layer keeps
         key = (rows, str(dev))
         ws = down.__dict__.setdefault('_splitk_ws', {})
         if key not in ws:
-            ws[key] = (torch.empty((V.p // 16, rows, down.outfeatures), dtype=torch.float32, device=dev),
-                       torch.zeros(down.outfeatures // 256, dtype=torch.int32, device=dev))
-        partials, arrived = ws[key]
+            ws[key] = torch.empty((V.p // 16, rows, down.outfeatures), dtype=torch.float32, device=dev)
         ops.decode_bigp_u([(q.U, y, bias_img, post, dest, imgs[i]) for i, (q, y, (dest, bias_img, post)) in enumerate(zip(ups, ys, tabs))], rows)
         ops.decode_bigp_v_gemm(V, imgs[0], imgs[1] if len(ups) == 2 else None, down.decode_qweight(), down.scales, yd, row_tiles_per_wave, bits=down.bits,
-                               partials=partials, arrived=arrived)
+                               partials=ws[key])
         return yd
     ops.decode_bigp_u([(q.U, y, bias_img, post, dest, imgs[i]) for i, (q, y, (dest, bias_img, post)) in enumerate(zip(ups, ys, tabs))], rows, clear=yd)
     ops.decode_bigp_v_gemm(V, imgs[0], imgs[1] if len(ups) == 2 else None, down.decode_qweight(), down.scales, yd, row_tiles_per_wave, bits=down.bits)

@@ -113,7 +113,7 @@ def main():
     if not a.skip_driver:
         import run_full_model as F
         ns = types.SimpleNamespace(model="opt-30b", nsamples=a.nsamples, seqlen=a.seqlen, layers=a.blocks, wbits=None, quant="ldlq", no_incoh=False, extra=0,
-                                   restatement=False, fast_hessian=False, device_rng=False, prefetch_operators=False, out=None)
+                                   restatement=False, fast_hessian=False, device_rng=False, prefetch_operators=True, out=None)
         res["block_through_reference_driver"] = F.run(ns)
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()

@@ -165,7 +165,11 @@ def main():
     ap.add_argument("--restatement", action="store_true")
     ap.add_argument("--fast-hessian", action="store_true", help="method.HESSIAN_FAST (opt-in, not the reference's arithmetic)")
     ap.add_argument("--device-rng", action="store_true", help="method.DEVICE_RNG (opt-in, not the reference's seeded operators)")
-    ap.add_argument("--prefetch-operators", action="store_true", help="method.OPERATOR_PREFETCH: sample the next operators on a host thread")
+    ap.add_argument("--prefetch-operators", dest="prefetch_operators", action="store_true", default=True,
+                    help="method.OPERATOR_PREFETCH: sample the next operators on a host thread (exact: the same draws from the same streams; "
+                         "the DEFAULT of this driver since round 5 -- a whole-model run never reseeds between constructing a method and its preproc, "
+                         "which is the one thing the library-level default, off, protects against)")
+    ap.add_argument("--no-prefetch-operators", dest="prefetch_operators", action="store_false")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     out = run(a)

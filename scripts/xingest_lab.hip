@@ -86,6 +86,78 @@ __global__ __launch_bounds__(64 * NW) void ingest_kernel(const uint16_t *x, unsi
     if (stamps && lane == 0) { stamps[(blockIdx.x * NW + wave) * 2] = t0; stamps[(blockIdx.x * NW + wave) * 2 + 1] = t1; }
 }
 
+// second generation of variants: run-time pattern.  kc = pattern(i, wave, cu):
+//   mode 0: (i NW + wave + mul cu) & 15        mode 1: (i NW + wave) ^ (mul cu & 15)        mode 2: (2 wave + i + mul cu) & 15 (a wave's two chunks adjacent)
+//   mode 3: like 0, and the 8 instructions of a slab issued column block by column block for BOTH chunks interleaved
+__global__ __launch_bounds__(64 * NW) void ingest2_kernel(const uint16_t *x, unsigned long long *stamps, uint32_t *sink, int mode, int mul)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    const int cu = (int)(blockIdx.x >> 3);
+    char *myreg = smem + wave * (NCH * SLAB);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, ROWS * ROWB, 0x00020000);
+    const uint32_t voff_lo = (lane >> 3) * ROWB + ((uint32_t)(lane & 7) << 4);
+    const uint32_t voff_hi = voff_lo + 8u * ROWB;
+    int kcs[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        kcs[i] = mode == 1 ? ((i * NW + wave) ^ ((mul * cu) & 15)) : mode == 2 ? ((2 * wave + i + mul * cu) & 15) : ((i * NW + wave + mul * cu) & 15);
+    if (mode == 3) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(myreg + i * SLAB + q * 1024), 16, (q & 1) ? voff_hi : voff_lo,
+                                                         kcs[i] * (KC * 2) + (q >> 1) * 128, 0, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(myreg + i * SLAB + q * 1024), 16, (q & 1) ? voff_hi : voff_lo,
+                                                         kcs[i] * (KC * 2) + (q >> 1) * 128, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t acc = *reinterpret_cast<const uint32_t *>(myreg + lane * 4);
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (acc == 0x12345678u) sink[0] = acc;
+    if (stamps && lane == 0) { stamps[(blockIdx.x * NW + wave) * 2] = t0; stamps[(blockIdx.x * NW + wave) * 2 + 1] = t1; }
+}
+
+static void run2(const char *name, int mode, int mul, const uint16_t *x, unsigned long long *stamps, uint32_t *sink, hipStream_t st)
+{
+    const int G = 256, steps = 200;
+    const size_t lds = (size_t)NW * NCH * SLAB;
+    CK(hipFuncSetAttribute((const void *)ingest2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipGraph_t g; hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < steps; ++i) ingest2_kernel<<<G, 64 * NW, lds, st>>>(x, nullptr, sink, mode, mul);
+    CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+    float best = 1e9;
+    for (int rep = 0; rep < 5; ++rep) {
+        CK(hipEventRecord(e0, st)); CK(hipGraphLaunch(ge, st)); CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+    }
+    std::vector<unsigned long long> h((size_t)G * NW * 2);
+    for (int rep = 0; rep < 5; ++rep) { ingest2_kernel<<<G, 64 * NW, lds, st>>>(x, stamps, sink, mode, mul); CK(hipStreamSynchronize(st)); }
+    CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> dur;
+    for (int b = 0; b < G; ++b) {
+        unsigned long long a = ~0ull, z = 0;
+        for (int w = 0; w < NW; ++w) { a = std::min(a, h[(b * NW + w) * 2]); z = std::max(z, h[(b * NW + w) * 2 + 1]); }
+        dur.push_back((double)(z - a));
+    }
+    std::sort(dur.begin(), dur.end());
+    printf("%-22s %7.3f us/launch in a graph   workgroup ingest clocks: median %6.0f  p10 %6.0f  p90 %6.0f\n", name, best * 1e3 / steps,
+           dur[dur.size() / 2], dur[dur.size() / 10], dur[dur.size() * 9 / 10]);
+    fflush(stdout);
+    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+}
+
 template <int V> static void run(const uint16_t *x, unsigned long long *stamps, uint32_t *sink, hipStream_t st)
 {
     const int G = 256, steps = 200;
@@ -134,6 +206,15 @@ int main()
         run<V_DMA>(x, stamps, sink, st); run<V_DMA_ROT>(x, stamps, sink, st); run<V_DMA_ROT2>(x, stamps, sink, st);
         run<V_REG>(x, stamps, sink, st); run<V_REG_ROT>(x, stamps, sink, st); run<V_HALF>(x, stamps, sink, st);
         run<V_XCD>(x, stamps, sink, st); run<V_OWN>(x, stamps, sink, st);
+    }
+    printf("-- run-time patterns (mode, multiplier of the workgroup's index in its XCD)\n");
+    for (int rep = 0; rep < 2; ++rep) {
+        run2("add x0 (lockstep)", 0, 0, x, stamps, sink, st);
+        run2("add x1", 0, 1, x, stamps, sink, st); run2("add x3", 0, 3, x, stamps, sink, st); run2("add x5", 0, 5, x, stamps, sink, st);
+        run2("add x7", 0, 7, x, stamps, sink, st); run2("add x8 (two phases)", 0, 8, x, stamps, sink, st); run2("add x2", 0, 2, x, stamps, sink, st);
+        run2("xor x1", 1, 1, x, stamps, sink, st); run2("xor x5", 1, 5, x, stamps, sink, st);
+        run2("adjacent x1", 2, 1, x, stamps, sink, st); run2("adjacent x2", 2, 2, x, stamps, sink, st); run2("adjacent x0", 2, 0, x, stamps, sink, st);
+        run2("interleaved x1", 3, 1, x, stamps, sink, st); run2("interleaved x0", 3, 0, x, stamps, sink, st);
     }
     return 0;
 }

@@ -74,5 +74,6 @@ def test_model_checkpoint_round_trip_in_a_new_process(tmp_path, arch, extra):
     assert torch.equal(a, b), float((a - b).abs().max())
     # 2 bits per weight + operators: the OPT test model has 2 x (4 x 2048^2 + 2 x 2048 x 8192) = 100.7 M weights = 25.2 MB of codes
     nw = 2 * (4 * 2048 * 2048 + 2 * 2048 * 8192) if arch == "opt" else 2 * (4 * 2048 * 2048 + 3 * 2048 * 11008)
-    assert out["save"]["bytes"] < (nw // 4) * (1.25 if extra == 1 else 3.0)
+    # Kronecker operators add p^2 + q^2 values per side (1.9 MB for Llama's 688 x 688 factor), blocked ones n (p + q)
+    assert out["save"]["bytes"] < (nw // 4) * ((1.25 if arch == "opt" else 1.4) if extra == 1 else 3.0)
     print(f"checkpoint {arch} extra {extra}: {out['save']['bytes'] / 1e6:.1f} MB packed for {nw / 1e6:.1f} M weights ({nw / 4e6:.1f} MB of codes)")
