@@ -38,7 +38,9 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
     if (fam == K2_FAM_H) {
         QA_REQUIRE(h_fits, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: kernel family h needs bs <= 16 and d <= %d", BITS == 2 ? 4096 : 4096);
         if constexpr (BITS == 2) {
-            if (p1 == 0) { p1 = nkc <= 8 ? 8 : 8; p2 = nkc <= 8 ? 1 : 2; }
+            // d = 4096 (16 chunks): 4 waves x 4 adjacent chunks since round 5 -- 4.33-4.42 us cold against 4.64-4.69 for 8 x 2 with the same
+            // chunk order (profiles/r05h_k2lab_hl.txt; with rounds 2-4's interleaved chunks 8 x 2 was the faster one); d <= 2048: 8 x 1
+            if (p1 == 0) { p1 = nkc <= 8 ? 8 : 4; p2 = nkc <= 8 ? 1 : 4; }
             if (p1 == 8 && p2 == 1 && nkc <= 8) return launch_h<2, ACT, 1, 8, 1>(A, s);
             if (p1 == 8 && p2 == 2) return launch_h<2, ACT, 1, 8, 2>(A, s);
             if (p1 == 16 && p2 == 1 && nkc <= 16) return launch_h<2, ACT, 1, 16, 1>(A, s);
@@ -110,7 +112,7 @@ int k2v2_launch_grouped(const K2Call *calls, int ngroups, void *stream)
     K2GArgs G;
     for (int i = 0; i < 3; ++i) k2_fill(G.g[i], calls[i < ngroups ? i : 0]);
     hipStream_t s = (hipStream_t)stream;
-    if (c.bits == 2) return nkc <= 8 ? launch_hg<2, ActF16, 1, 8, 1>(G, ngroups, s) : launch_hg<2, ActF16, 1, 8, 2>(G, ngroups, s);
+    if (c.bits == 2) return nkc <= 8 ? launch_hg<2, ActF16, 1, 8, 1>(G, ngroups, s) : launch_hg<2, ActF16, 1, 4, 4>(G, ngroups, s);   // (as run_family)
     return nkc <= 16 ? launch_hg<4, ActF16, 1, 8, 2>(G, ngroups, s) : launch_hg<4, ActF16, 1, 8, 4>(G, ngroups, s);
 }
 

@@ -17,6 +17,150 @@ __device__ unsigned long long *g_k2_probe = nullptr;
 #include "../quip_amd/csrc/dqgemm_v2.h"
 int k2v2_launch(const K2Call &, void *) { return K2V2_NOT_TAKEN; }     // the lab's "old" rows measure the round-1 kernels alone
 int k2v2_launch_grouped(const K2Call *, int, void *) { return K2V2_NOT_TAKEN; }
+namespace {
+// =====================================================================================================================
+// dq_hl_kernel (round 5, LAB ONLY -- a negative result, profiles/r05h_k2lab_hl.txt: 5.0 us cold / 4.07 warm against 4.68 / 3.60 for dq_h_kernel
+// with the same chunking): dq_h_kernel with the roles split by wave -- NW compute waves (x slabs by LDS-DMA, dequant, MFMA, meet) and NL
+// LOADER waves that bring the workgroup's weight tiles from HBM into LDS (one DMA instruction per 1 KiB tile, lane-linear = the STREAM
+// tile as it is), wait for them, meet the compute waves at one barrier and leave.
+// Why: vector memory returns IN ORDER per wave.  In dq_h_kernel a wave's weight loads (HBM: ~2000 clocks cold) sit in the same queue as
+// its sixteen x-slab DMAs (L2 hits): with the weights first nothing of x can return before HBM answers, with the weights last they leave
+// ~1500 clocks late -- either way the HBM round trip and the ingest of x (128 KiB per CU: ~3300 clocks) happen one after the other, and
+// that is the whole difference between the cold launch and the warm one (4.7 vs 3.6 us, profiles/r05g_k2lab_wfirst_ab.txt).  In another
+// wave's queue the weights cost the compute waves nothing: x streams in from clock 0, the tiles arrive under it.
+// EXACT shapes only (d / KC == NW * NCH), one row tile per workgroup; a compute wave's chunks are adjacent (NCH w + i).
+// LDS: [NW][NCH] x slabs (as dq_h_kernel), then NW * NCH weight tiles of 1 KiB.
+// =====================================================================================================================
+template <int BITS, class ACT, int NW, int NCH, int NL, bool HALF>
+__global__ __launch_bounds__(64 * (NW + NL)) void dq_hl_kernel(K2Args A)
+{
+    typedef DeqT<BITS, ACT> Q;
+    constexpr int KC = Q::KC, NT = Q::NT;
+    constexpr int ROWB = KC * 2, NCB = ROWB / 128, NI = 2 * NCB, XB = 16 * ROWB;
+    constexpr int NDMA = HALF ? NI / 2 : NI;
+    constexpr int NTILE = NW * NCH, TPL = NTILE / NL;
+    static_assert(NTILE % NL == 0 && (NCH - 1) * NDMA < 64 && TPL < 64, "tiles per loader wave; vmcnt range");
+    static_assert(1024 + 64 <= NCH * XB, "a wave parks its partials in its own slab region");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *wreg = smem + NW * NCH * XB;
+    const EpiArgs &e = A.e;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t rt0 = blockIdx.x;
+    if (wave >= NW) {
+        // ---- loader wave: TPL adjacent tiles of this row tile, HBM -> LDS, non-temporal -------------------------------------------------
+        const int lw = wave - NW;
+        __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)(A.qw + (uint64_t)rt0 * NTILE * 64), 0, NTILE * 1024, 0x00020000);
+        const uint32_t vl = (uint32_t)lane * 16u;
+#pragma unroll
+        for (int t = 0; t < TPL; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void2_t *)(wreg + (lw * TPL + t) * 1024), 16, vl, (uint32_t)(lw * TPL + t) * 1024u, 0, 2 /* nt */);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                 // the tiles are in LDS: hand-over to the compute waves
+        return;
+    }
+    const int j = lane & 15, g = lane >> 4;
+    const uint32_t rowbytes = (uint32_t)A.d * 2u;
+    char *myreg = smem + wave * (NCH * XB);
+
+    float e_sc = 0.f, e_zr = 0.f, e_bi = 0.f;
+    if (wave < 4) {
+        const int64_t row = (int64_t)rt0 * 16 + (lane & 15);
+        e_sc = e.qfn == QUIPAMD_QFN_B ? e.scale[0] : e.scale[row];
+        if (e.qfn != QUIPAMD_QFN_B) e_zr = e.zero[row];
+        if (e.bias) e_bi = e.bias[row];
+    }
+
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.x, 0, (int)(e.bs * (int64_t)rowbytes), 0x00020000);
+    const uint32_t voff_lo = (lane >> 3) * rowbytes + ((uint32_t)((lane & 7) ^ (lane >> 3)) << 4);
+    const uint32_t voff_hi = voff_lo + 8u * rowbytes;
+    const uint32_t rd_base = lds_addr(myreg) + (j >> 3) * 1024 + (j & 7) * 128;
+    const uint32_t rd0 = rd_base + (((0 + g) ^ (j & 7)) << 4);        // even MFMA steps
+    const uint32_t rd1 = rd_base + (((4 + g) ^ (j & 7)) << 4);        // odd MFMA steps
+    const uint32_t rdw = lds_addr(wreg) + (uint32_t)(NCH * wave) * 1024u + (uint32_t)lane * 16u;   // this wave's first weight tile
+
+    // ---- request all of x -------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const uint32_t kc = (uint32_t)(NCH * wave + i);
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            if ((q & 1) && HALF) continue;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void2_t *)(myreg + i * XB + q * 1024), 16, (q & 1) ? voff_hi : voff_lo,
+                                                     kc * ROWB + (q >> 1) * 128, 0, 0);
+        }
+    }
+    f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const u32x4 ones = {opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES)};
+    static_for<NCH>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        wait_vm<(NCH - 1 - i) * NDMA>();                              // the slabs up to mine (the epilogue parameters are older still)
+        if constexpr (i == 0) __builtin_amdgcn_s_barrier();           // ... and every loader wave has seen its tiles land
+        u32x4 wt;
+        lds_read16<i * 1024>(wt, rdw);
+        u32x4 xf[NT];
+        static_for<NT>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            lds_read16<i * XB + (t >> 1) * 2048>(xf[t], (t & 1) ? rd1 : rd0);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wt)::"memory");
+        wait_lgkm(xf);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t & 1] = ACT::mfma(Q::frag(wt, t), xf[t], acc[t & 1]);
+            accx[t & 1] = ACT::mfma(ones, xf[t], accx[t & 1]);       // row sums of x on the matrix pipe
+        }
+    });
+
+    // ---- meet: the NW k-partials (as dq_h_kernel, RT = 1) -------------------------------------------------------------------------
+    {
+        float *p = reinterpret_cast<float *>(myreg);
+        const f32x4_t a = acc[0] + acc[1];
+        p[lane] = a[0]; p[64 + lane] = a[1]; p[128 + lane] = a[2]; p[192 + lane] = a[3];
+        if (lane < 16) p[256 + lane] = accx[0][0] + accx[1][0];
+    }
+    __syncthreads();                                                  // (the loader waves have left: the compute waves only)
+    asm volatile("" : "+v"(e_sc), "+v"(e_zr), "+v"(e_bi));
+    if (wave < 4) {
+        const int q = wave;
+        const int b = 4 * q + (lane >> 4), wr = lane & 15;
+        const int src = (wr & 3) * 64 + b + 16 * (wr >> 2);
+        float a = 0.f, xsum = 0.f;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) {
+            const float *p = reinterpret_cast<const float *>(smem + v * (NCH * XB));
+            a += p[src];
+            xsum += p[256 + b];
+        }
+        const int64_t row = (int64_t)rt0 * 16 + wr;
+        if (b < e.bs) {
+            const float alpha = e.qfn == QUIPAMD_QFN_B ? e_sc * e.two_over_maxq : e_sc;
+            const float c0 = e.qfn == QUIPAMD_QFN_B ? Q::OFF + 0.5f * (float)e.maxq : Q::OFF + e_zr;
+            const float val = alpha * (a - c0 * xsum) + e_bi;
+            const int64_t o = (int64_t)b * e.m + row;
+            if (e.y_f32) ((float *)e.y)[o] = e.accumulate ? ((float *)e.y)[o] + val : val;
+            else ((uint16_t *)e.y)[o] = e.y_f16 ? f32_to_f16_bits(val) : f32_to_bf16_bits(val);
+        }
+    }
+}
+
+template <int BITS, class ACT, int NW, int NCH, int NL>
+int launch_hl(const K2Args &A, hipStream_t s)
+{
+    typedef DeqT<BITS, ACT> Q;
+    constexpr size_t lds = (size_t)NW * NCH * 16 * Q::KC * 2 + (size_t)NW * NCH * 1024;
+    static_assert(lds <= 160 * 1024 && NW >= 4, "LDS budget; four reducer waves");
+    const bool half = A.e.bs <= 8;
+    auto kern = half ? dq_hl_kernel<BITS, ACT, NW, NCH, NL, true> : dq_hl_kernel<BITS, ACT, NW, NCH, NL, false>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return qa_fail(QUIPAMD_ERR_LAUNCH, "dequant_gemm: cannot raise dynamic LDS to %zu", lds);
+    kern<<<dim3((unsigned)(A.e.m / 16)), 64 * (NW + NL), lds, s>>>(A);
+    QA_LAUNCH_CHECK("quipamd_dequant_gemm(hl)");
+    return QUIPAMD_OK;
+}
+
+}   // namespace
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -196,9 +340,13 @@ template <class ACT> static void run_mode(const std::string &mode, Problem &P)
 #define MB_CASE(B, WR, WB, RT, BT, NL) if (P.bits == B && P.d % 256 == 0) \
         bench(P, "mb<" #B "," #WR "x" #WB "," #RT "x" #BT ",nl" #NL ">", [&](int r) { return launch_mb2<B, ACT, WR, WB, RT, BT, NL>(mkargs(P, r), st); }, 100);
     if (mode == "old" || mode == "h" || mode == "s" || mode == "mb") old("old heuristic", 0, 0, 0, 0);
+#define HL_CASE(B, NW, NCH, NL) if (P.bits == B && P.d / (512 / B) == NW * NCH) \
+        bench(P, "hl<" #B ",nw" #NW ",nch" #NCH ",nl" #NL ">", [&](int r) { return launch_hl<B, ACT, NW, NCH, NL>(mkargs(P, r), st); });
     if (mode == "h") {
-        H_CASE(2, 1, 8, 2) H_CASE(2, 1, 4, 4) H_CASE(2, 1, 16, 1) H_CASE(2, 1, 8, 1) H_CASE(2, 1, 4, 2)
-        H_CASE(4, 1, 8, 4) H_CASE(4, 1, 8, 2)
+        HL_CASE(2, 8, 2, 4) HL_CASE(2, 8, 2, 2) HL_CASE(2, 8, 2, 8) HL_CASE(2, 8, 1, 2) HL_CASE(2, 8, 1, 4) HL_CASE(2, 4, 4, 4) HL_CASE(2, 16, 1, 4)
+        HL_CASE(4, 8, 4, 4) HL_CASE(4, 8, 2, 4)
+        H_CASE(2, 1, 8, 2) H_CASE(2, 1, 4, 4) H_CASE(2, 1, 2, 8) H_CASE(2, 1, 16, 1) H_CASE(2, 1, 8, 1) H_CASE(2, 1, 4, 2) H_CASE(2, 1, 2, 4)
+        H_CASE(4, 1, 8, 4) H_CASE(4, 1, 4, 8) H_CASE(4, 1, 8, 2) H_CASE(4, 1, 4, 4)
     }
     if (mode == "s") {
         S_CASE(2, 7, 2, 1, 3) S_CASE(2, 7, 2, 2, 2) S_CASE(2, 7, 1, 2, 3) S_CASE(2, 7, 1, 4, 2) S_CASE(2, 4, 3, 1, 3) S_CASE(2, 4, 3, 2, 2) S_CASE(2, 4, 2, 2, 3) S_CASE(2, 8, 1, 2, 3)
