@@ -187,6 +187,9 @@ int launch_h(const K2Args &A, hipStream_t s)
 // Past the end the loaders repeat the last stage (clamped): every counted wait stays a constant.
 // x is ingested once per workgroup: 8 KiB of x per NW * TPS KiB of weights.
 // =====================================================================================================================
+// (Round 5, negative result: MORE weight-loader waves -- the change that took dq_mb_kernel from 998 to 1323 TF -- do nothing here:
+//  28672 x 7168 bs 16 15.1-15.4 us with 2 or 4 weight loaders against 15.4 with one, profiles/r05m_k2lab_s_loaders.txt.  This kernel's ring
+//  is D deep with counted waits; the compute waves are its bound, as the round-2 probe said.)
 template <int BITS, class ACT, int NW, int KSP, int SPW, int D>
 __global__ __launch_bounds__(64 * (NW * KSP + 2)) void dq_s_kernel(K2Args A, uint32_t ntile)
 {

@@ -80,12 +80,25 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
     }
     if (fam == K2_FAM_MB) {
         QA_REQUIRE(mb_ok, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: kernel family mb needs d %% 256 == 0");
-        if (p1 == 0) p1 = (((m + 255) / 256) * ((bs + 127) / 128) >= 200) ? 44 : 22;
-        if (p1 == 44) {                                                   // 256 rows x 128 batch rows, 4 x 4 tiles per wave (4 bit: 128 rows)
-            if constexpr (BITS == 2) return launch_mb2<BITS, ACT, 4, 2, 4, 4, 2>(A, s);
-            else return launch_mb2<BITS, ACT, 4, 2, 2, 4, 2>(A, s);
+        // FOUR loader waves since round 5 (45 / 23; 44 / 22 are the two-loader forms of rounds 2-4).  The loaders were the bound: a loader
+        // issues its share of the stage's 80 DMA instructions (each behind an s_mov m0), waits for ALL of them, meets the barrier; with
+        // one loader 593 TF, two 998, three 1272, four 1323 at 28672 x 7168 bs 256 (4096^2 x 2048: 1078 -> 1268), six 585 -- 14 waves leave 128 registers per wave, the 4 x 4 tiles need 150
+        // (profiles/r05j_k2lab_mb.txt, r05k_k2lab_mb_loaders.txt).  Halving the VALU per MFMA instead (48: 4 x 8 tiles per wave) bought nothing.
+        if (p1 == 0) p1 = (((m + 255) / 256) * ((bs + 127) / 128) >= 200) ? 45 : 23;
+        if (p1 == 44 || p1 == 45) {                                       // 256 rows x 128 batch rows, 4 x 4 tiles per wave (4 bit: 128 rows)
+            if constexpr (BITS == 2) return p1 == 45 ? launch_mb2<BITS, ACT, 4, 2, 4, 4, 4>(A, s) : launch_mb2<BITS, ACT, 4, 2, 4, 4, 2>(A, s);
+            else return p1 == 45 ? launch_mb2<BITS, ACT, 4, 2, 2, 4, 4>(A, s) : launch_mb2<BITS, ACT, 4, 2, 2, 4, 2>(A, s);
         }
         if (p1 == 22) return launch_mb2<BITS, ACT, 4, 2, 2, 2, 2>(A, s);   // 128 rows x  64 batch rows
+        if (p1 == 23) return launch_mb2<BITS, ACT, 4, 2, 2, 2, 4>(A, s);
+        if constexpr (BITS == 2) {
+            // round 5 lab configurations (forced only)
+            if (p1 == 46) return launch_mb2<BITS, ACT, 4, 2, 4, 4, 3>(A, s);
+            // ONE compute wave per SIMD with 4 x 8 accumulator tiles: every dequantised A fragment feeds 8 MFMAs instead of 4 (VALU per MFMA
+            // 2.35 -> ~1.2), same workgroup tile, same LDS reads per step: 992 vs 998 TF with two loaders, 1256 vs 1323 with four
+            if (p1 == 48) return launch_mb2<BITS, ACT, 4, 1, 4, 8, 2>(A, s);
+            if (p1 == 49) return launch_mb2<BITS, ACT, 4, 1, 4, 8, 4>(A, s);
+        }
         return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: no mb kernel %d", p1);
     }
     return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: fp16 activations need d %% 256 == 0 (d=%lld)", (long long)d);

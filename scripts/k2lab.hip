@@ -349,11 +349,12 @@ template <class ACT> static void run_mode(const std::string &mode, Problem &P)
         H_CASE(4, 1, 8, 4) H_CASE(4, 1, 4, 8) H_CASE(4, 1, 8, 2) H_CASE(4, 1, 4, 4)
     }
     if (mode == "s") {
+        S_CASE(2, 2, 4, 1, 3) S_CASE(2, 1, 8, 1, 2)
         S_CASE(2, 7, 2, 1, 3) S_CASE(2, 7, 2, 2, 2) S_CASE(2, 7, 1, 2, 3) S_CASE(2, 7, 1, 4, 2) S_CASE(2, 4, 3, 1, 3) S_CASE(2, 4, 3, 2, 2) S_CASE(2, 4, 2, 2, 3) S_CASE(2, 8, 1, 2, 3)
         S_CASE(4, 7, 2, 1, 3) S_CASE(4, 7, 1, 2, 2)
     }
     if (mode == "mb") {
-        MB_CASE(2, 2, 4, 4, 2, 2) MB_CASE(2, 4, 2, 2, 4, 2) MB_CASE(2, 4, 2, 4, 4, 2) MB_CASE(2, 2, 4, 4, 2, 1) MB_CASE(2, 2, 2, 4, 4, 1)
+        MB_CASE(2, 4, 2, 4, 4, 4) MB_CASE(2, 4, 2, 4, 4, 3) MB_CASE(2, 4, 2, 2, 2, 4) MB_CASE(4, 4, 2, 2, 4, 4) MB_CASE(4, 4, 2, 2, 2, 4) MB_CASE(2, 4, 1, 4, 8, 4) MB_CASE(2, 4, 1, 4, 8, 2) MB_CASE(2, 2, 4, 4, 2, 2) MB_CASE(2, 4, 2, 2, 4, 2) MB_CASE(2, 4, 2, 4, 4, 2) MB_CASE(2, 2, 4, 4, 2, 1) MB_CASE(2, 2, 2, 4, 4, 1)
         MB_CASE(2, 2, 2, 2, 2, 1) MB_CASE(2, 2, 2, 4, 2, 1) MB_CASE(2, 4, 1, 2, 4, 1) MB_CASE(2, 2, 4, 2, 2, 2) MB_CASE(2, 4, 2, 2, 2, 2)
         MB_CASE(4, 2, 4, 4, 2, 2) MB_CASE(4, 4, 2, 2, 4, 2) MB_CASE(4, 2, 2, 2, 2, 1)
     }
