@@ -3,6 +3,7 @@
 // K2V2_NOT_TAKEN when the shape is better served by those (bf16 only), a status otherwise.  fp16 activations
 // (quant.py:226-229 widens x, it never narrows it: an fp16 model keeps all its activation bits on the fp16 MFMA pipe)
 // exist only here, so every fp16 shape is taken.
+#include <cstdlib>
 #include "dqgemm_v2.h"
 #include "k2_dispatch.h"
 
@@ -125,7 +126,32 @@ int k2v2_launch_grouped(const K2Call *calls, int ngroups, void *stream)
     K2GArgs G;
     for (int i = 0; i < 3; ++i) k2_fill(G.g[i], calls[i < ngroups ? i : 0]);
     hipStream_t s = (hipStream_t)stream;
-    if (c.bits == 2) return nkc <= 8 ? launch_hg<2, ActF16, 1, 8, 1>(G, ngroups, s) : launch_hg<2, ActF16, 1, 4, 4>(G, ngroups, s);   // (as run_family)
+    if (c.bits == 2 && nkc > 8) {
+        // Row tiles per workgroup: every workgroup pulls ALL of x~ (128 KiB at d = 4096), so a grid of many rounds of one-per-CU workgroups
+        // pays that ingest once per round -- Llama's gate / up at 16 rows is 2 x 688 tiles = 5.4 rounds of 256 at RT 1.  With RT row tiles
+        // per workgroup the grid is RT times smaller and each x~ slab feeds RT weight tiles.  (For ONE round -- the headline, 256 tiles -- RT > 1
+        // lost at every shape in round 2; QUIP_HG_RT=1|2|4 forces it for A/B runs.)
+        const int64_t tiles = c.m / 16;
+        int rt = 1;
+        if (tiles * ngroups > 256 && tiles % 2 == 0) rt = 2;
+        if (tiles * ngroups > 512 && tiles % 4 == 0) rt = 4;
+        if (const char *ev = getenv("QUIP_HG_RT")) {
+            const int f = atoi(ev);
+            if ((f == 1 || f == 2 || f == 4) && tiles % f == 0) rt = f;
+        }
+        if (rt == 4) return launch_hg<2, ActF16, 4, 4, 4>(G, ngroups, s);
+        if (rt == 2) return launch_hg<2, ActF16, 2, 4, 4>(G, ngroups, s);
+        return launch_hg<2, ActF16, 1, 4, 4>(G, ngroups, s);
+    }
+    if (c.bits == 2) {                                                               // d <= 2048: 8 waves x 1 chunk
+        const int64_t tiles = c.m / 16;
+        int rt = (tiles * ngroups > 256 && tiles % 2 == 0) ? 2 : 1;
+        if (const char *ev = getenv("QUIP_HG_RT")) {
+            const int f = atoi(ev);
+            if ((f == 1 || f == 2) && tiles % f == 0) rt = f;
+        }
+        return rt == 2 ? launch_hg<2, ActF16, 2, 8, 1>(G, ngroups, s) : launch_hg<2, ActF16, 1, 8, 1>(G, ngroups, s);
+    }
     return nkc <= 16 ? launch_hg<4, ActF16, 1, 8, 2>(G, ngroups, s) : launch_hg<4, ActF16, 1, 8, 4>(G, ngroups, s);
 }
 

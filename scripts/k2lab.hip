@@ -345,7 +345,7 @@ template <class ACT> static void run_mode(const std::string &mode, Problem &P)
     if (mode == "h") {
         HL_CASE(2, 8, 2, 4) HL_CASE(2, 8, 2, 2) HL_CASE(2, 8, 2, 8) HL_CASE(2, 8, 1, 2) HL_CASE(2, 8, 1, 4) HL_CASE(2, 4, 4, 4) HL_CASE(2, 16, 1, 4)
         HL_CASE(4, 8, 4, 4) HL_CASE(4, 8, 2, 4)
-        H_CASE(2, 1, 8, 2) H_CASE(2, 1, 4, 4) H_CASE(2, 1, 2, 8) H_CASE(2, 1, 16, 1) H_CASE(2, 1, 8, 1) H_CASE(2, 1, 4, 2) H_CASE(2, 1, 2, 4)
+        H_CASE(2, 2, 8, 1) H_CASE(2, 2, 4, 4) H_CASE(2, 4, 4, 4) H_CASE(2, 1, 8, 2) H_CASE(2, 1, 4, 4) H_CASE(2, 1, 2, 8) H_CASE(2, 1, 16, 1) H_CASE(2, 1, 8, 1) H_CASE(2, 1, 4, 2) H_CASE(2, 1, 2, 4)
         H_CASE(4, 1, 8, 4) H_CASE(4, 1, 4, 8) H_CASE(4, 1, 8, 2) H_CASE(4, 1, 4, 4)
     }
     if (mode == "s") {

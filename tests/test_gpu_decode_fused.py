@@ -100,6 +100,7 @@ CASES = [
     (4096, 11008 // 16 * 16, 2, False, "rms", False, False, 8),
     (2048, 2048, 1, True, None, False, True, 6),
     (2048, 2048, 2, True, "rms", False, True, 12),
+    (4096, 4096, 2, True, "rms", False, True, 10),            # 2 x 256 row tiles: the grouped h kernel with 2 row tiles per workgroup (3 x 256, 2 x 688: 4)
 ]
 
 
