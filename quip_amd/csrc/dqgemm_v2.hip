@@ -42,6 +42,16 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
             // d = 4096 (16 chunks): 4 waves x 4 adjacent chunks since round 5 -- 4.33-4.42 us cold against 4.64-4.69 for 8 x 2 with the same
             // chunk order (profiles/r05h_k2lab_hl.txt; with rounds 2-4's interleaved chunks 8 x 2 was the faster one); d <= 2048: 8 x 1
             if (p1 == 0) { p1 = nkc <= 8 ? 8 : 4; p2 = nkc <= 8 ? 1 : 4; }
+            // row tiles per workgroup (cfg[3]; 0 = by the grid): more than one round of 256 one-per-CU workgroups pays the ingest of x once
+            // per round -- 11008 x 4096: 10.5 us at 1 tile, 10.0 at 2, 8.2 at 4; 8192 x 2048: 4.70 / 4.39; at 256 tiles (the headline)
+            // 1 tile stays the fastest: 4.37 against 5.44 / 7.63 (profiles/r05p_k2lab_rt.txt)
+            int rt = c.cfg[3];
+            if (rt == 0) rt = (ntile > 512 && ntile % 4 == 0 && nkc > 8) ? 4 : (ntile > 256 && ntile % 2 == 0) ? 2 : 1;
+            if (rt == 2 && ntile % 2 == 0) {
+                if (p1 == 8 && p2 == 1 && nkc <= 8) return launch_h<2, ACT, 2, 8, 1>(A, s);
+                if (p1 == 4 && p2 == 4) return launch_h<2, ACT, 2, 4, 4>(A, s);
+            }
+            if (rt == 4 && ntile % 4 == 0 && p1 == 4 && p2 == 4) return launch_h<2, ACT, 4, 4, 4>(A, s);
             if (p1 == 8 && p2 == 1 && nkc <= 8) return launch_h<2, ACT, 1, 8, 1>(A, s);
             if (p1 == 8 && p2 == 2) return launch_h<2, ACT, 1, 8, 2>(A, s);
             if (p1 == 16 && p2 == 1 && nkc <= 16) return launch_h<2, ACT, 1, 16, 1>(A, s);

@@ -53,6 +53,12 @@ def _comm_device(group=None):
 
 def _default_compute(wgrid, LT, bits, eta):
     from . import ops                          # HIP kernel K4; raises on CPU tensors -- no fallback
+    if not wgrid.is_cuda and torch.cuda.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
+        # a host-memory backend (gloo) delivered the chunk on the CPU: stage it to this rank's GPU for the kernel and hand the codes back
+        # where the exchange expects them (tests/test_gpu_shard_two_ranks.py: several ranks sharing one GPU).  Still the HIP kernel.
+        dev = torch.device("cuda", torch.cuda.current_device())
+        out = ops.ldlq_round(wgrid.to(dev), LT.to(dev), bits, eta=None if eta is None else eta.to(dev))
+        return out.cpu()
     return ops.ldlq_round(wgrid, LT, bits, eta=eta)
 
 
@@ -174,6 +180,8 @@ def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=Non
                 stats.update({"s_broadcast_LT": t1 - t0, "s_scatter": t2 - t1, "s_round": t3 - t2, "s_gather": t4 - t3})
             last_stats.clear()
             last_stats.update(stats)
+        if out is not None and wgrid is not None and out.device != wgrid.device:
+            out = out.to(wgrid.device)                                 # a host-memory backend gathered on the CPU: back to where the caller's tensors live
         return (out, nxt) if d_next else out
 
     if gather_packed:
