@@ -129,10 +129,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # QUIP_BENCH_BACKEND=gloo (never set by the driver): a DRY RUN of the N > 1 flow on a box with fewer GPUs than ranks -- the ranks share
+    # the GPUs that exist and the collectives go through host memory.  It validates the control flow (every rank in every collective, the
+    # barriers, the max-over-ranks reduction, rank 0's single line); its numbers mean nothing and the line says so.
+    backend = os.environ.get("QUIP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -256,7 +265,7 @@ def main():
             barrier()
             t = e0.elapsed_time(e1) * 1e-3
         if dist is not None:
-            tt = torch.tensor([t], device=dev, dtype=torch.float64)
+            tt = torch.tensor([t], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t = float(tt.item())
         return t
@@ -308,6 +317,8 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": us_cold * 1e-3,
         "higher_is_better": True,
+        **({"dry_run": f"QUIP_BENCH_BACKEND={backend}: ranks share GPUs, collectives through host memory -- control flow only, the numbers mean nothing"}
+           if backend != "nccl" else {}),
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "bf16",
@@ -421,7 +432,7 @@ def main():
                     ts.append(time.perf_counter() - t0)
             tl = float(np.median(ts))
             if dist is not None:
-                tt = torch.tensor([tl], device=dev, dtype=torch.float64)
+                tt = torch.tensor([tl], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 tl = float(tt.item())
             out["sharded_ldlq"] = {"what": f"LDLQ codes of one {lm}x{ld} Linear (OPT-30B fc1 shape), w{BITS}, rows over {world} rank(s); "
@@ -437,6 +448,8 @@ def main():
                     st = dict(shard.last_stats)
                     out["sharded_ldlq"]["exchange"] = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in st.items()}
         except Exception as ex:                       # a side measurement must never take the headline line down
+            import traceback
+            sys.stderr.write(f"[bench.py rank {rank}] sharded_ldlq leg failed:\n{traceback.format_exc()}\n")
             out["sharded_ldlq"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     # ---- the sharded driver on WHOLE models (configs[4] path, north_star "OPT-1.3B full-model LDLQ at 1 / 2 / 4 / 8 GPUs"):
@@ -479,6 +492,8 @@ def main():
                 out["sharded_block_opt30b"] = r_
             torch.cuda.empty_cache()
         except Exception as ex:
+            import traceback
+            sys.stderr.write(f"[bench.py rank {rank}] sharded_model / sharded_block_opt30b leg failed:\n{traceback.format_exc()}\n")
             if rank == 0:
                 out["sharded_model"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 

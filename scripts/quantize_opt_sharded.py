@@ -59,9 +59,11 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
+    own_group = not dist.is_initialized()
+    if (args.backend if own_group else dist.get_backend()) != "nccl":
+        local %= max(torch.cuda.device_count(), 1)       # a host-memory backend: ranks may share a GPU (tests, bench.py's dry run)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    own_group = not dist.is_initialized()
     if own_group:
         dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev if args.backend == "nccl" else None)
     from quip_amd import bal, quant, shard, vector_balance
