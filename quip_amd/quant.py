@@ -854,6 +854,33 @@ def load_packed(path, device):
     return {name: QuantLinear.from_packed_state(st, device) for name, st in torch.load(path, map_location='cpu', weights_only=True).items()}
 
 
+def save_model(model, layers, path):
+    """ONE file for a quantised model -- the role of `--save` (opt.py:644-646: torch.save of the dense state dict): the packed records of
+    `layers` ({dotted name: QuantLinear}, e.g. decode.collect_packed().named(model)) + every tensor of `model.state_dict()` that does NOT
+    belong to one of those modules (embeddings, norms, head, Linears that stayed dense).  Works whether or not `layers` is installed in
+    `model` yet."""
+    own = tuple(n + "." for n in layers)
+    rest = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith(own)}
+    torch.save({"format": "quip_amd.model.v1", "packed": {name: ql.packed_state() for name, ql in layers.items()}, "rest": rest}, path)
+
+
+def load_model(model, path, device):
+    """inverse of save_model onto a fresh skeleton of the same architecture -- the role of `load_quant` (opt.py:350-381: build the model,
+    make_quant, load_state_dict): swaps the packed layers in (make_quant), loads the remaining tensors, moves the model to `device`.
+    Returns {dotted name: QuantLinear}; `decode.DecodeEngine.from_hf(model)` then serves it."""
+    blob = torch.load(path, map_location='cpu', weights_only=True)
+    assert blob.get("format") == "quip_amd.model.v1", "not a quip_amd.quant.save_model file"
+    layers = {name: QuantLinear.from_packed_state(st, device) for name, st in blob["packed"].items()}
+    make_quant(model, layers)
+    missing, unexpected = model.load_state_dict(blob["rest"], strict=False)
+    own = tuple(n + "." for n in layers)
+    stray = [k for k in missing if not k.startswith(own)]
+    if unexpected or stray:
+        raise RuntimeError(f"load_model: the skeleton does not match the file (unexpected {list(unexpected)[:3]}, missing {stray[:3]})")
+    model.to(device)
+    return layers
+
+
 def make_quant(module, layers, name=''):
     """Swap the named nn.Linear modules for packed QuantLinear layers (the role of make_quant3 / make_quant4,
     quant.py:236-246).  `layers`: {dotted name: QuantLinear already packed}."""

@@ -1,10 +1,10 @@
 """-m gpu: the model-level packed checkpoint (VERDICT r4 missing #3) -- the role of `--save` (opt.py:644-646: torch.save of the dense
 state dict) and of `load_quant` (opt.py:350-381: a fresh skeleton, make_quant, load_state_dict):
 
-    process A:  HF model -> the driver (LDLQ w2 + incoherence processing) with decode.collect_packed -> quant.save_packed of EVERY packed
-                Linear (2 bits / weight + operators) + the few non-quantised tensors (embeddings, norms, head) -> logits of the engine
-    process B:  (a NEW python process: nothing survives but the two files) fresh random-init skeleton of the same config ->
-                quant.load_packed -> DecodeEngine.from_hf(model, packed=...) -> logits
+    process A:  HF model -> the driver (LDLQ w2 + incoherence processing) with decode.collect_packed -> quant.save_model: EVERY packed
+                Linear (2 bits / weight + operators) + the few non-quantised tensors (embeddings, norms, head), one file -> logits of the engine
+    process B:  (a NEW python process: nothing survives but the file) fresh random-init skeleton of the same config ->
+                quant.load_model -> DecodeEngine.from_hf(model) -> logits
 
 B's logits equal A's BIT FOR BIT (the packed state round-trips exactly and the launches are deterministic for OPT; Llama under
 quant.DETERMINISTIC_SPLITK), for the Kronecker operators (fused launches) and the blocked ones (what --incoh_processing ships)."""
@@ -33,9 +33,8 @@ if role == "save":
     model = E.build(arch)
     packed, which = E.quantise(model, arch, extra)
     named = packed.named(model)
-    quant.save_packed(named, os.path.join(d, "packed.pt"))
-    rest = {{k: v.cpu() for k, v in model.state_dict().items() if not any(k.startswith(n + ".") for n in named)}}
-    torch.save(rest, os.path.join(d, "rest.pt"))                       # embeddings, norms, head: what is NOT a packed Linear
+    quant.save_packed(named, os.path.join(d, "packed.pt"))             # the packed layers alone (size check below)
+    quant.save_model(model, named, os.path.join(d, "model.pt"))        # ONE file: packed layers + embeddings, norms, head
     packed.install(model)
     eng = decode.DecodeEngine.from_hf(model, max_len=E.SEQLEN)
 else:
@@ -44,13 +43,8 @@ else:
     with torch.no_grad():
         for p_ in model.parameters():
             p_.add_(1.0)
-    layers = quant.load_packed(os.path.join(d, "packed.pt"), E.DEV)
-    rest = torch.load(os.path.join(d, "rest.pt"), map_location="cpu", weights_only=True)
-    eng = decode.DecodeEngine.from_hf(model, packed=layers, max_len=E.SEQLEN)      # make_quant: nn.Linear -> QuantLinear (quant.py:236-246's role)
-    missing, unexpected = model.load_state_dict(rest, strict=False)
-    assert not unexpected, unexpected
-    assert all(any(k.startswith(n + ".") for n in layers) for k in missing), [k for k in missing][:5]
-    eng = decode.DecodeEngine.from_hf(model, max_len=E.SEQLEN)         # (rebuilt over the loaded embeddings / norms)
+    layers = quant.load_model(model, os.path.join(d, "model.pt"), E.DEV)           # load_quant's role: make_quant + load_state_dict
+    eng = decode.DecodeEngine.from_hf(model, max_len=E.SEQLEN)
 logits = torch.stack([eng.forward(t)[0].float().clone() for t in toks]).cpu()
 torch.save(logits, os.path.join(d, role + "_logits.pt"))
 print(json.dumps({{"role": role, "mode": eng.mode, "packed_layers": sum(isinstance(m, quant.QuantLinear) for m in model.modules()),
