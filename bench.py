@@ -59,6 +59,10 @@ def parse():
                     help="for rocprofv3 passes: run only the cold bf16 regime (so per-kernel averages are the headline kernel's)")
     ap.add_argument("--eager", action="store_true", help="time eager launches queued behind a spin kernel (default for --steps <= 256)")
     ap.add_argument("--graph", action="store_true", help="time one hipGraph of K launches (default for --steps > 256)")
+    ap.add_argument("--preheat-ms", type=float, default=50.0,
+                    help="milliseconds of the measured launch itself, on the far end of the weight ring, in front of the W warm-up steps of a timed "
+                         "region: the clocks of a GPU that has been serving for a while (0: time from whatever state the set-up left; the line "
+                         "carries that figure too, as `from_idle`)")
     ap.add_argument("--no-spin", action="store_true",
                     help="with --eager: launch without the spin kernel in front (each kernel then starts on an idle GPU: the form the "
                          "rocprofv3 passes use, whose per-kernel durations are the kernel alone)")
@@ -191,8 +195,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(weights, steps, warmup):
-        """returns seconds for exactly `steps` launches (max over ranks).  `launch` is looked up at call time."""
+    def timed(weights, steps, warmup, preheat_ms=0.0):
+        """returns seconds for exactly `steps` launches (max over ranks).  `launch` is looked up at call time.
+        preheat_ms: that many milliseconds of the same launches BEFORE the warm-up steps (over the far end of the ring), so that the
+        clocks are where a GPU that has been serving for a while has them."""
         side = torch.cuda.Stream()
         nw = len(weights)
         if nw > 1:
@@ -210,6 +216,16 @@ def main():
         # graph pays its own start-up inside the timed region (K = 20: 5.3-5.4 us per launch as a graph, 4.96-4.98 queued eagerly,
         # 4.77 at K = 2000 either way; profiles/r02s_bench_ring_walk.txt, r02u_bench_launch_modes.txt) -- the kernel is the same.
         use_eager = args.eager or (not args.graph and steps <= 256)
+        if preheat_ms > 0:
+            with torch.cuda.stream(side):
+                st = vp(side.cuda_stream)
+                far = max(1, nw - nw // 3) if nw > 1 else 1              # the last two thirds of the ring: the timed copies stay untouched
+                t_end, i = time.perf_counter() + preheat_ms * 1e-3, 0
+                while time.perf_counter() < t_end:
+                    for _ in range(64):
+                        launch(weights[nw - 1 - (i % far)], st)
+                        i += 1
+                    side.synchronize()
         if use_eager:
             with torch.cuda.stream(side):
                 st = vp(side.cuda_stream)
@@ -270,14 +286,17 @@ def main():
             t = float(tt.item())
         return t
 
-    t_cold = timed(ring, args.steps, args.warmup)
+    t_idle = None
+    if args.preheat_ms > 0 and not args.profile_cold_only:
+        t_idle = timed(ring, args.steps, args.warmup)                  # first: the GPU as the set-up left it (a few short launches, then idle)
+    t_cold = timed(ring, args.steps, args.warmup, args.preheat_ms)
     if args.profile_cold_only:
         if rank == 0:
             emit(json.dumps({"profile_cold_only": True, "us_per_launch": t_cold / args.steps * 1e6}))
         if dist is not None:
             dist.destroy_process_group()
         return
-    t_warm = timed([qs], args.steps, args.warmup)
+    t_warm = timed([qs], args.steps, args.warmup, args.preheat_ms)
 
     # ---- the reference operator's own contract: y fp32, accumulated in place (quant.py:226-230) ---------------
     yacc = torch.zeros(BS, M, dtype=torch.float32, device=dev)
@@ -289,8 +308,8 @@ def main():
         if rc:
             raise RuntimeError(lib.quipamd_last_error())
     launch = launch_acc
-    t_acc_cold = timed(ring, args.steps, args.warmup)
-    t_acc_warm = timed([qs], args.steps, args.warmup)
+    t_acc_cold = timed(ring, args.steps, args.warmup, args.preheat_ms)
+    t_acc_warm = timed([qs], args.steps, args.warmup, args.preheat_ms)
     launch = launch_bf16
     BYTES_ACC = M * D * BITS // 8 + 2 * BS * D + 2 * 4 * BS * M      # y read + written as fp32
 
@@ -324,7 +343,9 @@ def main():
         "dtype": "bf16",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: single 4096x4096 Linear, w2 qfn-b, fused dequant-GEMM, bs=16, "
-                               f"cold weights (ring of {len(ring)} packed copies, {len(ring) * qs.numel() * 4 // 2**20} MiB; the timed launches stream copies 0..{min(len(ring), args.steps) - 1}, the warm-up ones come from the other end of the ring)", "m": M, "d": D, "bs": BS, "bits": BITS,
+                               f"cold weights (ring of {len(ring)} packed copies, {len(ring) * qs.numel() * 4 // 2**20} MiB; the timed launches stream copies 0..{min(len(ring), args.steps) - 1}, the warm-up ones come from the other end of the ring"
+                               + (f"; {args.preheat_ms:g} ms of the same launch on the far two thirds of the ring precede the warm-up steps (clocks at their serving state; "
+                                  "`from_idle` is the same measurement without them)" if args.preheat_ms > 0 else "") + ")", "m": M, "d": D, "bs": BS, "bits": BITS,
                    "launch": ("eager launches queued behind a spin kernel" if (args.eager or (not args.graph and args.steps <= 256))
                               else "one hipGraph of K launches"), "parallelism": f"dp{world} (replicas)"},
         "parity_rel_err": rel,
@@ -332,6 +353,10 @@ def main():
                      "frac": round(gbs_cold / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": BYTES, "us_per_launch": round(us_cold, 3),
                      "pct_mfma_peak": round(100 * tf_cold / world / MFMA_PEAK_TF, 2)},
+        **({"from_idle": {"what": f"the same K = {args.steps} launches after W = {args.warmup} warm-up steps on a GPU that was idle before them (no pre-heat): "
+                                  "2-3 % slower, the clocks are still ramping (profiles/r05v_headline_preheat.txt)",
+                          "us_per_launch": round(t_idle / args.steps * 1e6, 3), "value": round(FLOPS * world / (t_idle / args.steps) / 1e12, 3), "unit": "TFLOP/s"}}
+           if t_idle is not None else {}),
         "warm": {"value": round(tf_warm, 3), "unit": "TFLOP/s", "us_per_launch": round(us_warm, 3)},
         "roofline_warm": {"bound": "mfma", "achieved": round(tf_warm / world, 2), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
                           "frac": round(tf_warm / world / MFMA_PEAK_TF, 4)},
@@ -367,7 +392,7 @@ def main():
         keep = launch
         launch = l_
         try:
-            tt = timed(ring_, steps, min(steps, 20)) / steps
+            tt = timed(ring_, steps, min(steps, 20), args.preheat_ms) / steps
         finally:
             launch = keep
         by = wb + 2 * bs_ * d_ + 2 * bs_ * m_
@@ -379,7 +404,8 @@ def main():
             ring = [qs]
             torch.cuda.empty_cache()
             out["k2_shapes"] = {
-                "what": "quipamd_dequant_gemm, w2 qfn b, cold weights, default kernel choice; bytes/flops as SURVEY.md 8(d)",
+                "what": "quipamd_dequant_gemm, w2 qfn b, cold weights, default kernel choice; bytes/flops as SURVEY.md 8(d); every leg behind --preheat-ms of its "
+                        "own launch (the bs > 16 legs are 15 % slower on a GPU that was idle a moment ago: profiles/r05u_k2_mb_modes.jsonl)",
                 "4096x4096 bs16 fp16": k2_leg(4096, 4096, 16, torch.float16, 200),
                 "28672x7168 bs16 bf16 (weight stream)": k2_leg(28672, 7168, 16, torch.bfloat16, 100),
                 "28672x7168 bs256 bf16 (MFMA)": k2_leg(28672, 7168, 256, torch.bfloat16, 50),

@@ -142,6 +142,21 @@ class Quantizer(nn.Module):
 # fixed order through a scratch buffer -- bit-identical runs, one more L2 round trip per MLP tail.  Set it before the engine captures.
 DETERMINISTIC_SPLITK = False
 
+# Decode steps of several sequences: up to ops.FUSED_MAX_ROWS rows can ride in the single fused launch per layer group (its prologue
+# walks the rows one after the other, 1.3 - 2.7 us per row and launch), or the step takes [prologue-only launch, one workgroup per row] +
+# [dequant-GEMM] instead (fused_stage, fused_bigp_tail: one more launch per group, 2.9 us at OPT-1.3B's sizes, 4.5 at Llama-2-7B's).
+# TWO_LAUNCH_ROWS = the row count from which the second form is taken, 2 .. ops.FUSED_MAX_ROWS + 1; None = by the layer's size, from
+# profiles/r05s_two_launch_*.jsonl: OPT-1.3B (hidden 2048) 3 rows 1.32 -> 1.10 ms per step, 4 rows 1.55 -> 1.11, 2 rows 1.00 -> 1.09;
+# Llama-2-7B (hidden 4096) 2 / 3 / 4 rows 1.87 / 2.17 / 2.45 fused against 2.33 / 2.42 / 2.53.  Set it before the engine captures.
+TWO_LAUNCH_ROWS = None
+
+
+def two_launch_from(ql):
+    """the row count from which a decode step through packed layer `ql` takes the two-launch form (see TWO_LAUNCH_ROWS)"""
+    if TWO_LAUNCH_ROWS is not None:
+        return max(2, min(int(TWO_LAUNCH_ROWS), ops.FUSED_MAX_ROWS + 1))
+    return 3 if min(ql.infeatures, ql.outfeatures) <= 2048 else ops.FUSED_MAX_ROWS + 1
+
 
 class QuantLinear(nn.Module):
     """Packed 2/4-bit Linear (the runnable successor of Quant3Linear / Quant4Linear, quant.py:173-233,
@@ -737,8 +752,8 @@ def fused_bigp_tail(ups, down, ys, row_tiles_per_wave=0):
     dev = ys[0].device
     imgs = torch.empty((len(ups), rows, V.n), dtype=torch.float16, device=dev)
     yd = torch.empty((rows, down.outfeatures), dtype=torch.float32, device=dev)
-    if rows > 4:
-        # from 5 rows on: the activation-side pass as its own launch (x~ through a scratch the layer keeps: a hipGraph replays the same
+    if rows >= two_launch_from(down):
+        # from TWO_LAUNCH_ROWS rows on: the activation-side pass as its own launch (x~ through a scratch the layer keeps: a hipGraph replays the same
         # pointers), then the ordinary dequant-GEMM -- no atomics, deterministic
         key = ('xt', rows, str(dev))
         ws = down.__dict__.setdefault('_splitk_ws', {})
@@ -809,7 +824,7 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
     # more rows than the single launch walks in its prologue (ops.FUSED_MAX_ROWS): the same prologue as its own launch, one workgroup per
     # row (ops_only), x~ through global memory, then ONE grouped dequant-GEMM on the same decode-order codes -- the weights stream once for
     # all rows; 2 launches per layer group instead of the 3 of the operator / GEMM / operator form
-    two = rows > ops.FUSED_MAX_ROWS
+    two = rows >= two_launch_from(q0)
     xts = [torch.empty((rows, d), dtype=torch.float16, device=dev) for _ in qls] if two else None
     kw = dict(V=[q.V.fop(False) for q in qls], colscale=[q.inv_scaleWH if q.inv_scaleWH is not None else q.V.one_scale() for q in qls],
               qweight=[q.decode_qweight() for q in qls], scale=[q.scales for q in qls], y=xts if two else ys, m=m, bs=rows, bits=q0.bits,

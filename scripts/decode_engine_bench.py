@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--mode", default="auto")
     ap.add_argument("--bs", type=int, default=1, help="sequences decoded side by side (1..4 on the fused launches); tok/s is the aggregate")
     ap.add_argument("--blk-fused-n", type=int, default=-1, help="csrc/ortho_blk.hip: one launch per blocked operator up to this n (0: never)")
+    ap.add_argument("--two-launch-rows", default="", help="comma list: repeat every measurement with quant.TWO_LAUNCH_ROWS set to each value")
     ap.add_argument("--sweep", default="", help="'bs:fused_n,bs:fused_n,...' -- the model is built once, one JSON line per entry")
     a = ap.parse_args()
     if a.sweep:
@@ -42,13 +43,19 @@ def main():
         for item in a.sweep.split(","):
             b, f = item.split(":")
             a.bs, a.blk_fused_n = int(b), int(f)
-            try:
-                res, model = run(a, model=model, keep=True)
-            except Exception as e:                                    # a batch size a mode does not take: say so, go on
-                res = {"bs": a.bs, "blk_fused_n": a.blk_fused_n, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-                if model is None:
-                    raise
-            print(json.dumps(res), flush=True)
+            for tl in ([int(v) for v in a.two_launch_rows.split(",")] if a.two_launch_rows else [None]):
+                if tl is not None:
+                    from quip_amd import quant
+                    quant.TWO_LAUNCH_ROWS = tl
+                try:
+                    res, model = run(a, model=model, keep=True)
+                except Exception as e:                                    # a batch size a mode does not take: say so, go on
+                    res = {"bs": a.bs, "blk_fused_n": a.blk_fused_n, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                    if model is None:
+                        raise
+                if tl is not None:
+                    res["two_launch_rows"] = tl
+                print(json.dumps(res), flush=True)
         return
     print(json.dumps(run(a)))
 

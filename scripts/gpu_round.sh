@@ -12,10 +12,10 @@ echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== bench"; timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_$TAG.json 2> $O/bench_$TAG.err; echo "bench rc=$?"; cat $O/bench_$TAG.json; tail -3 $O/bench_$TAG.err
 cd /tmp
 echo "== rocprof kernel-trace (cold regime, eager launches)"
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --steps 1000 --warmup 100 --profile-cold-only --eager --no-spin > $O/prof_bench_$TAG.log 2>&1; echo "rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o trace -- python $R/bench.py --steps 1000 --warmup 100 --profile-cold-only --eager --no-spin --preheat-ms 0 > $O/prof_bench_$TAG.log 2>&1; echo "rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "== rocprof pmc $c"
-  timeout 600 rocprofv3 --pmc $c --kernel-trace -d $O/pmc_${c}_$TAG -o pmc -- python $R/bench.py --steps 300 --warmup 30 --profile-cold-only --eager --no-spin > $O/pmc_${c}_$TAG.log 2>&1; echo "rc=$?"
+  timeout 600 rocprofv3 --pmc $c --kernel-trace -d $O/pmc_${c}_$TAG -o pmc -- python $R/bench.py --steps 300 --warmup 30 --profile-cold-only --eager --no-spin --preheat-ms 0 > $O/pmc_${c}_$TAG.log 2>&1; echo "rc=$?"
 done
 echo "== rocprof pmc: MFMA utilisation of the MFMA-bound legs (bs 256 weight stream, prefill)"
 for shape in "28672 7168 256" "4096 4096 2048"; do

@@ -107,10 +107,22 @@ CASES = [
 @pytest.mark.parametrize("bits", [2, 4, 3])
 @pytest.mark.parametrize("d,m,groups,has_u,norm,relu,residual,bs", CASES)
 def test_fused_stage_matches_the_chain_in_fp64(d, m, groups, has_u, norm, relu, residual, bs, bits):
-    """bits 4 / 3: the 4-bit STREAM container (round 4: --wbits 4 and --wbits 3 models decode on the fused launches too)"""
-    from quip_amd.quant import fused_stage, fused_ok
+    """bits 4 / 3: the 4-bit STREAM container (round 4: --wbits 4 and --wbits 3 models decode on the fused launches too).
+    2..4 rows can take either form (quant.TWO_LAUNCH_ROWS: the single launch, or prologue-only launch + dequant-GEMM): both are checked."""
+    from quip_amd import quant
     if bits == 3 and not (d == 2048 and groups == 3 or d == 8192 and bs == 1):
         pytest.skip("3-bit codes ride in the 4-bit container: two shapes cover the only difference (maxq = 7 in the epilogue)")
+    keep = quant.TWO_LAUNCH_ROWS
+    try:
+        for form in ((5, 2) if 2 <= bs <= 4 else (None,)):
+            quant.TWO_LAUNCH_ROWS = form
+            _check_fused_stage(d, m, groups, has_u, norm, relu, residual, bs, bits, pair=form != 2)
+    finally:
+        quant.TWO_LAUNCH_ROWS = keep
+
+
+def _check_fused_stage(d, m, groups, has_u, norm, relu, residual, bs, bits, pair=True):
+    from quip_amd.quant import fused_stage, fused_ok
     qls, Whats = zip(*[_layer(d, m, 100 + 7 * i + d % 97, bits=bits) for i in range(groups)])
     prev = _layer(d if not has_u else 2048 if d == 8192 else d, d, 55)[0] if has_u else None     # prev: * -> d (its U is d wide)
     torch.manual_seed(d + m + bs)
@@ -148,7 +160,7 @@ def test_fused_stage_matches_the_chain_in_fp64(d, m, groups, has_u, norm, relu, 
         for a16, a32 in zip(ys16, ys):
             assert torch.equal(a16, a32.half())
     ys_all = [ys]
-    if d == 8192 and bs <= 2:                                # without `store` the layer-PAIR kernel runs (gather + scale + scatter folded into one scatter)
+    if d == 8192 and bs <= 2 and pair:                       # without `store` the layer-PAIR kernel runs (gather + scale + scatter folded into one scatter)
         ys_pair, t_none = fused_stage(list(qls), prev=prev, y_prev=prev.to_zt(y_prev), residual=res, relu=relu, ln=ln_mod, store=False)
         assert t_none is None and qls[0].__dict__.get('_pair_tables')
         ys_all.append(ys_pair)
