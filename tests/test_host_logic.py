@@ -319,3 +319,23 @@ def test_a_shared_input_that_stops_being_shared_is_an_error_not_a_wrong_hessian(
     with pytest.raises(RuntimeError, match="SHARE_IDENTICAL_INPUTS"):
         b.add_batch(y, None)
     a.free(); b.free()
+
+
+def test_two_launch_policy_of_a_decode_step():
+    """quant.two_launch_from: the row count from which a packed layer's decode launches split into [prologue-only launch] + [dequant-GEMM]
+    -- by the layer's size unless quant.TWO_LAUNCH_ROWS pins it (profiles/r05s_two_launch_*.jsonl), always inside 2 .. FUSED_MAX_ROWS + 1"""
+    from types import SimpleNamespace as NS
+    from quip_amd import quant, ops
+    keep = quant.TWO_LAUNCH_ROWS
+    try:
+        quant.TWO_LAUNCH_ROWS = None
+        assert quant.two_launch_from(NS(infeatures=2048, outfeatures=2048)) == 3
+        assert quant.two_launch_from(NS(infeatures=8192, outfeatures=2048)) == 3          # OPT-1.3B fc2
+        assert quant.two_launch_from(NS(infeatures=2048, outfeatures=8192)) == 3
+        assert quant.two_launch_from(NS(infeatures=4096, outfeatures=4096)) == ops.FUSED_MAX_ROWS + 1
+        assert quant.two_launch_from(NS(infeatures=11008, outfeatures=4096)) == ops.FUSED_MAX_ROWS + 1
+        for pinned, want in ((1, 2), (2, 2), (4, 4), (5, 5), (99, ops.FUSED_MAX_ROWS + 1)):
+            quant.TWO_LAUNCH_ROWS = pinned
+            assert quant.two_launch_from(NS(infeatures=4096, outfeatures=4096)) == want
+    finally:
+        quant.TWO_LAUNCH_ROWS = keep
