@@ -694,8 +694,8 @@ def main():
             del built
             torch.cuda.empty_cache()
             out["decode_batch"] = {"metric": "OPT-1.3B w2 (Kronecker operators) decode, aggregate tok/s with 2 / 4 / 8 / 16 sequences per step (quip_amd.decode.DecodeEngine, "
-                                             "one hipGraph per step); batch 1 is the `decode` leg; up to 4 rows ride in the single fused launch per layer group, 5..64 "
-                                             "rows run [prologue-only launch, one workgroup per row] + [dequant-GEMM] per group (mode v3)", **rows}
+                                             "one hipGraph per step); batch 1 is the `decode` leg; up to 2 rows (4 at hidden > 2048: quant.two_launch_from) ride in the single fused "
+                                             "launch per layer group, more rows run [prologue-only launch, one workgroup per row] + [dequant-GEMM] per group", **rows}
         except Exception as ex:
             out["decode_batch"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
