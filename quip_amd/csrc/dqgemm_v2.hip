@@ -141,6 +141,8 @@ int k2v2_launch_grouped(const K2Call *calls, int ngroups, void *stream)
         // pays that ingest once per round -- Llama's gate / up at 16 rows is 2 x 688 tiles = 5.4 rounds of 256 at RT 1.  With RT row tiles
         // per workgroup the grid is RT times smaller and each x~ slab feeds RT weight tiles.  (For ONE round -- the headline, 256 tiles -- RT > 1
         // lost at every shape in round 2; QUIP_HG_RT=1|2|4 forces it for A/B runs.)
+        // (8 row tiles -- Llama's gate / up as ONE round of 172 workgroups -- measured slower than 4: Llama-2-7B at 16 sequences 3.27 ms per step against
+        //  3.18, at 8 sequences 2.88 against 2.76, profiles/r05w_hg_rt8_llama.txt; the instantiation is not kept.)
         const int64_t tiles = c.m / 16;
         int rt = 1;
         if (tiles * ngroups > 256 && tiles % 2 == 0) rt = 2;
