@@ -23,6 +23,7 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t shifted, uint32_
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
@@ -39,6 +40,10 @@ struct ActBF16 {
     {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x16_t mfma32(const u32x4 &a, const u32x4 &b, const f32x16_t &c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
     static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c)
     {
         return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
@@ -50,6 +55,10 @@ struct ActF16 {
     static __device__ __forceinline__ f32x4_t mfma(const u32x4 &a, const u32x4 &b, const f32x4_t &c)
     {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16_t mfma32(const u32x4 &a, const u32x4 &b, const f32x16_t &c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c)
     {

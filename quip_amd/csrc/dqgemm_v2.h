@@ -383,7 +383,23 @@ int launch_s(const K2Args &A, hipStream_t s)
 //     loaders: wait stage s landed -> barrier(s) -> DMA stage s+1 into the buffer of stage s-1
 //     compute: barrier(s) -> 8 steps on buffer s & 1
 // =====================================================================================================================
-template <int BITS, class ACT, int WR, int WB, int RTw, int BTw, int NL>
+// T32 (round 5): the SAME workgroup tile, stages and loaders with the products on v_mfma_f32_32x32x16 (a bare issue loop of it reaches 2382 TFLOP/s
+// against 2075 for 16x16x32: cdna_hip_programming.md).  The STREAM tile is the 16-row A fragment of 16x16x32 -- lane (row j, k-group g) holds the codes
+// of k = 32 t + 8 g + 0..7 for its 8 steps t -- and the 32-row operand wants lane L = (row L % 32, k-group L / 32) with k = 16 s + 8 (L / 32) + 0..7:
+// that is old lane j + 16 (2 (s & 1) + L / 32) of tile (L % 32) / 16, step t = s / 2.  The tiles pass through LDS here, so the permutation is just the
+// address of two ds_read_b128 per tile PAIR (wE: even s, wO: odd s); the dequantiser, the loaders and the LDS image are unchanged.  x: lane L reads
+// batch row L % 32, 16-byte chunk 2 (s % 4) + L / 32 of column block s / 4 (same swizzle).  D: register r of lane L = weight row 8 (r / 4) + 4 (L / 32) +
+// r % 4, batch row L % 32 -- four consecutive weight rows per register quad, which is what epilogue_store takes.  The row sums S_1 / S_off stay on
+// 16x16x32 (a 32x32 product for a 1 x 32 result would cost a third of the main loop): the owner wave of a 16-row batch tile reads that tile's
+// fragments in the old layout.
+// RESULT (profiles/r05x_k2lab_mb32.txt, r05y_*, r05z_*): correct at every shape tried (bf16 / fp16, ragged m and batch, 2 and 4 bit) and SLOWER --
+// 1100-1130 TFLOP/s against 1330-1380 at 28672 x 7168 bs 256, 1040 / 1310 at 4096^2 x 2048, 1195 / 1490 at 8192^2 x 1024 -- with the x reads
+// conflict-free (the key below: 8 -> 4 LDS cycles per ds_read_b128, no change in time) and requested two steps ahead (pinned: +1 %).  A bare issue
+// loop on the same GPU (scripts/mfma_lab.hip, profiles/r05y_mfma_lab.txt) gives 2430 TFLOP/s for 32x32x16 with constant operands, 1813 with random
+// ones, and 1230-1370 for 16x16x32 either way: the 16x16x32 kernel already runs at its instruction's rate, the 32x32x16 one at 60 % of its own --
+// every part of the stage (dequantisation 10 us, the DMA 9, the x reads 4, the sums 5 of 92) adds to the time as if nothing overlapped, which is what
+// a power-capped clock looks like.  Kept as configuration 47 (forced only).
+template <int BITS, class ACT, int WR, int WB, int RTw, int BTw, int NL, bool T32 = false>
 __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, uint32_t nrb, uint32_t nby)
 {
     typedef DeqSel<BITS, ACT> Q;                                      // 2 bits: multi-exponent dequantisation (dq_common.h)
@@ -413,14 +429,17 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
         __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(A.x + brow0 * A.d), 0, (int)rem, 0x00020000);
         __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.qw, 0, (int)((uint64_t)ntile * nkc * 1024u), 0x00020000);
         const uint32_t vx = (lane >> 3) * rowbytes + ((uint32_t)((lane & 7) ^ (lane >> 3)) << 4), vw = (uint32_t)lane * 16u;
+        // T32: ds_read_b128 is served in four 16-lane groups ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) and a group of the 32-row operand
+        // spans FOUR row blocks: with the key (row & 7) alone rows r and r + 16 of a group share a 16-byte slot (2-way conflict on every x read).  Key (row & 7) ^ ((row >> 4) & 1): the odd 16-row halves are written one chunk over.
+        const uint32_t vx1 = (lane >> 3) * rowbytes + ((uint32_t)((lane & 7) ^ (lane >> 3) ^ 1) << 4);
         auto issue = [&](uint32_t st) {
             char *dst = smem + (st & 1) * SB;
 #pragma unroll
             for (int o = lw; o < NOPS; o += NL) {
                 if (o < NXP) {
                     const int cb = o / (NB / 8), rb = o % (NB / 8);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void2_t *)(dst + o * 1024), 16, vx + (uint32_t)rb * 8u * rowbytes,
-                                                             st * 512u + cb * 128, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void2_t *)(dst + o * 1024), 16,
+                                                             ((T32 && ((rb >> 1) & 1)) ? vx1 : vx) + (uint32_t)rb * 8u * rowbytes, st * 512u + cb * 128, 0, 0);
                 } else {
                     const int i = o - NXP;
                     const uint32_t r = rbk * NRT + i / TPG, rc = r < ntile ? r : ntile - 1;
@@ -451,13 +470,129 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
     const uint32_t rd1 = rdA + (((4 + g) ^ (j & 7)) << 4);
     const uint32_t wof = XBYTES + (uint32_t)(wr * RTw) * TPG * 1024 + (uint32_t)lane * 16;
 
+    // S_1 = sum_k x and S_off = sum_k OFF_k x of batch tile bt are kept, on the matrix pipe, by the wave with wr = bt % WR
+    constexpr int NSB = (BTw + WR - 1) / WR;
+    if constexpr (T32) {
+        static_assert(RTw % 2 == 0 && BTw % 2 == 0, "32 x 32 tiles: pairs of row tiles and of batch tiles");
+        constexpr int NP = RTw / 2, NB2 = BTw / 2;
+        const int l32 = lane & 31, kg = lane >> 5;
+        // weights: old lane (l32 & 15) + 16 kg (even steps) / + 16 (2 + kg) (odd steps) of tile 2 p + (l32 >> 4)
+        const uint32_t wofE = XBYTES + (uint32_t)(wr * RTw + (l32 >> 4)) * TPG * 1024 + (uint32_t)((l32 & 15) + 16 * kg) * 16;
+        // x: batch row (wb BTw 16 + 32 b + l32) -> row block, in-block row; chunk 2 q + kg of a column block for step q of it
+        const uint32_t rdB = (uint32_t)(wb * BTw) * 2048 + (l32 >> 3) * 1024 + (l32 & 7) * 128;
+        const uint32_t rd0s = rdA + (((0 + g) ^ (j & 7) ^ 1) << 4), rd1s = rdA + (((4 + g) ^ (j & 7) ^ 1) << 4);   // odd 16-row tiles
+        static_assert(BTw % 2 == 0, "tile parity = local tile parity");
+        uint32_t xo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xo[q] = rdB + (uint32_t)(((2 * q + kg) ^ (l32 & 7) ^ (l32 >> 4)) << 4);       // key (row & 7) ^ ((row >> 4) & 1)
+        f32x16_t acc[NP][NB2];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int b = 0; b < NB2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[p][b][i] = 0.f;
+        f32x4_t sum1[NSB], sumo[NSB];
+#pragma unroll
+        for (int q = 0; q < NSB; ++q) sum1[q] = sumo[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const typename Q::Consts qc = Q::make_consts();
+        const u32x4 ones = {opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES)};
+        const u32x4 offs[2] = {Q::off_frag(0, qc), Q::off_frag(1, qc)};
+        static_for<WR>([&](auto KK) {
+            constexpr int kk = decltype(KK)::value;
+            if (wr != kk) return;
+#pragma unroll 1
+            for (uint32_t s = 0; s < ns; ++s) {
+                __builtin_amdgcn_s_barrier();
+                const char *sl = smem + (s & 1) * SB;
+                u32x4 wE[NP][TPG], wO[NP][TPG];
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int t = 0; t < TPG; ++t) {
+                        wE[p][t] = *reinterpret_cast<const u32x4 *>(sl + wofE + (2 * p * TPG + t) * 1024);
+                        wO[p][t] = *reinterpret_cast<const u32x4 *>(sl + wofE + (2 * p * TPG + t) * 1024 + 512);
+                    }
+                // The x fragments of step u + 2 are requested in front of the products of step u and pinned there (sched_barrier: VALU / SALU may
+                // cross, DS reads and MFMAs may not): left to itself hipcc reloads the very registers a step has just freed and waits for them two products
+                // later -- an LDS round trip per step in the open.
+                u32x4 xr[3][NB2], sx[NSB][2];
+                auto ldx = [&](int u, u32x4 (&dst)[NB2]) {
+#pragma unroll
+                    for (int b = 0; b < NB2; ++b) dst[b] = *reinterpret_cast<const u32x4 *>(sl + (u >> 2) * (NB * 128) + b * 4096 + xo[u & 3]);
+                };
+                ldx(0, xr[0]);
+                ldx(1, xr[1]);
+                static_for<16>([&](auto U) {
+                    constexpr int u = decltype(U)::value, g32 = u >> 1, tile = g32 / NTT, tstep = g32 % NTT;   // 16-k step of the stage; its 32-k step
+                    constexpr int xi = u % 3;
+                    if constexpr (u + 2 < 16) ldx(u + 2, xr[(u + 2) % 3]);
+                    if constexpr ((u & 3) == 0) {                           // the row sums of this wave's own 16-row batch tile(s): old fragment layout
+#pragma unroll
+                        for (int q = 0; q < NSB; ++q)
+                            if (kk + q * WR < BTw) {
+                                // (16-row batch tile bt = kk + q WR: its rows carry the key bit bt & 1)
+                                sx[q][0] = *reinterpret_cast<const u32x4 *>(sl + (u >> 2) * (NB * 128) + (kk + q * WR) * 2048 + (((kk + q * WR) & 1) ? rd0s : rd0));
+                                sx[q][1] = *reinterpret_cast<const u32x4 *>(sl + (u >> 2) * (NB * 128) + (kk + q * WR) * 2048 + (((kk + q * WR) & 1) ? rd1s : rd1));
+                            }
+                    }
+                    __builtin_amdgcn_sched_barrier(0x6);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const u32x4 a = Q::frag((u & 1) ? wO[p][tile] : wE[p][tile], tstep, qc);
+#pragma unroll
+                        for (int b = 0; b < NB2; ++b) acc[p][b] = ACT::mfma32(a, xr[xi][b], acc[p][b]);
+                    }
+                    if constexpr ((u & 3) == 3) {
+#pragma unroll
+                        for (int q = 0; q < NSB; ++q)
+                            if (kk + q * WR < BTw) {
+                                sum1[q] = ACT::mfma(ones, sx[q][0], sum1[q]);
+                                sum1[q] = ACT::mfma(ones, sx[q][1], sum1[q]);
+                                if constexpr (!Q::UNIFORM) {
+                                    sumo[q] = ACT::mfma(offs[0], sx[q][0], sumo[q]);
+                                    sumo[q] = ACT::mfma(offs[1], sx[q][1], sumo[q]);
+                                }
+                            }
+                    }
+                });
+            }
+        });
+        __builtin_amdgcn_s_barrier();                                  // every fragment read retired: LDS is free
+        float *xsh = reinterpret_cast<float *>(smem), *xso = xsh + NB;
+#pragma unroll
+        for (int q = 0; q < NSB; ++q) {
+            const int bt = wr + q * WR;
+            if (bt < BTw && lane < 16) {
+                xsh[(wb * BTw + bt) * 16 + lane] = sum1[q][0];
+                if constexpr (!Q::UNIFORM) xso[(wb * BTw + bt) * 16 + lane] = sumo[q][0];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NB2; ++b) {
+            const int brow = wb * BTw * 16 + b * 32 + l32;               // batch row inside the workgroup's NB
+            const float xsum = xsh[brow], xoff = Q::UNIFORM ? 0.f : xso[brow];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const uint32_t rt = rt0 + 2 * p + (rg >> 1);
+                    if (rt >= ntile) continue;
+                    const int64_t r0 = (int64_t)rt * 16 + 8 * (rg & 1) + 4 * kg;
+                    const EpiRow epi = load_epi(e, r0);
+                    f32x4_t a = {acc[p][b][4 * rg] - xoff, acc[p][b][4 * rg + 1] - xoff, acc[p][b][4 * rg + 2] - xoff, acc[p][b][4 * rg + 3] - xoff};
+                    epilogue_store(e, epi, Q::OFF, a, xsum, brow0 + brow, r0);
+                }
+        }
+        return;
+    }
+
     f32x4_t acc[RTw][BTw];
 #pragma unroll
     for (int bt = 0; bt < BTw; ++bt)
 #pragma unroll
         for (int r = 0; r < RTw; ++r) acc[r][bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    // S_1 = sum_k x and S_off = sum_k OFF_k x of batch tile bt are kept, on the matrix pipe, by the wave with wr = bt % WR
-    constexpr int NSB = (BTw + WR - 1) / WR;
     f32x4_t sum1[NSB], sumo[NSB];
 #pragma unroll
     for (int q = 0; q < NSB; ++q) sum1[q] = sumo[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -539,14 +674,14 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
     }
 }
 
-template <int BITS, class ACT, int WR, int WB, int RTw, int BTw, int NL>
+template <int BITS, class ACT, int WR, int WB, int RTw, int BTw, int NL, bool T32 = false>
 int launch_mb2(const K2Args &A, hipStream_t s)
 {
     constexpr int NB = WB * BTw * 16, ROWS = WR * RTw * 16, TPG = 256 / (512 / BITS);
     constexpr size_t lds = (size_t)2 * (NB * 512 + ROWS / 16 * TPG * 1024);
     static_assert(lds <= 160 * 1024 && lds >= (size_t)NB * 8, "LDS budget");
     QA_REQUIRE(A.e.m * A.d * BITS / 8 < ((int64_t)1 << 32), QUIPAMD_ERR_SHAPE, "dequant_gemm(mb): packed weights >= 4 GiB");
-    auto kern = dq_mb_kernel<BITS, ACT, WR, WB, RTw, BTw, NL>;
+    auto kern = dq_mb_kernel<BITS, ACT, WR, WB, RTw, BTw, NL, T32>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return qa_fail(QUIPAMD_ERR_LAUNCH, "dequant_gemm: cannot raise dynamic LDS to %zu", lds);

@@ -105,6 +105,8 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
         if constexpr (BITS == 2) {
             // round 5 lab configurations (forced only)
             if (p1 == 46) return launch_mb2<BITS, ACT, 4, 2, 4, 4, 3>(A, s);
+            // the same tile on v_mfma_f32_32x32x16 (dq_mb_kernel<..., T32>)
+            if (p1 == 47) return launch_mb2<BITS, ACT, 4, 2, 4, 4, 4, true>(A, s);
             // ONE compute wave per SIMD with 4 x 8 accumulator tiles: every dequantised A fragment feeds 8 MFMAs instead of 4 (VALU per MFMA
             // 2.35 -> ~1.2), same workgroup tile, same LDS reads per step: 992 vs 998 TF with two loaders, 1256 vs 1323 with four
             if (p1 == 48) return launch_mb2<BITS, ACT, 4, 1, 4, 8, 2>(A, s);

@@ -339,6 +339,8 @@ template <class ACT> static void run_mode(const std::string &mode, Problem &P)
 #define S_CASE(B, NW, KSP, SPW, DD) if (P.bits == B) bench(P, "s<" #B ",nw" #NW ",ksp" #KSP ",spw" #SPW ",d" #DD ">", [&](int r) { return launch_s<B, ACT, NW, KSP, SPW, DD>(mkargs(P, r), st); });
 #define MB_CASE(B, WR, WB, RT, BT, NL) if (P.bits == B && P.d % 256 == 0) \
         bench(P, "mb<" #B "," #WR "x" #WB "," #RT "x" #BT ",nl" #NL ">", [&](int r) { return launch_mb2<B, ACT, WR, WB, RT, BT, NL>(mkargs(P, r), st); }, 100);
+#define MB32_CASE(B, WR, WB, RT, BT, NL) if (P.bits == B && P.d % 256 == 0) \
+        bench(P, "mb32<" #B "," #WR "x" #WB "," #RT "x" #BT ",nl" #NL ">", [&](int r) { return launch_mb2<B, ACT, WR, WB, RT, BT, NL, true>(mkargs(P, r), st); }, 100);
     if (mode == "old" || mode == "h" || mode == "s" || mode == "mb") old("old heuristic", 0, 0, 0, 0);
 #define HL_CASE(B, NW, NCH, NL) if (P.bits == B && P.d / (512 / B) == NW * NCH) \
         bench(P, "hl<" #B ",nw" #NW ",nch" #NCH ",nl" #NL ">", [&](int r) { return launch_hl<B, ACT, NW, NCH, NL>(mkargs(P, r), st); });
@@ -354,6 +356,7 @@ template <class ACT> static void run_mode(const std::string &mode, Problem &P)
         S_CASE(4, 7, 2, 1, 3) S_CASE(4, 7, 1, 2, 2)
     }
     if (mode == "mb") {
+        MB32_CASE(2, 4, 2, 4, 4, 4) MB32_CASE(2, 4, 2, 4, 4, 3) MB32_CASE(4, 4, 2, 2, 4, 4)
         MB_CASE(2, 4, 2, 4, 4, 4) MB_CASE(2, 4, 2, 4, 4, 3) MB_CASE(2, 4, 2, 2, 2, 4) MB_CASE(4, 4, 2, 2, 4, 4) MB_CASE(4, 4, 2, 2, 2, 4) MB_CASE(2, 4, 1, 4, 8, 4) MB_CASE(2, 4, 1, 4, 8, 2) MB_CASE(2, 2, 4, 4, 2, 2) MB_CASE(2, 4, 2, 2, 4, 2) MB_CASE(2, 4, 2, 4, 4, 2) MB_CASE(2, 2, 4, 4, 2, 1) MB_CASE(2, 2, 2, 4, 4, 1)
         MB_CASE(2, 2, 2, 2, 2, 1) MB_CASE(2, 2, 2, 4, 2, 1) MB_CASE(2, 4, 1, 2, 4, 1) MB_CASE(2, 2, 4, 2, 2, 2) MB_CASE(2, 4, 2, 2, 2, 2)
         MB_CASE(4, 2, 4, 4, 2, 2) MB_CASE(4, 4, 2, 2, 4, 2) MB_CASE(4, 2, 2, 2, 2, 1)

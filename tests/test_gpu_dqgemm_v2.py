@@ -105,7 +105,7 @@ def test_s_kernel(ops, O, dt, bits, qfn, m, d, bs):
 def test_mb_kernel(ops, O, dt, bits, qfn, m, d, bs):
     """batched kernel: ragged batch and row counts (workgroup tiles 256 x 128 and 128 x 64), more row blocks than 8
     (the XCD-aware block order), both tile shapes."""
-    for cfg in [(FAM_MB, 44), (FAM_MB, 22), (FAM_MB, 45), (FAM_MB, 23)] + ([(FAM_MB, 48), (FAM_MB, 49), (FAM_MB, 46)] if bits == 2 else []):     # 45 / 23 (round 5): four loader waves; 48 / 49: 4 x 8 tiles per wave
+    for cfg in [(FAM_MB, 44), (FAM_MB, 22), (FAM_MB, 45), (FAM_MB, 23)] + ([(FAM_MB, 48), (FAM_MB, 49), (FAM_MB, 46), (FAM_MB, 47)] if bits == 2 else []):     # 45 / 23 (round 5): four loader waves; 48 / 49: 4 x 8 tiles per wave; 47: the 32x32x16 form
         _run(ops, O, m, d, bs, bits, qfn, dt, cfg, seed=m + d + bs, check16=(cfg[1] == 44))
 
 
