@@ -492,12 +492,14 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
             for (int b = 0; b < NB2; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[p][b][i] = 0.f;
-        f32x4_t sum1[NSB], sumo[NSB];
+        f32x4_t sum1[NSB];
 #pragma unroll
-        for (int q = 0; q < NSB; ++q) sum1[q] = sumo[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NSB; ++q) sum1[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         const typename Q::Consts qc = Q::make_consts();
         const u32x4 ones = {opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES)};
         const u32x4 offs[2] = {Q::off_frag(0, qc), Q::off_frag(1, qc)};
+        const u32x4 zero4 = {0u, 0u, 0u, 0u};                          // both row sums from one product: see the 16x16x32 path below
+        const u32x4 sfr[2] = {j == 0 ? ones : (j == 1 ? offs[0] : zero4), j == 0 ? ones : (j == 1 ? offs[1] : zero4)};
         static_for<WR>([&](auto KK) {
             constexpr int kk = decltype(KK)::value;
             if (wr != kk) return;
@@ -547,12 +549,8 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
 #pragma unroll
                         for (int q = 0; q < NSB; ++q)
                             if (kk + q * WR < BTw) {
-                                sum1[q] = ACT::mfma(ones, sx[q][0], sum1[q]);
-                                sum1[q] = ACT::mfma(ones, sx[q][1], sum1[q]);
-                                if constexpr (!Q::UNIFORM) {
-                                    sumo[q] = ACT::mfma(offs[0], sx[q][0], sumo[q]);
-                                    sumo[q] = ACT::mfma(offs[1], sx[q][1], sumo[q]);
-                                }
+                                sum1[q] = ACT::mfma(sfr[0], sx[q][0], sum1[q]);
+                                sum1[q] = ACT::mfma(sfr[1], sx[q][1], sum1[q]);
                             }
                     }
                 });
@@ -565,7 +563,7 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
             const int bt = wr + q * WR;
             if (bt < BTw && lane < 16) {
                 xsh[(wb * BTw + bt) * 16 + lane] = sum1[q][0];
-                if constexpr (!Q::UNIFORM) xso[(wb * BTw + bt) * 16 + lane] = sumo[q][0];
+                if constexpr (!Q::UNIFORM) xso[(wb * BTw + bt) * 16 + lane] = sum1[q][1];
             }
         }
         __syncthreads();
@@ -593,12 +591,17 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
     for (int bt = 0; bt < BTw; ++bt)
 #pragma unroll
         for (int r = 0; r < RTw; ++r) acc[r][bt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    f32x4_t sum1[NSB], sumo[NSB];
+    f32x4_t sum1[NSB];
 #pragma unroll
-    for (int q = 0; q < NSB; ++q) sum1[q] = sumo[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < NSB; ++q) sum1[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const typename Q::Consts qc = Q::make_consts();
     const u32x4 ones = {opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES)};
     const u32x4 offs[2] = {Q::off_frag(0, qc), Q::off_frag(1, qc)};
+    // ONE product per 32-k step gives both row sums (round 5): A row 0 = ones, A row 1 = the OFF_k pattern, the other rows zero -- D[0][b] = S_1,
+    // D[1][b] = S_off (registers 0 and 1 of lanes 0..15).  As two products (ones, then offs: every row of D the same sum) the sums were 16 of a
+    // wave's 144 MFMAs per stage and 4.8 of 82 us (profiles/r05z_k2lab_mb16_ablations.txt).
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const u32x4 sfr[2] = {j == 0 ? ones : (j == 1 ? offs[0] : zero4), j == 0 ? ones : (j == 1 ? offs[1] : zero4)};
     // The stage loop exists WR times, once per value of wr: which batch tile's sums a wave keeps is then a compile-time
     // constant inside the loop.  Tested per MFMA step instead (`if (wr == kk)` in the body) it was four scalar test-and-branch
     // blocks per step, 116 SALU instructions and 32 taken / not-taken branches per 256-k stage.
@@ -634,8 +637,7 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
 #pragma unroll
                     for (int q = 0; q < NSB; ++q)
                         if (kk + q * WR < BTw) {
-                            sum1[q] = ACT::mfma(ones, xf[kk + q * WR][sh], sum1[q]);
-                            if constexpr (!Q::UNIFORM) sumo[q] = ACT::mfma(offs[sh], xf[kk + q * WR][sh], sumo[q]);
+                            sum1[q] = ACT::mfma(sfr[sh], xf[kk + q * WR][sh], sum1[q]);
                         }
                 }
             }
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
         const int bt = wr + q * WR;
         if (bt < BTw && lane < 16) {
             xsh[(wb * BTw + bt) * 16 + lane] = sum1[q][0];
-            if constexpr (!Q::UNIFORM) xso[(wb * BTw + bt) * 16 + lane] = sumo[q][0];
+            if constexpr (!Q::UNIFORM) xso[(wb * BTw + bt) * 16 + lane] = sum1[q][1];
         }
     }
     __syncthreads();

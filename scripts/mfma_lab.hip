@@ -10,14 +10,20 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
+// four independent products per asm statement (the accumulators stay where the register allocator put them; hipcc's own loop over the builtin rotates
+// them through shifted ranges and pads with s_nop)
+#define MFMA4(OP, A0, A1, A2, A3) asm volatile(OP " %0, %4, %5, %0\n\t" OP " %1, %4, %5, %1\n\t" OP " %2, %4, %5, %2\n\t" OP " %3, %4, %5, %3" \
+                                              : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3) : "v"(a), "v"(b))
 template <int NACC> __global__ __launch_bounds__(256) void k16(float *out, int iters, bf16x8_t a, bf16x8_t b, const bf16x8_t *rnd)
 {
     if (rnd) { a = rnd[threadIdx.x]; b = rnd[256 + threadIdx.x]; }
     f32x4_t acc[NACC];
     for (int i = 0; i < NACC; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int it = 0; it < iters; ++it)
+    for (int it = 0; it < iters; it += 8)
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < NACC; i += 4) MFMA4("v_mfma_f32_16x16x32_bf16", acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
     float s = 0.f;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][3];
     out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -28,9 +34,11 @@ template <int NACC> __global__ __launch_bounds__(256) void k32(float *out, int i
     f32x16_t acc[NACC];
     for (int i = 0; i < NACC; ++i)
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-    for (int it = 0; it < iters; ++it)
+    for (int it = 0; it < iters; it += 8)
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < NACC; i += 4) MFMA4("v_mfma_f32_32x32x16_bf16", acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
     float s = 0.f;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][15];
     out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -70,6 +78,8 @@ int main()
             char nm[96];
             snprintf(nm, sizeof nm, "16x16x32 bf16, 4 acc, %d wave(s) / SIMD", wps);
             run(nm, [&](int n, int it) { k16<4><<<n, 256>>>(out, it, a, b, rp); }, 4 * 2.0 * 16 * 16 * 32, nblk, iters);
+            snprintf(nm, sizeof nm, "16x16x32 bf16, 16 acc, %d wave(s) / SIMD", wps);
+            run(nm, [&](int n, int it) { k16<16><<<n, 256>>>(out, it, a, b, rp); }, 16 * 2.0 * 16 * 16 * 32, nblk, iters);
             snprintf(nm, sizeof nm, "32x32x16 bf16, 4 acc, %d wave(s) / SIMD", wps);
             run(nm, [&](int n, int it) { k32<4><<<n, 256>>>(out, it, a, b, rp); }, 4 * 2.0 * 32 * 32 * 16, nblk, iters);
         }
