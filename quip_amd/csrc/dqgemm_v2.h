@@ -395,10 +395,8 @@ int launch_s(const K2Args &A, hipStream_t s)
 // RESULT (profiles/r05x_k2lab_mb32.txt, r05y_*, r05z_*): correct at every shape tried (bf16 / fp16, ragged m and batch, 2 and 4 bit) and SLOWER --
 // 1100-1130 TFLOP/s against 1330-1380 at 28672 x 7168 bs 256, 1040 / 1310 at 4096^2 x 2048, 1195 / 1490 at 8192^2 x 1024 -- with the x reads
 // conflict-free (the key below: 8 -> 4 LDS cycles per ds_read_b128, no change in time) and requested two steps ahead (pinned: +1 %).  A bare issue
-// loop on the same GPU (scripts/mfma_lab.hip, profiles/r05y_mfma_lab.txt) gives 2430 TFLOP/s for 32x32x16 with constant operands, 1813 with random
-// ones, and 1230-1370 for 16x16x32 either way: the 16x16x32 kernel already runs at its instruction's rate, the 32x32x16 one at 60 % of its own --
-// every part of the stage (dequantisation 10 us, the DMA 9, the x reads 4, the sums 5 of 92) adds to the time as if nothing overlapped, which is what
-// a power-capped clock looks like.  Kept as configuration 47 (forced only).
+// loop on the same GPU (scripts/mfma_lab.hip, profiles/r05y_mfma_lab.txt) agrees: both shapes reach 2.46-2.49 PFLOP/s on constant operands, on random
+// ones 16x16x32 gives 2.2 and 32x32x16 1.9 -- the 32-row shape is the slower instruction on real data.  Kept as configuration 47 (forced only).
 template <int BITS, class ACT, int WR, int WB, int RTw, int BTw, int NL, bool T32 = false>
 __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, uint32_t nrb, uint32_t nby)
 {
