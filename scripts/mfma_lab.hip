@@ -55,11 +55,12 @@ template <class F> static void run(const char *name, F launch, double flops_per_
     const double tf = flops_per_wave_iter * iters * nblk * 4 / (best * 1e-3) / 1e12;
     printf("%-44s %8.3f ms  %8.1f TFLOP/s\n", name, best, tf);
 }
-int main()
+int main(int argc, char **argv)
 {
     float *out; CK(hipMalloc(&out, 4096 * 256 * 4));
     bf16x8_t a, b; for (int i = 0; i < 8; ++i) { a[i] = (__bf16)1.0f; b[i] = (__bf16)0.5f; }
-    const int iters = 20000;
+    const int iters = argc > 1 ? atoi(argv[1]) : 20000;                 // argv[1]: products per accumulator (long runs for clock sampling); argv[2]: 0 / 1 = only that operand kind
+    const int only = argc > 2 ? atoi(argv[2]) : -1;
     bf16x8_t *rnd; CK(hipMalloc(&rnd, 512 * 16));
     {
         __bf16 h[512 * 8]; unsigned st = 12345u;
@@ -71,6 +72,7 @@ int main()
         CK(hipMemcpy(rnd, h, sizeof h, hipMemcpyHostToDevice));
     }
     for (int pass = 0; pass < 2; ++pass) {
+        if (only >= 0 && pass != only) continue;
         const bf16x8_t *rp = pass ? rnd : nullptr;
         printf("--- operands: %s\n", pass ? "random N(0,1) per lane" : "constant 1.0 x 0.5");
         for (int wps = 1; wps <= 3; ++wps) {                               // waves per SIMD = blocks per CU (4 waves each)
