@@ -131,8 +131,9 @@ int quipamd_vecquant4matmul(const float *vec, const int32_t *mat, float *mul, co
 /* quipamd_dequant_gemm_cfg: the same call with the kernel chosen by the caller instead of the shape heuristic -- for
  * benchmarks and the forced-kernel parity tests; never needed for correctness.  cfg = int32[4] {family, p1, p2, 0}
  * (NULL or all 0 = heuristic): family 1 = round-1 kernels; 2 = "h" (bs <= 16, d <= 4096: p1 = waves, p2 = chunks per
- * wave); 3 = "s" (bs <= 16 weight stream: p1 = row tiles per workgroup, p2 = k-split); 4 = "mb" (bs > 16: p1 = 44 | 22,
- * the tile shape).  (Family 5, the round-3 prefill kernel, lost to "mb" at every shape and is no longer in the library:
+ * wave, [3] = row tiles per workgroup or 0); 3 = "s" (bs <= 16 weight stream: p1 = row tiles per workgroup, p2 = k-split); 4 = "mb" (bs > 16:
+ * p1 = 45 | 23 = the 256 x 128 / 128 x 64 workgroup tile with four loader waves, the defaults; 44 | 22 the two-loader forms of rounds 2-4; lab
+ * forms, 2 bit only: 46 three loaders, 48 | 49 one compute wave per SIMD with 4 x 8 tiles, 47 the 256 x 128 tile on v_mfma_f32_32x32x16).  (Family 5, the round-3 prefill kernel, lost to "mb" at every shape and is no longer in the library:
  * scripts/dqgemm_pf_lab.hip.)  An unsupported combination fails with QUIPAMD_ERR_UNSUPPORTED.  Per call, thread safe. */
 int quipamd_dequant_gemm_cfg(const void *x, int x_dtype, const int32_t *qweight, int bits, int layout, int qfn,
                              const float *scale, const float *zero, const float *bias, void *y, int y_dtype,
