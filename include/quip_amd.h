@@ -129,7 +129,7 @@ int quipamd_vecquant4matmul(const float *vec, const int32_t *mat, float *mul, co
                             int64_t m, int64_t d, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* quipamd_dequant_gemm_cfg: the same call with the kernel chosen by the caller instead of the shape heuristic -- for
- * benchmarks and the forced-kernel parity tests; never needed for correctness.  cfg = int32[4] {family, p1, p2, 0}
+ * benchmarks and the forced-kernel parity tests; never needed for correctness.  cfg = int32[4] {family, p1, p2, p3}
  * (NULL or all 0 = heuristic): family 1 = round-1 kernels; 2 = "h" (bs <= 16, d <= 4096: p1 = waves, p2 = chunks per
  * wave, [3] = row tiles per workgroup or 0); 3 = "s" (bs <= 16 weight stream: p1 = row tiles per workgroup, p2 = k-split); 4 = "mb" (bs > 16:
  * p1 = 45 | 23 = the 256 x 128 / 128 x 64 workgroup tile with four loader waves, the defaults; 44 | 22 the two-loader forms of rounds 2-4; lab
