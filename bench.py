@@ -799,7 +799,9 @@ def main():
                                "kind": "reference",
                                "kind_note": "the reference has no packed CPU GEMM: at inference it runs Hugging Face's dense nn.Linear on the "
                                             "fake-quantised weights, i.e. this very torch F.linear call (opt.py:193-299); the reference's LDLQ is "
-                                            "timed from its own files in `ldlq_cpu_reference`, the C restatement in `ldlq_cpu_port`",
+                                            "timed from its own files in `ldlq_cpu_reference`, the C restatement in `ldlq_cpu_port`.  On a GPU box the reference runs this op "
+                                            "on the GPU in fp16: that comparison is `decode.kronecker_operators.dense_fp16_same_harness_tok_per_s` / "
+                                            "`decode_llama.dense_fp16_same_harness_tok_per_s`; the CPU figure is the reported baseline the task asks for, not a speed-up claim",
                                "sample": f"{n} calls of torch CPU F.linear fp32 x[16,4096] @ What[4096,4096]^T "
                                          f"(dense fake-quant weights, what the reference runs at inference), "
                                          f"{dt * 1e3:.3f} ms/call"}
