@@ -170,6 +170,14 @@ template <int BITS, class ACT> struct DeqSel : DeqT<BITS, ACT> {
     static __device__ __forceinline__ u32x4 off_frag(int, const Consts &) { return u32x4{0u, 0u, 0u, 0u}; }
 };
 template <class ACT> struct DeqSel<2, ACT> : DeqME2<ACT> {};
+// the uniform-offset form for 2 bits as well (lab builds of dq_mb_kernel, -DK2_MB_UNIFORM: measured 5 % slower than the multi-exponent form)
+template <int BITS, class ACT> struct DeqUni : DeqT<BITS, ACT> {
+    static constexpr bool UNIFORM = true;
+    struct Consts { };
+    static __device__ __forceinline__ Consts make_consts() { return Consts{}; }
+    static __device__ __forceinline__ u32x4 frag(const u32x4 &w, int t, const Consts &) { return DeqT<BITS, ACT>::frag(w, t); }
+    static __device__ __forceinline__ u32x4 off_frag(int, const Consts &) { return u32x4{0u, 0u, 0u, 0u}; }
+};
 
 template <int BITS> using Deq = DeqT<BITS, ActBF16>;                  // the round-1 kernels are bf16-only
 

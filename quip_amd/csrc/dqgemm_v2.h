@@ -400,7 +400,15 @@ int launch_s(const K2Args &A, hipStream_t s)
 template <int BITS, class ACT, int WR, int WB, int RTw, int BTw, int NL, bool T32 = false>
 __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, uint32_t nrb, uint32_t nby)
 {
+    // Lab switches of this kernel (scripts/k2lab.hip builds with -DK2_MB_...; never defined in the library; the results are WRONG by construction,
+    // only the time is read -- profiles/r05y_*, r05z_*): NOSUMS drops the row-sum reads and products, NODEQ feeds the packed dwords to the MFMAs as
+    // they are, NOX re-uses the x fragments of a stage's first column block (step), NODMA brings in stage 0 only, UNIFORM takes the one-offset
+    // dequantiser for 2 bits as well (16 VALU per packed dword, no S_off).
+#ifdef K2_MB_UNIFORM
+    typedef DeqUni<BITS, ACT> Q;
+#else
     typedef DeqSel<BITS, ACT> Q;                                      // 2 bits: multi-exponent dequantisation (dq_common.h)
+#endif
     constexpr int KC = Q::KC, NTT = Q::NT;
     constexpr int TPG = 256 / KC;                                      // weight tiles per stage and row tile
     constexpr int NCW = WR * WB, NB = WB * BTw * 16, NRT = WR * RTw;   // compute waves, batch rows, row tiles per workgroup
@@ -434,6 +442,9 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
             char *dst = smem + (st & 1) * SB;
 #pragma unroll
             for (int o = lw; o < NOPS; o += NL) {
+#ifdef K2_MB_NODMA
+                if (st > 0) continue;
+#endif
                 if (o < NXP) {
                     const int cb = o / (NB / 8), rb = o % (NB / 8);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void2_t *)(dst + o * 1024), 16,
@@ -525,8 +536,13 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
                 ldx(1, xr[1]);
                 static_for<16>([&](auto U) {
                     constexpr int u = decltype(U)::value, g32 = u >> 1, tile = g32 / NTT, tstep = g32 % NTT;   // 16-k step of the stage; its 32-k step
+#ifdef K2_MB_NOX
+                    constexpr int xi = u & 1;
+#else
                     constexpr int xi = u % 3;
                     if constexpr (u + 2 < 16) ldx(u + 2, xr[(u + 2) % 3]);
+#endif
+#ifndef K2_MB_NOSUMS
                     if constexpr ((u & 3) == 0) {                           // the row sums of this wave's own 16-row batch tile(s): old fragment layout
 #pragma unroll
                         for (int q = 0; q < NSB; ++q)
@@ -536,13 +552,19 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
                                 sx[q][1] = *reinterpret_cast<const u32x4 *>(sl + (u >> 2) * (NB * 128) + (kk + q * WR) * 2048 + (((kk + q * WR) & 1) ? rd1s : rd1));
                             }
                     }
+#endif
                     __builtin_amdgcn_sched_barrier(0x6);
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
+#ifdef K2_MB_NODEQ
+                        const u32x4 a = (u & 1) ? wO[p][tile] : wE[p][tile];
+#else
                         const u32x4 a = Q::frag((u & 1) ? wO[p][tile] : wE[p][tile], tstep, qc);
+#endif
 #pragma unroll
                         for (int b = 0; b < NB2; ++b) acc[p][b] = ACT::mfma32(a, xr[xi][b], acc[p][b]);
                     }
+#ifndef K2_MB_NOSUMS
                     if constexpr ((u & 3) == 3) {
 #pragma unroll
                         for (int q = 0; q < NSB; ++q)
@@ -551,6 +573,7 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
                                 sum1[q] = ACT::mfma(sfr[1], sx[q][1], sum1[q]);
                             }
                     }
+#endif
                 });
             }
         });
@@ -620,23 +643,34 @@ __global__ __launch_bounds__(64 * (WR * WB + NL)) void dq_mb_kernel(K2Args A, ui
                 u32x4 xf[BTw][2];
 #pragma unroll
                 for (int bt = 0; bt < BTw; ++bt) {
+#ifdef K2_MB_NOX
+                    xf[bt][0] = *reinterpret_cast<const u32x4 *>(sl + bt * 2048 + rd0);
+                    xf[bt][1] = *reinterpret_cast<const u32x4 *>(sl + bt * 2048 + rd1);
+#else
                     xf[bt][0] = *reinterpret_cast<const u32x4 *>(sl + cb * (NB * 128) + bt * 2048 + rd0);
                     xf[bt][1] = *reinterpret_cast<const u32x4 *>(sl + cb * (NB * 128) + bt * 2048 + rd1);
+#endif
                 }
 #pragma unroll
                 for (int sh = 0; sh < 2; ++sh) {
                     const int gstep = 2 * cb + sh, tile = gstep / NTT, tstep = gstep % NTT;   // MFMA step inside the stage
 #pragma unroll
                     for (int r = 0; r < RTw; ++r) {
+#ifdef K2_MB_NODEQ
+                        const u32x4 a = wc[r][tile];
+#else
                         const u32x4 a = Q::frag(wc[r][tile], tstep, qc);
+#endif
 #pragma unroll
                         for (int bt = 0; bt < BTw; ++bt) acc[r][bt] = ACT::mfma(a, xf[bt][sh], acc[r][bt]);
                     }
+#ifndef K2_MB_NOSUMS
 #pragma unroll
                     for (int q = 0; q < NSB; ++q)
                         if (kk + q * WR < BTw) {
                             sum1[q] = ACT::mfma(sfr[sh], xf[kk + q * WR][sh], sum1[q]);
                         }
+#endif
                 }
             }
         }

@@ -1,4 +1,6 @@
 #!/bin/bash
+# lab binaries: for v in <switches>; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off $(for s in $v; do echo -DK2_MB_$s; done) -I include -I quip_amd/csrc scripts/k2lab.hip -o build_gpu/k2lab_<name>; done
+#   k2lab_nosums = NOSUMS (the switches were named K2_T32_* when this ran; they are K2_MB_* in dqgemm_v2.h now and act on both forms of the kernel)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
 {

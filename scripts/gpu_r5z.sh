@@ -1,4 +1,6 @@
 #!/bin/bash
+# lab binaries: for v in <switches>; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off $(for s in $v; do echo -DK2_MB_$s; done) -I include -I quip_amd/csrc scripts/k2lab.hip -o build_gpu/k2lab_<name>; done
+#   every binary here = NOSUMS + the switches in its name (K2_T32_* when this ran, K2_MB_* now)
 # ablations of the T32 stage loop (all without the row sums; results are wrong by construction, only the time matters)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R

@@ -1,4 +1,6 @@
 #!/bin/bash
+# lab binaries: for v in <switches>; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off $(for s in $v; do echo -DK2_MB_$s; done) -I include -I quip_amd/csrc scripts/k2lab.hip -o build_gpu/k2lab_<name>; done
+#   k2lab_<A>_<B> = -DK2_MB_<A> -DK2_MB_<B>
 # ablations of the 16x16x32 stage loop of dq_mb_kernel (results wrong by construction, only the time matters), both headline shapes
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
