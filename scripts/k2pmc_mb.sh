@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 counter passes over single K2 lab variants (each pass: counters only + kernel trace, as gpurun requires)
-# usage: k2pmc.sh <tag> ; results -> gpurun_out/k2pmc_<tag>.txt
+# usage: k2pmc_mb.sh <tag> ; results -> gpurun_out/k2pmc_<tag>.txt   (LDS counters of dq_mb_kernel, both MFMA shapes)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 export K2LAB_STEPS=10
@@ -27,16 +27,9 @@ for k, c in acc.items():
 PY
 }
 {
-S="s 28672 7168 16 2 bf16 nw7,ksp2,d3"
-pass s_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -- $S
-pass s_sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC -- $S
-pass s_sq3 SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_WAVES SQ_INSTS_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM SQ_ACTIVE_INST_FLAT -- $S
-pass s_grbm GRBM_GUI_ACTIVE GRBM_COUNT -- $S
-H="h 4096 4096 16 2 bf16 nw8,nch2,mixfalse"
-pass h_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -- $H
-M="mb 28672 7168 256 2 bf16 4x2,4x4"
-pass m_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -- $M
-pass m_sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC -- $M
-pass m_grbm GRBM_GUI_ACTIVE GRBM_COUNT -- $M
+M16="mb 28672 7168 256 2 bf16 mb<2,4x2,4x4,nl4"
+M32="mb 28672 7168 256 2 bf16 mb32<2,4x2,4x4,nl4"
+pass mb16_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -- $M16
+pass mb32_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -- $M32
 } > $O/k2pmc_$1.txt 2>&1
-mkdir -p $O/pmc_csv; for d in /tmp/pmc_*/; do n=$(basename $d); cp $d/p_counter_collection.csv $O/pmc_csv/$n.csv 2>/dev/null; done; du -sh $O/pmc_csv
+grep -v "^/tmp" $O/k2pmc_$1.txt | cut -c1-200
