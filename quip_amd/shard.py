@@ -8,8 +8,10 @@ What shards and why
     assignment would cap the speed-up at 1.5x because fc2 is 2/3 of an OPT block (SURVEY.md 8(e));
   * everything that couples rows (the qfn-b scalar scale = global RMS, vector_balance.py:522; U*W row mixing,
     method.py:175; the Cholesky of H) is done by the owner BEFORE the scatter, so the exchange is
-        broadcast  LT      [d, d]        fp32   (owner -> all)
-        scatter    Wgrid   [m/k, d]      fp32   (owner -> rank r)
+        broadcast  LT      strict upper triangle of [d, d] fp32, as 8 row slabs cut at their first column: 0.56 d^2 words
+                                          (owner -> all; round 6: the lower half is zero by construction and no longer travels)
+        scatter    W       [m/k, d]      the layer's own 16-bit rows + the grid parameters; every rank runs the grid map (K5) itself
+                                          (round 6; fp32 grid coordinates, 4 B per weight, only when W is not a 16-bit tensor)
         (scatter   eta     [m/k, d]      fp32   only with --unbiased)
         gather     codes   [m/k, d]      2/4-bit STREAM-packed words (uint8 on the gloo test path)  (rank r -> owner)
     and no all-reduce exists on the path.  xGMI is point-to-point, so scatter/gather from the owner run over
@@ -51,15 +53,92 @@ def _comm_device(group=None):
     return torch.device("cpu")
 
 
-def _default_compute(wgrid, LT, bits, eta):
+LT_SLABS = 8            # row slabs the LT factor travels in (each cut at its first column)
+
+
+def lt_slabs(d):
+    """[(r0, r1)] row slabs of LT = strict-upper(L^T) [d, d]; slab rows r0..r1 are zero left of column r0, so only columns r0..d travel"""
+    if d < 16 * LT_SLABS:
+        return [(0, d)]
+    b = -(-d // LT_SLABS)
+    return [(r0, min(r0 + b, d)) for r0 in range(0, d, b)]
+
+
+def lt_wire_numel(d):
+    return sum((r1 - r0) * (d - r0) for r0, r1 in lt_slabs(d))
+
+
+def lt_bytes(d):
+    """bytes one LT broadcast moves per receiving rank (0.5625 d^2 fp32 words with 8 slabs instead of d^2)"""
+    return 4 * lt_wire_numel(d)
+
+
+class _TriBroadcast:
+    """work handle of an LT broadcast in slab form: wait() lets the flat buffer land and, on the receiving ranks, cuts it back into the
+    zero-initialised [d, d] tensor (stream-ordered on RCCL: the unpack is queued behind the collective)."""
+
+    def __init__(self, flat, work, LT, unpack):
+        self.flat, self.work, self.LT, self.unpack = flat, work, LT, unpack
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self.unpack:
+            d, off = self.LT.shape[0], 0
+            for r0, r1 in lt_slabs(d):
+                n = (r1 - r0) * (d - r0)
+                self.LT[r0:r1, r0:] = self.flat[off:off + n].view(r1 - r0, d - r0)
+                off += n
+            self.unpack = False
+        self.flat = None
+
+
+def broadcast_LT(LT, d, src, group, dev, async_op=False):
+    """LT [d, d] fp32 from `src` to every rank of `group`, upper slabs only.  Returns (LT on the comm device, handle | None): the tensor is
+    valid after handle.wait() (already waited when async_op is False).  On `src` LT is the factor; elsewhere it is ignored."""
+    rank = dist.get_rank(group)
+    slabs = lt_slabs(d)
+    if rank == src:
+        LT = LT.to(dev, torch.float32).contiguous()
+        flat = LT.reshape(-1) if len(slabs) == 1 else torch.cat([LT[r0:r1, r0:].reshape(-1) for r0, r1 in slabs])
+    else:
+        LT = torch.zeros(d, d, dtype=torch.float32, device=dev) if len(slabs) > 1 else torch.empty(d, d, dtype=torch.float32, device=dev)
+        flat = LT.reshape(-1) if len(slabs) == 1 else torch.empty(lt_wire_numel(d), dtype=torch.float32, device=dev)
+    work = dist.broadcast(flat, src=src, group=group, async_op=async_op)
+    h = _TriBroadcast(flat, work if async_op else None, LT, unpack=(rank != src and len(slabs) > 1))
+    if not async_op:
+        h.wait()
+        return LT, None
+    return LT, h
+
+
+def _host_backend(group=None):
+    return dist.is_initialized() and dist.get_backend(group) != "nccl"
+
+
+def _default_compute(wgrid, LT, bits, eta, group=None):
     from . import ops                          # HIP kernel K4; raises on CPU tensors -- no fallback
-    if not wgrid.is_cuda and torch.cuda.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
+    if not wgrid.is_cuda and torch.cuda.is_available() and _host_backend(group):
         # a host-memory backend (gloo) delivered the chunk on the CPU: stage it to this rank's GPU for the kernel and hand the codes back
         # where the exchange expects them (tests/test_gpu_shard_two_ranks.py: several ranks sharing one GPU).  Still the HIP kernel.
         dev = torch.device("cuda", torch.cuda.current_device())
         out = ops.ldlq_round(wgrid.to(dev), LT.to(dev), bits, eta=None if eta is None else eta.to(dev))
         return out.cpu()
     return ops.ldlq_round(wgrid, LT, bits, eta=eta)
+
+
+def _default_gridmap(w, qfn, scale, zero, maxq, group=None):
+    """grid coordinates of a row chunk on the rank that rounds it (K5, csrc/gridmap.hip; vector_balance.py:515, 522-524)"""
+    from . import ops
+    if not w.is_cuda and torch.cuda.is_available() and _host_backend(group):        # a host-memory backend delivered the rows on the CPU
+        dev = torch.device("cuda", torch.cuda.current_device())
+        return ops.gridmap(w.to(dev), qfn, scale.to(dev), None if zero is None else zero.to(dev), maxq).cpu()
+    return ops.gridmap(w, qfn, scale, zero, maxq)
+
+
+_RAW_DTYPES = {torch.float16: 1, torch.bfloat16: 2}
+_RAW_CODES = {v: k for k, v in _RAW_DTYPES.items()}
 
 
 def _pack_chunk(codes, bits):
@@ -86,7 +165,7 @@ def _tick(dev):
 
 
 def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=None, gather_packed=None, force_exchange=False,
-                       lt_ready=None, next_LT=None):
+                       lt_ready=None, next_LT=None, raw=None, gridmap=None):
     """LDLQ codes of one Linear with its rows split over the ranks of `group`.
     gather_packed: return the codes to the owner as STREAM-packed words (bits/8 bytes per code instead of 1; the
     STREAM layout is row-tile-major, so the per-rank chunks concatenate into the whole matrix's packing).  Default:
@@ -95,6 +174,10 @@ def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=Non
     Collective: every rank calls it.  On `src`: wgrid float32 [m,d] grid coordinates, LT float32 [d,d]
     (ops.unit_lower_t of the Cholesky factor), eta float32 [m,d] or None; returns codes uint8 [m,d].
     On the other ranks the tensor arguments are ignored (pass None) and None is returned.
+    raw (round 6, instead of wgrid): (W [m,d] fp16 | bf16 -- the layer's own rows as vector_balance.py:513-524 sees them --, qfn 'a' | 'b',
+    scale fp32 [1] | [m], zero fp32 [m] | None, maxq): the rows travel in their 16-bit dtype (half the bytes of the fp32 grid coordinates)
+    and EVERY rank runs the grid map on its chunk (`gridmap(w, qfn, scale, zero, maxq) -> fp32`, default K5): the map is elementwise
+    given the grid parameters, so the chunk's coordinates are bit for bit the rows of the owner's full map.
     `compute(wgrid_chunk, LT, bits, eta_chunk) -> uint8 codes` defaults to the HIP kernel.
     force_exchange: run broadcast / scatter / gather (and the HIP pack / unpack around the gather) also with ONE rank -- how a
     single-GPU box exercises the RCCL path.
@@ -102,18 +185,31 @@ def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=Non
     LT broadcast of this job is skipped.  next_LT (owner: float32 [d2, d2], others: anything non-None the header says): the
     NEXT job's LT is broadcast between this job's scatter and its compute, i.e. it travels while every rank rounds
     (SURVEY.md 8(e)); returned as the second element of the result tuple (codes | None, (LT_next, work))."""
-    compute = compute or _default_compute
+    if compute is None:
+        def compute(wg, lt, b, e):
+            return _default_compute(wg, lt, b, e, group=group)
+    if gridmap is None:
+        def gridmap(w, qfn, sc, zr, mq):
+            return _default_gridmap(w, qfn, sc, zr, mq, group=group)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = _comm_device(group)
-    hdr = torch.zeros(6, dtype=torch.int64, device=dev)
+    hdr = torch.zeros(9, dtype=torch.int64, device=dev)
     if rank == src:
-        assert wgrid.dim() == 2 and LT.shape == (wgrid.shape[1], wgrid.shape[1])
-        hdr = torch.tensor([wgrid.shape[0], wgrid.shape[1], int(bits), int(eta is not None), int(lt_ready is not None),
-                            0 if next_LT is None else next_LT.shape[0]], dtype=torch.int64, device=dev)
+        shape = raw[0].shape if raw is not None else wgrid.shape
+        assert len(shape) == 2 and LT.shape == (shape[1], shape[1])
+        rawdt, qfnc, maxq = 0, 0, 0
+        if raw is not None:
+            assert wgrid is None and raw[0].dtype in _RAW_DTYPES and raw[1] in ('a', 'b')
+            rawdt, qfnc, maxq = _RAW_DTYPES[raw[0].dtype], int(raw[1] == 'b'), int(raw[4])
+        hdr = torch.tensor([shape[0], shape[1], int(bits), int(eta is not None), int(lt_ready is not None),
+                            0 if next_LT is None else next_LT.shape[0], rawdt, qfnc, maxq], dtype=torch.int64, device=dev)
     if world > 1 or force_exchange:
         dist.broadcast(hdr, src=src, group=group)
-    m, d, bits, has_eta, lt_pref, d_next = (int(v) for v in hdr.tolist())
+    m, d, bits, has_eta, lt_pref, d_next, rawdt, qfnc, maxq = (int(v) for v in hdr.tolist())
+    qfn = 'b' if qfnc else 'a'
     if world == 1 and not force_exchange:
+        if raw is not None:
+            wgrid = gridmap(raw[0], raw[1], raw[2], raw[3], raw[4])
         out = compute(wgrid, LT, bits, eta)
         return (out, None) if next_LT is not None else out
     if gather_packed is None:
@@ -122,13 +218,13 @@ def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=Non
     c = row_chunk(m, world)
     pad = c * world - m
 
-    def padded_chunks(t):
-        t = t.to(dev, torch.float32)
+    def padded_chunks(t, dtype=torch.float32):
+        t = t.to(dev, dtype)
         if pad:
-            t = torch.cat([t, torch.zeros(pad, d, dtype=torch.float32, device=dev)], 0)
+            t = torch.cat([t, torch.zeros((pad,) + tuple(t.shape[1:]), dtype=dtype, device=dev)], 0)
         return list(t.split(c, 0))
 
-    stats = {"world": world, "m": m, "d": d, "bytes_broadcast_LT": 0, "bytes_scatter": 0, "bytes_gather": 0}
+    stats = {"world": world, "m": m, "d": d, "bytes_broadcast_LT": 0, "bytes_scatter": 0, "bytes_gather": 0, "scatter_form": "raw16" if rawdt else "grid32"}
     t0 = _tick(dev)
     if lt_pref:                                                       # prefetched under the previous job's rounding
         assert lt_ready is not None, "the owner announced a prefetched LT this rank does not hold"
@@ -139,38 +235,58 @@ def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=Non
     else:
         if lt_ready is not None and lt_ready[1] is not None:          # the owner dropped its queue (desync): drain, forget
             lt_ready[1].wait()
-        if rank == src:
-            LT = LT.to(dev, torch.float32).contiguous()
-        else:
-            LT = torch.empty(d, d, dtype=torch.float32, device=dev)
-        dist.broadcast(LT, src=src, group=group)                      # the one tree/ring-shaped transfer
-        stats["bytes_broadcast_LT"] = 4 * d * d
+        LT, _ = broadcast_LT(LT, d, src, group, dev)                   # the one tree/ring-shaped transfer
+        stats["bytes_broadcast_LT"] = lt_bytes(d)
     t1 = _tick(dev)
 
-    mine = torch.empty(c, d, dtype=torch.float32, device=dev)
-    dist.scatter(mine, padded_chunks(wgrid) if rank == src else None, src=src, group=group)
+    sc_mine = zr_mine = None
+    if rawdt:                                                         # 16-bit rows (as bytes: gloo and RCCL both move uint8) + the grid parameters
+        mine8 = torch.empty(c, 2 * d, dtype=torch.uint8, device=dev)
+        dist.scatter(mine8, padded_chunks(raw[0].contiguous().view(torch.uint8), torch.uint8) if rank == src else None, src=src, group=group)
+        mine = mine8.view(_RAW_CODES[rawdt])
+        if qfn == 'b':                                                # one scalar for the whole matrix (vector_balance.py:522)
+            sc_mine = raw[2].to(dev, torch.float32).reshape(1).clone() if rank == src else torch.empty(1, dtype=torch.float32, device=dev)
+            dist.broadcast(sc_mine, src=src, group=group)
+        else:                                                         # per-row (scale, zero): [c, 2]
+            sz = torch.empty(c, 2, dtype=torch.float32, device=dev)
+            parts = None
+            if rank == src:
+                parts = padded_chunks(torch.stack([raw[2].reshape(-1).float().expand(m) if raw[2].numel() == 1 else raw[2].reshape(-1).float(),
+                                                   raw[3].reshape(-1).float().expand(m) if raw[3].numel() == 1 else raw[3].reshape(-1).float()], 1))
+                parts = [p_.contiguous() for p_ in parts]
+                if pad:
+                    parts[-1][c - pad:, 0] = 1.0                      # padded rows: a finite grid (never rounded, never returned)
+            dist.scatter(sz, parts, src=src, group=group)
+            sc_mine, zr_mine = sz[:, 0].contiguous(), sz[:, 1].contiguous()
+        stats["bytes_scatter"] = 2 * c * d * (world - 1)
+    else:
+        mine = torch.empty(c, d, dtype=torch.float32, device=dev)
+        dist.scatter(mine, padded_chunks(wgrid) if rank == src else None, src=src, group=group)
+        stats["bytes_scatter"] = 4 * c * d * (world - 1)
     eta_mine = None
     if has_eta:
         eta_mine = torch.empty(c, d, dtype=torch.float32, device=dev)
         dist.scatter(eta_mine, padded_chunks(eta) if rank == src else None, src=src, group=group)
-    stats["bytes_scatter"] = 4 * c * d * (world - 1) * (2 if has_eta else 1)
+        stats["bytes_scatter"] += 4 * c * d * (world - 1)
     t2 = _tick(dev)
 
     nxt = None
     if d_next:                                                        # the next job's LT rides under this job's rounding
-        if rank == src:
-            nl = next_LT.to(dev, torch.float32).contiguous()
-        else:
-            nl = torch.empty(d_next, d_next, dtype=torch.float32, device=dev)
-        nxt = (nl, dist.broadcast(nl, src=src, group=group, async_op=True))
-        stats["bytes_broadcast_next_LT"] = 4 * d_next * d_next
+        nxt = broadcast_LT(next_LT if rank == src else None, d_next, src, group, dev, async_op=True)
+        stats["bytes_broadcast_next_LT"] = lt_bytes(d_next)
 
     lo, hi = row_partition(m, world)[rank]
     n_real = hi - lo
     codes = torch.zeros(c, d, dtype=torch.uint8, device=dev)
     if n_real > 0:                                                    # padded rows are never rounded
-        codes[:n_real] = compute(mine[:n_real], LT, bits, None if eta_mine is None else eta_mine[:n_real])
+        if rawdt:
+            wg = gridmap(mine[:n_real], qfn, sc_mine if qfn == 'b' else sc_mine[:n_real], None if zr_mine is None else zr_mine[:n_real], maxq)
+        else:
+            wg = mine[:n_real]
+        codes[:n_real] = compute(wg, LT, bits, None if eta_mine is None else eta_mine[:n_real])
     t3 = _tick(dev)
+
+    ref = raw[0] if raw is not None else wgrid
 
     def done(out):
         if rank == src:
@@ -180,8 +296,8 @@ def ldlq_round_sharded(wgrid, LT, bits, eta=None, src=0, group=None, compute=Non
                 stats.update({"s_broadcast_LT": t1 - t0, "s_scatter": t2 - t1, "s_round": t3 - t2, "s_gather": t4 - t3})
             last_stats.clear()
             last_stats.update(stats)
-        if out is not None and wgrid is not None and out.device != wgrid.device:
-            out = out.to(wgrid.device)                                 # a host-memory backend gathered on the CPU: back to where the caller's tensors live
+        if out is not None and ref is not None and out.device != ref.device:
+            out = out.to(ref.device)                                   # a host-memory backend gathered on the CPU: back to where the caller's tensors live
         return (out, nxt) if d_next else out
 
     if gather_packed:
@@ -202,9 +318,10 @@ class ShardedLDLQ:
     """Owner-side handle used by vector_balance.quantize_weight_vecbal when a process group with more than one
     rank is active: announces a job to the ranks parked in serve(), then joins the collective itself."""
 
-    def __init__(self, group=None, src=0, compute=None, force_exchange=False, spmd=False):
+    def __init__(self, group=None, src=0, compute=None, force_exchange=False, spmd=False, gridmap=None):
         """spmd=True: every rank runs the same driver loop and joins each collective by itself (worker_round): no job announcements"""
         self.group, self.src, self.compute, self.force_exchange, self.spmd = group, src, compute, force_exchange, spmd
+        self.gridmap = gridmap     # tests on CPU ranks inject the oracle's grid map next to its rounding kernel
         self._lt_ready = None      # (key, (LT, work)): the coming job's LT, already broadcast under the previous job's rounding
         self._queue = []           # [(key, LT, H)] of the coming round() calls, in call order (queue_LTs); H held so that its address stays its own
         self.desyncs = 0           # how often a round() call did not match the head of the queue (the queue is dropped then)
@@ -239,7 +356,8 @@ class ShardedLDLQ:
         """is the next round() call served from the queue?  key = h_key(H) of the H about to be rounded"""
         return bool(self._queue) and (key is None or self._queue[0][0] == key)
 
-    def round(self, wgrid, LT, bits, eta=None, key=None):
+    def round(self, wgrid, LT, bits, eta=None, key=None, raw=None):
+        """raw: see ldlq_round_sharded -- the rows in their 16-bit dtype plus the grid parameters instead of fp32 grid coordinates"""
         if dist.get_world_size(self.group) > 1 and not self.spmd:
             self._announce(_OP_LDLQ)
         ready = None
@@ -256,7 +374,7 @@ class ShardedLDLQ:
         assert LT is not None, "round(): no LT given and none queued for this H"
         nxt_key, nxt, _ = self._queue[0] if self._queue else (None, None, None)
         out = ldlq_round_sharded(wgrid, LT, bits, eta=eta, src=self.src, group=self.group, compute=self.compute,
-                                 force_exchange=self.force_exchange, lt_ready=ready, next_LT=nxt)
+                                 force_exchange=self.force_exchange, lt_ready=ready, next_LT=nxt, raw=raw, gridmap=self.gridmap)
         if nxt is not None:
             out, pre = out
             self._lt_ready = (nxt_key, pre) if pre is not None else None
@@ -267,7 +385,7 @@ class ShardedLDLQ:
             self._announce(_OP_STOP)
 
 
-def serve(group=None, src=0, compute=None):
+def serve(group=None, src=0, compute=None, gridmap=None):
     """Worker loop for every rank except the owner: wait for a job header, join the collective, repeat until the
     owner calls ShardedLDLQ.shutdown().  Returns the number of jobs served."""
     dev = _comm_device(group)
@@ -277,16 +395,16 @@ def serve(group=None, src=0, compute=None):
         dist.broadcast(op, src=src, group=group)
         if int(op.item()) == _OP_STOP:
             return jobs
-        out = ldlq_round_sharded(None, None, 0, src=src, group=group, compute=compute, lt_ready=ready, next_LT=True)
+        out = ldlq_round_sharded(None, None, 0, src=src, group=group, compute=compute, lt_ready=ready, next_LT=True, gridmap=gridmap)
         ready = out[1] if isinstance(out, tuple) else None           # a prefetched LT for the next job, if the owner sent one
         jobs += 1
 
 
-def worker_round(ready=None, group=None, src=0, compute=None):
+def worker_round(ready=None, group=None, src=0, compute=None, gridmap=None):
     """SPMD counterpart of ShardedLDLQ.round on every rank but the owner: join ONE rounding job (the header broadcast by the owner says
     what it is).  `ready`: what the previous call returned -- the LT the owner prefetched for this job, or None.  Returns the `ready`
     for the next call."""
-    out = ldlq_round_sharded(None, None, 0, src=src, group=group, compute=compute, lt_ready=ready, next_LT=True)
+    out = ldlq_round_sharded(None, None, 0, src=src, group=group, compute=compute, lt_ready=ready, next_LT=True, gridmap=gridmap)
     return out[1] if isinstance(out, tuple) else None
 
 
@@ -328,7 +446,8 @@ def assign_owners(shapes, world):
     return owners
 
 
-def block_owner_per_linear(methods, layers, owners, prepare, skip, finish, group=None, compute=None, force_exchange=False, timers=None):
+def block_owner_per_linear(methods, layers, owners, prepare, skip, finish, group=None, compute=None, force_exchange=False, timers=None,
+                           gridmap=None):
     """One transformer block's Linears quantised with ONE OWNER PER LINEAR (SPMD: every rank calls this with the same lists).
 
       methods   the block's QuantMethod objects in the driver's call order (opt.py:147-170), Hessians already all-reduced
@@ -372,19 +491,16 @@ def block_owner_per_linear(methods, layers, owners, prepare, skip, finish, group
         if world > 1:
             dist.all_reduce(dims, group=group)                         # every rank learns every factor's size (one entry per owner)
         for j in range(n):
-            d = int(dims[j])
-            if owners[j] == rank:
-                buf = prepared[j][1].to(dev, torch.float32).contiguous()
-            else:
-                buf = torch.empty(d, d, dtype=torch.float32, device=dev)
-            ready[j] = (buf, dist.broadcast(buf, src=owners[j], group=group, async_op=True))
+            ready[j] = broadcast_LT(prepared[j][1] if owners[j] == rank else None, int(dims[j]), owners[j], group, dev, async_op=True)
+            if timers is not None:
+                timers["bytes_broadcast_LT"] = timers.get("bytes_broadcast_LT", 0) + lt_bytes(int(dims[j]))
     t2 = tick()
     errors = torch.zeros(n, dtype=torch.float64, device=dev)
     prev = active()
     try:
         for j, m in enumerate(methods):                                # (C)
             if owners[j] == rank:
-                handle = ShardedLDLQ(group=group, src=rank, compute=compute, force_exchange=force_exchange, spmd=True)
+                handle = ShardedLDLQ(group=group, src=rank, compute=compute, force_exchange=force_exchange, spmd=True, gridmap=gridmap)
                 H, LT = prepared.pop(j)
                 if exchange:
                     handle.preload(H, LT, ready[j])
@@ -395,7 +511,7 @@ def block_owner_per_linear(methods, layers, owners, prepare, skip, finish, group
                 activate(None)
                 assert handle.desyncs == 0 and not handle.queued(), "block_owner_per_linear: finish() did not round the prepared Hessian"
             elif exchange:
-                worker_round(ready[j], group=group, src=owners[j], compute=compute)
+                worker_round(ready[j], group=group, src=owners[j], compute=compute, gridmap=gridmap)
             ready[j] = None
     finally:
         activate(prev)
@@ -445,6 +561,8 @@ def all_reduce_hessians(methods, group=None):
     # gets there and would issue one all-reduce per Linear while the others issue one per leader: the calls would pair different
     # Linears' Hessians.  So: every rank reports the leader (as a position in `methods`) of each method, MAX over ranks, and a rank
     # that has not seen the sharing adopts it before the Hessians move.
+    # Every failure below is decided COLLECTIVELY: a rank that raised alone would leave its peers inside the H all-reduces.
+    # Each rank computes its error code, the codes are MAX-reduced, and all ranks raise the same exception together.
     def _leader_of(m):
         lead = getattr(m, "_leader", None) or getattr(m, "_auto_leader", None)
         if lead is None:
@@ -452,14 +570,23 @@ def all_reduce_hessians(methods, group=None):
         for k, o in enumerate(methods):
             if o is lead:
                 return float(k)
-        raise RuntimeError("all_reduce_hessians: a method shares the Hessian of a leader that is not in the list")
-    lead_ix = torch.tensor([_leader_of(m) for m in methods], dtype=torch.float64, device=dev)
+        return -2.0                                                     # a leader outside the list: reported below, by every rank
+    mine = [_leader_of(m) for m in methods]
+    lead_ix = torch.tensor([max(v, -1.0) for v in mine], dtype=torch.float64, device=dev)
     dist.all_reduce(lead_ix, op=dist.ReduceOp.MAX, group=group)
+    err = 1.0 if any(v == -2.0 for v in mine) else 0.0
+    for m, k in zip(methods, lead_ix.tolist()):
+        if k >= 0 and m.H is not None and (m.nsamples != 0 or getattr(m, "_followers", 0) > 0):
+            err = max(err, 2.0)
+    errt = torch.tensor([err], dtype=torch.float64, device=dev)
+    dist.all_reduce(errt, op=dist.ReduceOp.MAX, group=group)
+    if float(errt.item()) == 1.0:
+        raise RuntimeError("all_reduce_hessians: on some rank a method shares the Hessian of a leader that is not in the list")
+    if float(errt.item()) == 2.0:
+        raise RuntimeError("all_reduce_hessians: the ranks disagree on which Linears share a Hessian, and a rank has already accumulated "
+                           "samples into its own (set method.SHARE_IDENTICAL_INPUTS = False)")
     for m, k in zip(methods, lead_ix.tolist()):
         if k >= 0 and m.H is not None:
-            if m.nsamples != 0 or getattr(m, "_followers", 0) > 0:
-                raise RuntimeError("all_reduce_hessians: the ranks disagree on which Linears share a Hessian, and this rank has "
-                                   "already accumulated samples into its own (set method.SHARE_IDENTICAL_INPUTS = False)")
             m.share_hessian_from(methods[int(k)])
     for m, n, t in zip(methods, counts.tolist(), tri.tolist()):
         if m.H is None:                     # a follower of QuantMethod.share_hessian_from (q/k/v share one accumulator): its

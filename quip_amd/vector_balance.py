@@ -12,6 +12,9 @@ from . import ops
 from . import shard
 
 
+SHARD_RAW16 = True      # row-sharded runs scatter 16-bit layers in their own dtype (False: fp32 grid coordinates, rounds 1-5)
+
+
 def check_nbits(wr, nbits):
     """vector_balance.py:8-11."""
     vals, counts = torch.unique(wr, sorted=True, return_counts=True)
@@ -52,8 +55,17 @@ def _greedy_passes(w, codes, H, nbits, n_greedy_passes):
     return wr.to(torch.uint8)
 
 
-def _round_ldl_codes(w, H, nbits, n_greedy_passes, unbiased):
+def _round_ldl_codes(w, H, nbits, n_greedy_passes, unbiased, raw=None):
+    """raw (row-sharded runs only): (W 16-bit, qfn, scale, zero, maxq) instead of the grid coordinates `w` -- the rows travel in their own
+    dtype and every rank maps its chunk onto the grid itself (shard.ldlq_round_sharded)"""
     assert (not unbiased) or (n_greedy_passes == 0), "greedy passes are incompatible with unbiased LDL rounding"
+    if raw is not None:
+        assert w is None and n_greedy_passes == 0 and shard.active() is not None
+        eta = torch.rand(raw[0].shape).to(raw[0].device) if unbiased else None     # same CPU draw as vector_balance.py:174-175
+        sharded = shard.active()
+        key = shard.h_key(H)
+        LT = None if sharded.queued(key) else _ldl_transposed(H)
+        return sharded.round(None, LT, nbits, eta=eta, key=key, raw=raw)
     w = w.to(torch.float32)
     if n_greedy_passes != 0:
         assert shard.active() is None, "greedy passes are not row-sharded (they need s @ H on the owner)"
@@ -134,15 +146,23 @@ def quantize_weight_vecbal(w, H, nbits, npasses, scale, zero, maxq, unbiased=Fal
     else:
         def rounder(wgrid):
             return _round_ldl_codes(wgrid, H, nbits, npasses, unbiased)
+    # row-sharded plain LDLQ on a 16-bit layer (every HF checkpoint: the Balance path hands over layer.weight.data itself, bal.py:29):
+    # the rows are scattered as they are, 2 bytes per weight, and each rank runs the grid map on its chunk (shard.py, round 6)
+    raw16 = (shard.active() is not None and SHARD_RAW16 and qmethod == 'ldlq' and npasses == 0 and w.dtype in (torch.float16, torch.bfloat16)
+             and qfn in ('a', 'b'))
     if qfn == 'a':
-        wgrid = ops.gridmap(w, 'a', scale, zero, mq)
-        codes = rounder(wgrid)
+        if raw16:
+            codes = _round_ldl_codes(None, H, nbits, npasses, unbiased, raw=(w.contiguous(), 'a', scale, zero, mq))
+        else:
+            codes = rounder(ops.gridmap(w, 'a', scale, zero, mq))
         out = ops.codes_to_weight(codes, 'a', scale, zero, mq, out_dtype=torch.float16)
         s_out, z_out = scale.reshape(-1).float(), zero.reshape(-1).float()
     elif qfn == 'b':
         s = ops.qfnb_scale(w)                                    # 2.4*rms(w)+1e-16 in w's dtype (:522)
-        wgrid = ops.gridmap(w, 'b', s, None, mq)
-        codes = rounder(wgrid)
+        if raw16:
+            codes = _round_ldl_codes(None, H, nbits, npasses, unbiased, raw=(w.contiguous(), 'b', s, None, mq))
+        else:
+            codes = rounder(ops.gridmap(w, 'b', s, None, mq))
         out = ops.codes_to_weight(codes, 'b', s, None, mq, out_dtype=torch.float16)
         s_out, z_out = s, None
     else:

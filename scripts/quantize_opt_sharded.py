@@ -130,6 +130,7 @@ def main(argv=None):
             phases["broadcast_LT_s"] = 0.0
         owner_table = None
         bytes_weights = 0
+        bytes_lt_explicit = 0                                  # per-linear owners: the LT slabs broadcast outside the rounding jobs
 
         def tick():
             torch.cuda.synchronize()
@@ -194,6 +195,7 @@ def main(argv=None):
                     for k in ("owner_preproc_factor_s", "broadcast_LT_s", "round_s", "broadcast_weights_s"):
                         phases[k] += blk.get(k, 0.0)
                     bytes_weights += blk.get("bytes_broadcast_weights", 0)
+                    bytes_lt_explicit += blk.get("bytes_broadcast_LT", 0)
                     phases["reforward_s"] += t6 - t6a
                     continue
                 if rank == 0:
@@ -234,7 +236,7 @@ def main(argv=None):
             return {"rank": rank, "samples": mine}
         out = {"world": world, "backend": args.backend, "calibration": args.calibration, "wall_s": round(wall, 3), "linears": len(report),
                "mean_proxy_error": float(np.mean([r["error"] for r in report])), "errors": [r["error"] for r in report], **totals,
-               "bytes_broadcast_weights": bytes_weights, "samples_rank0": mine, "owners": args.owners if spmd else "rank0",
+               "bytes_broadcast_weights": bytes_weights, "bytes_broadcast_LT_explicit": bytes_lt_explicit, "samples_rank0": mine, "owners": args.owners if spmd else "rank0",
                "owner_of_each_linear_last_block": owner_table,
                "phase_seconds_rank0": {k: round(v, 4) for k, v in phases.items()},
                "config": {k: v for k, v in vars(args).items()}}

@@ -53,19 +53,60 @@ def test_rccl_exchange_with_hip_pack_unpack(nccl_group, m, d, bits):
     got = h.round(W, LT, bits)
     assert torch.equal(got, want)
     st = shard.last_stats
-    assert st["world"] == 1 and st["bytes_broadcast_LT"] == 4 * d * d and st["bytes_gather"] == 0 and st["bytes_scatter"] == 0
+    assert st["world"] == 1 and st["bytes_broadcast_LT"] == shard.lt_bytes(d) and st["bytes_gather"] == 0 and st["bytes_scatter"] == 0
     # the queued form: LT of job 2 is broadcast under the rounding of job 1
     W2, LT2 = _fixture(m, d, seed=m + 1)
     Ha, Hb = torch.zeros(2, 2), torch.zeros(2, 2)                       # the queue is keyed by the identity of the H tensor
     h.queue_LTs([(Ha, LT), (Hb, LT2)])
     a = h.round(W, None, bits, key=shard.h_key(Ha))
-    assert shard.last_stats["bytes_broadcast_next_LT"] == 4 * d * d
+    assert shard.last_stats["bytes_broadcast_next_LT"] == shard.lt_bytes(d)
     b = h.round(W2, None, bits, key=shard.h_key(Hb))
     assert shard.last_stats["bytes_broadcast_LT"] == 0
     assert torch.equal(a, want) and torch.equal(b, ops.ldlq_round(W2, LT2, bits))
     # unpacked gather (the branch RCCL takes when the shape does not pack) gives the same codes
     c = shard.ldlq_round_sharded(W, LT, bits, force_exchange=True, gather_packed=False)
     assert torch.equal(c, want)
+
+
+@pytest.mark.parametrize("qfn,bits,dt", [('b', 2, torch.float16), ('a', 4, torch.float16), ('b', 2, torch.bfloat16)])
+def test_rows_travel_in_their_own_dtype(nccl_group, qfn, bits, dt):
+    """round 6: quantize_weight_vecbal under a row-sharding handle scatters a 16-bit layer as it is (2 B per weight) and maps each chunk
+    onto the grid with K5 on the receiving rank: codes, weights and grid parameters bit for bit those of the one-process call; the LT factor
+    travels as upper slabs only (0.5625 d^2 words) and arrives with exact zeros below"""
+    from quip_amd import ops, shard, vector_balance as vb, quant
+    m, d = 200, 1024
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(d, d, generator=g) / d ** 0.5
+    X = (torch.randn(2 * d, d, generator=g) * torch.arange(1, d + 1) ** -0.75) @ A
+    H = (X.T @ X / (2 * d)).to(DEV)
+    H = H + 0.01 * H.diag().mean() * torch.eye(d, device=DEV)
+    W = (0.02 * torch.randn(m, d, generator=g)).to(DEV).to(dt)
+    q = quant.Quantizer()
+    q.configure(bits, perchannel=True, sym=False, qfn=qfn, mse=False)
+    q.find_params(W, weight=True)
+    kw = dict(w=W, H=H, nbits=bits, npasses=0, scale=q.scale, zero=q.zero, maxq=q.maxq, qfn=qfn, qmethod='ldlq', return_codes=True)
+    want = vb.quantize_weight_vecbal(**kw)
+    shard.activate(shard.ShardedLDLQ(force_exchange=True))
+    try:
+        got = vb.quantize_weight_vecbal(**kw)
+        st = dict(shard.last_stats)
+        vb.SHARD_RAW16 = False
+        old = vb.quantize_weight_vecbal(**kw)
+        st_old = dict(shard.last_stats)
+    finally:
+        vb.SHARD_RAW16 = True
+        shard.activate(None)
+    assert st["scatter_form"] == "raw16" and st_old["scatter_form"] == "grid32" and st["bytes_broadcast_LT"] == shard.lt_bytes(d) < 0.6 * 4 * d * d
+    for a, b, c in zip(want, got, old):
+        if a is None:
+            assert b is None and c is None
+        else:
+            assert torch.equal(a, b) and torch.equal(a, c)
+    # the slab broadcast itself: upper part equal, exact zeros below the diagonal on a receiver-shaped buffer
+    LT = ops.cholesky_lt(H)
+    got_lt, h = shard.broadcast_LT(LT, d, 0, None, torch.device(DEV), async_op=True)
+    h.wait()
+    assert torch.equal(got_lt, LT)
 
 
 def test_sharded_driver_script_one_rank(nccl_group):

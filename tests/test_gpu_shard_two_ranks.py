@@ -40,12 +40,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, extra=(), argv=None):
+def _run(world, extra=(), argv=None, one_gpu_each=False):
     argv = ARGV if argv is None else argv
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r) if one_gpu_each else "0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, "-c", CHILD.format(root=ROOT)] + list(argv) + list(extra), env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
@@ -83,3 +84,23 @@ def test_rank_without_samples_with_hip_kernels():
     assert three["linears"] == one["linears"] == 12
     for a, b in zip(one["errors"], three["errors"]):
         assert abs(a - b) <= 2e-2 * abs(a) + 1e-9
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device (runs by itself on any multi-GPU lease)")
+def test_spmd_driver_on_rccl_one_gpu_per_rank():
+    """the first thing a multi-GPU box should run: the same SPMD driver on REAL RCCL, one rank per GPU -- fp64 Hessian all-reduce, LT slab
+    broadcasts, 16-bit row scatter + K5 + K4 on every rank, packed-code gather, weight broadcast -- against the one-rank run"""
+    argv = [a for a in ARGV if a not in ("--backend", "gloo")] + ["--backend", "nccl"]
+    one = _run(1, argv=argv, one_gpu_each=True)
+    world = min(_gpus(), 4)
+    many = _run(world, argv=argv, one_gpu_each=True)
+    assert many["world"] == world and many["backend"] == "nccl" and many["linears"] == one["linears"] == 12
+    for a, b in zip(one["errors"], many["errors"]):
+        assert b == b and abs(a - b) <= 2e-2 * abs(a) + 1e-9, (one["errors"], many["errors"])
+    assert abs(many["mean_proxy_error"] - one["mean_proxy_error"]) <= 5e-3 * abs(one["mean_proxy_error"])
+    assert many["bytes_scatter"] > 0 and many["bytes_gather"] > 0

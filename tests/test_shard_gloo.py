@@ -25,6 +25,18 @@ def _oracle_compute(wgrid, LT, bits, eta):
     return torch.from_numpy(np.ascontiguousarray(codes).astype(np.uint8))
 
 
+def _oracle_gridmap(w, qfn, scale, zero, maxq):
+    """the grid map in the layer's own dtype (vector_balance.py:515, 522-524 as oracle.gridmap_qfnb / gridmap_qfna restate it), given the
+    grid parameters -- what K5 computes on a rank's row chunk"""
+    from oracle import quip_oracle as O
+    wn = w.numpy()
+    if qfn == 'b':
+        dt = wn.dtype.type
+        s = dt(float(scale.reshape(-1)[0]))
+        return torch.from_numpy(np.clip(((wn / s + dt(1)) / dt(2)) * dt(maxq), 0, maxq).astype(np.float32))
+    return torch.from_numpy(O.gridmap_qfna(wn, scale.numpy().reshape(-1, 1), zero.numpy().reshape(-1, 1), maxq))
+
+
 def _fixture(m, d, seed):
     g = torch.Generator().manual_seed(seed)
     A = torch.randn(d, d, generator=g) / d ** 0.5
@@ -57,7 +69,7 @@ def _worker(rank, world, port, m, d, bits, use_eta, mode, out_path):
                 h.queue_LTs([(H1, LT), (H2, LT2), (H3, LT)])
                 assert h.queued(k1) and not h.queued(k2)
                 got = h.round(W, None, bits, eta=eta, key=k1)
-                assert shard.last_stats["bytes_broadcast_LT"] == 4 * d * d and shard.last_stats["bytes_broadcast_next_LT"] == d * d
+                assert shard.last_stats["bytes_broadcast_LT"] == shard.lt_bytes(d) and shard.last_stats["bytes_broadcast_next_LT"] == shard.lt_bytes(d // 2)
                 got2 = h.round(W2, None, bits, key=k2)
                 assert shard.last_stats["bytes_broadcast_LT"] == 0     # came with the previous job
                 got3 = h.round(W[: m // 2], None, bits, key=k3)
@@ -70,11 +82,11 @@ def _worker(rank, world, port, m, d, bits, use_eta, mode, out_path):
                 # NOT be used: job 6 runs with the LT it was handed, the queue is dropped, job 7 is a plain job again.
                 h.queue_LTs([(H1, LT), (H2, LT2)])
                 got5 = h.round(W, None, bits, key=k1)
-                assert shard.last_stats["bytes_broadcast_next_LT"] == d * d
+                assert shard.last_stats["bytes_broadcast_next_LT"] == shard.lt_bytes(d // 2)
                 got6 = h.round(W, LT, bits, key=kx)                    # same shape as the queued job's, a different H
-                assert h.desyncs == 1 and not h.queued() and shard.last_stats["bytes_broadcast_LT"] == 4 * d * d
+                assert h.desyncs == 1 and not h.queued() and shard.last_stats["bytes_broadcast_LT"] == shard.lt_bytes(d)
                 got7 = h.round(W2, LT2, bits, key=k2)
-                assert shard.last_stats["bytes_broadcast_LT"] == d * d
+                assert shard.last_stats["bytes_broadcast_LT"] == shard.lt_bytes(d // 2)
                 assert torch.equal(got5, _oracle_compute(W, LT, bits, None)) and torch.equal(got6, got5) and torch.equal(got7, got2)
                 h.shutdown()
             else:
@@ -107,6 +119,26 @@ def _worker(rank, world, port, m, d, bits, use_eta, mode, out_path):
             want_w = _oracle_compute(W, LT, bits, eta).to(torch.float16)
             assert torch.equal(lins[0].weight.data, want_w)            # every rank now holds the owner's quantised weights
             assert torch.equal(lins[1].weight.data, _oracle_compute(W2, LT2, bits, None).to(torch.float16))
+        elif mode in ("raw_b", "raw_a"):
+            # round 6: the rows travel as the 16-bit tensor they are + the grid parameters; every rank maps its chunk onto the grid
+            g = torch.Generator().manual_seed(11)
+            W16 = (0.02 * torch.randn(m, d, generator=g)).half()
+            maxq = 2 ** bits - 1
+            if mode == "raw_b":
+                qfn, sc, zr = 'b', torch.tensor([float((2.4 * W16.float().square().mean().sqrt()).half())]), None
+            else:
+                qfn = 'a'
+                lo_, hi_ = W16.float().min(1).values.clamp(max=0), W16.float().max(1).values.clamp(min=0)
+                sc = (hi_ - lo_) / maxq
+                zr = torch.round(-lo_ / sc)
+            raw = (W16, qfn, sc, zr, maxq) if rank == 0 else None
+            got = shard.ldlq_round_sharded(None, LT if rank == 0 else None, bits, eta=eta if rank == 0 else None, compute=_oracle_compute,
+                                           raw=raw, gridmap=_oracle_gridmap)
+            assert (got is None) == (rank != 0)
+            if rank == 0:
+                assert shard.last_stats["scatter_form"] == "raw16"
+                assert shard.last_stats["bytes_scatter"] == (2 + (4 if use_eta else 0)) * shard.row_chunk(m, world) * d * (world - 1)
+            W = _oracle_gridmap(W16, qfn, sc, zr, maxq)                   # what the unsharded run rounds
         elif mode == "collective":
             got = shard.ldlq_round_sharded(W if rank == 0 else None, LT if rank == 0 else None, bits,
                                            eta=eta if rank == 0 else None, compute=_oracle_compute)
@@ -130,7 +162,8 @@ def _worker(rank, world, port, m, d, bits, use_eta, mode, out_path):
 
 @pytest.mark.parametrize("m,d,bits,use_eta,mode", [(96, 128, 2, False, "collective"), (40, 128, 4, True, "collective"),
                                                     (16, 64, 2, False, "collective"), (70, 128, 2, True, "serve"),
-                                                    (48, 128, 2, False, "queue"), (64, 128, 2, True, "spmd")])
+                                                    (48, 128, 2, False, "queue"), (64, 128, 2, True, "spmd"),
+                                                    (70, 128, 2, False, "raw_b"), (40, 128, 4, True, "raw_a")])
 def test_sharded_ldlq_matches_unsharded(tmp_path, m, d, bits, use_eta, mode):
     out = str(tmp_path / "res.pt")
     mp.spawn(_worker, args=(2, _free_port(), m, d, bits, use_eta, mode, out), nprocs=2, join=True)
@@ -169,7 +202,7 @@ def test_world_size_one_is_a_plain_call():
         # force_exchange: the whole broadcast / scatter / gather path with one rank (what a single-GPU box uses to run RCCL)
         hx = shard.ShardedLDLQ(compute=_oracle_compute, force_exchange=True)
         assert torch.equal(hx.round(W, LT, 2), got)
-        assert shard.last_stats["world"] == 1 and shard.last_stats["bytes_broadcast_LT"] == 4 * 64 * 64
+        assert shard.last_stats["world"] == 1 and shard.last_stats["bytes_broadcast_LT"] == shard.lt_bytes(64)
     finally:
         dist.destroy_process_group()
 
