@@ -54,6 +54,10 @@ enum quipamd_qfn { QUIPAMD_QFN_A = 0, QUIPAMD_QFN_B = 1, QUIPAMD_QFN_C = 2 };
 
 int quipamd_version(void);
 const char *quipamd_last_error(void); /* host string, valid until the next failing call on this thread */
+/* Measurement hook (no reference counterpart): in the probe build (csrc/probe.h, -DQA_PROBE) the decode launches write s_memtime stamps
+ * of their phases -- slot i of wave w of one workgroup at buf[16 w + i] -- into `buf` (device, 256 x uint64; NULL switches them off).
+ * The shipped library returns QUIPAMD_ERR_UNSUPPORTED. */
+int quipamd_probe_set(void *buf);
 
 /* ---- K1: integer pack / unpack (bit-exact) ------------------------------------------------
  * Replaces the Python/numpy packing loops zeroShot/models/quant.py:198-199 and

@@ -86,6 +86,7 @@ SIGNATURES = {
     "quipamd_hessian_finish": [c_vp, c_double, c_vp, c_i64, c_vp],
     "quipamd_hessian_fast_workspace": [c_i64, c_i64],
     "quipamd_hessian_accum_fast": [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
+    "quipamd_probe_set": [c_vp],
 }
 
 _lib = None

@@ -15,6 +15,7 @@
 // fp32 throughout (the eager chain rounds scores and probabilities to fp16); the result differs from it by that rounding.
 #include "common.h"
 #include "fpass.h"
+#include "probe.h"
 
 namespace {
 
@@ -48,7 +49,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
     float *scores = sm, *red = sm + maxlen, *part = sm + maxlen + 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / heads, head = blockIdx.x % heads;
+    QA_STAMP(0);
     const int64_t pos = *pos_p, T = pos + 1;
+    QA_STAMP(1);                                                    // the position landed
     const S *qh = q + (int64_t)b * ldq + head * HD, *kh = k + (int64_t)b * ldq + head * HD, *vh = v + (int64_t)b * ldq + head * HD;
     S *kcb = kc + ((int64_t)b * heads + head) * maxlen * HD, *vcb = vc + ((int64_t)b * heads + head) * maxlen * HD;
 
@@ -57,6 +60,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
     if (tid < HD) kcb[pos * HD + tid] = kh[tid];
     else if (tid < 2 * HD) vcb[pos * HD + tid - HD] = vh[tid - HD];
     __syncthreads();
+    QA_STAMP(8);                                                    // k, v of this token landed and appended + barrier
 
     float qr[HD];
 #pragma unroll
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
     }
     mx = wave_reduce<true>(mx);
     if (lane == 0) red[wave] = mx;
+    QA_STAMP(9);                                                    // scores: q and the K rows landed
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
@@ -104,6 +109,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
     sum = wave_reduce<false>(sum);
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
+    QA_STAMP(10);
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
 
     // ---- phase 2: o = p V ---------------------------------------------------------------------------------------------
@@ -141,11 +147,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
 #pragma unroll
         for (int e = 0; e < 8; ++e) part[wave * HD + 8 * ch + e] = o[e];
     }
+    QA_STAMP(11);
     __syncthreads();
     if (tid < HD) {
         const float r = (part[tid] + part[HD + tid]) + (part[2 * HD + tid] + part[3 * HD + tid]);
         DT<TI>::store(out + (int64_t)b * ldq + head * HD, tid, r * inv);
     }
+    QA_STAMP(12);
 }
 
 template <class TI, int HD>
@@ -260,7 +268,9 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / G.heads, head = blockIdx.x % G.heads;
+    QA_STAMP(0);
     const int64_t pos = *G.pos, T = pos + 1;
+    QA_STAMP(1);                                                      // the position landed (first dependent round trip)
     if (pos < 0 || pos >= G.maxlen) return;                         // uniform; a full cache is the caller's error
     S *kcb = G.kc + ((int64_t)b * G.heads + head) * G.maxlen * HD, *vcb = G.vc + ((int64_t)b * G.heads + head) * G.maxlen * HD;
 
@@ -304,6 +314,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
             }
         }
     }
+    QA_STAMP(2);                                                      // every request of the prologue issued
 #pragma unroll
     for (int oi = 0; oi < NOP; ++oi) {
         const int o = NGRP == 3 ? grp : oi;
@@ -311,7 +322,9 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
 #pragma unroll
         for (int u = 0; u < NCV; ++u) copy_chunk_zt<P, Q>(ZT, yc[oi][u], t4 + 256 * u);
     }
+    QA_STAMP(3);                                                      // y landed and copied into the image
     __syncthreads();
+    QA_STAMP(4);
 #pragma unroll
     for (int oi = 0; oi < NOP; ++oi) {
         const int o = NGRP == 3 ? grp : oi;
@@ -319,6 +332,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
         mix_stage1<P, Q, NW>(ZT, Z1, fr[oi], w4, lane);
     }
     __syncthreads();
+    QA_STAMP(5);                                                      // stage 1 (its factor fragments landed) + barrier
 #pragma unroll
     for (int oi = 0; oi < NOP; ++oi) {
         const int o = NGRP == 3 ? grp : oi;
@@ -327,6 +341,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
         mix_stage2<P, Q, NW>(Z1, ZF, fr[oi], w4, lane);
     }
     __syncthreads();
+    QA_STAMP(6);                                                      // stage 2 + barrier
     if (NGRP == 3 && wave >= 4) return;                               // the k and v groups are done (hardware barriers count live waves only)
 #pragma unroll
     for (int it = 0; it < GR; ++it) {
@@ -340,6 +355,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
         }
     }
     __syncthreads();
+    QA_STAMP(7);                                                      // gather of the head's slice (index / bias loads landed) + barrier
     if (G.cos_t) {                                                    // rotate_half form of HF's apply_rotary_pos_emb (llama.py:418-471), fp32 math
         float r[GR];
 #pragma unroll
@@ -369,6 +385,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
         else if (t >= 2 * HD && t < 3 * HD) vcb[pos * HD + t - 2 * HD] = qkv[t];
     }
     __syncthreads();
+    QA_STAMP(8);                                                      // (rotary) + cache append + barrier
 
     // q as packed fp16 pairs (half the registers of an fp32 copy: head dim 128 then fits the 768-thread form), scores on v_dot2_f32_f16
     // (exact products, fp32 accumulation), the 1 / sqrt(hd) applied to the finished score
@@ -404,6 +421,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     }
     mx = wave_reduce<true>(mx);
     if (lane == 0) red[wave] = mx;
+    QA_STAMP(9);                                                      // scores: the K rows of the cache landed
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
@@ -415,6 +433,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     sum = wave_reduce<false>(sum);
     if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
+    QA_STAMP(10);                                                     // softmax
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
     float o[8];
 #pragma unroll
@@ -447,11 +466,13 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
 #pragma unroll
         for (int e = 0; e < 8; ++e) part[wave * HD + 8 * ch + e] = o[e];
     }
+    QA_STAMP(11);                                                     // p V
     __syncthreads();
     if (tid < HD) {
         const float r = (part[tid] + part[HD + tid]) + (part[2 * HD + tid] + part[3 * HD + tid]);
         DT<TI>::store(G.out + (int64_t)b * G.ldo + head * HD, tid, r * inv);
     }
+    QA_STAMP(12);
 }
 
 template <int HD, int P, int Q> int launch_attn_u(const AttnUArgs &A, int64_t bs, hipStream_t s)

@@ -25,6 +25,7 @@
 #include "common.h"
 #include "dq_common.h"
 #include "fpass.h"
+#include "probe.h"
 
 namespace {
 
@@ -55,6 +56,9 @@ __device__ unsigned long long fg_wprobe_buf[16 * 8];
         if (blockIdx.x == FG_PROBE_WG && blockIdx.y == 0 && (threadIdx.x & 63) == 0)                                  \
             fg_wprobe_buf[(threadIdx.x >> 6) * 8 + (i)] = __builtin_amdgcn_s_memtime();                               \
     } while (0)
+#elif defined(QA_PROBE)
+#define FG_STAMP(i) QA_STAMP(i)            // in situ (csrc/probe.h): every wave of one workgroup, the same slots
+#define FG_WSTAMP(i)
 #else
 #define FG_STAMP(i)
 #define FG_WSTAMP(i)

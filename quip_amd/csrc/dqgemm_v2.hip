@@ -128,6 +128,17 @@ static void k2_fill(K2Args &A, const K2Call &c)
     e.y_f32 = c.y_dtype == QUIPAMD_F32; e.y_f16 = c.y_dtype == QUIPAMD_F16; e.accumulate = c.accumulate; e.bs = c.bs; e.m = c.m;
 }
 
+// A/B runs only: QUIP_HG_RT=1|2|4 forces the row tiles per workgroup of the grouped h kernel.  Read ONCE per process (a getenv on
+// every grouped GEMM sat on the decode hot path, and a variable set mid-run silently changed the kernel selection).
+static int hg_rt_override()
+{
+    static const int v = [] {
+        const char *ev = getenv("QUIP_HG_RT");
+        return ev ? atoi(ev) : 0;
+    }();
+    return v;
+}
+
 int k2v2_launch_grouped(const K2Call *calls, int ngroups, void *stream)
 {
     const K2Call &c = calls[0];
@@ -149,10 +160,7 @@ int k2v2_launch_grouped(const K2Call *calls, int ngroups, void *stream)
         int rt = 1;
         if (tiles * ngroups > 256 && tiles % 2 == 0) rt = 2;
         if (tiles * ngroups > 512 && tiles % 4 == 0) rt = 4;
-        if (const char *ev = getenv("QUIP_HG_RT")) {
-            const int f = atoi(ev);
-            if ((f == 1 || f == 2 || f == 4) && tiles % f == 0) rt = f;
-        }
+        if (const int f = hg_rt_override(); (f == 1 || f == 2 || f == 4) && tiles % f == 0) rt = f;
         if (rt == 4) return launch_hg<2, ActF16, 4, 4, 4>(G, ngroups, s);
         if (rt == 2) return launch_hg<2, ActF16, 2, 4, 4>(G, ngroups, s);
         return launch_hg<2, ActF16, 1, 4, 4>(G, ngroups, s);
@@ -160,9 +168,8 @@ int k2v2_launch_grouped(const K2Call *calls, int ngroups, void *stream)
     if (c.bits == 2) {                                                               // d <= 2048: 8 waves x 1 chunk
         const int64_t tiles = c.m / 16;
         int rt = (tiles * ngroups > 256 && tiles % 2 == 0) ? 2 : 1;
-        if (const char *ev = getenv("QUIP_HG_RT")) {
-            const int f = atoi(ev);
-            if ((f == 1 || f == 2) && tiles % f == 0) rt = f;
+        if (const int f = hg_rt_override(); (f == 1 || f == 2) && tiles % f == 0) {
+            rt = f;
         }
         return rt == 2 ? launch_hg<2, ActF16, 2, 8, 1>(G, ngroups, s) : launch_hg<2, ActF16, 1, 8, 1>(G, ngroups, s);
     }

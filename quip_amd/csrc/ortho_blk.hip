@@ -21,6 +21,7 @@
 // Forward = mix a (B0) then mix b (B1); transpose = mix b (B1^T) then mix a (B0^T): the host hands over the factor arrays of the
 // orientation it wants (ops.OrthoOp.blk_factors).
 #include "common.h"
+#include "probe.h"
 
 namespace {
 
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
     const int g = blockIdx.x / tiles, tile = blockIdx.x - g * tiles;
     const int gr0 = blockIdx.z * BK_MAXR;                              // this workgroup's rows: gr0 .. gr0 + R - 1
     const int R = S.rows - gr0 < BK_MAXR ? S.rows - gr0 : BK_MAXR;
+    QA_STAMP(0);
 
     // ---- the factor fragments of this wave's k-steps: requested first (the only HBM traffic of the launch) -------------------------
     const int nk = (P + 31) / 32;                                     // k-steps of 32; the last one may be half (P % 32 == 16)
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         }
     }
 
+    QA_STAMP(1);                                                       // every up-front request issued (factors, index -> value, destinations)
     // ---- statistics of the rows (first stage with a norm): every workgroup reduces the whole row -- n <= 16384 values from L2 ---------
     if (!FUSED && S.norm) {
         // ONE pass over the row: sums of (x - c) and (x - c)^2 with c = the row's first element (a shift removes the cancellation of
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         }
     }
 
+    QA_STAMP(2);                                                       // (unfused, with a norm) the row statistics
     // ---- the group's input vector into LDS as fp16 hi + lo; rows R .. 15 are whatever LDS held (MFMA columns nobody stores) --------------------------
     auto finish = [&](float v, float u, uint16_t gm, uint16_t bt, float cs, int r) {
         if (has_gu) {
@@ -273,7 +277,9 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
                 *reinterpret_cast<uint2 *>(IDX + 4 * e4) = make_uint2((uint32_t)ix.x | ((uint32_t)ix.y << 16), (uint32_t)ix.z | ((uint32_t)ix.w << 16));
             }
         }
+        QA_STAMP(3);                                                     // FUSED: rows + permutation landed and staged
         __syncthreads();
+        QA_STAMP(4);
         if (S.norm) {                                                    // the statistics from LDS: one pass, shifted like the two-launch form
             for (int r = 0; r < R; ++r) {
                 const float c0 = S.norm == 1 ? XIN[r * n] : 0.f;
@@ -323,6 +329,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
             }
             __syncthreads();
         }
+        QA_STAMP(5);                                                     // FUSED: statistics + gains in place
         // the work items: factor chunk (k, ch) against the 8 entries of the input it meets, for every row
 #pragma unroll
         for (int c = 0; c < MAXI; ++c) {
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
                 }
             }
         }
+        QA_STAMP(6);                                                     // FUSED: first-stage partials (their factor chunks landed)
         __syncthreads();
         for (int dd = tid; dd < RP; dd += BK_T) {                        // chunk partials in a fixed order: deterministic
             const int r = dd / P, k = dd - r * P;
@@ -368,7 +376,9 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
                       btp[S.norm == 1 ? src : 0], csp[has_cs ? src : 0], r));
     }
     // (rows R .. 15 of XH / XL stay as they are: MFMA column j depends on B[:, j] only, and columns >= R are never stored)
+    QA_STAMP(7);                                                       // the group's input vector is in LDS (unfused: index -> value landed)
     __syncthreads();
+    QA_STAMP(8);
 
     // ---- this wave's k-steps: D[16 out rows][16 columns = batch rows] ------------------------------------------------------------------
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -389,7 +399,9 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
     }
     float *pw = part + wave * 256 + lane;
     pw[0] = acc[0]; pw[64] = acc[1]; pw[128] = acc[2]; pw[192] = acc[3];
+    QA_STAMP(9);                                                       // MFMAs (the stage's own factor fragments landed)
     __syncthreads();
+    QA_STAMP(10);
     if (wave == 0) {
         // D: column = lane & 15 (batch row), row = 4 (lane >> 4) + reg; destination, bias and residual were fetched at the top
         const int r = lane & 15;
@@ -403,6 +415,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
             }
         }
     }
+    QA_STAMP(11);
 }
 
 size_t blk_lds(const BlkStage &S, bool fused)

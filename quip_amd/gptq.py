@@ -61,6 +61,30 @@ class GPTQ(QuantMethod):
             del self.H
 
     def _kernel_round(self, W, H, groupsize, debug_equiv, blocksize=128):
+        """the kernels want in_features % 16 == 0.  A ragged width is padded on the RIGHT with zero columns whose Hessian block is a
+        multiple of the identity: H' = diag(H, c I) factors block by block (gptq.py:51-54: Hinv' = diag(Hinv, I / sqrt(c))), so no error of
+        a real column reaches a padded one or comes back from it -- the real columns see exactly the sweep of gptq.py:56-93; the padded
+        columns, their codes and their column scales are cut off again (round 6; the column walk below now serves debug_equiv, blocksize != 128
+        with groups, and a qfn-b Linear with more rows than co-resident workgroups)."""
+        d = W.shape[1] if W.dim() == 2 else 0
+        pad = (-d) % 16
+        if not pad or not USE_KERNEL or debug_equiv or W.dim() != 2 or not W.is_cuda or groupsize != -1:
+            return self._kernel_round_aligned(W, H, groupsize, debug_equiv, blocksize)
+        Wp = torch.nn.functional.pad(W, (0, pad))
+        Hp = torch.zeros((d + pad, d + pad), dtype=H.dtype, device=H.device)
+        Hp[:d, :d] = H
+        Hp[d:, d:] = torch.eye(pad, dtype=H.dtype, device=H.device) * H.diagonal().mean()
+        Q = self._kernel_round_aligned(Wp, Hp, groupsize, debug_equiv, blocksize)
+        if Q is None:
+            return None
+        if getattr(self, 'codes', None) is not None and self.codes.shape[-1] == d + pad:
+            self.codes = self.codes[:, :d].contiguous()
+        if getattr(self, 'column_scale', None) is not None and self.column_scale.shape[0] == d + pad:
+            self.column_scale = self.column_scale[:d].contiguous()
+            self.quantizer.scale = self.column_scale[-1].clone()         # the last REAL column's scale (quant.py:158-160)
+        return Q[:, :d].contiguous()
+
+    def _kernel_round_aligned(self, W, H, groupsize, debug_equiv, blocksize=128):
         """the K4 launch that covers this configuration, or None.  The feedback matrix comes from H through K8 and one
         triangular inverse (ops.gptq_feedback) -- the Cholesky / inverse / Cholesky of gptq.py:51-54 is never formed."""
         qz = self.quantizer

@@ -36,6 +36,10 @@ OPERATOR_PREFETCH = False  # True: sample the operators of the Linears whose Qua
                            # and its preproc (a draw made ahead of a reseed would be taken as if made behind it).  The reference's drivers
                            # never do; tests and notebooks do.  So the library default is off and the whole-model drivers of this repo
                            # (scripts/run_full_model.py, bench.py's quantise_model leg) switch it on.
+                           # Second restriction: `unbiased=True` draws torch.rand on the CPU global generator INSIDE fasterquant
+                           # (vector_balance.py:174-175), i.e. between two preprocs -- a prefetched draw would then sit on the wrong side of
+                           # it.  vector_balance._draw_eta therefore DRAINS the prefetcher (rewinds both generators to where a run without it would stand and
+                           # forgets the queue) before it draws; the Linears queued behind it sample synchronously.
 
 
 def _prime_factors(n):

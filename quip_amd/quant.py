@@ -192,6 +192,12 @@ class QuantLinear(nn.Module):
         super()._apply(fn, recurse)
         if self.qweight.device != dev0:       # everything the decode launches derived from the packed state holds device pointers
             self._drop_derived()
+            # the operators are ops.OrthoOp objects with a fixed .device (not buffers): rebuild them from their state on the new device, or the
+            # fused launches would get factor pointers on the old GPU beside codes on the new one
+            for side in ('U', 'V'):
+                op = getattr(self, side, None)
+                if op is not None and torch.device(op.device) != self.qweight.device:
+                    setattr(self, side, ops.OrthoOp(op.state(), self.qweight.device))
             if only_decode and qd is not None:
                 # after decode_only() the decode-order words are the ONLY copy of the weights: they travel with the module (the tables
                 # derived from them are still rebuilt on the new device)
@@ -887,6 +893,10 @@ def load_model(model, path, device):
     assert blob.get("format") == "quip_amd.model.v1", "not a quip_amd.quant.save_model file"
     layers = {name: QuantLinear.from_packed_state(st, device) for name, st in blob["packed"].items()}
     make_quant(model, layers)
+    mods = dict(model.named_modules())
+    lost = [n for n, ql in layers.items() if mods.get(n) is not ql]       # make_quant skips names the skeleton does not have
+    if lost:
+        raise RuntimeError(f"load_model: the skeleton has no module for {len(lost)} packed layer(s) of the file (first: {lost[:3]})")
     missing, unexpected = model.load_state_dict(blob["rest"], strict=False)
     own = tuple(n + "." for n in layers)
     stray = [k for k in missing if not k.startswith(own)]

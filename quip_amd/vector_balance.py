@@ -27,6 +27,16 @@ def hessian_loss(dw, H):
     return ((dw @ H) * dw).sum()
 
 
+def _draw_eta(shape, device):
+    """the uniform draw of `unbiased` rounding, vector_balance.py:174-175: torch.rand on the CPU global generator, then moved.  With the
+    operator prefetch thread on (method.OPERATOR_PREFETCH) that generator may already have been advanced by draws for LATER Linears: drain
+    the prefetcher first, which rewinds numpy and torch to where the reference's streams stand at this point."""
+    from . import method
+    if method.OPERATOR_PREFETCH:
+        method.operator_prefetcher().drain()
+    return torch.rand(shape).to(device)
+
+
 def _ldl_transposed(H):
     """unit-lower LDL factor of H as LT = L^T - strict (vector_balance.py:171-173): blocked fp32 Cholesky of the upper
     triangle + row scaling in quip_amd/csrc/cholesky.hip (K8); raises LinAlgError like torch.linalg.cholesky."""
@@ -61,7 +71,7 @@ def _round_ldl_codes(w, H, nbits, n_greedy_passes, unbiased, raw=None):
     assert (not unbiased) or (n_greedy_passes == 0), "greedy passes are incompatible with unbiased LDL rounding"
     if raw is not None:
         assert w is None and n_greedy_passes == 0 and shard.active() is not None
-        eta = torch.rand(raw[0].shape).to(raw[0].device) if unbiased else None     # same CPU draw as vector_balance.py:174-175
+        eta = _draw_eta(raw[0].shape, raw[0].device) if unbiased else None
         sharded = shard.active()
         key = shard.h_key(H)
         LT = None if sharded.queued(key) else _ldl_transposed(H)
@@ -71,7 +81,7 @@ def _round_ldl_codes(w, H, nbits, n_greedy_passes, unbiased, raw=None):
         assert shard.active() is None, "greedy passes are not row-sharded (they need s @ H on the owner)"
         codes = ops.ldlq_round(w, _ldl_transposed(H), nbits, eta=None)
         return _greedy_passes(w, codes, H.to(torch.float32), nbits, n_greedy_passes)
-    eta = torch.rand(w.shape).to(w.device) if unbiased else None     # same CPU draw as vector_balance.py:174-175
+    eta = _draw_eta(w.shape, w.device) if unbiased else None
     sharded = shard.active()
     if sharded is not None:                                           # rows split over the ranks of the node (shard.py)
         key = shard.h_key(H)                                          # a queued LT is used only for the H it was factored from
@@ -88,10 +98,15 @@ def round_ldl(w, H, nbits, n_greedy_passes=9, unbiased=False):
 
 
 def round_ldl_block(w, H, nbits, blocksize=128, n_greedy_passes=9, unbiased=False):
-    """`--lazy_batch` variant (vector_balance.py:218-291).  The HIP kernel always works in 128-column lazy
-    blocks, so this and round_ldl share one implementation; they differ in the reference only by fp32
-    summation order."""
-    assert blocksize == 128, "the kernel's lazy block is 128 columns (vector_balance.py:222 default)"
+    """`--lazy_batch` variant (vector_balance.py:218-291).  In the reference `blocksize` only regroups the SAME sum: column i is rounded at
+    w_i + (W1 - WHat1) @ L1[i1:i2, i] + W2Hdiff @ L1[i2:, i] (:254) -- the in-block part plus the far field of every finished block -- which
+    is round_ldl's single mat-vec (:180) split at the block edge; the codes of two block sizes differ only where the fp32 summation order
+    moves a value across a rounding boundary (0 of 2.1 M codes at 2 bits between the block and the plain form).  K4's
+    lazy block is a compile-time 128 columns (csrc/ldlq.hip BS: LDS image of the diagonal block, MFMA tiling of the far field), with its own
+    summation order inside and across blocks, so every `blocksize` runs that kernel: the caller's value is validated like the reference's
+    loop would use it (a positive integer, :243) and does not change the launch."""
+    if not (isinstance(blocksize, int) and blocksize >= 1):
+        raise ValueError(f"round_ldl_block: blocksize must be a positive integer (vector_balance.py:243 steps range(d, 0, -blocksize)); got {blocksize!r}")
     return round_ldl(w, H, nbits, n_greedy_passes=n_greedy_passes, unbiased=unbiased)
 
 
@@ -99,7 +114,7 @@ def round_ldl_gptqequiv(w, H, nbits, unbiased=False):
     """LDLQ in OPTQ's column order (vector_balance.py:381-422, used by optq_ldlq_equiv.py): Cholesky of the flipped H,
     factor flipped back, columns rounded left to right -- i.e. round_ldl on the column-reversed problem."""
     w = w.to(torch.float32)
-    eta = torch.rand(w.shape).to(w.device).flip(1).contiguous() if unbiased else None      # eta[:, i] belongs to column i
+    eta = _draw_eta(w.shape, w.device).flip(1).contiguous() if unbiased else None      # eta[:, i] belongs to column i
     LT = _ldl_transposed(torch.flip(H.to(torch.float32), [0, 1]).contiguous())
     codes = ops.ldlq_round(w.flip(1).contiguous(), LT, nbits, eta=eta).flip(1).contiguous().to(torch.float32)
     check_nbits(codes, nbits)

@@ -57,15 +57,25 @@ quipamd_fop make_fop(int p, int q)
     return o;
 }
 
+// regime (round 6): 0 = as rounds 3-5 (ncopies copies of the WEIGHTS only, every other operand shared: the prologue's operands are L2-warm and
+// 16-48 copies of 1-6 MB sit in the 256 MiB Infinity Cache); 1 = HBM-cold: enough copies of EVERYTHING a launch reads (weights, factor
+// fragments, index vectors, gains, bias, residual) to exceed 320 MiB, as a decode step finds them (508 MB stream through the caches per token);
+// 2 = Infinity-Cache-warm: the same with ~48 MiB of copies (what a prefetch of layer L + 1 into the MALL would give); 3 = one copy (L2-warm)
+int g_regime = 0;
 void run(const char *name, int p, int q, int64_t m, int groups, bool has_u, int norm, int bs, int ncopies, bool res = true, bool pair = false)
 {
     const int n = p * q;
+    const size_t wbytes = (size_t)groups * m * n / 4;
+    if (g_regime == 1) ncopies = (int)((320u << 20) / wbytes) + 1;
+    if (g_regime == 2) ncopies = (int)((48u << 20) / wbytes) + 1;
+    if (g_regime == 3) ncopies = 1;
+    const bool own_ops = g_regime == 1 || g_regime == 2;
     std::vector<quipamd_fused_gemm_args> args(ncopies);
     for (int c = 0; c < ncopies; ++c) {                      // distinct weights per copy: every launch streams cold codes
         quipamd_fused_gemm_args &a = args[c];
         memset(&a, 0, sizeof(a));
         a.act_dtype = QUIPAMD_F16; a.bits = 2; a.has_u = has_u; a.norm = norm; a.ln_eps = 1e-5f; a.ngroups = groups; a.bs = bs; a.m = m; a.y_dtype = QUIPAMD_F16;
-        if (c == 0) {
+        if (c == 0 || own_ops) {
             a.U = make_fop(p, q);
             a.u_y = dev_alloc<uint16_t>((size_t)bs * n); a.u_bias = dev_alloc<uint16_t>(n); a.u_residual = res ? dev_alloc<uint16_t>((size_t)bs * n) : nullptr;
             a.ld_residual = n; a.t_out = pair ? nullptr : dev_alloc<uint16_t>((size_t)bs * n); a.ld_t = n; a.x = dev_alloc<uint16_t>((size_t)bs * n); a.ldx = n;
@@ -103,8 +113,9 @@ void run(const char *name, int p, int q, int64_t m, int groups, bool has_u, int 
     CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(exec, s)); CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("%-28s p=%d q=%d m=%lld groups=%d u=%d norm=%d bs=%d : %.3f us per launch (graph of %d, cold weights x%d)\n", name, p, q,
-           (long long)m, groups, (int)has_u, norm, bs, ms * 1e3 / K, K, ncopies);
+    static const char *rn[4] = {"weights x copies, operands shared (rounds 3-5)", "HBM-cold, every operand its own copy", "Infinity-Cache-warm", "L2-warm (one copy)"};
+    printf("%-28s p=%d q=%d m=%lld groups=%d u=%d norm=%d bs=%d : %.3f us per launch (graph of %d, %d copies: %s)\n", name, p, q,
+           (long long)m, groups, (int)has_u, norm, bs, ms * 1e3 / K, K, ncopies, rn[g_regime]);
 #ifdef FG_PROBE
     CK(hipStreamSynchronize(s));
     quipamd_decode_fused_gemm(&args[1 % ncopies], s);
@@ -133,8 +144,9 @@ void run(const char *name, int p, int q, int64_t m, int groups, bool has_u, int 
 #endif
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1) g_regime = atoi(argv[1]);
     run("L3 out_proj (V only)", 64, 32, 2048, 1, false, 0, 1, 48);
     run("L1 qkv block 0 (LN, V)", 64, 32, 2048, 3, false, 1, 1, 16);
     run("L1 qkv (U, LN, V)", 64, 32, 2048, 3, true, 1, 1, 16);

@@ -224,6 +224,21 @@ def gen_ldlq():
          "(SURVEY.md 8(d)), d=192 (one full + one ragged 128-block), m=40", **arrs)
 
 
+def gen_ldl_blocksizes():
+    """round 6: the reference's round_ldl_block at block sizes other than its default (vector_balance.py:218-257, `blocksize`), same
+    fixture as gen_ldlq: d = 192, m = 40, correlated H"""
+    arrs = {}
+    d, m = 192, 40
+    H = correlated_H(d, 3)
+    for bits in (2, 4):
+        g = torch.Generator().manual_seed(10 + bits)
+        maxq = 2 ** bits - 1
+        W = (torch.rand(m, d, generator=g) * (maxq + 0.6) - 0.3).clamp(0, maxq).float()
+        for bsz in (32, 64, 1000):
+            arrs[f"ldlblock{bits}_bs{bsz}"] = ref_vb.round_ldl_block(W, H, bits, blocksize=bsz, n_greedy_passes=0)
+    save("ldl_blocksizes", "vector_balance.py:218-257 round_ldl_block(blocksize = 32, 64, 1000), n_greedy_passes=0, on ldlq.npz's H / W2 / W4", **arrs)
+
+
 # ---------------------------------------------------------------- F/G. QuantMethod end to end
 def gen_method():
     arrs = {}
@@ -618,6 +633,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rounders":
         gen_rounders()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ldl_blocksizes":
+        gen_ldl_blocksizes()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gptq_groups":
         gen_gptq_groups()
         sys.exit(0)
@@ -634,6 +652,7 @@ if __name__ == "__main__":
     gen_pack()
     gen_butterfly()
     gen_ldlq()
+    gen_ldl_blocksizes()
     gen_method()
     gen_counter()
     gen_rounders()

@@ -73,6 +73,39 @@ def test_gptq_class_kernel_path_equals_reference_order_loop():
     assert abs(outs[True][1] - outs[False][1]) <= 2e-2 * outs[False][1]
 
 
+@pytest.mark.parametrize("d,qfn", [(200, 'a'), (72, 'a'), (200, 'b'), (136, 'c')])
+def test_gptq_class_ragged_width_runs_on_the_kernels(d, qfn):
+    """in_features % 16 != 0 (round 6): padded on the right with decoupled identity columns, rounded by the kernels, cut back -- against the
+    same class forced onto the reference-order column loop (gptq.py:56-93); the padded columns leave no trace in the state kept for packing"""
+    from quip_amd import gptq as G, quant as Q
+    m, bits = 48, 4
+    W, H, _, _, _ = _fixture(m, d, bits, seed=d)
+    outs = {}
+    for use in (True, False):
+        G.USE_KERNEL = use
+        try:
+            lin = torch.nn.Linear(d, m, bias=False).to(DEV)
+            lin.weight.data = W.to(DEV)
+            meth = G.GPTQ(lin)
+            meth.quantizer = Q.Quantizer()
+            meth.quantizer.configure(bits, perchannel=True, sym=False, qfn=qfn, mse=False)
+            meth.H = H.clone().to(DEV)
+            meth.preproc(preproc_gptqH=True, percdamp=.01)
+            meth.fasterquant()
+            outs[use] = (lin.weight.data.float().clone(), meth.error, meth)
+        finally:
+            G.USE_KERNEL = True
+    k, w = outs[True], outs[False]
+    assert k[0].shape == (m, d) and bool(torch.isfinite(k[0]).all())
+    step = float(w[0].abs().max()) / (2 ** bits - 1)
+    assert ((k[0] - w[0]).abs() > 0.25 * step).float().mean().item() <= 1e-2
+    assert abs(k[1] - w[1]) <= 2e-2 * w[1]
+    if qfn == 'a':
+        assert k[2].codes.shape == (m, d)
+    if qfn == 'b':
+        assert k[2].column_scale.shape[0] == d
+
+
 def test_full_size_is_one_launch_fast():
     """OPT-1.3B fc2 shape (2048 x 8192): the kernel path finishes in milliseconds and keeps the grid invariant."""
     import time

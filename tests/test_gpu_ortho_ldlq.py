@@ -112,6 +112,23 @@ def test_ldlq_golden_bit_exact_vs_kernel_order_oracle_and_statistical_vs_referen
     assert np.mean(cu.cpu().numpy().astype(np.float32) != g[f"ldl{bits}_unbiased"]) <= 1e-3
 
 
+@pytest.mark.parametrize("bits", [2, 4])
+@pytest.mark.parametrize("bsz", [32, 64, 1000])
+def test_round_ldl_block_at_caller_chosen_block_sizes(O, bits, bsz):
+    """vector_balance.py:218-257 `blocksize`: the reference's own outputs at 32 / 64 / 1000 columns per lazy block (tests/golden/
+    ldl_blocksizes.npz) against quip_amd.round_ldl_block with the same argument -- K4 keeps its 128-column block, the codes agree up to the
+    near-ties the summation order moves (the bar of SURVEY.md 8(c) for K4 vs round_ldl: <= 1e-3 of the codes, proxy within 1e-3)"""
+    from quip_amd import vector_balance as vb
+    g, gb = load_golden("ldlq"), load_golden("ldl_blocksizes")
+    W, H = g[f"W{bits}"], g["H"]
+    ref = gb[f"ldlblock{bits}_bs{bsz}"]
+    got = vb.round_ldl_block(torch.from_numpy(W).to(DEV), torch.from_numpy(H).to(DEV), bits, blocksize=bsz, n_greedy_passes=0).cpu().numpy()
+    assert np.mean(got != ref) <= 1e-3
+    p_got, p_ref = O.proxy_loss(got - W, H), O.proxy_loss(ref - W, H)
+    assert abs(p_got - p_ref) <= 1e-3 * p_ref
+    assert np.array_equal(got, vb.round_ldl(torch.from_numpy(W).to(DEV), torch.from_numpy(H).to(DEV), bits, n_greedy_passes=0).cpu().numpy())
+
+
 @pytest.mark.parametrize("m,d,bits", [(100, 512, 2), (64, 1024, 4), (37, 336, 2), (512, 2048, 2)])
 def test_ldlq_bit_exact_at_larger_sizes(ops, O, m, d, bits):
     H = _corr_H(d, seed=d)

@@ -290,3 +290,24 @@ def test_gptq_round_matches_reference():
     dw = (Q - g["gptq_W0"]).astype(np.float64)
     err = float(((dw @ g["gptq_Hdamped"].astype(np.float64)) * dw).sum())
     assert abs(err - float(g["gptq_w4_error"])) <= 1e-3 * float(g["gptq_w4_error"])
+
+
+def test_oracle_round_ldl_vs_reference_block_sizes():
+    """the reference's round_ldl_block at blocksize 32 / 64 / 1000 (tests/golden/ldl_blocksizes.npz, vector_balance.py:218-257) gives the codes
+    of its plain round_ldl up to fp32 summation order: the oracle's restatement of :155-199 is within 1e-3 of every one of them"""
+    g, gb = load_golden("ldlq"), load_golden("ldl_blocksizes")
+    for bits in (2, 4):
+        W, H = g[f"W{bits}"], g["H"]
+        mine = O.round_ldl(W, H, bits)
+        for bsz in (32, 64, 1000):
+            ref = gb[f"ldlblock{bits}_bs{bsz}"]
+            assert ref.shape == mine.shape and np.mean(mine != ref) <= 1e-3, (bits, bsz)
+
+
+def test_round_ldl_block_rejects_a_block_size_the_reference_loop_cannot_step():
+    import pytest
+    import torch
+    from quip_amd import vector_balance as vb
+    for bad in (0, -128, 64.0, None):
+        with pytest.raises(ValueError):
+            vb.round_ldl_block(torch.zeros(4, 16), torch.eye(16), 2, blocksize=bad, n_greedy_passes=0)
