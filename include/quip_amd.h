@@ -58,6 +58,12 @@ const char *quipamd_last_error(void); /* host string, valid until the next faili
  * of their phases -- slot i of wave w of one workgroup at buf[16 w + i] -- into `buf` (device, 256 x uint64; NULL switches them off).
  * The shipped library returns QUIPAMD_ERR_UNSUPPORTED. */
 int quipamd_probe_set(void *buf);
+/* Operand prefetch (no reference counterpart; csrc/prefetch.h): attach up to 40 device ranges to the NEXT quipamd_decode_fused_gemm /
+ * quipamd_decode_attention_fused launch of the calling thread.  That launch carries 8 extra workgroups (one per XCD) that read one dword per
+ * 128-byte line of every range and leave -- the step-independent operands of a LATER launch of the decode step (factor fragments, index
+ * vectors, gains, column scales, biases: 50-150 KB, cold in L2 once per token) are then L2-resident on every XCD when it starts.  Purely a
+ * hint: results never depend on it.  ptrs / bytes: HOST arrays; n = 0 clears a pending list. */
+int quipamd_decode_prefetch_next(const void *const *ptrs, const int64_t *bytes, int n);
 
 /* ---- K1: integer pack / unpack (bit-exact) ------------------------------------------------
  * Replaces the Python/numpy packing loops zeroShot/models/quant.py:198-199 and
@@ -158,6 +164,10 @@ int quipamd_dequant_gemm_grouped(int ngroups, const void *const *x, int x_dtype,
  * workgroup (1, 2 or 4).  Applies to the round-1 kernels and to the CALLING THREAD only; never needed for correctness.  An
  * unsupported combination makes quipamd_dequant_gemm fail with QUIPAMD_ERR_UNSUPPORTED. */
 int quipamd_tune_dequant_gemm(int rt, int bt, int nw, int split);
+/* tests / A-B runs: which kernel serves quipamd_dequant_gemm_grouped's fp16 problems of d = 4096 (q / k / v, gate / up of a 5..16-row decode
+ * step).  0: the heuristic; 1 | 2 | 4: the grouped h kernel with that many row tiles per workgroup; 74 | 72 | 81: the grouped weight-stream
+ * kernel (dq_sg_kernel) with 4 | 7 | 8 row tiles per workgroup.  Process-wide. */
+void quipamd_dequant_gemm_grouped_config(int form);
 
 /* ---- K3: structured orthogonal (two-factor butterfly / Kronecker) apply ------------------------
  * Replaces mul_ortho_butterfly (method.py:46-67) and the dense U @ W @ V^T, V @ H @ V^T products of

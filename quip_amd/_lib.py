@@ -87,6 +87,8 @@ SIGNATURES = {
     "quipamd_hessian_fast_workspace": [c_i64, c_i64],
     "quipamd_hessian_accum_fast": [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
     "quipamd_probe_set": [c_vp],
+    "quipamd_dequant_gemm_grouped_config": [c_int],
+    "quipamd_decode_prefetch_next": [c_vp, c_vp, c_int],
 }
 
 _lib = None
@@ -111,7 +113,8 @@ def load():
         except AttributeError as e:
             raise QuipAmdError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else None if name in ("quipamd_vecquant_invalidate", "quipamd_cholesky_config", "quipamd_ldlq_config", "quipamd_gptq_qfnb_debug", "quipamd_ortho_blocked_config") else
+        fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else None if name in ("quipamd_vecquant_invalidate", "quipamd_cholesky_config", "quipamd_ldlq_config", "quipamd_gptq_qfnb_debug", "quipamd_ortho_blocked_config",
+                                                                                                      "quipamd_dequant_gemm_grouped_config") else
                       c_i64 if name in ("quipamd_hessian_fast_workspace", "quipamd_vecquant_workspace_bytes", "quipamd_gptq_qfnb_workspace_bytes", "quipamd_gptq_qfnb_info_offset", "quipamd_preproc_workspace_bytes") else c_int)
     _lib = lib
     return lib

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "fpass.h"
 #include "probe.h"
+#include "prefetch.h"
 
 namespace {
 
@@ -56,6 +57,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
     S *kcb = kc + ((int64_t)b * heads + head) * maxlen * HD, *vcb = vc + ((int64_t)b * heads + head) * maxlen * HD;
 
     if (pos < 0 || pos >= maxlen) return;                           // uniform; a full cache is the caller's error
+    // Round 6: the first 256 K rows of the cache are requested NOW, with the kernel's first loads, not behind the append barrier and the q
+    // loads (the scores phase used to open with a cold round trip).  This token's own row is not in the cache yet: its owner reads it from k.
+    uint4 kpre[HD / 8];
+    {
+        const int64_t tpre = tid < maxlen ? tid : 0;
+#pragma unroll
+        for (int e8 = 0; e8 < HD; e8 += 8) kpre[e8 / 8] = *reinterpret_cast<const uint4 *>(kcb + tpre * HD + e8);
+    }
     // append this token; the barrier (workgroup-scope fence) makes it visible to the reads below
     if (tid < HD) kcb[pos * HD + tid] = kh[tid];
     else if (tid < 2 * HD) vcb[pos * HD + tid - HD] = vh[tid - HD];
@@ -82,16 +91,26 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
 
     // ---- phase 1: scores --------------------------------------------------------------------------------------------
     float mx = -INFINITY;
-    for (int64_t t = tid; t < T; t += 256) {
-        const S *row = kcb + t * HD;
+    auto dot_row = [&](auto get) {                                   // q . (one K row), the row handed over as 16-byte pieces
         float acc = 0.f;
 #pragma unroll
         for (int e8 = 0; e8 < HD; e8 += 8) {
             S raw[8];
-            *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(row + e8);
+            *reinterpret_cast<uint4 *>(raw) = get(e8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc = fmaf(qr[e8 + e], DT<TI>::load(raw, e), acc);
         }
+        return acc;
+    };
+    if (tid < T) {                                                   // first pass: the prefetched row (this token's own row straight from k)
+        const float acc = tid == pos ? dot_row([&](int e8) { return *reinterpret_cast<const uint4 *>(kh + e8); })
+                                     : dot_row([&](int e8) { return kpre[e8 / 8]; });
+        scores[tid] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    for (int64_t t = (int64_t)tid + 256; t < T; t += 256) {
+        const S *row = t == pos ? kh : kcb + t * HD;                 // (same values as the appended copy)
+        const float acc = dot_row([&](int e8) { return *reinterpret_cast<const uint4 *>(row + e8); });
         scores[t] = acc;
         mx = fmaxf(mx, acc);
     }
@@ -241,6 +260,7 @@ struct AttnUArgs {
     int64_t table_rows, maxlen, ldo;
     int heads;
     float scale;
+    QaPfList pf;                          // operands of a later launch, touched by QA_PF_WGS extra workgroups (csrc/prefetch.h); n = 0: none
 };
 
 // 768 threads: waves 0-3 / 4-7 / 8-11 run the operator pass of q / k / v side by side (round 3a ran the three passes one after the other on
@@ -265,6 +285,10 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
                  "s"(G.U[1].store_idx), "s"(G.U[2].F0), "s"(G.U[2].F1), "s"(G.U[2].store_idx),
                  "s"(G.y[0]), "s"(G.y[1]), "s"(G.y[2]), "s"(G.bias[0]), "s"(G.bias[1]), "s"(G.bias[2]), "s"(G.kc), "s"(G.vc), "s"(G.out),
                  "s"(G.pos), "s"(G.cos_t), "s"(G.sin_t), "s"(G.table_rows), "s"(G.maxlen), "s"(G.ldo), "s"(G.heads), "s"(G.scale));
+    if (G.pf.n > 0 && (int)blockIdx.x >= G.pf.first) {                // a prefetch workgroup (uniform): touch the lines, leave
+        qa_pf_run(G.pf, 256u * NGRP);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / G.heads, head = blockIdx.x % G.heads;
@@ -312,6 +336,23 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
                 rc[it] = G.cos_t[pos * HD + (ge % (HD / 2))];
                 rs_[it] = G.sin_t[pos * HD + (ge % (HD / 2))];
             }
+        }
+    }
+    // Round 6 (profiles/r06_decode_stamps.txt): the scores phase opened with a COLD round trip -- the K rows of the cache were requested only
+    // after the whole prologue, 3700 clocks on the last wave for 97 positions.  The first 256 rows (one per thread of the scoring group) do not
+    // depend on anything computed here: request them NOW, behind the prologue's own operands (vector memory returns in order: they land last,
+    // under the operator passes).  The row of THIS token (t == pos) is not in the cache yet: the thread that owns it takes it from the LDS
+    // slice instead -- its prefetched registers hold whatever the cache held before.  Head dim 64 only: 16 more 16-byte registers per lane do
+    // not fit the 768-thread form at head dim 128.
+    constexpr bool KPF = HD <= 64;
+    uint4 kpre[KPF ? HD / 8 : 1];
+    if constexpr (KPF) {
+        const int64_t tpre = tid < G.maxlen ? tid : 0;
+#pragma unroll
+        for (int e8 = 0; e8 < HD; e8 += 8) kpre[e8 / 8] = make_uint4(0u, 0u, 0u, 0u);
+        if (wave < 4) {                                               // the scoring group only (waves 4..11 leave after their operator pass)
+#pragma unroll
+            for (int e8 = 0; e8 < HD; e8 += 8) kpre[e8 / 8] = *reinterpret_cast<const uint4 *>(kcb + tpre * HD + e8);
         }
     }
     QA_STAMP(2);                                                      // every request of the prologue issued
@@ -406,10 +447,15 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     float mx = -INFINITY;
     for (int64_t t = tid; t < T; t += 256) {
         const S *row = kcb + t * HD;
+        const bool pre = KPF && t == tid;                             // first pass: the row came in with the prologue's requests
+        const bool own = t == pos;                                    // this token's row: from the LDS slice (k = qkv[HD .. 2 HD))
         float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
         for (int e8 = 0; e8 < HD; e8 += 8) {
-            const uint4 k4 = *reinterpret_cast<const uint4 *>(row + e8);
+            uint4 k4;
+            if (KPF && own) k4 = *reinterpret_cast<const uint4 *>(qkv + HD + e8);
+            else if (pre) k4 = kpre[KPF ? e8 / 8 : 0];
+            else k4 = *reinterpret_cast<const uint4 *>(row + e8);
             acc0 = ActF16::dot2(qp[e8 / 2 + 0], k4.x, acc0);
             acc1 = ActF16::dot2(qp[e8 / 2 + 1], k4.y, acc1);
             acc0 = ActF16::dot2(qp[e8 / 2 + 2], k4.z, acc0);
@@ -491,7 +537,10 @@ template <int HD, int P, int Q> int launch_attn_u(const AttnUArgs &A, int64_t bs
             return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_attention_fused: cannot reserve %zu B of LDS", lds);
         if (known) reserved[dev] = lds;
     }
-    kern<<<(unsigned)(bs * A.heads), 256 * NGRP, lds, s>>>(A);
+    AttnUArgs Ap = A;
+    Ap.pf = qa_pf_take();
+    Ap.pf.first = (int)(bs * A.heads);
+    kern<<<(unsigned)(bs * A.heads) + (Ap.pf.n ? QA_PF_WGS : 0), 256 * NGRP, lds, s>>>(Ap);
     QA_LAUNCH_CHECK("decode_attention_fused");
     return QUIPAMD_OK;
 }

@@ -26,6 +26,7 @@
 #include "dq_common.h"
 #include "fpass.h"
 #include "probe.h"
+#include "prefetch.h"
 
 namespace {
 
@@ -86,6 +87,7 @@ struct FusedArgs {
     int64_t m;
     FGroup g[FG_MAXG];
     const uint4 *pair_sig, *pair_bias, *pair_cs;   // fused_pair_kernel: per-lane tables in D-fragment order (include/quip_amd.h)
+    QaPfList pf;                          // operands of a later launch, touched by QA_PF_WGS extra workgroups (csrc/prefetch.h); n = 0: none
 };
 
 // keep a kernarg pointer's scalar load where it is written: hipcc fetches kernarg fields lazily, one s_load + s_waitcnt per first
@@ -146,6 +148,10 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     float *red = reinterpret_cast<float *>(pass + (D::BYTES > PARK_B ? D::BYTES : PARK_B));            // [2][16] norm, [bs][16] sum x~, [bs][16] sum OFF x~
     const typename DQ::Consts qc = DQ::make_consts();
 
+    if (G.pf.n > 0 && (int)blockIdx.x >= G.pf.first) {                          // a prefetch workgroup (uniform): touch the lines, leave
+        if (blockIdx.y == 0) qa_pf_run(G.pf, 1024u);
+        return;
+    }
     const int gi = blockIdx.y;
     const FGroup &Gg = G.g[gi];
     const Fop &V = Gg.V;
@@ -494,6 +500,10 @@ __global__ __launch_bounds__(1024) void fused_pair_kernel(FusedArgs G, float two
     uint4 *FRV = FRU + NFR * 64;
     float *red = reinterpret_cast<float *>(FRV + NFR * 64);                                 // [MAXBS][16] sum x~
 
+    if (G.pf.n > 0 && (int)blockIdx.x >= G.pf.first) {
+        qa_pf_run(G.pf, 1024u);
+        return;
+    }
     const FGroup &Gg = G.g[0];
     const Fop &V = Gg.V;
     asm volatile("" ::"s"(Gg.qw), "s"(V.F0), "s"(V.F1), "s"(Gg.scale), "s"(Gg.y), "s"(G.U.F0), "s"(G.U.F1), "s"(G.u_y), "s"(G.floor), "s"(G.bs),
@@ -656,7 +666,11 @@ template <int P, int Q, int BITS> int launch_pair(const FusedArgs &A, float maxq
             return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_fused_gemm (pair): cannot raise dynamic LDS to %zu", lds);
         if (d >= 0) attr.done[d] = true;
     }
-    kern<<<dim3((unsigned)(A.m / 16), 1), 1024, lds, s>>>(A, 2.0f / maxq, DeqT<BITS, ActF16>::OFF + 0.5f * maxq);
+    FusedArgs Ap = A;
+    const unsigned gxp = (unsigned)(A.m / 16);
+    Ap.pf = qa_pf_take();
+    Ap.pf.first = (int)gxp;
+    kern<<<dim3(gxp + (Ap.pf.n ? QA_PF_WGS : 0), 1), 1024, lds, s>>>(Ap, 2.0f / maxq, DeqT<BITS, ActF16>::OFF + 0.5f * maxq);
     QA_LAUNCH_CHECK("quipamd_decode_fused_gemm (pair)");
     return QUIPAMD_OK;
 }
@@ -684,7 +698,10 @@ int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
     }
     const float maxq = g_fused_maxq;
     const unsigned gx = OPS ? (unsigned)A.bs : (unsigned)((A.m / 16 + RT * NRT - 1) / (RT * NRT));
-    kern<<<dim3(gx, (unsigned)ngroups), 1024, lds, s>>>(A, 2.0f / maxq, 0.5f * maxq);
+    FusedArgs Ap = A;
+    Ap.pf = qa_pf_take();
+    Ap.pf.first = (int)gx;
+    kern<<<dim3(gx + (Ap.pf.n ? QA_PF_WGS : 0), (unsigned)ngroups), 1024, lds, s>>>(Ap, 2.0f / maxq, 0.5f * maxq);
     QA_LAUNCH_CHECK("quipamd_decode_fused_gemm");
     return QUIPAMD_OK;
 }
@@ -750,6 +767,7 @@ extern "C" int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *a, void 
     A.x = (const uint16_t *)a->x; A.ldx = a->ldx;
     A.gamma = (const uint16_t *)a->ln_gamma; A.beta = (const uint16_t *)a->ln_beta; A.eps = a->ln_eps;
     A.pair_sig = A.pair_bias = A.pair_cs = nullptr;
+    A.pf.n = 0;
     A.bs = (int)a->bs; A.m = a->m; A.y_f16 = a->y_dtype == QUIPAMD_F16;
     QA_REQUIRE(a->y_dtype == QUIPAMD_F16 || a->y_dtype == QUIPAMD_F32, QUIPAMD_ERR_ARG, "decode_fused_gemm: y_dtype f32 or f16");
     QA_REQUIRE(a->norm >= 0 && a->norm <= 2 && (a->norm == 0 || a->ln_gamma) && (a->norm != 1 || a->ln_beta), QUIPAMD_ERR_ARG,

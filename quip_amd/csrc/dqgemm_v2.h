@@ -194,164 +194,17 @@ int launch_h(const K2Args &A, hipStream_t s)
 template <int BITS, class ACT, int NW, int KSP, int SPW, int D>
 __global__ __launch_bounds__(64 * (NW * KSP + 2)) void dq_s_kernel(K2Args A, uint32_t ntile)
 {
-    typedef DeqSel<BITS, ACT> Q;                                      // 2 bits: multi-exponent dequantisation (dq_common.h)
-    constexpr int KC = Q::KC, NT = Q::NT;
-    constexpr int KS = 256, TPS = KS / KC;                            // k per stage, weight tiles per stage and row tile
-    constexpr int XB = 16 * KS * 2, NI = 8;                            // slab bytes, DMA instructions per slab
-    constexpr int NWT = NW * TPS, SB1 = XB + NWT * 1024;               // weight tiles per stage, bytes per stage
-    constexpr int SPS = KSP * SPW;                                     // stages per ring step: SPW for each of the KSP k-parts
-    constexpr int SB = SPS * SB1, NCW = NW * KSP;                      // ring slot; compute waves
-    static_assert(SPS * NI * (D - 2) < 64 && SPS * NWT * (D - 2) < 64 && D >= 2, "vmcnt range");
-    static_assert(NCW * 1024 + NCW * 128 <= D * SB && NW <= 8, "exchange area");
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [D] slots of KSP stages {x slab, NWT weight tiles}
-    const EpiArgs &e = A.e;
+#include "dq_s_body.inc"
+}
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t ns = (uint32_t)(A.d / KS), nss = (ns + SPS - 1) / SPS;   // stages, ring steps
-    const uint32_t rowbytes = (uint32_t)A.d * 2u;
-    const uint32_t tile0 = blockIdx.x * NW;                            // first row tile of the workgroup
-
-    if (wave == NCW) {
-        // ---- weight loader: tile (row tile r, chunk c) is 1 KiB at ((r * nkc + c) * 1024) -------------------------------------
-        const uint32_t nkc = ns * TPS;
-        __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.qw, 0, (int)((uint64_t)ntile * nkc * 1024u), 0x00020000);
-        const uint32_t vl = (uint32_t)lane * 16u;
-        auto issue_w = [&](uint32_t ss) {
-            const uint32_t slot = ss % D;
-#pragma unroll
-            for (int h = 0; h < SPS; ++h) {
-                const uint32_t st = ss * SPS + h, sc = st < ns ? st : ns - 1;
-#pragma unroll
-                for (int i = 0; i < NWT; ++i) {
-                    const uint32_t r = tile0 + i / TPS, rc = r < ntile ? r : ntile - 1;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void2_t *)(smem + slot * SB + h * SB1 + XB + i * 1024), 16, vl,
-                                                             (rc * nkc + sc * TPS + i % TPS) * 1024u, 0, 2 /* nt */);
-                }
-            }
-        };
-        K2_ACC_DECL;
-#pragma unroll
-        for (int c = 0; c < D - 1; ++c) issue_w(c);
-#pragma unroll 1
-        for (uint32_t ss = 0; ss < nss; ++ss) {
-            K2_ACC(0, wait_vm<SPS * NWT * (D - 2)>());                 // ring step ss has landed
-            K2_ACC(1, __builtin_amdgcn_s_barrier());
-            K2_ACC(2, issue_w(ss + D - 1));
-        }
-        wait_vm<0>();
-        __builtin_amdgcn_s_barrier();                                  // "LDS is free"
-        __builtin_amdgcn_s_barrier();                                  // the exchange below
-        K2_ACC_FLUSH();
-        return;
-    }
-    if (wave == NCW + 1) {
-        // ---- x loader --------------------------------------------------------------------------------------------------------
-        __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.x, 0, (int)(e.bs * (int64_t)rowbytes), 0x00020000);
-        const uint32_t voff_lo = (lane >> 3) * rowbytes + ((uint32_t)((lane & 7) ^ (lane >> 3)) << 4);
-        const uint32_t voff_hi = voff_lo + 8u * rowbytes;
-        auto issue_x = [&](uint32_t ss) {
-            const uint32_t slot = ss % D;
-#pragma unroll
-            for (int h = 0; h < SPS; ++h) {
-                const uint32_t st = ss * SPS + h, sc = st < ns ? st : ns - 1;
-#pragma unroll
-                for (int i = 0; i < NI; ++i)                           // DMA instruction i = 2 * column block + row half
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void2_t *)(smem + slot * SB + h * SB1 + i * 1024), 16,
-                                                             (i & 1) ? voff_hi : voff_lo, sc * (KS * 2) + (i >> 1) * 128, 0, 0);
-            }
-        };
-        K2_ACC_DECL;
-#pragma unroll
-        for (int c = 0; c < D - 1; ++c) issue_x(c);
-#pragma unroll 1
-        for (uint32_t ss = 0; ss < nss; ++ss) {
-            K2_ACC(0, wait_vm<SPS * NI * (D - 2)>());
-            K2_ACC(1, __builtin_amdgcn_s_barrier());
-            K2_ACC(2, issue_x(ss + D - 1));
-        }
-        wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_barrier();
-        K2_ACC_FLUSH();
-        return;
-    }
-
-    // ---- compute waves: wave = h * NW + (row tile in the workgroup); k-half h takes stage ss*KSP + h of every ring step ----
-    K2_ACC_DECL;
-    const int j = lane & 15, g = lane >> 4;
-    const int hh = wave / NW, wt = wave - hh * NW;
-    const uint32_t rt = tile0 + wt;
-    const bool live = rt < ntile;                                      // wave-uniform; a dead wave still meets the barriers
-    const uint32_t rd_base = (j >> 3) * 1024 + (j & 7) * 128;
-    const uint32_t rd0 = rd_base + (((0 + g) ^ (j & 7)) << 4);
-    const uint32_t rd1 = rd_base + (((4 + g) ^ (j & 7)) << 4);
-    const uint32_t wof = XB + (uint32_t)wt * TPS * 1024 + (uint32_t)lane * 16;
-
-    // four accumulator chains: a dependent MFMA behind other instructions costs ~60 cycles, an independent one 16
-    f32x4_t acc[4], accx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acco[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const u32x4 ones = {opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES)};
-    const typename Q::Consts qc = Q::make_consts();
-    const u32x4 offs[2] = {Q::off_frag(0, qc), Q::off_frag(1, qc)};
-#pragma unroll 1
-    for (uint32_t ss = 0; ss < nss; ++ss) {
-        K2_ACC(1, __builtin_amdgcn_s_barrier());
-#pragma unroll
-        for (int u = 0; u < SPW; ++u) {
-            if (ss * SPS + hh * SPW + u >= ns) continue;              // ragged tail of the ring step (wave-uniform)
-            const char *sl = smem + (ss % D) * SB + (hh * SPW + u) * SB1;
-            u32x4 ws[TPS], xf[8];
-#pragma unroll
-            for (int t = 0; t < TPS; ++t) ws[t] = *reinterpret_cast<const u32x4 *>(sl + wof + t * 1024);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) xf[t] = *reinterpret_cast<const u32x4 *>(sl + (t >> 1) * 2048 + ((t & 1) ? rd1 : rd0));
-#pragma unroll
-            for (int t = 0; t < 8; ++t) acc[t & 3] = ACT::mfma(Q::frag(ws[(t * 32) / KC], t % NT, qc), xf[t], acc[t & 3]);
-            // one wave per stage keeps S_1 = sum x and S_off = sum OFF_k x (dealing the 8 steps round-robin to the NW waves
-            // through a switch was measured 20 % SLOWER per wave: profiles/r02h_k2lab.log)
-            if (((ss * SPW + u) % NW) == (uint32_t)wt) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    accx[t & 1] = ACT::mfma(ones, xf[t], accx[t & 1]);
-                    if constexpr (!Q::UNIFORM) acco[t & 1] = ACT::mfma(offs[t & 1], xf[t], acco[t & 1]);
-                }
-            }
-        }
-    }
-    K2_ACC_FLUSH();
-    __builtin_amdgcn_s_barrier();                                      // every ring read retired: LDS is free
-    const f32x4_t asum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    float *xch = reinterpret_cast<float *>(smem);                      // [NCW][4][64] k-half partials, then [NCW][16] S_1, [NCW][16] S_off
-    float *xsh = xch + NCW * 256, *xso = xsh + NCW * 16;
-    if (KSP > 1 && hh > 0) {
-        float *p = xch + wave * 256 + lane;
-        p[0] = asum[0]; p[64] = asum[1]; p[128] = asum[2]; p[192] = asum[3];
-    }
-    if (lane < 16) {
-        xsh[wave * 16 + lane] = accx[0][0] + accx[1][0];
-        if constexpr (!Q::UNIFORM) xso[wave * 16 + lane] = acco[0][0] + acco[1][0];
-    }
-    const uint32_t rtc = live ? rt : ntile - 1;
-    EpiRow epi = load_epi(e, (int64_t)rtc * 16 + 4 * g);
-    __syncthreads();
-    if (hh == 0) {
-        f32x4_t a = asum;
-#pragma unroll
-        for (int h = 1; h < KSP; ++h) {
-            const float *p = xch + (h * NW + wt) * 256 + lane;
-            a[0] += p[0]; a[1] += p[64]; a[2] += p[128]; a[3] += p[192];
-        }
-        float xsum = 0.f, xoff = 0.f;
-#pragma unroll
-        for (int v = 0; v < NCW; ++v) {
-            xsum += xsh[v * 16 + j];
-            if constexpr (!Q::UNIFORM) xoff += xso[v * 16 + j];
-        }
-        if constexpr (!Q::UNIFORM) { a[0] -= xoff; a[1] -= xoff; a[2] -= xoff; a[3] -= xoff; }
-        if (live) epilogue_store(e, epi, Q::OFF, a, xsum, (int64_t)j, (int64_t)rt * 16 + 4 * g);
-    }
+// up to three problems of ONE shape in one launch (blockIdx.y picks), each with its own x: the weight-stream kernel for the grouped GEMMs of
+// a 5..16-row decode step (round 6).  The same body text; the loads are LDS-DMA builtins the compiler sees, so the copy of the picked
+// problem's arguments out of the kernarg segment moves nothing that matters.
+template <int BITS, class ACT, int NW, int KSP, int SPW, int D>
+__global__ __launch_bounds__(64 * (NW * KSP + 2)) void dq_sg_kernel(K2GArgs G, uint32_t ntile)
+{
+    const K2Args A = G.g[blockIdx.y];
+#include "dq_s_body.inc"
 }
 
 template <int BITS, class ACT, int NW, int KSP, int SPW, int D>
@@ -368,6 +221,24 @@ int launch_s(const K2Args &A, hipStream_t s)
     const uint32_t ntile = (uint32_t)(A.e.m / 16);
     kern<<<dim3((ntile + NW - 1) / NW), 64 * (NW * KSP + 2), lds, s>>>(A, ntile);
     QA_LAUNCH_CHECK("quipamd_dequant_gemm(s)");
+    return QUIPAMD_OK;
+}
+
+template <int BITS, class ACT, int NW, int KSP, int SPW, int D>
+int launch_sg(const K2GArgs &G, int ngroups, hipStream_t s)
+{
+    constexpr int TPS = 256 / (512 / BITS);
+    constexpr size_t lds = (size_t)D * KSP * SPW * (16 * 256 * 2 + NW * TPS * 1024);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    const K2Args &A = G.g[0];
+    QA_REQUIRE(A.e.m * A.d * BITS / 8 < ((int64_t)1 << 32), QUIPAMD_ERR_SHAPE, "dequant_gemm_grouped(s): packed weights >= 4 GiB");
+    auto kern = dq_sg_kernel<BITS, ACT, NW, KSP, SPW, D>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return qa_fail(QUIPAMD_ERR_LAUNCH, "dequant_gemm_grouped: cannot raise dynamic LDS to %zu", lds);
+    const uint32_t ntile = (uint32_t)(A.e.m / 16);
+    kern<<<dim3((ntile + NW - 1) / NW, (unsigned)ngroups), 64 * (NW * KSP + 2), lds, s>>>(G, ntile);
+    QA_LAUNCH_CHECK("quipamd_dequant_gemm_grouped(s)");
     return QUIPAMD_OK;
 }
 

@@ -130,14 +130,22 @@ static void k2_fill(K2Args &A, const K2Call &c)
 
 // A/B runs only: QUIP_HG_RT=1|2|4 forces the row tiles per workgroup of the grouped h kernel.  Read ONCE per process (a getenv on
 // every grouped GEMM sat on the decode hot path, and a variable set mid-run silently changed the kernel selection).
+static int g_grouped_form = 0;          // quipamd_dequant_gemm_grouped_config (tests, A/B runs); 0 = the environment's value, else the heuristic
 static int hg_rt_override()
 {
     static const int v = [] {
         const char *ev = getenv("QUIP_HG_RT");
         return ev ? atoi(ev) : 0;
     }();
-    return v;
+    return g_grouped_form ? g_grouped_form : v;
 }
+
+extern "C" void quipamd_dequant_gemm_grouped_config(int form) { g_grouped_form = form; }
+
+// which grouped weight-stream form serves the big grouped GEMMs of a 5..16-row step by default (0: none, the grouped h kernel)
+#ifndef K2_SG_DEFAULT
+#define K2_SG_DEFAULT 0
+#endif
 
 int k2v2_launch_grouped(const K2Call *calls, int ngroups, void *stream)
 {
@@ -157,6 +165,15 @@ int k2v2_launch_grouped(const K2Call *calls, int ngroups, void *stream)
         // (8 row tiles -- Llama's gate / up as ONE round of 172 workgroups -- measured slower than 4: Llama-2-7B at 16 sequences 3.27 ms per step against
         //  3.18, at 8 sequences 2.88 against 2.76, profiles/r05w_hg_rt8_llama.txt; the instantiation is not kept.)
         const int64_t tiles = c.m / 16;
+        // Round 6: beyond two rounds of one-per-CU workgroups the grouped WEIGHT-STREAM kernel (dq_sg_kernel: x~ staged once per 4 / 7 / 8 row
+        // tiles by a loader wave, weights through the LDS ring) instead of the h kernel, whose every workgroup ingests all of x~ by itself.
+        // QUIP_HG_RT = 74 / 72 / 81 force its <4,2,1,4> / <7,2,1,3> / <8,1,2,3> forms, 1 / 2 / 4 the h kernel's row tiles (A/B runs).
+        int sg = (tiles * ngroups > 512) ? K2_SG_DEFAULT : 0;
+        if (const int f = hg_rt_override(); f == 74 || f == 72 || f == 81) sg = f;
+        else if (f == 1 || f == 2 || f == 4) sg = 0;
+        if (sg == 74) return launch_sg<2, ActF16, 4, 2, 1, 4>(G, ngroups, s);
+        if (sg == 72) return launch_sg<2, ActF16, 7, 2, 1, 3>(G, ngroups, s);
+        if (sg == 81) return launch_sg<2, ActF16, 8, 1, 2, 3>(G, ngroups, s);
         int rt = 1;
         if (tiles * ngroups > 256 && tiles % 2 == 0) rt = 2;
         if (tiles * ngroups > 512 && tiles % 4 == 0) rt = 4;

@@ -31,9 +31,11 @@ import torch.nn.functional as F
 from . import method as _method
 from . import ops
 from .quant import (QuantLinear, make_quant, packed_forward_fused, fused_stage, fused_ok, fused_attention, fused_attention_ok,
-                    fused_u_only, fused_head, fused_head_ok, fused_bigp_tail, bigp_tail_ok, packed_u_stage)
+                    fused_u_only, fused_head, fused_head_ok, fused_bigp_tail, bigp_tail_ok, packed_u_stage, stage_operands, attention_operands)
 
 MODES = ("plain", "fused", "v3", "v3_head")
+OPERAND_PREFETCH = True    # v3 launches carry 8 spare workgroups that pull the step-independent operands of a LATER launch of the block into every
+                           # XCD's L2 (csrc/prefetch.h; round 6: in a decode step they are cold once per token).  False: the round-5 launches
 
 
 # ------------------------------------------------------------------------------------------------ packed layers out of a driver run
@@ -172,26 +174,50 @@ class OPTDecoder(nn.Module):
         prev, y2, x = self.blocks_v3(x, pos, caches)
         return fused_head(prev, y2, x, self.lnf, self.head_weight, logits, part_val, part_idx, pos_inc=pos)
 
+    def _operand_lists(self):
+        """per block: the step-independent operand tensors of each of its five launches (quant.stage_operands), built once"""
+        pf = self.__dict__.get('_pf_lists')
+        if pf is None:
+            pf, prev = [], None
+            for blk in self.blocks:
+                qkv = [blk.q_proj, blk.k_proj, blk.v_proj]
+                pf.append({"qkv": stage_operands(qkv, prev=prev, ln=blk.ln1), "attn": attention_operands(qkv), "o": stage_operands([blk.out_proj]),
+                           "fc1": stage_operands([blk.fc1], prev=blk.out_proj, ln=blk.ln2), "fc2": stage_operands([blk.fc2], prev=blk.fc1)})
+                prev = blk.fc2
+            # (the fc1 -> fc2 launch's per-lane tables are built by its first call: keep the lists only once they are in)
+            if all(b.fc2.__dict__.get('_pair_tables') or (b.fc2.V.p, b.fc2.V.q) != (128, 64) for b in self.blocks):
+                self.__dict__['_pf_lists'] = pf
+        return pf
+
     def blocks_v3(self, x, pos, caches):
         """per block: [U_fc2^T(prev) + residual -> LN1 -> V_qkv -> GEMM qkv] [U_qkv^T + attention] [V_o -> GEMM o]
         [U_o^T + residual -> LN2 -> V_fc1 -> GEMM fc1] [U_fc1^T + relu -> V_fc2 -> GEMM fc2]; returns (fc2 of the last block, its output
-        in the projected basis, the residual stream): the last U_fc2^T + residual belongs to whatever ends the step."""
+        in the projected basis, the residual stream): the last U_fc2^T + residual belongs to whatever ends the step.
+        With OPERAND_PREFETCH the qkv launch (192 workgroups on 256 CUs) also pulls the attention launch's operands into the L2s, the
+        attention launch (32 workgroups) those of out_proj and fc1, the out_proj launch (64) those of fc2 and of the next block's qkv."""
         dt = x.dtype
         prev, y2 = None, None
         h16 = torch.float16                                     # y consumed by another fused launch: fp16 (its scatter rounds to fp16 anyway)
-        for blk, (kc, vc) in zip(self.blocks, caches):
+        pf = self._operand_lists() if OPERAND_PREFETCH else None
+        for bi, (blk, (kc, vc)) in enumerate(zip(self.blocks, caches)):
             qkv = [blk.q_proj, blk.k_proj, blk.v_proj]
             attn_u = self.v3_attn and fused_attention_ok(qkv, kc)
             ydt = h16 if attn_u else torch.float32
+            if pf is not None and attn_u:
+                ops.decode_prefetch_next(pf[bi]["attn"])
             if prev is None:
                 ys, _ = fused_stage(qkv, x=x, ln=blk.ln1, y_dtype=ydt)
             else:
                 ys, x = fused_stage(qkv, prev=prev, y_prev=y2, residual=x, ln=blk.ln1, store=True, y_dtype=ydt)
             if attn_u:                                          # U_q^T, U_k^T, U_v^T + bias in the attention launch's prologue
+                if pf is not None:
+                    ops.decode_prefetch_next((pf[bi]["o"] + pf[bi]["fc1"])[:40])
                 o = fused_attention(qkv, ys, kc, vc, pos)
             else:                                               # (the fused launches hand y over in ZT order: K3 wants the natural one)
                 q, k, v = packed_u_stage(qkv, [l.from_zt(y) for l, y in zip(qkv, ys)], dt)
                 o = ops.decode_attention(q, k, v, kc, vc, pos)
+            if pf is not None:
+                ops.decode_prefetch_next((pf[bi]["fc2"] + (pf[bi + 1]["qkv"] if bi + 1 < len(pf) else []))[:40])
             yo = fused_stage([blk.out_proj], x=o, y_dtype=h16)[0][0]
             (y1,), x = fused_stage([blk.fc1], prev=blk.out_proj, y_prev=yo, residual=x, ln=blk.ln2, store=True, y_dtype=h16)
             y2 = fused_stage([blk.fc2], prev=blk.fc1, y_prev=y1, relu=True, y_dtype=h16)[0][0]

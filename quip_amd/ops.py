@@ -249,6 +249,11 @@ def dequant_gemm_grouped(xs, qweights, bits, qfn, scales, zeros, outs, m):
     return outs
 
 
+def dequant_gemm_grouped_config(form=0):
+    """tests / A-B runs: 0 heuristic; 1 | 2 | 4 grouped h kernel row tiles; 74 | 72 | 81 grouped weight-stream kernel, 4 | 7 | 8 row tiles (process-wide)"""
+    _lib.load().quipamd_dequant_gemm_grouped_config(int(form))
+
+
 # ------------------------------------------------------------------------------------------------- K3
 class SmallOp(ctypes.Structure):
     """mirror of `quipamd_small_op` (include/quip_amd.h)."""
@@ -529,6 +534,19 @@ def decode_fused_gemm(*, V, colscale, qweight, scale, y, m, bs, x=None, U=None, 
     if pair is not None:
         a.pair_sig, a.pair_bias, a.pair_cs = (t.data_ptr() for t in pair)
     _lib.call("quipamd_decode_fused_gemm", ctypes.byref(a), _stream())
+
+
+def decode_prefetch_next(tensors):
+    """attach the byte ranges of `tensors` (device tensors, contiguous) to the NEXT fused decode launch of this thread: 8 spare workgroups of
+    that launch pull them into every XCD's L2 (quipamd_decode_prefetch_next, csrc/prefetch.h).  A hint: never changes a result."""
+    ts = [t for t in tensors if t is not None and t.numel()]
+    n = len(ts)
+    if n == 0:
+        return
+    assert n <= 40, "decode_prefetch_next: at most 40 ranges"
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    sizes = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t in ts])
+    _lib.call("quipamd_decode_prefetch_next", ptrs, sizes, n)
 
 
 def ortho_blocked_multi(entries, out_dtype):

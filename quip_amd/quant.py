@@ -863,6 +863,38 @@ def fused_stage(qls, x=None, prev=None, y_prev=None, residual=None, relu=False, 
     return ys, t
 
 
+def stage_operands(qls, prev=None, ln=None):
+    """the device tensors the prologue of fused_stage(qls, prev=prev, ln=ln) reads that do NOT depend on the step -- factor fragments, index
+    vectors, bias, gains, column scales, grid scales (50-150 KB) -- for ops.decode_prefetch_next (csrc/prefetch.h): in a decode step they are
+    cold in L2 once per token, and an earlier launch's spare workgroups can pull them in"""
+    out = []
+    if prev is not None:
+        prev.U.fop(True)
+        F0, F1, _, st = prev.U._fops[True][1]
+        out += [F0, F1, st, bias16(prev)]
+    lnp = _ln_params(ln)
+    if lnp is not None:
+        out += [lnp[0]] + ([lnp[1]] if lnp[1] is not None else [])
+    for q in qls:
+        q.V.fop(False)
+        F0, F1, ld, _ = q.V._fops[False][1]
+        out += [F0, F1, ld, q.inv_scaleWH if q.inv_scaleWH is not None else q.V.one_scale(), q.scales]
+    if prev is not None and len(qls) == 1:
+        for tabs in qls[0].__dict__.get('_pair_tables', {}).values():     # the fc1 -> fc2 pair launch reads its per-lane tables instead
+            out += list(tabs)
+    return out
+
+
+def attention_operands(qkv):
+    """the same for fused_attention(qkv, ...): the transposed output-side operators of q / k / v and their biases"""
+    out = []
+    for l in qkv:
+        l.U.fop(True)
+        F0, F1, _, st = l.U._fops[True][1]
+        out += [F0, F1, st, bias16(l)]
+    return out
+
+
 def save_packed(layers, path):
     """Packed checkpoint: {dotted module name: QuantLinear} -> one torch file of CPU tensors (replaces the dense fp16
     `torch.save(model.state_dict())` of opt.py:644-646 for the quantised Linears; 2 bits/weight + factors)."""

@@ -86,11 +86,17 @@ def main():
     launches = [r for r in rec if r[0] != "quipamd_probe_set"]
     names_seq = [r[0] for r in launches]
     per, first = 0, 0
-    for p_ in range(2, 64):                                             # the block's launch sequence = the shortest period of the name sequence
-        hits = [i for i in range(len(names_seq) - 2 * p_) if names_seq[i:i + p_] == names_seq[i + p_:i + 2 * p_]]
-        if hits:
-            per, first = p_, hits[0]
+    n_ = len(names_seq)
+    for p_ in range(2, 80):                                             # the block's launch sequence = the shortest period that holds over the whole step
+        lo_, hi_ = 2, n_ - p_ - 3
+        if hi_ - lo_ < 2 * p_:
             break
+        if all(names_seq[i] == names_seq[i + p_] for i in range(lo_, hi_)):
+            per = p_
+            break
+    first = (n_ - nb * per) // 2 if per else 0                         # what is not a block sits at the two ends (embed | head, argmax)
+    if eng.mode == "v3_head":
+        first = 1
     blk = a.block if a.block >= 0 else nb // 2
     first += min(blk, nb - 2) * per
     print(f"# {arch}; operators: {'blocked butterfly (the shipped flag, preproc_proj_extra = 0)' if a.blocked else 'Kronecker (preproc_proj_extra = 1)'}; "

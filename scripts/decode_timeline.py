@@ -23,6 +23,8 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--tokens", type=int, default=48)
     ap.add_argument("--head", default="", help="substring of the kernel that ends a step (default: the longest-running frequent kernel)")
+    ap.add_argument("--offset", type=int, default=-1, help="launches of a step in front of the first block (default: half of what the blocks leave over)")
+    ap.add_argument("--dump", default="", help="write (kernel name ids, start, end) of the analysed steps to this .npz for later re-analysis")
     a = ap.parse_args()
     con = sqlite3.connect(a.db)
     rows = con.execute("select name, start, end from kernels order by start").fetchall()
@@ -44,11 +46,16 @@ def main():
     steps = [(c, b) for c, b in steps if b - c == L]
     seq = names[steps[-1][0]:steps[-1][1]]
     per, off = 0, 0
-    for p_ in range(2, 64):
-        hits = [i for i in range(L - 2 * p_) if seq[i:i + p_] == seq[i + p_:i + 2 * p_] and seq[i:i + p_] == seq[i + 2 * p_:i + 3 * p_]]
-        if hits:
-            per, off = p_, hits[0]
+    for p_ in range(2, 80):                                             # the block's launch sequence: the shortest period that holds over the whole step
+        lo_, hi_ = 3, L - p_ - 4
+        if hi_ - lo_ < 2 * p_:
             break
+        if all(seq[i] == seq[i + p_] for i in range(lo_, hi_)):
+            per = p_
+            break
+    if not per:
+        raise SystemExit(f"no periodic block structure found in a step of {L} launches: " + ", ".join(seq[:40]))
+    off = a.offset if a.offset >= 0 else (L - (L // per) * per + 1) // 2
     nblk = (L - off) // per
     dur = np.zeros((len(steps), nblk - 1, per))
     gap = np.zeros_like(dur)
@@ -58,6 +65,12 @@ def main():
                 i = c + off + b * per + k
                 dur[si, b, k] = en[i] - st[i]
                 gap[si, b, k] = st[i + 1] - en[i]
+    if a.dump:
+        uniq = sorted(set(names))
+        ix = {n: i for i, n in enumerate(uniq)}
+        lo_i, hi_i = steps[0][0], steps[-1][1]
+        np.savez_compressed(a.dump, names=np.array(uniq), ids=np.array([ix[n] for n in names[lo_i:hi_i]], dtype=np.int32), start=st[lo_i:hi_i], end=en[lo_i:hi_i],
+                            steps=np.array(steps) - lo_i)
     tok = np.array([st[b - 1] + (en[b - 1] - st[b - 1]) - st[c] for c, b in steps])
     print(f"# {a.db}: {len(steps)} steps of {L} launches (step = up to '{head}'), {per} launches per block x {nblk} blocks; "
           f"median step {np.median(tok) / 1e3:.1f} us from the first launch's start to the head's end")

@@ -208,14 +208,18 @@ def test_fused_stage_rejects_what_it_cannot_run():
 
 
 @pytest.mark.parametrize("n,heads,hd,rope,bs,pos", [(2048, 32, 64, False, 1, 37), (2048, 32, 64, False, 2, 0), (4096, 32, 128, True, 1, 21),
-                                                     (4096, 32, 128, False, 2, 5), (2048, 16, 128, True, 1, 63)])
+                                                     (4096, 32, 128, False, 2, 5), (2048, 16, 128, True, 1, 63),
+                                                     # round 6: the first 256 K rows are requested with the prologue's operands -- this token's row
+                                                     # inside (255), just outside (256) and far outside (300, 700) that first pass; head dim 128 keeps the old path
+                                                     (2048, 32, 64, False, 1, 255), (2048, 32, 64, False, 2, 256), (2048, 32, 64, False, 1, 300),
+                                                     (2048, 32, 64, False, 1, 700), (4096, 32, 128, True, 1, 300)])
 def test_attention_with_the_output_side_operators_in_its_prologue(n, heads, hd, rope, bs, pos):
     """quipamd_decode_attention_fused against the three launches it replaces (tiled U^T + bias of q / k / v [+ rotary] + decode
     attention): out and the appended cache rows"""
     from quip_amd import ops
     from quip_amd.quant import packed_u_stage, fused_attention, fused_attention_ok
     qkv = [_layer(n, n, 700 + i + n % 13)[0] for i in range(3)]
-    maxlen = 64
+    maxlen = 64 if pos < 64 else 768
     torch.manual_seed(n + pos)
     kc = (0.5 * torch.randn(bs, heads, maxlen, hd, device=DEV)).half()
     vc = (0.5 * torch.randn(bs, heads, maxlen, hd, device=DEV)).half()

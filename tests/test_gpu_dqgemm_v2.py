@@ -225,3 +225,33 @@ def test_fp16_layer_keeps_its_mantissa(ops):
     assert gotb.dtype == torch.bfloat16
     wantb = xb.double() @ What.double().T + ql.bias.double()
     assert float((gotb.double() - wantb).norm() / wantb.norm()) <= 5e-3
+
+
+@pytest.mark.parametrize("form", [74, 72, 81, 4])
+@pytest.mark.parametrize("m,groups,bs", [(11008, 2, 16), (4096, 3, 5), (2064, 2, 9)])
+def test_grouped_weight_stream_kernel(ops, O, form, m, groups, bs):
+    """round 6: dq_sg_kernel -- the weight-stream kernel on 2 / 3 problems of one shape, each with its OWN x~ (gate / up, q / k / v of a
+    5..16-row decode step at d = 4096) -- in its three workgroup forms, and the grouped h kernel beside it, against the fp64 formula per
+    problem (rows of a sample for the big shape: the oracle's dense product is the slow part).  Ragged row-tile counts included
+    (688 = 7 x 98 + 2 tiles; 129 tiles)."""
+    d, bits, dt = 4096, 2, torch.float16
+    xs, qws, scs, refs = [], [], [], []
+    rng = np.random.default_rng(form + m)
+    rows = np.sort(rng.choice(m, size=min(m, 512), replace=False))
+    for g in range(groups):
+        xt, x, codes, scale, zero, maxq = _case(O, m, d, bs, bits, "b", dt, seed=10 * g + bs)
+        xs.append(xt.to(DEV))
+        qws.append(ops.pack(torch.from_numpy(codes).to(DEV), bits, ops.LAYOUT_STREAM))
+        scs.append(torch.tensor(np.asarray(scale, np.float32).reshape(-1)).to(DEV))
+        refs.append(O.dequant_linear(x, codes[rows], "b", scale, None, maxq, None))
+    outs = [torch.full((bs, m), float("nan"), dtype=torch.float32, device=DEV) for _ in range(groups)]
+    ops.dequant_gemm_grouped_config(form)
+    try:
+        ops.dequant_gemm_grouped(xs, qws, bits, "b", scs, None, outs, m)
+        torch.cuda.synchronize()
+    finally:
+        ops.dequant_gemm_grouped_config(0)
+    for g in range(groups):
+        got = outs[g].cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all(), (form, g)
+        assert _rel(got[:, rows], refs[g]) <= TOL_F32, (form, g)
