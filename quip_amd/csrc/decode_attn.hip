@@ -18,6 +18,13 @@
 #include "probe.h"
 #include "prefetch.h"
 
+// A/B builds (python __graft_entry__.py --variant nokpf -DQA_NO_KPF): round 5's request order -- no early K rows, no touched V lines
+#ifdef QA_NO_KPF
+#define QA_KPF 0
+#else
+#define QA_KPF 1
+#endif
+
 namespace {
 
 // wave-wide reductions on the DPP network (4 DPP operands + 4 v_readlane instead of six ds_bpermute round trips each)
@@ -57,25 +64,35 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
     S *kcb = kc + ((int64_t)b * heads + head) * maxlen * HD, *vcb = vc + ((int64_t)b * heads + head) * maxlen * HD;
 
     if (pos < 0 || pos >= maxlen) return;                           // uniform; a full cache is the caller's error
-    // Round 6: the first 256 K rows of the cache are requested NOW, with the kernel's first loads, not behind the append barrier and the q
-    // loads (the scores phase used to open with a cold round trip).  This token's own row is not in the cache yet: its owner reads it from k.
+    // Round 6 (profiles/r06_decode_stamps.txt): the scores phase opened with a COLD round trip for the K rows of the cache, p V with one for the
+    // V rows.  Order of the requests now (vector memory returns in order): this token's k, v and q first -- written by the previous launch,
+    // L2 -- then the first 256 K rows of the cache into registers and a touch of the V rows' lines, which travel under the append and the
+    // conversion of q.  This token's own row is not in the cache yet: its owner reads it from k.
+    S knew = S(), vnew = S();
+    if (tid < HD) knew = kh[tid];
+    else if (tid < 2 * HD) vnew = vh[tid - HD];
+    uint4 qraw[HD / 8];
+#pragma unroll
+    for (int e8 = 0; e8 < HD; e8 += 8) qraw[e8 / 8] = *reinterpret_cast<const uint4 *>(qh + e8);
     uint4 kpre[HD / 8];
     {
         const int64_t tpre = tid < maxlen ? tid : 0;
 #pragma unroll
         for (int e8 = 0; e8 < HD; e8 += 8) kpre[e8 / 8] = *reinterpret_cast<const uint4 *>(kcb + tpre * HD + e8);
     }
+    qa_sink_t sink = 0;                                             // (csrc/prefetch.h: the touches' destination, kept alive to the end)
+    if constexpr (QA_KPF) qa_touch_lines<HD * 2 / 128>(vcb + (tid < T ? (int64_t)tid : T - 1) * HD, sink);
     // append this token; the barrier (workgroup-scope fence) makes it visible to the reads below
-    if (tid < HD) kcb[pos * HD + tid] = kh[tid];
-    else if (tid < 2 * HD) vcb[pos * HD + tid - HD] = vh[tid - HD];
+    if (tid < HD) kcb[pos * HD + tid] = knew;
+    else if (tid < 2 * HD) vcb[pos * HD + tid - HD] = vnew;
     __syncthreads();
     QA_STAMP(8);                                                    // k, v of this token landed and appended + barrier
 
     float qr[HD];
 #pragma unroll
-    for (int e8 = 0; e8 < HD; e8 += 8) {                            // 16-byte loads (HD scalar 2-byte loads per thread before)
+    for (int e8 = 0; e8 < HD; e8 += 8) {
         S raw[8];
-        *reinterpret_cast<uint4 *>(raw) = *reinterpret_cast<const uint4 *>(qh + e8);
+        *reinterpret_cast<uint4 *>(raw) = qraw[e8 / 8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) qr[e8 + e] = DT<TI>::load(raw, e) * scale;
     }
@@ -104,7 +121,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
     };
     if (tid < T) {                                                   // first pass: the prefetched row (this token's own row straight from k)
         const float acc = tid == pos ? dot_row([&](int e8) { return *reinterpret_cast<const uint4 *>(kh + e8); })
-                                     : dot_row([&](int e8) { return kpre[e8 / 8]; });
+                          : QA_KPF ? dot_row([&](int e8) { return kpre[e8 / 8]; })
+                                   : dot_row([&](int e8) { return *reinterpret_cast<const uint4 *>(kcb + (int64_t)tid * HD + e8); });
         scores[tid] = acc;
         mx = fmaxf(mx, acc);
     }
@@ -172,6 +190,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
         const float r = (part[tid] + part[HD + tid]) + (part[2 * HD + tid] + part[3 * HD + tid]);
         DT<TI>::store(out + (int64_t)b * ldq + head * HD, tid, r * inv);
     }
+    qa_touch_done(sink);
     QA_STAMP(12);
 }
 
@@ -344,7 +363,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     // under the operator passes).  The row of THIS token (t == pos) is not in the cache yet: the thread that owns it takes it from the LDS
     // slice instead -- its prefetched registers hold whatever the cache held before.  Head dim 64 only: 16 more 16-byte registers per lane do
     // not fit the 768-thread form at head dim 128.
-    constexpr bool KPF = HD <= 64;
+    constexpr bool KPF = HD <= 64 && QA_KPF;
     uint4 kpre[KPF ? HD / 8 : 1];
     if constexpr (KPF) {
         const int64_t tpre = tid < G.maxlen ? tid : 0;
@@ -354,6 +373,13 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
 #pragma unroll
             for (int e8 = 0; e8 < HD; e8 += 8) kpre[e8 / 8] = *reinterpret_cast<const uint4 *>(kcb + tpre * HD + e8);
         }
+    }
+    // ... and the lines of the V rows (and of the K rows at head dim 128) are TOUCHED here: loads nobody waits for, behind the prologue's own
+    // requests (vector memory returns in order: in front of them they would put an HBM round trip before the first activations)
+    qa_sink_t sink = 0;                                               // (csrc/prefetch.h: the touches' destination, kept alive to the end)
+    if constexpr (HD <= 64 && QA_KPF) {   // (no branch around the statement: threads past the end touch row T - 1 again)
+        const int64_t tt = tid < T ? tid : T - 1;
+        qa_touch_lines<HD * 2 / 128>(vcb + tt * HD, sink);
     }
     QA_STAMP(2);                                                      // every request of the prologue issued
 #pragma unroll
@@ -383,7 +409,18 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     }
     __syncthreads();
     QA_STAMP(6);                                                      // stage 2 + barrier
-    if (NGRP == 3 && wave >= 4) return;                               // the k and v groups are done (hardware barriers count live waves only)
+    if (NGRP == 3 && wave >= 4) {                                     // the k and v groups are done (hardware barriers count live waves only)
+        if constexpr (HD > 64 && QA_KPF) {
+            // head dim 128: any early touch of the cache rows cost this instantiation a register array in scratch memory (it sits at its register
+            // budget), so the waves that LEAVE here touch the K and V lines of the first 512 positions on their way out -- ~1000 clocks ahead
+            // of the scores instead of ~5000, still ahead
+            const int64_t tt = tid - 256 < T ? tid - 256 : T - 1;
+            qa_touch_lines<HD * 2 / 128>(kcb + tt * HD, sink);
+            qa_touch_lines<HD * 2 / 128>(vcb + tt * HD, sink);
+        }
+        qa_touch_done(sink);
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < GR; ++it) {
         const int t = tid + 256 * it;
@@ -518,6 +555,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
         const float r = (part[tid] + part[HD + tid]) + (part[2 * HD + tid] + part[3 * HD + tid]);
         DT<TI>::store(G.out + (int64_t)b * G.ldo + head * HD, tid, r * inv);
     }
+    qa_touch_done(sink);
     QA_STAMP(12);
 }
 

@@ -142,9 +142,11 @@ static int hg_rt_override()
 
 extern "C" void quipamd_dequant_gemm_grouped_config(int form) { g_grouped_form = form; }
 
-// which grouped weight-stream form serves the big grouped GEMMs of a 5..16-row step by default (0: none, the grouped h kernel)
+// which grouped weight-stream form serves the big grouped GEMMs of a 5..16-row step by default (0: none, the grouped h kernel).
+// profiles/r06b_grouped_forms.jsonl (Llama-2-7B, one box, alternating, ms per step at 16 / 8 sequences): grouped h kernel with 4 row tiles
+// 3.21 / 2.78; dq_sg <4,2,1,4> 3.14 / 2.78; <7,2,1,3> 3.00 / 2.63; <8,1,2,3> 3.08 / 2.70.
 #ifndef K2_SG_DEFAULT
-#define K2_SG_DEFAULT 0
+#define K2_SG_DEFAULT 72
 #endif
 
 int k2v2_launch_grouped(const K2Call *calls, int ngroups, void *stream)

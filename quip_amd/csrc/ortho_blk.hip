@@ -169,23 +169,31 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         tbias[reg] = tres[reg] = 0.f;
     }
     if (wave == 0 && (lane & 15) < R) {
-        const int r = lane & 15;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int io = tile * 16 + 4 * g4 + reg;
             const int pos = S.mix_a ? io * q + g : g * q + io;
             tdst[reg] = S.out_idx ? S.out_idx[pos] : pos;
         }
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            if (S.bias) tbias[reg] = S.bias[tdst[reg]];
-            if (S.residual) {
-                const int64_t ri = (int64_t)(gr0 + r) * S.ld_res + tdst[reg];
-                tres[reg] = S.res_dtype == QUIPAMD_F32 ? ((const float *)S.residual)[ri]
-                            : S.res_dtype == QUIPAMD_F16 ? f16_bits_to_f32(((const uint16_t *)S.residual)[ri]) : bf16_bits_to_f32(((const uint16_t *)S.residual)[ri]);
-            }
-        }
     }
+    // bias / residual hang on those indices: a DEPENDENT round trip.  Requested right here (rounds 4-5) it made wave 0 wait for the -- cold --
+    // index vector before it could issue anything else, and in the FUSED form every wave then waited for wave 0 at the first barrier: 2000-4000
+    // clocks on the launch's critical path (profiles/r06_decode_stamps.txt, "requests issued").  FUSED launches fetch them behind that barrier,
+    // where the indices have long landed; the unfused ones keep the request here (all their waves chase an index of their own anyway).
+#define BK_FETCH_TAIL()                                                                                                                       \
+    if (wave == 0 && (lane & 15) < R) {                                                                                                       \
+        const int r_ = lane & 15;                                                                                                             \
+        _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                                                 \
+            if (S.bias) tbias[reg] = S.bias[tdst[reg]];                                                                                       \
+            if (S.residual) {                                                                                                                 \
+                const int64_t ri = (int64_t)(gr0 + r_) * S.ld_res + tdst[reg];                                                                \
+                tres[reg] = S.res_dtype == QUIPAMD_F32   ? ((const float *)S.residual)[ri]                                                   \
+                            : S.res_dtype == QUIPAMD_F16 ? f16_bits_to_f32(((const uint16_t *)S.residual)[ri])                               \
+                                                         : bf16_bits_to_f32(((const uint16_t *)S.residual)[ri]);                              \
+            }                                                                                                                                 \
+        }                                                                                                                                     \
+    }
+    if constexpr (!FUSED) BK_FETCH_TAIL()
 
     QA_STAMP(1);                                                       // every up-front request issued (factors, index -> value, destinations)
     // ---- statistics of the rows (first stage with a norm): every workgroup reduces the whole row -- n <= 16384 values from L2 ---------
@@ -256,6 +264,13 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
             const int k = wc / C, ch = wc - k * C;
             fi[c] = *reinterpret_cast<const uint4 *>(S.F1 + ((int64_t)k * P1 + g) * P1 + 8 * ch);
         }
+        // Round 6: the gains, the LayerNorm bias and the column scale of this thread's first column chunk are requested HERE too.  They used to be
+        // loaded inside the "gains in place" loop, behind three barriers: a second cold round trip in the middle of the launch (5300-5500 clocks
+        // for statistics + gains on the LayerNorm launches, profiles/r06_decode_stamps.txt; n = 2048: the first chunk is the thread's only one).
+        const int c8p = tid < n8 ? tid : 0;
+        const uint4 gm_p = *reinterpret_cast<const uint4 *>(gmp + (S.norm ? 8 * c8p : 0));
+        const uint4 bt_p = *reinterpret_cast<const uint4 *>(btp + (S.norm == 1 ? 8 * c8p : 0));
+        const float4 csa_p = *reinterpret_cast<const float4 *>(csp + (has_cs ? 8 * c8p : 0)), csb_p = *reinterpret_cast<const float4 *>(csp + (has_cs ? 8 * c8p + 4 : 0));
 #pragma unroll 2
         for (int e8 = tid; e8 < R * n8; e8 += BK_T) {
             const int r = e8 / n8, c8 = e8 - r * n8;
@@ -280,6 +295,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         QA_STAMP(3);                                                     // FUSED: rows + permutation landed and staged
         __syncthreads();
         QA_STAMP(4);
+        BK_FETCH_TAIL()                                                  // (the destination indices landed long ago: no stall)
         if (S.norm) {                                                    // the statistics from LDS: one pass, shifted like the two-launch form
             for (int r = 0; r < R; ++r) {
                 const float c0 = S.norm == 1 ? XIN[r * n] : 0.f;
@@ -307,11 +323,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
             __syncthreads();
         }
         if (S.norm || has_cs) {                                          // gains / column scale in place, per column chunk for all rows
-#pragma unroll 2
-            for (int c8 = tid; c8 < n8; c8 += BK_T) {
-                const uint4 gm4 = *reinterpret_cast<const uint4 *>(gmp + (S.norm ? 8 * c8 : 0));
-                const uint4 bt4 = *reinterpret_cast<const uint4 *>(btp + (S.norm == 1 ? 8 * c8 : 0));
-                const float4 csa = *reinterpret_cast<const float4 *>(csp + (has_cs ? 8 * c8 : 0)), csb = *reinterpret_cast<const float4 *>(csp + (has_cs ? 8 * c8 + 4 : 0));
+            auto gains = [&](int c8, const uint4 gm4, const uint4 bt4, const float4 csa, const float4 csb) {
                 const uint32_t gmw[4] = {gm4.x, gm4.y, gm4.z, gm4.w}, btw[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
                 const float csv[8] = {csa.x, csa.y, csa.z, csa.w, csb.x, csb.y, csb.z, csb.w};
                 for (int r = 0; r < R; ++r) {
@@ -326,7 +338,12 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
                         xr[i8] = v;
                     }
                 }
-            }
+            };
+            if (tid < n8) gains(tid, gm_p, bt_p, csa_p, csb_p);          // the chunk requested at the top of the launch
+#pragma unroll 2
+            for (int c8 = tid + BK_T; c8 < n8; c8 += BK_T)               // n > 2048: the rest from memory, as before
+                gains(c8, *reinterpret_cast<const uint4 *>(gmp + (S.norm ? 8 * c8 : 0)), *reinterpret_cast<const uint4 *>(btp + (S.norm == 1 ? 8 * c8 : 0)),
+                      *reinterpret_cast<const float4 *>(csp + (has_cs ? 8 * c8 : 0)), *reinterpret_cast<const float4 *>(csp + (has_cs ? 8 * c8 + 4 : 0)));
             __syncthreads();
         }
         QA_STAMP(5);                                                     // FUSED: statistics + gains in place

@@ -27,21 +27,35 @@ struct QaPfList {
 QaPfList qa_pf_take();              // capi.hip: the calling thread's pending list (n = 0 when none), cleared
 
 #ifdef __HIPCC__
-// every prefetch workgroup touches EVERY line (its XCD's L2 is private); the loads' results are dead and nobody waits for them -- the wave
-// ends behind them (s_endpgm waits for outstanding memory operations by itself)
+// A load nobody waits for still WRITES its destination register when it lands -- possibly thousands of clocks later.  hipcc does not see an
+// asm load's pending write: with a throw-away output it hands the register to the next value and the late write-back corrupts it (round 6:
+// the first form of this file did exactly that -- a prefetch workgroup's address registers were overwritten, memory access faults in every
+// decode test).  So every touch of a wave writes ONE register the caller keeps alive ("+v") until qa_touch_done() at the end of its work.
+typedef uint32_t qa_sink_t;
+
+// NL consecutive 128-byte lines from one address register pair (immediate offsets): pull them towards this CU (its XCD's L2, its L1)
+template <int NL> __device__ __forceinline__ void qa_touch_lines(const void *p, qa_sink_t &sink)
+{
+    static_assert(NL >= 1 && NL <= 4, "1..4 lines");
+    asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p));
+    if constexpr (NL > 1) asm volatile("global_load_dword %0, %1, off offset:128" : "+v"(sink) : "v"(p));
+    if constexpr (NL > 2) asm volatile("global_load_dword %0, %1, off offset:256" : "+v"(sink) : "v"(p));
+    if constexpr (NL > 3) asm volatile("global_load_dword %0, %1, off offset:384" : "+v"(sink) : "v"(p));
+}
+// the register stays allocated up to here (no instruction is emitted)
+__device__ __forceinline__ void qa_touch_done(qa_sink_t &sink) { asm volatile("" ::"v"(sink)); }
+
+// every prefetch workgroup touches EVERY line (its XCD's L2 is private); nobody waits for the loads -- the wave ends behind them (s_endpgm
+// waits for outstanding memory operations by itself)
 __device__ __forceinline__ void qa_pf_run(const QaPfList &L, unsigned nthreads)
 {
+    qa_sink_t sink = 0;
     for (int r = 0; r < L.n; ++r) {
         const char *p = reinterpret_cast<const char *>(L.ptr[r]);
         const uint32_t nb = L.bytes[r];
-        for (uint32_t off = threadIdx.x * 128u; off < nb; off += nthreads * 128u) {
-            uint32_t d;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p + off) : "memory");
-        }
-        if (threadIdx.x == 0 && nb >= 4) {                             // the last line of a range that does not start on a line boundary
-            uint32_t d;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p + ((nb - 4) & ~3u)) : "memory");
-        }
+        for (uint32_t off = threadIdx.x * 128u; off < nb; off += nthreads * 128u) qa_touch_lines<1>(p + off, sink);
+        if (threadIdx.x == 0 && nb >= 4) qa_touch_lines<1>(p + ((nb - 4) & ~3u), sink);      // the last line of a range that starts inside a line
     }
+    qa_touch_done(sink);
 }
 #endif

@@ -347,6 +347,15 @@ class LlamaDecoder(nn.Module):
         prev, yd, x = self.blocks_v3(x, pos, caches)
         return fused_head(prev, yd, x, self.norm, self.head_weight, logits, part_val, part_idx, pos_inc=pos)
 
+    def _operand_lists(self):
+        """per block: the step-independent operand tensors of the attention, o_proj and gate / up launches (quant.stage_operands), built once"""
+        pf = self.__dict__.get('_pf_lists')
+        if pf is None:
+            pf = [{"attn": attention_operands([b.q_proj, b.k_proj, b.v_proj]), "o": stage_operands([b.o_proj]),
+                   "gu": stage_operands([b.gate_proj, b.up_proj], prev=b.o_proj, ln=b.n2)} for b in self.blocks]
+            self.__dict__['_pf_lists'] = pf
+        return pf
+
     def blocks_v3(self, x, pos, caches):
         """per block, six launches: [U_down^T(prev) + residual -> RMSNorm -> V_qkv -> GEMM q,k,v] [U_qkv^T + rotary + attention]
         [V_o -> GEMM o] [U_o^T + residual -> RMSNorm -> V_gate/up -> GEMM gate, up] [U_gate^T, U_up^T (/) s: 688 x 16, decode_bigp.hip]
@@ -354,12 +363,17 @@ class LlamaDecoder(nn.Module):
         11008-wide operators are cut over the p index (csrc/decode_bigp.hip)"""
         h16 = torch.float16
         prev, yd = None, None
-        for blk, (kc, vc) in zip(self.blocks, caches):
+        pf = self._operand_lists() if OPERAND_PREFETCH else None
+        for bi, (blk, (kc, vc)) in enumerate(zip(self.blocks, caches)):
             qkv = [blk.q_proj, blk.k_proj, blk.v_proj]
+            if pf is not None:                                      # (the q / k / v launch is 192 workgroups: 64 CUs are free for the 8 extra ones)
+                ops.decode_prefetch_next(pf[bi]["attn"])
             if prev is None:
                 ys, _ = fused_stage(qkv, x=x, ln=blk.n1, y_dtype=h16)
             else:
                 ys, x = fused_stage(qkv, prev=prev, y_prev=yd, residual=x, ln=blk.n1, store=True, y_dtype=h16)
+            if pf is not None:                                      # the attention launch (32 workgroups): operands of o_proj and of gate / up
+                ops.decode_prefetch_next((pf[bi]["o"] + pf[bi]["gu"])[:40])
             o = fused_attention(qkv, ys, kc, vc, pos, self.cos, self.sin)
             yo = fused_stage([blk.o_proj], x=o, y_dtype=h16)[0][0]
             gu = [blk.gate_proj, blk.up_proj]

@@ -45,18 +45,26 @@ def main():
     L = int(np.median(lens))
     steps = [(c, b) for c, b in steps if b - c == L]
     seq = names[steps[-1][0]:steps[-1][1]]
-    per, off = 0, 0
-    for p_ in range(2, 80):                                             # the block's launch sequence: the shortest period that holds over the whole step
-        lo_, hi_ = 3, L - p_ - 4
-        if hi_ - lo_ < 2 * p_:
-            break
-        if all(seq[i] == seq[i + p_] for i in range(lo_, hi_)):
-            per = p_
+    per, off, run = 0, 0, 0
+    for p_ in range(2, 80):                                             # the block's launch sequence: the shortest period that holds over most of the step
+        best, cur, start, bstart = 0, 0, 0, 0
+        for i in range(L - p_):
+            if seq[i] == seq[i + p_]:
+                if cur == 0:
+                    start = i
+                cur += 1
+                if cur > best:
+                    best, bstart = cur, start
+            else:
+                cur = 0
+        if best >= 0.6 * L:
+            per, off, run = p_, bstart, best + p_
             break
     if not per:
         raise SystemExit(f"no periodic block structure found in a step of {L} launches: " + ", ".join(seq[:40]))
-    off = a.offset if a.offset >= 0 else (L - (L // per) * per + 1) // 2
-    nblk = (L - off) // per
+    if a.offset >= 0:
+        off = a.offset
+    nblk = run // per if a.offset < 0 else (L - off) // per
     dur = np.zeros((len(steps), nblk - 1, per))
     gap = np.zeros_like(dur)
     for si, (c, _) in enumerate(steps):
