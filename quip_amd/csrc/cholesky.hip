@@ -508,6 +508,20 @@ static int trailing_update(float *A, int64_t d, int64_t prow0, int nk, int64_t b
     return launch_syrk<1>(A, d, prow0, nk, base, false, s);
 }
 
+// ---- out-of-place entry: LT <- H (grid-stride, 16-byte pieces when both pointers allow) --------------------------------------------------
+__global__ __launch_bounds__(256) void chol_copy_kernel(const float *__restrict__ H, float *__restrict__ LT, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    if ((((uintptr_t)H | (uintptr_t)LT) & 15) == 0) {
+        const size_t n4 = n / 4;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+            reinterpret_cast<float4 *>(LT)[i] = reinterpret_cast<const float4 *>(H)[i];
+        for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) LT[i] = H[i];
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) LT[i] = H[i];
+    }
+}
+
 // ---- finish: LT[c][j] = U[c][j] * (1 / U[c][c]) for j > c, else 0, in place -------------------------------------------------
 __global__ __launch_bounds__(256) void chol_finish_kernel(float *A, int64_t d)
 {
@@ -565,9 +579,10 @@ extern "C" int quipamd_cholesky_lt(const float *H, float *LT, int64_t d, int *in
     QA_REQUIRE(H && LT && info, QUIPAMD_ERR_ARG, "cholesky_lt: null pointer");
     QA_REQUIRE(d <= (1 << 17), QUIPAMD_ERR_SHAPE, "cholesky_lt: d too large");
     hipStream_t s = (hipStream_t)stream;
-    if ((const void *)H != (const void *)LT &&
-        hipMemcpyAsync(LT, H, (size_t)d * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: copy failed");
+    // (round 6: the out-of-place copy is a kernel of this library, not a runtime copy: one runtime command less in front of a chain that
+    //  showed ONE transient non-finite result in ~6000 runs of a stress loop -- DESIGN.md section 4 -- and 5-10 us less per call)
+    if ((const void *)H != (const void *)LT)
+        chol_copy_kernel<<<(unsigned)((((size_t)d * d + 3) / 4 + 255) / 256 < 65535u * 16u ? (((size_t)d * d + 3) / 4 + 255) / 256 : 65535u * 16u), 256, 0, s>>>(H, LT, (size_t)d * d);
     if (hipMemsetAsync(info, 0, sizeof(int), s) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "cholesky_lt: memset failed");
     auto diag = [&](int64_t k0) {
         if (k0 + NB <= d) {

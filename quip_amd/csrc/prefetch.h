@@ -46,15 +46,19 @@ template <int NL> __device__ __forceinline__ void qa_touch_lines(const void *p, 
 __device__ __forceinline__ void qa_touch_done(qa_sink_t &sink) { asm volatile("" ::"v"(sink)); }
 
 // every prefetch workgroup touches EVERY line (its XCD's L2 is private); nobody waits for the loads -- the wave ends behind them (s_endpgm
-// waits for outstanding memory operations by itself)
+// waits for outstanding memory operations by itself).  The ranges are dealt to the WAVES (wave w: ranges w, w + nw, ...), a range's lines to the
+// lanes: 2-4 scalar round trips for the list entries per wave, then every touch in flight at once.  (First form: every wave walked all ranges,
+// one kernarg round trip each -- 33 ranges took a prefetch workgroup ~6 us, longer than the 3 us launch that carried it:
+// profiles/r06c_decode_ab.jsonl, OPT-1.3B 1190 -> 1099 tok/s.)
 __device__ __forceinline__ void qa_pf_run(const QaPfList &L, unsigned nthreads)
 {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, nw = (int)(nthreads >> 6);
     qa_sink_t sink = 0;
-    for (int r = 0; r < L.n; ++r) {
+    for (int r = wave; r < L.n; r += nw) {
         const char *p = reinterpret_cast<const char *>(L.ptr[r]);
         const uint32_t nb = L.bytes[r];
-        for (uint32_t off = threadIdx.x * 128u; off < nb; off += nthreads * 128u) qa_touch_lines<1>(p + off, sink);
-        if (threadIdx.x == 0 && nb >= 4) qa_touch_lines<1>(p + ((nb - 4) & ~3u), sink);      // the last line of a range that starts inside a line
+        for (uint32_t off = (uint32_t)lane * 128u; off < nb; off += 64u * 128u) qa_touch_lines<1>(p + off, sink);
+        if (lane == 0 && nb >= 4) qa_touch_lines<1>(p + ((nb - 4) & ~3u), sink);            // the last line of a range that starts inside a line
     }
     qa_touch_done(sink);
 }

@@ -54,8 +54,14 @@ def test_feedback_under_poison_and_load(d):
         assert err <= tol, f"d={d} it={it}: {err}"
         # the stages apart: K8 on the flipped Hessian, then the inverse into NaN-prefilled X / work
         _poison(d)
-        LT = ops.cholesky_lt(torch.flip(Hd, [0, 1]).contiguous())
-        assert bool(torch.isfinite(LT).all()), f"d={d} it={it}: K8 produced non-finite entries"
+        Hf = torch.flip(Hd, [0, 1]).contiguous()
+        LT = ops.cholesky_lt(Hf)
+        if not bool(torch.isfinite(LT).all()):                          # say where, and whether it repeats on the same input
+            w = torch.nonzero(~torch.isfinite(LT))
+            again = ops.cholesky_lt(Hf)
+            raise AssertionError(f"d={d} it={it}: K8 produced {w.shape[0]} non-finite entries, rows {int(w[:, 0].min())}..{int(w[:, 0].max())}, columns "
+                                 f"{int(w[:, 1].min())}..{int(w[:, 1].max())}, first {w[:6].tolist()}; input finite: {bool(torch.isfinite(Hf).all())}; the same "
+                                 f"call again: {int((~torch.isfinite(again)).sum())} non-finite entries")
         Xo = torch.full((d, d), float("nan"), device=DEV)
         work = torch.full((d, d), float("nan"), device=DEV)
         _lib.call("quipamd_unit_upper_inverse", ops._p(LT), ops._p(Xo), ops._p(work), d, ops._stream())
