@@ -122,6 +122,114 @@ __global__ __launch_bounds__(64 * NW) void dq_hg_kernel(K2GArgs G)
 #include "dq_h_body.inc"
 }
 
+// =====================================================================================================================
+// dq_hr_kernel (round 6): the one-pass kernel with the activations straight into REGISTERS.
+// profiles/r06_k2h_stamps.txt (in-situ stamps of dq_h_kernel, 4 x 4, cold): a wave needs 3800 clocks just to ISSUE its 4 weight loads and 32
+// LDS-DMA instructions (the CU's vector-memory queue fills), the last slab lands at 6150 -- 144 KiB through the LDS-DMA path at 24 B per
+// clock, against 64 B per clock the L1 returns to registers.  The B fragment of MFMA step t of k-chunk c is, per lane (batch row j, k group g),
+// 16 CONSECUTIVE bytes of row j of x: x[j][256 c + 32 t + 8 g .. + 8) -- row-major x as the caller hands it over needs no LDS hop and no
+// swizzle at all.  So: one address register pair per wave, 32 x global_load_dwordx4 with immediate offsets (a wave's 4 chunks are adjacent:
+// 2 KiB of every row), requested right behind the 4 weight tiles, each MFMA step behind `s_waitcnt vmcnt(31 - 8 i - t)` -- the asm-load
+// discipline of the weight tiles (form (ii); tests/test_k2_isa.py audits this kernel too).  LDS is the meet's only.
+// Exact fit only (d = 256 NW NCH), one row tile per workgroup, 2-bit; batch rows past bs re-read row bs - 1 (their columns are never stored).
+// =====================================================================================================================
+template <int BITS, class ACT, int NW, int NCH>
+__global__ __launch_bounds__(64 * NW) void dq_hr_kernel(K2Args A)
+{
+    typedef DeqT<BITS, ACT> Q;
+    constexpr int KC = Q::KC, NT = Q::NT;
+    static_assert(BITS == 2 && NT == 8 && KC == 256, "2-bit tiles: 256 columns, 8 MFMA steps");
+    static_assert(4 + NCH * NT <= 63, "vmcnt range");
+    constexpr int NLD = NCH * NT;                                        // x loads of a wave, behind its NCH weight loads
+    extern __shared__ __attribute__((aligned(16))) char smem[];         // [NW][1024 + 64]: the k-partials of the tile, then 16 row sums
+    const EpiArgs &e = A.e;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    K2_STAMP(0);
+    const int j = lane & 15, g = lane >> 4;
+    const uint32_t nkc = (uint32_t)(NW * NCH);
+    const uint32_t rt0 = blockIdx.x;
+    char *myreg = smem + wave * (1024 + 64);
+
+    float e_sc = 0.f, e_zr = 0.f, e_bi = 0.f;                             // reducer role q = wave: its epilogue parameters, requested now
+    {
+        const int64_t row = (int64_t)rt0 * 16 + (lane & 15);
+        e_sc = e.qfn == QUIPAMD_QFN_B ? e.scale[0] : e.scale[row];
+        if (e.qfn != QUIPAMD_QFN_B) e_zr = e.zero[row];
+        if (e.bias) e_bi = e.bias[row];
+    }
+    // ---- request everything: the weight tiles (HBM), then the B fragments (L2) -----------------------------------------------------
+    u32x4 w[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) load_w_nt(w[i], A.qw + ((uint64_t)rt0 * nkc + (uint32_t)(NCH * wave + i)) * 64 + lane);
+    const int jr = j < (int)e.bs ? j : (int)e.bs - 1;
+    const char *xb = reinterpret_cast<const char *>(A.x) + ((int64_t)jr * A.d + (int64_t)(NCH * wave) * KC + 8 * g) * 2;
+    u32x4 xf[NCH][NT];
+    static_for<NLD>([&](auto IT) {
+        constexpr int i = decltype(IT)::value / NT, t = decltype(IT)::value % NT;
+        u32x4 &dst = xf[i][t];                                            // (named outside the asm statement: a generic lambda captures nothing an
+        const char *src = xb;                                             //  asm operand alone mentions)
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(src), "n"((i * KC + 32 * t) * 2) : "memory");
+    });
+    K2_STAMP(1);
+    f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const u32x4 ones = {opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES), opaque(ACT::ONES)};
+    static_for<NLD>([&](auto IT) {
+        constexpr int i = decltype(IT)::value / NT, t = decltype(IT)::value % NT;
+        // memory returns in order: behind this wait the NCH weight tiles and the fragments up to (i, t) have landed
+        u32x4 &wi = w[i], &xi = xf[i][t];
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wi), "+v"(xi) : "n"(NLD - 1 - (i * NT + t)) : "memory");
+        if constexpr (i == 0 && t == 0) K2_STAMP(2);
+        if constexpr (i == NCH - 1 && t == NT - 1) K2_STAMP(3);
+        acc[t & 1] = ACT::mfma(Q::frag(wi, t), xi, acc[t & 1]);
+        accx[t & 1] = ACT::mfma(ones, xi, accx[t & 1]);                   // row sums of x on the matrix pipe: D[.][b] = sum_k x[b,k]
+    });
+    K2_STAMP(4);
+    // ---- meet: the NW k-partials of the tile (as dq_h_body.inc, one row tile) ----------------------------------------------------------
+    {
+        float *p = reinterpret_cast<float *>(myreg);
+        const f32x4_t a = acc[0] + acc[1];
+        p[lane] = a[0]; p[64 + lane] = a[1]; p[128 + lane] = a[2]; p[192 + lane] = a[3];
+        if (lane < 16) p[256 + lane] = accx[0][0] + accx[1][0];
+    }
+    K2_STAMP(5);
+    __syncthreads();
+    K2_STAMP(6);
+    asm volatile("" : "+v"(e_sc), "+v"(e_zr), "+v"(e_bi));
+#pragma unroll 1
+    for (int u = wave; u < 4; u += NW) {                                 // role u: batch rows 4u .. 4u + 3 x the 16 weight rows
+        const int b = 4 * u + (lane >> 4), wr = lane & 15;
+        const int src = (wr & 3) * 64 + b + 16 * (wr >> 2);
+        float a = 0.f, xsum = 0.f;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) {
+            const float *p = reinterpret_cast<const float *>(smem + v * (1024 + 64));
+            a += p[src];
+            xsum += p[256 + b];
+        }
+        const int64_t row = (int64_t)rt0 * 16 + wr;
+        if (b < e.bs) {
+            const float alpha = e.qfn == QUIPAMD_QFN_B ? e_sc * e.two_over_maxq : e_sc;
+            const float c0 = e.qfn == QUIPAMD_QFN_B ? Q::OFF + 0.5f * (float)e.maxq : Q::OFF + e_zr;
+            const float val = alpha * (a - c0 * xsum) + e_bi;
+            const int64_t o = (int64_t)b * e.m + row;
+            if (e.y_f32) ((float *)e.y)[o] = e.accumulate ? ((float *)e.y)[o] + val : val;
+            else ((uint16_t *)e.y)[o] = e.y_f16 ? f32_to_f16_bits(val) : f32_to_bf16_bits(val);
+        }
+    }
+    K2_STAMP(7);
+}
+
+template <int BITS, class ACT, int NW, int NCH>
+int launch_hr(const K2Args &A, hipStream_t s)
+{
+    static_assert(NW == 4, "four reducer roles, one per wave");
+    auto kern = dq_hr_kernel<BITS, ACT, NW, NCH>;
+    kern<<<dim3((unsigned)(A.e.m / 16)), 64 * NW, NW * (1024 + 64), s>>>(A);
+    QA_LAUNCH_CHECK("quipamd_dequant_gemm(hr)");
+    return QUIPAMD_OK;
+}
+
 template <int BITS, class ACT, int RT, int NW, int NCH, bool HALF, bool EXACT>
 int launch_h2(const K2Args &A, hipStream_t s)
 {

@@ -52,6 +52,11 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
                 if (p1 == 4 && p2 == 4) return launch_h<2, ACT, 2, 4, 4>(A, s);
             }
             if (rt == 4 && ntile % 4 == 0 && p1 == 4 && p2 == 4) return launch_h<2, ACT, 4, 4, 4>(A, s);
+            // round 6: x straight into registers (dq_hr_kernel), exact fit d = 4096 only.  p1 = 44 forces it, p1 = 4 keeps the LDS-DMA form
+            if (p1 == 44 && p2 == 4) {
+                QA_REQUIRE(nkc == 16, QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: the register-x form holds d = 4096 only (d=%lld)", (long long)d);
+                return launch_hr<2, ACT, 4, 4>(A, s);
+            }
             if (p1 == 8 && p2 == 1 && nkc <= 8) return launch_h<2, ACT, 1, 8, 1>(A, s);
             if (p1 == 8 && p2 == 2) return launch_h<2, ACT, 1, 8, 2>(A, s);
             if (p1 == 16 && p2 == 1 && nkc <= 16) return launch_h<2, ACT, 1, 16, 1>(A, s);

@@ -34,8 +34,10 @@ from .quant import (QuantLinear, make_quant, packed_forward_fused, fused_stage, 
                     fused_u_only, fused_head, fused_head_ok, fused_bigp_tail, bigp_tail_ok, packed_u_stage, stage_operands, attention_operands)
 
 MODES = ("plain", "fused", "v3", "v3_head")
-OPERAND_PREFETCH = True    # v3 launches carry 8 spare workgroups that pull the step-independent operands of a LATER launch of the block into every
-                           # XCD's L2 (csrc/prefetch.h; round 6: in a decode step they are cold once per token).  False: the round-5 launches
+OPERAND_PREFETCH = False   # True: v3 launches carry 8 spare workgroups that pull the step-independent operands of a LATER launch of the block into
+                           # every XCD's L2 (csrc/prefetch.h; in a decode step they are cold once per token).  Measured NEUTRAL (profiles/
+                           # r06f_decode_ab.jsonl, one box, alternating: OPT-1.3B 1183-1194 tok/s off, 1180-1191 on; Llama-2-7B 610-617 / 618-620;
+                           # 4 sequences -2 %): what the warm operands save the consuming launch, the extra workgroups cost the hosting one.  Off.
 
 
 # ------------------------------------------------------------------------------------------------ packed layers out of a driver run

@@ -255,3 +255,26 @@ def test_grouped_weight_stream_kernel(ops, O, form, m, groups, bs):
         got = outs[g].cpu().numpy().astype(np.float64)
         assert np.isfinite(got).all(), (form, g)
         assert _rel(got[:, rows], refs[g]) <= TOL_F32, (form, g)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("qfn", ["b", "a"])
+@pytest.mark.parametrize("m,bs", [(4096, 16), (4096, 1), (176, 11), (2048, 8), (16, 5)])
+def test_register_x_kernel(ops, O, dt, qfn, m, bs):
+    """round 6: dq_hr_kernel (family h, p1 = 44) -- the B fragments as 16-byte global loads into registers behind counted waits, no LDS
+    staging of x -- at its only K (d = 4096), every batch size (rows past bs re-read row bs - 1), fp32 and 16-bit outputs, bias, qfn a / b,
+    and one-hot weights (a wrong k order inside a chunk or between a wave's chunks cannot pass)."""
+    cfg = (FAM_H, 44, 4)
+    _run(ops, O, m, 4096, bs, 2, qfn, dt, cfg, seed=m + bs)
+    if m == 176:
+        rng = np.random.default_rng(9)
+        d = 4096
+        codes = np.zeros((m, d), dtype=np.uint8)
+        perm = rng.permutation(d)[:m]
+        codes[np.arange(m), perm] = 3
+        xt, x = _round16(rng.standard_normal((bs, d)).astype(np.float32), dt)
+        qs = ops.pack(torch.from_numpy(codes).to(DEV), 2, ops.LAYOUT_STREAM)
+        sc = torch.tensor([1.0])
+        y = ops.dequant_gemm(xt.to(DEV), qs, 2, "b", sc, None, None, out_dtype=torch.float32, cfg=cfg).cpu().numpy().astype(np.float64)
+        want = O.dequant_linear(x, codes, "b", np.float32(1.0), None, 3, None)
+        assert _rel(y, want) <= TOL_F32

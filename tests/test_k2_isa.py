@@ -58,11 +58,13 @@ def _h_kernels(asm):
     picked by blockIdx.y)"""
     yield from _functions(asm, "dq_h_kernel")
     yield from _functions(asm, "dq_hg_kernel")
+    yield from _functions(asm, "dq_hr_kernel")       # round 6: x as asm loads into registers too (32 per wave behind the 4 weight tiles)
 
 
 def test_h_kernel_asm_loads_are_not_touched_before_their_wait(asm):
     n = 0
     assert sum(1 for _ in _functions(asm, "dq_hg_kernel")) >= 4, "no dq_hg_kernel instantiations found"
+    assert sum(1 for _ in _functions(asm, "dq_hr_kernel")) >= 2, "no dq_hr_kernel instantiations found"
     for name, body in _h_kernels(asm):
         n += 1
         queue = []          # outstanding vector-memory operations, oldest first: (dest registers of an asm load | empty set)
