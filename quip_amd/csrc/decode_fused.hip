@@ -28,6 +28,13 @@
 #include "probe.h"
 #include "prefetch.h"
 
+// A/B builds (python __graft_entry__.py --variant noshf -DQA_NO_SHF): round 5's per-wave fragment loads
+#ifdef QA_NO_SHF
+#define QA_SHF 0
+#else
+#define QA_SHF 1
+#endif
+
 namespace {
 
 constexpr int FG_MAXG = 3, FG_MAXBS = 4, FG_NW = 16;
@@ -146,6 +153,17 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     float *park = reinterpret_cast<float *>(pass);                              // [NS][RT PB][4][64]: after the last pass
     constexpr size_t PARK_B = (size_t)(FG_NW * PB * 256) * 4;
     float *red = reinterpret_cast<float *>(pass + (D::BYTES > PARK_B ? D::BYTES : PARK_B));            // [2][16] norm, [bs][16] sum x~, [bs][16] sum OFF x~
+    // Round 6: the factor fragments of both operators are SHARED through LDS (p <= 64).  Rounds 3-5: every wave that owns tiles pulled its
+    // own copy from global memory -- 64 x 64: 16 waves x 4 KiB per operator for 16 KiB of distinct fragments, 128 of the 288 KiB a workgroup of
+    // Llama's q / k / v launch drags through its CU's one vector-memory path (in-situ stamps, profiles/r06_decode_stamps.txt: the waves finish
+    // ISSUING their requests at 2100 / 4000 / 5400 / 7500 clocks, four at a time -- the launch is bound by that queue).  Now thread t loads piece
+    // entry t of an operator ONCE (F0 and F1 are piece-major [tile][k-step][lane] uint4, exactly the LDS image), the fragments reach LDS with
+    // the scatter in front of the pass that needs them, and a wave reads the pieces of its tiles from there (as fused_pair_kernel does at 128 x 64).
+    constexpr bool SHF = P <= 64 && QA_SHF;
+    constexpr int NF0 = (P / 16) * D::S0, NF1 = (Q / 16) * D::S1, NFR = NF0 + NF1;      // 1 KiB pieces per operator
+    static_assert(!SHF || NFR * 64 <= 1024, "one fragment entry per thread");
+    uint4 *FRU = reinterpret_cast<uint4 *>(red + (2 + 2 * FG_MAXBS) * FG_NW + 16);                       // [NFR][64] uint4 (SHF)
+    uint4 *FRV = FRU + NFR * 64;
     const typename DQ::Consts qc = DQ::make_consts();
 
     if (G.pf.n > 0 && (int)blockIdx.x >= G.pf.first) {                          // a prefetch workgroup (uniform): touch the lines, leave
@@ -206,9 +224,28 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
             return yc[u];
         }
     };
+    uint4 shU = make_uint4(0u, 0u, 0u, 0u), shV = shU;                           // SHF: this thread's entry of U's / V's fragment pieces
+    auto load_shared = [&](const Fop &op) {
+        const int e_ = tid < NFR * 64 ? tid : 0;                                  // (clamped address + select below: no branch around the load)
+        const uint4 *src = e_ < NF0 * 64 ? reinterpret_cast<const uint4 *>(op.F0) + e_ : reinterpret_cast<const uint4 *>(op.F1) + (e_ - NF0 * 64);
+        return *src;
+    };
+    auto frags_from_lds = [&](const uint4 *FR, PassFrags<P, Q> &fr) {
+        if (wave < D::NT) {
+            const int at = wave % (P / 16), bt = wave % (Q / 16);
+#pragma unroll
+            for (int S = 0; S < D::S0; ++S) fr.f0[S] = FR[(at * D::S0 + S) * 64 + lane];
+#pragma unroll
+            for (int S = 0; S < D::S1; ++S) fr.f1[S] = FR[(NF0 + bt * D::S1 + S) * 64 + lane];
+        }
+    };
     auto load_u_frags = [&]() {
-        load_f0<P, Q>(G.U, wave, lane, frU);
-        load_f1<P, Q>(G.U, wave, lane, frU);
+        if constexpr (SHF) {
+            shU = load_shared(G.U);
+        } else {
+            load_f0<P, Q>(G.U, wave, lane, frU);
+            load_f1<P, Q>(G.U, wave, lane, frU);
+        }
     };
     auto load_u_side = [&](int b) {
 #pragma unroll
@@ -223,8 +260,12 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         }
     };
     auto load_v_frags = [&]() {
-        load_f0<P, Q>(V, wave, lane, frV);
-        load_f1<P, Q>(V, wave, lane, frV);
+        if constexpr (SHF) {
+            shV = load_shared(V);
+        } else {
+            load_f0<P, Q>(V, wave, lane, frV);
+            load_f1<P, Q>(V, wave, lane, frV);
+        }
     };
     auto load_v_side = [&]() {
 #pragma unroll
@@ -293,9 +334,13 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                 load_u_side(b);
                 load_v_side();
             }
+            if constexpr (SHF) {
+                if (b == b_lo && tid < NFR * 64) FRU[tid] = shU;                 // (once per launch: the region is nobody else's)
+            }
             FG_STAMP(1);                                                         // first loads landed, scatter done
             __syncthreads();
             FG_STAMP(2);
+            if constexpr (SHF) frags_from_lds(FRU, frU);
             mix_stages<P, Q>(ZT, Z1, ZF, frU, wave, lane);
             if (!EARLY) load_v_frags();                                         // ... and its fragments under the gather (registers)
             FG_STAMP(3);
@@ -386,9 +431,13 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
                 scatter4<P, Q>(ZT, v, vld[u]);
             }
         }
+        if constexpr (SHF) {
+            if (b == b_lo && tid < NFR * 64) FRV[tid] = shV;
+        }
         FG_STAMP(7);
         __syncthreads();
         FG_STAMP(8);
+        if constexpr (SHF) frags_from_lds(FRV, frV);
         mix_stage1<P, Q>(ZT, Z1, frV, wave, lane);
         FG_STAMP(9);
         __syncthreads();
@@ -679,7 +728,8 @@ template <int P, int Q, int NRT> constexpr size_t fused_lds()
 {
     typedef PassDims<P, Q> D;
     const size_t parkb = (size_t)(FG_NW * (NRT < 4 ? NRT : 4) * 256) * 4;
-    return (size_t)FG_MAXBS * (D::N + 8) * 2 + (D::BYTES > parkb ? D::BYTES : parkb) + (2 + 2 * FG_MAXBS) * FG_NW * 4 + 64;
+    const size_t frags = (P <= 64 && QA_SHF) ? (size_t)2 * ((P / 16) * D::S0 + (Q / 16) * D::S1) * 1024 : 0;          // shared fragment pieces of U and V (round 6)
+    return (size_t)FG_MAXBS * (D::N + 8) * 2 + (D::BYTES > parkb ? D::BYTES : parkb) + (2 + 2 * FG_MAXBS) * FG_NW * 4 + 64 + frags + 64;
 }
 
 thread_local float g_fused_maxq = 3.f;      // set by the entry point right before the dispatch (same thread): 3, 7 (3-bit codes in the 4-bit container) or 15

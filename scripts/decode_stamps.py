@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--block", type=int, default=-1, help="the block whose launches are printed (default: the middle one)")
     ap.add_argument("--position", type=int, default=96, help="tokens decoded before the stamped step")
     ap.add_argument("--clock-ghz", type=float, default=2.4)
+    ap.add_argument("--per-wave", action="store_true", help="print every wave's clock for every slot (who is late)")
     a = ap.parse_args()
     if not os.path.exists(PROBE):
         raise SystemExit(f"{PROBE} missing: python __graft_entry__.py --probe")
@@ -124,6 +125,8 @@ def main():
             nm = names[i] if i < len(names) else f"slot {i}"
             print(f"    {i:2d} {nm:<52} {lo:7d} .. {hi:7d}   (+{hi - prev:6d} on the last wave)")
             prev = hi
+            if a.per_wave:
+                print("         waves: " + " ".join(f"{int(v) - t0:6d}" if v > 0 else "     -" for v in st[:, i]))
 
 
 if __name__ == "__main__":

@@ -103,7 +103,24 @@ __global__ __launch_bounds__(64 * NW) void ingest2_kernel(const uint16_t *x, uns
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
         kcs[i] = mode == 1 ? ((i * NW + wave) ^ ((mul * cu) & 15)) : mode == 2 ? ((2 * wave + i + mul * cu) & 15) : ((i * NW + wave + mul * cu) & 15);
-    if (mode == 3) {
+    if (mode == 4 || mode == 6) {
+        // round 6: the FOOTPRINT of one DMA instruction.  Rounds 2-5: 8 rows x 128 B (eight lines 8 KiB apart).  Here: 2 rows x 512 B -- lanes
+        // 0..31 walk 512 contiguous bytes of row 2 q, lanes 32..63 of row 2 q + 1 (two runs of four consecutive lines); chunks adjacent (mode 2's order)
+        const uint32_t vw = (uint32_t)(lane >> 5) * ROWB + ((uint32_t)(lane & 31) << 4);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int kc = (2 * wave + i + (mode == 6 ? mul * cu : 0)) & 15;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(myreg + i * SLAB + q * 1024), 16, vw + (uint32_t)(2 * q) * ROWB, kc * (KC * 2), 0, 0);
+        }
+    } else if (mode == 5) {
+        // ... and 1 row x 1 KiB: the wave's two adjacent chunks of ONE row per instruction (eight consecutive lines), 16 instructions
+        const uint32_t vr = (uint32_t)lane << 4;
+#pragma unroll
+        for (int n = 0; n < 16; ++n)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t *)(myreg + n * 1024), 16, vr + (uint32_t)n * ROWB, ((2 * wave) & 15) * (KC * 2), 0, 0);
+    } else if (mode == 3) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
 #pragma unroll
@@ -202,10 +219,8 @@ int main()
     CK(hipMalloc(&x, xbytes)); CK(hipMemset(x, 0x11, xbytes));
     CK(hipMalloc(&stamps, (size_t)256 * NW * 2 * 8)); CK(hipMalloc(&sink, 64));
     run<V_NULL>(x, stamps, sink, st);
-    for (int rep = 0; rep < 2; ++rep) {
-        run<V_DMA>(x, stamps, sink, st); run<V_DMA_ROT>(x, stamps, sink, st); run<V_DMA_ROT2>(x, stamps, sink, st);
-        run<V_REG>(x, stamps, sink, st); run<V_REG_ROT>(x, stamps, sink, st); run<V_HALF>(x, stamps, sink, st);
-        run<V_XCD>(x, stamps, sink, st); run<V_OWN>(x, stamps, sink, st);
+    for (int rep = 0; rep < 1; ++rep) {
+        run<V_DMA>(x, stamps, sink, st); run<V_REG>(x, stamps, sink, st); run<V_HALF>(x, stamps, sink, st);
     }
     printf("-- run-time patterns (mode, multiplier of the workgroup's index in its XCD)\n");
     for (int rep = 0; rep < 2; ++rep) {
@@ -215,6 +230,8 @@ int main()
         run2("xor x1", 1, 1, x, stamps, sink, st); run2("xor x5", 1, 5, x, stamps, sink, st);
         run2("adjacent x1", 2, 1, x, stamps, sink, st); run2("adjacent x2", 2, 2, x, stamps, sink, st); run2("adjacent x0", 2, 0, x, stamps, sink, st);
         run2("interleaved x1", 3, 1, x, stamps, sink, st); run2("interleaved x0", 3, 0, x, stamps, sink, st);
+        run2("2 rows x 512 B, adjacent", 4, 0, x, stamps, sink, st); run2("2 rows x 512 B, adj, rot", 6, 1, x, stamps, sink, st);
+        run2("1 row x 1 KiB, adjacent", 5, 0, x, stamps, sink, st);
     }
     return 0;
 }
