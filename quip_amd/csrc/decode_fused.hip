@@ -159,7 +159,11 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     // ISSUING their requests at 2100 / 4000 / 5400 / 7500 clocks, four at a time -- the launch is bound by that queue).  Now thread t loads piece
     // entry t of an operator ONCE (F0 and F1 are piece-major [tile][k-step][lane] uint4, exactly the LDS image), the fragments reach LDS with
     // the scatter in front of the pass that needs them, and a wave reads the pieces of its tiles from there (as fused_pair_kernel does at 128 x 64).
-    constexpr bool SHF = P <= 64 && QA_SHF;
+    // Measured (profiles/r06h_decode_ab_shared_fragments.jsonl, in-situ stamps r06h vs r06c): in the fused launches (<= 4 rows) the shared copy
+    // is NEUTRAL to slightly negative -- the first barrier now waits for a fragment entry that is cold (OPT q / k / v launch: first barrier 3990
+    // instead of 2970 clocks, the pass behind it 790 instead of 970; whole launch 11771 vs 11533; tok/s equal) -- and in the prologue-only launches
+    // of a 5..16-row step it pays (Llama-2-7B, 16 sequences: 3.03 -> 2.99 ms).  So: the OPS launches only.
+    constexpr bool SHF = P <= 64 && OPS && QA_SHF;
     constexpr int NF0 = (P / 16) * D::S0, NF1 = (Q / 16) * D::S1, NFR = NF0 + NF1;      // 1 KiB pieces per operator
     static_assert(!SHF || NFR * 64 <= 1024, "one fragment entry per thread");
     uint4 *FRU = reinterpret_cast<uint4 *>(red + (2 + 2 * FG_MAXBS) * FG_NW + 16);                       // [NFR][64] uint4 (SHF)
@@ -724,11 +728,11 @@ template <int P, int Q, int BITS> int launch_pair(const FusedArgs &A, float maxq
     return QUIPAMD_OK;
 }
 
-template <int P, int Q, int NRT> constexpr size_t fused_lds()
+template <int P, int Q, int NRT, bool OPS = false> constexpr size_t fused_lds()
 {
     typedef PassDims<P, Q> D;
     const size_t parkb = (size_t)(FG_NW * (NRT < 4 ? NRT : 4) * 256) * 4;
-    const size_t frags = (P <= 64 && QA_SHF) ? (size_t)2 * ((P / 16) * D::S0 + (Q / 16) * D::S1) * 1024 : 0;          // shared fragment pieces of U and V (round 6)
+    const size_t frags = (P <= 64 && OPS && QA_SHF) ? (size_t)2 * ((P / 16) * D::S0 + (Q / 16) * D::S1) * 1024 : 0;          // shared fragment pieces of U and V (round 6)
     return (size_t)FG_MAXBS * (D::N + 8) * 2 + (D::BYTES > parkb ? D::BYTES : parkb) + (2 + 2 * FG_MAXBS) * FG_NW * 4 + 64 + frags + 64;
 }
 
@@ -737,7 +741,7 @@ thread_local float g_fused_maxq = 3.f;      // set by the entry point right befo
 template <int P, int Q, bool HAS_U, bool HAS_RES, int NORM, int RT, int CPW, int NRT, bool YF32 = false, int BITS = 2, bool OPS = false>
 int launch_fused(const FusedArgs &A, int ngroups, hipStream_t s)
 {
-    const size_t lds = fused_lds<P, Q, NRT>();
+    const size_t lds = fused_lds<P, Q, NRT, OPS>();
     auto kern = fused_gemm_kernel<P, Q, HAS_U, HAS_RES, NORM, RT, CPW, NRT, YF32, BITS, OPS>;
     static QaPerDevice attr;
     const int d = attr.dev();
