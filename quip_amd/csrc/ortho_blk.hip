@@ -84,6 +84,36 @@ template <> __device__ __forceinline__ void bk_load8<BF16>(const void *p, int64_
     for (int k = 0; k < 8; ++k) v[k] = bf16_bits_to_f32((uint16_t)(w[k >> 1] >> (16 * (k & 1))));
 }
 
+// the same eight elements as the load delivers them: requested at the top of a launch, unpacked where they are consumed (an unpack at the
+// point of the load would put the wait there)
+template <class T> __device__ __forceinline__ float bk_bits_to_f32(uint16_t h);
+template <> __device__ __forceinline__ float bk_bits_to_f32<F16>(uint16_t h) { return f16_bits_to_f32(h); }
+template <> __device__ __forceinline__ float bk_bits_to_f32<BF16>(uint16_t h) { return bf16_bits_to_f32(h); }
+template <class T> struct Raw8 {
+    uint4 a;
+    __device__ __forceinline__ void load(const void *p, int64_t i) { a = *reinterpret_cast<const uint4 *>((const uint16_t *)p + i); }
+    __device__ __forceinline__ void unpack(float (&v)[8]) const
+    {
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = bk_bits_to_f32<T>((uint16_t)(w[k >> 1] >> (16 * (k & 1))));
+    }
+};
+template <> struct Raw8<F32> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const void *p, int64_t i)
+    {
+        a = *reinterpret_cast<const float4 *>((const float *)p + i);
+        b = *reinterpret_cast<const float4 *>((const float *)p + i + 4);
+    }
+    __device__ __forceinline__ void unpack(float (&v)[8]) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
+};
+
+// a / d for 0 <= a < 2^22 with rcp = 1.0f / d: exact (the product is off by less than a 2^-23 < 0.5 / d ... relative to the next integer, and
+// a + 0.5 sits 0.5 / d away from both).  An integer division by a run-time divisor is ~50 instructions per wave; the fused prologue had
+// a dozen of them between its loads.
+__device__ __forceinline__ int bk_div(int a, float rcp) { return (int)(((float)a + 0.5f) * rcp); }
+
 constexpr int BK_MAXOPS = 3;                                          // operators of one launch (q / k / v, gate / up): blockIdx.y
 struct BlkStages {
     BlkStage s[BK_MAXOPS];
@@ -96,7 +126,10 @@ struct BlkStages {
 //     second stage mixes b (block a = g):   in2[b'] = sum_j F1[b'][g][j] x[j q + b']            (first stage = mix a, F1 [q][p][p])
 // n MACs and n factor values per workgroup and row: the first stage's factors are read (q / 16) or (p / 16) times in total instead of once,
 // and the all-to-all between the stages -- a launch boundary plus a round trip through memory -- is gone.
-template <class IN, class OUT, bool FUSED = false>
+// MAXI (FUSED): first-stage factor chunks a thread keeps in registers = ceil(n / 8 / 256): 1 up to n = 2048 (the default bound of the
+// one-launch form), 8 up to 16384.  One instantiation for all n unrolled eight copies of the partial-product code (4000 lines of ISA),
+// seven of which a launch at n = 2048 jumped over, one cold instruction-cache line each.
+template <class IN, class OUT, bool FUSED = false, int MAXI = 8>
 __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
 {
     const BlkStage &S = SS.s[blockIdx.y];
@@ -120,20 +153,45 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
     const int R = S.rows - gr0 < BK_MAXR ? S.rows - gr0 : BK_MAXR;
     QA_STAMP(0);
 
-    // ---- the factor fragments of this wave's k-steps: requested first (the only HBM traffic of the launch) -------------------------
+    const bool has_gu = S.gate_up != nullptr, has_cs = S.colscale != nullptr;
+    const void *gup = has_gu ? S.gate_up : S.in;
+    // ---- FUSED: the input rows and the permutation are what the first barrier waits for: requested FIRST (loads return in order; they used
+    // to sit behind 18 cold factor / gain loads, the permutation behind a wait for all of those: two to three HBM round trips in series in
+    // front of the first barrier -- "rows + permutation staged" 5400 clocks into the launch, profiles/r06_decode_stamps.txt) ------------
+    const int n8 = n >> 3, n4 = n >> 2;
+    const float rn8 = 1.0f / (float)n8;
+    Raw8<IN> rw_v, rw_u;
+    int4 ix_p[2];
+    if constexpr (FUSED) {
+        const int ec = tid < R * n8 ? tid : 0;
+        const int r = bk_div(ec, rn8), c8 = ec - r * n8;
+        const int64_t at = (int64_t)(gr0 + r) * S.ld_in + 8 * c8;
+        rw_v.load(S.in, at);
+        rw_u.load(gup, at);                                            // (no gate: the same line again)
+        const int4 *ip = reinterpret_cast<const int4 *>(S.in_idx ? S.in_idx : reinterpret_cast<const int32_t *>(S.F));
+        ix_p[0] = ip[S.in_idx && tid < n4 ? tid : 0];
+        ix_p[1] = ip[S.in_idx && tid + BK_T < n4 ? tid + BK_T : 0];
+    }
+
+    // ---- the factor fragments of this wave's k-steps (the only HBM traffic of an unfused launch: requested first there; FUSED launches
+    // request them LAST of their up-front loads -- the MFMAs that consume them are the launch's last phase) -----------------------------
     const int nk = (P + 31) / 32;                                     // k-steps of 32; the last one may be half (P % 32 == 16)
     const int i = lane & 15, g4 = lane >> 4;
     const uint16_t *Frow = S.F + ((int64_t)g * P + (tile * 16 + i)) * P + 8 * g4;
     constexpr int MAXS = 6;                                           // k-steps per wave held in registers: P <= 768
     uint4 af[MAXS];
+    auto load_af = [&]() {
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) {
-        const int ks = wave + 4 * s;
-        const bool ok = ks < nk && ks * 32 + 8 * g4 < P;
-        const int ksc = ok ? ks : 0;                                   // clamped address + select: every load unconditional, all in flight
-        const uint4 v = *reinterpret_cast<const uint4 *>(Frow + (ok ? ksc * 32 : -8 * g4));
-        af[s] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
-    }
+        for (int s = 0; s < MAXS; ++s) {
+            const int ks = wave + 4 * s;
+            const bool ok = ks < nk && ks * 32 + 8 * g4 < P;
+            // clamped address, every load unconditional and all in flight.  What a clamped load delivers is never multiplied into a result: a
+            // k-step past nk is skipped, a quarter past P meets a zero B fragment (finite factor values x 0).  (A select to zero here made hipcc
+            // branch around the loads, with a vmcnt(0) and a register copy inside one of the branches.)
+            af[s] = *reinterpret_cast<const uint4 *>(Frow + (ok ? ks * 32 : -8 * g4));
+        }
+    };
+    if constexpr (!FUSED) load_af();
 
     // ---- everything else this workgroup will read from memory is requested NOW, before the statistics and the MFMAs: the launch is a chain
     // of dependent round trips (index -> value; index -> bias / residual), and requested early they travel under each other --------------
@@ -142,18 +200,24 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
     //     round trip of its own)
     constexpr int NPF = 3;
     const int RP = R * P;
-    const bool has_gu = S.gate_up != nullptr, has_cs = S.colscale != nullptr;
-    const void *gup = has_gu ? S.gate_up : S.in;
     const uint16_t *gmp = S.norm ? S.gamma : S.F, *btp = S.norm == 1 ? S.beta : S.F;
     const float *csp = has_cs ? S.colscale : reinterpret_cast<const float *>(S.F);
     float pv[NPF], pu[NPF], pc[NPF];
     uint16_t pg[NPF], pb[NPF];
+    // every index first, then every value: written as one loop, hipcc waited for index c (vmcnt(0): and for the values of c - 1) before it
+    // requested index c + 1 -- NPF index round trips in series in front of the values
+    int psrc[NPF], prow[NPF];
 #pragma unroll
     for (int c = 0; c < (FUSED ? 0 : NPF); ++c) {
         const int e = tid + BK_T * c, ec = e < RP ? e : 0;
         const int r = ec / P, k = ec - r * P;
         const int pos = S.mix_a ? k * q + g : g * q + k;
-        const int src = S.in_idx ? S.in_idx[pos] : pos;
+        prow[c] = r;
+        psrc[c] = S.in_idx ? S.in_idx[pos] : pos;
+    }
+#pragma unroll
+    for (int c = 0; c < (FUSED ? 0 : NPF); ++c) {
+        const int src = psrc[c], r = prow[c];
         pv[c] = DT<IN>::load(S.in, (int64_t)(gr0 + r) * S.ld_in + src);
         pu[c] = DT<IN>::load(gup, (int64_t)(gr0 + r) * S.ld_in + src);
         pg[c] = gmp[S.norm ? src : 0];
@@ -162,11 +226,13 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
     }
     // (b) wave 0 finishes the tile: where its four results per lane go, and the bias / residual that go with them
     int tdst[4];
-    float tbias[4], tres[4];
+    float tbias[4];
+    uint32_t tres_raw[4];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         tdst[reg] = 0;
-        tbias[reg] = tres[reg] = 0.f;
+        tbias[reg] = 0.f;
+        tres_raw[reg] = 0u;                                            // (+0 in each of the three dtypes)
     }
     if (wave == 0 && (lane & 15) < R) {
 #pragma unroll
@@ -183,13 +249,14 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
 #define BK_FETCH_TAIL()                                                                                                                       \
     if (wave == 0 && (lane & 15) < R) {                                                                                                       \
         const int r_ = lane & 15;                                                                                                             \
-        _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                                                 \
-            if (S.bias) tbias[reg] = S.bias[tdst[reg]];                                                                                       \
-            if (S.residual) {                                                                                                                 \
-                const int64_t ri = (int64_t)(gr0 + r_) * S.ld_res + tdst[reg];                                                                \
-                tres[reg] = S.res_dtype == QUIPAMD_F32   ? ((const float *)S.residual)[ri]                                                   \
-                            : S.res_dtype == QUIPAMD_F16 ? f16_bits_to_f32(((const uint16_t *)S.residual)[ri])                               \
-                                                         : bf16_bits_to_f32(((const uint16_t *)S.residual)[ri]);                              \
+        if (S.bias) {                                                                                                                         \
+            _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) tbias[reg] = S.bias[tdst[reg]];                                               \
+        }                                                                                                                                     \
+        if (S.residual) {               /* as loaded; converted where it is added (a conversion here is a wait per element) */                \
+            if (S.res_dtype == QUIPAMD_F32) {                                                                                                 \
+                _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) tres_raw[reg] = ((const uint32_t *)S.residual)[(int64_t)(gr0 + r_) * S.ld_res + tdst[reg]]; \
+            } else {                                                                                                                          \
+                _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) tres_raw[reg] = ((const uint16_t *)S.residual)[(int64_t)(gr0 + r_) * S.ld_res + tdst[reg]]; \
             }                                                                                                                                 \
         }                                                                                                                                     \
     }
@@ -251,17 +318,16 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         // instead of a round trip through L2), the permutation itself as 16-bit entries.  (The first form of this prologue gathered from
         // memory -- index, then value, n / 256 times in sequence -- and walked its dot products 16 at a time: 14-55 us per launch.)
         float *XIN = stat + 2 * BK_MAXR;                                 // [R][n] fp32: the pre-processed input rows, natural order
-        const int n8 = n >> 3;
         float *PART = XIN + R * n;                                       // [R][n / 8]: partial dot products, one per factor chunk
         uint16_t *IDX = reinterpret_cast<uint16_t *>(PART + R * n8);    // [n]: image position -> source column
         const int P1 = S.mix_a ? q : S.p;                               // length of the first stage's dot products
         const int C = P1 >> 3;                                           // 16-byte chunks per factor row; P C = n / 8 work items
-        constexpr int MAXI = 8;                                          // items per thread held in registers: n <= 16384
-        uint4 fi[MAXI];
+        const float rC = 1.0f / (float)C;
+        uint4 fi[MAXI];                                                  // items per thread held in registers: n <= 2048 MAXI
 #pragma unroll
         for (int c = 0; c < MAXI; ++c) {
             const int w = tid + BK_T * c, wc = w < n8 ? w : 0;
-            const int k = wc / C, ch = wc - k * C;
+            const int k = bk_div(wc, rC), ch = wc - k * C;
             fi[c] = *reinterpret_cast<const uint4 *>(S.F1 + ((int64_t)k * P1 + g) * P1 + 8 * ch);
         }
         // Round 6: the gains, the LayerNorm bias and the column scale of this thread's first column chunk are requested HERE too.  They used to be
@@ -271,26 +337,40 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         const uint4 gm_p = *reinterpret_cast<const uint4 *>(gmp + (S.norm ? 8 * c8p : 0));
         const uint4 bt_p = *reinterpret_cast<const uint4 *>(btp + (S.norm == 1 ? 8 * c8p : 0));
         const float4 csa_p = *reinterpret_cast<const float4 *>(csp + (has_cs ? 8 * c8p : 0)), csb_p = *reinterpret_cast<const float4 *>(csp + (has_cs ? 8 * c8p + 4 : 0));
-#pragma unroll 2
-        for (int e8 = tid; e8 < R * n8; e8 += BK_T) {
-            const int r = e8 / n8, c8 = e8 - r * n8;
+        load_af();
+        // the rows (silu(gate) * up applied) as fp32 and the permutation as 16-bit entries into LDS: each thread's first chunk is the one it
+        // requested at the top of the launch
+        auto stage_row = [&](int e8, const Raw8<IN> &rv, const Raw8<IN> &ru) {
+            const int r = bk_div(e8, rn8), c8 = e8 - r * n8;
             float v[8], u[8];
-            bk_load8<IN>(S.in, (int64_t)(gr0 + r) * S.ld_in + 8 * c8, v);
+            rv.unpack(v);
             if (has_gu) {
-                bk_load8<IN>(gup, (int64_t)(gr0 + r) * S.ld_in + 8 * c8, u);
+                ru.unpack(u);
 #pragma unroll
                 for (int i8 = 0; i8 < 8; ++i8) v[i8] = DT<IN>::rnd(DT<IN>::rnd(v[i8] / (1.0f + __expf(-v[i8]))) * u[i8]);
             }
             float4 *dst = reinterpret_cast<float4 *>(XIN + r * n + 8 * c8);
             dst[0] = make_float4(v[0], v[1], v[2], v[3]);
             dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+        };
+        auto stage_idx = [&](int e4, const int4 ix) {
+            *reinterpret_cast<uint2 *>(IDX + 4 * e4) = make_uint2((uint32_t)ix.x | ((uint32_t)ix.y << 16), (uint32_t)ix.z | ((uint32_t)ix.w << 16));
+        };
+        if (tid < R * n8) stage_row(tid, rw_v, rw_u);
+        if (S.in_idx) {
+            if (tid < n4) stage_idx(tid, ix_p[0]);
+            if (tid + BK_T < n4) stage_idx(tid + BK_T, ix_p[1]);
+        }
+        for (int e8 = tid + BK_T; e8 < R * n8; e8 += BK_T) {             // more rows / wider operators: the rest from memory, as before
+            const int r = bk_div(e8, rn8), c8 = e8 - r * n8;
+            Raw8<IN> rv, ru;
+            rv.load(S.in, (int64_t)(gr0 + r) * S.ld_in + 8 * c8);
+            ru.load(gup, (int64_t)(gr0 + r) * S.ld_in + 8 * c8);
+            stage_row(e8, rv, ru);
         }
         if (S.in_idx) {
 #pragma unroll 2
-            for (int e4 = tid; e4 < (n >> 2); e4 += BK_T) {
-                const int4 ix = reinterpret_cast<const int4 *>(S.in_idx)[e4];
-                *reinterpret_cast<uint2 *>(IDX + 4 * e4) = make_uint2((uint32_t)ix.x | ((uint32_t)ix.y << 16), (uint32_t)ix.z | ((uint32_t)ix.w << 16));
-            }
+            for (int e4 = tid + 2 * BK_T; e4 < n4; e4 += BK_T) stage_idx(e4, reinterpret_cast<const int4 *>(S.in_idx)[e4]);
         }
         QA_STAMP(3);                                                     // FUSED: rows + permutation landed and staged
         __syncthreads();
@@ -352,7 +432,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         for (int c = 0; c < MAXI; ++c) {
             const int w = tid + BK_T * c;
             if (w < n8) {
-                const int k = w / C, ch = w - k * C;
+                const int k = bk_div(w, rC), ch = w - k * C;
                 const uint32_t fw[4] = {fi[c].x, fi[c].y, fi[c].z, fi[c].w};
                 int src[8];
 #pragma unroll
@@ -372,12 +452,15 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         }
         QA_STAMP(6);                                                     // FUSED: first-stage partials (their factor chunks landed)
         __syncthreads();
+        const float rP = 1.0f / (float)P;
         for (int dd = tid; dd < RP; dd += BK_T) {                        // chunk partials in a fixed order: deterministic
-            const int r = dd / P, k = dd - r * P;
+            const int r = bk_div(dd, rP), k = dd - r * P;
             const float *pp = PART + r * n8 + k * C;
             float a1 = 0.f;
             for (int ch = 0; ch < C; ++ch) a1 += pp[ch];
-            put(dd, a1);
+            const uint16_t hi = f32_to_f16_bits(a1);
+            XH[r * PS + k] = hi;
+            XL[r * PS + k] = f32_to_f16_bits(a1 - f16_bits_to_f32(hi));
         }
     }
 #pragma unroll
@@ -426,7 +509,10 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         for (int reg = 0; reg < 4; ++reg) {
             float v = (part[reg * 64 + lane] + part[256 + reg * 64 + lane]) + (part[512 + reg * 64 + lane] + part[768 + reg * 64 + lane]);
             if (r < R) {
-                v = (v + tbias[reg]) + tres[reg];
+                const float tres = S.res_dtype == QUIPAMD_F32   ? __uint_as_float(tres_raw[reg])
+                                   : S.res_dtype == QUIPAMD_F16 ? f16_bits_to_f32((uint16_t)tres_raw[reg])
+                                                                : bf16_bits_to_f32((uint16_t)tres_raw[reg]);
+                v = (v + tbias[reg]) + tres;
                 if (S.relu) v = fmaxf(v, 0.f);
                 DT<OUT>::store(S.out, (int64_t)(gr0 + r) * S.ld_out + tdst[reg], v);
             }
@@ -442,12 +528,15 @@ size_t blk_lds(const BlkStage &S, bool fused)
     return (size_t)2 * BK_MAXR * (P + 8) * 2 + (4 * 256 + 8 + 2 * BK_MAXR) * 4 + 64 + (fused ? (size_t)S.p * S.q * 4 * rw + (size_t)(S.p * S.q / 8) * 4 * rw + (size_t)S.p * S.q * 2 + 64 : 0);
 }
 
-template <class IN, class OUT, bool FUSED = false> int launch_stage(const BlkStages &SS, int nops, hipStream_t s)
+template <class IN, class OUT, bool FUSED = false, int MAXI = 8> int launch_stage(const BlkStages &SS, int nops, hipStream_t s)
 {
     const BlkStage &S = SS.s[0];
     const int P = S.mix_a ? S.p : S.q, G = S.mix_a ? S.q : S.p;
+    if constexpr (FUSED && MAXI == 8) {
+        if (S.p * S.q <= 8 * BK_T) return launch_stage<IN, OUT, true, 1>(SS, nops, s);      // one factor chunk per thread
+    }
     const size_t lds = blk_lds(S, FUSED);
-    auto kern = blk_stage_kernel<IN, OUT, FUSED>;
+    auto kern = blk_stage_kernel<IN, OUT, FUSED, MAXI>;
     if (lds > 64 * 1024) {
         static QaPerDevice attr;
         static size_t raised[64] = {};
