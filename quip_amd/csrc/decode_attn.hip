@@ -16,6 +16,7 @@
 #include "common.h"
 #include "fpass.h"
 #include "probe.h"
+#include "wavered.h"
 #include "prefetch.h"
 
 // A/B builds (python __graft_entry__.py --variant nokpf -DQA_NO_KPF): round 5's request order -- no early K rows, no touched V lines
@@ -26,24 +27,6 @@
 #endif
 
 namespace {
-
-// wave-wide reductions on the DPP network (4 DPP operands + 4 v_readlane instead of six ds_bpermute round trips each)
-template <int CTRL> __device__ __forceinline__ float dpp_f(float x)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
-}
-template <bool MAX> __device__ __forceinline__ float wave_reduce(float v)
-{
-    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
-    v = op(v, dpp_f<0xB1>(v));       // quad_perm [1,0,3,2]
-    v = op(v, dpp_f<0x4E>(v));       // quad_perm [2,3,0,1]
-    v = op(v, dpp_f<0x141>(v));      // row_half_mirror
-    v = op(v, dpp_f<0x140>(v));      // row_mirror: every lane of a 16-lane row holds the row's result
-    const int b = __builtin_bit_cast(int, v);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
-    return op(op(r0, r1), op(r2, r3));
-}
 
 template <class TI, int HD>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>::storage *q, const typename DT<TI>::storage *k,

@@ -33,8 +33,9 @@ NAMES = {
     "quipamd_decode_fused_gemm": FUSED,
     "quipamd_decode_attention_fused": ["start", "position landed", "requests issued", "y landed, copied", "barrier", "stage 1 + barrier", "stage 2 + barrier",
                                        "gather + barrier", "rotary / append + barrier", "scores (K rows landed)", "softmax", "p V", "end"],
-    "quipamd_ortho_blocked_rows": ["start", "requests issued", "row statistics (unfused + norm)", "FUSED: rows + perm staged", "barrier", "FUSED: stats + gains",
-                                   "FUSED: first-stage partials", "input vector in LDS", "barrier", "MFMAs (factors landed)", "barrier", "store"],
+    "quipamd_ortho_blocked_rows": ["start", "requests issued", "row statistics (unfused + norm)", "FUSED: rows pre-processed (registers) / staged (general form)",
+                                   "barrier", "FUSED: rows in LDS (general form: + statistics, gains)", "FUSED: first-stage products", "input vector in LDS",
+                                   "barrier", "MFMAs (factors landed)", "barrier (not SOLO)", "store"],
     "quipamd_dequant_gemm": ["start", "requests issued", "first chunk landed", "last chunk landed", "MFMAs done", "parked", "barrier", "reduce + store"],
 }
 NAMES["quipamd_decode_attention"] = NAMES["quipamd_decode_attention_fused"]     # the plain launch stamps slots 0, 1, 8 .. 12 of the same list

@@ -83,6 +83,51 @@ def test_activation_side_with_the_norm_and_scale_in_front(n, norm, rows):
     assert float((got.double() - want).norm() / want.norm()) <= 3e-3                        # bf16 output: 2^-9
 
 
+@pytest.mark.parametrize("rows", [1, 2, 4])
+@pytest.mark.parametrize("n", [512, 1024, 2048, 2560, 4096, 8192])
+@pytest.mark.parametrize("norm", ["ln", "rms", None])
+def test_rows_in_registers_forms(n, norm, rows):
+    """round 6: up to 256 x 4 sixteen-byte chunks of input (n a multiple of 512) stay in the threads' registers from the load to the fp32 image in
+    LDS -- statistics on the DPP network, gains and scale applied there -- and a stage of <= 4 k-steps is finished by wave 0 alone.  Every
+    shape class of the dispatch (1 / 4 chunks per thread, 1 / 8 factor chunks, n8 = 320: five wave slots per row), with an offset mean (the
+    shifted statistics), the residual in each dtype and the gate on the input."""
+    op = _op(n, 11)
+    Q = _dense(op)
+    torch.manual_seed(n + rows)
+    x = (torch.randn(rows, n, device=DEV) * 1.5 + 3.0).half()
+    g = (1 + 0.1 * torch.randn(n, device=DEV)).half()
+    b = (0.05 * torch.randn(n, device=DEV)).half()
+    cs = 0.5 + torch.rand(n, device=DEV)
+    ln = None if norm is None else (g, b, 1e-5) if norm == "ln" else (g, None, 1e-5)
+    xf = x.float()
+    if norm == "ln":
+        h = torch.nn.functional.layer_norm(xf, (n,), g.float(), b.float(), 1e-5).half()
+    elif norm == "rms":
+        h = g * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).half()
+    else:
+        h = x
+    want = (h.double() * cs.double()) @ Q.t()
+    got = op.apply_rows_blocked(x, colscale=cs, ln=ln, out_dtype=torch.float16)
+    assert float((got.double() - want).norm() / want.norm()) <= 1.5e-3
+    # rows of a batch do not see each other: row 0 alone gives the same bits
+    if rows * n // 8 <= 1024:                                             # (beyond, the batch takes the general form and the lone row does not)
+        alone = op.apply_rows_blocked(x[:1].contiguous(), colscale=cs, ln=ln, out_dtype=torch.float16)
+        assert torch.equal(alone[0], got[0])
+    for rdt in (torch.float16, torch.bfloat16, torch.float32):
+        res = torch.randn(rows, n, device=DEV).to(rdt)
+        bias = 0.1 * torch.randn(n, device=DEV)
+        got = op.apply_rows_blocked(x, transpose=True, ln=ln, bias=bias, residual=res, relu=(rdt == torch.float16), out_dtype=torch.float32)
+        want = h.double() @ Q + bias.double() + res.double()
+        if rdt == torch.float16:
+            want = torch.relu(want)
+        assert float((got.double() - want).norm() / want.norm()) <= 1.5e-3, rdt
+    if norm is None:
+        up = torch.randn(rows, n, device=DEV).half()
+        got = op.apply_rows_blocked(x, colscale=cs, gate_up=up, out_dtype=torch.float32)
+        want = ((torch.nn.functional.silu(x) * up).double() * cs.double()) @ Q.t()
+        assert float((got.double() - want).norm() / want.norm()) <= 1e-3
+
+
 @pytest.mark.parametrize("rows", [2, 18])
 def test_output_side_with_bias_residual_relu_and_the_gated_input(rows):
     n = 11008
