@@ -245,16 +245,8 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         prow[c] = r;
         psrc[c] = S.in_idx ? S.in_idx[pos] : pos;
     }
-#pragma unroll
-    for (int c = 0; c < (FUSED ? 0 : NPF); ++c) {
-        const int src = psrc[c], r = prow[c];
-        pv[c] = DT<IN>::load(S.in, (int64_t)(gr0 + r) * S.ld_in + src);
-        pu[c] = DT<IN>::load(gup, (int64_t)(gr0 + r) * S.ld_in + src);
-        pg[c] = gmp[S.norm ? src : 0];
-        pb[c] = btp[S.norm == 1 ? src : 0];
-        pc[c] = csp[has_cs ? src : 0];
-    }
-    // (b) wave 0 finishes the tile: where its four results per lane go, and the bias / residual that go with them.  EVERY wave requests them,
+    // (b) [requested between the indices and the values of (a): the unfused launch is two dependent round trips -- index, then value / bias /
+    //     residual -- and the destination indices used to leave only after the values, a third one]  wave 0 finishes the tile: where its four results per lane go, and the bias / residual that go with them.  EVERY wave requests them,
     // unconditionally and from the same addresses (null operands read a dummy line): vector memory returns in order and hipcc counts the
     // loads a wait may leave outstanding along the path with the FEWEST loads, so a load only wave 0 issues, or one behind a null check, turns
     // every later wait for an OLDER load into a wait for these too -- the first-stage products waited for the bias (vmcnt(0)), a cold
@@ -270,6 +262,15 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         const int pos = S.mix_a ? io * q + g : g * q + io;
         const uint32_t *oi = S.out_idx ? reinterpret_cast<const uint32_t *>(S.out_idx) : reinterpret_cast<const uint32_t *>(S.F);
         tdst[reg] = oi[S.out_idx ? pos : 0];                             // (no permutation: BK_FETCH_TAIL puts the position itself)
+    }
+#pragma unroll
+    for (int c = 0; c < (FUSED ? 0 : NPF); ++c) {
+        const int src = psrc[c], r = prow[c];
+        pv[c] = DT<IN>::load(S.in, (int64_t)(gr0 + r) * S.ld_in + src);
+        pu[c] = DT<IN>::load(gup, (int64_t)(gr0 + r) * S.ld_in + src);
+        pg[c] = gmp[S.norm ? src : 0];
+        pb[c] = btp[S.norm == 1 ? src : 0];
+        pc[c] = csp[has_cs ? src : 0];
     }
     // bias / residual hang on those indices: a DEPENDENT round trip.  Requested right here (rounds 4-5) it made wave 0 wait for the -- cold --
     // index vector before it could issue anything else, and in the FUSED form every wave then waited for wave 0 at the first barrier: 2000-4000
