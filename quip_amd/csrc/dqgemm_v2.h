@@ -234,7 +234,7 @@ template <int BITS, class ACT, int RT, int NW, int NCH, bool HALF, bool EXACT>
 int launch_h2(const K2Args &A, hipStream_t s)
 {
     typedef DeqT<BITS, ACT> Q;
-    constexpr size_t lds = (size_t)NW * NCH * 16 * Q::KC * 2;
+    constexpr size_t lds = (size_t)NW * NCH * (HALF ? 8 : 16) * Q::KC * 2;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = dq_h_kernel<BITS, ACT, RT, NW, NCH, HALF, EXACT>;
     if (lds > 64 * 1024 &&
@@ -248,7 +248,7 @@ template <int BITS, class ACT, int RT, int NW, int NCH, bool HALF, bool EXACT>
 int launch_h2g(const K2GArgs &G, int ngroups, hipStream_t s)
 {
     typedef DeqT<BITS, ACT> Q;
-    constexpr size_t lds = (size_t)NW * NCH * 16 * Q::KC * 2;
+    constexpr size_t lds = (size_t)NW * NCH * (HALF ? 8 : 16) * Q::KC * 2;
     auto kern = dq_hg_kernel<BITS, ACT, RT, NW, NCH, HALF, EXACT>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

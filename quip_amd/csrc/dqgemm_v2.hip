@@ -25,6 +25,12 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
         //      over 16 waves, are faster
         //   mb: bs > 16 when there are >= ~200 workgroup tiles of 256 x 128
         if (bs <= 16) {
+            // round 6: 16 < chunks <= 32 (d <= 8192) at bs <= 8 -- the one-pass kernel with 8-row slabs (dq_h_body.inc HALF: 4 KiB per chunk):
+            // OPT's fc2 (2048 x 8192) in a blocked-operator decode step, which the round-1 tile kernel served in 6.6 us
+            if constexpr (BITS == 2) {
+                if (bs <= 8 && nkc > 16 && nkc <= 32 && ntile <= 512)
+                    return nkc == 32 ? launch_h2<2, ACT, 1, 8, 4, true, true>(A, s) : launch_h2<2, ACT, 1, 8, 4, true, false>(A, s);
+            }
             if (h_fits && ntile <= 768) fam = K2_FAM_H;
             else if (ntile >= 1024 && d % 256 == 0) fam = K2_FAM_S;
             else if (f16) fam = h_fits ? K2_FAM_H : (d % 256 == 0) ? K2_FAM_S : K2_FAM_NONE;   // fp16 exists only here: any shape a kernel can hold

@@ -562,9 +562,12 @@ def packed_forward_fused(qls, x, ln=None, residual=None, relu=False, gate_up=Non
         # blocked butterfly (what --incoh_processing really yields): two launches per operator with the norm / silu * up / column scale of
         # the block fused into the first (csrc/ortho_blk.hip)
         lnp, gu = _ln_params(ln), (None if gate_up is None else gate_up.contiguous())
+        # x~ in the model's own 16-bit type where K2 has a kernel for it (QuantLinear.act_dtype): an fp16 model keeps its mantissa bits, and
+        # the grouped one-pass kernels (csrc/dqgemm_v2.hip: fp16 only) take q / k / v -- in bf16 they fell to the round-1 tile kernel
+        xt_dtype = qls[0].act_dtype(x)
         xts = []
         for i in range(0, len(qls), 3):                         # up to three operators per launch pair (q / k / v, gate / up)
-            xts += ops.ortho_blocked_multi([(q.V, x, dict(colscale=q.inv_scaleWH, ln=lnp, gate_up=gu)) for q in qls[i:i + 3]], torch.bfloat16)
+            xts += ops.ortho_blocked_multi([(q.V, x, dict(colscale=q.inv_scaleWH, ln=lnp, gate_up=gu)) for q in qls[i:i + 3]], xt_dtype)
         gate_up = None
     else:
         if gate_up is not None:

@@ -90,6 +90,16 @@ def test_h_kernel(ops, O, dt, bits, qfn, m, d, bs):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("qfn", ["a", "b"])
+@pytest.mark.parametrize("m,d,bs", [(2048, 8192, 1), (2048, 8192, 8), (96, 8192, 3), (512, 6144, 5), (64, 4352, 2), (8192, 8192, 4)])
+def test_half_slab_one_pass_kernel_up_to_d_8192(ops, O, dt, qfn, m, d, bs):
+    """round 6: at bs <= 8 a slab of the one-pass kernel holds 8 rows (4 KiB per 256-column chunk), so 32 chunks -- d = 8192, OPT's fc2 in a
+    blocked-operator decode step -- fit one workgroup's LDS: the default heuristic takes 16 < chunks <= 32 there (exact fit and ragged K); the
+    same shapes at bs 9 keep their old kernels."""
+    _run(ops, O, m, d, bs, 2, qfn, dt, None, seed=m + d + bs)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("bits,qfn", [(2, "b"), (2, "a"), (4, "a"), (4, "b")])
 @pytest.mark.parametrize("m,d,bs", [(112, 256, 1), (224, 512, 16), (16, 768, 5), (1808, 1024, 16), (4096, 2304, 7), (336, 7168, 16)])
 def test_s_kernel(ops, O, dt, bits, qfn, m, d, bs):
