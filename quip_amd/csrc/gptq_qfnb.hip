@@ -19,6 +19,7 @@
 // column of the workgroup's rows is one contiguous run.
 #include "common.h"
 #include "fpass.h"
+#include "wavered.h"
 
 namespace {
 
@@ -149,6 +150,96 @@ __global__ __launch_bounds__(GB_T) void gptqb_chain_kernel(GbArgs A)
         for (int cl = cg; cl < nb; cl += NCG) A.ET[(int64_t)cl * A.m + row] = W1[cl * R + r];
 }
 
+// Round 6: the PIPELINED chain, 64 rows per workgroup.  The form above runs a column as [owner's squares -> barrier -> wave 0: reduce, publish, poll
+// -> barrier -> quantise -> barrier -> every thread feeds the residual to ALL remaining columns], 3.2-4.0 us per column of which the
+// granule hand-off is ~1-2 (MI355X_MICROARCH.md: handoff-1to1 0.8 us idle, all-gather of 64-256 granules 2.4-3): everything else sat in
+// series with it.  Here wave 0 IS the chain: lane = row, the current column's 64 values live in its registers, sums run on the DPP network,
+// and the only thing it does between receiving the column's sum and publishing the next column's partial is: scale, quantise, residual, ONE
+// fma for the next column (its own residual times F[c - 1][c]), 64 squares, a wave sum.  Waves 1-3 feed residual c to the columns
+// < c - 1 while the chain wave's next granule travels; one barrier per column orders the two (the chain reads column c - 1 only after the
+// helpers have applied every residual > c to it, the helpers read residual c only after the chain has written it).  W1[c] is column c until
+// the chain has quantised it and its residual afterwards -- the block of residuals the far-field kernel reads is W1 at the end, as above.
+__global__ __launch_bounds__(GB_T) void gptqb_chain64_kernel(GbArgs A)
+{
+    constexpr int R = 64;
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float *W1 = gsm;                                                  // [128][64]
+    float *F1 = gsm + GB_NB * R;                                      // [128][128]: F1[jl][cl] = FT[b0 + jl][b0 + cl]
+    float *gaveup = F1 + GB_NB * GB_NB;                               // [1] != 0: the sweep was abandoned (bounded poll below)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wg = blockIdx.x, G = A.G, nb = A.nb, b0 = A.b0;
+    const int64_t row = (int64_t)wg * R + lane;
+    const bool live = row < A.m;
+    if (tid == 0)
+        gaveup[0] = __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
+    const int64_t rowc = live ? row : A.m - 1;                        // (clamped address + select: a guarded load is a branch and a round trip)
+    for (int cl = wave; cl < nb; cl += 4) {
+        const float v = A.WT[(int64_t)(b0 + cl) * A.m + rowc];
+        W1[cl * R + lane] = live ? v : 0.f;
+    }
+    for (int i = tid; i < nb * nb; i += GB_T) {
+        const int jl = i / nb, cl = i - jl * nb;
+        F1[jl * GB_NB + cl] = A.FT[(int64_t)(b0 + jl) * A.d + b0 + cl];
+    }
+    __syncthreads();
+    if (gaveup[0] != 0.f) return;
+    const float fm = (float)A.m;
+    if (wave == 0) {
+        float w = W1[(nb - 1) * R + lane];
+        for (int cl = nb - 1; cl >= 0; --cl) {
+            const int cp = b0 + cl;                                   // reversed column index
+            const float p = wave_reduce<false>(w * w);
+            const unsigned tag = (unsigned)(A.d - cp);               // 1 .. d, unique per column of the sweep
+            unsigned long long *gr = A.gran + (size_t)(tag & 1) * G;
+            if (lane == 0)
+                __hip_atomic_store(gr + wg, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, p), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            // gather: lane l polls granules l, l + 64, ...; bounded as above (co-residency is inferred, not guaranteed)
+            float sgr = 0.f;
+            bool bad = false;
+            for (int i = lane; i < G && !bad; i += 64) {
+                unsigned long long v;
+                long long spins = 0;
+                for (;;) {
+                    v = __hip_atomic_load(gr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(v >> 32) == tag) break;
+                    if (++spins >= A.spin_limit ||
+                        ((spins & 255) == 0 && __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        bad = true;
+                        break;
+                    }
+                }
+                sgr += __builtin_bit_cast(float, (unsigned)v);
+            }
+            const bool dead = __any(bad);
+            if (dead && lane == 0) {
+                __hip_atomic_store(A.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gaveup[0] = 1.f;
+            }
+            const float S = wave_reduce<false>(sgr);                  // (every lane active again here; fixed order: deterministic)
+            const float scale = 2.4f * sqrtf(__fdiv_rn(S, fm)) + 1e-16f;     // quant.py:159
+            const float q = gb_quant(w, scale, A.maxq);
+            const float res = live ? w - q : 0.f;                     // rows past m stay zero: they are part of every column's sum
+            W1[cl * R + lane] = res;
+            __syncthreads();                                          // residual c is out; every residual > c has been applied to the columns < c
+            if (gaveup[0] != 0.f) return;
+            if (cl > 0) w = fmaf(res, F1[(cl - 1) * GB_NB + cl], W1[(cl - 1) * R + lane]);
+            if (live) A.QT[(int64_t)cp * A.m + row] = q;             // (off the chain: behind the next column's value)
+            if (wg == 0 && lane == 0) A.colscale[cp] = scale;
+        }
+    } else {
+        for (int cl = nb - 1; cl >= 0; --cl) {
+            __syncthreads();
+            if (gaveup[0] != 0.f) return;
+            const float e = W1[cl * R + lane];
+            for (int jl = cl - 1 - wave; jl >= 0; jl -= 3) W1[jl * R + lane] = fmaf(e, F1[jl * GB_NB + cl], W1[jl * R + lane]);   // cl - 2 first: the chain needs it next
+        }
+    }
+    __syncthreads();
+    if (live)
+        for (int cl = wave; cl < nb; cl += 4) A.ET[(int64_t)cl * A.m + row] = W1[cl * R + lane];
+}
+
 // WT[j'][rows] += sum_cl FT[j'][b0 + cl] ET[cl][rows] for j' < b0.  Workgroup = 64 j' x 64 rows, wave = 16 j' x 64 rows (4 tiles).
 __global__ __launch_bounds__(256) void gptqb_far_kernel(GbArgs A)
 {
@@ -212,12 +303,28 @@ template <int R> int gb_chain(const GbArgs &A, hipStream_t s)
     return QUIPAMD_OK;
 }
 
+constexpr size_t GB_LDS64 = (size_t)(GB_NB * 64 + GB_NB * GB_NB + 4) * sizeof(float);
+int gb_chain64(const GbArgs &A, hipStream_t s)
+{
+    static QaPerDevice attr;
+    const int dv = attr.dev();
+    if (dv < 0 || !attr.done[dv]) {
+        if (hipFuncSetAttribute((const void *)gptqb_chain64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS64) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: cannot raise dynamic LDS to %zu", GB_LDS64);
+        if (dv >= 0) attr.done[dv] = true;
+    }
+    gptqb_chain64_kernel<<<(unsigned)(A.G - g_gb_debug_short_grid > 0 ? A.G - g_gb_debug_short_grid : 1), GB_T, GB_LDS64, s>>>(A);
+    return QUIPAMD_OK;
+}
+
 }   // namespace
 
 extern "C" void quipamd_gptq_qfnb_debug(int short_grid, int64_t spin_limit, int force_rows)
 {
     g_gb_debug_short_grid = short_grid > 0 ? short_grid : 0;
     g_gb_spin_limit = spin_limit > 0 ? spin_limit : GB_SPIN_LIMIT;
+    // 16 / 32 / 64 / 128: the barrier-per-phase chain of rounds 3-5 with that many rows per workgroup (A/B runs); 0: the heuristic (the pipelined
+    // 64-row chain wherever its grid is co-resident)
     g_gb_force_rows = (force_rows == 16 || force_rows == 32 || force_rows == 64 || force_rows == 128) ? force_rows : 0;
 }
 
@@ -253,7 +360,18 @@ extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits,
         return (m + R - 1) / R <= (int64_t)per_cu * ncu;
     };
     int R = 0;
-    if (g_gb_force_rows == 16 && fits(16, (const void *)gptqb_chain_kernel<16>)) R = 16;
+    bool pipelined = false;
+    if (g_gb_force_rows == 0) {
+        int per_cu = 0;
+        if (hipFuncSetAttribute((const void *)gptqb_chain64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS64) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)gptqb_chain64_kernel, GB_T, GB_LDS64) == hipSuccess &&
+            (m + 63) / 64 <= (int64_t)per_cu * ncu) {
+            pipelined = true;
+            R = 64;
+        }
+    }
+    if (pipelined) {
+    } else if (g_gb_force_rows == 16 && fits(16, (const void *)gptqb_chain_kernel<16>)) R = 16;
     else if (g_gb_force_rows == 32 && fits(32, (const void *)gptqb_chain_kernel<32>)) R = 32;
     else if (g_gb_force_rows == 64 && fits(64, (const void *)gptqb_chain_kernel<64>)) R = 64;
     else if (g_gb_force_rows == 128 && fits(128, (const void *)gptqb_chain_kernel<128>)) R = 128;
@@ -283,7 +401,7 @@ extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits,
         const int64_t nb = (b1 % GB_NB) ? (b1 % GB_NB) : GB_NB;
         const int64_t b0 = b1 - nb;
         A.b0 = (int)b0; A.nb = (int)nb;
-        int rc = R == 128 ? gb_chain<128>(A, s) : R == 64 ? gb_chain<64>(A, s) : R == 32 ? gb_chain<32>(A, s) : gb_chain<16>(A, s);
+        int rc = pipelined ? gb_chain64(A, s) : R == 128 ? gb_chain<128>(A, s) : R == 64 ? gb_chain<64>(A, s) : R == 32 ? gb_chain<32>(A, s) : gb_chain<16>(A, s);
         if (rc != QUIPAMD_OK) return rc;
         if (b0 > 0) gptqb_far_kernel<<<dim3((unsigned)((b0 + 63) / 64), (unsigned)((m + 63) / 64)), 256, 0, s>>>(A);
         b1 = b0;
