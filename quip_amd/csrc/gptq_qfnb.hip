@@ -38,6 +38,9 @@ struct GbArgs {
     int64_t m, d;
     int b0, nb, G;
     float maxq;
+    int *claim;                   // XL: this launch's participant counter (zeroed with the granules)
+    int absent;                   // XL, test hook: that many participants never show up
+    int xcc, first;               // XL: the XCD the sweep runs on; first: the sweep's first launch (its first exchange is the roll call)
 };
 
 __device__ __forceinline__ float gb_quant(float w, float s, float maxq)
@@ -150,58 +153,85 @@ __global__ __launch_bounds__(GB_T) void gptqb_chain_kernel(GbArgs A)
         for (int cl = cg; cl < nb; cl += NCG) A.ET[(int64_t)cl * A.m + row] = W1[cl * R + r];
 }
 
-// Round 6: the PIPELINED chain, 64 rows per workgroup.  The form above runs a column as [owner's squares -> barrier -> wave 0: reduce, publish, poll
-// -> barrier -> quantise -> barrier -> every thread feeds the residual to ALL remaining columns], 3.2-4.0 us per column of which the
-// granule hand-off is ~1-2 (MI355X_MICROARCH.md: handoff-1to1 0.8 us idle, all-gather of 64-256 granules 2.4-3): everything else sat in
-// series with it.  Here wave 0 IS the chain: lane = row, the current column's 64 values live in its registers, sums run on the DPP network,
-// and the only thing it does between receiving the column's sum and publishing the next column's partial is: scale, quantise, residual, ONE
-// fma for the next column (its own residual times F[c - 1][c]), 64 squares, a wave sum.  Waves 1-3 feed residual c to the columns
-// < c - 1 while the chain wave's next granule travels; one barrier per column orders the two (the chain reads column c - 1 only after the
-// helpers have applied every residual > c to it, the helpers read residual c only after the chain has written it).  W1[c] is column c until
-// the chain has quantised it and its residual afterwards -- the block of residuals the far-field kernel reads is W1 at the end, as above.
-__global__ __launch_bounds__(GB_T) void gptqb_chain64_kernel(GbArgs A)
+// Round 6: the PIPELINED chain.  The form above runs a column as [owner's squares -> barrier -> wave 0: reduce, publish, poll -> barrier ->
+// quantise -> barrier -> every thread feeds the residual to ALL remaining columns], 3.2-4.0 us per column of which the granule hand-off is
+// ~1.5-2 (scripts/xcdsync_lab.hip: 1.6-2.0 us per all-gather of 32-64 granules at agent scope): everything else sat in series with it.
+// Here a CHAIN WAVE owns 64 rows for the whole block: lane = row, the current column's 64 values live in its registers, sums run on the DPP
+// network, and all it does between receiving a column's sum and publishing the next column's partial is: scale, quantise, residual, ONE fma
+// for the next column (its own residual times F[c - 1][c]), 64 squares, a wave sum.  Three HELPER waves per chain wave feed residual c to
+// the columns < c - 1 while the chain wave's next granule travels; one barrier per column orders the two (the chain reads column c - 1
+// only after the helpers have applied every residual > c to it, the helpers read residual c only after the chain has written it).  W1[c] is
+// column c until the chain has quantised it and its residual afterwards -- the block of residuals the far-field kernel reads is W1 at the end.
+//
+// XL -- the exchange confined to ONE XCD.  A plain store is written through but STAYS in the XCD's L2, and an sc1 load bypasses the reader's
+// L1 and is served by that L2 (MI355X_MICROARCH.md, "stores of each flavour"): between workgroups of one XCD an all-gather of 16-64
+// granules costs 0.55 us instead of 1.4-2.4 (profiles/r06o_xcdsync_lab.txt; across XCDs the same pair of instructions reads stale lines
+// forever -- the lab's control).  So for m <= 4096 rows the sweep runs on the 32 CUs of XCD `A.xcc`: a full grid of one-per-CU workgroups
+// is launched, every workgroup reads HW_REG_XCC_ID, the ones on that XCD claim a participant slot from a counter, everybody else leaves.
+// Nothing is assumed about which block lands where (HIP promises nothing; block b on XCD b % 8 is what is observed); what is needed is
+// that ceil(m / rows) workgroups of that XCD become resident.  The first column's exchange is the roll call: if it times out nothing
+// has been written yet, the abort word becomes 2 and the caller repeats the sweep with the cross-XCD form (ops.gptq_round_qfnb does).
+template <int NC, bool XL>                                            // chain waves per workgroup (rows = 64 NC)
+__global__ __launch_bounds__(GB_T * NC) void gptqb_chainp_kernel(GbArgs A)
 {
-    constexpr int R = 64;
+    constexpr int R = 64 * NC;
     extern __shared__ __attribute__((aligned(16))) float gsm[];
-    float *W1 = gsm;                                                  // [128][64]
+    float *W1 = gsm;                                                  // [128][R]
     float *F1 = gsm + GB_NB * R;                                      // [128][128]: F1[jl][cl] = FT[b0 + jl][b0 + cl]
-    float *gaveup = F1 + GB_NB * GB_NB;                               // [1] != 0: the sweep was abandoned (bounded poll below)
+    float *gaveup = F1 + GB_NB * GB_NB;                               // [0] != 0: the sweep was abandoned (bounded poll below); [1]: the slot
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wg = blockIdx.x, G = A.G, nb = A.nb, b0 = A.b0;
-    const int64_t row = (int64_t)wg * R + lane;
-    const bool live = row < A.m;
-    if (tid == 0)
+    const int NP = A.G, nb = A.nb, b0 = A.b0;                         // participants = workgroups that hold rows
+    if (tid == 0) {
+        int slot = (int)blockIdx.x;
+        if constexpr (XL) {
+            const int xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15;       // HW_REG_XCC_ID
+            slot = xcc == A.xcc ? atomicAdd(A.claim, 1) : -1;
+        }
+        gaveup[1] = __builtin_bit_cast(float, slot);
         gaveup[0] = __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
-    const int64_t rowc = live ? row : A.m - 1;                        // (clamped address + select: a guarded load is a branch and a round trip)
-    for (int cl = wave; cl < nb; cl += 4) {
-        const float v = A.WT[(int64_t)(b0 + cl) * A.m + rowc];
-        W1[cl * R + lane] = live ? v : 0.f;
     }
-    for (int i = tid; i < nb * nb; i += GB_T) {
+    __syncthreads();
+    const int wg = __builtin_bit_cast(int, gaveup[1]);
+    if (wg < 0 || wg >= NP - (XL ? A.absent : 0) || gaveup[0] != 0.f) return;      // (uniform; `absent`: the test hook's missing workgroups)
+    const int chain = wave < NC ? wave : (wave - NC) / 3;             // the 64-row slice this wave works on
+    const int rl = chain * 64 + lane;
+    const int64_t row = (int64_t)wg * R + rl;
+    const bool live = row < A.m;
+    const int64_t rowc = live ? row : A.m - 1;                        // (clamped address + select: a guarded load is a branch and a round trip)
+    for (int i = tid; i < nb * R; i += GB_T * NC) {
+        const int cl = i / R, r = i - cl * R;
+        const int64_t rr = (int64_t)wg * R + r;
+        const float v = A.WT[(int64_t)(b0 + cl) * A.m + (rr < A.m ? rr : A.m - 1)];
+        W1[cl * R + r] = rr < A.m ? v : 0.f;
+    }
+    for (int i = tid; i < nb * nb; i += GB_T * NC) {
         const int jl = i / nb, cl = i - jl * nb;
         F1[jl * GB_NB + cl] = A.FT[(int64_t)(b0 + jl) * A.d + b0 + cl];
     }
     __syncthreads();
-    if (gaveup[0] != 0.f) return;
+    (void)rowc;
     const float fm = (float)A.m;
-    if (wave == 0) {
-        float w = W1[(nb - 1) * R + lane];
+    const int NG = NP * NC;                                           // granules per column: one per chain wave
+    if (wave < NC) {
+        float w = W1[(nb - 1) * R + rl];
         for (int cl = nb - 1; cl >= 0; --cl) {
             const int cp = b0 + cl;                                   // reversed column index
             const float p = wave_reduce<false>(w * w);
             const unsigned tag = (unsigned)(A.d - cp);               // 1 .. d, unique per column of the sweep
-            unsigned long long *gr = A.gran + (size_t)(tag & 1) * G;
-            if (lane == 0)
-                __hip_atomic_store(gr + wg, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, p), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            // gather: lane l polls granules l, l + 64, ...; bounded as above (co-residency is inferred, not guaranteed)
+            unsigned long long *gr = A.gran + (size_t)(tag & 1) * NG;
+            const unsigned long long mine = ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, p);
+            if (lane == 0) {
+                if constexpr (XL) __hip_atomic_store(gr + wg * NC + wave, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // plain: stays in the XCD's L2
+                else __hip_atomic_store(gr + wg * NC + wave, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // gather: lane l polls granules l, l + 64, ...; bounded (co-residency is inferred, not guaranteed)
             float sgr = 0.f;
             bool bad = false;
-            for (int i = lane; i < G && !bad; i += 64) {
+            for (int i = lane; i < NG && !bad; i += 64) {
                 unsigned long long v;
                 long long spins = 0;
                 for (;;) {
-                    v = __hip_atomic_load(gr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = __hip_atomic_load(gr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1: past the L1, served by the L2
                     if ((unsigned)(v >> 32) == tag) break;
                     if (++spins >= A.spin_limit ||
                         ((spins & 255) == 0 && __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
@@ -213,31 +243,38 @@ __global__ __launch_bounds__(GB_T) void gptqb_chain64_kernel(GbArgs A)
             }
             const bool dead = __any(bad);
             if (dead && lane == 0) {
-                __hip_atomic_store(A.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the roll call (first column of the sweep's first launch, nothing written yet) failing is code 2: repeat with the other form
+                int expect = 0;
+                __hip_atomic_compare_exchange_strong(A.abort_flag, &expect, (XL && A.first && cl == nb - 1) ? 2 : 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
                 gaveup[0] = 1.f;
             }
             const float S = wave_reduce<false>(sgr);                  // (every lane active again here; fixed order: deterministic)
             const float scale = 2.4f * sqrtf(__fdiv_rn(S, fm)) + 1e-16f;     // quant.py:159
             const float q = gb_quant(w, scale, A.maxq);
             const float res = live ? w - q : 0.f;                     // rows past m stay zero: they are part of every column's sum
-            W1[cl * R + lane] = res;
+            if (!dead) W1[cl * R + rl] = res;
             __syncthreads();                                          // residual c is out; every residual > c has been applied to the columns < c
             if (gaveup[0] != 0.f) return;
-            if (cl > 0) w = fmaf(res, F1[(cl - 1) * GB_NB + cl], W1[(cl - 1) * R + lane]);
+            if (cl > 0) w = fmaf(res, F1[(cl - 1) * GB_NB + cl], W1[(cl - 1) * R + rl]);
             if (live) A.QT[(int64_t)cp * A.m + row] = q;             // (off the chain: behind the next column's value)
-            if (wg == 0 && lane == 0) A.colscale[cp] = scale;
+            if (wg == 0 && tid == 0) A.colscale[cp] = scale;
         }
     } else {
+        const int sub = (wave - NC) % 3;
         for (int cl = nb - 1; cl >= 0; --cl) {
             __syncthreads();
             if (gaveup[0] != 0.f) return;
-            const float e = W1[cl * R + lane];
-            for (int jl = cl - 1 - wave; jl >= 0; jl -= 3) W1[jl * R + lane] = fmaf(e, F1[jl * GB_NB + cl], W1[jl * R + lane]);   // cl - 2 first: the chain needs it next
+            const float e = W1[cl * R + rl];
+            for (int jl = cl - 2 - sub; jl >= 0; jl -= 3) W1[jl * R + rl] = fmaf(e, F1[jl * GB_NB + cl], W1[jl * R + rl]);   // cl - 2 first: the chain needs it next
         }
     }
     __syncthreads();
-    if (live)
-        for (int cl = wave; cl < nb; cl += 4) A.ET[(int64_t)cl * A.m + row] = W1[cl * R + lane];
+    for (int i = tid; i < nb * R; i += GB_T * NC) {
+        const int cl = i / R, r = i - cl * R;
+        const int64_t rr = (int64_t)wg * R + r;
+        if (rr < A.m) A.ET[(int64_t)cl * A.m + rr] = W1[cl * R + r];
+    }
 }
 
 // WT[j'][rows] += sum_cl FT[j'][b0 + cl] ET[cl][rows] for j' < b0.  Workgroup = 64 j' x 64 rows, wave = 16 j' x 64 rows (4 tiles).
@@ -247,6 +284,7 @@ __global__ __launch_bounds__(256) void gptqb_far_kernel(GbArgs A)
     const int jc = lane & 15, g = lane >> 4;
     const int64_t j0 = (int64_t)blockIdx.x * 64 + 16 * wave, r0 = (int64_t)blockIdx.y * 64;
     if (j0 >= A.b0) return;
+    if (__hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // an abandoned sweep left no residuals: W stays as it is
     const int64_t ja = j0 + jc < A.b0 ? j0 + jc : A.b0 - 1;          // A operand row (clamped: its results are not stored)
     const float *Fa = A.FT + ja * A.d + A.b0;
     f32x4_t acc[4];
@@ -303,18 +341,28 @@ template <int R> int gb_chain(const GbArgs &A, hipStream_t s)
     return QUIPAMD_OK;
 }
 
-constexpr size_t GB_LDS64 = (size_t)(GB_NB * 64 + GB_NB * GB_NB + 4) * sizeof(float);
-int gb_chain64(const GbArgs &A, hipStream_t s)
+template <int NC, bool XL> int gb_chainp(const GbArgs &A, int grid, hipStream_t s)
 {
+    constexpr size_t lds = (size_t)(GB_NB * 64 * NC + GB_NB * GB_NB + 4) * sizeof(float);
+    auto kern = gptqb_chainp_kernel<NC, XL>;
     static QaPerDevice attr;
     const int dv = attr.dev();
     if (dv < 0 || !attr.done[dv]) {
-        if (hipFuncSetAttribute((const void *)gptqb_chain64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS64) != hipSuccess)
-            return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: cannot raise dynamic LDS to %zu", GB_LDS64);
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: cannot raise dynamic LDS to %zu", lds);
         if (dv >= 0) attr.done[dv] = true;
     }
-    gptqb_chain64_kernel<<<(unsigned)(A.G - g_gb_debug_short_grid > 0 ? A.G - g_gb_debug_short_grid : 1), GB_T, GB_LDS64, s>>>(A);
+    if (!XL) grid -= g_gb_debug_short_grid;                             // (XL: GbArgs.absent -- which blocks land on the XCD is not the host's to say)
+    kern<<<(unsigned)(grid > 0 ? grid : 1), GB_T * NC, lds, s>>>(A);
     return QUIPAMD_OK;
+}
+template <int NC, bool XL> bool gb_chainp_fits(int64_t blocks, int ncu)
+{
+    constexpr size_t lds = (size_t)(GB_NB * 64 * NC + GB_NB * GB_NB + 4) * sizeof(float);
+    auto kern = gptqb_chainp_kernel<NC, XL>;
+    int per_cu = 0;
+    return hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, GB_T * NC, lds) == hipSuccess && blocks <= (int64_t)per_cu * ncu;
 }
 
 }   // namespace
@@ -323,9 +371,10 @@ extern "C" void quipamd_gptq_qfnb_debug(int short_grid, int64_t spin_limit, int 
 {
     g_gb_debug_short_grid = short_grid > 0 ? short_grid : 0;
     g_gb_spin_limit = spin_limit > 0 ? spin_limit : GB_SPIN_LIMIT;
-    // 16 / 32 / 64 / 128: the barrier-per-phase chain of rounds 3-5 with that many rows per workgroup (A/B runs); 0: the heuristic (the pipelined
-    // 64-row chain wherever its grid is co-resident)
-    g_gb_force_rows = (force_rows == 16 || force_rows == 32 || force_rows == 64 || force_rows == 128) ? force_rows : 0;
+    // 0: the heuristic -- the pipelined chain, confined to one XCD up to 4096 rows (gptqb_chainp_kernel); 1: the pipelined chain across the XCDs
+    // (what ops.gptq_round_qfnb repeats a sweep with when the one-XCD roll call fails: abort word 2); 2: the one-XCD form or an error;
+    // 16 / 32 / 64 / 128: the barrier-per-phase chain of rounds 3-5 with that many rows per workgroup (A/B runs)
+    g_gb_force_rows = (force_rows == 1 || force_rows == 2 || force_rows == 16 || force_rows == 32 || force_rows == 64 || force_rows == 128) ? force_rows : 0;
 }
 
 extern "C" int64_t quipamd_gptq_qfnb_info_offset(int64_t m, int64_t d)
@@ -337,7 +386,8 @@ extern "C" int64_t quipamd_gptq_qfnb_info_offset(int64_t m, int64_t d)
 extern "C" int64_t quipamd_gptq_qfnb_workspace_bytes(int64_t m, int64_t d)
 {
     (void)d;
-    return (int64_t)GB_NB * m * 4 + 2 * ((m + 15) / 16) * 8 + 64;     // residuals of a block + two granules per possible workgroup
+    // residuals of a block + two granules per possible workgroup + 64 bytes (abort word) + one participant counter per lazy block
+    return (int64_t)GB_NB * m * 4 + 2 * ((m + 15) / 16) * 8 + 64 + 4 * ((d + GB_NB - 1) / GB_NB + 1);
 }
 
 extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits, float *QT_rev, float *colscale_rev, void *workspace,
@@ -360,18 +410,19 @@ extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits,
         return (m + R - 1) / R <= (int64_t)per_cu * ncu;
     };
     int R = 0;
-    bool pipelined = false;
-    if (g_gb_force_rows == 0) {
-        int per_cu = 0;
-        if (hipFuncSetAttribute((const void *)gptqb_chain64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS64) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)gptqb_chain64_kernel, GB_T, GB_LDS64) == hipSuccess &&
-            (m + 63) / 64 <= (int64_t)per_cu * ncu) {
-            pipelined = true;
-            R = 64;
-        }
+    // form: 0 barrier-per-phase chain (rounds 3-5), 1 pipelined across the XCDs, 2 / 3 pipelined on one XCD with 1 / 2 chain waves per workgroup
+    int form = 0;
+    if (g_gb_force_rows == 0 || g_gb_force_rows == 2) {
+        // one XCD = ncu / 8 compute units, one workgroup each; the full grid of ncu one-per-CU workgroups must be resident
+        if (ncu % 8 == 0 && m <= (int64_t)64 * (ncu / 8) && gb_chainp_fits<1, true>(ncu, ncu)) form = 2;
+        else if (ncu % 8 == 0 && m <= (int64_t)128 * (ncu / 8) && gb_chainp_fits<2, true>(ncu, ncu)) form = 3;
+        QA_REQUIRE(form != 0 || g_gb_force_rows == 0, QUIPAMD_ERR_UNSUPPORTED, "gptq_round_qfnb: %lld rows do not fit one XCD (%d CUs / 8 x 128 rows)",
+                   (long long)m, ncu);
     }
-    if (pipelined) {
-    } else if (g_gb_force_rows == 16 && fits(16, (const void *)gptqb_chain_kernel<16>)) R = 16;
+    if (form == 0 && (g_gb_force_rows == 0 || g_gb_force_rows == 1) && gb_chainp_fits<1, false>((m + 63) / 64, ncu)) form = 1;
+    if (form == 1 || form == 2) R = 64;
+    else if (form == 3) R = 128;
+    else if (g_gb_force_rows == 16 && fits(16, (const void *)gptqb_chain_kernel<16>)) R = 16;
     else if (g_gb_force_rows == 32 && fits(32, (const void *)gptqb_chain_kernel<32>)) R = 32;
     else if (g_gb_force_rows == 64 && fits(64, (const void *)gptqb_chain_kernel<64>)) R = 64;
     else if (g_gb_force_rows == 128 && fits(128, (const void *)gptqb_chain_kernel<128>)) R = 128;
@@ -392,8 +443,11 @@ extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits,
     A.m = m; A.d = d; A.G = (int)G; A.maxq = (float)((1 << bits) - 1);
     A.abort_flag = (int *)((char *)workspace + quipamd_gptq_qfnb_info_offset(m, d));
     A.spin_limit = g_gb_spin_limit;
-    // granules AND the abort flag behind them (2 * ceil(m / 16) * 8 bytes of granule space + 64 spare, all zeroed)
-    if (hipMemsetAsync(A.gran, 0, (size_t)(2 * ((m + 15) / 16) * 8 + 64), s) != hipSuccess) return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: memset failed");
+    A.claim = A.abort_flag + 16;                                          // (behind the 64 spare bytes)
+    A.xcc = 0; A.first = 1; A.absent = g_gb_debug_short_grid;
+    // granules, the abort flag behind them and the participant counters (2 * ceil(m / 16) * 8 bytes of granule space + 64 spare + counters, all zeroed)
+    if (hipMemsetAsync(A.gran, 0, (size_t)(2 * ((m + 15) / 16) * 8 + 64 + 4 * ((d + GB_NB - 1) / GB_NB + 1)), s) != hipSuccess)
+        return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: memset failed");
     // lazy blocks from the top of the reversed order; block edges at multiples of 128, so a remainder of d is the FIRST block (where a
     // block ends only decides when its residuals reach the columns behind it, not what they are)
     int64_t b1 = d;
@@ -401,8 +455,11 @@ extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits,
         const int64_t nb = (b1 % GB_NB) ? (b1 % GB_NB) : GB_NB;
         const int64_t b0 = b1 - nb;
         A.b0 = (int)b0; A.nb = (int)nb;
-        int rc = pipelined ? gb_chain64(A, s) : R == 128 ? gb_chain<128>(A, s) : R == 64 ? gb_chain<64>(A, s) : R == 32 ? gb_chain<32>(A, s) : gb_chain<16>(A, s);
+        int rc = form == 3 ? gb_chainp<2, true>(A, ncu, s) : form == 2 ? gb_chainp<1, true>(A, ncu, s) : form == 1 ? gb_chainp<1, false>(A, (int)G, s)
+                 : R == 128 ? gb_chain<128>(A, s) : R == 64 ? gb_chain<64>(A, s) : R == 32 ? gb_chain<32>(A, s) : gb_chain<16>(A, s);
         if (rc != QUIPAMD_OK) return rc;
+        A.claim += 1;
+        A.first = 0;
         if (b0 > 0) gptqb_far_kernel<<<dim3((unsigned)((b0 + 63) / 64), (unsigned)((m + 63) / 64)), 256, 0, s>>>(A);
         b1 = b0;
     }

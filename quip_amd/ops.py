@@ -1013,15 +1013,30 @@ def gptq_round_qfnb(W, FT, bits):
     # the sweep's workgroups wait for each other behind a BOUNDED poll (include/quip_amd.h): the abort word is read once the stream has
     # drained -- the callers synchronise right behind this call anyway (gptq.py: torch.cuda.synchronize() closes fasterquant's timer)
     off = int(lib.quipamd_gptq_qfnb_info_offset(m, d))
-    if m and d and int(ws[off:off + 4].view(torch.int32).item()) != 0:
+    code = int(ws[off:off + 4].view(torch.int32).item()) if m and d else 0
+    if code == 2:
+        # the one-XCD form's roll call failed before anything was written (fewer workgroups than needed became resident on that XCD):
+        # the same sweep once more with the exchange across the XCDs
+        short, spin, rows = _GB_DEBUG
+        lib.quipamd_gptq_qfnb_debug(short, spin, 1)
+        try:
+            _lib.call("quipamd_gptq_round_qfnb", _p(wt), _p(FT), int(bits), _p(qt), _p(cs), _p(ws), m, d, _stream())
+            code = int(ws[off:off + 4].view(torch.int32).item())
+        finally:
+            lib.quipamd_gptq_qfnb_debug(short, spin, rows)
+    if code != 0:
         raise _lib.QuipAmdError("quipamd_gptq_round_qfnb: the sweep was abandoned -- its workgroups were not all co-resident "
                                 "(is another grid / an RCCL collective holding compute units of this device?)")
     return qt.t().flip(1).contiguous(), cs.flip(0).contiguous()
 
 
+_GB_DEBUG = [0, 0, 0]
+
+
 def gptq_qfnb_debug(short_grid=0, spin_limit=0, force_rows=0):
     """test / lab hook of csrc/gptq_qfnb.hip (quipamd_gptq_qfnb_debug): launch `short_grid` workgroups too few, give up after `spin_limit`
     polls, `force_rows` rows per workgroup"""
+    _GB_DEBUG[:] = [int(short_grid), int(spin_limit), int(force_rows)]
     _lib.load().quipamd_gptq_qfnb_debug(int(short_grid), int(spin_limit), int(force_rows))
 
 

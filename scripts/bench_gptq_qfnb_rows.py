@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quip_amd import ops  # noqa: E402
 
 dev = "cuda:0"
-for (m, d) in [(2048, 2048), (4096, 4096), (8192, 2048), (2048, 8192), (11008, 4096)]:
+for (m, d) in [(2048, 2048), (4096, 4096), (8192, 2048), (2048, 8192), (11008, 4096), (1024, 1024)]:
     torch.manual_seed(m + d)
     X = torch.randn(d + 256, d, device=dev)
     H = X.T @ X / (d + 256) + 0.01 * torch.eye(d, device=dev)
@@ -21,7 +21,7 @@ for (m, d) in [(2048, 2048), (4096, 4096), (8192, 2048), (2048, 8192), (11008, 4
     ref, cs_ref = ops.gptq_round_qfnb(W.clone(), FT, 2)
     step = 2.0 * cs_ref[None, :] / 3                                # grid step of every column (the criterion of tests/test_gpu_gptq_qfnb.py)
     row = {"shape": f"{m}x{d}"}
-    for R in (0, 16, 32, 64, 128):
+    for R in (0, 1, 64):                                              # 0 default (one XCD up to 4096 rows), 1 pipelined across the XCDs, 64 rounds 3-5
         ops.gptq_qfnb_debug(0, 0, R)
         try:
             try:

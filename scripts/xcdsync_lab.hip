@@ -7,7 +7,7 @@
 #include <cstdio>
 #include <vector>
 
-template <int SCOPE>
+template <int SCOPE, int LSCOPE = SCOPE>
 __global__ __launch_bounds__(64) void gather_rounds(unsigned long long *gran, int G, int rounds, int stride, int *errors, int *xcc, long long limit)
 {
     if (blockIdx.x % stride) return;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64) void gather_rounds(unsigned long long *gran, in
             unsigned long long v;
             long long spins = 0;
             for (;;) {
-                v = __hip_atomic_load(gr + i, __ATOMIC_RELAXED, SCOPE);
+                v = __hip_atomic_load(gr + i, __ATOMIC_RELAXED, LSCOPE);
                 if ((unsigned)(v >> 32) == (unsigned)t) break;
                 if (++spins >= limit) { bad = true; break; }
             }
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void gather_rounds(unsigned long long *gran, in
     if (lane == 0) errors[wg] = err;
 }
 
-template <int SCOPE> void run(const char *name, int G, int stride, int rounds)
+template <int SCOPE, int LSCOPE = SCOPE> void run(const char *name, int G, int stride, int rounds)
 {
     unsigned long long *gran;
     int *errors, *xcc;
@@ -55,7 +55,7 @@ template <int SCOPE> void run(const char *name, int G, int stride, int rounds)
         hipMemset(errors, 0, sizeof(int) * G);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        gather_rounds<SCOPE><<<G * stride, 64>>>(gran, G, rounds, stride, errors, xcc, 1ll << 20);
+        gather_rounds<SCOPE, LSCOPE><<<G * stride, 64>>>(gran, G, rounds, stride, errors, xcc, 1ll << 20);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms;
@@ -75,9 +75,13 @@ template <int SCOPE> void run(const char *name, int G, int stride, int rounds)
 int main()
 {
     const int rounds = 2000;
-    for (int G : {32, 64, 128}) {
+    for (int G : {16, 32, 64}) {
         run<__HIP_MEMORY_SCOPE_AGENT>("agent", G, 1, rounds);
         run<__HIP_MEMORY_SCOPE_AGENT>("agent", G, 8, rounds);
+        // round 6: PLAIN (workgroup-scope) store -- written through, but the line stays in the XCD's L2 -- polled with sc1 (agent-scope) loads, which
+        // bypass the reader's L1 and are served by that L2: same-XCD only
+        run<__HIP_MEMORY_SCOPE_WORKGROUP, __HIP_MEMORY_SCOPE_AGENT>("st wg/ld ag", G, 8, rounds);
+        run<__HIP_MEMORY_SCOPE_WORKGROUP, __HIP_MEMORY_SCOPE_AGENT>("st wg/ld ag", G, 1, rounds);   // across XCDs: the control (stale or slow)
         run<__HIP_MEMORY_SCOPE_WORKGROUP>("workgroup", G, 8, rounds);
         run<__HIP_MEMORY_SCOPE_WORKGROUP>("workgroup", G, 1, rounds);          // across XCDs: expected to fail (stale) or abort -- the control
     }

@@ -92,3 +92,63 @@ def test_a_grid_that_is_not_co_resident_is_an_error_not_a_hang():
         ops.gptq_qfnb_debug(0, 0, 0)
     again, _ = ops.gptq_round_qfnb(W.clone(), FT, 2)                  # the device and the library are fine afterwards
     assert torch.equal(again, good)
+
+
+@pytest.mark.parametrize("m,d", [(200, 256), (2048, 384), (2100, 256), (4096, 256)])
+def test_every_chain_form_gives_the_same_sweep(m, d):
+    """round 6: the pipelined chain on one XCD (default up to 4096 rows; 1 / 2 chain waves per workgroup), the pipelined chain across the
+    XCDs (forced: 1) and the barrier-per-phase chain of rounds 3-5 (forced: 64) differ in the ORDER the column's squares are summed only:
+    the same gates as against the column walk, and each form deterministic."""
+    from quip_amd import ops
+    W, H = _fixture(m, d, m + d)
+    FT = ops.gptq_feedback(H)
+    outs = {}
+    try:
+        for form in (0, 1, 2, 64):
+            ops.gptq_qfnb_debug(0, 0, form)
+            q, cs = ops.gptq_round_qfnb(W.clone(), FT, 2)
+            q2, cs2 = ops.gptq_round_qfnb(W.clone(), FT, 2)
+            assert torch.equal(q, q2) and torch.equal(cs, cs2), form
+            outs[form] = (q, cs)
+    finally:
+        ops.gptq_qfnb_debug(0, 0, 0)
+    assert torch.equal(outs[0][0], outs[2][0])                          # the default at these sizes IS the one-XCD form
+    ref, csr = outs[64]
+    step = 2.0 * csr[None, :] / 3
+    for form in (0, 1):
+        flipped = ((outs[form][0] - ref).abs() > 0.25 * step).float().mean().item()
+        assert flipped <= 2e-3, (form, flipped)
+        assert float((outs[form][1] - csr).abs().max() / csr.abs().max()) <= 1e-4
+
+
+def test_one_xcd_roll_call_failure_falls_back_without_touching_anything():
+    """the one-XCD form's first exchange is its roll call: with a participant missing (test hook) it raises abort word 2 before anything is
+    written, ops repeats the sweep across the XCDs -- where the same hook makes it fail for good: the error of the co-residency test; with
+    the hook lifted in between (spin limit only) the repeated sweep completes and equals the forced cross-XCD run."""
+    from quip_amd import _lib, ops
+    m, d = 512, 256
+    W, H = _fixture(m, d, 5)
+    FT = ops.gptq_feedback(H)
+    ops.gptq_qfnb_debug(0, 0, 1)
+    try:
+        want, _ = ops.gptq_round_qfnb(W.clone(), FT, 2)
+    finally:
+        ops.gptq_qfnb_debug(0, 0, 0)
+    lib = _lib.load()
+    wt = W.flip(1).t().contiguous()
+    keep = wt.clone()
+    qt = torch.full_like(wt, 7.0)
+    cs = torch.full((d,), 7.0, device=DEV)
+    ws = torch.empty(int(lib.quipamd_gptq_qfnb_workspace_bytes(m, d)), dtype=torch.uint8, device=DEV)
+    ops.gptq_qfnb_debug(short_grid=1, spin_limit=20000, force_rows=2)
+    try:
+        _lib.call("quipamd_gptq_round_qfnb", ops._p(wt), ops._p(FT), 2, ops._p(qt), ops._p(cs), ops._p(ws), m, d, ops._stream())
+        off = int(lib.quipamd_gptq_qfnb_info_offset(m, d))
+        assert int(ws[off:off + 4].view(torch.int32).item()) == 2
+        assert torch.equal(wt, keep) and bool((qt == 7.0).all()) and bool((cs == 7.0).all())
+        ops.gptq_qfnb_debug(0, 0, 1)                                    # what ops does next (without the hook)
+        _lib.call("quipamd_gptq_round_qfnb", ops._p(wt), ops._p(FT), 2, ops._p(qt), ops._p(cs), ops._p(ws), m, d, ops._stream())
+        assert int(ws[off:off + 4].view(torch.int32).item()) == 0
+        assert torch.equal(qt.t().flip(1).contiguous(), want)
+    finally:
+        ops.gptq_qfnb_debug(0, 0, 0)
