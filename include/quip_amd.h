@@ -622,12 +622,12 @@ int quipamd_preproc_trace_ridge(float *H, int64_t d, float ridge, void *workspac
  * then undefined.  The call is asynchronous, so the caller reads that word once the stream has drained:
  *   int32 at byte quipamd_gptq_qfnb_info_offset(m, d) of `workspace`: 0 = the sweep completed, 1 = abandoned (treat as QUIPAMD_ERR_LAUNCH;
  *   quip_amd.ops.gptq_round_qfnb raises, quip_amd.gptq falls back to the column walk), 2 = NOTHING was written (WT_rev, QT_rev,
- *   colscale_rev untouched): up to 4096 rows the sweep runs on the workgroups of ONE XCD (their exchange goes through that XCD's L2: 0.55 us
+ *   colscale_rev untouched): up to 16384 rows the sweep runs on the workgroups of ONE XCD (their exchange goes through that XCD's L2: 0.55 us
  *   per column instead of 1.5-2.4), and fewer workgroups than it needs became resident there -- call quipamd_gptq_qfnb_debug(.., .., 1)
  *   and repeat the call (the exchange across the XCDs), as quip_amd.ops.gptq_round_qfnb does.
  * quipamd_gptq_qfnb_debug(short_grid, spin_limit, force_rows): test / lab hook -- `short_grid` workgroups too few take part and the rest
  * give up after `spin_limit` polls (exercises the abandon path on a healthy device); force_rows = 1: the pipelined chain across the XCDs,
- * 2: on one XCD (an error beyond 4096 rows), 16 | 32 | 64 | 128: the barrier-per-phase chain of rounds 3-5 with that many rows per
+ * 2: on one XCD (an error beyond 16384 rows), 16 | 32 | 64 | 128: the barrier-per-phase chain of rounds 3-5 with that many rows per
  * workgroup.  (0, 0, 0) restores the defaults. */
 int64_t quipamd_gptq_qfnb_workspace_bytes(int64_t m, int64_t d);
 int64_t quipamd_gptq_qfnb_info_offset(int64_t m, int64_t d);

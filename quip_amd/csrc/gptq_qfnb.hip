@@ -166,19 +166,21 @@ __global__ __launch_bounds__(GB_T) void gptqb_chain_kernel(GbArgs A)
 // XL -- the exchange confined to ONE XCD.  A plain store is written through but STAYS in the XCD's L2, and an sc1 load bypasses the reader's
 // L1 and is served by that L2 (MI355X_MICROARCH.md, "stores of each flavour"): between workgroups of one XCD an all-gather of 16-64
 // granules costs 0.55 us instead of 1.4-2.4 (profiles/r06o_xcdsync_lab.txt; across XCDs the same pair of instructions reads stale lines
-// forever -- the lab's control).  So for m <= 4096 rows the sweep runs on the 32 CUs of XCD `A.xcc`: a full grid of one-per-CU workgroups
+// forever -- the lab's control).  So up to 16384 rows the sweep runs on the 32 CUs of XCD `A.xcc`: a full grid of one-per-CU workgroups
 // is launched, every workgroup reads HW_REG_XCC_ID, the ones on that XCD claim a participant slot from a counter, everybody else leaves.
 // Nothing is assumed about which block lands where (HIP promises nothing; block b on XCD b % 8 is what is observed); what is needed is
 // that ceil(m / rows) workgroups of that XCD become resident.  The first column's exchange is the roll call: if it times out nothing
 // has been written yet, the abort word becomes 2 and the caller repeats the sweep with the cross-XCD form (ops.gptq_round_qfnb does).
-template <int NC, bool XL>                                            // chain waves per workgroup (rows = 64 NC)
-__global__ __launch_bounds__(GB_T * NC) void gptqb_chainp_kernel(GbArgs A)
+// More rows per workgroup (the one-XCD form beyond 4096 rows): NBK = 64 columns per lazy block and HP = 1 helper wave per chain wave keep
+// 256 / 512 rows x 64 columns + the 64 x 64 feedback tile within a workgroup's LDS and its 1024 threads.
+template <int NC, bool XL, int NBK = GB_NB, int HP = 3>               // chain waves per workgroup (rows = 64 NC)
+__global__ __launch_bounds__(64 * NC * (1 + HP)) void gptqb_chainp_kernel(GbArgs A)
 {
-    constexpr int R = 64 * NC;
+    constexpr int R = 64 * NC, NTH = 64 * NC * (1 + HP);
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     float *W1 = gsm;                                                  // [128][R]
-    float *F1 = gsm + GB_NB * R;                                      // [128][128]: F1[jl][cl] = FT[b0 + jl][b0 + cl]
-    float *gaveup = F1 + GB_NB * GB_NB;                               // [0] != 0: the sweep was abandoned (bounded poll below); [1]: the slot
+    float *F1 = gsm + NBK * R;                                        // [NBK][NBK]: F1[jl][cl] = FT[b0 + jl][b0 + cl]
+    float *gaveup = F1 + NBK * NBK;                                   // [0] != 0: the sweep was abandoned (bounded poll below); [1]: the slot
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NP = A.G, nb = A.nb, b0 = A.b0;                         // participants = workgroups that hold rows
     if (tid == 0) {
@@ -193,20 +195,20 @@ __global__ __launch_bounds__(GB_T * NC) void gptqb_chainp_kernel(GbArgs A)
     __syncthreads();
     const int wg = __builtin_bit_cast(int, gaveup[1]);
     if (wg < 0 || wg >= NP - (XL ? A.absent : 0) || gaveup[0] != 0.f) return;      // (uniform; `absent`: the test hook's missing workgroups)
-    const int chain = wave < NC ? wave : (wave - NC) / 3;             // the 64-row slice this wave works on
+    const int chain = wave < NC ? wave : (wave - NC) / HP;             // the 64-row slice this wave works on
     const int rl = chain * 64 + lane;
     const int64_t row = (int64_t)wg * R + rl;
     const bool live = row < A.m;
     const int64_t rowc = live ? row : A.m - 1;                        // (clamped address + select: a guarded load is a branch and a round trip)
-    for (int i = tid; i < nb * R; i += GB_T * NC) {
+    for (int i = tid; i < nb * R; i += NTH) {
         const int cl = i / R, r = i - cl * R;
         const int64_t rr = (int64_t)wg * R + r;
         const float v = A.WT[(int64_t)(b0 + cl) * A.m + (rr < A.m ? rr : A.m - 1)];
         W1[cl * R + r] = rr < A.m ? v : 0.f;
     }
-    for (int i = tid; i < nb * nb; i += GB_T * NC) {
+    for (int i = tid; i < nb * nb; i += NTH) {
         const int jl = i / nb, cl = i - jl * nb;
-        F1[jl * GB_NB + cl] = A.FT[(int64_t)(b0 + jl) * A.d + b0 + cl];
+        F1[jl * NBK + cl] = A.FT[(int64_t)(b0 + jl) * A.d + b0 + cl];
     }
     __syncthreads();
     (void)rowc;
@@ -256,21 +258,21 @@ __global__ __launch_bounds__(GB_T * NC) void gptqb_chainp_kernel(GbArgs A)
             if (!dead) W1[cl * R + rl] = res;
             __syncthreads();                                          // residual c is out; every residual > c has been applied to the columns < c
             if (gaveup[0] != 0.f) return;
-            if (cl > 0) w = fmaf(res, F1[(cl - 1) * GB_NB + cl], W1[(cl - 1) * R + rl]);
+            if (cl > 0) w = fmaf(res, F1[(cl - 1) * NBK + cl], W1[(cl - 1) * R + rl]);
             if (live) A.QT[(int64_t)cp * A.m + row] = q;             // (off the chain: behind the next column's value)
             if (wg == 0 && tid == 0) A.colscale[cp] = scale;
         }
     } else {
-        const int sub = (wave - NC) % 3;
+        const int sub = (wave - NC) % HP;
         for (int cl = nb - 1; cl >= 0; --cl) {
             __syncthreads();
             if (gaveup[0] != 0.f) return;
             const float e = W1[cl * R + rl];
-            for (int jl = cl - 2 - sub; jl >= 0; jl -= 3) W1[jl * R + rl] = fmaf(e, F1[jl * GB_NB + cl], W1[jl * R + rl]);   // cl - 2 first: the chain needs it next
+            for (int jl = cl - 2 - sub; jl >= 0; jl -= HP) W1[jl * R + rl] = fmaf(e, F1[jl * NBK + cl], W1[jl * R + rl]);   // cl - 2 first: the chain needs it next
         }
     }
     __syncthreads();
-    for (int i = tid; i < nb * R; i += GB_T * NC) {
+    for (int i = tid; i < nb * R; i += NTH) {
         const int cl = i / R, r = i - cl * R;
         const int64_t rr = (int64_t)wg * R + r;
         if (rr < A.m) A.ET[(int64_t)cl * A.m + rr] = W1[cl * R + r];
@@ -341,10 +343,10 @@ template <int R> int gb_chain(const GbArgs &A, hipStream_t s)
     return QUIPAMD_OK;
 }
 
-template <int NC, bool XL> int gb_chainp(const GbArgs &A, int grid, hipStream_t s)
+template <int NC, bool XL, int NBK = GB_NB, int HP = 3> int gb_chainp(const GbArgs &A, int grid, hipStream_t s)
 {
-    constexpr size_t lds = (size_t)(GB_NB * 64 * NC + GB_NB * GB_NB + 4) * sizeof(float);
-    auto kern = gptqb_chainp_kernel<NC, XL>;
+    constexpr size_t lds = (size_t)(NBK * 64 * NC + NBK * NBK + 4) * sizeof(float);
+    auto kern = gptqb_chainp_kernel<NC, XL, NBK, HP>;
     static QaPerDevice attr;
     const int dv = attr.dev();
     if (dv < 0 || !attr.done[dv]) {
@@ -353,16 +355,16 @@ template <int NC, bool XL> int gb_chainp(const GbArgs &A, int grid, hipStream_t 
         if (dv >= 0) attr.done[dv] = true;
     }
     if (!XL) grid -= g_gb_debug_short_grid;                             // (XL: GbArgs.absent -- which blocks land on the XCD is not the host's to say)
-    kern<<<(unsigned)(grid > 0 ? grid : 1), GB_T * NC, lds, s>>>(A);
+    kern<<<(unsigned)(grid > 0 ? grid : 1), 64 * NC * (1 + HP), lds, s>>>(A);
     return QUIPAMD_OK;
 }
-template <int NC, bool XL> bool gb_chainp_fits(int64_t blocks, int ncu)
+template <int NC, bool XL, int NBK = GB_NB, int HP = 3> bool gb_chainp_fits(int64_t blocks, int ncu)
 {
-    constexpr size_t lds = (size_t)(GB_NB * 64 * NC + GB_NB * GB_NB + 4) * sizeof(float);
-    auto kern = gptqb_chainp_kernel<NC, XL>;
+    constexpr size_t lds = (size_t)(NBK * 64 * NC + NBK * NBK + 4) * sizeof(float);
+    auto kern = gptqb_chainp_kernel<NC, XL, NBK, HP>;
     int per_cu = 0;
     return hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, GB_T * NC, lds) == hipSuccess && blocks <= (int64_t)per_cu * ncu;
+           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, 64 * NC * (1 + HP), lds) == hipSuccess && blocks <= (int64_t)per_cu * ncu;
 }
 
 }   // namespace
@@ -387,7 +389,7 @@ extern "C" int64_t quipamd_gptq_qfnb_workspace_bytes(int64_t m, int64_t d)
 {
     (void)d;
     // residuals of a block + two granules per possible workgroup + 64 bytes (abort word) + one participant counter per lazy block
-    return (int64_t)GB_NB * m * 4 + 2 * ((m + 15) / 16) * 8 + 64 + 4 * ((d + GB_NB - 1) / GB_NB + 1);
+    return (int64_t)GB_NB * m * 4 + 2 * ((m + 15) / 16) * 8 + 64 + 4 * ((d + 63) / 64 + 1);
 }
 
 extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits, float *QT_rev, float *colscale_rev, void *workspace,
@@ -410,18 +412,23 @@ extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits,
         return (m + R - 1) / R <= (int64_t)per_cu * ncu;
     };
     int R = 0;
-    // form: 0 barrier-per-phase chain (rounds 3-5), 1 pipelined across the XCDs, 2 / 3 pipelined on one XCD with 1 / 2 chain waves per workgroup
+    // form: 0 barrier-per-phase chain (rounds 3-5), 1 pipelined across the XCDs, 2 / 3 / 4 / 5 pipelined on one XCD with 1 / 2 / 4 / 8 chain waves
+    // (64 / 128 / 256 / 512 rows) per workgroup
     int form = 0;
     if (g_gb_force_rows == 0 || g_gb_force_rows == 2) {
         // one XCD = ncu / 8 compute units, one workgroup each; the full grid of ncu one-per-CU workgroups must be resident
         if (ncu % 8 == 0 && m <= (int64_t)64 * (ncu / 8) && gb_chainp_fits<1, true>(ncu, ncu)) form = 2;
         else if (ncu % 8 == 0 && m <= (int64_t)128 * (ncu / 8) && gb_chainp_fits<2, true>(ncu, ncu)) form = 3;
-        QA_REQUIRE(form != 0 || g_gb_force_rows == 0, QUIPAMD_ERR_UNSUPPORTED, "gptq_round_qfnb: %lld rows do not fit one XCD (%d CUs / 8 x 128 rows)",
+        else if (ncu % 8 == 0 && m <= (int64_t)256 * (ncu / 8) && gb_chainp_fits<4, true, 64, 3>(ncu, ncu)) form = 4;   // 64-column lazy blocks from here on
+        else if (ncu % 8 == 0 && m <= (int64_t)512 * (ncu / 8) && gb_chainp_fits<8, true, 64, 1>(ncu, ncu)) form = 5;
+        QA_REQUIRE(form != 0 || g_gb_force_rows == 0, QUIPAMD_ERR_UNSUPPORTED, "gptq_round_qfnb: %lld rows do not fit one XCD (%d CUs / 8 x 512 rows)",
                    (long long)m, ncu);
     }
     if (form == 0 && (g_gb_force_rows == 0 || g_gb_force_rows == 1) && gb_chainp_fits<1, false>((m + 63) / 64, ncu)) form = 1;
     if (form == 1 || form == 2) R = 64;
     else if (form == 3) R = 128;
+    else if (form == 4) R = 256;
+    else if (form == 5) R = 512;
     else if (g_gb_force_rows == 16 && fits(16, (const void *)gptqb_chain_kernel<16>)) R = 16;
     else if (g_gb_force_rows == 32 && fits(32, (const void *)gptqb_chain_kernel<32>)) R = 32;
     else if (g_gb_force_rows == 64 && fits(64, (const void *)gptqb_chain_kernel<64>)) R = 64;
@@ -435,6 +442,7 @@ extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits,
     QA_REQUIRE(R != 0, QUIPAMD_ERR_UNSUPPORTED, "gptq_round_qfnb: %lld rows do not fit this device as one grid of co-resident workgroups (%d CUs)",
                (long long)m, ncu);
     const int64_t G = (m + R - 1) / R;
+    const int64_t NBmax = form >= 4 ? 64 : GB_NB;                         // columns per lazy block
     hipStream_t s = (hipStream_t)stream;
     GbArgs A;
     A.WT = WT_rev; A.FT = FT; A.QT = QT_rev; A.colscale = colscale_rev;
@@ -446,16 +454,17 @@ extern "C" int quipamd_gptq_round_qfnb(float *WT_rev, const float *FT, int bits,
     A.claim = A.abort_flag + 16;                                          // (behind the 64 spare bytes)
     A.xcc = 0; A.first = 1; A.absent = g_gb_debug_short_grid;
     // granules, the abort flag behind them and the participant counters (2 * ceil(m / 16) * 8 bytes of granule space + 64 spare + counters, all zeroed)
-    if (hipMemsetAsync(A.gran, 0, (size_t)(2 * ((m + 15) / 16) * 8 + 64 + 4 * ((d + GB_NB - 1) / GB_NB + 1)), s) != hipSuccess)
+    if (hipMemsetAsync(A.gran, 0, (size_t)(2 * ((m + 15) / 16) * 8 + 64 + 4 * ((d + 63) / 64 + 1)), s) != hipSuccess)
         return qa_fail(QUIPAMD_ERR_LAUNCH, "gptq_round_qfnb: memset failed");
     // lazy blocks from the top of the reversed order; block edges at multiples of 128, so a remainder of d is the FIRST block (where a
     // block ends only decides when its residuals reach the columns behind it, not what they are)
     int64_t b1 = d;
     while (b1 > 0) {
-        const int64_t nb = (b1 % GB_NB) ? (b1 % GB_NB) : GB_NB;
+        const int64_t nb = (b1 % NBmax) ? (b1 % NBmax) : NBmax;
         const int64_t b0 = b1 - nb;
         A.b0 = (int)b0; A.nb = (int)nb;
-        int rc = form == 3 ? gb_chainp<2, true>(A, ncu, s) : form == 2 ? gb_chainp<1, true>(A, ncu, s) : form == 1 ? gb_chainp<1, false>(A, (int)G, s)
+        int rc = form == 5 ? gb_chainp<8, true, 64, 1>(A, ncu, s) : form == 4 ? gb_chainp<4, true, 64, 3>(A, ncu, s)
+                 : form == 3 ? gb_chainp<2, true>(A, ncu, s) : form == 2 ? gb_chainp<1, true>(A, ncu, s) : form == 1 ? gb_chainp<1, false>(A, (int)G, s)
                  : R == 128 ? gb_chain<128>(A, s) : R == 64 ? gb_chain<64>(A, s) : R == 32 ? gb_chain<32>(A, s) : gb_chain<16>(A, s);
         if (rc != QUIPAMD_OK) return rc;
         A.claim += 1;

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quip_amd import ops  # noqa: E402
 
 dev = "cuda:0"
-for (m, d) in [(2048, 2048), (4096, 4096), (8192, 2048), (2048, 8192), (11008, 4096), (1024, 1024)]:
+for (m, d) in [(2048, 2048), (4096, 4096), (8192, 2048), (2048, 8192), (11008, 4096), (1024, 1024), (16384, 2048)]:
     torch.manual_seed(m + d)
     X = torch.randn(d + 256, d, device=dev)
     H = X.T @ X / (d + 256) + 0.01 * torch.eye(d, device=dev)

@@ -94,9 +94,10 @@ def test_a_grid_that_is_not_co_resident_is_an_error_not_a_hang():
     assert torch.equal(again, good)
 
 
-@pytest.mark.parametrize("m,d", [(200, 256), (2048, 384), (2100, 256), (4096, 256)])
+@pytest.mark.parametrize("m,d", [(200, 256), (2048, 384), (2100, 256), (4096, 256), (8192, 208), (11008, 128), (16384, 96)])
 def test_every_chain_form_gives_the_same_sweep(m, d):
-    """round 6: the pipelined chain on one XCD (default up to 4096 rows; 1 / 2 chain waves per workgroup), the pipelined chain across the
+    """round 6: the pipelined chain on one XCD (default up to 16384 rows; 1 / 2 / 4 / 8 chain waves per workgroup, 64-column lazy blocks beyond
+    4096 rows), the pipelined chain across the
     XCDs (forced: 1) and the barrier-per-phase chain of rounds 3-5 (forced: 64) differ in the ORDER the column's squares are summed only:
     the same gates as against the column walk, and each form deterministic."""
     from quip_amd import ops
