@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / heads, head = blockIdx.x % heads;
     QA_STAMP(0);
+    QA_LOG(0)
     const int64_t pos = *pos_p, T = pos + 1;
     QA_STAMP(1);                                                    // the position landed
     const S *qh = q + (int64_t)b * ldq + head * HD, *kh = k + (int64_t)b * ldq + head * HD, *vh = v + (int64_t)b * ldq + head * HD;
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename DT<TI>:
     }
     qa_touch_done(sink);
     QA_STAMP(12);
+    QA_LOG(1)
 }
 
 template <class TI, int HD>

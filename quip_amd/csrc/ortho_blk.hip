@@ -162,6 +162,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
     const int gr0 = blockIdx.z * BK_MAXR;                              // this workgroup's rows: gr0 .. gr0 + R - 1
     const int R = S.rows - gr0 < BK_MAXR ? S.rows - gr0 : BK_MAXR;
     QA_STAMP(0);
+    QA_LOG(0)
 
     const bool has_gu = S.gate_up != nullptr, has_cs = S.colscale != nullptr;
     const void *gup = has_gu ? S.gate_up : S.in;
@@ -676,6 +677,7 @@ __global__ __launch_bounds__(BK_T) void blk_stage_kernel(BlkStages SS)
         }
     }
     QA_STAMP(11);
+    QA_LOG(1)
 }
 
 size_t blk_lds(const BlkStage &S, bool fused)

@@ -25,8 +25,36 @@ struct QaProbeReg {
             if (qa_p_) qa_p_[(threadIdx.x >> 6) * 16 + (i)] = __builtin_amdgcn_s_memtime();                                            \
         }                                                                                                                               \
     } while (0)
+// QA_LOG(0) / QA_LOG(1) at a kernel's first / last statement, both at function scope (round 6): thread 0 of EVERY workgroup records its start and
+// end in s_memrealtime ticks (100 MHz, one counter for the whole device) -- no atomics on the way (a log appended through one atomic counter
+// made a 384-workgroup launch 15 us longer): buf[256] is a LAUNCH counter that workgroup 0 of an instrumented launch bumps when it ends and every
+// workgroup of the next one reads when it starts (the kernel boundary orders the two), and a workgroup's record is slot
+// (launch % 1024) * 1024 + workgroup of the table behind buf[258] (two words: start, end).  buf[257] != 0 switches it on.
+// scripts/decode_wglog.py replays the engine's graph and splits a launch's period into dispatch skew, body, tail and the true gap.
+#define QA_LOG_0                                                                                                                        \
+    unsigned long long qa_lt0_ = 0, qa_lseq_ = 0;                                                                                       \
+    if (threadIdx.x == 0) {                                                                                                             \
+        unsigned long long *qa_p_ = qa_probe_ptr;                                                                                       \
+        if (qa_p_ && qa_p_[257]) {                                                                                                      \
+            qa_lt0_ = __builtin_amdgcn_s_memrealtime();                                                                                 \
+            qa_lseq_ = __hip_atomic_load(qa_p_ + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                                      \
+        }                                                                                                                               \
+    }
+#define QA_LOG_1                                                                                                                        \
+    if (threadIdx.x == 0 && qa_lt0_) {                                                                                                  \
+        unsigned long long *qa_p_ = qa_probe_ptr;                                                                                       \
+        const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                                            \
+        if (wg_ < 1024u) {                                                                                                              \
+            unsigned long long *r_ = qa_p_ + 258 + ((qa_lseq_ & 1023ull) * 1024ull + wg_) * 2ull;                                       \
+            r_[0] = qa_lt0_;                                                                                                            \
+            r_[1] = __builtin_amdgcn_s_memrealtime();                                                                                   \
+        }                                                                                                                               \
+        if (wg_ == 0) atomicAdd(qa_p_ + 256, 1ull);                                                                                     \
+    }
+#define QA_LOG(e) QA_LOG_##e
 #else
 #define QA_STAMP(i)                                                                                                                     \
     do {                                                                                                                                \
     } while (0)
+#define QA_LOG(e)
 #endif
