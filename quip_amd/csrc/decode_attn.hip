@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / G.heads, head = blockIdx.x % G.heads;
     QA_STAMP(0);
+    QA_LOG(0)
     const int64_t pos = *G.pos, T = pos + 1;
     QA_STAMP(1);                                                      // the position landed (first dependent round trip)
     if (pos < 0 || pos >= G.maxlen) return;                         // uniform; a full cache is the caller's error
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     }
     qa_touch_done(sink);
     QA_STAMP(12);
+    QA_LOG(1)
 }
 
 template <int HD, int P, int Q> int launch_attn_u(const AttnUArgs &A, int64_t bs, hipStream_t s)

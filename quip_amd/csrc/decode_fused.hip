@@ -194,6 +194,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     const int bs = G.bs;
     const int b_lo = OPS ? (int)blockIdx.x : 0, b_hi = OPS ? b_lo + 1 : bs;     // the batch rows this workgroup's prologue walks
     FG_STAMP(0);
+    QA_LOG(0)
 
     // ---- every operand of the prologue is requested NOW, in the order the phases consume them; the packed weights go LAST: vector
     // memory returns in order (s_waitcnt vmcnt counts from the oldest), so a wait for the first activations behind a cold HBM
@@ -520,6 +521,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         }
     }
     FG_STAMP(15);
+    QA_LOG(1)
 }
 
 // ---- n = 8192 (OPT's fc1 -> fc2 hand-over): t = relu(U^T y + bias) feeds x~ = V (t (/) s) with no norm and no residual in between ------
@@ -566,6 +568,7 @@ __global__ __launch_bounds__(1024) void fused_pair_kernel(FusedArgs G, float two
     const int j = lane & 15, g = lane >> 4;
     const int bs = G.bs;
     FG_STAMP(0);
+    QA_LOG(0)
     FG_WSTAMP(0);
 
     // ---- requests, in the order of use: the row, U's fragments | (barrier) | the pair tables, V's fragments, the weights ---------------
@@ -704,6 +707,7 @@ __global__ __launch_bounds__(1024) void fused_pair_kernel(FusedArgs G, float two
         }
     }
     FG_STAMP(15);
+    QA_LOG(1)
 }
 
 template <int P, int Q, int BITS> int launch_pair(const FusedArgs &A, float maxq, hipStream_t s)
