@@ -34,6 +34,14 @@
 #else
 #define QA_SHF 1
 #endif
+// A/B builds (--variant unc -DQA_UNC): the prologue's per-thread operand loads unconditional -- threads past the row's last 4-element group read
+// group 0 again -- so that hipcc's vmcnt waits count them (a load behind `if (v4 < N / 4)` is not counted: the wait for the ROW, the oldest
+// load, becomes a wait for every operand requested behind it; csrc/ortho_blk.hip gained 2000 clocks per launch from this)
+#ifdef QA_UNC
+#define QA_UNCOND 1
+#else
+#define QA_UNCOND 0
+#endif
 
 namespace {
 
@@ -208,7 +216,8 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     auto load_u_row = [&](int b) {                                              // what the first scatter needs: the row itself, in ZT order
 #pragma unroll
         for (int u = 0; u < NCV; ++u) {
-            const int c = tid + 1024 * u;
+            const int c0_ = tid + 1024 * u;
+            const int c = QA_UNCOND ? (c0_ < N / 8 ? c0_ : 0) : c0_;
             if (c < N / 8) {
                 if constexpr (YF32) {
                     const float *src = reinterpret_cast<const float *>(G.u_y) + (int64_t)b * N + (uint32_t)(8 * c);
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     auto load_u_side = [&](int b) {
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-            const int v4 = tid + 1024 * u;
+            const int v4_ = tid + 1024 * u, v4 = QA_UNCOND ? (v4_ < N / 4 ? v4_ : 0) : v4_;
             rs[u] = make_uint2(0u, 0u);
             if (v4 < N / 4) {
                 st[u] = *reinterpret_cast<const uint2 *>(G.U.store_idx + 4 * v4);
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     auto load_v_side = [&]() {
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-            const int v4 = tid + 1024 * u;
+            const int v4_ = tid + 1024 * u, v4 = QA_UNCOND ? (v4_ < N / 4 ? v4_ : 0) : v4_;
             gm[u] = bt_[u] = make_uint2(0u, 0u);
             if (v4 < N / 4) {
                 if (NORM) gm[u] = *reinterpret_cast<const uint2 *>(G.gamma + 4 * v4);
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
     auto load_x_row = [&](int b) {
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-            const int v4 = tid + 1024 * u;
+            const int v4_ = tid + 1024 * u, v4 = QA_UNCOND ? (v4_ < N / 4 ? v4_ : 0) : v4_;
             xr[u] = make_uint2(0u, 0u);
             if (v4 < N / 4) xr[u] = *reinterpret_cast<const uint2 *>((G.x + (int64_t)b * G.ldx) + (uint32_t)(4 * v4));
         }
