@@ -339,3 +339,39 @@ def test_two_launch_policy_of_a_decode_step():
             assert quant.two_launch_from(NS(infeatures=4096, outfeatures=4096)) == want
     finally:
         quant.TWO_LAUNCH_ROWS = keep
+
+
+def test_float_reciprocal_division_of_the_blocked_stage_is_exact():
+    """csrc/ortho_blk.hip `bk_div`: int((float(a) + 0.5f) * (1.0f / d)) == a // d for 0 <= a < 2^22 -- the kernel replaced a dozen integer
+    divisions by run-time divisors (~50 instructions each on a wave that issues one instruction every 4+ clocks) with this.  Checked here in
+    float32 arithmetic as the device does it (round to nearest, no fused contraction: -ffp-contract=off), for every divisor the kernel can
+    meet (n / 8 chunks per row, P / 8 chunks per factor row, P) and every dividend up to 2^22."""
+    import numpy as np
+    a = np.arange(0, 1 << 22, dtype=np.int64)
+    af = a.astype(np.float32) + np.float32(0.5)
+    for d in list(range(1, 130)) + [160, 192, 256, 320, 344, 512, 688, 768, 1024, 1376, 2048, 4095, 4096]:
+        rcp = np.float32(1.0) / np.float32(d)
+        q = (af * rcp).astype(np.int64)                                  # truncation of a non-negative float
+        assert np.array_equal(q, a // d), d
+
+
+def test_dpp_group_sums_of_the_blocked_stage():
+    """csrc/ortho_blk.hip sums the C chunk products of one first-stage dot product -- they sit in C adjacent lanes, C = 2 / 4 / 8 / 16 -- on the
+    DPP network: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror, as many steps as log2 C.  Lane-level emulation: after
+    the steps EVERY lane of a group holds the group's sum (the kernel lets the lane with chunk 0 write it), other groups untouched; and
+    csrc/wavered.h's wave sum (the four steps + four v_readlane) is the sum of all 64 lanes."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    lanes = np.arange(64)
+    src = [lanes ^ 1, lanes ^ 2, (lanes & ~7) | (7 - (lanes & 7)), (lanes & ~15) | (15 - (lanes & 15))]
+    for C, steps in ((2, 1), (4, 2), (8, 3), (16, 4)):
+        v = rng.integers(-1000, 1000, 64).astype(np.int64)              # integers: the check is about WHICH lanes meet, not rounding
+        want = v.reshape(64 // C, C).sum(1).repeat(C)
+        for s in range(steps):
+            v = v + v[src[s]]
+        assert np.array_equal(v, want), C
+    v = rng.integers(-1000, 1000, 64).astype(np.int64)
+    total = v.sum()
+    for s in range(4):
+        v = v + v[src[s]]
+    assert (v[0] + v[16]) + (v[32] + v[48]) == total
