@@ -28,14 +28,15 @@ def main():
     ap.add_argument("--blocked", action="store_true")
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--bits", type=int, default=2)
+    ap.add_argument("--bs", type=int, default=1)
     ap.add_argument("--tokens", type=int, default=2, help="tokens logged (the table holds 1024 launches)")
     a = ap.parse_args()
     from quip_amd import _lib, decode
     import decode_engine_bench as B
     model, nbytes, arch = B.build(a)
     dev = torch.device("cuda:0")
-    eng = decode.DecodeEngine(model, bs=1, max_len=160, mode="auto")
-    ids = torch.randint(0, 30000, (1, 128), device=dev)
+    eng = decode.DecodeEngine(model, bs=a.bs, max_len=160, mode="auto")
+    ids = torch.randint(0, 30000, (a.bs, 128), device=dev)
     for i in range(96):                                                 # fill the cache, capture and warm the graph
         eng.forward(ids[:, i])
     torch.cuda.synchronize()
