@@ -62,6 +62,7 @@ SIGNATURES = {
     "quipamd_ortho_blocked_rows": [c_vp, c_vp, c_vp],
     "quipamd_ortho_blocked_rows_multi": [c_vp, c_int, c_vp, c_vp],
     "quipamd_ortho_blocked_config": [c_int, c_int],
+    "quipamd_decode_attention_config": [c_int],
     "quipamd_decode_fused_gemm": [c_vp, c_vp],
     "quipamd_decode_bigp_supported": [c_int, c_int],
     "quipamd_decode_bigp_u": [c_vp, c_int, c_int, c_i64, c_vp, c_i64, c_vp],
@@ -114,7 +115,7 @@ def load():
             raise QuipAmdError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == "quipamd_last_error" else None if name in ("quipamd_vecquant_invalidate", "quipamd_cholesky_config", "quipamd_ldlq_config", "quipamd_gptq_qfnb_debug", "quipamd_ortho_blocked_config",
-                                                                                                      "quipamd_dequant_gemm_grouped_config") else
+                                                                                                      "quipamd_dequant_gemm_grouped_config", "quipamd_decode_attention_config") else
                       c_i64 if name in ("quipamd_hessian_fast_workspace", "quipamd_vecquant_workspace_bytes", "quipamd_gptq_qfnb_workspace_bytes", "quipamd_gptq_qfnb_info_offset", "quipamd_preproc_workspace_bytes") else c_int)
     _lib = lib
     return lib

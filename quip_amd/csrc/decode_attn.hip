@@ -546,11 +546,10 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     QA_LOG(1)
 }
 
-template <int HD, int P, int Q> int launch_attn_u(const AttnUArgs &A, int64_t bs, hipStream_t s)
+template <int HD, int P, int Q, int NGRP> int launch_attn_u_n(const AttnUArgs &A, int64_t bs, hipStream_t s)
 {
     typedef PassDims<P, Q, 4> D;
     const size_t lds = 3 * D::BYTES + 3 * HD * 2 + 32 + (size_t)(A.maxlen + 8 + 4 * HD) * sizeof(float);
-    constexpr int NGRP = 3;
     auto kern = decode_attn_u_kernel<HD, P, Q, NGRP>;
     static size_t reserved[64] = {};
     int dev = 0;
@@ -568,6 +567,18 @@ template <int HD, int P, int Q> int launch_attn_u(const AttnUArgs &A, int64_t bs
     kern<<<(unsigned)(bs * A.heads) + (Ap.pf.n ? QA_PF_WGS : 0), 256 * NGRP, lds, s>>>(Ap);
     QA_LAUNCH_CHECK("decode_attention_fused");
     return QUIPAMD_OK;
+}
+
+// Round 6 (profiles/r06C_decode_wglog_kron_bs16.txt): at 16 sequences the launch is 512 workgroups of 12 waves at 120 registers -- one per CU,
+// TWO rounds (first -> last workgroup start 4.25 us, the launch 9.7 us).  The four-wave form (one wave group runs the three operator passes in
+// turn; two workgroups share a CU: one round) was built against that and is SLOWER: OPT-1.3B 16 sequences 1.41-1.42 -> 1.45 ms per step,
+// Llama-2-7B 2.98 -> 3.07, 8 sequences equal (profiles/r06D_attn_forms.jsonl) -- what the second round cost, the serial passes and two workgroups
+// on one CU's memory path cost again.  Kept as a forced form (quipamd_decode_attention_config), off by default.
+int g_attn_u_one_group_from = 0;       // workgroups from which the 4-wave form is launched (0 = never)
+template <int HD, int P, int Q> int launch_attn_u(const AttnUArgs &A, int64_t bs, hipStream_t s)
+{
+    if (g_attn_u_one_group_from > 0 && bs * A.heads >= g_attn_u_one_group_from) return launch_attn_u_n<HD, P, Q, 1>(A, bs, s);
+    return launch_attn_u_n<HD, P, Q, 3>(A, bs, s);
 }
 
 }   // namespace
@@ -756,6 +767,8 @@ extern "C" int quipamd_argmax_rows(const void *x, int dtype, int64_t rows, int64
     QA_LAUNCH_CHECK("quipamd_argmax_rows");
     return QUIPAMD_OK;
 }
+
+extern "C" void quipamd_decode_attention_config(int one_group_from) { g_attn_u_one_group_from = one_group_from < 0 ? 0 : one_group_from; }
 
 extern "C" int quipamd_decode_attention_fused(const quipamd_fop *U, const void *const *y, const void *const *bias, void *kcache, void *vcache,
                                               const int64_t *pos, void *out, const float *cos_table, const float *sin_table,

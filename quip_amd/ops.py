@@ -571,6 +571,12 @@ BLK_FUSED_N = 2048                 # csrc/ortho_blk.hip's default: one launch pe
 BLK_FUSED_ROWS = 4                 # ... and up to this many rows
 
 
+def decode_attention_config(one_group_from=0):
+    """csrc/decode_attn.hip: from this many (sequence, head) workgroups on the fused attention launch takes its 4-wave form (two workgroups per CU:
+    one round at 16 sequences -- measured slower, off by default); 0 = always the 12-wave form"""
+    _lib.load().quipamd_decode_attention_config(int(one_group_from))
+
+
 def ortho_blocked_config(max_fused_n=BLK_FUSED_N, max_fused_rows=BLK_FUSED_ROWS):
     """csrc/ortho_blk.hip: one launch per operator for n = p q up to `max_fused_n` and `max_fused_rows` rows (where the input rows fit LDS),
     two stage launches beyond; 0 / False = always two, True = wherever it fits (A/B runs, tests)"""

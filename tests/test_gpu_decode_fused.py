@@ -246,6 +246,39 @@ def test_attention_with_the_output_side_operators_in_its_prologue(n, heads, hd, 
     assert float((got.float() - want.float()).norm() / want.float().norm()) <= 3e-3
 
 
+@pytest.mark.parametrize("n,heads,hd,rope,pos", [(2048, 32, 64, False, 37), (2048, 32, 64, False, 300), (4096, 32, 128, True, 21)])
+def test_attention_four_wave_form_equals_the_twelve_wave_form(n, heads, hd, rope, pos):
+    """round 6: quipamd_decode_attention_config forces the 4-wave form of the fused attention launch (one wave group runs U_q, U_k, U_v in turn;
+    built for grids of more workgroups than CUs, measured slower, off by default): same values in the same order -- output and cache rows bit
+    for bit."""
+    from quip_amd import ops
+    from quip_amd.quant import fused_attention
+    qkv = [_layer(n, n, 700 + i + n % 13)[0] for i in range(3)]
+    maxlen, bs = (64 if pos < 64 else 384), 2
+    torch.manual_seed(n + pos)
+    kc0 = (0.5 * torch.randn(bs, heads, maxlen, hd, device=DEV)).half()
+    vc0 = (0.5 * torch.randn(bs, heads, maxlen, hd, device=DEV)).half()
+    ys = [(0.5 * torch.randn(bs, n, device=DEV)).half() for _ in range(3)]
+    p_t = torch.tensor([pos], device=DEV)
+    cos = sin = None
+    if rope:
+        inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+        emb = torch.cat([torch.outer(torch.arange(maxlen, dtype=torch.float32), inv)] * 2, -1)
+        cos, sin = emb.cos().to(DEV).contiguous(), emb.sin().to(DEV).contiguous()
+    outs = []
+    try:
+        for form in (0, 1):
+            ops.decode_attention_config(form)
+            kc, vc = kc0.clone(), vc0.clone()
+            got = fused_attention(qkv, [l.to_zt(y) for l, y in zip(qkv, ys)], kc, vc, p_t, cos, sin)
+            torch.cuda.synchronize()
+            outs.append((got.clone(), kc, vc))
+    finally:
+        ops.decode_attention_config()
+    for a, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.bfloat16])
 def test_argmax_rows_is_torch_argmax(dtype):
     from quip_amd import ops
