@@ -409,11 +409,12 @@ int quipamd_decode_fused_gemm(const quipamd_fused_gemm_args *args, void *stream)
 int quipamd_decode_attention_fused(const quipamd_fop *U, const void *const *y, const void *const *bias, void *kcache, void *vcache,
                                    const int64_t *pos, void *out, const float *cos_table, const float *sin_table, int64_t table_rows,
                                    int64_t bs, int heads, int hd, int64_t maxlen, float scale, int64_t ldo, void *stream);
-/* decode_attention_fused launches one workgroup per (sequence, head): 12 waves, three wave groups running U_q, U_k, U_v side by side.  From
- * `one_group_from` workgroups on, a 4-wave form whose one wave group runs the three operator passes in turn (two workgroups share a CU: 512
- * workgroups are one round instead of two).  Measured slower at 16 sequences (csrc/decode_attn.hip), so the default is 0 = never; A/B runs
- * and tests force it.  Both forms compute the same values in the same order. */
-void quipamd_decode_attention_config(int one_group_from);
+/* decode_attention_fused launches one workgroup per (sequence, head): 12 waves, three wave groups running U_q, U_k, U_v side by side, two of
+ * which leave after their pass.  From `three_heads_from` (sequence, head) pairs on (default 257: more than one per CU) a workgroup serves THREE
+ * heads: the k and v groups stay and each group runs the attention of its own head -- a third of the workgroups and of the (redundant) operator
+ * passes; 0 = never, negative = the default.  `one_group_from`: a 4-wave form whose one wave group runs the three passes in turn (two
+ * workgroups per CU); measured slower (csrc/decode_attn.hip), default 0 = never.  All forms compute the same values in the same order. */
+void quipamd_decode_attention_config(int one_group_from, int three_heads_from);
 
 /* The output side of a packed layer on its own (the end of the last decoder block): out = [relu](U^T y + bias + residual), fp16.
  * U: the TRANSPOSED operator (quipamd_fop; 64 x 32, 64 x 64 or 128 x 64); y: fp16 [bs, n] in ZT order (see below); bias fp16 [n];

@@ -62,7 +62,7 @@ SIGNATURES = {
     "quipamd_ortho_blocked_rows": [c_vp, c_vp, c_vp],
     "quipamd_ortho_blocked_rows_multi": [c_vp, c_int, c_vp, c_vp],
     "quipamd_ortho_blocked_config": [c_int, c_int],
-    "quipamd_decode_attention_config": [c_int],
+    "quipamd_decode_attention_config": [c_int, c_int],
     "quipamd_decode_fused_gemm": [c_vp, c_vp],
     "quipamd_decode_bigp_supported": [c_int, c_int],
     "quipamd_decode_bigp_u": [c_vp, c_int, c_int, c_i64, c_vp, c_i64, c_vp],

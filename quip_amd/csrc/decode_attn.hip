@@ -272,7 +272,11 @@ struct AttnUArgs {
 // 256 threads go on to the gather, the rotary embedding and the attention itself.
 // (NGRP = 1 is the round-3a form: the three passes one after the other on 256 threads.  With q held as fp32 head dim 128 did not fit the 168
 //  registers of a 768-thread workgroup -- 43 spilled, 605 -> 594 tok/s on Llama -- so q is held as packed fp16 pairs now.)
-template <int HD, int P, int Q, int NGRP>
+// MH (round 6, with NGRP = 3): a workgroup serves THREE heads of its sequence -- after the operator passes (which produce the whole q, k, v rows
+// anyway: every workgroup of the one-head form redoes them for its single head) the k and v wave groups do not leave: each of the three groups
+// gathers ITS head's slices, appends, scores, softmax, p V in its own LDS region.  A third of the workgroups and of the redundant passes: at 16
+// sequences x 32 heads 176 workgroups in one round instead of 512 in two.
+template <int HD, int P, int Q, int NGRP, bool MH = false>
 __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
 {
     typedef uint16_t S;
@@ -282,8 +286,11 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     extern __shared__ __attribute__((aligned(16))) char smem_u[];
     // [3 image sets][q k v slices f16 3 x HD][scores maxlen][red 8][part 4 x HD]
     char *img = smem_u;
-    uint16_t *qkv = reinterpret_cast<uint16_t *>(smem_u + 3 * D::BYTES);
-    float *scores = reinterpret_cast<float *>(smem_u + 3 * D::BYTES + 3 * HD * 2 + 32);
+    static_assert(!MH || NGRP == 3, "three heads per workgroup ride on the three wave groups");
+    const size_t AB = (3 * HD * 2 + 32 + (size_t)(G.maxlen + 8 + 4 * HD) * sizeof(float) + 15) & ~(size_t)15;     // one group's attention buffers
+    char *abuf = smem_u + 3 * D::BYTES + (MH ? (size_t)(threadIdx.x >> 8) * AB : 0);
+    uint16_t *qkv = reinterpret_cast<uint16_t *>(abuf);
+    float *scores = reinterpret_cast<float *>(abuf + 3 * HD * 2 + 32);
     float *red = scores + G.maxlen, *part = red + 8;
     asm volatile("" ::"s"(G.U[0].F0), "s"(G.U[0].F1), "s"(G.U[0].store_idx), "s"(G.U[1].F0), "s"(G.U[1].F1),
                  "s"(G.U[1].store_idx), "s"(G.U[2].F0), "s"(G.U[2].F1), "s"(G.U[2].store_idx),
@@ -295,7 +302,11 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / G.heads, head = blockIdx.x % G.heads;
+    const int hpb = MH ? (G.heads + 2) / 3 : G.heads;                 // workgroups per sequence
+    const int b = blockIdx.x / hpb, head_ = MH ? (int)(blockIdx.x % hpb) * 3 + (wave >> 2) : (int)(blockIdx.x % hpb);
+    const bool active = head_ < G.heads;                              // (MH: the last workgroup of a sequence may hold fewer than three heads)
+    const int head = active ? head_ : 0;                              // an idle group walks head 0's addresses and stores nothing
+    const int ta = MH ? (tid & 255) : tid, wa = MH ? (wave & 3) : wave;   // thread / wave within the group that runs the attention
     QA_STAMP(0);
     QA_LOG(0)
     const int64_t pos = *G.pos, T = pos + 1;
@@ -331,9 +342,9 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     float rc[GR], rs_[GR];
 #pragma unroll
     for (int it = 0; it < GR; ++it) {
-        const int t = tid + 256 * it;
+        const int t = ta + 256 * it;
         gst[it] = 0; gbi[it] = 0; rc[it] = 1.f; rs_[it] = 0.f;
-        if (wave < 4 && t < 3 * HD) {                               // (the gather is the first 256 threads' job)
+        if ((MH || wave < 4) && t < 3 * HD) {                       // (the gather is the first 256 threads' job; MH: every group's, for its head)
             const int gop = t / HD, ge = t - gop * HD, i = head * HD + ge;
             gst[it] = gop == 0 ? G.U[0].store_idx[i] : gop == 1 ? G.U[1].store_idx[i] : G.U[2].store_idx[i];
             gbi[it] = gop == 0 ? G.bias[0][i] : gop == 1 ? G.bias[1][i] : G.bias[2][i];
@@ -352,10 +363,10 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     constexpr bool KPF = HD <= 64 && QA_KPF;
     uint4 kpre[KPF ? HD / 8 : 1];
     if constexpr (KPF) {
-        const int64_t tpre = tid < G.maxlen ? tid : 0;
+        const int64_t tpre = ta < G.maxlen ? ta : 0;
 #pragma unroll
         for (int e8 = 0; e8 < HD; e8 += 8) kpre[e8 / 8] = make_uint4(0u, 0u, 0u, 0u);
-        if (wave < 4) {                                               // the scoring group only (waves 4..11 leave after their operator pass)
+        if (MH || wave < 4) {                                         // the scoring group(s) only (one head: waves 4..11 leave after their operator pass)
 #pragma unroll
             for (int e8 = 0; e8 < HD; e8 += 8) kpre[e8 / 8] = *reinterpret_cast<const uint4 *>(kcb + tpre * HD + e8);
         }
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     // requests (vector memory returns in order: in front of them they would put an HBM round trip before the first activations)
     qa_sink_t sink = 0;                                               // (csrc/prefetch.h: the touches' destination, kept alive to the end)
     if constexpr (HD <= 64 && QA_KPF) {   // (no branch around the statement: threads past the end touch row T - 1 again)
-        const int64_t tt = tid < T ? tid : T - 1;
+        const int64_t tt = ta < T ? ta : T - 1;
         qa_touch_lines<HD * 2 / 128>(vcb + tt * HD, sink);
     }
     QA_STAMP(2);                                                      // every request of the prologue issued
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     }
     __syncthreads();
     QA_STAMP(6);                                                      // stage 2 + barrier
-    if (NGRP == 3 && wave >= 4) {                                     // the k and v groups are done (hardware barriers count live waves only)
+    if (NGRP == 3 && !MH && wave >= 4) {                              // the k and v groups are done (hardware barriers count live waves only)
         if constexpr (HD > 64 && QA_KPF) {
             // head dim 128: any early touch of the cache rows cost this instantiation a register array in scratch memory (it sits at its register
             // budget), so the waves that LEAVE here touch the K and V lines of the first 512 positions on their way out -- ~1000 clocks ahead
@@ -409,7 +420,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     }
 #pragma unroll
     for (int it = 0; it < GR; ++it) {
-        const int t = tid + 256 * it;
+        const int t = ta + 256 * it;
         if (t < 3 * HD) {
             constexpr int qsh = __builtin_ctz(Q);
             const int gop = t / HD;
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
         float r[GR];
 #pragma unroll
         for (int it = 0; it < GR; ++it) {
-            const int t = tid + 256 * it;
+            const int t = ta + 256 * it;
             r[it] = 0.f;
             if (t < 2 * HD) {
                 const int ge = t % HD;
@@ -436,7 +447,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < GR; ++it) {
-            const int t = tid + 256 * it;
+            const int t = ta + 256 * it;
             if (t < 2 * HD) qkv[t] = f32_to_f16_bits(r[it]);
         }
         __syncthreads();
@@ -444,7 +455,8 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     // append this token's k, v; the barrier makes them visible to the cache reads below
 #pragma unroll
     for (int it = 0; it < GR; ++it) {
-        const int t = tid + 256 * it;
+        const int t = ta + 256 * it;
+        if (!active) continue;
         if (t >= HD && t < 2 * HD) kcb[pos * HD + t - HD] = qkv[t];
         else if (t >= 2 * HD && t < 3 * HD) vcb[pos * HD + t - 2 * HD] = qkv[t];
     }
@@ -464,13 +476,13 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     uint4 vraw0[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int64_t t = (int64_t)wave * RS + (int64_t)u * 4 * RS + rsub;
+        const int64_t t = (int64_t)wa * RS + (int64_t)u * 4 * RS + rsub;
         vraw0[u] = t < T ? *reinterpret_cast<const uint4 *>(vcb + t * HD + 8 * ch) : make_uint4(0, 0, 0, 0);
     }
     float mx = -INFINITY;
-    for (int64_t t = tid; t < T; t += 256) {
+    for (int64_t t = ta; t < T; t += 256) {
         const S *row = kcb + t * HD;
-        const bool pre = KPF && t == tid;                             // first pass: the row came in with the prologue's requests
+        const bool pre = KPF && t == ta;                             // first pass: the row came in with the prologue's requests
         const bool own = t == pos;                                    // this token's row: from the LDS slice (k = qkv[HD .. 2 HD))
         float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
@@ -489,18 +501,18 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
         mx = fmaxf(mx, acc);
     }
     mx = wave_reduce<true>(mx);
-    if (lane == 0) red[wave] = mx;
+    if (lane == 0) red[wa] = mx;
     QA_STAMP(9);                                                      // scores: the K rows of the cache landed
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
-    for (int64_t t = tid; t < T; t += 256) {
+    for (int64_t t = ta; t < T; t += 256) {
         const float p_ = __expf(scores[t] - mx);
         scores[t] = p_;
         sum += p_;
     }
     sum = wave_reduce<false>(sum);
-    if (lane == 0) red[4 + wave] = sum;
+    if (lane == 0) red[4 + wa] = sum;
     __syncthreads();
     QA_STAMP(10);                                                     // softmax
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
     bool first = true;
-    for (int64_t tb = (int64_t)wave * RS; tb < T; tb += 4 * RS * 8) {
+    for (int64_t tb = (int64_t)wa * RS; tb < T; tb += 4 * RS * 8) {
         uint4 raw[8];
         float pw[8];
 #pragma unroll
@@ -533,24 +545,25 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
         for (int e = 0; e < 8; ++e) o[e] += __shfl_xor(o[e], off);
     if (rsub == 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) part[wave * HD + 8 * ch + e] = o[e];
+        for (int e = 0; e < 8; ++e) part[wa * HD + 8 * ch + e] = o[e];
     }
     QA_STAMP(11);                                                     // p V
     __syncthreads();
-    if (tid < HD) {
-        const float r = (part[tid] + part[HD + tid]) + (part[2 * HD + tid] + part[3 * HD + tid]);
-        DT<TI>::store(G.out + (int64_t)b * G.ldo + head * HD, tid, r * inv);
+    if (ta < HD && active) {
+        const float r = (part[ta] + part[HD + ta]) + (part[2 * HD + ta] + part[3 * HD + ta]);
+        DT<TI>::store(G.out + (int64_t)b * G.ldo + head * HD, ta, r * inv);
     }
     qa_touch_done(sink);
     QA_STAMP(12);
     QA_LOG(1)
 }
 
-template <int HD, int P, int Q, int NGRP> int launch_attn_u_n(const AttnUArgs &A, int64_t bs, hipStream_t s)
+template <int HD, int P, int Q, int NGRP, bool MH = false> int launch_attn_u_n(const AttnUArgs &A, int64_t bs, hipStream_t s)
 {
     typedef PassDims<P, Q, 4> D;
-    const size_t lds = 3 * D::BYTES + 3 * HD * 2 + 32 + (size_t)(A.maxlen + 8 + 4 * HD) * sizeof(float);
-    auto kern = decode_attn_u_kernel<HD, P, Q, NGRP>;
+    const size_t ab = (3 * HD * 2 + 32 + (size_t)(A.maxlen + 8 + 4 * HD) * sizeof(float) + 15) & ~(size_t)15;     // one group's attention buffers
+    const size_t lds = 3 * D::BYTES + (MH ? 3 : 1) * ab;
+    auto kern = decode_attn_u_kernel<HD, P, Q, NGRP, MH>;
     static size_t reserved[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -561,23 +574,28 @@ template <int HD, int P, int Q, int NGRP> int launch_attn_u_n(const AttnUArgs &A
             return qa_fail(QUIPAMD_ERR_LAUNCH, "decode_attention_fused: cannot reserve %zu B of LDS", lds);
         if (known) reserved[dev] = lds;
     }
+    const int64_t wgs = bs * (MH ? (A.heads + 2) / 3 : A.heads);
     AttnUArgs Ap = A;
     Ap.pf = qa_pf_take();
-    Ap.pf.first = (int)(bs * A.heads);
-    kern<<<(unsigned)(bs * A.heads) + (Ap.pf.n ? QA_PF_WGS : 0), 256 * NGRP, lds, s>>>(Ap);
+    Ap.pf.first = (int)wgs;
+    kern<<<(unsigned)wgs + (Ap.pf.n ? QA_PF_WGS : 0), 256 * NGRP, lds, s>>>(Ap);
     QA_LAUNCH_CHECK("decode_attention_fused");
     return QUIPAMD_OK;
 }
 
 // Round 6 (profiles/r06C_decode_wglog_kron_bs16.txt): at 16 sequences the launch is 512 workgroups of 12 waves at 120 registers -- one per CU,
-// TWO rounds (first -> last workgroup start 4.25 us, the launch 9.7 us).  The four-wave form (one wave group runs the three operator passes in
-// turn; two workgroups share a CU: one round) was built against that and is SLOWER: OPT-1.3B 16 sequences 1.41-1.42 -> 1.45 ms per step,
-// Llama-2-7B 2.98 -> 3.07, 8 sequences equal (profiles/r06D_attn_forms.jsonl) -- what the second round cost, the serial passes and two workgroups
-// on one CU's memory path cost again.  Kept as a forced form (quipamd_decode_attention_config), off by default.
-int g_attn_u_one_group_from = 0;       // workgroups from which the 4-wave form is launched (0 = never)
+// TWO rounds (first -> last workgroup start 4.25 us, the launch 9.7 us).  Two forms were built against that:
+//   * four waves (one wave group runs the three operator passes in turn; two workgroups share a CU: one round): SLOWER -- OPT-1.3B 16 sequences
+//     1.41-1.42 -> 1.45 ms per step, Llama-2-7B 2.98 -> 3.07 (profiles/r06D_attn_forms.jsonl): what the second round cost, the serial passes and
+//     two workgroups on one CU's memory path cost again.  Forced only (one_group_from).
+//   * three heads per workgroup (MH above): a third of the workgroups and of the redundant operator passes; default from more than one
+//     (sequence, head) pair per CU on.
+int g_attn_u_one_group_from = 0;       // (sequence, head) pairs from which the 4-wave form is launched (0 = never)
+int g_attn_u_three_heads_from = 257;   // ... from which a workgroup serves three heads (0 = never)
 template <int HD, int P, int Q> int launch_attn_u(const AttnUArgs &A, int64_t bs, hipStream_t s)
 {
     if (g_attn_u_one_group_from > 0 && bs * A.heads >= g_attn_u_one_group_from) return launch_attn_u_n<HD, P, Q, 1>(A, bs, s);
+    if (g_attn_u_three_heads_from > 0 && bs * A.heads >= g_attn_u_three_heads_from) return launch_attn_u_n<HD, P, Q, 3, true>(A, bs, s);
     return launch_attn_u_n<HD, P, Q, 3>(A, bs, s);
 }
 
@@ -768,7 +786,11 @@ extern "C" int quipamd_argmax_rows(const void *x, int dtype, int64_t rows, int64
     return QUIPAMD_OK;
 }
 
-extern "C" void quipamd_decode_attention_config(int one_group_from) { g_attn_u_one_group_from = one_group_from < 0 ? 0 : one_group_from; }
+extern "C" void quipamd_decode_attention_config(int one_group_from, int three_heads_from)
+{
+    g_attn_u_one_group_from = one_group_from < 0 ? 0 : one_group_from;
+    g_attn_u_three_heads_from = three_heads_from < 0 ? 257 : three_heads_from;       // (negative: the default)
+}
 
 extern "C" int quipamd_decode_attention_fused(const quipamd_fop *U, const void *const *y, const void *const *bias, void *kcache, void *vcache,
                                               const int64_t *pos, void *out, const float *cos_table, const float *sin_table,

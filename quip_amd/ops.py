@@ -571,10 +571,10 @@ BLK_FUSED_N = 2048                 # csrc/ortho_blk.hip's default: one launch pe
 BLK_FUSED_ROWS = 4                 # ... and up to this many rows
 
 
-def decode_attention_config(one_group_from=0):
-    """csrc/decode_attn.hip: from this many (sequence, head) workgroups on the fused attention launch takes its 4-wave form (two workgroups per CU:
-    one round at 16 sequences -- measured slower, off by default); 0 = always the 12-wave form"""
-    _lib.load().quipamd_decode_attention_config(int(one_group_from))
+def decode_attention_config(one_group_from=0, three_heads_from=-1):
+    """csrc/decode_attn.hip, forms of the fused attention launch by the number of (sequence, head) pairs: `three_heads_from` (default 257, -1 = the
+    default, 0 = never): a workgroup serves three heads; `one_group_from` (default 0 = never): the 4-wave form (measured slower).  A/B runs, tests."""
+    _lib.load().quipamd_decode_attention_config(int(one_group_from), int(three_heads_from))
 
 
 def ortho_blocked_config(max_fused_n=BLK_FUSED_N, max_fused_rows=BLK_FUSED_ROWS):

@@ -22,12 +22,12 @@ def main():
     a = types.SimpleNamespace(arch=a0.arch, layers=0, bits=2, blocked=False, prompt=64, tokens=64, mode="auto", bs=1, blk_fused_n=-1)
     model = B.build(a)
     for rep in range(a0.reps):
-        for form in (0, 257):
-            ops.decode_attention_config(form)
+        for form in ((0, 0), (0, 257)):                                  # one head per workgroup | three from 257 pairs on
+            ops.decode_attention_config(*form)
             for bs in (8, 16):
                 a.bs = bs
                 r = B.measure(a, *model)
-                print(json.dumps({"arch": a0.arch, "attention_one_group_from": form, "bs": bs, "rep": rep, "tok_per_s": round(r["tok_per_s"], 1),
+                print(json.dumps({"arch": a0.arch, "attention_forms (one_group_from, three_heads_from)": list(form), "bs": bs, "rep": rep, "tok_per_s": round(r["tok_per_s"], 1),
                                   "ms_per_step": round(r["ms_per_step_median"], 4), "engine_mode": r["engine_mode"]}), flush=True)
     ops.decode_attention_config()
 

@@ -247,9 +247,10 @@ def test_attention_with_the_output_side_operators_in_its_prologue(n, heads, hd, 
 
 
 @pytest.mark.parametrize("n,heads,hd,rope,pos", [(2048, 32, 64, False, 37), (2048, 32, 64, False, 300), (4096, 32, 128, True, 21)])
-def test_attention_four_wave_form_equals_the_twelve_wave_form(n, heads, hd, rope, pos):
-    """round 6: quipamd_decode_attention_config forces the 4-wave form of the fused attention launch (one wave group runs U_q, U_k, U_v in turn;
-    built for grids of more workgroups than CUs, measured slower, off by default): same values in the same order -- output and cache rows bit
+def test_attention_forms_equal_the_twelve_wave_one_head_form(n, heads, hd, rope, pos):
+    """round 6: quipamd_decode_attention_config forces the other forms of the fused attention launch -- three heads per workgroup (the k and v
+    wave groups stay and run the attention of their own head; default from 257 (sequence, head) pairs on; 32 heads = ten full workgroups and
+    one with two heads) and the 4-wave form (measured slower, off by default): same values in the same order -- output and cache rows bit
     for bit."""
     from quip_amd import ops
     from quip_amd.quant import fused_attention
@@ -267,16 +268,17 @@ def test_attention_four_wave_form_equals_the_twelve_wave_form(n, heads, hd, rope
         cos, sin = emb.cos().to(DEV).contiguous(), emb.sin().to(DEV).contiguous()
     outs = []
     try:
-        for form in (0, 1):
-            ops.decode_attention_config(form)
+        for form in ((0, 0), (1, 0), (0, 1)):
+            ops.decode_attention_config(*form)
             kc, vc = kc0.clone(), vc0.clone()
             got = fused_attention(qkv, [l.to_zt(y) for l, y in zip(qkv, ys)], kc, vc, p_t, cos, sin)
             torch.cuda.synchronize()
             outs.append((got.clone(), kc, vc))
     finally:
         ops.decode_attention_config()
-    for a, b_ in zip(outs[0], outs[1]):
-        assert torch.equal(a, b_)
+    for other in outs[1:]:
+        for a, b_ in zip(outs[0], other):
+            assert torch.equal(a, b_)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.bfloat16])

@@ -23,8 +23,10 @@ ALLOWED = [
                                                        "96 before the operand-prefetch branch of round 6 entered the kernel"),
     (r"fused_gemm_kernelILi128ELi64ELb1ELb0ELi0ELi1ELi2ELi1E", 24, "the generic n = 8192 launch (bs 3-4; bs <= 2 runs fused_pair_kernel); 16 before round 6"),
     (r"fused_gemm_kernelILi128ELi64ELb1ELb0ELi0ELi1ELi4ELi1ELb0ELi4E", 64, "the same launch for the 4-bit container (round 4; bs 3-4 only, like the 2-bit one)"),
-    (r"decode_attn_u_kernelILi64ELi64ELi32ELi1E", 64, "the forced 4-wave form of the fused attention launch (round 6: one wave group holds the fragments of "
+    (r"decode_attn_u_kernelILi64ELi64ELi32ELi1ELb0E", 64, "the forced 4-wave form of the fused attention launch (round 6: one wave group holds the fragments of "
                                                        "all three operators; measured slower than the 12-wave form, off by default)"),
+    (r"decode_attn_u_kernelILi64ELi64ELi32ELi3ELb1E", 72, "the three-heads-per-workgroup form at head dim 64 (round 6; from 257 (sequence, head) pairs on): all "
+                                                          "three wave groups keep their prefetched K rows and stay to the end, at the 170 registers 768 threads allow"),
     (r"hsyrk_fast_kernel", 8, "opt-in Hessian mode"),
     (r"ortho_small_split_kernel", 340, "round-2 operator kernels with run-time (p, q); the decode path uses the compile-time fpass.h forms"),
 ]
