@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
     // under the operator passes).  The row of THIS token (t == pos) is not in the cache yet: the thread that owns it takes it from the LDS
     // slice instead -- its prefetched registers hold whatever the cache held before.  Head dim 64 only: 16 more 16-byte registers per lane do
     // not fit the 768-thread form at head dim 128.
-    constexpr bool KPF = HD <= 64 && QA_KPF;
+    constexpr bool KPF = HD <= 64 && QA_KPF;                          // (MH without it: no scratch, same speed -- profiles/r06F_mh_kpf.jsonl)
     uint4 kpre[KPF ? HD / 8 : 1];
     if constexpr (KPF) {
         const int64_t tpre = ta < G.maxlen ? ta : 0;
