@@ -96,6 +96,8 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
         if (p1 == 1 && p2 == 8) return launch_s<BITS, ACT, 1, 8, 1, 2>(A, s);
         if (p1 == 2 && p2 == 4) return launch_s<BITS, ACT, 2, 4, 1, 3>(A, s);
         if (p1 == 7 && p2 == 2) return launch_s<BITS, ACT, 7, 2, 1, 3>(A, s);
+        // (round 6, lab: ring depth 4 / 5 and two stages per k-half and ring step for the 7 x 2 form -- 15.2 / 16.0 / 15.6 us against 15.0 at
+        //  28672 x 7168 bs 16, profiles/r06G_k2_s_cfgs.jsonl: the per-step barrier is not what the compute waves wait for; not in the library)
         if (p1 == 4 && p2 == 2) return launch_s<BITS, ACT, 4, 2, 1, 4>(A, s);
         if (p1 == 8 && p2 == 1) return launch_s<BITS, ACT, 8, 1, 2, 3>(A, s);
         return qa_fail(QUIPAMD_ERR_UNSUPPORTED, "dequant_gemm: no s kernel for nw=%d ksp=%d", p1, p2);

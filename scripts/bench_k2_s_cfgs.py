@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quip_amd import ops  # noqa: E402
 
 FAM_S = 3
-CFGS = [None, (FAM_S, 7, 2), (FAM_S, 8, 1), (FAM_S, 4, 2), (FAM_S, 2, 4), (FAM_S, 1, 8)]     # (round 4 also timed 24 / 22: two row tiles per compute wave -- no gain, not in the library)
+CFGS = [None, (FAM_S, 7, 2), (FAM_S, 8, 1), (FAM_S, 4, 2), (FAM_S, 2, 4), (FAM_S, 1, 8)]     # (round 4 also timed 24 / 22; round 6 ring depth 4 / 5 and two stages per step: no gain, not in the library)     # (round 4 also timed 24 / 22: two row tiles per compute wave -- no gain, not in the library)
 
 
 def main():
