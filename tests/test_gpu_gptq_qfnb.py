@@ -153,3 +153,23 @@ def test_one_xcd_roll_call_failure_falls_back_without_touching_anything():
         assert torch.equal(qt.t().flip(1).contiguous(), want)
     finally:
         ops.gptq_qfnb_debug(0, 0, 0)
+
+
+def test_more_rows_than_one_xcd_holds_take_the_cross_xcd_forms():
+    """beyond 16384 rows (512 per workgroup x 32 CUs) the sweep leaves the one-XCD form: 20480 rows run the round-3 chain with 128 rows per
+    workgroup (the pipelined cross-XCD form needs <= 256 workgroups of 64 rows), forcing the one-XCD form is an error, and the result is the
+    forced 128-row run's bit for bit."""
+    from quip_amd import _lib, ops
+    m, d = 20480, 128
+    W, H = _fixture(m, d, 11)
+    FT = ops.gptq_feedback(H)
+    q0, c0 = ops.gptq_round_qfnb(W.clone(), FT, 2)
+    try:
+        ops.gptq_qfnb_debug(0, 0, 128)
+        q1, c1 = ops.gptq_round_qfnb(W.clone(), FT, 2)
+        ops.gptq_qfnb_debug(0, 0, 2)
+        with pytest.raises(_lib.QuipAmdError, match="do not fit one XCD"):
+            ops.gptq_round_qfnb(W.clone(), FT, 2)
+    finally:
+        ops.gptq_qfnb_debug(0, 0, 0)
+    assert torch.equal(q0, q1) and torch.equal(c0, c1)
