@@ -30,6 +30,18 @@ int run_family(const K2Call &c, const K2Args &A, hipStream_t s)
             if constexpr (BITS == 2) {
                 if (bs <= 8 && nkc > 16 && nkc <= 32 && ntile <= 512)
                     return nkc == 32 ? launch_h2<2, ACT, 1, 8, 4, true, true>(A, s) : launch_h2<2, ACT, 1, 8, 4, true, false>(A, s);
+                // 9..16 rows: the same kernel as a GROUPED launch of two problems that share the weights -- rows 0..7 and rows 8.. of x and y
+                // (blockIdx.y): every weight tile is streamed twice, but 2 x ntile workgroups fit one round up to 128 row tiles, where the
+                // weight-stream family (1 tile x 8 k-parts per workgroup) took 7.1 us for OPT's fc2 at 16 rows
+                if (bs > 8 && nkc > 16 && nkc <= 32 && ntile <= 128 && !c.accumulate) {
+                    K2GArgs G;
+                    G.g[0] = A; G.g[1] = A; G.g[2] = A;
+                    G.g[0].e.bs = 8;
+                    G.g[1].e.bs = bs - 8;
+                    G.g[1].x = A.x + 8 * d;
+                    G.g[1].e.y = (char *)A.e.y + (size_t)8 * m * (A.e.y_f32 ? 4 : 2);
+                    return nkc == 32 ? launch_h2g<2, ACT, 1, 8, 4, true, true>(G, 2, s) : launch_h2g<2, ACT, 1, 8, 4, true, false>(G, 2, s);
+                }
             }
             if (h_fits && ntile <= 768) fam = K2_FAM_H;
             else if (ntile >= 1024 && d % 256 == 0) fam = K2_FAM_S;

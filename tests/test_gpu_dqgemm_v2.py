@@ -91,11 +91,12 @@ def test_h_kernel(ops, O, dt, bits, qfn, m, d, bs):
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("qfn", ["a", "b"])
-@pytest.mark.parametrize("m,d,bs", [(2048, 8192, 1), (2048, 8192, 8), (96, 8192, 3), (512, 6144, 5), (64, 4352, 2), (8192, 8192, 4)])
+@pytest.mark.parametrize("m,d,bs", [(2048, 8192, 1), (2048, 8192, 8), (96, 8192, 3), (512, 6144, 5), (64, 4352, 2), (8192, 8192, 4),
+                                    (2048, 8192, 16), (2048, 8192, 9), (1024, 6144, 12)])      # 9..16 rows: two half-batch problems in one launch
 def test_half_slab_one_pass_kernel_up_to_d_8192(ops, O, dt, qfn, m, d, bs):
     """round 6: at bs <= 8 a slab of the one-pass kernel holds 8 rows (4 KiB per 256-column chunk), so 32 chunks -- d = 8192, OPT's fc2 in a
-    blocked-operator decode step -- fit one workgroup's LDS: the default heuristic takes 16 < chunks <= 32 there (exact fit and ragged K); the
-    same shapes at bs 9 keep their old kernels."""
+    blocked-operator decode step -- fit one workgroup's LDS: the default heuristic takes 16 < chunks <= 32 there (exact fit and ragged K); 9..16
+    rows of up to 128 row tiles run it as two half-batch problems sharing the weights in one grouped launch."""
     _run(ops, O, m, d, bs, 2, qfn, dt, None, seed=m + d + bs)
 
 
