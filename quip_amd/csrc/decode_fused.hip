@@ -474,6 +474,7 @@ __global__ __launch_bounds__(1024) void fused_gemm_kernel(FusedArgs G, float two
         uint16_t *dst = reinterpret_cast<uint16_t *>(Gg.y) + (int64_t)b_lo * N;
         for (int c = tid; c < N / 8; c += 1024) *reinterpret_cast<uint4 *>(dst + 8 * c) = *reinterpret_cast<const uint4 *>(XT + 8 * c);
         (void)w; (void)e_sc; (void)rt0; (void)rtmax; (void)qc; (void)park; (void)two_over_maxq; (void)c0; (void)slot; (void)r; (void)j; (void)g;
+        QA_LOG(1)
         return;
     }
     // ---- dequant + MFMA: this wave's CPW chunks of 256 columns x 16 rows -------------------------------------------------------------
