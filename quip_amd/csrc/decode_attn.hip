@@ -275,7 +275,9 @@ struct AttnUArgs {
 // MH (round 6, with NGRP = 3): a workgroup serves THREE heads of its sequence -- after the operator passes (which produce the whole q, k, v rows
 // anyway: every workgroup of the one-head form redoes them for its single head) the k and v wave groups do not leave: each of the three groups
 // gathers ITS head's slices, appends, scores, softmax, p V in its own LDS region.  A third of the workgroups and of the redundant passes: at 16
-// sequences x 32 heads 176 workgroups in one round instead of 512 in two.
+// sequences x 32 heads 176 workgroups in one round instead of 512 in two.  (The groups stay consecutive wave quadruples: with a group = the
+// waves of one residue mod 3 -- meant to put the three heads' busy first waves on different SIMDs -- the 16-sequence step took 2.03 ms
+// instead of 1.35, profiles/r06K_decode_bs.jsonl.)
 template <int HD, int P, int Q, int NGRP, bool MH = false>
 __global__ __launch_bounds__(256 * NGRP) void decode_attn_u_kernel(AttnUArgs G)
 {
